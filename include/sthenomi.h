@@ -1,0 +1,222 @@
+/*
+ * sthenomi.h -- C ABI of libsthenomi.so: MI355X (gfx950) dense Gaussian-process inference
+ * behind the Stheno.jl / AbstractGPs.jl operator surface.
+ *
+ * The reference (Stheno.jl v0.8.2, /root/reference) has no FFI seam: the seam is Julia
+ * multiple dispatch on FiniteGP{<:Union{GPPP,SthenoAbstractGP}}.  Each entry point below
+ * names the reference method(s) it replaces (file:line relative to /root/reference; [EXT]
+ * marks AbstractGPs.jl / KernelFunctions.jl arithmetic the reference delegates to, see
+ * SURVEY.md section 8a).  The Julia-side binding is shown in INTEGRATION.md and
+ * julia/SthenoMI355X.jl.
+ *
+ * Conventions
+ *   - all reals are IEEE fp64, all matrices column-major, all sizes int64_t;
+ *   - inputs are KernelFunctions.ColVecs layout: a D x n column-major matrix, each point D
+ *     contiguous doubles (docs/src/input_types.md:48-55); 1-D inputs are D = 1;
+ *   - the caller owns every host buffer; nothing host-side is retained after return;
+ *   - return value: 0 ok; >0 LAPACK potrf convention (order of the first non-positive
+ *     leading minor -> the shim throws PosDefException(info), as `cholesky` does in the
+ *     reference path); <0 bad argument / HIP failure, text via sgp_last_error();
+ *   - a ctx serialises its own calls (one in-flight operation per ctx).
+ *
+ * A covariance "spec" is the flattened form of a Stheno GP tree evaluated at BlockData
+ * inputs: for each (row block I, column block J) a list of terms
+ *     K[I,J] = sum_t coef_t * diag(rs_t) * k_{kind_t}(Xr_t, Xc_t) * diag(cs_t)
+ * which is what src/gp/derived_gp.jl:31-44 + src/affine_transformations/{cross,addition,
+ * product,compose}.jl evaluate recursively.  A block pair with zero terms is an exact-zero
+ * block (src/gp/atomic_gp.jl:36-38).
+ */
+#ifndef STHENOMI_H
+#define STHENOMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGP_ABI_VERSION 1
+
+/* kernel kinds: KernelFunctions.jl SimpleKernels [EXT] */
+enum {
+  SGP_SE = 0,       /* SEKernel / SqExponentialKernel: exp(-d^2/2)                       */
+  SGP_MATERN12 = 1, /* Matern12Kernel / ExponentialKernel: exp(-d)                       */
+  SGP_MATERN32 = 2, /* Matern32Kernel: (1+sqrt3 d) exp(-sqrt3 d)                         */
+  SGP_MATERN52 = 3, /* Matern52Kernel: (1+sqrt5 d+5d^2/3) exp(-sqrt5 d)                  */
+  SGP_WHITE = 4,    /* WhiteKernel: 1[x == y]                                            */
+  SGP_CONST = 5     /* ConstantKernel(c): param                                          */
+};
+
+/* noise kinds for FiniteGP(f, x, Sigma_y)  (AbstractGPs FiniteGP [EXT], App. A.2) */
+enum {
+  SGP_NOISE_SCALAR = 0, /* f(x, s2)  -> s2 * I   (noise[0] = s2; f(x) passes 1e-18)      */
+  SGP_NOISE_DIAG = 1,   /* f(x, v)   -> Diagonal(v), noise = v[N]                        */
+  SGP_NOISE_DENSE = 2   /* f(x, S)   -> dense N x N column-major, noise = S (ld = N)     */
+};
+
+/* one transformed input collection: a D x n ColVecs matrix (host pointer) */
+typedef struct {
+  int64_t dim;      /* D                                                                 */
+  int64_t n;        /* number of points                                                  */
+  int64_t ld;       /* leading dimension (>= D)                                          */
+  const double* x;  /* host, column-major D x n                                          */
+} sgp_input;
+
+/* one term of one block pair */
+typedef struct {
+  int32_t kind;       /* SGP_SE ...                                                      */
+  int32_t row_input;  /* index into sgp_cov_spec.inputs; must have n == row block length */
+  int32_t col_input;  /* index into sgp_cov_spec.inputs; must have n == col block length */
+  int32_t reserved;
+  double coef;        /* product of scalar scales (may be negative)                      */
+  double param;       /* SGP_CONST: c                                                    */
+  const double* row_scale; /* host, length = row block length, or NULL (== ones)         */
+  const double* col_scale; /* host, length = col block length, or NULL                   */
+} sgp_term;
+
+/* flattened covariance cov(f, x, x') over BlockData x (rows) and x' (cols).
+ * Replaces the recursion entered at src/gaussian_process_probabilistic_programme.jl:51-64
+ * (cov(f::GPPP, x[, x'])) -> src/affine_transformations/cross.jl:59-86. */
+typedef struct {
+  int32_t n_row_blocks, n_col_blocks;
+  const int64_t* row_len;   /* [n_row_blocks]                                            */
+  const int64_t* col_len;   /* [n_col_blocks]                                            */
+  int32_t n_inputs;
+  const sgp_input* inputs;
+  const int32_t* term_ptr;  /* CSR over block pairs, row-major (I * n_col_blocks + J)    */
+  const sgp_term* terms;
+  int32_t symmetric;        /* 1: x' === x (cov(f, x)); lets the library build one
+                               triangle and guarantees an exactly symmetric result       */
+  int32_t reserved;
+} sgp_cov_spec;
+
+typedef struct sgp_ctx sgp_ctx;
+typedef struct sgp_post sgp_post;
+typedef struct sgp_sparse_post sgp_sparse_post;
+
+/* ---- context ---------------------------------------------------------------------- */
+int sgp_abi_version(void);
+/* device: HIP ordinal.  Fails (<0) when no gfx950 device is present: there is no CPU path. */
+int sgp_ctx_create(int device, sgp_ctx** out);
+int sgp_ctx_destroy(sgp_ctx* ctx);
+const char* sgp_last_error(void); /* thread-local */
+
+/* ---- covariance assembly (K1-K3, S2-S7) --------------------------------------------
+ * sgp_kernelmatrix      : cov(f, x) / cov(f, x, x') -> dense N x M host matrix.
+ *                         [EXT kernelmatrix; src/gp/atomic_gp.jl:30-33, cross.jl:59-72]
+ * sgp_kernelmatrix_diag : var(f, x) / var(f, x, x') -> N-vector (blocks pairwise equal
+ *                         length). [EXT kernelmatrix_diag; src/gp/util.jl:5-7, cross.jl:64-77] */
+int sgp_kernelmatrix(sgp_ctx* ctx, const sgp_cov_spec* spec, double* K, int64_t ldk);
+int sgp_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, double* out);
+
+/* ---- logpdf(fx, y) / logpdf(fx, Y) (A2; AbstractGPs logpdf [EXT], App. A.3) ----------
+ * spec must be symmetric; mean = mean(fx) (N, host; NULL == zeros); Y is N x ncols.
+ * out[s] = -(N log 2pi + logdet C + |L^-1 (Y[:,s]-m)|^2)/2,  C = K + Sigma_y = L L'. */
+int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+               const double* noise, const double* Y, int64_t ldy, int64_t ncols, double* out);
+
+/* ---- rand(rng, fx, S) (A3; App. A.4): out = mean .+ L * Z, Z = randn(rng, N, S) drawn by
+ * the caller's RNG (column-major fill order), so the integer RNG stream stays the caller's. */
+int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+             const double* noise, const double* Z, int64_t ldz, int64_t S, double* out,
+             int64_t ldo);
+
+/* ---- posterior(fx, y) (A4; App. A.5) -------------------------------------------------
+ * Keeps L and L^-1 (y - m) in HBM.  alpha_out (N, may be NULL) receives C^-1 (y - m),
+ * the `α` field of AbstractGPs.PosteriorGP.data [EXT]. */
+int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
+                         int noise_kind, const double* noise, const double* y,
+                         double* alpha_out, sgp_post** out);
+/* cross : cov(f, x*, x) spec (rows = x* blocks, cols = training blocks)  [gppp.jl:60-64]
+ * prior_ss: symmetric spec at x* (used for var / cov of the prior)       [gppp.jl:51-58]
+ * mean_s : prior mean at x* (Ns; NULL == zeros)
+ * mean_out (Ns) / var_out (Ns) / cov_out (Ns x Ns, ld = ldcov): any may be NULL.
+ * mean* = m* + K*x alpha; var* = diag K** - colsumsq(L^-1 Kx*); cov* = K** - V'V. */
+int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross, const sgp_cov_spec* prior_ss,
+                          const double* mean_s, double* mean_out, double* var_out,
+                          double* cov_out, int64_t ldcov);
+int sgp_posterior_destroy(sgp_post* post);
+
+/* ---- elbo(VFE(fz), fx, y) (A5; App. A.6; src/gp/sparse_finite_gp.jl:52-58) -----------
+ * zz: symmetric spec at the inducing inputs z (M);  xz: cross spec rows = x (N), cols = z;
+ * var_x: prior var(f, x) (N) -- obtain with sgp_kernelmatrix_diag;  mean_x (N; NULL==0);
+ * noise_x: diagonal of Sigma_y (noise_kind SCALAR or DIAG only, as the reference requires);
+ * z_noise_kind/z_noise: Sigma_z of fz (jitter).  out[0] = elbo. */
+int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+             const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+             const double* z_noise, const double* y, double* out);
+
+/* posterior(VFE(fz), fx, y) (src/gp/sparse_finite_gp.jl:60-62) */
+int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
+                                const double* mean_x, int noise_kind, const double* noise_x,
+                                int z_noise_kind, const double* z_noise, const double* y,
+                                sgp_sparse_post** out);
+/* cross: rows = x*, cols = z.  mean* = m* + K*z alpha; var* = k** - |B|^2 + |Le^-1 B|^2 */
+int sgp_sparse_posterior_predict(sgp_sparse_post* post, const sgp_cov_spec* cross,
+                                 const sgp_cov_spec* prior_ss, const double* mean_s,
+                                 double* mean_out, double* var_out, double* cov_out,
+                                 int64_t ldcov);
+int sgp_sparse_posterior_destroy(sgp_sparse_post* post);
+
+/* =====================================================================================
+ * Device-resident variants (bench / multi-GPU host orchestration).  Pointers prefixed d_
+ * are HBM addresses valid on the ctx device; `stream` is a hipStream_t passed as void*
+ * (NULL == the ctx's own stream).  These never copy K to the host.
+ * ===================================================================================== */
+typedef struct sgp_dspec sgp_dspec; /* a cov spec whose inputs / scales live in HBM */
+int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* spec, sgp_dspec** out);
+int sgp_dspec_destroy(sgp_dspec* ds);
+
+/* Storage geometry of the bordered factor matrix for N points and S right-hand sides:
+ * n_pad = N rounded up to 128, m_tot = n_pad + (S rounded up to 128): the matrix is
+ * m_tot x n_pad column-major with ld = m_tot; rows n_pad.. hold (Y - m)' so that the
+ * forward substitution L^-1 (Y - m) falls out of the factorisation itself. */
+int sgp_geometry(int64_t N, int64_t S, int64_t* n_pad, int64_t* m_tot);
+
+/* whole logpdf with everything resident: d_A is caller-provided scratch of
+ * m_tot * n_pad doubles (left holding L and the solved rows); d_mean may be NULL;
+ * d_noise: SCALAR -> host value *noise_host is used, DIAG -> d_noise[N];
+ * d_Y: N x ncols (ld = ldy); out_host[ncols].  timings (may be NULL) receives
+ * {assemble_ms, cholesky_ms, finalize_ms, trailing_update_ms_sum, n_trailing_update_launches,
+ *  trailing_update_algorithmic_flops} (6 doubles). */
+int sgp_dev_logpdf(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, const double* d_mean,
+                   int noise_kind, const double* noise_host, const double* d_noise,
+                   const double* d_Y, int64_t ldy, int64_t ncols, double* out_host,
+                   double* timings);
+
+/* building blocks used by the multi-GPU host loop (one process per GPU; the host moves
+ * panels between ranks with torch.distributed / RCCL) */
+/* assemble columns [c0, c0+nc) (nc multiple of 128, c0 global) of K + Sigma_y, rows >= c0
+ * only, into d_dst (ld = ldd, column 0 of d_dst == global column c0, row index global);
+ * also writes the bordered rows from d_Y/d_mean when ncols > 0. */
+int sgp_dev_assemble_cols(sgp_ctx* ctx, const sgp_dspec* ds, int64_t N, int64_t c0, int64_t nc,
+                          double* d_dst, int64_t ldd, int64_t m_tot, const double* d_mean,
+                          int noise_kind, const double* noise_host, const double* d_noise,
+                          const double* d_Y, int64_t ldy, int64_t ncols, void* stream);
+/* factor a column panel in place: d_P is m x w (ld), its top w x w block is the diagonal
+ * block; on return it holds L11 and L21 = A21 L11^-T.  w multiple of 128.
+ * d_logdet[0] += 2 sum log diag;  d_info: device int, set to g0 + j + 1 on the first bad pivot. */
+int sgp_dev_panel_factor(sgp_ctx* ctx, double* d_P, int64_t ld, int64_t m, int64_t w,
+                         int64_t g0, double* d_logdet, int* d_info, void* stream);
+/* trailing update C -= P[r,:] P[c,:]' for the nc columns of d_C (ld = ldc) whose global
+ * column indices are c0..c0+nc and rows c0..m_tot: d_P (ld = ldp) is the factored panel
+ * with row index global offset p_row0 (d_P[0] is global row p_row0), width w. */
+int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp, int64_t p_row0, int64_t w,
+                         double* d_C, int64_t ldc, int64_t c0, int64_t nc, int64_t m_tot,
+                         void* stream);
+/* sum of squares of bordered row s over columns [0, nc) of a local panel set, accumulated
+ * into d_out[s] (atomic-free: one block per s). */
+int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nc, int64_t nrows,
+                     double* d_out, void* stream);
+
+/* micro-benchmarks used to pin the roofline peaks on the box */
+int sgp_bench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops_out, double* layout_maxerr_out);
+int sgp_bench_hbm(sgp_ctx* ctx, int64_t bytes, int iters, double* write_gbs_out, double* copy_gbs_out);
+/* raw GEMM-NT kernel timing: C(m x n) -= A(m x k) B(n x k)' on random data */
+int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only, int iters,
+                   double* tflops_out, double* maxerr_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STHENOMI_H */

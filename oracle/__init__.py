@@ -1,0 +1,23 @@
+"""CPU oracle for the Stheno.jl dense-GP hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package,
+and only as the checker / reported CPU baseline -- never as a product code path.  The product
+(stheno.jl_amd + libsthenomi.so) raises when the HIP library or a gfx950 device is missing.
+
+PARITY UNPINNED.  The reference cannot run in the build container (no Julia), its numerical
+arithmetic lives in un-vendored, un-pinned dependencies -- AbstractGPs.jl (compat "0.4, 0.5")
+and KernelFunctions.jl (compat "0.9.6, 0.10"), /root/reference/Project.toml:16,19 -- and its
+own test-suite holds no golden numbers for this path: only
+properties.  This oracle therefore
+
+  * follows the in-tree covariance algebra line by line (oracle/stheno.py cites
+    src/gp/derived_gp.jl, src/gp/atomic_gp.jl, src/affine_transformations/*.jl,
+    src/gaussian_process_probabilistic_programme.jl),
+  * restates the published formulas of the [EXT] packages (oracle/kernelfunctions.py,
+    oracle/abstractgps.py),
+  * is pinned by (a) every property the reference's tests assert for the path, ported to
+    tests/test_oracle_reference_properties.py, and (b) an independent third implementation
+    (scikit-learn GaussianProcessRegressor log-marginal-likelihood / predict) in
+    tests/test_oracle_vs_sklearn.py, whose golden vectors are committed under tests/golden/.
+"""
+from . import kernelfunctions, abstractgps, stheno  # noqa: F401

@@ -1,0 +1,1253 @@
+// libsthenomi.so host driver + C ABI (include/sthenomi.h).  gfx950 only; no CPU fallback:
+// every numerical result is produced by the HIP kernels in this directory.
+#include "common.h"
+#include "../../include/sthenomi.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace sgp {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+
+void set_gemm_tn_workspace(double* ws, size_t bytes);
+int run_mfma_bench(hipStream_t s, int iters, double* tflops_out, double* layout_maxerr_out);
+int run_hbm_bench(hipStream_t s, long bytes, int iters, double* write_gbs, double* copy_gbs);
+
+static inline long rup(long x, long m) { return (x + m - 1) / m * m; }
+constexpr long NOMASK = -(1L << 40);
+constexpr long WOUT = 512;  // outer panel width of the two-level blocked Cholesky
+
+}  // namespace sgp
+
+using namespace sgp;
+
+struct sgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
+  double* d_w = nullptr;       // 128 x 128 scratch inverse
+  double* d_slots = nullptr;   // per-128-block logdet contributions
+  long n_slots = 0;
+  double* d_scal = nullptr;    // [0] logdet, [1] misc, [16 ..] per-rhs sums
+  long n_scal = 0;
+  int* d_info = nullptr;
+  double* d_tn_ws = nullptr;
+  size_t tn_ws_bytes = 0;
+  std::mutex mu;
+  // optional per-launch timing of the trailing updates (roofline evidence for bench.py)
+  bool time_updates = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<double> ev_flops;
+};
+
+struct sgp_dspec {
+  sgp_ctx* ctx = nullptr;
+  int nrb = 0, ncb = 0, symmetric = 0;
+  std::vector<long> row_len, col_len, row_off, col_off;
+  long N = 0, M = 0;
+  std::vector<double*> d_bufs;          // everything to free
+  std::vector<int> term_ptr;            // CSR over pairs
+  std::vector<DevTerm> h_terms;         // host copy (device pointers inside)
+  DevTerm* d_terms = nullptr;
+  std::vector<int> pair_dmax;
+};
+
+#define CHECK_ARG(cond, msg)       \
+  do {                             \
+    if (!(cond)) {                 \
+      sgp::set_error(msg);         \
+      return -1;                   \
+    }                              \
+  } while (0)
+#define CHECK_RC(expr)        \
+  do {                        \
+    int _rc = (expr);         \
+    if (_rc != 0) return _rc; \
+  } while (0)
+
+extern "C" int sgp_abi_version(void) { return SGP_ABI_VERSION; }
+extern "C" const char* sgp_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sgp_geometry(int64_t N, int64_t S, int64_t* n_pad, int64_t* m_tot) {
+  long np = rup(N, TILE);
+  if (np == 0) np = TILE;
+  long mt = np + (S > 0 ? rup(S, TILE) : 0);
+  if (n_pad) *n_pad = np;
+  if (m_tot) *m_tot = mt;
+  return 0;
+}
+
+extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
+  CHECK_ARG(out != nullptr, "sgp_ctx_create: out is NULL");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    set_error("sgp_ctx_create: no HIP device visible (libsthenomi has no CPU path)");
+    return -3;
+  }
+  CHECK_ARG(device >= 0 && device < ndev, "sgp_ctx_create: bad device ordinal");
+  SGP_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  SGP_HIP(hipGetDeviceProperties(&prop, device));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos) {
+    set_error(std::string("sgp_ctx_create: device is ") + prop.gcnArchName +
+              ", libsthenomi is built for gfx950 only");
+    return -3;
+  }
+  sgp_ctx* c = new sgp_ctx();
+  c->device = device;
+  SGP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
+  SGP_HIP(hipMalloc(&c->d_w, sizeof(double) * TILE * TILE));
+  c->n_slots = 1 << 15;
+  SGP_HIP(hipMalloc(&c->d_slots, sizeof(double) * c->n_slots));
+  c->n_scal = 16 + (1 << 16);
+  SGP_HIP(hipMalloc(&c->d_scal, sizeof(double) * c->n_scal));
+  SGP_HIP(hipMalloc(&c->d_info, sizeof(int)));
+  *out = c;
+  return 0;
+}
+
+extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
+  if (!c) return 0;
+  hipSetDevice(c->device);
+  hipStreamSynchronize(c->stream);
+  for (auto e : c->ev) hipEventDestroy(e);
+  hipFree(c->d_invd);
+  hipFree(c->d_w);
+  hipFree(c->d_slots);
+  hipFree(c->d_scal);
+  hipFree(c->d_info);
+  if (c->d_tn_ws) hipFree(c->d_tn_ws);
+  hipStreamDestroy(c->stream);
+  delete c;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// device-resident specs
+// ---------------------------------------------------------------------------------------
+static int pow2ceil(int d) {
+  int p = 1;
+  while (p < d) p <<= 1;
+  return p;
+}
+
+extern "C" int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out) {
+  CHECK_ARG(ctx && sp && out, "sgp_dspec_create: NULL argument");
+  CHECK_ARG(sp->n_row_blocks >= 1 && sp->n_col_blocks >= 1, "spec: need >= 1 block");
+  SGP_HIP(hipSetDevice(ctx->device));
+  sgp_dspec* ds = new sgp_dspec();
+  ds->ctx = ctx;
+  ds->nrb = sp->n_row_blocks;
+  ds->ncb = sp->n_col_blocks;
+  ds->symmetric = sp->symmetric;
+  long off = 0;
+  for (int i = 0; i < ds->nrb; ++i) {
+    ds->row_len.push_back(sp->row_len[i]);
+    ds->row_off.push_back(off);
+    off += sp->row_len[i];
+  }
+  ds->N = off;
+  off = 0;
+  for (int j = 0; j < ds->ncb; ++j) {
+    ds->col_len.push_back(sp->col_len[j]);
+    ds->col_off.push_back(off);
+    off += sp->col_len[j];
+  }
+  ds->M = off;
+  auto fail = [&](const char* msg) {
+    set_error(msg);
+    sgp_dspec_destroy(ds);
+    return -1;
+  };
+  if (ds->symmetric && (ds->nrb != ds->ncb || ds->row_len != ds->col_len))
+    return fail("spec: symmetric spec needs identical row / col blocks");
+  // inputs -> HBM, packed with ld == dim
+  std::vector<double*> d_in(sp->n_inputs, nullptr);
+  for (int k = 0; k < sp->n_inputs; ++k) {
+    const sgp_input& in = sp->inputs[k];
+    if (in.dim < 1 || in.dim > 64) return fail("spec: input dimension must be in [1, 64]");
+    if (in.n < 0 || in.ld < in.dim) return fail("spec: bad input n / ld");
+    size_t bytes = sizeof(double) * (size_t)std::max<long>(1, in.dim * in.n);
+    double* d = nullptr;
+    if (hipMalloc(&d, bytes) != hipSuccess) return fail("spec: hipMalloc failed (input)");
+    ds->d_bufs.push_back(d);
+    if (in.n > 0) {
+      if (hipMemcpy2D(d, sizeof(double) * in.dim, in.x, sizeof(double) * in.ld,
+                      sizeof(double) * in.dim, (size_t)in.n, hipMemcpyHostToDevice) != hipSuccess)
+        return fail("spec: input upload failed");
+    }
+    d_in[k] = d;
+  }
+  int npairs = ds->nrb * ds->ncb;
+  ds->term_ptr.assign(sp->term_ptr, sp->term_ptr + npairs + 1);
+  ds->pair_dmax.assign(npairs, 1);
+  for (int I = 0; I < ds->nrb; ++I)
+    for (int J = 0; J < ds->ncb; ++J) {
+      int p = I * ds->ncb + J;
+      for (int t = sp->term_ptr[p]; t < sp->term_ptr[p + 1]; ++t) {
+        const sgp_term& T = sp->terms[t];
+        if (T.kind < 0 || T.kind > SGP_CONST) return fail("spec: unknown kernel kind");
+        if (T.row_input < 0 || T.row_input >= sp->n_inputs || T.col_input < 0 ||
+            T.col_input >= sp->n_inputs)
+          return fail("spec: term input index out of range");
+        const sgp_input& ri = sp->inputs[T.row_input];
+        const sgp_input& ci = sp->inputs[T.col_input];
+        if (ri.dim != ci.dim) return fail("spec: row / col input dimension mismatch");
+        if (ri.n != ds->row_len[I] || ci.n != ds->col_len[J])
+          return fail("spec: input length does not match block length");
+        DevTerm D;
+        D.kind = T.kind;
+        D.dim = (int)ri.dim;
+        D.coef = T.coef;
+        D.param = T.param;
+        D.xr = d_in[T.row_input];
+        D.ldr = ri.dim;
+        D.xc = d_in[T.col_input];
+        D.ldc = ci.dim;
+        D.rs = nullptr;
+        D.cs = nullptr;
+        auto up = [&](const double* h, long n, const double** dst) -> bool {
+          if (!h || n == 0) return true;
+          double* d = nullptr;
+          if (hipMalloc(&d, sizeof(double) * n) != hipSuccess) return false;
+          ds->d_bufs.push_back(d);
+          if (hipMemcpy(d, h, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return false;
+          *dst = d;
+          return true;
+        };
+        if (!up(T.row_scale, ds->row_len[I], &D.rs) || !up(T.col_scale, ds->col_len[J], &D.cs))
+          return fail("spec: scale upload failed");
+        ds->h_terms.push_back(D);
+        ds->pair_dmax[p] = std::max(ds->pair_dmax[p], pow2ceil(D.dim));
+      }
+    }
+  size_t tb = sizeof(DevTerm) * std::max<size_t>(1, ds->h_terms.size());
+  if (hipMalloc(&ds->d_terms, tb) != hipSuccess) return fail("spec: hipMalloc failed (terms)");
+  if (!ds->h_terms.empty() &&
+      hipMemcpy(ds->d_terms, ds->h_terms.data(), sizeof(DevTerm) * ds->h_terms.size(),
+                hipMemcpyHostToDevice) != hipSuccess)
+    return fail("spec: term upload failed");
+  *out = ds;
+  return 0;
+}
+
+extern "C" int sgp_dspec_destroy(sgp_dspec* ds) {
+  if (!ds) return 0;
+  for (double* p : ds->d_bufs) hipFree(p);
+  if (ds->d_terms) hipFree(ds->d_terms);
+  delete ds;
+  return 0;
+}
+
+// Assemble the block pairs of `ds` into the matrix whose element (r, c) (global indices,
+// optionally shifted by row_shift) lives at Kv[r + row_shift + c*ld], restricted to the
+// global tile window [tile_r_lo, tile_r_hi) x [tile_c_lo, tile_c_hi).
+static int assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long tile_r_hi,
+                    long tile_c_lo, long tile_c_hi, int lower_only, int noise_kind, double sigma2,
+                    const double* d_noise_diag, hipStream_t s) {
+  for (int I = 0; I < ds->nrb; ++I) {
+    if (ds->row_len[I] == 0) continue;
+    for (int J = 0; J < ds->ncb; ++J) {
+      if (ds->col_len[J] == 0) continue;
+      if (lower_only && I < J) continue;
+      long r0 = ds->row_off[I], nr = ds->row_len[I], c0 = ds->col_off[J], nc = ds->col_len[J];
+      long trf = std::max(r0 / TILE, tile_r_lo), trl = std::min((r0 + nr - 1) / TILE + 1, tile_r_hi);
+      long tcf = std::max(c0 / TILE, tile_c_lo), tcl = std::min((c0 + nc - 1) / TILE + 1, tile_c_hi);
+      if (trf >= trl || tcf >= tcl) continue;
+      int p = I * ds->ncb + J;
+      int t0 = ds->term_ptr[p], t1 = ds->term_ptr[p + 1];
+      int dmax = ds->pair_dmax[p];
+      int per = std::max(1, 64 / dmax);  // terms per launch: <= 64 KiB of LDS
+      int nk = (ds->symmetric && I == J) ? noise_kind : -1;
+      if (t0 == t1) {
+        CHECK_RC(launch_assemble_block(Kv, ld, r0, nr, c0, nc, ds->d_terms, 0, 1, lower_only, 0, nk,
+                                       sigma2, d_noise_diag, trf, tcf, trl - trf, tcl - tcf, s));
+        continue;
+      }
+      for (int t = t0; t < t1; t += per) {
+        int cnt = std::min(per, t1 - t);
+        CHECK_RC(launch_assemble_block(Kv, ld, r0, nr, c0, nc, ds->d_terms + t, cnt, dmax,
+                                       lower_only, t > t0 ? 1 : 0, t == t0 ? nk : -1, sigma2,
+                                       d_noise_diag, trf, tcf, trl - trf, tcl - tcf, s));
+      }
+    }
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// blocked Cholesky on the bordered matrix
+// ---------------------------------------------------------------------------------------
+// Factor one column panel in place (inner right-looking loop, nb = 128).
+// P: m x w, top w x w block is the diagonal block.  d_wstore: optional array of 128x128
+// inverse diagonal blocks to keep (indexed by block within the panel), else ctx scratch.
+static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_slots,
+                        int* d_info, double* d_wstore, hipStream_t s) {
+  for (long j = 0; j < w; j += TILE) {
+    double* D = P + j + j * ld;
+    double* W = d_wstore ? d_wstore + (j / TILE) * (TILE * TILE) : ctx->d_w;
+    CHECK_RC(launch_potrf_diag(D, ld, ctx->d_invd, d_slots + j / TILE, d_info, g0 + j, s));
+    long mrest = m - j - TILE;
+    if (mrest > 0 || d_wstore) CHECK_RC(launch_trtri(D, ld, ctx->d_invd, W, s));
+    if (mrest > 0) {
+      double* A21 = P + (j + TILE) + j * ld;
+      // L21 = A21 * inv(L11)^T  (in place: every workgroup owns full rows of the panel)
+      CHECK_RC(launch_gemm_nt(A21, ld, W, TILE, A21, ld, mrest, TILE, TILE, 1.0, 0.0, NOMASK, 0, 0, s));
+      long wrest = w - j - TILE;
+      if (wrest > 0)
+        CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest,
+                                TILE, -1.0, 1.0, 0, 0, 0, s));
+    }
+  }
+  return 0;
+}
+
+static double update_flops(long m, long nc, long k) {
+  // algorithmic flops of C[lower, m x nc] -= P P': triangle of the square part + rows below
+  double sq = (double)k * (double)nc * (double)(nc + 1);
+  double below = 2.0 * (double)k * (double)(m - nc) * (double)nc;
+  return sq + below;
+}
+
+static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
+                         hipStream_t s) {
+  CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
+  for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
+    long wj = std::min(WOUT, n_pad - J0);
+    CHECK_RC(panel_factor(ctx, A + J0 + J0 * ld, ld, m_tot - J0, wj, J0, ctx->d_slots + J0 / TILE,
+                          ctx->d_info, d_wall ? d_wall + (J0 / TILE) * (TILE * TILE) : nullptr, s));
+    long c0 = J0 + wj;
+    if (c0 < n_pad) {
+      const double* P = A + c0 + J0 * ld;
+      if (ctx->time_updates) {
+        hipEvent_t e0, e1;
+        SGP_HIP(hipEventCreate(&e0));
+        SGP_HIP(hipEventCreate(&e1));
+        SGP_HIP(hipEventRecord(e0, s));
+        CHECK_RC(launch_gemm_nt(P, ld, P, ld, A + c0 + c0 * ld, ld, m_tot - c0, n_pad - c0, wj, -1.0,
+                                1.0, 0, 0, 0, s));
+        SGP_HIP(hipEventRecord(e1, s));
+        ctx->ev.push_back(e0);
+        ctx->ev.push_back(e1);
+        ctx->ev_flops.push_back(update_flops(m_tot - c0, n_pad - c0, wj));
+      } else {
+        CHECK_RC(launch_gemm_nt(P, ld, P, ld, A + c0 + c0 * ld, ld, m_tot - c0, n_pad - c0, wj, -1.0,
+                                1.0, 0, 0, 0, s));
+      }
+    }
+  }
+  return 0;
+}
+
+// K + Sigma_y (lower tiles), identity padding, bordered rows
+static int build_bordered(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, long n_pad, long m_tot,
+                          const double* d_mean, int noise_kind, double sigma2,
+                          const double* d_noise, const double* d_dense, long ld_dense,
+                          const double* d_Y, long ldy, long ncols, hipStream_t s) {
+  long N = ds->N;
+  int nk = noise_kind == SGP_NOISE_DENSE ? -1 : noise_kind;
+  CHECK_RC(assemble(ds, dA, m_tot, 0, n_pad / TILE, 0, n_pad / TILE, 1, nk, sigma2, d_noise, s));
+  if (noise_kind == SGP_NOISE_DENSE) CHECK_RC(launch_add_dense(dA, m_tot, d_dense, ld_dense, N, 1, s));
+  CHECK_RC(launch_fill_pad(dA, m_tot, N, n_pad, 0, n_pad, m_tot, 0, s));
+  CHECK_RC(launch_border_rows(dA, m_tot, n_pad, N, 0, n_pad, d_Y, ldy, ncols, d_mean, s));
+  return 0;
+}
+
+static int fetch_info(sgp_ctx* ctx, hipStream_t s) {
+  int info = 0;
+  SGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  SGP_HIP(hipStreamSynchronize(s));
+  return info;
+}
+
+static int dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, const double* d_mean,
+                           int noise_kind, double sigma2, const double* d_noise,
+                           const double* d_dense, long ld_dense, const double* d_Y, long ldy,
+                           long ncols, double* out_host, double* timings) {
+  CHECK_ARG(ds->symmetric, "logpdf: spec must be symmetric");
+  CHECK_ARG(ncols >= 1 && ncols + 16 <= ctx->n_scal, "logpdf: bad number of columns");
+  hipStream_t s = ctx->stream;
+  long N = ds->N;
+  int64_t n_pad, m_tot;
+  sgp_geometry(N, ncols, &n_pad, &m_tot);
+  hipEvent_t ev[4];
+  if (timings)
+    for (auto& e : ev) SGP_HIP(hipEventCreate(&e));
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  if (timings) SGP_HIP(hipEventRecord(ev[0], s));
+  CHECK_RC(build_bordered(ctx, ds, dA, n_pad, m_tot, d_mean, noise_kind, sigma2, d_noise, d_dense,
+                          ld_dense, d_Y, ldy, ncols, s));
+  if (timings) SGP_HIP(hipEventRecord(ev[1], s));
+  ctx->time_updates = timings != nullptr;
+  for (auto e : ctx->ev) hipEventDestroy(e);
+  ctx->ev.clear();
+  ctx->ev_flops.clear();
+  int rc = chol_bordered(ctx, dA, m_tot, n_pad, m_tot, nullptr, s);
+  ctx->time_updates = false;
+  if (rc) return rc;
+  if (timings) SGP_HIP(hipEventRecord(ev[2], s));
+  double* d_logdet = ctx->d_scal;
+  double* d_sq = ctx->d_scal + 16;
+  double* d_out = ctx->d_scal + 16 + ncols;
+  CHECK_ARG(16 + 2 * ncols <= ctx->n_scal, "logpdf: too many columns");
+  CHECK_RC(launch_rowsumsq(dA + n_pad, m_tot, N, ncols, d_sq, 0, s));
+  CHECK_RC(launch_sum_array(ctx->d_slots, n_pad / TILE, d_logdet, s));
+  CHECK_RC(launch_logpdf_final(d_logdet, d_sq, N, ncols, d_out, s));
+  if (timings) SGP_HIP(hipEventRecord(ev[3], s));
+  SGP_HIP(hipMemcpyAsync(out_host, d_out, sizeof(double) * ncols, hipMemcpyDeviceToHost, s));
+  int info = fetch_info(ctx, s);
+  if (timings) {
+    float a = 0, b = 0, c = 0;
+    SGP_HIP(hipEventElapsedTime(&a, ev[0], ev[1]));
+    SGP_HIP(hipEventElapsedTime(&b, ev[1], ev[2]));
+    SGP_HIP(hipEventElapsedTime(&c, ev[2], ev[3]));
+    timings[0] = a;
+    timings[1] = b;
+    timings[2] = c;
+    double ms_sum = 0, fl = 0;
+    for (size_t i = 0; i + 1 < ctx->ev.size(); i += 2) {
+      float ms = 0;
+      SGP_HIP(hipEventElapsedTime(&ms, ctx->ev[i], ctx->ev[i + 1]));
+      ms_sum += ms;
+      fl += ctx->ev_flops[i / 2];
+    }
+    timings[3] = ms_sum;
+    timings[4] = (double)(ctx->ev.size() / 2);
+    timings[5] = fl;
+    for (auto& e : ev) hipEventDestroy(e);
+  }
+  if (info > 0) {
+    set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
+              std::to_string(info));
+    return info;
+  }
+  return 0;
+}
+
+extern "C" int sgp_dev_logpdf(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, const double* d_mean,
+                              int noise_kind, const double* noise_host, const double* d_noise,
+                              const double* d_Y, int64_t ldy, int64_t ncols, double* out_host,
+                              double* timings) {
+  CHECK_ARG(ctx && ds && d_A && d_Y && out_host, "sgp_dev_logpdf: NULL argument");
+  CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+            "sgp_dev_logpdf: noise kind must be SCALAR or DIAG");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  double s2 = noise_host ? noise_host[0] : 0.0;
+  return dev_logpdf_impl(ctx, ds, d_A, d_mean, noise_kind, s2, d_noise, nullptr, 0, d_Y, ldy, ncols,
+                         out_host, timings);
+}
+
+// ---------------------------------------------------------------------------------------
+// host-buffer helpers
+// ---------------------------------------------------------------------------------------
+struct DevBuf {
+  double* p = nullptr;
+  ~DevBuf() {
+    if (p) hipFree(p);
+  }
+  int alloc(size_t n) {
+    if (hipMalloc(&p, sizeof(double) * std::max<size_t>(1, n)) != hipSuccess) {
+      set_error("hipMalloc failed (" + std::to_string(n * 8) + " bytes)");
+      p = nullptr;
+      return -2;
+    }
+    return 0;
+  }
+  int upload(const double* h, size_t n) {
+    CHECK_RC(alloc(n));
+    if (n && hipMemcpy(p, h, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("hipMemcpy H2D failed");
+      return -2;
+    }
+    return 0;
+  }
+};
+struct SpecGuard {
+  sgp_dspec* ds = nullptr;
+  ~SpecGuard() { sgp_dspec_destroy(ds); }
+};
+
+static int upload_matrix(DevBuf& b, const double* h, long ldh, long nr, long nc) {
+  CHECK_RC(b.alloc((size_t)nr * nc));
+  if (nr && nc &&
+      hipMemcpy2D(b.p, sizeof(double) * nr, h, sizeof(double) * ldh, sizeof(double) * nr, (size_t)nc,
+                  hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("hipMemcpy2D H2D failed");
+    return -2;
+  }
+  return 0;
+}
+
+struct NoiseDev {
+  int kind = SGP_NOISE_SCALAR;
+  double sigma2 = 0.0;
+  DevBuf diag, dense;
+  long ld_dense = 0;
+};
+static int upload_noise(NoiseDev& nd, int kind, const double* noise, long N) {
+  CHECK_ARG(noise != nullptr, "noise is NULL");
+  CHECK_ARG(kind >= SGP_NOISE_SCALAR && kind <= SGP_NOISE_DENSE, "bad noise kind");
+  nd.kind = kind;
+  if (kind == SGP_NOISE_SCALAR) nd.sigma2 = noise[0];
+  if (kind == SGP_NOISE_DIAG) CHECK_RC(nd.diag.upload(noise, N));
+  if (kind == SGP_NOISE_DENSE) {
+    CHECK_RC(nd.dense.upload(noise, (size_t)N * N));
+    nd.ld_dense = N;
+  }
+  return 0;
+}
+
+extern "C" int sgp_kernelmatrix(sgp_ctx* ctx, const sgp_cov_spec* spec, double* K, int64_t ldk) {
+  CHECK_ARG(ctx && spec && K, "sgp_kernelmatrix: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard g;
+  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  long N = g.ds->N, M = g.ds->M;
+  CHECK_ARG(ldk >= N, "sgp_kernelmatrix: ldk < N");
+  if (N == 0 || M == 0) return 0;
+  DevBuf dK;
+  CHECK_RC(dK.alloc((size_t)N * M));
+  hipStream_t s = ctx->stream;
+  CHECK_RC(assemble(g.ds, dK.p, N, 0, rup(N, TILE) / TILE, 0, rup(M, TILE) / TILE, 0, -1, 0.0, nullptr, s));
+  SGP_HIP(hipStreamSynchronize(s));
+  SGP_HIP(hipMemcpy2D(K, sizeof(double) * ldk, dK.p, sizeof(double) * N, sizeof(double) * N, (size_t)M,
+                      hipMemcpyDeviceToHost));
+  return 0;
+}
+
+static int diag_of_spec(sgp_ctx* ctx, const sgp_dspec* ds, double* d_out, hipStream_t s) {
+  CHECK_ARG(ds->nrb == ds->ncb, "kernelmatrix_diag: row / col block counts differ");
+  for (int I = 0; I < ds->nrb; ++I) {
+    CHECK_ARG(ds->row_len[I] == ds->col_len[I], "kernelmatrix_diag: block lengths differ");
+    int p = I * ds->ncb + I;
+    int t0 = ds->term_ptr[p], t1 = ds->term_ptr[p + 1];
+    CHECK_RC(launch_diag_terms(d_out + ds->row_off[I], ds->row_len[I], ds->d_terms + t0, t1 - t0, s));
+  }
+  return 0;
+}
+
+extern "C" int sgp_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, double* out) {
+  CHECK_ARG(ctx && spec && out, "sgp_kernelmatrix_diag: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard g;
+  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  long N = g.ds->N;
+  if (N == 0) return 0;
+  DevBuf d;
+  CHECK_RC(d.alloc(N));
+  CHECK_RC(diag_of_spec(ctx, g.ds, d.p, ctx->stream));
+  SGP_HIP(hipStreamSynchronize(ctx->stream));
+  SGP_HIP(hipMemcpy(out, d.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                          const double* noise, const double* Y, int64_t ldy, int64_t ncols,
+                          double* out) {
+  CHECK_ARG(ctx && spec && Y && out, "sgp_logpdf: NULL argument");
+  CHECK_ARG(spec->symmetric, "sgp_logpdf: spec must be symmetric");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard g;
+  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  long N = g.ds->N;
+  CHECK_ARG(N >= 1 && ncols >= 1 && ldy >= N, "sgp_logpdf: bad sizes");
+  int64_t n_pad, m_tot;
+  sgp_geometry(N, ncols, &n_pad, &m_tot);
+  DevBuf dA, dmean, dY;
+  NoiseDev nd;
+  CHECK_RC(dA.alloc((size_t)m_tot * n_pad));
+  if (mean) CHECK_RC(dmean.upload(mean, N));
+  CHECK_RC(upload_noise(nd, noise_kind, noise, N));
+  CHECK_RC(upload_matrix(dY, Y, ldy, N, ncols));
+  return dev_logpdf_impl(ctx, g.ds, dA.p, mean ? dmean.p : nullptr, nd.kind, nd.sigma2, nd.diag.p,
+                         nd.dense.p, nd.ld_dense, dY.p, N, ncols, out, nullptr);
+}
+
+extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                        const double* noise, const double* Z, int64_t ldz, int64_t S, double* out,
+                        int64_t ldo) {
+  CHECK_ARG(ctx && spec && Z && out, "sgp_rand: NULL argument");
+  CHECK_ARG(spec->symmetric, "sgp_rand: spec must be symmetric");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard g;
+  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  long N = g.ds->N;
+  CHECK_ARG(N >= 1 && S >= 1 && ldz >= N && ldo >= N, "sgp_rand: bad sizes");
+  int64_t n_pad, m_tot;
+  sgp_geometry(N, 0, &n_pad, &m_tot);
+  long s_pad = rup(S, TILE);
+  hipStream_t s = ctx->stream;
+  DevBuf dA, dmean, dZ, dZt, dOt, dOut;
+  NoiseDev nd;
+  CHECK_RC(dA.alloc((size_t)m_tot * n_pad));
+  if (mean) CHECK_RC(dmean.upload(mean, N));
+  CHECK_RC(upload_noise(nd, noise_kind, noise, N));
+  CHECK_RC(upload_matrix(dZ, Z, ldz, N, S));
+  CHECK_RC(dZt.alloc((size_t)s_pad * n_pad));
+  CHECK_RC(dOt.alloc((size_t)s_pad * n_pad));
+  CHECK_RC(dOut.alloc((size_t)N * S));
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  CHECK_RC(build_bordered(ctx, g.ds, dA.p, n_pad, m_tot, nullptr, nd.kind, nd.sigma2, nd.diag.p,
+                          nd.dense.p, nd.ld_dense, nullptr, 0, 0, s));
+  CHECK_RC(chol_bordered(ctx, dA.p, m_tot, n_pad, m_tot, nullptr, s));
+  SGP_HIP(hipMemsetAsync(dZt.p, 0, sizeof(double) * s_pad * n_pad, s));
+  // Zt[s, k] = Z[k, s]
+  CHECK_RC(launch_transpose_add(dZ.p, N, N, S, dZt.p, s_pad, nullptr, s));
+  // Ot[s, i] = sum_{k <= i} Zt[s, k] L[i, k]
+  CHECK_RC(launch_gemm_nt(dZt.p, s_pad, dA.p, m_tot, dOt.p, s_pad, s_pad, n_pad, n_pad, 1.0, 0.0,
+                          NOMASK, 1, 0, s));
+  // out[i, s] = Ot[s, i] + mean[i]
+  CHECK_RC(launch_transpose_add(dOt.p, s_pad, S, N, dOut.p, N, mean ? dmean.p : nullptr, s));
+  int info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
+              std::to_string(info));
+    return info;
+  }
+  SGP_HIP(hipMemcpy2D(out, sizeof(double) * ldo, dOut.p, sizeof(double) * N, sizeof(double) * N,
+                      (size_t)S, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// posterior
+// ---------------------------------------------------------------------------------------
+struct sgp_post {
+  sgp_ctx* ctx = nullptr;
+  long N = 0, n_pad = 0, m_tot = 0;
+  double* dA = nullptr;     // L (lower tiles) + row n_pad = (L^-1 (y - m))'
+  double* d_wall = nullptr; // inverse diagonal blocks
+};
+
+// rows <- rows * L^-T for `nrows` (multiple of 128) bordered rows stored at R (ld = ldr),
+// against the factor L (ld = ldl) with stored inverse diagonal blocks.  Right-looking.
+static int row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl,
+                    const double* d_wall, long n_pad, hipStream_t s) {
+  for (long k = 0; k < n_pad; k += TILE) {
+    double* Rk = R + k * ldr;
+    CHECK_RC(launch_gemm_nt(Rk, ldr, d_wall + (k / TILE) * (TILE * TILE), TILE, Rk, ldr, nrows, TILE,
+                            TILE, 1.0, 0.0, NOMASK, 0, 0, s));
+    long rest = n_pad - k - TILE;
+    if (rest > 0)
+      CHECK_RC(launch_gemm_nt(Rk, ldr, L + (k + TILE) + k * ldl, ldl, R + (k + TILE) * ldr, ldr, nrows,
+                              rest, TILE, -1.0, 1.0, NOMASK, 0, 0, s));
+  }
+  return 0;
+}
+
+// back substitution kernels for alpha = L^-T z (reduce.hip would do; kept here: tiny)
+__global__ void backsolve_gemvt_kernel(const double* L, long ld, long k0, long n_pad,
+                                       const double* alpha, double* z) {
+  // z[k0 + j] -= sum_{r >= k0+128} L[r, k0+j] * alpha[r], one workgroup per j
+  __shared__ double sh[4];
+  const int j = blockIdx.x;
+  const double* col = L + (long)(k0 + j) * ld;
+  double acc = 0.0;
+  for (long r = k0 + TILE + threadIdx.x; r < n_pad; r += blockDim.x) acc = fma(col[r], alpha[r], acc);
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) z[k0 + j] -= (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ void backsolve_diag_kernel(const double* W, const double* z, double* alpha, long k0) {
+  // alpha[k0 + j] = sum_i W[i][j] z[k0 + i]   (W = inv(L_kk), so this is L_kk^-T z_k)
+  __shared__ double zs[TILE];
+  int j = threadIdx.x;
+  zs[j] = z[k0 + j];
+  __syncthreads();
+  double acc = 0.0;
+  for (int i = j; i < TILE; ++i) acc = fma(W[i + j * TILE], zs[i], acc);
+  alpha[k0 + j] = acc;
+}
+
+static int back_substitute(const sgp_post* post, double* d_z /*n_pad, overwritten*/,
+                           double* d_alpha, hipStream_t s) {
+  for (long k0 = post->n_pad - TILE; k0 >= 0; k0 -= TILE) {
+    if (k0 + TILE < post->n_pad) {
+      hipLaunchKernelGGL(backsolve_gemvt_kernel, dim3(TILE), dim3(256), 0, s, post->dA, post->m_tot,
+                         k0, post->n_pad, d_alpha, d_z);
+      SGP_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(backsolve_diag_kernel, dim3(1), dim3(TILE), 0, s,
+                       post->d_wall + (k0 / TILE) * (TILE * TILE), d_z, d_alpha, k0);
+    SGP_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+__global__ void copy_strided_kernel(const double* src, long lds, long n, double* dst) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i * lds];
+}
+
+extern "C" int sgp_posterior_destroy(sgp_post* p) {
+  if (!p) return 0;
+  if (p->dA) hipFree(p->dA);
+  if (p->d_wall) hipFree(p->d_wall);
+  delete p;
+  return 0;
+}
+
+extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
+                                    int noise_kind, const double* noise, const double* y,
+                                    double* alpha_out, sgp_post** out) {
+  CHECK_ARG(ctx && spec && y && out, "sgp_posterior_create: NULL argument");
+  CHECK_ARG(spec->symmetric, "sgp_posterior_create: spec must be symmetric");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard g;
+  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  long N = g.ds->N;
+  CHECK_ARG(N >= 1, "sgp_posterior_create: empty data");
+  int64_t n_pad, m_tot;
+  sgp_geometry(N, 1, &n_pad, &m_tot);
+  hipStream_t s = ctx->stream;
+  DevBuf dmean, dY;
+  NoiseDev nd;
+  if (mean) CHECK_RC(dmean.upload(mean, N));
+  CHECK_RC(upload_noise(nd, noise_kind, noise, N));
+  CHECK_RC(dY.upload(y, N));
+  sgp_post* post = new sgp_post();
+  post->ctx = ctx;
+  post->N = N;
+  post->n_pad = n_pad;
+  post->m_tot = m_tot;
+  auto fail = [&](int rc) {
+    sgp_posterior_destroy(post);
+    return rc;
+  };
+  if (hipMalloc(&post->dA, sizeof(double) * m_tot * n_pad) != hipSuccess ||
+      hipMalloc(&post->d_wall, sizeof(double) * (n_pad / TILE) * TILE * TILE) != hipSuccess) {
+    set_error("sgp_posterior_create: hipMalloc failed");
+    return fail(-2);
+  }
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  int rc = build_bordered(ctx, g.ds, post->dA, n_pad, m_tot, mean ? dmean.p : nullptr, nd.kind,
+                          nd.sigma2, nd.diag.p, nd.dense.p, nd.ld_dense, dY.p, N, 1, s);
+  if (rc) return fail(rc);
+  rc = chol_bordered(ctx, post->dA, m_tot, n_pad, m_tot, post->d_wall, s);
+  if (rc) return fail(rc);
+  if (alpha_out) {
+    DevBuf dz, dal;
+    if (dz.alloc(n_pad) || dal.alloc(n_pad)) return fail(-2);
+    hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, s,
+                       post->dA + n_pad, m_tot, n_pad, dz.p);
+    rc = back_substitute(post, dz.p, dal.p, s);
+    if (rc) return fail(rc);
+    SGP_HIP(hipStreamSynchronize(s));
+    SGP_HIP(hipMemcpy(alpha_out, dal.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  }
+  int info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
+              std::to_string(info));
+    return fail(info);
+  }
+  *out = post;
+  return 0;
+}
+
+// shared by dense and sparse prediction: V rows (x* bordered rows, ns_pad x n_pad)
+static int predict_common(sgp_ctx* ctx, const sgp_dspec* cross, const sgp_dspec* prior,
+                          const double* d_means, long Ns, long ns_pad, double* dV, long n_pad,
+                          const double* d_z, long ldz, long N_cols, double* mean_out,
+                          double* var_out, double* cov_out, int64_t ldcov, double var_sign_second,
+                          const double* dV2, hipStream_t s) {
+  DevBuf dmu, dprior, dvar, dcov;
+  if (mean_out) {
+    CHECK_RC(dmu.alloc(Ns));
+    CHECK_RC(launch_gemv_rows(dV, ns_pad, Ns, N_cols, d_z, ldz, d_means, dmu.p, s));
+  }
+  if (var_out) {
+    CHECK_ARG(prior != nullptr, "predict: prior_ss spec required for var");
+    CHECK_RC(dprior.alloc(Ns));
+    CHECK_RC(dvar.alloc(Ns));
+    CHECK_RC(diag_of_spec(ctx, prior, dprior.p, s));
+    CHECK_RC(launch_colsumsq_sub(dV, ns_pad, Ns, N_cols, dprior.p, dvar.p, -1.0, s));
+    if (dV2) CHECK_RC(launch_colsumsq_sub(dV2, ns_pad, Ns, N_cols, dvar.p, dvar.p, var_sign_second, s));
+  }
+  if (cov_out) {
+    CHECK_ARG(prior != nullptr, "predict: prior_ss spec required for cov");
+    CHECK_RC(dcov.alloc((size_t)ns_pad * ns_pad));
+    SGP_HIP(hipMemsetAsync(dcov.p, 0, sizeof(double) * ns_pad * ns_pad, s));
+    CHECK_RC(assemble(prior, dcov.p, ns_pad, 0, ns_pad / TILE, 0, ns_pad / TILE, 0, -1, 0.0, nullptr, s));
+    CHECK_RC(launch_gemm_nt(dV, ns_pad, dV, ns_pad, dcov.p, ns_pad, ns_pad, ns_pad, n_pad, -1.0, 1.0,
+                            NOMASK, 0, 0, s));
+    if (dV2)
+      CHECK_RC(launch_gemm_nt(dV2, ns_pad, dV2, ns_pad, dcov.p, ns_pad, ns_pad, ns_pad, n_pad,
+                              var_sign_second, 1.0, NOMASK, 0, 0, s));
+  }
+  SGP_HIP(hipStreamSynchronize(s));
+  if (mean_out) SGP_HIP(hipMemcpy(mean_out, dmu.p, sizeof(double) * Ns, hipMemcpyDeviceToHost));
+  if (var_out) SGP_HIP(hipMemcpy(var_out, dvar.p, sizeof(double) * Ns, hipMemcpyDeviceToHost));
+  if (cov_out)
+    SGP_HIP(hipMemcpy2D(cov_out, sizeof(double) * ldcov, dcov.p, sizeof(double) * ns_pad,
+                        sizeof(double) * Ns, (size_t)Ns, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+extern "C" int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross,
+                                     const sgp_cov_spec* prior_ss, const double* mean_s,
+                                     double* mean_out, double* var_out, double* cov_out,
+                                     int64_t ldcov) {
+  CHECK_ARG(post && cross, "sgp_posterior_predict: NULL argument");
+  sgp_ctx* ctx = post->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard gc, gp;
+  CHECK_RC(sgp_dspec_create(ctx, cross, &gc.ds));
+  if (prior_ss) CHECK_RC(sgp_dspec_create(ctx, prior_ss, &gp.ds));
+  long Ns = gc.ds->N;
+  CHECK_ARG(gc.ds->M == post->N, "sgp_posterior_predict: cross spec columns != training size");
+  CHECK_ARG(!gp.ds || gp.ds->N == Ns, "sgp_posterior_predict: prior_ss size != number of x*");
+  CHECK_ARG(!cov_out || ldcov >= Ns, "sgp_posterior_predict: ldcov < Ns");
+  if (Ns == 0) return 0;
+  long ns_pad = rup(Ns, TILE), n_pad = post->n_pad;
+  hipStream_t s = ctx->stream;
+  DevBuf dV, dms;
+  CHECK_RC(dV.alloc((size_t)ns_pad * n_pad));
+  if (mean_s) CHECK_RC(dms.upload(mean_s, Ns));
+  SGP_HIP(hipMemsetAsync(dV.p, 0, sizeof(double) * ns_pad * n_pad, s));
+  CHECK_RC(assemble(gc.ds, dV.p, ns_pad, 0, ns_pad / TILE, 0, n_pad / TILE, 0, -1, 0.0, nullptr, s));
+  CHECK_RC(row_trsm(ctx, dV.p, ns_pad, ns_pad, post->dA, post->m_tot, post->d_wall, n_pad, s));
+  return predict_common(ctx, gc.ds, gp.ds, mean_s ? dms.p : nullptr, Ns, ns_pad, dV.p, n_pad,
+                        post->dA + n_pad, post->m_tot, post->N, mean_out, var_out, cov_out, ldcov,
+                        0.0, nullptr, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// VFE: elbo and sparse posterior (App. A.6)
+// ---------------------------------------------------------------------------------------
+// o[0] = sum log s2_n, o[1] = sum delta_n^2, o[2] = sum var_n / s2_n, delta_n = (y_n - m_n)/sqrt(s2_n)
+__global__ void elbo_scalars_kernel(const double* y, const double* mean, const double* var_x,
+                                    int noise_kind, double sigma2, const double* noise, long N,
+                                    double* delta, double* rsig, double* o) {
+  __shared__ double sh[3][4];
+  double a0 = 0, a1 = 0, a2 = 0;
+  for (long i = threadIdx.x; i < N; i += blockDim.x) {
+    double s2 = noise_kind == 0 ? sigma2 : noise[i];
+    double rs = 1.0 / sqrt(s2);
+    double d = (y[i] - (mean ? mean[i] : 0.0)) * rs;
+    delta[i] = d;
+    rsig[i] = rs;
+    a0 += log(s2);
+    a1 = fma(d, d, a1);
+    if (var_x) a2 += var_x[i] / s2;
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    a0 += __shfl_xor(a0, off, 64);
+    a1 += __shfl_xor(a1, off, 64);
+    a2 += __shfl_xor(a2, off, 64);
+  }
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][w] = a0;
+    sh[1][w] = a1;
+    sh[2][w] = a2;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int q = 0; q < 3; ++q) o[q] = (sh[q][0] + sh[q][1]) + (sh[q][2] + sh[q][3]);
+  }
+}
+// per column j of the bordered rows R (nrows x ncols): dots[j] = sum_n R[n, j] delta[n],
+// sq[j] = sum_n R[n, j]^2
+__global__ void coldot_kernel(const double* R, long ld, long nrows, const double* delta,
+                              double* dots, double* sq) {
+  __shared__ double sh[2][4];
+  const long j = blockIdx.x;
+  const double* col = R + j * ld;
+  double a = 0, b = 0;
+  for (long n = threadIdx.x; n < nrows; n += blockDim.x) {
+    double v = col[n];
+    a = fma(v, delta[n], a);
+    b = fma(v, v, b);
+  }
+  for (int off = 32; off >= 1; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][w] = a;
+    sh[1][w] = b;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    dots[j] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    sq[j] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+  }
+}
+__global__ void add_identity_kernel(double* G, long ld, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) G[i + i * ld] += 1.0;
+}
+__global__ void accum_kernel(double* dst, const double* src) { dst[0] += src[0]; }
+__global__ void set_row_kernel(double* G, long ld, long row, const double* v, long n) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) G[row + i * ld] = v[i];
+}
+
+struct sgp_sparse_post {
+  sgp_ctx* ctx = nullptr;
+  long M = 0, m_pad = 0;
+  double* dLz = nullptr;   // m_pad x m_pad factor of Kzz + Sigma_z (ld = m_pad)
+  double* d_wz = nullptr;  // inverse diagonal blocks of Lz
+  double* dG = nullptr;    // (m_pad + 128) x m_pad: factor of A A' + I, row m_pad = (Le^-1 A delta)'
+  double* d_wg = nullptr;
+  long ldg = 0;
+};
+
+extern "C" int sgp_sparse_posterior_destroy(sgp_sparse_post* p) {
+  if (!p) return 0;
+  if (p->dLz) hipFree(p->dLz);
+  if (p->d_wz) hipFree(p->d_wz);
+  if (p->dG) hipFree(p->dG);
+  if (p->d_wg) hipFree(p->d_wg);
+  delete p;
+  return 0;
+}
+
+// shared VFE pipeline.  Returns elbo terms in h[0..5]:
+//  h[0]=sum log s2, h[1]=delta'delta, h[2]=sum var/s2, h[3]=|A|_F^2, h[4]=logdet Le, h[5]=|Le^-1 A delta|^2
+static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
+                        const double* var_x, const double* mean_x, int noise_kind,
+                        const double* noise_x, int z_noise_kind, const double* z_noise,
+                        const double* y, double* h, sgp_sparse_post* keep) {
+  CHECK_ARG(zz->symmetric, "vfe: zz spec must be symmetric");
+  CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+            "vfe: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
+  SpecGuard gz, gx;
+  CHECK_RC(sgp_dspec_create(ctx, zz, &gz.ds));
+  CHECK_RC(sgp_dspec_create(ctx, xz, &gx.ds));
+  long M = gz.ds->N, N = gx.ds->N;
+  CHECK_ARG(gx.ds->M == M, "vfe: xz spec columns != number of inducing points");
+  CHECK_ARG(M >= 1 && N >= 1, "vfe: empty inputs");
+  long m_pad = rup(M, TILE), n_rows = rup(N, TILE);
+  long ld = m_pad + n_rows;
+  hipStream_t s = ctx->stream;
+  DevBuf dA, dy, dmean, dvar, ddelta, drsig, dots, sq, dG_local;
+  NoiseDev ndx, ndz;
+  CHECK_RC(dA.alloc((size_t)ld * m_pad));
+  CHECK_RC(dy.upload(y, N));
+  if (mean_x) CHECK_RC(dmean.upload(mean_x, N));
+  if (var_x) CHECK_RC(dvar.upload(var_x, N));
+  CHECK_RC(upload_noise(ndx, noise_kind, noise_x, N));
+  CHECK_RC(upload_noise(ndz, z_noise_kind, z_noise, M));
+  CHECK_RC(ddelta.alloc(n_rows));
+  CHECK_RC(drsig.alloc(n_rows));
+  CHECK_RC(dots.alloc(m_pad));
+  CHECK_RC(sq.alloc(m_pad));
+  double* d_o = ctx->d_scal + 1;  // 3 scalars
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  SGP_HIP(hipMemsetAsync(ddelta.p, 0, sizeof(double) * n_rows, s));
+  SGP_HIP(hipMemsetAsync(drsig.p, 0, sizeof(double) * n_rows, s));
+  hipLaunchKernelGGL(elbo_scalars_kernel, dim3(1), dim3(256), 0, s, dy.p, mean_x ? dmean.p : nullptr,
+                     var_x ? dvar.p : nullptr, ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p,
+                     d_o);
+  SGP_HIP(hipGetLastError());
+  // top: Kzz + Sigma_z (lower), identity padding; bottom rows: K(x, z) Lambda_y^-1
+  int nkz = ndz.kind == SGP_NOISE_DENSE ? -1 : ndz.kind;
+  CHECK_RC(assemble(gz.ds, dA.p, ld, 0, m_pad / TILE, 0, m_pad / TILE, 1, nkz, ndz.sigma2, ndz.diag.p, s));
+  if (ndz.kind == SGP_NOISE_DENSE) CHECK_RC(launch_add_dense(dA.p, ld, ndz.dense.p, M, M, 1, s));
+  CHECK_RC(launch_fill_pad(dA.p, ld, M, m_pad, 0, m_pad, ld, 0, s));
+  // zero the row padding of the bordered block, then assemble the cross block into it
+  if (n_rows > N) {
+    // rows [m_pad + N, ld) of every column
+    SGP_HIP(hipMemset2DAsync(dA.p + m_pad + N, sizeof(double) * ld, 0, sizeof(double) * (n_rows - N),
+                             (size_t)m_pad, s));
+  }
+  CHECK_RC(assemble(gx.ds, dA.p + m_pad, ld, 0, n_rows / TILE, 0, m_pad / TILE, 0, -1, 0.0, nullptr, s));
+  CHECK_RC(launch_scale_rows(dA.p + m_pad, ld, N, m_pad, drsig.p, s));
+  double* d_wz = nullptr;
+  if (keep) {
+    SGP_HIP(hipMalloc(&keep->d_wz, sizeof(double) * (m_pad / TILE) * TILE * TILE));
+    d_wz = keep->d_wz;
+  }
+  CHECK_RC(chol_bordered(ctx, dA.p, ld, m_pad, ld, d_wz, s));
+  int info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("vfe: Kzz + Sigma_z is not positive definite (leading minor " + std::to_string(info) + ")");
+    return info;
+  }
+  // rows now hold A' (N x M).  A delta, |A|_F^2
+  const double* R = dA.p + m_pad;
+  hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, R, ld, n_rows, ddelta.p,
+                     dots.p, sq.p);
+  SGP_HIP(hipGetLastError());
+  CHECK_RC(launch_sum_array(sq.p, m_pad, ctx->d_scal + 4, s));
+  // G = A A' + I, bordered with (A delta)'
+  long ldg = m_pad + TILE;
+  double* dG = nullptr;
+  if (keep) {
+    SGP_HIP(hipMalloc(&keep->dG, sizeof(double) * ldg * m_pad));
+    SGP_HIP(hipMalloc(&keep->d_wg, sizeof(double) * (m_pad / TILE) * TILE * TILE));
+    dG = keep->dG;
+  } else {
+    CHECK_RC(dG_local.alloc((size_t)ldg * m_pad));
+    dG = dG_local.p;
+  }
+  SGP_HIP(hipMemsetAsync(dG, 0, sizeof(double) * ldg * m_pad, s));
+  // split-K workspace
+  {
+    size_t need = (size_t)64 * ldg * m_pad * sizeof(double);
+    size_t cap = (size_t)4 << 30;
+    if (need > cap) need = cap;
+    if (ctx->tn_ws_bytes < need) {
+      if (ctx->d_tn_ws) hipFree(ctx->d_tn_ws);
+      ctx->d_tn_ws = nullptr;
+      ctx->tn_ws_bytes = 0;
+      if (hipMalloc(&ctx->d_tn_ws, need) == hipSuccess) ctx->tn_ws_bytes = need;
+    }
+    set_gemm_tn_workspace(ctx->d_tn_ws, ctx->tn_ws_bytes);
+  }
+  CHECK_RC(launch_gemm_tn(R, ld, R, ld, dG, ldg, m_pad, m_pad, n_rows, 1.0, 0.0, 1, s));
+  hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG,
+                     ldg, m_pad);
+  hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg,
+                     m_pad, dots.p, m_pad);
+  SGP_HIP(hipGetLastError());
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  CHECK_RC(chol_bordered(ctx, dG, ldg, m_pad, ldg, keep ? keep->d_wg : nullptr, s));
+  CHECK_RC(launch_sum_array(ctx->d_slots, m_pad / TILE, ctx->d_scal + 5, s));
+  CHECK_RC(launch_rowsumsq(dG + m_pad, ldg, m_pad, 1, ctx->d_scal + 6, 0, s));
+  SGP_HIP(hipMemcpyAsync(h, ctx->d_scal + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
+  info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("vfe: A A' + I is not positive definite (leading minor " + std::to_string(info) + ")");
+    return info;
+  }
+  if (keep) {
+    keep->ctx = ctx;
+    keep->M = M;
+    keep->m_pad = m_pad;
+    keep->ldg = ldg;
+    // keep Lz: copy the top m_pad x m_pad block
+    SGP_HIP(hipMalloc(&keep->dLz, sizeof(double) * m_pad * m_pad));
+    SGP_HIP(hipMemcpy2DAsync(keep->dLz, sizeof(double) * m_pad, dA.p, sizeof(double) * ld,
+                             sizeof(double) * m_pad, (size_t)m_pad, hipMemcpyDeviceToDevice, s));
+    SGP_HIP(hipStreamSynchronize(s));
+  }
+  return 0;
+}
+
+extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
+                        const double* var_x, const double* mean_x, int noise_kind,
+                        const double* noise_x, int z_noise_kind, const double* z_noise,
+                        const double* y, double* out) {
+  CHECK_ARG(ctx && zz && xz && var_x && noise_x && z_noise && y && out, "sgp_elbo: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  double h[6];
+  CHECK_RC(vfe_pipeline(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, h,
+                        nullptr));
+  long N = 0;
+  for (int i = 0; i < xz->n_row_blocks; ++i) N += xz->row_len[i];
+  // elbo = -(N log 2pi + logdet Sy + logdet Le + d'd - |Le^-1 A d|^2)/2 - (sum var/s2 - |A|_F^2)/2
+  double tmp = h[0] + h[4] + h[1] - h[5];
+  double dtc = -0.5 * ((double)N * 1.8378770664093453 + tmp);
+  out[0] = dtc - 0.5 * (h[2] - h[3]);
+  return 0;
+}
+
+extern "C" int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz,
+                                           const sgp_cov_spec* xz, const double* mean_x,
+                                           int noise_kind, const double* noise_x, int z_noise_kind,
+                                           const double* z_noise, const double* y,
+                                           sgp_sparse_post** out) {
+  CHECK_ARG(ctx && zz && xz && noise_x && z_noise && y && out, "sgp_sparse_posterior_create: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  sgp_sparse_post* p = new sgp_sparse_post();
+  double h[6];
+  int rc = vfe_pipeline(ctx, zz, xz, nullptr, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y,
+                        h, p);
+  if (rc) {
+    sgp_sparse_posterior_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return 0;
+}
+
+extern "C" int sgp_sparse_posterior_predict(sgp_sparse_post* post, const sgp_cov_spec* cross,
+                                            const sgp_cov_spec* prior_ss, const double* mean_s,
+                                            double* mean_out, double* var_out, double* cov_out,
+                                            int64_t ldcov) {
+  CHECK_ARG(post && cross, "sgp_sparse_posterior_predict: NULL argument");
+  sgp_ctx* ctx = post->ctx;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard gc, gp;
+  CHECK_RC(sgp_dspec_create(ctx, cross, &gc.ds));
+  if (prior_ss) CHECK_RC(sgp_dspec_create(ctx, prior_ss, &gp.ds));
+  long Ns = gc.ds->N;
+  CHECK_ARG(gc.ds->M == post->M, "sparse predict: cross spec columns != number of inducing points");
+  CHECK_ARG(!gp.ds || gp.ds->N == Ns, "sparse predict: prior_ss size != number of x*");
+  CHECK_ARG(!cov_out || ldcov >= Ns, "sparse predict: ldcov < Ns");
+  if (Ns == 0) return 0;
+  long ns_pad = rup(Ns, TILE), m_pad = post->m_pad;
+  hipStream_t s = ctx->stream;
+  DevBuf dB, dB2, dms;
+  CHECK_RC(dB.alloc((size_t)ns_pad * m_pad));
+  CHECK_RC(dB2.alloc((size_t)ns_pad * m_pad));
+  if (mean_s) CHECK_RC(dms.upload(mean_s, Ns));
+  SGP_HIP(hipMemsetAsync(dB.p, 0, sizeof(double) * ns_pad * m_pad, s));
+  CHECK_RC(assemble(gc.ds, dB.p, ns_pad, 0, ns_pad / TILE, 0, m_pad / TILE, 0, -1, 0.0, nullptr, s));
+  // B' = K(x*, z) Lz^-T ; then C' = B' Le^-T
+  CHECK_RC(row_trsm(ctx, dB.p, ns_pad, ns_pad, post->dLz, m_pad, post->d_wz, m_pad, s));
+  SGP_HIP(hipMemcpyAsync(dB2.p, dB.p, sizeof(double) * ns_pad * m_pad, hipMemcpyDeviceToDevice, s));
+  CHECK_RC(row_trsm(ctx, dB2.p, ns_pad, ns_pad, post->dG, post->ldg, post->d_wg, m_pad, s));
+  // mean* = m* + K*z alpha, alpha = Lz^-T Le^-T (Le^-1 A delta)  =>  mean* = m* + C' (Le^-1 A delta)
+  // var*  = k** - |B|^2 + |C|^2
+  if (mean_out)
+    CHECK_RC(predict_common(ctx, gc.ds, gp.ds, mean_s ? dms.p : nullptr, Ns, ns_pad, dB2.p, m_pad,
+                            post->dG + m_pad, post->ldg, post->M, mean_out, nullptr, nullptr, 0,
+                            0.0, nullptr, s));
+  if (var_out || cov_out)
+    CHECK_RC(predict_common(ctx, gc.ds, gp.ds, nullptr, Ns, ns_pad, dB.p, m_pad, post->dG + m_pad,
+                            post->ldg, post->M, nullptr, var_out, cov_out, ldcov, +1.0, dB2.p, s));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// multi-GPU building blocks (device pointers)
+// ---------------------------------------------------------------------------------------
+extern "C" int sgp_dev_assemble_cols(sgp_ctx* ctx, const sgp_dspec* ds, int64_t N, int64_t c0,
+                                     int64_t nc, double* d_dst, int64_t ldd, int64_t m_tot,
+                                     const double* d_mean, int noise_kind, const double* noise_host,
+                                     const double* d_noise, const double* d_Y, int64_t ldy,
+                                     int64_t ncols, void* stream) {
+  CHECK_ARG(ctx && ds && d_dst, "sgp_dev_assemble_cols: NULL argument");
+  CHECK_ARG(ds->symmetric && ds->N == N, "sgp_dev_assemble_cols: spec must be symmetric of size N");
+  CHECK_ARG(c0 % TILE == 0 && nc % TILE == 0, "sgp_dev_assemble_cols: c0, nc must be multiples of 128");
+  CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG, "bad noise kind");
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  int64_t n_pad, mt;
+  sgp_geometry(N, ncols, &n_pad, &mt);
+  CHECK_ARG(mt == m_tot && ldd >= m_tot, "sgp_dev_assemble_cols: geometry mismatch");
+  double* Kv = d_dst - c0 * ldd;  // virtual base: global column index
+  double s2 = noise_host ? noise_host[0] : 0.0;
+  CHECK_RC(assemble(ds, Kv, ldd, c0 / TILE, n_pad / TILE, c0 / TILE, (c0 + nc) / TILE, 1, noise_kind,
+                    s2, d_noise, s));
+  CHECK_RC(launch_fill_pad(d_dst, ldd, N, n_pad, c0, nc, m_tot, c0, s));
+  CHECK_RC(launch_border_rows(d_dst, ldd, n_pad, N, c0, nc, d_Y, ldy, ncols, d_mean, s));
+  return 0;
+}
+
+extern "C" int sgp_dev_panel_factor(sgp_ctx* ctx, double* d_P, int64_t ld, int64_t m, int64_t w,
+                                    int64_t g0, double* d_logdet, int* d_info, void* stream) {
+  CHECK_ARG(ctx && d_P && d_logdet && d_info, "sgp_dev_panel_factor: NULL argument");
+  CHECK_ARG(w % TILE == 0 && m % TILE == 0 && m >= w, "sgp_dev_panel_factor: bad sizes");
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  // per-block logdet slots live in ctx scratch; accumulate their sum into d_logdet[0]
+  CHECK_RC(panel_factor(ctx, d_P, ld, m, w, g0, ctx->d_slots, d_info, nullptr, s));
+  CHECK_RC(launch_sum_array(ctx->d_slots, w / TILE, ctx->d_scal + 8, s));
+  hipLaunchKernelGGL(accum_kernel, dim3(1), dim3(1), 0, s, d_logdet, ctx->d_scal + 8);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp, int64_t p_row0,
+                                    int64_t w, double* d_C, int64_t ldc, int64_t c0, int64_t nc,
+                                    int64_t m_tot, void* stream) {
+  CHECK_ARG(ctx && d_P && d_C, "sgp_dev_panel_update: NULL argument");
+  CHECK_ARG(c0 % TILE == 0 && nc % TILE == 0 && w % 16 == 0 && c0 >= p_row0, "sgp_dev_panel_update: bad sizes");
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  const double* A = d_P + (c0 - p_row0);  // panel rows c0.. (global)
+  // d_C column 0 == global column c0; rows are global
+  CHECK_RC(launch_gemm_nt(A, ldp, A, ldp, d_C + c0, ldc, m_tot - c0, nc, w, -1.0, 1.0, 0, 0, 0, s));
+  return 0;
+}
+
+extern "C" int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nc,
+                                int64_t nrows, double* d_out, void* stream) {
+  CHECK_ARG(ctx && d_rows && d_out, "sgp_dev_rowsumsq: NULL argument");
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return launch_rowsumsq(d_rows, ld, nc, nrows, d_out, 1, s);
+}
+
+// ---------------------------------------------------------------------------------------
+// micro-benchmarks
+// ---------------------------------------------------------------------------------------
+extern "C" int sgp_bench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops_out, double* layout_maxerr_out) {
+  CHECK_ARG(ctx && tflops_out && layout_maxerr_out, "sgp_bench_mfma_f64: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  return run_mfma_bench(ctx->stream, iters, tflops_out, layout_maxerr_out);
+}
+extern "C" int sgp_bench_hbm(sgp_ctx* ctx, int64_t bytes, int iters, double* write_gbs_out, double* copy_gbs_out) {
+  CHECK_ARG(ctx && write_gbs_out && copy_gbs_out, "sgp_bench_hbm: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  return run_hbm_bench(ctx->stream, bytes, iters, write_gbs_out, copy_gbs_out);
+}
+
+__global__ void fill_rand_kernel(double* p, long n, unsigned long long seed) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long x = seed + (unsigned long long)i * 0x9E3779B97F4A7C15ULL;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31;
+  p[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+}
+
+extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only,
+                              int iters, double* tflops_out, double* maxerr_out) {
+  CHECK_ARG(ctx && tflops_out && maxerr_out, "sgp_bench_gemm: NULL argument");
+  CHECK_ARG(m % TILE == 0 && n % TILE == 0 && k % 16 == 0 && m >= n, "sgp_bench_gemm: bad sizes");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = ctx->stream;
+  DevBuf A, C;
+  CHECK_RC(A.alloc((size_t)m * k));
+  CHECK_RC(C.alloc((size_t)m * n));
+  hipLaunchKernelGGL(fill_rand_kernel, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, s, A.p, m * k, 1234ULL);
+  SGP_HIP(hipMemsetAsync(C.p, 0, sizeof(double) * m * n, s));
+  // C = -A[0:m] A[0:n]'
+  CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, 0, 0, s));
+  SGP_HIP(hipStreamSynchronize(s));
+  // spot check 64 entries in the lower part against a host dot product
+  std::vector<double> hA((size_t)m * k);
+  SGP_HIP(hipMemcpy(hA.data(), A.p, sizeof(double) * m * k, hipMemcpyDeviceToHost));
+  double me = 0;
+  for (int q = 0; q < 64; ++q) {
+    long c = (long)((q * 7919L) % n), r = c + (long)((q * 104729L) % (m - c));
+    double ref = 0;
+    for (long kk = 0; kk < k; ++kk) ref -= hA[r + kk * m] * hA[c + kk * m];
+    double got = 0;
+    SGP_HIP(hipMemcpy(&got, C.p + r + c * m, sizeof(double), hipMemcpyDeviceToHost));
+    me = std::max(me, std::fabs(got - ref));
+  }
+  *maxerr_out = me;
+  hipEvent_t e0, e1;
+  SGP_HIP(hipEventCreate(&e0));
+  SGP_HIP(hipEventCreate(&e1));
+  SGP_HIP(hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i)
+    CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, 0, 0, s));
+  SGP_HIP(hipEventRecord(e1, s));
+  SGP_HIP(hipEventSynchronize(e1));
+  float ms = 0;
+  SGP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  double fl = lower_only ? update_flops(m, n, k) : 2.0 * (double)m * (double)n * (double)k;
+  *tflops_out = fl * iters / (ms * 1e-3) / 1e12;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return 0;
+}

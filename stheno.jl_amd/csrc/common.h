@@ -1,0 +1,99 @@
+// Internal definitions shared by the HIP translation units of libsthenomi.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+namespace sgp {
+
+constexpr int TILE = 128;      // tile edge of every blocked kernel (rows and cols)
+constexpr int MICRO = 16;      // MFMA f64 16x16x4 micro-tile edge
+constexpr int LDS_LD = 144;    // LDS leading dimension for 128-row operand panels:
+                               // 144 % 32 == 16 makes the (16 rows x 2 k) ds_read_b64 pattern
+                               // of a 32-lane group hit 32 distinct 8-byte slots.
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// D = A(16x4) * B(4x16) + C on one wave.  Operand/result lane maps (guide section 3):
+//   A-operand lane l holds A[m = l & 15][k = l >> 4]
+//   B-operand lane l holds B[k = l >> 4][n = l & 15]
+//   result    lane l, reg r holds D[m = (l >> 4) + 4 r][n = l & 15]
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// device-side description of one covariance term of one block pair
+struct DevTerm {
+  int kind;
+  int dim;
+  double coef;
+  double param;
+  const double* xr;  // D x nr, first point of the row block
+  long ldr;
+  const double* xc;  // D x nc
+  long ldc;
+  const double* rs;  // row scale or nullptr
+  const double* cs;  // col scale or nullptr
+};
+
+void set_error(const std::string& s);
+
+#define SGP_HIP(expr)                                                                     \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      sgp::set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " at " + __FILE__ + \
+                     ":" + std::to_string(__LINE__));                                     \
+      return -2;                                                                          \
+    }                                                                                     \
+  } while (0)
+
+// ---- launchers implemented in the .hip files -------------------------------------------
+// kernelmatrix.hip
+int launch_assemble_block(double* K, long ld, long r0, long nr, long c0, long nc,
+                          const DevTerm* d_terms, int nterms, int lds_dim_sum, int lower_only,
+                          int accumulate, int noise_kind, double sigma2, const double* d_noise_diag,
+                          long tile_r_first, long tile_c_first, long tile_r_cnt, long tile_c_cnt,
+                          hipStream_t s);
+int launch_fill_pad(double* K, long ld, long N, long n_pad, long c0, long nc, long m_tot,
+                    long row_lo, hipStream_t s);
+int launch_border_rows(double* A, long ld, long n_pad, long N, long c0, long nc, const double* dY,
+                       long ldy, long ncols, const double* d_mean, hipStream_t s);
+int launch_diag_terms(double* out, long n, const DevTerm* d_terms, int nterms, hipStream_t s);
+int launch_add_dense(double* K, long ld, const double* S, long lds, long N, int lower_only,
+                     hipStream_t s);
+
+// gemm_nt.hip : C = beta*C + alpha * A B'   (A: M x K, B: Nc x K, all column-major)
+// tiles (tr, tc) with tr < tc + mask_off are skipped.  kcap_mode: per-tile K limited to
+// (tc + 1) * 128 + kcap_off (used by L*Z products where only the lower triangle of B is valid).
+int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                   long M, long Nc, long K, double alpha, double beta, long mask_off,
+                   int kcap_mode, long kcap_off, hipStream_t s);
+// gemm_tn: C(M x Nc) = beta*C + alpha * A' B with A: K x M, B: K x Nc (K is the contiguous dim)
+int launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
+                   long M, long Nc, long K, double alpha, double beta, int lower_only,
+                   hipStream_t s);
+
+void set_gemm_tn_workspace(double* ws, size_t bytes);
+
+// potrf.hip
+int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,
+                      long gcol0, hipStream_t s);
+int launch_trtri(const double* L, long ld, const double* d_invd, double* d_w, hipStream_t s);
+
+// reduce.hip
+int launch_rowsumsq(const double* rows, long ld, long nc, long nrows, double* out, int accumulate,
+                    hipStream_t s);
+int launch_sum_array(const double* in, long n, double* out, hipStream_t s);
+int launch_logpdf_final(const double* d_logdet, const double* d_sq, long N, long ncols,
+                        double* d_out, hipStream_t s);
+int launch_colsumsq_sub(const double* V, long ld, long nrows, long ncols, const double* prior,
+                        double* out, double sign, hipStream_t s);
+int launch_gemv_rows(const double* rows, long ld, long nrows, long nc, const double* z, long ldz,
+                     const double* add, double* out, hipStream_t s);
+int launch_transpose_add(const double* src, long lds, long nr, long nc, double* dst, long ldd,
+                         const double* add_vec, hipStream_t s);
+int launch_scale_rows(double* rows, long ld, long nrows, long nc, const double* scale,
+                      hipStream_t s);
+
+}  // namespace sgp

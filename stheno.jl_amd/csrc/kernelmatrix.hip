@@ -1,0 +1,292 @@
+// Covariance assembly kernels: fused pairwise distance + kernel + scale + sum-of-terms + noise,
+// written once into the (bordered) factor matrix in HBM.
+//
+// Replaces, on the reference path, KernelFunctions.kernelmatrix [EXT] (Distances.pairwise +
+// map(kappa, D)) as reached from src/gp/atomic_gp.jl:30-33, together with the block assembly
+// of src/affine_transformations/cross.jl:59-86 (_collect(_mortar(...)) copies), the nested
+// broadcasts of addition.jl:28-47 / product.jl:25-70, and the `C + Sigma_y` pass of
+// AbstractGPs.FiniteGP [EXT].  One pass, written once: the kernel is HBM-write/fp64-VALU bound.
+//
+// Work decomposition: the global matrix is cut into 128x128 tiles aligned to the global tile
+// grid (the same grid the Cholesky uses).  One 256-thread workgroup per tile; thread t owns row
+// (t & 127) and the 64 columns of half (t >> 7), so each store instruction of a wave writes 64
+// consecutive doubles of one column (512 B, coalesced; ColVecs/column-major output).
+// The 128 column points of every term are staged in LDS point-major ([point][DMAX], a straight
+// copy of the ColVecs segment) and read as wave-uniform broadcasts; the row point lives in
+// registers.  Distances are the direct sum_d (a_d - b_d)^2 (exactly 0 on coincident points, so
+// SE diagonals are exactly 1: test/gp/atomic_gp.jl:34), not the GEMM trick.
+#include "common.h"
+
+namespace sgp {
+
+enum { K_SE = 0, K_M12 = 1, K_M32 = 2, K_M52 = 3, K_WHITE = 4, K_CONST = 5 };
+
+__device__ __forceinline__ double kern_eval(int kind, double d2, double param) {
+  switch (kind) {
+    case K_SE:
+      return exp(-0.5 * d2);
+    case K_M12:
+      return exp(-sqrt(d2));
+    case K_M32: {
+      double l = 1.7320508075688772 * sqrt(d2);
+      return (1.0 + l) * exp(-l);
+    }
+    case K_M52: {
+      double l = 2.23606797749979 * sqrt(d2);
+      return (1.0 + l + l * l / 3.0) * exp(-l);
+    }
+    case K_WHITE:
+      return d2 == 0.0 ? 1.0 : 0.0;
+    default:
+      return param;
+  }
+}
+
+constexpr int CCHUNK = 8;  // columns processed per accumulator chunk
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void assemble_block_kernel(
+    double* K, long ld, long r0, long nr, long c0, long nc, const DevTerm* terms, int nterms,
+    int lower_only, int accumulate, int noise_kind, double sigma2, const double* noise_diag,
+    long tile_r_first, long tile_c_first) {
+  const long gtr = tile_r_first + blockIdx.x;
+  const long gtc = tile_c_first + blockIdx.y;
+  if (lower_only && gtr < gtc) return;
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [nterms][128][DMAX]
+  const int t = threadIdx.x;
+  const int trow = t & 127, th = t >> 7;
+
+  // column range of this tile inside the block-pair rectangle
+  long cbeg = gtc * TILE, cend = cbeg + TILE;
+  if (cbeg < c0) cbeg = c0;
+  if (cend > c0 + nc) cend = c0 + nc;
+  long rbeg = gtr * TILE, rend = rbeg + TILE;
+  if (rbeg < r0) rbeg = r0;
+  if (rend > r0 + nr) rend = r0 + nr;
+  if (cbeg >= cend || rbeg >= rend) return;
+
+  // stage column points of every term: smem[(tm*128 + p)*DMAX + d], p relative to gtc*128
+  for (int tm = 0; tm < nterms; ++tm) {
+    const DevTerm T = terms[tm];
+    const int D = T.dim;
+    for (int idx = t; idx < TILE * DMAX; idx += 256) {
+      int p = idx / DMAX, d = idx % DMAX;
+      long gc = gtc * TILE + p;
+      double v = 0.0;
+      if (d < D && gc >= cbeg && gc < cend) v = T.xc[(gc - c0) * T.ldc + d];
+      smem[(tm * TILE + p) * DMAX + d] = v;
+    }
+  }
+  __syncthreads();
+
+  const long grow = gtr * TILE + trow;
+  const bool row_ok = grow >= rbeg && grow < rend;
+  if (!row_ok) return;  // no further barriers below
+  const long lrow = grow - r0;
+  const bool diag_noise = noise_kind >= 0;
+  double nval = 0.0;
+  if (diag_noise) nval = (noise_kind == 0) ? sigma2 : noise_diag[grow];
+
+  for (int jc = 0; jc < 64; jc += CCHUNK) {
+    const int pbase = th * 64 + jc;  // point index within the tile
+    if (gtc * TILE + pbase >= cend) break;
+    double acc[CCHUNK];
+#pragma unroll
+    for (int q = 0; q < CCHUNK; ++q) acc[q] = 0.0;
+    for (int tm = 0; tm < nterms; ++tm) {
+      const DevTerm T = terms[tm];
+      double xi[DMAX];
+      {
+        const double* xr = T.xr + lrow * T.ldr;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) xi[d] = (d < T.dim) ? xr[d] : 0.0;
+      }
+      const double rsv = T.coef * (T.rs ? T.rs[lrow] : 1.0);
+      const double* sp = &smem[(tm * TILE + pbase) * DMAX];
+#pragma unroll
+      for (int q = 0; q < CCHUNK; ++q) {
+        double d2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+          double df = xi[d] - sp[q * DMAX + d];
+          d2 = fma(df, df, d2);
+        }
+        double kv = kern_eval(T.kind, d2, T.param) * rsv;
+        if (T.cs) {
+          long gc = gtc * TILE + pbase + q;
+          long lc = gc - c0;
+          kv *= (gc >= cbeg && gc < cend) ? T.cs[lc] : 0.0;
+        }
+        acc[q] += kv;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CCHUNK; ++q) {
+      long gc = gtc * TILE + pbase + q;
+      if (gc >= cbeg && gc < cend) {
+        double v = acc[q];
+        if (diag_noise && gc == grow) v += nval;
+        double* p = K + grow + gc * ld;
+        if (accumulate) v += *p;
+        *p = v;
+      }
+    }
+  }
+}
+
+template <int DMAX>
+static int launch_assemble_t(double* K, long ld, long r0, long nr, long c0, long nc,
+                             const DevTerm* d_terms, int nterms, int lower_only, int accumulate,
+                             int noise_kind, double sigma2, const double* d_noise_diag,
+                             long tile_r_first, long tile_c_first, long tile_r_cnt,
+                             long tile_c_cnt, hipStream_t s) {
+  size_t lds = (size_t)nterms * TILE * DMAX * sizeof(double);
+  if (lds == 0) lds = 16;
+  dim3 grid((unsigned)tile_r_cnt, (unsigned)tile_c_cnt), block(256);
+  hipLaunchKernelGGL(assemble_block_kernel<DMAX>, grid, block, lds, s, K, ld, r0, nr, c0, nc,
+                     d_terms, nterms, lower_only, accumulate, noise_kind, sigma2, d_noise_diag,
+                     tile_r_first, tile_c_first);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_assemble_block(double* K, long ld, long r0, long nr, long c0, long nc,
+                          const DevTerm* d_terms, int nterms, int dmax, int lower_only,
+                          int accumulate, int noise_kind, double sigma2,
+                          const double* d_noise_diag, long tile_r_first, long tile_c_first,
+                          long tile_r_cnt, long tile_c_cnt, hipStream_t s) {
+  if (tile_r_cnt <= 0 || tile_c_cnt <= 0) return 0;
+#define SGP_ASM(DM)                                                                            \
+  return launch_assemble_t<DM>(K, ld, r0, nr, c0, nc, d_terms, nterms, lower_only, accumulate, \
+                               noise_kind, sigma2, d_noise_diag, tile_r_first, tile_c_first,   \
+                               tile_r_cnt, tile_c_cnt, s)
+  if (dmax <= 1) SGP_ASM(1);
+  if (dmax <= 2) SGP_ASM(2);
+  if (dmax <= 4) SGP_ASM(4);
+  if (dmax <= 8) SGP_ASM(8);
+  if (dmax <= 16) SGP_ASM(16);
+  if (dmax <= 32) SGP_ASM(32);
+  if (dmax <= 64) SGP_ASM(64);
+#undef SGP_ASM
+  set_error("assemble: input dimension > 64 is not supported on device");
+  return -1;
+}
+
+// identity padding: rows/cols in [N, n_pad) of the square part get delta(r, c); everything in a
+// padded column below the square part (border rows) gets 0.
+__global__ void fill_pad_rows_kernel(double* K, long ld, long N, long n_pad, long nc, long gc0) {
+  // rows [N, n_pad) x local cols [0, nc)
+  long h = n_pad - N;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= h * nc) return;
+  long r = N + idx % h, lc = idx / h;
+  long gc = gc0 + lc;
+  K[r + lc * ld] = (r == gc) ? 1.0 : 0.0;
+}
+__global__ void fill_pad_cols_kernel(double* K, long ld, long N, long n_pad, long m_tot, long nc,
+                                     long gc0, long row_lo) {
+  // local cols whose global index >= N, rows [row_lo, m_tot)
+  long h = m_tot - row_lo;
+  long first = N > gc0 ? N - gc0 : 0;  // first padded local col
+  long w = nc - first;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (w <= 0 || idx >= h * w) return;
+  long r = row_lo + idx % h, lc = first + idx / h;
+  long gc = gc0 + lc;
+  K[r + lc * ld] = (r == gc) ? 1.0 : 0.0;
+}
+
+int launch_fill_pad(double* K, long ld, long N, long n_pad, long c0, long nc, long m_tot,
+                    long row_lo, hipStream_t s) {
+  // K points at local column 0 (global column c0), row index global.
+  if (n_pad > N) {
+    long tot = (n_pad - N) * nc;
+    hipLaunchKernelGGL(fill_pad_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
+                       K, ld, N, n_pad, nc, c0);
+    SGP_HIP(hipGetLastError());
+    long first = N > c0 ? N - c0 : 0;
+    long w = nc - first;
+    if (w > 0) {
+      long tot2 = (m_tot - row_lo) * w;
+      hipLaunchKernelGGL(fill_pad_cols_kernel, dim3((unsigned)((tot2 + 255) / 256)), dim3(256), 0,
+                         s, K, ld, N, n_pad, m_tot, nc, c0, row_lo);
+      SGP_HIP(hipGetLastError());
+    }
+  }
+  return 0;
+}
+
+// bordered rows: A[n_pad + s, lc] = Y[gc, s] - mean[gc] for gc < N, s < ncols; 0 otherwise
+__global__ void border_rows_kernel(double* A, long ld, long n_pad, long N, long gc0, long nc,
+                                   const double* Y, long ldy, long ncols, const double* mean,
+                                   long r_pad) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= r_pad * nc) return;
+  long s = idx % r_pad, lc = idx / r_pad;
+  long gc = gc0 + lc;
+  double v = 0.0;
+  if (s < ncols && gc < N) v = Y[gc + s * ldy] - (mean ? mean[gc] : 0.0);
+  A[n_pad + s + lc * ld] = v;
+}
+
+int launch_border_rows(double* A, long ld, long n_pad, long N, long c0, long nc, const double* dY,
+                       long ldy, long ncols, const double* d_mean, hipStream_t s) {
+  if (ncols <= 0) return 0;
+  long r_pad = (ncols + TILE - 1) / TILE * TILE;
+  long tot = r_pad * nc;
+  hipLaunchKernelGGL(border_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A,
+                     ld, n_pad, N, c0, nc, dY, ldy, ncols, d_mean, r_pad);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// diag of a block: out[i] = sum_t coef rs[i] cs[i] k(xr_i, xc_i)   (kernelmatrix_diag [EXT],
+// src/gp/util.jl:5-7, cross.jl:64-77, addition.jl:31-40, product.jl:32-47)
+__global__ void diag_terms_kernel(double* out, long n, const DevTerm* terms, int nterms) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double acc = 0.0;
+  for (int tm = 0; tm < nterms; ++tm) {
+    const DevTerm T = terms[tm];
+    double d2 = 0.0;
+    for (int d = 0; d < T.dim; ++d) {
+      double df = T.xr[i * T.ldr + d] - T.xc[i * T.ldc + d];
+      d2 = fma(df, df, d2);
+    }
+    double kv = kern_eval(T.kind, d2, T.param) * T.coef;
+    if (T.rs) kv *= T.rs[i];
+    if (T.cs) kv *= T.cs[i];
+    acc += kv;
+  }
+  out[i] = acc;
+}
+
+int launch_diag_terms(double* out, long n, const DevTerm* d_terms, int nterms, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(diag_terms_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, n,
+                     d_terms, nterms);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// dense Sigma_y: K[r, c] += S[r, c] on the tiles the factorisation reads
+__global__ void add_dense_kernel(double* K, long ld, const double* S, long lds, long N,
+                                 int lower_only) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * N) return;
+  long r = idx % N, c = idx / N;
+  if (lower_only && (r / TILE) < (c / TILE)) return;
+  K[r + c * ld] += S[r + c * lds];
+}
+
+int launch_add_dense(double* K, long ld, const double* S, long lds, long N, int lower_only,
+                     hipStream_t s) {
+  long tot = N * N;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(add_dense_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K, ld,
+                     S, lds, N, lower_only);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sgp

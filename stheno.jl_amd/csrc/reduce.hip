@@ -1,0 +1,161 @@
+// Small HBM-bound reductions / vector kernels around the factorisation: all deterministic
+// (fixed-order tree reductions, no floating-point atomics) so results are bit-identical
+// run to run.
+#include "common.h"
+
+namespace sgp {
+
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+  int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0) {
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) s += sh[i];
+  }
+  return s;  // valid in thread 0
+}
+
+// out[s] (+)= sum_{c < nc} rows[s + c*ld]^2     (|L^-1 (y - m)|^2 from the bordered rows)
+__global__ void rowsumsq_kernel(const double* rows, long ld, long nc, double* out, int accumulate) {
+  __shared__ double sh[4];
+  const long s = blockIdx.x;
+  double acc = 0.0;
+  for (long c = threadIdx.x; c < nc; c += blockDim.x) {
+    double v = rows[s + c * ld];
+    acc = fma(v, v, acc);
+  }
+  double tot = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[s] = accumulate ? out[s] + tot : tot;
+}
+
+int launch_rowsumsq(const double* rows, long ld, long nc, long nrows, double* out, int accumulate,
+                    hipStream_t s) {
+  if (nrows <= 0) return 0;
+  hipLaunchKernelGGL(rowsumsq_kernel, dim3((unsigned)nrows), dim3(256), 0, s, rows, ld, nc, out,
+                     accumulate);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+__global__ void sum_array_kernel(const double* in, long n, double* out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) acc += in[i];
+  double tot = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+
+int launch_sum_array(const double* in, long n, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(sum_array_kernel, dim3(1), dim3(256), 0, s, in, n, out);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// out[s] = -(N log 2pi + logdet + sq[s]) / 2      (AbstractGPs.logpdf [EXT], App. A.3)
+__global__ void logpdf_final_kernel(const double* logdet, const double* sq, long N, long ncols,
+                                    double* out) {
+  long s = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ncols) return;
+  out[s] = -0.5 * ((double)N * 1.8378770664093453 + logdet[0] + sq[s]);
+}
+
+int launch_logpdf_final(const double* d_logdet, const double* d_sq, long N, long ncols,
+                        double* d_out, hipStream_t s) {
+  hipLaunchKernelGGL(logpdf_final_kernel, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s,
+                     d_logdet, d_sq, N, ncols, d_out);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// out[j] = prior[j] + sign * sum_{c<ncols} V[j + c*ld]^2   (posterior variance, App. A.5)
+__global__ void rowsumsq_axpy_kernel(const double* V, long ld, long ncols, const double* prior,
+                                     double* out, double sign) {
+  __shared__ double sh[4];
+  const long j = blockIdx.x;
+  double acc = 0.0;
+  for (long c = threadIdx.x; c < ncols; c += blockDim.x) {
+    double v = V[j + c * ld];
+    acc = fma(v, v, acc);
+  }
+  double tot = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[j] = prior[j] + sign * tot;
+}
+
+int launch_colsumsq_sub(const double* V, long ld, long nrows, long ncols, const double* prior,
+                        double* out, double sign, hipStream_t s) {
+  if (nrows <= 0) return 0;
+  hipLaunchKernelGGL(rowsumsq_axpy_kernel, dim3((unsigned)nrows), dim3(256), 0, s, V, ld, ncols,
+                     prior, out, sign);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// out[j] = add[j] + sum_{c<nc} rows[j + c*ld] * z[c*ldz]   (posterior mean m* + V' z)
+__global__ void gemv_rows_kernel(const double* rows, long ld, long nc, const double* z, long ldz,
+                                 const double* add, double* out) {
+  __shared__ double sh[4];
+  const long j = blockIdx.x;
+  double acc = 0.0;
+  for (long c = threadIdx.x; c < nc; c += blockDim.x) acc = fma(rows[j + c * ld], z[c * ldz], acc);
+  double tot = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) out[j] = (add ? add[j] : 0.0) + tot;
+}
+
+int launch_gemv_rows(const double* rows, long ld, long nrows, long nc, const double* z, long ldz,
+                     const double* add, double* out, hipStream_t s) {
+  if (nrows <= 0) return 0;
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)nrows), dim3(256), 0, s, rows, ld, nc, z, ldz,
+                     add, out);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// dst[c + r*ldd] = src[r + c*lds] (+ add_vec[c])   -- tiled transpose, nr x nc -> nc x nr
+__global__ void transpose_add_kernel(const double* src, long lds, long nr, long nc, double* dst,
+                                     long ldd, const double* add_vec) {
+  __shared__ double tile[32][33];
+  long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
+  int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
+  for (int k = ty; k < 32; k += 8) {
+    long r = r0 + tx, c = c0 + k;
+    tile[k][tx] = (r < nr && c < nc) ? src[r + c * lds] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    long c = c0 + tx, r = r0 + k;
+    if (r < nr && c < nc) dst[c + r * ldd] = tile[tx][k] + (add_vec ? add_vec[c] : 0.0);
+  }
+}
+
+int launch_transpose_add(const double* src, long lds, long nr, long nc, double* dst, long ldd,
+                         const double* add_vec, hipStream_t s) {
+  if (nr <= 0 || nc <= 0) return 0;
+  dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((nc + 31) / 32));
+  hipLaunchKernelGGL(transpose_add_kernel, grid, dim3(256), 0, s, src, lds, nr, nc, dst, ldd,
+                     add_vec);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// rows[j + c*ld] *= scale[j]   (Lambda_y^-1 scaling of K(x, z) rows for the ELBO, App. A.6)
+__global__ void scale_rows_kernel(double* rows, long ld, long nrows, long nc, const double* scale) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nrows * nc) return;
+  long j = idx % nrows, c = idx / nrows;
+  rows[j + c * ld] *= scale[j];
+}
+
+int launch_scale_rows(double* rows, long ld, long nrows, long nc, const double* scale,
+                      hipStream_t s) {
+  long tot = nrows * nc;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, rows,
+                     ld, nrows, nc, scale);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sgp

@@ -1,0 +1,267 @@
+"""ctypes binding of libsthenomi.so (include/sthenomi.h).
+
+This is the only place the Python host touches native code.  There is deliberately no
+CPU fallback: if the HIP library is missing or no gfx950 device is visible, every entry
+point raises (`SthenoMIError`), so a silently-eager test run is impossible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsthenomi.so")
+
+# kernel kinds / noise kinds (sthenomi.h enums)
+SE, MATERN12, MATERN32, MATERN52, WHITE, CONST = range(6)
+NOISE_SCALAR, NOISE_DIAG, NOISE_DENSE = range(3)
+
+
+class SthenoMIError(RuntimeError):
+    pass
+
+
+class PosDefException(SthenoMIError):
+    """Mirrors LinearAlgebra.PosDefException(info) thrown by `cholesky` on the reference path."""
+
+    def __init__(self, info, msg=""):
+        super().__init__(f"PosDefException: matrix is not positive definite; "
+                         f"Cholesky factorization failed (info={info}). {msg}")
+        self.info = info
+
+
+class sgp_input(C.Structure):
+    _fields_ = [("dim", C.c_int64), ("n", C.c_int64), ("ld", C.c_int64),
+                ("x", C.POINTER(C.c_double))]
+
+
+class sgp_term(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("row_input", C.c_int32), ("col_input", C.c_int32),
+                ("reserved", C.c_int32), ("coef", C.c_double), ("param", C.c_double),
+                ("row_scale", C.POINTER(C.c_double)), ("col_scale", C.POINTER(C.c_double))]
+
+
+class sgp_cov_spec(C.Structure):
+    _fields_ = [("n_row_blocks", C.c_int32), ("n_col_blocks", C.c_int32),
+                ("row_len", C.POINTER(C.c_int64)), ("col_len", C.POINTER(C.c_int64)),
+                ("n_inputs", C.c_int32), ("inputs", C.POINTER(sgp_input)),
+                ("term_ptr", C.POINTER(C.c_int32)), ("terms", C.POINTER(sgp_term)),
+                ("symmetric", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+_P = C.c_void_p
+_D = C.POINTER(C.c_double)
+_SIGS = {
+    "sgp_abi_version": (C.c_int, []),
+    "sgp_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "sgp_ctx_destroy": (C.c_int, [_P]),
+    "sgp_last_error": (C.c_char_p, []),
+    "sgp_kernelmatrix": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int64]),
+    "sgp_kernelmatrix_diag": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D]),
+    "sgp_logpdf": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64,
+                             C.c_int64, _D]),
+    "sgp_rand": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64, C.c_int64,
+                           _D, C.c_int64]),
+    "sgp_posterior_create": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D,
+                                       C.POINTER(_P)]),
+    "sgp_posterior_predict": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D,
+                                        _D, _D, _D, C.c_int64]),
+    "sgp_posterior_destroy": (C.c_int, [_P]),
+    "sgp_elbo": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int,
+                           _D, C.c_int, _D, _D, _D]),
+    "sgp_sparse_posterior_create": (C.c_int, [_P, C.POINTER(sgp_cov_spec),
+                                              C.POINTER(sgp_cov_spec), _D, C.c_int, _D, C.c_int,
+                                              _D, _D, C.POINTER(_P)]),
+    "sgp_sparse_posterior_predict": (C.c_int, [_P, C.POINTER(sgp_cov_spec),
+                                               C.POINTER(sgp_cov_spec), _D, _D, _D, _D, C.c_int64]),
+    "sgp_sparse_posterior_destroy": (C.c_int, [_P]),
+    "sgp_dspec_create": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(_P)]),
+    "sgp_dspec_destroy": (C.c_int, [_P]),
+    "sgp_geometry": (C.c_int, [C.c_int64, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "sgp_dev_logpdf": (C.c_int, [_P, _P, _P, _P, C.c_int, _D, _P, _P, C.c_int64, C.c_int64, _D, _D]),
+    "sgp_dev_assemble_cols": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64,
+                                        C.c_int64, _P, C.c_int, _D, _P, _P, C.c_int64, C.c_int64,
+                                        _P]),
+    "sgp_dev_panel_factor": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, C.c_int64, _P, _P,
+                                       _P]),
+    "sgp_dev_panel_update": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64,
+                                       C.c_int64, C.c_int64, C.c_int64, _P]),
+    "sgp_dev_rowsumsq": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "sgp_bench_mfma_f64": (C.c_int, [_P, C.c_int, _D, _D]),
+    "sgp_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D]),
+    "sgp_bench_gemm": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _D, _D]),
+}
+
+
+def exported_symbols():
+    """Names include/sthenomi.h declares (used by the CPU-side symbol test)."""
+    return sorted(_SIGS)
+
+
+def load():
+    """dlopen libsthenomi.so (after torch, so both share one HIP runtime) and type its symbols."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SthenoMIError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                f"g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        try:  # torch bundles its own libamdhip64 (SONAME libamdhip64.so.7): load it first
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the pure C-ABI
+            pass
+        lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def last_error():
+    return load().sgp_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what=""):
+    if rc == 0:
+        return
+    msg = last_error()
+    if rc > 0:
+        raise PosDefException(rc, msg)
+    raise SthenoMIError(f"{what} failed (rc={rc}): {msg}")
+
+
+def dptr(a):
+    """double* of a numpy array (or NULL)."""
+    if a is None:
+        return C.cast(None, _D)
+    return a.ctypes.data_as(_D)
+
+
+class Context:
+    """One sgp_ctx (one GPU, one stream).  `default_context()` gives a process-wide one."""
+
+    def __init__(self, device=0):
+        lib = load()
+        h = _P()
+        check(lib.sgp_ctx_create(int(device), C.byref(h)), "sgp_ctx_create")
+        self.handle = h
+        self.device = device
+        self.lib = lib
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.sgp_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("LOCAL_RANK", "0"))
+        try:
+            import torch
+            if torch.cuda.is_available() and dev >= torch.cuda.device_count():
+                dev = 0
+        except Exception:
+            pass
+        _default_ctx = Context(dev)
+    return _default_ctx
+
+
+class Spec:
+    """Owns the numpy buffers and ctypes arrays behind one sgp_cov_spec.
+
+    row_len / col_len : block lengths
+    inputs            : list of (D x n) float64 Fortran-ordered arrays (ColVecs layout)
+    pairs             : dict (I, J) -> list of term tuples
+                        (kind, row_input, col_input, coef, param, row_scale|None, col_scale|None)
+    """
+
+    def __init__(self, row_len, col_len, inputs, pairs, symmetric):
+        self.row_len = np.asarray(row_len, dtype=np.int64)
+        self.col_len = np.asarray(col_len, dtype=np.int64)
+        self.N = int(self.row_len.sum())
+        self.M = int(self.col_len.sum())
+        self._keep = []
+        self.inputs = []
+        for x in inputs:
+            x = np.asarray(x, dtype=np.float64)
+            if x.ndim == 1:
+                x = x.reshape(1, -1)
+            x = np.asfortranarray(x)
+            self.inputs.append(x)
+        nrb, ncb = len(self.row_len), len(self.col_len)
+        self._in_arr = (sgp_input * max(1, len(self.inputs)))()
+        for k, x in enumerate(self.inputs):
+            self._in_arr[k].dim = x.shape[0]
+            self._in_arr[k].n = x.shape[1]
+            self._in_arr[k].ld = x.shape[0]
+            self._in_arr[k].x = dptr(x)
+        term_ptr = [0]
+        terms = []
+        for I in range(nrb):
+            for J in range(ncb):
+                terms.extend(pairs.get((I, J), []))
+                term_ptr.append(len(terms))
+        self.n_terms = len(terms)
+        self._term_ptr = np.asarray(term_ptr, dtype=np.int32)
+        self._terms = (sgp_term * max(1, len(terms)))()
+        for k, (kind, ri, ci, coef, param, rs, cs) in enumerate(terms):
+            t = self._terms[k]
+            t.kind, t.row_input, t.col_input, t.reserved = int(kind), int(ri), int(ci), 0
+            t.coef, t.param = float(coef), float(param)
+            if rs is not None:
+                rs = np.ascontiguousarray(rs, dtype=np.float64)
+                self._keep.append(rs)
+            if cs is not None:
+                cs = np.ascontiguousarray(cs, dtype=np.float64)
+                self._keep.append(cs)
+            t.row_scale = dptr(rs)
+            t.col_scale = dptr(cs)
+        s = sgp_cov_spec()
+        s.n_row_blocks, s.n_col_blocks = nrb, ncb
+        s.row_len = self.row_len.ctypes.data_as(C.POINTER(C.c_int64))
+        s.col_len = self.col_len.ctypes.data_as(C.POINTER(C.c_int64))
+        s.n_inputs = len(self.inputs)
+        s.inputs = self._in_arr
+        s.term_ptr = self._term_ptr.ctypes.data_as(C.POINTER(C.c_int32))
+        s.terms = self._terms
+        s.symmetric = 1 if symmetric else 0
+        s.reserved = 0
+        self.c = s
+
+    def ref(self):
+        return C.byref(self.c)
+
+
+def _noise_args(noise, N):
+    """(kind, buffer) for a FiniteGP noise: scalar -> s2*I, vector -> Diagonal, matrix -> dense."""
+    a = np.asarray(noise, dtype=np.float64)
+    if a.ndim == 0:
+        return NOISE_SCALAR, np.array([float(a)], dtype=np.float64)
+    if a.ndim == 1:
+        if a.shape[0] != N:
+            raise ValueError("diagonal noise has the wrong length")
+        return NOISE_DIAG, np.ascontiguousarray(a)
+    if a.shape != (N, N):
+        raise ValueError("dense noise has the wrong shape")
+    return NOISE_DENSE, np.asfortranarray(a)
