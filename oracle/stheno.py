@@ -1,0 +1,492 @@
+"""Oracle restatement of Stheno.jl's covariance algebra, following the in-tree sources line by
+line (dense NumPy blocks, the reference's own recursion and evaluation order).
+TEST INFRASTRUCTURE -- the product never imports this (it flattens trees into kernel terms
+instead; tests check flattening == this recursion).
+
+Reference files restated (all under /root/reference/src):
+  input_collection_types.jl:24-33,61-95   GPPPInput, BlockData, blocks
+  gp/util.jl:2-25                          SthenoAbstractGP, cov(fx, gx), GPC
+  gp/atomic_gp.jl:11-41                    AtomicGP, atomic, 4-arg cov/var between atoms
+  gp/derived_gp.jl:7-60                    DerivedGP, creation-order dispatcher
+  gp/sparse_finite_gp.jl:30-62             SparseFiniteGP
+  affine_transformations/cross.jl:37-93    cross
+  affine_transformations/addition.jl:8-86  +, -
+  affine_transformations/product.jl:11-73  *
+  affine_transformations/compose.jl:8-127  o, Stretch, Select, Periodic, Shift
+  affine_transformations/additive_gp.jl:10-29
+  gaussian_process_probabilistic_programme.jl:13-135   GPPP, extract_components, split
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import abstractgps as agp
+from . import kernelfunctions as kf
+from .kernelfunctions import ColVecs
+
+
+# ---- input collection types (input_collection_types.jl) --------------------------------------
+class GPPPInput:
+    """(process key, inputs) -- input_collection_types.jl:24-33."""
+
+    def __init__(self, p, x):
+        self.p, self.x = p, x
+
+    def __len__(self):
+        return len(self.x)
+
+
+class BlockData:
+    """Ordered ragged concatenation of input vectors -- input_collection_types.jl:61-95."""
+
+    def __init__(self, *xs):
+        if len(xs) == 1 and isinstance(xs[0], (list, tuple)):
+            xs = tuple(xs[0])
+        self.X = list(xs)
+
+    def __len__(self):
+        return sum(len(b) for b in self.X)
+
+
+def blocks(x):
+    return x.X
+
+
+# ---- GPC + node types (gp/util.jl, gp/atomic_gp.jl, gp/derived_gp.jl) -----------------------
+class GPC:
+    def __init__(self):
+        self.n = 0
+
+
+class SthenoAbstractGP:
+    def __call__(self, x, noise=1e-18):
+        return agp.FiniteGP(self, x, noise)
+
+    # operator sugar (addition.jl:8-12,62-65; product.jl:11-13,73)
+    def __add__(self, other):
+        if isinstance(other, SthenoAbstractGP):
+            assert self.gpc is other.gpc
+            return DerivedGP(("+", self, other), self.gpc)
+        return DerivedGP(("+known", other, self), self.gpc)
+
+    def __radd__(self, other):
+        return DerivedGP(("+known", other, self), self.gpc)
+
+    def __neg__(self):
+        return DerivedGP(("*", -1.0, self), self.gpc)
+
+    def __sub__(self, other):
+        if isinstance(other, SthenoAbstractGP):
+            return self + (-other)
+        return self + (-other)
+
+    def __rsub__(self, other):
+        return other + (-self)
+
+    def __mul__(self, s):
+        if isinstance(s, SthenoAbstractGP):
+            raise ValueError("Cannot multiply two GPs together.")
+        return DerivedGP(("*", s, self), self.gpc)
+
+    __rmul__ = __mul__
+
+    # the internal AbstractGPs API, all routed through the 4-arg dispatcher semantics
+    def cov_cross(self, other, x, x2):
+        return cov4(self, other, x, x2)
+
+
+class AtomicGP(SthenoAbstractGP):
+    """atomic_gp.jl:11-22: wraps a leaf GP, takes the next creation index."""
+
+    def __init__(self, gp, gpc):
+        self.gp, self.gpc = gp, gpc
+        self.n = gpc.n + 1
+        gpc.n += 1
+
+    def mean(self, x):
+        return self.gp.mean(x)
+
+    def cov(self, x, x2=None):
+        return self.gp.cov(x, x2)
+
+    def var(self, x, x2=None):
+        return self.gp.var(x, x2)
+
+
+def atomic(gp, gpc):
+    return AtomicGP(gp, gpc)
+
+
+class DerivedGP(SthenoAbstractGP):
+    """derived_gp.jl:7-29: (op, args...) + creation index."""
+
+    def __init__(self, args, gpc):
+        self.args, self.gpc = args, gpc
+        self.n = gpc.n + 1
+        gpc.n += 1
+
+    def mean(self, x):
+        return mean_args(self.args, x)
+
+    def cov(self, x, x2=None):
+        return cov_args(self.args, x, x2)
+
+    def var(self, x, x2=None):
+        return var_args(self.args, x, x2)
+
+
+def cov4(f, f2, x, x2):
+    """derived_gp.jl:31-44 (and atomic_gp.jl:36-38 for two atoms)."""
+    assert f.gpc is f2.gpc
+    if f.n == f2.n:
+        return f.cov(x, x2)
+    if (isinstance(f, AtomicGP) and f.n > f2.n) or (isinstance(f2, AtomicGP) and f2.n > f.n):
+        return np.zeros((len(x), len(x2)))
+    if f.n >= f2.n:
+        return cov_args_left(f.args, f2, x, x2)
+    return cov_args_right(f, f2.args, x, x2)
+
+
+def var4(f, f2, x, x2):
+    """derived_gp.jl:46-60."""
+    assert f.gpc is f2.gpc
+    if f.n == f2.n:
+        return f.var(x, x2)
+    if (isinstance(f, AtomicGP) and f.n > f2.n) or (isinstance(f2, AtomicGP) and f2.n > f.n):
+        return np.zeros(len(x))
+    if f.n >= f2.n:
+        return var_args_left(f.args, f2, x, x2)
+    return var_args_right(f, f2.args, x, x2)
+
+
+# ---- input warps (compose.jl:36-127) ------------------------------------------------------------
+class Stretch:
+    def __init__(self, l):
+        self.l = l
+
+    def __call__(self, x):
+        l = self.l
+        if isinstance(x, ColVecs):
+            if np.ndim(l) == 0:
+                return ColVecs(l * x.X)
+            return ColVecs(np.asarray(l) @ x.X)
+        return l * np.asarray(x, dtype=np.float64)
+
+
+class Select:
+    def __init__(self, idx):
+        self.idx = idx
+
+    def __call__(self, x):
+        if isinstance(self.idx, (int, np.integer)):
+            return x.X[self.idx, :].copy()       # compose.jl:77 -> plain vector of reals
+        return ColVecs(x.X[np.asarray(self.idx), :])
+
+
+class Periodic:
+    def __init__(self, f):
+        self.f = float(f)
+
+    def __call__(self, x):
+        t = (2.0 * np.pi * self.f) * np.asarray(x, dtype=np.float64)
+        return ColVecs(np.vstack([np.cos(t), np.sin(t)]))
+
+
+class Shift:
+    def __init__(self, a):
+        self.a = a
+
+    def __call__(self, x):
+        if isinstance(x, ColVecs):
+            a = np.asarray(self.a, dtype=np.float64)
+            return ColVecs(x.X - (a[:, None] if a.ndim == 1 else a))
+        return np.asarray(x, dtype=np.float64) - self.a
+
+
+def _warp(g, x):
+    """g.(x): the four structured warps broadcast over the collection, anything else maps."""
+    if isinstance(g, (Stretch, Select, Periodic, Shift)):
+        return g(x)
+    if isinstance(x, ColVecs):
+        vals = [g(x.X[:, i]) for i in range(len(x))]
+    else:
+        vals = [g(float(v)) for v in np.asarray(x)]
+    if np.ndim(vals[0]) == 0:
+        return np.array(vals, dtype=np.float64)
+    return ColVecs(np.stack(vals, axis=1))
+
+
+def compose(f, g):
+    return DerivedGP(("o", f, g), f.gpc)
+
+
+def stretch(f, l):
+    if np.ndim(l) == 1:
+        l = np.diag(np.asarray(l, dtype=np.float64))
+    return compose(f, Stretch(l))
+
+
+def select(f, idx):
+    return compose(f, Select(idx))
+
+
+def periodic(f, freq):
+    return compose(f, Periodic(freq))
+
+
+def shift(f, a):
+    return compose(f, Shift(a))
+
+
+def additive_gp(fs, indices=None):
+    """additive_gp.jl:10-29 (0-based indices here)."""
+    if indices is None:
+        indices = list(range(len(fs)))
+    proj = [compose(f, Select(idx)) for f, idx in zip(fs, indices)]
+    out = proj[0]
+    for p in proj[1:]:
+        out = out + p
+    return out
+
+
+def cross(fs):
+    """cross.jl:37-45."""
+    assert len(fs) >= 1 and all(f.gpc is fs[0].gpc for f in fs)
+    return DerivedGP(("cross", list(fs)), fs[0].gpc)
+
+
+def _sigma(s, x):
+    """sigma.(x) for a function scale (product.jl:25)."""
+    if isinstance(x, ColVecs):
+        return np.array([float(s(x.X[:, i])) for i in range(len(x))])
+    return np.array([float(s(float(v))) for v in np.asarray(x)])
+
+
+def _is_real(s):
+    return isinstance(s, (int, float, np.integer, np.floating))
+
+
+# ---- mean / cov / var of (op, args...) ---------------------------------------------------------
+def mean_args(args, x):
+    op = args[0]
+    if op == "+":
+        return args[1].mean(x) + args[2].mean(x)                              # addition.jl:26
+    if op == "+known":
+        b, f = args[1], args[2]
+        return (b if _is_real(b) else _sigma(b, x)) + f.mean(x)               # addition.jl:73-74
+    if op == "*":
+        s, g = args[1], args[2]
+        return (s if _is_real(s) else _sigma(s, x)) * g.mean(x)               # product.jl:25,54
+    if op == "o":
+        return args[1].mean(_warp(args[2], x))                                # compose.jl:16
+    if op == "cross":
+        return np.concatenate([f.mean(b) for f, b in zip(args[1], blocks(x))])  # cross.jl:54-57
+    raise ValueError(op)
+
+
+def cov_args(args, x, x2=None):
+    op = args[0]
+    if op == "+":
+        fa, fb = args[1], args[2]
+        y = x if x2 is None else x2                                           # addition.jl:28-37
+        return fa.cov(x, x2) + fb.cov(x, x2) + cov4(fa, fb, x, y) + cov4(fb, fa, x, y)
+    if op == "+known":
+        return args[2].cov(x, x2)                                             # addition.jl:76,79
+    if op == "*":
+        s, g = args[1], args[2]
+        if _is_real(s):
+            return (s ** 2) * g.cov(x, x2)                                    # product.jl:56,59
+        sx = _sigma(s, x)
+        sy = sx if x2 is None else _sigma(s, x2)
+        return sx[:, None] * g.cov(x, x2) * sy[None, :]                       # product.jl:27-36
+    if op == "o":
+        f, g = args[1], args[2]
+        return f.cov(_warp(g, x), None if x2 is None else _warp(g, x2))       # compose.jl:18,21
+    if op == "cross":
+        fs = args[1]
+        y = x if x2 is None else x2                                           # cross.jl:59-72
+        rows = [cov_args_right(f, args, blk, y) for f, blk in zip(fs, blocks(x))]
+        return np.vstack(rows)
+    raise ValueError(op)
+
+
+def var_args(args, x, x2=None):
+    op = args[0]
+    if op == "+":
+        fa, fb = args[1], args[2]
+        y = x if x2 is None else x2                                           # addition.jl:31-40
+        return fa.var(x, x2) + fb.var(x, x2) + var4(fa, fb, x, y) + var4(fb, fa, x, y)
+    if op == "+known":
+        return args[2].var(x, x2)
+    if op == "*":
+        s, g = args[1], args[2]
+        if _is_real(s):
+            return (s ** 2) * g.var(x, x2)                                    # product.jl:57,60
+        sx = _sigma(s, x)
+        sy = sx if x2 is None else _sigma(s, x2)
+        return sx * g.var(x, x2) * sy                                         # product.jl:32,38-40
+    if op == "o":
+        f, g = args[1], args[2]
+        return f.var(_warp(g, x), None if x2 is None else _warp(g, x2))       # compose.jl:19,22
+    if op == "cross":
+        fs = args[1]
+        if x2 is None:
+            return np.concatenate([f.var(b) for f, b in zip(fs, blocks(x))])  # cross.jl:64-67
+        return np.concatenate([f.var(b, b2) for f, b, b2 in zip(fs, blocks(x), blocks(x2))])
+    raise ValueError(op)
+
+
+def cov_args_left(args, f2, x, x2):
+    """cov(args, f', x, x')."""
+    op = args[0]
+    if op == "+":
+        return cov4(args[1], f2, x, x2) + cov4(args[2], f2, x, x2)            # addition.jl:42-44
+    if op == "+known":
+        return cov4(args[2], f2, x, x2)                                       # addition.jl:82
+    if op == "*":
+        s, f = args[1], args[2]
+        if _is_real(s):
+            return s * cov4(f, f2, x, x2)                                     # product.jl:62
+        return _sigma(s, x)[:, None] * cov4(f, f2, x, x2)                     # product.jl:42
+    if op == "o":
+        return cov4(args[1], f2, _warp(args[2], x), x2)                       # compose.jl:24
+    if op == "cross":
+        return np.vstack([cov4(f, f2, blk, x2) for f, blk in zip(args[1], blocks(x))])  # cross.jl:79-82
+    raise ValueError(op)
+
+
+def cov_args_right(f, args, x, x2):
+    """cov(f, args', x, x')."""
+    op = args[0]
+    if op == "+":
+        return cov4(f, args[1], x, x2) + cov4(f, args[2], x, x2)              # addition.jl:45-47
+    if op == "+known":
+        return cov4(f, args[2], x, x2)                                        # addition.jl:83
+    if op == "*":
+        s, f2 = args[1], args[2]
+        if _is_real(s):
+            return cov4(f, f2, x, x2) * s                                     # product.jl:63
+        return cov4(f, f2, x, x2) * _sigma(s, x2)[None, :]                    # product.jl:43
+    if op == "o":
+        return cov4(f, args[1], x, _warp(args[2], x2))                        # compose.jl:25
+    if op == "cross":
+        return np.hstack([cov4(f, f2, x, blk) for f2, blk in zip(args[1], blocks(x2))])  # cross.jl:83-86
+    raise ValueError(op)
+
+
+def var_args_left(args, f2, x, x2):
+    op = args[0]
+    if op == "+":
+        return var4(args[1], f2, x, x2) + var4(args[2], f2, x, x2)
+    if op == "+known":
+        return var4(args[2], f2, x, x2)
+    if op == "*":
+        s, f = args[1], args[2]
+        return (s if _is_real(s) else _sigma(s, x)) * var4(f, f2, x, x2)
+    if op == "o":
+        return var4(args[1], f2, _warp(args[2], x), x2)
+    if op == "cross":
+        return np.diag(cov_args_left(args, f2, x, x2))                        # cross.jl:88-90
+    raise ValueError(op)
+
+
+def var_args_right(f, args, x, x2):
+    op = args[0]
+    if op == "+":
+        return var4(f, args[1], x, x2) + var4(f, args[2], x, x2)
+    if op == "+known":
+        return var4(f, args[2], x, x2)
+    if op == "*":
+        s, f2 = args[1], args[2]
+        return var4(f, f2, x, x2) * (s if _is_real(s) else _sigma(s, x2))
+    if op == "o":
+        return var4(f, args[1], x, _warp(args[2], x2))
+    if op == "cross":
+        return np.diag(cov_args_right(f, args, x, x2))                        # cross.jl:91-93
+    raise ValueError(op)
+
+
+# ---- GPPP (gaussian_process_probabilistic_programme.jl) ----------------------------------------
+class GPPP:
+    """GPPP(fs::NamedTuple, gpc) -- gppp.jl:13-18."""
+
+    def __init__(self, fs, gpc):
+        self.fs, self.gpc = dict(fs), gpc
+
+    def __call__(self, x, noise=1e-18):
+        return agp.FiniteGP(self, x, noise)
+
+    def mean(self, x):
+        fs, vs = extract_components(self, x)
+        return fs.mean(vs)
+
+    def cov(self, x, x2=None):
+        fs, vs = extract_components(self, x)
+        if x2 is None:
+            return fs.cov(vs)                                                  # gppp.jl:50-53
+        fs2, vs2 = extract_components(self, x2)
+        return cov4(fs, fs2, vs, vs2)                                          # gppp.jl:60-64
+
+    def var(self, x, x2=None):
+        fs, vs = extract_components(self, x)
+        if x2 is None:
+            return fs.var(vs)
+        fs2, vs2 = extract_components(self, x2)
+        return var4(fs, fs2, vs, vs2)
+
+    def cov_cross(self, other, x, x2):
+        assert other is self
+        return self.cov(x, x2)
+
+
+def extract_components(f, x):
+    """gppp.jl:25-43."""
+    if isinstance(x, GPPPInput):
+        return f.fs[x.p], x.x
+    if isinstance(x, BlockData):
+        pairs = [extract_components(f, b) for b in x.X]
+        return cross([p[0] for p in pairs]), BlockData([p[1] for p in pairs])
+    # generic vector of (key, value) tuples: regroup by unique key (order of first appearance)
+    keys = [p for p, _ in x]
+    vals = [v for _, v in x]
+    uniq = []
+    for k in keys:
+        if k not in uniq:
+            uniq.append(k)
+    blks = []
+    for k in uniq:
+        sel = [v for kk, v in zip(keys, vals) if kk == k]
+        if np.ndim(sel[0]) == 0:
+            blks.append(GPPPInput(k, np.array(sel, dtype=np.float64)))
+        else:
+            blks.append(GPPPInput(k, ColVecs(np.stack(sel, axis=1))))
+    return extract_components(f, BlockData(blks))
+
+
+def split(x, Y):
+    """gppp.jl:121-135."""
+    Y = np.asarray(Y)
+    if len(x) != Y.shape[0]:
+        raise ValueError("Expected length(x) == size(Y, 1)")
+    out, o = [], 0
+    for b in x.X:
+        out.append(Y[o:o + len(b)])
+        o += len(b)
+    return out
+
+
+# ---- SparseFiniteGP (gp/sparse_finite_gp.jl:30-62) ---------------------------------------------
+class SparseFiniteGP:
+    def __init__(self, fobs, finducing):
+        self.fobs, self.finducing = fobs, finducing
+
+    def __len__(self):
+        return len(self.fobs)
+
+
+def sparse_logpdf(f, y):
+    return agp.elbo(agp.VFE(f.finducing), f.fobs, y)
+
+
+def sparse_posterior(f, y):
+    return agp.posterior_vfe(agp.VFE(f.finducing), f.fobs, y)

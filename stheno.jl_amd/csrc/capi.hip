@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -15,12 +16,14 @@ static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 
 void set_gemm_tn_workspace(double* ws, size_t bytes);
+void set_gemm_wave_layout(int wn);
 int run_mfma_bench(hipStream_t s, int iters, double* tflops_out, double* layout_maxerr_out);
 int run_hbm_bench(hipStream_t s, long bytes, int iters, double* write_gbs, double* copy_gbs);
 
 static inline long rup(long x, long m) { return (x + m - 1) / m * m; }
 constexpr long NOMASK = -(1L << 40);
-constexpr long WOUT = 512;  // outer panel width of the two-level blocked Cholesky
+constexpr long WOUT_SMALL = 512;   // outer panel width of the two-level blocked Cholesky
+constexpr long WOUT_LARGE = 1024;  // ... for n_pad >= 32768 (halves the C-tile traffic per flop)
 
 }  // namespace sgp
 
@@ -28,7 +31,11 @@ using namespace sgp;
 
 struct sgp_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;   // panel / critical-path stream (high priority)
+  hipStream_t stream2 = nullptr;  // trailing-update stream (look-ahead overlap)
+  hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
+  int lookahead = 1;
+  long wout = 0;  // 0 = automatic
   double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
   double* d_w = nullptr;       // 128 x 128 scratch inverse
   double* d_slots = nullptr;   // per-128-block logdet contributions
@@ -101,7 +108,18 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
   }
   sgp_ctx* c = new sgp_ctx();
   c->device = device;
-  SGP_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;
+    SGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    SGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    SGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+    SGP_HIP(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
+    SGP_HIP(hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming));
+    const char* la = getenv("SGP_LOOKAHEAD");
+    if (la) c->lookahead = atoi(la);
+    const char* wo = getenv("SGP_WOUT");
+    if (wo) c->wout = atol(wo) / TILE * TILE;
+  }
   SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
   SGP_HIP(hipMalloc(&c->d_w, sizeof(double) * TILE * TILE));
   c->n_slots = 1 << 15;
@@ -124,6 +142,10 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   hipFree(c->d_scal);
   hipFree(c->d_info);
   if (c->d_tn_ws) hipFree(c->d_tn_ws);
+  hipStreamSynchronize(c->stream2);
+  hipEventDestroy(c->ev_panel);
+  hipEventDestroy(c->ev_rest);
+  hipStreamDestroy(c->stream2);
   hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -316,33 +338,65 @@ static double update_flops(long m, long nc, long k) {
   return sq + below;
 }
 
+// timed (optional) trailing-update launch
+static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long M, long Nc, long K,
+                         hipStream_t s) {
+  if (M <= 0 || Nc <= 0) return 0;
+  if (ctx->time_updates) {
+    hipEvent_t e0, e1;
+    SGP_HIP(hipEventCreate(&e0));
+    SGP_HIP(hipEventCreate(&e1));
+    SGP_HIP(hipEventRecord(e0, s));
+    CHECK_RC(launch_gemm_nt(P, ld, P, ld, C, ld, M, Nc, K, -1.0, 1.0, 0, 0, 0, s));
+    SGP_HIP(hipEventRecord(e1, s));
+    ctx->ev.push_back(e0);
+    ctx->ev.push_back(e1);
+    ctx->ev_flops.push_back(update_flops(M, Nc, K));
+    return 0;
+  }
+  return launch_gemm_nt(P, ld, P, ld, C, ld, M, Nc, K, -1.0, 1.0, 0, 0, 0, s);
+}
+
+// Two-level right-looking Cholesky of the bordered matrix with one-panel look-ahead:
+// the outer panel J+1 is updated and factored on the (high-priority) panel stream while the
+// rest of the trailing matrix is still being updated with panel J on the update stream.
 static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
                          hipStream_t s) {
   CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
+  const long WOUT = ctx->wout > 0 ? ctx->wout : (n_pad >= 32768 ? WOUT_LARGE : WOUT_SMALL);
+  const bool la = ctx->lookahead && s == ctx->stream;
+  hipStream_t sB = la ? ctx->stream2 : s;
+  bool rest_pending = false;
+  if (la) {
+    // the update stream must see everything enqueued on s so far (assembly)
+    SGP_HIP(hipEventRecord(ctx->ev_panel, s));
+    SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
+  }
   for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
     long wj = std::min(WOUT, n_pad - J0);
     CHECK_RC(panel_factor(ctx, A + J0 + J0 * ld, ld, m_tot - J0, wj, J0, ctx->d_slots + J0 / TILE,
                           ctx->d_info, d_wall ? d_wall + (J0 / TILE) * (TILE * TILE) : nullptr, s));
     long c0 = J0 + wj;
-    if (c0 < n_pad) {
-      const double* P = A + c0 + J0 * ld;
-      if (ctx->time_updates) {
-        hipEvent_t e0, e1;
-        SGP_HIP(hipEventCreate(&e0));
-        SGP_HIP(hipEventCreate(&e1));
-        SGP_HIP(hipEventRecord(e0, s));
-        CHECK_RC(launch_gemm_nt(P, ld, P, ld, A + c0 + c0 * ld, ld, m_tot - c0, n_pad - c0, wj, -1.0,
-                                1.0, 0, 0, 0, s));
-        SGP_HIP(hipEventRecord(e1, s));
-        ctx->ev.push_back(e0);
-        ctx->ev.push_back(e1);
-        ctx->ev_flops.push_back(update_flops(m_tot - c0, n_pad - c0, wj));
-      } else {
-        CHECK_RC(launch_gemm_nt(P, ld, P, ld, A + c0 + c0 * ld, ld, m_tot - c0, n_pad - c0, wj, -1.0,
-                                1.0, 0, 0, 0, s));
+    if (c0 >= n_pad) break;
+    long w1 = std::min(WOUT, n_pad - c0);   // width of the next panel
+    long c1 = c0 + w1;
+    if (la) {
+      SGP_HIP(hipEventRecord(ctx->ev_panel, s));
+      // look-ahead: next panel's columns on the panel stream (after the previous rest update)
+      if (rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
+      CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_tot - c0, w1, wj, s));
+      if (c1 < n_pad) {
+        SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
+        CHECK_RC(launch_update(ctx, A + c1 + J0 * ld, ld, A + c1 + c1 * ld, m_tot - c1, n_pad - c1,
+                               wj, sB));
+        SGP_HIP(hipEventRecord(ctx->ev_rest, sB));
+        rest_pending = true;
       }
+    } else {
+      CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_tot - c0, n_pad - c0, wj, s));
     }
   }
+  if (la && rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
   return 0;
 }
 
@@ -1220,7 +1274,7 @@ extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int
   hipLaunchKernelGGL(fill_rand_kernel, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, s, A.p, m * k, 1234ULL);
   SGP_HIP(hipMemsetAsync(C.p, 0, sizeof(double) * m * n, s));
   // C = -A[0:m] A[0:n]'
-  CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, 0, 0, s));
+  CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, (lower_only & 1) ? 0 : NOMASK, 0, 0, s));
   SGP_HIP(hipStreamSynchronize(s));
   // spot check 64 entries in the lower part against a host dot product
   std::vector<double> hA((size_t)m * k);
@@ -1239,8 +1293,13 @@ extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int
   SGP_HIP(hipEventCreate(&e0));
   SGP_HIP(hipEventCreate(&e1));
   SGP_HIP(hipEventRecord(e0, s));
+  const int wn = (lower_only & 2) ? 2 : 4;  // bench-only: bit 1 selects the 4-wave layout
+  const int abl = lower_only & ~15;         // bench-only: bits 4.. select an ablation build
+  lower_only &= 1;
+  set_gemm_wave_layout(wn);
   for (int i = 0; i < iters; ++i)
-    CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, 0, 0, s));
+    CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, abl, 0, s));
+  set_gemm_wave_layout(4);
   SGP_HIP(hipEventRecord(e1, s));
   SGP_HIP(hipEventSynchronize(e1));
   float ms = 0;

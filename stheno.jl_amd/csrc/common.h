@@ -22,6 +22,12 @@ __device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// 4-block form: D_b(4x4) = A_b(4x4) B_b(4x4) + C_b for b = 0..3, one f64 per lane
+// (lane maps in gemm_nt.hip).  Issues every 16 cycles on gfx950 -- the full fp64 matrix rate.
+__device__ __forceinline__ double mfma44_f64(double a, double b, double c) {
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+
 // device-side description of one covariance term of one block pair
 struct DevTerm {
   int kind;

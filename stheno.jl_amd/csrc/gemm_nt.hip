@@ -1,4 +1,16 @@
-// fp64 MFMA GEMM kernels for gfx950 (v_mfma_f64_16x16x4_f64).
+// fp64 MFMA GEMM kernels for gfx950.
+//
+// Instruction choice (measured on MI355X, profiles/r01_microbench.md): v_mfma_f64_16x16x4_f64
+// issues only every ~96 cycles per SIMD (49 TF/s chip-wide, 62 % of the 78.6 TF/s datasheet
+// rate) while the 4-block v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (71 TF/s, 90 %).
+// The GEMM therefore runs on the 4x4x4 form.  Its lane maps (probed on hardware,
+// tools/gpu_probe44.py; b = (l >> 2) & 3 is the block):
+//   A-operand lane l holds A_b[i = l & 3][k = l >> 4]
+//   B-operand lane l holds B_b[k = l >> 4][j = l & 3]
+//   result    lane l holds D_b[i = l >> 4][j = l & 3]
+// Feeding every block the same A (4 columns of C) and block b rows 4b..4b+3 of a 16-row
+// fragment as B makes one instruction a 16(row) x 4(col) x 4(k) update whose result lanes run
+// along the contiguous row dimension of C (row = l & 15, col = l >> 4).
 //
 // gemm_nt:  C = beta*C + alpha * A * B'   A: M x K, B: Nc x K, C: M x Nc, column-major.
 //   This single kernel is the SYRK/GEMM trailing update of the blocked Cholesky
@@ -20,35 +32,52 @@ namespace sgp {
 
 constexpr int KB = 16;  // K chunk per LDS stage
 
-template <bool KCAP>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const double* A, long lda,
-                                                         const double* B, long ldb, double* C,
-                                                         long ldc, long K, double alpha,
-                                                         double beta, long mask_off, long kcap_off,
-                                                         int xcd_swizzle, long n_tr, long n_tc) {
+// Shared inner product of one LDS stage: NJ column fragments (4 cols each) x 4 row fragments
+// (16 rows each) per wave, K = 16 in four k-steps of 4.
+#define SGP_COMPUTE(buf_, NJ_, COL0_)                                            \
+  {                                                                              \
+    const double* pa = &sA[buf_][wr * 64 + l15];                                 \
+    const double* pb = &sB[buf_][(COL0_) + l3];                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                           \
+      const int kk = ks * 4 + lq;                                                \
+      double a_r[4], b_c[NJ_];                                                   \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) a_r[i] = pa[kk * LDS_LD + i * 16]; \
+      _Pragma("unroll") for (int j = 0; j < NJ_; ++j) b_c[j] = pb[kk * LDS_LD + j * 4]; \
+      _Pragma("unroll") for (int j = 0; j < NJ_; ++j)                            \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i)                          \
+              acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);                 \
+    }                                                                            \
+  }
+
+// WN = number of wave columns: 2 -> 4 waves (64x64 per wave), 4 -> 8 waves (64x32 per wave,
+// half the registers, 4 waves per SIMD at 2 workgroups per CU: more latency hiding).
+template <bool KCAP, int WN, int ABL = 0>
+__global__ __launch_bounds__(128 * WN, WN) void gemm_nt_kernel(const double* A, long lda,
+                                                               const double* B, long ldb,
+                                                               double* C, long ldc, long K,
+                                                               double alpha, double beta,
+                                                               long mask_off, long kcap_off,
+                                                               long n_tr, long n_tc) {
+  constexpr int NT = 128 * WN;        // threads
+  constexpr int NJ = (128 / WN) / 4;  // column fragments (4 cols each) per wave
+  constexpr int WCOLS = 128 / WN;     // columns per wave
+  constexpr int NU = 1024 / NT;       // double2 staging units per thread per operand
   long tr, tc;
   {
-    // XCD-aware remap: consecutive workgroup ids land on different XCDs (id % 8); give each
-    // XCD a contiguous run of tiles in column-major tile order so that tiles sharing a B
-    // row-panel (same tc) and neighbouring A panels hit the same L2.
-    long id = (long)blockIdx.x;
-    long total = n_tr * n_tc;
-    if (xcd_swizzle) {
-      long q = total / 8, r = total % 8;
-      long xcd = id % 8, k = id / 8;
-      long base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-      id = base + k;
-    }
-    // grouped order: 8 tile-rows x all tile-cols per group, row index fastest, so 64
-    // consecutive ids form an 8x8 patch sharing 8 A panels and 8 B panels (L2 reuse).
-    const long GM = 8;
-    long group_size = GM * n_tc;
-    long g = id / group_size;
-    long first_tr = g * GM;
-    long gm = n_tr - first_tr < GM ? n_tr - first_tr : GM;
-    long rem = id % group_size;
-    tr = first_tr + rem % gm;
-    tc = rem / gm;
+    // XCD-aware, load-balanced tile order.  Hardware places workgroup id on XCD id % 8.
+    // XCD x owns the tile rows tr == x (mod 8): every A row-panel is read through exactly one
+    // XCD's L2, and at any position in the grid all 8 XCDs see (almost) the same lower-
+    // triangular mask, so the live work stays balanced however the dispatcher paces XCDs.
+    // Inside an XCD the order is 8 owned rows x 8 tile columns, row fastest: 64 consecutive
+    // workgroups form a patch sharing 8 A panels and 8 B panels in that XCD's L2.
+    const long id = (long)blockIdx.x;
+    const long xcd = id & 7, k = id >> 3;
+    const long gs = 8 * n_tc;
+    const long jgroup = k / gs, within = k % gs;
+    const long j = jgroup * 8 + (within & 7);
+    tr = 8 * j + xcd;
+    tc = within >> 3;
+    if (tr >= n_tr) return;
   }
   if (tr < tc + mask_off) return;
   long Keff = K;
@@ -64,48 +93,51 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const double* A, long l
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w = t >> 6;
-  const int wr = w >> 1, wc = w & 1;
-  const int l15 = lane & 15, lq = lane >> 4;
+  const int wr = w / WN, wc = w % WN;
+  const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
 
   const double* Ag = A + tr * TILE;
   const double* Bg = B + tc * TILE;
 
-  // staging map: unit i of thread t -> column (t>>6)+4i of the chunk, rows 2*(t&63), +1
+  // staging map: unit i of thread t -> column (t>>6) + (NT/64) i of the chunk, rows 2*(t&63), +1
   const int scol = t >> 6;
   const int srow = 2 * (t & 63);
-  double2 ra[4], rb[4];
+  double2 ra[NU], rb[NU];
 
-  d4 acc[4][4];
+  // acc[j][i] = C[row = r0 + 16 i + l15][col = c0 + 4 j + lq].  The accumulators are seeded
+  // with (beta / alpha) * C so that the old tile is read in the prologue (its latency hides
+  // behind the first operand loads and the co-resident workgroup's MFMAs) and the epilogue is
+  // store-only: C_new = alpha * (A B' + (beta / alpha) C).
+  double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * WCOLS + lq) * ldc;
+  double acc[NJ][4];
+  if (beta != 0.0) {
+    const double seed = beta / alpha;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int i = 0; i < 4; ++i) acc[j][i] = Cg[i * 16 + (long)(j * 4) * ldc];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] *= seed;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = 0.0;
+  }
 
 #define SGP_GLOAD(k0_)                                                           \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
-    long col = (k0_) + scol + 4 * i;                                             \
+  _Pragma("unroll") for (int i = 0; i < NU; ++i) {                               \
+    long col = (k0_) + scol + (NT / 64) * i;                                     \
     ra[i] = *reinterpret_cast<const double2*>(Ag + srow + col * lda);            \
     rb[i] = *reinterpret_cast<const double2*>(Bg + srow + col * ldb);            \
   }
 #define SGP_SSTORE(buf_)                                                         \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
-    int col = scol + 4 * i;                                                      \
+  _Pragma("unroll") for (int i = 0; i < NU; ++i) {                               \
+    int col = scol + (NT / 64) * i;                                              \
     *reinterpret_cast<double2*>(&sA[buf_][col * LDS_LD + srow]) = ra[i];         \
     *reinterpret_cast<double2*>(&sB[buf_][col * LDS_LD + srow]) = rb[i];         \
-  }
-#define SGP_COMPUTE(buf_)                                                        \
-  {                                                                              \
-    const double* pa = &sA[buf_][wr * 64 + l15];                                 \
-    const double* pb = &sB[buf_][wc * 64 + l15];                                 \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                           \
-      const int kk = ks * 4 + lq;                                                \
-      double a_r[4], b_c[4];                                                     \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) a_r[i] = pa[kk * LDS_LD + i * 16]; \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j) b_c[j] = pb[kk * LDS_LD + j * 16]; \
-      _Pragma("unroll") for (int j = 0; j < 4; ++j)                              \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i)                          \
-              acc[j][i] = mfma_f64(b_c[j], a_r[i], acc[j][i]);                   \
-    }                                                                            \
   }
 
   if (Keff > 0) {
@@ -113,39 +145,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const double* A, long l
     SGP_SSTORE(0);
     __syncthreads();
     int buf = 0;
+    // ABL != 0 only in the bench-only ablation builds (tools/gpu_gemm_abl.py): 1 = no global
+    // loads / LDS stores, 2 = no LDS operand reads, 3 = no barrier, 4 = 1+2 (MFMA + barrier only)
+    double inv_a[4], inv_b[NJ];
+    if (ABL == 2 || ABL == 4) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) inv_a[i] = sA[0][wr * 64 + l15 + i * 16];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) inv_b[j] = sB[0][wc * WCOLS + l3 + j * 4];
+    }
     for (long k0 = KB; k0 < Keff; k0 += KB) {
-      SGP_GLOAD(k0);
-      SGP_COMPUTE(buf);
-      SGP_SSTORE(buf ^ 1);
-      __syncthreads();
+      if (ABL != 1 && ABL != 4) { SGP_GLOAD(k0); }
+      if (ABL == 2 || ABL == 4) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(inv_b[j], inv_a[i], acc[j][i]);
+      } else {
+        SGP_COMPUTE(buf, NJ, wc * WCOLS);
+      }
+      if (ABL != 1 && ABL != 4) { SGP_SSTORE(buf ^ 1); }
+      if (ABL != 3) __syncthreads();
       buf ^= 1;
     }
-    SGP_COMPUTE(buf);
+    SGP_COMPUTE(buf, NJ, wc * WCOLS);
   }
+#undef SGP_GLOAD
+#undef SGP_SSTORE
 
-  // epilogue: lane holds C[row = r0 + i*16 + l15][col = c0 + j*16 + lq + 4*reg]
-  double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * 64 + lq) * ldc;
-  if (beta == 0.0) {
+  // epilogue (store only): every store instruction writes 4 columns x 16 consecutive rows
+  // (4 x 128-byte runs).
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Cg[i * 16 + (long)(j * 16 + 4 * r) * ldc] = alpha * acc[j][i][r];
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        double cv[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cv[r] = Cg[i * 16 + (long)(j * 16 + 4 * r) * ldc];
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          Cg[i * 16 + (long)(j * 16 + 4 * r) * ldc] = beta * cv[r] + alpha * acc[j][i][r];
-      }
-  }
+    for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = alpha * acc[j][i];
 }
+
+static int g_gemm_wn = 4;  // default wave layout; sgp_bench_gemm flips it for A/B comparisons
+void set_gemm_wave_layout(int wn) { g_gemm_wn = (wn == 2) ? 2 : 4; }
 
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                    long M, long Nc, long K, double alpha, double beta, long mask_off,
@@ -156,15 +195,30 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
     return -1;
   }
   long n_tr = M / TILE, n_tc = Nc / TILE;
-  long total = n_tr * n_tc;
-  int swz = total >= 64 ? 1 : 0;
-  dim3 grid((unsigned)total), block(256);
-  if (kcap_mode)
-    hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha,
-                       beta, mask_off, kcap_off, swz, n_tr, n_tc);
-  else
-    hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha,
-                       beta, mask_off, kcap_off, swz, n_tr, n_tc);
+  long groups = (n_tr + 7) / 8;
+  long groups_pad = (groups + 7) / 8 * 8;
+  long total = groups_pad * 8 * n_tc;
+  dim3 grid((unsigned)total);
+#define SGP_LAUNCH(KC, WNV)                                                                       \
+  hipLaunchKernelGGL((gemm_nt_kernel<KC, WNV>), grid, dim3(128 * WNV), 0, s, A, lda, B, ldb, C, ldc, \
+                     K, alpha, beta, mask_off, kcap_off, n_tr, n_tc)
+  if (kcap_mode >= 16) {  // bench-only ablations of the 8-wave kernel
+#define SGP_LAUNCH_ABL(AB)                                                                        \
+  hipLaunchKernelGGL((gemm_nt_kernel<false, 4, AB>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, \
+                     alpha, beta, mask_off, kcap_off, n_tr, n_tc)
+    switch (kcap_mode >> 4) {
+      case 1: SGP_LAUNCH_ABL(1); break;
+      case 2: SGP_LAUNCH_ABL(2); break;
+      case 3: SGP_LAUNCH_ABL(3); break;
+      default: SGP_LAUNCH_ABL(4); break;
+    }
+#undef SGP_LAUNCH_ABL
+  } else if (g_gemm_wn == 2) {
+    if (kcap_mode) SGP_LAUNCH(true, 2); else SGP_LAUNCH(false, 2);
+  } else {
+    if (kcap_mode) SGP_LAUNCH(true, 4); else SGP_LAUNCH(false, 4);
+  }
+#undef SGP_LAUNCH
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -193,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const double* A, long l
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int wr = w >> 1, wc = w & 1;
-  const int l15 = lane & 15, lq = lane >> 4;
+  const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
   const long kbeg = ksplit * k_per_split;
   long kend = kbeg + k_per_split;
   if (kend > K) kend = K;
@@ -204,11 +258,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const double* A, long l
   const double* Ag = A + (tr * TILE + sc) * lda;
   const double* Bg = B + (tc * TILE + sc) * ldb;
   double2 ra[4], rb[4];
-  d4 acc[4][4];
+  double acc[16][4];  // acc[j][i] = C[row = r0 + 16 i + l15][col = c0 + 4 j + lq]
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 16; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < 4; ++i) acc[j][i] = 0.0;
 
 #define SGP_TN_GLOAD(k0_)                                                        \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
@@ -231,36 +285,32 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const double* A, long l
     int buf = 0;
     for (long k0 = kbeg + KB; k0 < kend; k0 += KB) {
       SGP_TN_GLOAD(k0);
-      SGP_COMPUTE(buf);
+      SGP_COMPUTE(buf, 16, wc * 64);
       SGP_TN_SSTORE(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
-    SGP_COMPUTE(buf);
+    SGP_COMPUTE(buf, 16, wc * 64);
   }
   if (Cpart) {
     // split-K: write the partial tile; a second kernel reduces in fixed order (deterministic)
     double* P = Cpart + ksplit * part_stride + (tr * TILE + wr * 64 + l15) +
                 (tc * TILE + wc * 64 + lq) * ldc;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 16; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) P[i * 16 + (long)(j * 16 + 4 * r) * ldc] = acc[j][i][r];
+      for (int i = 0; i < 4; ++i) P[i * 16 + (long)(j * 4) * ldc] = acc[j][i];
     return;
   }
   double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * 64 + lq) * ldc;
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 16; ++j)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double* p = Cg + i * 16 + (long)(j * 16 + 4 * r) * ldc;
-        double old = (beta == 0.0) ? 0.0 : beta * (*p);
-        *p = old + alpha * acc[j][i][r];
-      }
+    for (int i = 0; i < 4; ++i) {
+      double* p = Cg + i * 16 + (long)(j * 4) * ldc;
+      double old = (beta == 0.0) ? 0.0 : beta * (*p);
+      *p = old + alpha * acc[j][i];
+    }
 }
 
 __global__ void splitk_reduce_kernel(const double* part, long part_stride, int nsplit, double* C,

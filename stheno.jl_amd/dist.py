@@ -1,0 +1,227 @@
+"""Multi-GPU logpdf: one process per GPU, the N x N covariance sharded in column panels
+(block-cyclic, width W) across ranks, right-looking Cholesky with one-panel look-ahead;
+panels travel between ranks with torch.distributed broadcast (backend "nccl" == RCCL over xGMI
+on the MI355X node; "gloo" in the CPU tests), scalars (logdet, |L^-1 (y - m)|^2, info) with one
+all-reduce at the end.  SURVEY.md 8e / DESIGN.md section 6.
+
+The reference has no distributed path at all: this is the MI355X-side
+scaling of `logpdf(f(X, s2), y)` (AbstractGPs.logpdf [EXT], Appendix A.3).
+
+All numerics are the C-ABI building blocks of include/sthenomi.h (sgp_dev_assemble_cols,
+sgp_dev_panel_factor, sgp_dev_panel_update, sgp_dev_rowsumsq) driven through an `ops` object;
+`HipOps` is the product implementation.  The orchestration below is backend-agnostic so that
+the CPU test-suite can drive it with a NumPy test double over gloo (tests/test_dist_gloo.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import lib as _lib
+
+LOG2PI = math.log(2.0 * math.pi)
+TILE = 128
+
+
+def geometry(N, ncols):
+    n_pad = max(TILE, (N + TILE - 1) // TILE * TILE)
+    m_tot = n_pad + ((ncols + TILE - 1) // TILE * TILE if ncols > 0 else 0)
+    return n_pad, m_tot
+
+
+class PanelLayout:
+    """Block-cyclic ownership of the column panels of the bordered matrix."""
+
+    def __init__(self, n_pad, W, world, rank):
+        assert W % TILE == 0
+        self.n_pad, self.W, self.world, self.rank = n_pad, W, world, rank
+        self.n_panels = (n_pad + W - 1) // W
+        self.mine = [J for J in range(self.n_panels) if J % world == rank]
+
+    def owner(self, J):
+        return J % self.world
+
+    def col0(self, J):
+        return J * self.W
+
+    def width(self, J):
+        return min(self.W, self.n_pad - J * self.W)
+
+    def local_index(self, J):
+        return J // self.world
+
+    def n_local_cols(self):
+        return len(self.mine) * self.W
+
+
+class HipOps:
+    """Product backend: torch CUDA tensors for HBM, libsthenomi.so for every kernel."""
+
+    def __init__(self, ctx=None):
+        import torch
+        self.torch = torch
+        self.ctx = ctx or _lib.default_context()
+        self.lib = self.ctx.lib
+        self.device = torch.device("cuda", self.ctx.device)
+
+    # -- memory ---------------------------------------------------------------------------
+    def empty(self, n):
+        return self.torch.empty(n, dtype=self.torch.float64, device=self.device)
+
+    def zeros(self, n):
+        return self.torch.zeros(n, dtype=self.torch.float64, device=self.device)
+
+    def from_host(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    def izeros(self, n):
+        return self.torch.zeros(n, dtype=self.torch.int32, device=self.device)
+
+    def stream(self):
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def to_host(self, t):
+        return t.cpu().numpy()
+
+    # -- model ----------------------------------------------------------------------------
+    def make_dspec(self, spec):
+        h = C.c_void_p()
+        _lib.check(self.lib.sgp_dspec_create(self.ctx.handle, spec.ref(), C.byref(h)), "sgp_dspec_create")
+        return h
+
+    def free_dspec(self, h):
+        self.lib.sgp_dspec_destroy(h)
+
+    # -- kernels --------------------------------------------------------------------------
+    def assemble_cols(self, ds, N, c0, nc, A, col_off, m_tot, mean, sigma2, Y, ncols):
+        nz = np.array([sigma2], dtype=np.float64)
+        rc = self.lib.sgp_dev_assemble_cols(self.ctx.handle, ds, N, c0, nc, A.data_ptr() + 8 * col_off * m_tot,
+                                            m_tot, m_tot, mean.data_ptr() if mean is not None else None,
+                                            _lib.NOISE_SCALAR, _lib.dptr(nz), None,
+                                            Y.data_ptr() if Y is not None else None, N, ncols, self.stream())
+        _lib.check(rc, "sgp_dev_assemble_cols")
+
+    def panel_factor(self, A, col_off, m_tot, J0, w, logdet, info):
+        ptr = A.data_ptr() + 8 * (col_off * m_tot + J0)
+        rc = self.lib.sgp_dev_panel_factor(self.ctx.handle, ptr, m_tot, m_tot - J0, w, J0, logdet.data_ptr(),
+                                           info.data_ptr(), self.stream())
+        _lib.check(rc, "sgp_dev_panel_factor")
+
+    def pack_panel(self, A, col_off, m_tot, J0, w, buf):
+        """buf[(m_tot - J0) x w contiguous] <- A[J0:, panel cols]"""
+        t = self.torch
+        src = t.as_strided(A, (w, m_tot - J0), (m_tot, 1), col_off * m_tot + J0)
+        dst = buf[: w * (m_tot - J0)].view(w, m_tot - J0)
+        dst.copy_(src)
+
+    def panel_update(self, buf, J0, w, A, col_off, m_tot, c0, nc):
+        rc = self.lib.sgp_dev_panel_update(self.ctx.handle, buf.data_ptr(), m_tot - J0, J0, w,
+                                           A.data_ptr() + 8 * col_off * m_tot, m_tot, c0, nc, m_tot, self.stream())
+        _lib.check(rc, "sgp_dev_panel_update")
+
+    def rowsumsq(self, A, col_off, m_tot, n_pad, nc, nrows, out):
+        rc = self.lib.sgp_dev_rowsumsq(self.ctx.handle, A.data_ptr() + 8 * (col_off * m_tot + n_pad), m_tot, nc,
+                                       nrows, out.data_ptr(), self.stream())
+        _lib.check(rc, "sgp_dev_rowsumsq")
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+def dist_logpdf(ops, spec, y, mean, sigma2, world=1, rank=0, group=None, W=1024, A=None, stats=None):
+    """logpdf(f(X, sigma2), y) with the covariance sharded over `world` ranks.
+
+    spec : lib.Spec (symmetric) of the prior covariance, identical on every rank
+    y    : (N,) observations, mean: (N,) prior mean or None
+    A    : optional preallocated local panel storage (m_tot * n_local_cols doubles)
+    Every rank returns the same float.  Raises lib.PosDefException like the single-GPU path."""
+    import torch
+    import torch.distributed as dist
+
+    N = spec.N
+    n_pad, m_tot = geometry(N, 1)
+    W = min(W, n_pad)
+    lay = PanelLayout(n_pad, W, world, rank)
+    ds = ops.make_dspec(spec)
+    try:
+        if A is None:
+            A = ops.empty(max(1, m_tot * lay.n_local_cols()))
+        dY = ops.from_host(np.asarray(y, dtype=np.float64))
+        dmean = ops.from_host(mean) if mean is not None else None
+        logdet = ops.zeros(1)
+        sq = ops.zeros(1)
+        info = ops.izeros(1)
+        bufs = [ops.empty(m_tot * W), ops.empty(m_tot * W)]
+
+        # 1. every rank assembles its own column panels (no communication)
+        for J in lay.mine:
+            ops.assemble_cols(ds, N, lay.col0(J), lay.width(J), A, lay.local_index(J) * W, m_tot, dmean, sigma2,
+                              dY, 1)
+
+        def bcast(J):
+            J0, w = lay.col0(J), lay.width(J)
+            buf = bufs[J % 2]
+            if world == 1:
+                return None
+            t = buf[: w * (m_tot - J0)]
+            return dist.broadcast(t, src=_global_rank(group, lay.owner(J)), group=group, async_op=True)
+
+        def factor_and_pack(J):
+            J0, w = lay.col0(J), lay.width(J)
+            ops.panel_factor(A, lay.local_index(J) * W, m_tot, J0, w, logdet, info)
+            ops.pack_panel(A, lay.local_index(J) * W, m_tot, J0, w, bufs[J % 2])
+
+        def update(J, Jp):
+            """local panel Jp (> J) -= P_J[rows] P_J[cols Jp]'"""
+            ops.panel_update(bufs[J % 2], lay.col0(J), lay.width(J), A, lay.local_index(Jp) * W, m_tot,
+                             lay.col0(Jp), lay.width(Jp))
+
+        # 2. right-looking factorisation with one-panel look-ahead
+        if lay.owner(0) == rank:
+            factor_and_pack(0)
+        work = bcast(0)
+        if work is not None:
+            work.wait()
+        for J in range(lay.n_panels):
+            nxt = J + 1
+            if nxt < lay.n_panels and lay.owner(nxt) == rank:
+                update(J, nxt)          # look-ahead: bring the next panel up to date first,
+                factor_and_pack(nxt)    # factor it and get its broadcast going
+            work = bcast(nxt) if nxt < lay.n_panels else None
+            for Jp in lay.mine:         # the rest of this rank's trailing panels
+                if Jp > nxt:
+                    update(J, Jp)
+            if work is not None:
+                work.wait()
+
+        # 3. scalars: |L^-1 (y - m)|^2 from the bordered row, logdet, info
+        for J in lay.mine:
+            nc = min(lay.width(J), max(0, N - lay.col0(J)))
+            if nc > 0:
+                ops.rowsumsq(A, lay.local_index(J) * W, m_tot, n_pad, nc, 1, sq)
+        red = torch.stack([logdet.reshape(()), sq.reshape(())])
+        inf = info.to(torch.float64)
+        big = float(2 ** 52)
+        inf = torch.where(inf > 0, inf, torch.full_like(inf, big))
+        if world > 1:
+            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
+            dist.all_reduce(inf, op=dist.ReduceOp.MIN, group=group)
+        red_h = ops.to_host(red)
+        inf_h = float(ops.to_host(inf)[0])
+        if stats is not None:
+            stats.update(n_pad=n_pad, m_tot=m_tot, W=W, n_panels=lay.n_panels, local_panels=len(lay.mine),
+                         logdet=float(red_h[0]), sqmahal=float(red_h[1]))
+        if inf_h < big:
+            raise _lib.PosDefException(int(inf_h), "distributed Cholesky")
+        return -0.5 * (N * LOG2PI + float(red_h[0]) + float(red_h[1]))
+    finally:
+        ops.free_dspec(ds)
+
+
+def _global_rank(group, r):
+    import torch.distributed as dist
+    if group is None:
+        return r
+    return dist.get_global_rank(group, r)

@@ -1,0 +1,394 @@
+"""FiniteGP operator surface: f(x, s2), logpdf, rand, posterior, marginals, mean/cov/var,
+VFE / elbo, SparseFiniteGP -- the AbstractGPs.jl API Stheno inherits and
+src/gp/sparse_finite_gp.jl:30-62, routed through the C-ABI (include/sthenomi.h).
+
+Every number comes out of libsthenomi.so (HIP, gfx950).  The host only flattens the model
+(flatten.py), evaluates prior means (O(N)) and draws Z for `rand` from the caller's RNG.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .flatten import build_spec, zero_spec
+from .gp import SthenoAbstractGP, mean_vector
+from .gppp import GPPP
+from .inputs import BlockData
+
+
+def _ctx():
+    return _lib.default_context()
+
+
+def _f64(a, order="F"):
+    return np.require(np.asarray(a, dtype=np.float64), requirements=["F" if order == "F" else "C", "A"])
+
+
+class FiniteGP:
+    """f(x, Sigma_y): Sigma_y real -> s2*I, vector -> Diagonal, matrix -> dense; default 1e-18."""
+
+    def __init__(self, f, x, noise=1e-18):
+        self.f, self.x, self.noise = f, x, noise
+
+    def __len__(self):
+        return len(self.x)
+
+
+# ---- a prior-like object is anything below; dispatch by type ---------------------------------
+def _is_prior(f):
+    return isinstance(f, (GPPP, SthenoAbstractGP))
+
+
+def _prior_spec(f, x, x2=None):
+    spec, _, _ = build_spec(f, x, None, x2)
+    return spec
+
+
+def _kernelmatrix(spec):
+    K = np.zeros((spec.N, spec.M), order="F")
+    if spec.N and spec.M:
+        _lib.check(_ctx().lib.sgp_kernelmatrix(_ctx().handle, spec.ref(), _lib.dptr(K), spec.N), "sgp_kernelmatrix")
+    return K
+
+
+def _kernelmatrix_diag(spec):
+    out = np.zeros(spec.N)
+    if spec.N:
+        _lib.check(_ctx().lib.sgp_kernelmatrix_diag(_ctx().handle, spec.ref(), _lib.dptr(out)), "sgp_kernelmatrix_diag")
+    return out
+
+
+def _noise_dense(noise, n):
+    a = np.asarray(noise, dtype=np.float64)
+    if a.ndim == 0:
+        return float(a) * np.eye(n)
+    if a.ndim == 1:
+        return np.diag(a)
+    return a
+
+
+def _noise_diag(noise, n):
+    a = np.asarray(noise, dtype=np.float64)
+    if a.ndim == 0:
+        return np.full(n, float(a))
+    if a.ndim == 1:
+        return a
+    return np.diag(a).copy()
+
+
+# ---- statistics of the underlying process ------------------------------------------------------
+def prior_mean(f, x):
+    if _is_prior(f):
+        return mean_vector(f, x)
+    return f.mean(x)
+
+
+def prior_cov(f, x, x2=None):
+    if _is_prior(f):
+        return _kernelmatrix(_prior_spec(f, x, x2))
+    return f.cov(x, x2)
+
+
+def prior_var(f, x):
+    if _is_prior(f):
+        return _kernelmatrix_diag(_prior_spec(f, x))
+    return f.var(x)
+
+
+def mean(fx):
+    return prior_mean(fx.f, fx.x)
+
+
+def cov(fx, gx=None):
+    if gx is None:
+        return prior_cov(fx.f, fx.x) + _noise_dense(fx.noise, len(fx))
+    # src/gp/util.jl:12-14: cov(fx, gx) = cov(fx.f, gx.f, fx.x, gx.x) -- no noise
+    if _is_prior(fx.f) and _is_prior(gx.f):
+        spec, _, _ = build_spec(fx.f, fx.x, gx.f, gx.x)
+        return _kernelmatrix(spec)
+    raise TypeError("cov(fx, gx) needs two FiniteGPs of one Stheno model")
+
+
+def var(fx):
+    return prior_var(fx.f, fx.x) + _noise_diag(fx.noise, len(fx))
+
+
+def mean_and_cov(fx):
+    return mean(fx), cov(fx)
+
+
+def mean_and_var(fx):
+    if isinstance(fx.f, (PosteriorGP, ApproxPosteriorGP)):
+        m, v = fx.f.mean_and_var(fx.x)
+        return m, v + _noise_diag(fx.noise, len(fx))
+    return mean(fx), var(fx)
+
+
+class Normal:
+    def __init__(self, mu, sigma):
+        self.mu, self.sigma = mu, sigma
+
+    def __eq__(self, other):
+        return self.mu == other.mu and self.sigma == other.sigma
+
+
+def marginals(fx):
+    """Vector of Normal(mean_i, sqrt(var_i)) (test/gp/util.jl:15-20)."""
+    if isinstance(fx, SparseFiniteGP):
+        return marginals(fx.fobs)
+    m, v = mean_and_var(fx)
+    return [Normal(a, b) for a, b in zip(m, np.sqrt(v))]
+
+
+# ---- logpdf / rand ---------------------------------------------------------------------------
+def _spec_mean_noise(fx):
+    """(spec, mean, noise_kind, noise_buf) for the C-ABI; explicit-covariance processes
+    (posteriors) enter as a zero-term spec + dense noise = their covariance."""
+    n = len(fx)
+    if _is_prior(fx.f):
+        spec = _prior_spec(fx.f, fx.x)
+        kind, buf = _lib._noise_args(fx.noise, n)
+        return spec, mean_vector(fx.f, fx.x), kind, buf
+    Cm = fx.f.cov(fx.x) + _noise_dense(fx.noise, n)
+    return zero_spec(n), fx.f.mean(fx.x), _lib.NOISE_DENSE, np.asfortranarray(Cm)
+
+
+def logpdf(fx, y):
+    """logpdf(fx, y::Vector) -> float;  logpdf(fx, Y::Matrix) -> one value per column."""
+    if isinstance(fx, SparseFiniteGP):
+        Y = np.asarray(y, dtype=np.float64)
+        if Y.ndim == 2:
+            return np.array([elbo(VFE(fx.finducing), fx.fobs, Y[:, j]) for j in range(Y.shape[1])])
+        return elbo(VFE(fx.finducing), fx.fobs, Y)
+    Y = np.asarray(y, dtype=np.float64)
+    vec = Y.ndim == 1
+    Y = _f64(Y.reshape(len(fx), -1))
+    if Y.shape[0] != len(fx):
+        raise ValueError("length(y) != length(fx)")
+    spec, m, kind, nbuf = _spec_mean_noise(fx)
+    m = _f64(m)
+    out = np.zeros(Y.shape[1])
+    rc = _ctx().lib.sgp_logpdf(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(Y),
+                               Y.shape[0], Y.shape[1], _lib.dptr(out))
+    _lib.check(rc, "sgp_logpdf")
+    return float(out[0]) if vec else out
+
+
+def _draw(rng, n, s):
+    """Z = randn(rng, n, s) in Julia's column-major fill order, from the caller's RNG."""
+    if hasattr(rng, "standard_normal"):
+        z = rng.standard_normal(n * s)
+    else:
+        z = rng.randn(n * s)
+    return np.asfortranarray(np.asarray(z, dtype=np.float64).reshape((n, s), order="F"))
+
+
+def rand(rng, fx, S=None, Z=None):
+    """rand(rng, fx) -> vector; rand(rng, fx, S) -> N x S.  m .+ L Z with Z from `rng`
+    (pass Z explicitly to reuse a caller-side draw)."""
+    if isinstance(fx, SparseFiniteGP):
+        return rand(rng, fx.fobs, S, Z)     # sparse_finite_gp.jl:47-50: samples from the dense fobs
+    n = len(fx)
+    s = 1 if S is None else int(S)
+    if Z is None:
+        Z = _draw(rng, n, s)
+    Z = _f64(np.asarray(Z, dtype=np.float64).reshape(n, s))
+    spec, m, kind, nbuf = _spec_mean_noise(fx)
+    m = _f64(m)
+    out = np.zeros((n, s), order="F")
+    rc = _ctx().lib.sgp_rand(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(Z), n, s,
+                             _lib.dptr(out), n)
+    _lib.check(rc, "sgp_rand")
+    return out[:, 0].copy() if S is None else out
+
+
+# ---- exact posterior ---------------------------------------------------------------------------
+class PosteriorGP:
+    """posterior(fx, y): keeps L and L^-1 (y - m) in HBM (sgp_post); data = (alpha, x, delta)."""
+
+    def __init__(self, prior, x, handle, alpha, delta):
+        self.prior, self.x, self._h, self.alpha, self.delta = prior, x, handle, alpha, delta
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self._h:
+                _lib.load().sgp_posterior_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def __call__(self, xs, noise=1e-18):
+        return FiniteGP(self, xs, noise)
+
+    def _predict(self, xs, want_mean, want_var, want_cov):
+        cross, _, _ = build_spec(self.prior, xs, self.prior, self.x)
+        pss = _prior_spec(self.prior, xs) if (want_var or want_cov) else None
+        ns = cross.N
+        ms = _f64(mean_vector(self.prior, xs))
+        mo = np.zeros(ns) if want_mean else None
+        vo = np.zeros(ns) if want_var else None
+        co = np.zeros((ns, ns), order="F") if want_cov else None
+        rc = _ctx().lib.sgp_posterior_predict(self._h, cross.ref(), pss.ref() if pss is not None else None,
+                                              _lib.dptr(ms), _lib.dptr(mo), _lib.dptr(vo), _lib.dptr(co), max(ns, 1))
+        _lib.check(rc, "sgp_posterior_predict")
+        return mo, vo, co
+
+    def mean(self, xs):
+        return self._predict(xs, True, False, False)[0]
+
+    def var(self, xs):
+        return self._predict(xs, False, True, False)[1]
+
+    def cov(self, xs, zs=None):
+        if zs is None:
+            return self._predict(xs, False, False, True)[2]
+        # cov(post, x*, z*) = K(x*, z*) - V_x*' V_z*: the off-diagonal block of the joint covariance
+        joint = self._predict(BlockData([xs, zs]) if not isinstance(xs, BlockData) else _concat(xs, zs),
+                              False, False, True)[2]
+        nx = len(xs)
+        return joint[:nx, nx:]
+
+    def mean_and_var(self, xs):
+        m, v, _ = self._predict(xs, True, True, False)
+        return m, v
+
+    def mean_and_cov(self, xs):
+        m, _, c = self._predict(xs, True, False, True)
+        return m, c
+
+
+def _concat(xs, zs):
+    zb = zs.X if isinstance(zs, BlockData) else [zs]
+    return BlockData(list(xs.X) + list(zb))
+
+
+def posterior(fx, y):
+    if isinstance(fx, SparseFiniteGP):
+        return posterior_vfe(VFE(fx.finducing), fx.fobs, y)
+    if not _is_prior(fx.f):
+        raise NotImplementedError("posterior of a posterior: condition the prior on the stacked data instead")
+    y = _f64(np.asarray(y, dtype=np.float64).ravel())
+    n = len(fx)
+    if y.shape[0] != n:
+        raise ValueError("length(y) != length(fx)")
+    spec = _prior_spec(fx.f, fx.x)
+    m = _f64(mean_vector(fx.f, fx.x))
+    kind, nbuf = _lib._noise_args(fx.noise, n)
+    alpha = np.zeros(n)
+    h = C.c_void_p()
+    rc = _ctx().lib.sgp_posterior_create(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(y),
+                                         _lib.dptr(alpha), C.byref(h))
+    _lib.check(rc, "sgp_posterior_create")
+    return PosteriorGP(fx.f, fx.x, h, alpha, y - m)
+
+
+# ---- VFE / sparse --------------------------------------------------------------------------------
+class VFE:
+    def __init__(self, fz):
+        self.fz = fz
+
+
+class SparseFiniteGP:
+    """SparseFiniteGP(fobs, finducing): logpdf == elbo, posterior == VFE posterior."""
+
+    def __init__(self, fobs, finducing):
+        self.fobs, self.finducing = fobs, finducing
+
+    def __len__(self):
+        return len(self.fobs)
+
+
+_COV_ERR = ("The covariance matrix of a sparse GP can often be dense and can cause the computer to run out of "
+            "memory. If you are sure you have enough memory, you can use `cov(f.fobs)`.")
+
+
+def sparse_cov(f):
+    raise RuntimeError(_COV_ERR)      # sparse_finite_gp.jl:39-43
+
+
+def _vfe_args(vfe, fx):
+    fz = vfe.fz
+    if fz.f is not fx.f:
+        raise AssertionError("VFE requires fz.f === fx.f")
+    if not _is_prior(fx.f):
+        raise NotImplementedError("VFE needs a prior Stheno process")
+    n, m = len(fx), len(fz)
+    zz = _prior_spec(fz.f, fz.x)
+    xz, _, _ = build_spec(fx.f, fx.x, fz.f, fz.x)
+    a = np.asarray(fx.noise, dtype=np.float64)
+    if a.ndim > 1:
+        raise ValueError("elbo needs isotropic or diagonal observation noise")
+    nk, nbuf = _lib._noise_args(fx.noise, n)
+    zk, zbuf = _lib._noise_args(fz.noise, m)
+    mean_x = _f64(mean_vector(fx.f, fx.x))
+    return zz, xz, mean_x, nk, nbuf, zk, zbuf
+
+
+def elbo(vfe, fx, y=None):
+    if isinstance(vfe, SparseFiniteGP):      # elbo(f::SparseFiniteGP, y)
+        return elbo(VFE(vfe.finducing), vfe.fobs, fx)
+    zz, xz, mean_x, nk, nbuf, zk, zbuf = _vfe_args(vfe, fx)
+    y = _f64(np.asarray(y, dtype=np.float64).ravel())
+    var_x = _f64(prior_var(fx.f, fx.x))
+    out = np.zeros(1)
+    rc = _ctx().lib.sgp_elbo(_ctx().handle, zz.ref(), xz.ref(), _lib.dptr(var_x), _lib.dptr(mean_x), nk,
+                             _lib.dptr(nbuf), zk, _lib.dptr(zbuf), _lib.dptr(y), _lib.dptr(out))
+    _lib.check(rc, "sgp_elbo")
+    return float(out[0])
+
+
+class ApproxPosteriorGP:
+    def __init__(self, prior, z, handle):
+        self.prior, self.z, self._h = prior, z, handle
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self._h:
+                _lib.load().sgp_sparse_posterior_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def __call__(self, xs, noise=1e-18):
+        return FiniteGP(self, xs, noise)
+
+    def _predict(self, xs, want_mean, want_var, want_cov):
+        cross, _, _ = build_spec(self.prior, xs, self.prior, self.z)
+        pss = _prior_spec(self.prior, xs) if (want_var or want_cov) else None
+        ns = cross.N
+        ms = _f64(mean_vector(self.prior, xs))
+        mo = np.zeros(ns) if want_mean else None
+        vo = np.zeros(ns) if want_var else None
+        co = np.zeros((ns, ns), order="F") if want_cov else None
+        rc = _ctx().lib.sgp_sparse_posterior_predict(self._h, cross.ref(), pss.ref() if pss is not None else None,
+                                                     _lib.dptr(ms), _lib.dptr(mo), _lib.dptr(vo), _lib.dptr(co),
+                                                     max(ns, 1))
+        _lib.check(rc, "sgp_sparse_posterior_predict")
+        return mo, vo, co
+
+    def mean(self, xs):
+        return self._predict(xs, True, False, False)[0]
+
+    def var(self, xs):
+        return self._predict(xs, False, True, False)[1]
+
+    def cov(self, xs, zs=None):
+        if zs is not None:
+            raise NotImplementedError
+        return self._predict(xs, False, False, True)[2]
+
+    def mean_and_var(self, xs):
+        m, v, _ = self._predict(xs, True, True, False)
+        return m, v
+
+
+def posterior_vfe(vfe, fx, y):
+    zz, xz, mean_x, nk, nbuf, zk, zbuf = _vfe_args(vfe, fx)
+    y = _f64(np.asarray(y, dtype=np.float64).ravel())
+    h = C.c_void_p()
+    rc = _ctx().lib.sgp_sparse_posterior_create(_ctx().handle, zz.ref(), xz.ref(), _lib.dptr(mean_x), nk,
+                                                _lib.dptr(nbuf), zk, _lib.dptr(zbuf), _lib.dptr(y), C.byref(h))
+    _lib.check(rc, "sgp_sparse_posterior_create")
+    return ApproxPosteriorGP(fx.f, vfe.fz.x, h)

@@ -1,0 +1,130 @@
+"""Model recipes written once against an "API namespace", so that the same Stheno programme can
+be built with the oracle (oracle.*) and with the product (stheno_jl_amd) and compared.
+The recipes are the models the reference's tests and examples use (cited per recipe)."""
+import types
+
+import numpy as np
+
+
+def oracle_api():
+    import oracle.abstractgps as agp
+    import oracle.kernelfunctions as kf
+    import oracle.stheno as st
+    ns = types.SimpleNamespace()
+    for name in ("GPC", "atomic", "stretch", "select", "periodic", "shift", "compose", "cross",
+                 "additive_gp", "GPPP", "GPPPInput", "BlockData"):
+        setattr(ns, name, getattr(st, name))
+    for name in ("SEKernel", "Matern12Kernel", "Matern32Kernel", "Matern52Kernel", "WhiteKernel",
+                 "ConstantKernel", "ScaledKernel", "KernelSum", "with_lengthscale", "ColVecs"):
+        setattr(ns, name, getattr(kf, name))
+    ns.GP = agp.GP
+    ns.is_oracle = True
+    return ns
+
+
+def product_api():
+    import stheno_jl_amd as p
+    ns = types.SimpleNamespace()
+    for name in ("GPC", "atomic", "stretch", "select", "periodic", "shift", "compose", "cross",
+                 "additive_gp", "GPPP", "GPPPInput", "BlockData", "SEKernel", "Matern12Kernel",
+                 "Matern32Kernel", "Matern52Kernel", "WhiteKernel", "ConstantKernel", "ScaledKernel",
+                 "KernelSum", "with_lengthscale", "ColVecs", "GP"):
+        setattr(ns, name, getattr(p, name))
+    ns.is_oracle = False
+    return ns
+
+
+def _sumsin(x):
+    return float(np.sum(np.sin(x)))
+
+
+def _sumcos(x):
+    return float(np.sum(np.cos(x)))
+
+
+# ---------------------------------------------------------------------------------------------
+# each recipe: api -> (dict name -> process, gpc)
+# ---------------------------------------------------------------------------------------------
+def gppp_docstring(api):
+    """@gppp docstring model, gaussian_process_probabilistic_programme.jl:145-149."""
+    gpc = api.GPC()
+    f1 = api.atomic(api.GP(api.SEKernel()), gpc)
+    f2 = api.atomic(api.GP(api.Matern52Kernel()), gpc)
+    return {"f1": f1, "f2": f2, "f3": f1 + f2}, gpc
+
+
+def toy_gppp(api):
+    """test/gaussian_process_probabilistic_programme.jl:19-26: f3 = f1 + 3 f2 with means."""
+    gpc = api.GPC()
+    f1 = api.atomic(api.GP(np.sin, api.SEKernel()), gpc)
+    f2 = api.atomic(api.GP(np.cos, api.Matern52Kernel()), gpc)
+    return {"f1": f1, "f2": f2, "f3": f1 + 3 * f2}, gpc
+
+
+def correlated_sums(api):
+    """test/affine_transformations/addition.jl:3-9: f4 = f1 + f3, f5 = f3 + f4."""
+    gpc = api.GPC()
+    f1 = api.atomic(api.GP(1, api.SEKernel()), gpc)
+    f2 = api.atomic(api.GP(2, api.SEKernel()), gpc)
+    f3 = f1 + f2
+    f4 = f1 + f3
+    f5 = f3 + f4
+    return {"f1": f1, "f2": f2, "f3": f3, "f4": f4, "f5": f5, "f6": f2 - f1}, gpc
+
+
+def scaled(api):
+    """test/affine_transformations/product.jl:8-14,55-60: constant and function scaling."""
+    gpc = api.GPC()
+    g1 = api.atomic(api.GP(1, api.SEKernel()), gpc)
+    c, c2 = -4.3, 2.1
+    g2, g2p = c * g1, g1 * c2
+    g3, g3p = c * g2, g2p * c2
+    h2, h2p = _sumsin * g1, g1 * _sumcos
+    h3 = _sumsin * h2
+    return {"g1": g1, "g2": g2, "g2p": g2p, "g3": g3, "g3p": g3p, "h2": h2, "h2p": h2p, "h3": h3,
+            "mix": h2 + g3p}, gpc
+
+
+def warped(api):
+    """test/affine_transformations/compose.jl: stretch / shift / select / arbitrary maps."""
+    gpc = api.GPC()
+    f = api.atomic(api.GP(np.sin, api.SEKernel()), gpc)
+    h = api.atomic(api.GP(np.exp, api.Matern12Kernel()), gpc)
+    return {"f": f, "h": h, "fs": api.stretch(f, 0.51), "fsh": api.shift(f, 0.3),
+            "fcos": api.compose(f, np.cos), "sum": api.stretch(f, 0.51) + 2.0 * h,
+            "hs": api.stretch(h, 2.0)}, gpc
+
+
+def warped_colvecs(api, D=3):
+    gpc = api.GPC()
+    f = api.atomic(api.GP(1.3, api.SEKernel()), gpc)
+    g = api.atomic(api.GP(api.Matern32Kernel()), gpc)
+    lam = np.array([0.7, 1.3, 0.4])[:D]
+    A = np.array([[0.5, 0.1, 0.0], [0.2, 1.1, -0.3], [0.0, 0.4, 0.9]])[:D, :D]
+    a = np.array([0.1, -0.2, 0.3])[:D]
+    return {"f": f, "g": g, "fs": api.stretch(f, 0.6), "fv": api.stretch(f, lam), "fA": api.stretch(g, A),
+            "fsh": api.shift(f, a), "fsel": api.select(g, [0, D - 1]), "fsel1": api.select(f, 1),
+            "add": api.additive_gp([f, g, f][:D])}, gpc
+
+
+def composite_kernels(api):
+    """examples/*: scaled / summed / lengthscaled leaf kernels (KernelFunctions composites)."""
+    gpc = api.GPC()
+    k1 = api.ScaledKernel(api.with_lengthscale(api.SEKernel(), 0.7), 2.5)
+    k2 = api.KernelSum([api.Matern32Kernel(), api.ScaledKernel(api.WhiteKernel(), 0.1)])
+    k3 = api.KernelSum([api.ConstantKernel(0.4), api.with_lengthscale(api.Matern52Kernel(), 1.9)])
+    f1 = api.atomic(api.GP(k1), gpc)
+    f2 = api.atomic(api.GP(0.5, k2), gpc)
+    f3 = api.atomic(api.GP(k3), gpc)
+    return {"f1": f1, "f2": f2, "f3": f3, "s": f1 + 0.5 * f2 - f3}, gpc
+
+
+def periodic_model(api):
+    gpc = api.GPC()
+    f = api.atomic(api.GP(api.SEKernel()), gpc)
+    g = api.atomic(api.GP(api.Matern32Kernel()), gpc)
+    return {"g": g, "p": api.periodic(f, 2.0), "s": api.periodic(f, 0.5) + g, "pp": api.periodic(f, 0.5) + api.periodic(f, 2.0)}, gpc
+
+
+RECIPES_1D = [gppp_docstring, toy_gppp, correlated_sums, warped, composite_kernels, periodic_model]
+RECIPES_ND = [gppp_docstring, correlated_sums, scaled, warped_colvecs, composite_kernels]

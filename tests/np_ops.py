@@ -1,0 +1,98 @@
+"""NumPy test double of stheno_jl_amd.dist.HipOps (TEST INFRASTRUCTURE ONLY).
+
+Drives the multi-rank orchestration of stheno.jl_amd/dist.py on CPU tensors over gloo so that
+panel ownership, broadcast order, look-ahead indexing and the final reductions are covered by
+the CPU suite (the HIP kernels themselves are covered by the -m gpu tests).  Mirrors the
+semantics of the C-ABI building blocks in include/sthenomi.h; the product never imports it."""
+import numpy as np
+import torch
+
+import np_terms
+
+
+class NumpyOps:
+    def __init__(self):
+        self.calls = []
+
+    def empty(self, n):
+        return torch.full((n,), float("nan"), dtype=torch.float64)
+
+    def zeros(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def izeros(self, n):
+        return torch.zeros(n, dtype=torch.int32)
+
+    def from_host(self, a):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).clone()
+
+    def to_host(self, t):
+        return t.numpy()
+
+    def make_dspec(self, spec):
+        return {"K": np_terms.dense_from_spec(spec)}
+
+    def free_dspec(self, h):
+        pass
+
+    def synchronize(self):
+        pass
+
+    @staticmethod
+    def _mat(A, col_off, m_tot, ncols):
+        return A.numpy()[col_off * m_tot:(col_off + ncols) * m_tot].reshape(ncols, m_tot).T  # view (m_tot, ncols)
+
+    def assemble_cols(self, ds, N, c0, nc, A, col_off, m_tot, mean, sigma2, Y, ncols):
+        self.calls.append(("assemble", c0, nc))
+        n_pad = m_tot - 128 * ((ncols + 127) // 128)
+        M = self._mat(A, col_off, m_tot, nc)
+        K = ds["K"]
+        for lc in range(nc):
+            gc = c0 + lc
+            col = np.zeros(m_tot)
+            if gc < N:
+                col[:N] = K[:, gc]
+                col[gc] += sigma2
+                for s in range(ncols):
+                    col[n_pad + s] = Y.numpy().reshape(-1)[gc + s * N] - (mean.numpy()[gc] if mean is not None else 0.0)
+            else:
+                col[gc] = 1.0
+            M[c0:, lc] = col[c0:]     # rows above c0 are never touched (stay NaN: catches misuse)
+
+    def panel_factor(self, A, col_off, m_tot, J0, w, logdet, info):
+        self.calls.append(("factor", J0, w))
+        M = self._mat(A, col_off, m_tot, w)
+        P = M[J0:, :]
+        D = np.tril(P[:w, :w]) + np.tril(P[:w, :w], -1).T
+        try:
+            L = np.linalg.cholesky(D)
+        except np.linalg.LinAlgError:
+            if int(info[0]) == 0:
+                # first failing leading minor, LAPACK convention
+                for k in range(1, w + 1):
+                    try:
+                        np.linalg.cholesky(D[:k, :k])
+                    except np.linalg.LinAlgError:
+                        info[0] = J0 + k
+                        break
+            P[:] = np.nan
+            return
+        P[:w, :w] = L
+        P[w:, :] = np.linalg.solve(L, P[w:, :].T).T
+        logdet[0] += 2.0 * np.log(np.diag(L)).sum()
+
+    def pack_panel(self, A, col_off, m_tot, J0, w, buf):
+        M = self._mat(A, col_off, m_tot, w)
+        buf.numpy()[: w * (m_tot - J0)].reshape(w, m_tot - J0)[:] = M[J0:, :].T
+
+    def panel_update(self, buf, J0, w, A, col_off, m_tot, c0, nc):
+        self.calls.append(("update", J0, c0))
+        P = buf.numpy()[: w * (m_tot - J0)].reshape(w, m_tot - J0).T     # rows J0..m_tot
+        M = self._mat(A, col_off, m_tot, nc)
+        rows = P[c0 - J0:, :]
+        M[c0:, :] -= rows @ P[c0 - J0:c0 - J0 + nc, :].T
+
+    def rowsumsq(self, A, col_off, m_tot, n_pad, nc, nrows, out):
+        M = self._mat(A, col_off, m_tot, nc)
+        for s in range(nrows):
+            out[s] += float((M[n_pad + s, :nc] ** 2).sum())

@@ -1,0 +1,146 @@
+"""Host logic (no GPU): the product's flattener (tree -> kernel terms, stheno.jl_amd/flatten.py)
+must describe exactly the matrix the reference's recursion (restated literally in
+oracle/stheno.py from src/gp/derived_gp.jl:31-60 etc.) evaluates.  The terms are evaluated by
+the NumPy test double tests/np_terms.py, so this isolates flattening from the HIP kernels."""
+import itertools
+
+import numpy as np
+import pytest
+
+import models
+import np_terms
+import oracle.abstractgps as oagp
+import oracle.kernelfunctions as okf
+import oracle.stheno as ost
+import stheno_jl_amd as P
+
+RTOL = 1e-12
+
+
+def _inputs_1d(rng, n):
+    return rng.standard_normal(n)
+
+
+def _pair(recipe):
+    fo, go = recipe(models.oracle_api())
+    fp, gp = recipe(models.product_api())
+    return fo, go, fp, gp
+
+
+def _mean_close(a, b):
+    np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("recipe", models.RECIPES_1D, ids=lambda r: r.__name__)
+def test_gppp_blockdata_1d(recipe):
+    rng = np.random.default_rng(123456)
+    fo, go, fp, gp = _pair(recipe)
+    names = list(fo)
+    sizes = [3 + (i % 4) for i in range(len(names))]
+    xs = [_inputs_1d(rng, n) for n in sizes]
+    xo = ost.BlockData([ost.GPPPInput(k, x) for k, x in zip(names, xs)])
+    xp = P.BlockData([P.GPPPInput(k, x) for k, x in zip(names, xs)])
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    Ko = Fo.cov(xo)
+    spec, _, _ = P.build_spec(Fp, xp)
+    Kp = np_terms.dense_from_spec(spec)
+    np.testing.assert_allclose(Kp, Ko, rtol=RTOL, atol=1e-13)
+    _mean_close(P.mean_vector(Fp, xp), Fo.mean(xo))
+    # exact zeros between independent processes must be *no terms*, not small numbers
+    assert np.array_equal(Kp == 0.0, np.abs(Ko) == 0.0) or np.all((Ko == 0) <= (Kp == 0))
+    # cross-covariance against a different BlockData (subset, different sizes)
+    sub = names[::2]
+    ys = [_inputs_1d(rng, 2 + i) for i in range(len(sub))]
+    yo = ost.BlockData([ost.GPPPInput(k, y) for k, y in zip(sub, ys)])
+    yp = P.BlockData([P.GPPPInput(k, y) for k, y in zip(sub, ys)])
+    Kxo = Fo.cov(xo, yo)
+    specx, _, _ = P.build_spec(Fp, xp, Fp, yp)
+    np.testing.assert_allclose(np_terms.dense_from_spec(specx), Kxo, rtol=RTOL, atol=1e-13)
+
+
+@pytest.mark.parametrize("recipe", models.RECIPES_ND, ids=lambda r: r.__name__)
+def test_pairs_colvecs(recipe):
+    rng = np.random.default_rng(20260925)
+    D = 3
+    fo, go, fp, gp = _pair(recipe)
+    X1 = np.asfortranarray(rng.standard_normal((D, 5)))
+    X2 = np.asfortranarray(rng.standard_normal((D, 4)))
+    tested = 0
+    for a, b in itertools.product(list(fo), repeat=2):
+        try:
+            Ko = ost.cov4(fo[a], fo[b], okf.ColVecs(X1), okf.ColVecs(X2))
+        except Exception:
+            # dimension-incompatible views of one atom (e.g. select(f, 1) against f): the product
+            # must refuse as well
+            with pytest.raises(Exception):
+                s, _, _ = P.build_spec(fp[a], P.ColVecs(X1), fp[b], P.ColVecs(X2))
+                np_terms.dense_from_spec(s)
+            continue
+        s, _, _ = P.build_spec(fp[a], P.ColVecs(X1), fp[b], P.ColVecs(X2))
+        np.testing.assert_allclose(np_terms.dense_from_spec(s), Ko, rtol=RTOL, atol=1e-13, err_msg=f"{a},{b}")
+        _mean_close(P.mean_vector(fp[a], P.ColVecs(X1)), fo[a].mean(okf.ColVecs(X1)))
+        tested += 1
+    assert tested >= len(fo)
+
+
+def test_term_merging_counts():
+    """f4 = f1 + (f1 + f2): the diagonal block is 4 k1 + k2.  Here k1 and k2 are both SE on the
+    same inputs, so everything merges into ONE term with coefficient 5; with different leaf
+    kernels the two atoms stay separate (coefficients 4 and 1)."""
+    fp, gp = models.correlated_sums(models.product_api())
+    x = np.linspace(-1, 1, 6)
+    s, _, _ = P.build_spec(fp["f4"], x)
+    terms = np_terms.spec_terms(s)
+    assert len(terms) == 1 and terms[0][5] == 5.0
+    g = P.GPC()
+    a, b = P.atomic(P.GP(P.SEKernel()), g), P.atomic(P.GP(P.Matern32Kernel()), g)
+    s, _, _ = P.build_spec(a + (a + b), x)
+    assert sorted(t[5] for t in np_terms.spec_terms(s)) == [1.0, 4.0]
+
+
+def test_independent_blocks_have_no_terms():
+    fp, gp = models.gppp_docstring(models.product_api())
+    F = P.GPPP(fp, gp)
+    x = P.BlockData([P.GPPPInput("f1", np.arange(3.0)), P.GPPPInput("f2", np.arange(4.0))])
+    s, _, _ = P.build_spec(F, x)
+    pairs = {(t[0], t[1]) for t in np_terms.spec_terms(s)}
+    assert pairs == {(0, 0), (1, 1)}
+
+
+def test_generic_tuple_vector_regroups_like_reference():
+    """gppp.jl:32-43: a plain vector of (key, value) is regrouped by unique key."""
+    fo, go, fp, gp = _pair(models.toy_gppp)
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    items = [("f2", 0.3), ("f3", -1.0), ("f2", 0.7), ("f1", 0.1), ("f3", 2.0)]
+    Ko = Fo.cov(items)
+    s, _, _ = P.build_spec(Fp, items)
+    np.testing.assert_allclose(np_terms.dense_from_spec(s), Ko, rtol=RTOL, atol=1e-14)
+    _mean_close(P.mean_vector(Fp, items), Fo.mean(items))
+
+
+def test_nested_gppp():
+    """test/gaussian_process_probabilistic_programme.jl:107-120."""
+    fo, go, fp, gp = _pair(models.toy_gppp)
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    g2o, g2p = ost.GPC(), P.GPC()
+    f1o, f1p = ost.atomic(Fo, g2o), P.atomic(Fp, g2p)
+    Oo = ost.GPPP({"f1": f1o, "f2": 5 * f1o}, g2o)
+    Op = P.GPPP({"f1": f1p, "f2": 5 * f1p}, g2p)
+    x0, x1 = np.array([0.1, 0.5, -0.3]), np.array([1.0, -1.0])
+    xo = ost.BlockData([ost.GPPPInput("f1", ost.GPPPInput("f1", x0)), ost.GPPPInput("f2", ost.GPPPInput("f3", x1))])
+    xp = P.BlockData([P.GPPPInput("f1", P.GPPPInput("f1", x0)), P.GPPPInput("f2", P.GPPPInput("f3", x1))])
+    Ko = Oo.cov(xo)
+    s, _, _ = P.build_spec(Op, xp)
+    np.testing.assert_allclose(np_terms.dense_from_spec(s), Ko, rtol=RTOL, atol=1e-14)
+    _mean_close(P.mean_vector(Op, xp), Oo.mean(xo))
+
+
+def test_gpc_mismatch_is_rejected():
+    a, _ = models.gppp_docstring(models.product_api())
+    b, _ = models.gppp_docstring(models.product_api())
+    with pytest.raises(AssertionError):
+        a["f1"] + b["f1"]
+    with pytest.raises(AssertionError):
+        P.build_spec(a["f1"], np.arange(3.0), b["f1"], np.arange(3.0))
+    with pytest.raises(ValueError):
+        a["f1"] * a["f2"]

@@ -1,0 +1,347 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C-ABI via the
+product's host mirror, against the CPU oracle on identical seeded inputs.
+
+Tolerances (fp64): north star demands logpdf and posterior mean/var within 1e-8 relative; the
+tests hold 1e-10 where conditioning allows and say so where it does not.  Exact identities the
+reference's tests pin with `==` are asserted bit-exact here as well."""
+import numpy as np
+import pytest
+
+import models
+import oracle.abstractgps as oagp
+import oracle.kernelfunctions as okf
+import oracle.stheno as ost
+import stheno_jl_amd as P
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-10
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def both(recipe):
+    fo, go = recipe(models.oracle_api())
+    fp, gp = recipe(models.product_api())
+    return ost.GPPP(fo, go), P.GPPP(fp, gp), fo, fp
+
+
+def blockdata(names, xs, colvecs):
+    wrap_o = (lambda x: okf.ColVecs(x)) if colvecs else (lambda x: x)
+    wrap_p = (lambda x: P.ColVecs(x)) if colvecs else (lambda x: x)
+    xo = ost.BlockData([ost.GPPPInput(k, wrap_o(x)) for k, x in zip(names, xs)])
+    xp = P.BlockData([P.GPPPInput(k, wrap_p(x)) for k, x in zip(names, xs)])
+    return xo, xp
+
+
+def test_library_is_native_and_loaded():
+    import ctypes
+    lib = P.lib.load()
+    assert lib.sgp_abi_version() == 1
+    ctx = P.lib.default_context()
+    assert ctx.handle
+    # the loaded object is the in-tree HIP library
+    with open("/proc/self/maps") as fh:
+        assert any("stheno.jl_amd/csrc/libsthenomi.so" in ln for ln in fh)
+    tf, err = ctypes.c_double(), ctypes.c_double()
+    P.lib.check(lib.sgp_bench_mfma_f64(ctx.handle, 50, ctypes.byref(tf), ctypes.byref(err)))
+    assert err.value == 0.0  # documented MFMA lane maps hold on this device
+
+
+# ---- covariance assembly ---------------------------------------------------------------------
+@pytest.mark.parametrize("recipe", models.RECIPES_1D, ids=lambda r: r.__name__)
+def test_cov_mean_var_blockdata_1d(recipe):
+    rng = np.random.default_rng(123456)
+    Fo, Fp, fo, fp = both(recipe)
+    names = list(fo)
+    xs = [rng.standard_normal(40 + 37 * i) for i in range(len(names))]
+    xo, xp = blockdata(names, xs, False)
+    Ko = Fo.cov(xo)
+    Kp = P.prior_cov(Fp, xp)
+    assert np.abs(Kp - Ko).max() < 1e-12
+    assert np.array_equal(Kp, Kp.T)                      # exactly symmetric
+    assert np.all(Kp[np.abs(Ko) == 0.0] == 0.0)          # independent blocks are exact zeros
+    np.testing.assert_allclose(P.prior_var(Fp, xp), Fo.var(xo), rtol=0, atol=1e-12)
+    assert np.array_equal(P.prior_var(Fp, xp), np.diag(Kp))  # var == diag(cov) bit for bit
+    np.testing.assert_allclose(P.prior_mean(Fp, xp), Fo.mean(xo), rtol=0, atol=1e-13)
+    # cross covariance between two different input collections
+    ys = [rng.standard_normal(5 + 3 * i) for i in range(len(names))]
+    yo, yp = blockdata(names[::-1], ys, False)
+    np.testing.assert_allclose(P.prior_cov(Fp, xp, yp), Fo.cov(xo, yo), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(P.prior_cov(Fp, yp, xp), P.prior_cov(Fp, xp, yp).T, rtol=0, atol=1e-15)
+
+
+@pytest.mark.parametrize("recipe", [models.gppp_docstring, models.correlated_sums, models.scaled,
+                                    models.composite_kernels], ids=lambda r: r.__name__)
+@pytest.mark.parametrize("D", [1, 2, 3, 8, 17])
+def test_cov_colvecs(recipe, D):
+    rng = np.random.default_rng(7 + D)
+    Fo, Fp, fo, fp = both(recipe)
+    names = list(fo)[:4]
+    xs = [np.asfortranarray(rng.standard_normal((D, 60 + 71 * i))) for i in range(len(names))]
+    xo, xp = blockdata(names, xs, True)
+    Ko, Kp = Fo.cov(xo), P.prior_cov(Fp, xp)
+    assert np.abs(Kp - Ko).max() < 2e-12 * max(1.0, np.abs(Ko).max())
+
+
+def test_warps_colvecs():
+    rng = np.random.default_rng(99)
+    Fo, Fp, fo, fp = both(models.warped_colvecs)
+    X = np.asfortranarray(rng.standard_normal((3, 150)))
+    for name in ["f", "g", "fs", "fv", "fA", "fsh", "fsel", "fsel1", "add"]:
+        Ko = fo[name].cov(okf.ColVecs(X))
+        Kp = P.prior_cov(fp[name], P.ColVecs(X))
+        assert np.abs(Kp - Ko).max() < 1e-12, name
+
+
+def test_exact_identities_from_reference_tests():
+    """`==` pins: test/gp/atomic_gp.jl:15,33,34; test/affine_transformations/compose.jl:53-54,73-74."""
+    rng = np.random.default_rng(3)
+    gpc = P.GPC()
+    f1 = P.atomic(P.GP(P.SEKernel()), gpc)
+    f2 = P.atomic(P.GP(5, P.SEKernel()), gpc)
+    x, x2 = rng.standard_normal(5), rng.standard_normal(6)
+    assert np.array_equal(P.prior_var(f1, x), np.ones(5))                       # SE diagonal == 1
+    K12 = P.cov(f1(x), f2(x2))
+    assert K12.shape == (5, 6) and np.array_equal(K12, np.zeros((5, 6)))         # independent atoms
+    lam = 0.51
+    g = P.stretch(f1, lam)
+    xs = rng.standard_normal(1)
+    assert P.cov(f1(lam * xs), g(xs))[0, 0] == 1.0                                # cov(f, stretch(f,l), [l x],[x]) == 1
+    Dn = 11
+    Xc = rng.standard_normal((Dn, 1))
+    assert P.cov(f1(P.ColVecs(lam * Xc)), g(P.ColVecs(Xc)))[0, 0] == 1.0
+    fg = P.compose(f1, np.cos)
+    assert np.array_equal(P.prior_cov(fg, x), P.prior_cov(f1, np.cos(x)))        # compose.jl:15-16
+    # cov(f, x) == kernelmatrix(k, x): a one-atom tree is exactly the leaf kernel matrix
+    np.testing.assert_allclose(P.prior_cov(f1, x), okf.kernelmatrix(okf.SEKernel(), x, faithful=False),
+                               rtol=0, atol=2e-16)
+
+
+# ---- logpdf ---------------------------------------------------------------------------------------
+SIZES = [1, 2, 127, 128, 129, 300, 1000]
+
+
+@pytest.mark.parametrize("N", SIZES)
+@pytest.mark.parametrize("kind", ["se", "matern52", "matern32", "matern12"])
+def test_logpdf_single_gp(N, kind):
+    rng = np.random.default_rng(N * 7 + len(kind))
+    D = 3
+    ko = {"se": okf.SEKernel, "matern52": okf.Matern52Kernel, "matern32": okf.Matern32Kernel,
+          "matern12": okf.Matern12Kernel}[kind]()
+    kp = {"se": P.SEKernel, "matern52": P.Matern52Kernel, "matern32": P.Matern32Kernel,
+          "matern12": P.Matern12Kernel}[kind]()
+    fo = ost.atomic(oagp.GP(0.3, ko), ost.GPC())
+    fp = P.atomic(P.GP(0.3, kp), P.GPC())
+    X = np.asfortranarray(rng.standard_normal((D, N)))
+    y = rng.standard_normal(N)
+    Y = rng.standard_normal((N, 3))
+    for noise in (0.1, 0.05 + rng.random(N)):
+        lo = oagp.logpdf(fo(okf.ColVecs(X), noise), y)
+        lp = P.logpdf(fp(P.ColVecs(X), noise), y)
+        assert abs(lp - lo) <= REL * abs(lo), (lp, lo)
+        Lo = oagp.logpdf(fo(okf.ColVecs(X), noise), Y)
+        Lp = P.logpdf(fp(P.ColVecs(X), noise), Y)
+        assert Lp.shape == (3,) and rel(Lp, Lo) < REL
+    if N <= 300:
+        A = rng.standard_normal((N, N))
+        S = A @ A.T / N + 0.1 * np.eye(N)
+        lo = oagp.logpdf(fo(okf.ColVecs(X), S), y)
+        lp = P.logpdf(fp(P.ColVecs(X), S), y)
+        assert abs(lp - lo) <= REL * abs(lo)
+
+
+@pytest.mark.parametrize("recipe", [models.gppp_docstring, models.toy_gppp, models.correlated_sums,
+                                    models.composite_kernels], ids=lambda r: r.__name__)
+def test_logpdf_rand_posterior_gppp(recipe):
+    rng = np.random.default_rng(42)
+    Fo, Fp, fo, fp = both(recipe)
+    names = list(fo)[:3]
+    xs = [rng.standard_normal(n) for n in (211, 95, 160)][:len(names)]
+    xo, xp = blockdata(names, xs, False)
+    N = sum(len(x) for x in xs)
+    y = rng.standard_normal(N)
+    s2 = 0.2
+    lo, lp = oagp.logpdf(Fo(xo, s2), y), P.logpdf(Fp(xp, s2), y)
+    assert abs(lp - lo) <= REL * abs(lo)
+    # rand: same Z -> same sample (deterministic kernels; summation order differs from LAPACK)
+    Z = rng.standard_normal((N, 4))
+    Ro = oagp.rand(Fo(xo, s2), Z)
+    Rp = P.rand(None, Fp(xp, s2), 4, Z=Z)
+    assert rel(Rp, Ro) < 1e-11
+    Rp2 = P.rand(None, Fp(xp, s2), 4, Z=Z)
+    assert np.array_equal(Rp, Rp2)                       # bit-identical run to run
+    # posterior at new inputs of two processes
+    po, pp = oagp.posterior(Fo(xo, s2), y), P.posterior(Fp(xp, s2), y)
+    assert rel(pp.alpha, po.alpha) < 1e-9
+    ts = [np.linspace(-2, 2, 33), rng.standard_normal(20)]
+    to, tp = blockdata([names[-1], names[0]], ts, False)
+    mo, vo = po.mean_and_var(to)
+    mp, vp = pp.mean_and_var(tp)
+    assert rel(mp, mo) < REL and np.abs(vp - vo).max() < 1e-10
+    Co, Cp = po.cov(to), pp.cov(tp)
+    assert np.abs(Cp - Co).max() < 1e-10
+    assert np.abs(np.diag(Cp) - vp).max() < 1e-12
+    # a posterior FiniteGP is again a FiniteGP: logpdf / rand / marginals on top of it
+    yt = rng.standard_normal(len(to))
+    assert abs(P.logpdf(pp(tp, 0.3), yt) - oagp.logpdf(po(to, 0.3), yt)) <= 1e-9 * abs(oagp.logpdf(po(to, 0.3), yt))
+    mg = P.marginals(pp(tp, 0.3))
+    m_o, s_o = oagp.marginals(po(to, 0.3))
+    assert rel([g.mu for g in mg], m_o) < REL and rel([g.sigma for g in mg], s_o) < REL
+
+
+def test_posterior_external_consistency():
+    """test/gaussian_process_probabilistic_programme.jl:28-42: GPPP == manual construction."""
+    rng = np.random.default_rng(5)
+    fp, gp = models.toy_gppp(models.product_api())
+    F = P.GPPP(fp, gp)
+    x0, x1 = rng.standard_normal(4), rng.standard_normal(3)
+    assert np.array_equal(P.prior_mean(fp["f1"], x0), P.prior_mean(F, P.GPPPInput("f1", x0)))
+    assert np.array_equal(P.prior_cov(fp["f3"], x1), P.prior_cov(F, P.GPPPInput("f3", x1)))
+    assert np.array_equal(P.cov(fp["f1"](x0), fp["f3"](x1)), P.prior_cov(F, P.GPPPInput("f1", x0), P.GPPPInput("f3", x1)))
+    y = P.rand(np.random.default_rng(1), F(P.GPPPInput("f3", x1)))
+    a = P.posterior(fp["f3"](x1), y)(x1)
+    b = P.posterior(F(P.GPPPInput("f3", x1)), y)(P.GPPPInput("f3", x1))
+    assert np.array_equal(P.cov(a), P.cov(b))
+
+
+def test_non_positive_definite_raises_posdef():
+    f = P.atomic(P.GP(P.SEKernel()), P.GPC())
+    x = np.zeros(10)                       # rank-one covariance, negative "noise"
+    with pytest.raises(P.PosDefException) as ei:
+        P.logpdf(f(x, -0.5), np.zeros(10))
+    assert ei.value.info == 2              # LAPACK potrf convention: first failing leading minor
+    with pytest.raises(oagp.PosDefException):
+        oagp.logpdf(ost.atomic(oagp.GP(okf.SEKernel()), ost.GPC())(x, -0.5), np.zeros(10))
+
+
+def test_rand_statistics():
+    """test/gp/util.jl:36-47: S = 100000 samples, N = 10, D = 2."""
+    rng = np.random.default_rng(123456)
+    X = P.ColVecs(rng.standard_normal((2, 10)))
+    fx = P.atomic(P.GP(1, P.SEKernel()), P.GPC())(X, 1e-12)
+    S = 100_000
+    fh = P.rand(rng, fx, S)
+    assert fh.shape == (10, S)
+    assert np.abs(fh.mean(1) - P.mean(fx)).max() < 1e-2
+    Sig = (fh - P.mean(fx)[:, None]) @ (fh - P.mean(fx)[:, None]).T / S
+    assert np.mean(np.abs(Sig - P.cov(fx))) < 1e-2
+    assert P.rand(rng, fx).shape == (10,)
+
+
+def test_rand_sum_model_consistency():
+    """additive sample check, @gppp docstring (gppp.jl:150-160): f1 + f2 ~= f3 at s2 = 1e-12."""
+    rng = np.random.default_rng(0)
+    F = P.gppp_sum_model()
+    xl = rng.standard_normal(5)
+    x = P.BlockData([P.GPPPInput("f1", xl), P.GPPPInput("f2", xl), P.GPPPInput("f3", xl)])
+    y = P.rand(rng, F(x, 1e-12))
+    a, b, c = P.split(x, y)
+    np.testing.assert_allclose(a + b, c, rtol=1e-4, atol=1e-4)
+
+
+# ---- sparse / VFE --------------------------------------------------------------------------------
+def test_sparse_finite_gp_reference_properties():
+    """test/gp/sparse_finite_gp.jl:1-42."""
+    x = np.arange(0.0, 10.0001, 0.1)
+    xu = np.arange(0.0, 10.5, 1.0)
+    sig, sigu = 1.0, 1e-3
+    fo = ost.atomic(oagp.GP(okf.Matern32Kernel()), ost.GPC())
+    fp = P.atomic(P.GP(P.Matern32Kernel()), P.GPC())
+    fx = fp(x, sig)
+    fxu = P.SparseFiniteGP(fp(x, sig), fp(xu, sigu))
+    assert len(fxu) == len(x)
+    y = P.rand(np.random.default_rng(12345), fxu)
+    assert np.array_equal(y, P.rand(np.random.default_rng(12345), fx))       # samples the dense fobs
+    e1 = P.elbo(fxu, y)
+    assert e1 == P.logpdf(fxu, y) == P.elbo(P.VFE(fxu.finducing), fxu.fobs, y)
+    e_o = oagp.elbo(oagp.VFE(fo(xu, sigu)), fo(x, sig), y)
+    assert abs(e1 - e_o) <= 1e-9 * abs(e_o)
+    yy = P.rand(np.random.default_rng(3), fxu, 10)
+    assert np.all(P.logpdf(fx, yy) > P.logpdf(fxu, yy))                       # ELBO is a lower bound
+    p1 = P.finite_gp.posterior_vfe(P.VFE(fxu.finducing), fxu.fobs, y)
+    p2 = P.posterior(fxu, y)
+    m1, v1 = p1.mean_and_var(x)
+    m2, v2 = p2.mean_and_var(x)
+    assert np.array_equal(m1, m2) and np.array_equal(v1, v2)
+    po = oagp.posterior_vfe(oagp.VFE(fo(xu, sigu)), fo(x, sig), y)
+    assert rel(m1, po.mean(x)) < 1e-8 and np.abs(v1 - po.var(x)).max() < 1e-8
+    assert np.abs(p1.cov(x[:40]) - po.cov(x[:40])).max() < 1e-8
+    with pytest.raises(RuntimeError):
+        P.sparse_cov(fxu)
+
+
+def test_elbo_equals_logpdf_when_z_is_x():
+    """README.md:71-78 (not CI'd in the reference): elbo -> logpdf for Z = X, tiny jitter."""
+    rng = np.random.default_rng(8)
+    f = P.atomic(P.GP(P.SEKernel()), P.GPC())
+    x = np.sort(rng.uniform(-5, 5, 60))
+    y = rng.standard_normal(60)
+    lp = P.logpdf(f(x, 0.1), y)
+    el = P.elbo(P.VFE(f(x, 1e-9)), f(x, 0.1), y)
+    assert abs(lp - el) < 1e-5 * abs(lp)
+
+
+@pytest.mark.parametrize("N,M,D", [(777, 130, 2), (3000, 256, 4)])
+def test_elbo_gppp_with_diag_noise(N, M, D):
+    rng = np.random.default_rng(N)
+    Fo, Fp, fo, fp = both(models.gppp_docstring)
+    X = np.asfortranarray(rng.standard_normal((D, N)))
+    Z = np.asfortranarray(X[:, rng.permutation(N)[:M]])
+    y = rng.standard_normal(N)
+    noise = 0.05 + rng.random(N)
+    eo = oagp.elbo(oagp.VFE(Fo(ost.GPPPInput("f3", okf.ColVecs(Z)), 1e-6)), Fo(ost.GPPPInput("f3", okf.ColVecs(X)), noise), y)
+    ep = P.elbo(P.VFE(Fp(P.GPPPInput("f3", P.ColVecs(Z)), 1e-6)), Fp(P.GPPPInput("f3", P.ColVecs(X)), noise), y)
+    assert abs(ep - eo) <= 1e-9 * abs(eo)
+
+
+# ---- full-size, size-independent properties -----------------------------------------------------------
+@pytest.mark.parametrize("N", [16384])
+def test_full_size_round_trip_and_scaling(N):
+    """At BASELINE size the oracle is too slow to run in a test, so check domain properties:
+    (1) rand -> logpdf round trip: for y = m + L z, |L^-1 (y - m)|^2 == |z|^2;
+    (2) scaling K and noise by a: logdet grows by N log a and the quadratic form shrinks by a."""
+    rng = np.random.default_rng(1)
+    D = 8
+    X = P.ColVecs(rng.standard_normal((D, N)) / np.sqrt(D))
+    f = P.atomic(P.GP(P.Matern52Kernel()), P.GPC())
+    s2 = 0.1
+    z = rng.standard_normal(N)
+    y = P.rand(None, f(X, s2), Z=z)
+    lp = P.logpdf(f(X, s2), y)
+    a = 3.7
+    lp_a = P.logpdf((np.sqrt(a) * f)(X, a * s2), y)
+    # lp = -(N log2pi + logdet + q)/2 ; lp_a = -(N log2pi + logdet + N log a + q/a)/2, q = |z|^2
+    q = float(z @ z)
+    logdet = -2 * lp - N * np.log(2 * np.pi) - q
+    expect_a = -0.5 * (N * np.log(2 * np.pi) + logdet + N * np.log(a) + q / a)
+    assert abs(lp_a - expect_a) <= 1e-9 * abs(expect_a)
+    # interpolation property of the posterior: tiny noise reproduces the data it was given
+    post = P.posterior(f(X, s2), y)
+    sub = P.ColVecs(X.X[:, :256])
+    m, v = post.mean_and_var(sub)
+    assert np.all(v > 0) and np.all(v < 1.0 + 1e-12)
+    K = P.prior_cov(f, sub, X)
+    np.testing.assert_allclose(m, K @ post.alpha, rtol=1e-8, atol=1e-8)
+
+
+def test_golden_sklearn_vectors():
+    """Committed golden vectors (tests/golden/make_golden.py): an independent third
+    implementation (scikit-learn) pins both the oracle and the HIP path."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sklearn_gpr.json")))
+    for case in g["cases"]:
+        X = np.asfortranarray(np.array(case["X"]).T)       # stored N x D
+        y = np.array(case["y"])
+        kp = {"se": P.SEKernel, "matern52": P.Matern52Kernel, "matern32": P.Matern32Kernel}[case["kernel"]]()
+        f = P.stretch(P.atomic(P.GP(kp), P.GPC()), 1.0 / case["lengthscale"])
+        lp = P.logpdf(f(P.ColVecs(X), case["sigma2"]), y)
+        assert abs(lp - case["lml"]) <= 1e-9 * abs(case["lml"])
+        post = P.posterior(f(P.ColVecs(X), case["sigma2"]), y)
+        Xs = P.ColVecs(np.asfortranarray(np.array(case["Xs"]).T))
+        m, v = post.mean_and_var(Xs)
+        assert rel(m, case["mean"]) < 1e-8 and np.abs(np.sqrt(v) - np.array(case["std"])).max() < 1e-8
