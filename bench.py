@@ -61,13 +61,27 @@ def cpu_baseline(kernel, D, n_sample, N_target):
     """Oracle (CPU restatement) timed on a bounded sample; extrapolated to N_target with the
     measured stage split: assembly ~ N^2, Cholesky ~ N^3."""
     from oracle import reference_model as orm
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    import scipy.linalg as sla
+    from threadpoolctl import threadpool_limits
+    # OpenBLAS with every hardware thread is far from its best on these sizes: calibrate the
+    # thread count on a small Cholesky and give the CPU its best configuration.
+    ncpu = os.cpu_count() or 1
+    cands = sorted({c for c in (8, 16, 32, 64, 128, ncpu) if c <= ncpu})
+    r0 = np.random.default_rng(0)
+    B = r0.standard_normal((3072, 3072))
+    S = B @ B.T + 3072 * np.eye(3072)
+    best, threads = None, cands[0]
+    for c in cands:
+        with threadpool_limits(limits=c):
+            sla.cholesky(S, lower=True, check_finite=False)
+            t0 = time.perf_counter()
+            sla.cholesky(S, lower=True, check_finite=False)
+            dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, threads = dt, c
     X, y = make_inputs(n_sample, D)
-    val, t_tot, t_chol = orm.cpu_logpdf_timed(kernel, math.sqrt(D), X, y, 0.1)
+    with threadpool_limits(limits=threads):
+        val, t_tot, t_chol = orm.cpu_logpdf_timed(kernel, math.sqrt(D), X, y, 0.1)
     t_other = t_tot - t_chol
     r = N_target / n_sample
     t_target = t_other * r ** 2 + t_chol * r ** 3

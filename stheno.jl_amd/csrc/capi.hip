@@ -571,7 +571,9 @@ extern "C" int sgp_kernelmatrix(sgp_ctx* ctx, const sgp_cov_spec* spec, double* 
   DevBuf dK;
   CHECK_RC(dK.alloc((size_t)N * M));
   hipStream_t s = ctx->stream;
-  CHECK_RC(assemble(g.ds, dK.p, N, 0, rup(N, TILE) / TILE, 0, rup(M, TILE) / TILE, 0, -1, 0.0, nullptr, s));
+  CHECK_RC(assemble(g.ds, dK.p, N, 0, rup(N, TILE) / TILE, 0, rup(M, TILE) / TILE, g.ds->symmetric, -1, 0.0,
+                    nullptr, s));
+  if (g.ds->symmetric) CHECK_RC(launch_mirror_lower(dK.p, N, N, s));
   SGP_HIP(hipStreamSynchronize(s));
   SGP_HIP(hipMemcpy2D(K, sizeof(double) * ldk, dK.p, sizeof(double) * N, sizeof(double) * N, (size_t)M,
                       hipMemcpyDeviceToHost));

@@ -68,6 +68,7 @@ int launch_border_rows(double* A, long ld, long n_pad, long N, long c0, long nc,
 int launch_diag_terms(double* out, long n, const DevTerm* d_terms, int nterms, hipStream_t s);
 int launch_add_dense(double* K, long ld, const double* S, long lds, long N, int lower_only,
                      hipStream_t s);
+int launch_mirror_lower(double* K, long ld, long N, hipStream_t s);
 
 // gemm_nt.hip : C = beta*C + alpha * A B'   (A: M x K, B: Nc x K, all column-major)
 // tiles (tr, tc) with tr < tc + mask_off are skipped.  kcap_mode: per-tile K limited to

@@ -289,4 +289,21 @@ int launch_add_dense(double* K, long ld, const double* S, long lds, long N, int 
   return 0;
 }
 
+// K[r, c] = K[c, r] for r < c: makes a symmetric covariance bit-exactly symmetric (multi-term
+// blocks sum their cross terms in a different order above and below the diagonal).
+__global__ void mirror_lower_kernel(double* K, long ld, long N) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * N) return;
+  long r = idx % N, c = idx / N;
+  if (r < c) K[r + c * ld] = K[c + r * ld];
+}
+
+int launch_mirror_lower(double* K, long ld, long N, hipStream_t s) {
+  long tot = N * N;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(mirror_lower_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, K, ld, N);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace sgp

@@ -65,6 +65,13 @@ class HipOps:
         self.ctx = ctx or _lib.default_context()
         self.lib = self.ctx.lib
         self.device = torch.device("cuda", self.ctx.device)
+        # every kernel of this rank (torch copies, libsthenomi kernels, collectives' stream
+        # dependencies) is ordered on ONE explicit non-default stream: the HIP null stream (handle
+        # 0) cannot be named through the C-ABI, where NULL means "the ctx's own stream".
+        self._stream = torch.cuda.Stream(self.device)
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self._stream)
 
     # -- memory ---------------------------------------------------------------------------
     def empty(self, n):
@@ -80,7 +87,10 @@ class HipOps:
         return self.torch.zeros(n, dtype=self.torch.int32, device=self.device)
 
     def stream(self):
-        return self.torch.cuda.current_stream(self.device).cuda_stream
+        h = self.torch.cuda.current_stream(self.device).cuda_stream
+        if not h:
+            raise _lib.SthenoMIError("HipOps kernels must run inside ops.stream_context()")
+        return h
 
     def to_host(self, t):
         return t.cpu().numpy()
@@ -137,87 +147,89 @@ def dist_logpdf(ops, spec, y, mean, sigma2, world=1, rank=0, group=None, W=1024,
     y    : (N,) observations, mean: (N,) prior mean or None
     A    : optional preallocated local panel storage (m_tot * n_local_cols doubles)
     Every rank returns the same float.  Raises lib.PosDefException like the single-GPU path."""
+    ds = ops.make_dspec(spec)
+    try:
+        with ops.stream_context():
+            return _dist_logpdf(ops, ds, spec.N, y, mean, sigma2, world, rank, group, W, A, stats)
+    finally:
+        ops.free_dspec(ds)
+
+
+def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats):
     import torch
     import torch.distributed as dist
 
-    N = spec.N
     n_pad, m_tot = geometry(N, 1)
     W = min(W, n_pad)
     lay = PanelLayout(n_pad, W, world, rank)
-    ds = ops.make_dspec(spec)
-    try:
-        if A is None:
-            A = ops.empty(max(1, m_tot * lay.n_local_cols()))
-        dY = ops.from_host(np.asarray(y, dtype=np.float64))
-        dmean = ops.from_host(mean) if mean is not None else None
-        logdet = ops.zeros(1)
-        sq = ops.zeros(1)
-        info = ops.izeros(1)
-        bufs = [ops.empty(m_tot * W), ops.empty(m_tot * W)]
+    if A is None:
+        A = ops.empty(max(1, m_tot * lay.n_local_cols()))
+    dY = ops.from_host(np.asarray(y, dtype=np.float64))
+    dmean = ops.from_host(mean) if mean is not None else None
+    logdet = ops.zeros(1)
+    sq = ops.zeros(1)
+    info = ops.izeros(1)
+    bufs = [ops.empty(m_tot * W), ops.empty(m_tot * W)]
 
-        # 1. every rank assembles its own column panels (no communication)
-        for J in lay.mine:
-            ops.assemble_cols(ds, N, lay.col0(J), lay.width(J), A, lay.local_index(J) * W, m_tot, dmean, sigma2,
-                              dY, 1)
+    # 1. every rank assembles its own column panels (no communication)
+    for J in lay.mine:
+        ops.assemble_cols(ds, N, lay.col0(J), lay.width(J), A, lay.local_index(J) * W, m_tot, dmean, sigma2, dY, 1)
 
-        def bcast(J):
-            J0, w = lay.col0(J), lay.width(J)
-            buf = bufs[J % 2]
-            if world == 1:
-                return None
-            t = buf[: w * (m_tot - J0)]
-            return dist.broadcast(t, src=_global_rank(group, lay.owner(J)), group=group, async_op=True)
+    def bcast(J):
+        J0, w = lay.col0(J), lay.width(J)
+        if world == 1:
+            return None
+        t = bufs[J % 2][: w * (m_tot - J0)]
+        return dist.broadcast(t, src=_global_rank(group, lay.owner(J)), group=group, async_op=True)
 
-        def factor_and_pack(J):
-            J0, w = lay.col0(J), lay.width(J)
-            ops.panel_factor(A, lay.local_index(J) * W, m_tot, J0, w, logdet, info)
-            ops.pack_panel(A, lay.local_index(J) * W, m_tot, J0, w, bufs[J % 2])
+    def factor_and_pack(J):
+        J0, w = lay.col0(J), lay.width(J)
+        ops.panel_factor(A, lay.local_index(J) * W, m_tot, J0, w, logdet, info)
+        ops.pack_panel(A, lay.local_index(J) * W, m_tot, J0, w, bufs[J % 2])
 
-        def update(J, Jp):
-            """local panel Jp (> J) -= P_J[rows] P_J[cols Jp]'"""
-            ops.panel_update(bufs[J % 2], lay.col0(J), lay.width(J), A, lay.local_index(Jp) * W, m_tot,
-                             lay.col0(Jp), lay.width(Jp))
+    def update(J, Jp):
+        """local panel Jp (> J) -= P_J[rows] P_J[cols Jp]'"""
+        ops.panel_update(bufs[J % 2], lay.col0(J), lay.width(J), A, lay.local_index(Jp) * W, m_tot,
+                         lay.col0(Jp), lay.width(Jp))
 
-        # 2. right-looking factorisation with one-panel look-ahead
-        if lay.owner(0) == rank:
-            factor_and_pack(0)
-        work = bcast(0)
+    # 2. right-looking factorisation with one-panel look-ahead
+    if lay.owner(0) == rank:
+        factor_and_pack(0)
+    work = bcast(0)
+    if work is not None:
+        work.wait()
+    for J in range(lay.n_panels):
+        nxt = J + 1
+        if nxt < lay.n_panels and lay.owner(nxt) == rank:
+            update(J, nxt)          # look-ahead: bring the next panel up to date first,
+            factor_and_pack(nxt)    # factor it and get its broadcast going
+        work = bcast(nxt) if nxt < lay.n_panels else None
+        for Jp in lay.mine:         # the rest of this rank's trailing panels
+            if Jp > nxt:
+                update(J, Jp)
         if work is not None:
             work.wait()
-        for J in range(lay.n_panels):
-            nxt = J + 1
-            if nxt < lay.n_panels and lay.owner(nxt) == rank:
-                update(J, nxt)          # look-ahead: bring the next panel up to date first,
-                factor_and_pack(nxt)    # factor it and get its broadcast going
-            work = bcast(nxt) if nxt < lay.n_panels else None
-            for Jp in lay.mine:         # the rest of this rank's trailing panels
-                if Jp > nxt:
-                    update(J, Jp)
-            if work is not None:
-                work.wait()
 
-        # 3. scalars: |L^-1 (y - m)|^2 from the bordered row, logdet, info
-        for J in lay.mine:
-            nc = min(lay.width(J), max(0, N - lay.col0(J)))
-            if nc > 0:
-                ops.rowsumsq(A, lay.local_index(J) * W, m_tot, n_pad, nc, 1, sq)
-        red = torch.stack([logdet.reshape(()), sq.reshape(())])
-        inf = info.to(torch.float64)
-        big = float(2 ** 52)
-        inf = torch.where(inf > 0, inf, torch.full_like(inf, big))
-        if world > 1:
-            dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
-            dist.all_reduce(inf, op=dist.ReduceOp.MIN, group=group)
-        red_h = ops.to_host(red)
-        inf_h = float(ops.to_host(inf)[0])
-        if stats is not None:
-            stats.update(n_pad=n_pad, m_tot=m_tot, W=W, n_panels=lay.n_panels, local_panels=len(lay.mine),
-                         logdet=float(red_h[0]), sqmahal=float(red_h[1]))
-        if inf_h < big:
-            raise _lib.PosDefException(int(inf_h), "distributed Cholesky")
-        return -0.5 * (N * LOG2PI + float(red_h[0]) + float(red_h[1]))
-    finally:
-        ops.free_dspec(ds)
+    # 3. scalars: |L^-1 (y - m)|^2 from the bordered row, logdet, info
+    for J in lay.mine:
+        nc = min(lay.width(J), max(0, N - lay.col0(J)))
+        if nc > 0:
+            ops.rowsumsq(A, lay.local_index(J) * W, m_tot, n_pad, nc, 1, sq)
+    red = torch.stack([logdet.reshape(()), sq.reshape(())])
+    inf = info.to(torch.float64)
+    big = float(2 ** 52)
+    inf = torch.where(inf > 0, inf, torch.full_like(inf, big))
+    if world > 1:
+        dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(inf, op=dist.ReduceOp.MIN, group=group)
+    red_h = ops.to_host(red)
+    inf_h = float(ops.to_host(inf)[0])
+    if stats is not None:
+        stats.update(n_pad=n_pad, m_tot=m_tot, W=W, n_panels=lay.n_panels, local_panels=len(lay.mine),
+                     logdet=float(red_h[0]), sqmahal=float(red_h[1]))
+    if inf_h < big:
+        raise _lib.PosDefException(int(inf_h), "distributed Cholesky")
+    return -0.5 * (N * LOG2PI + float(red_h[0]) + float(red_h[1]))
 
 
 def _global_rank(group, r):

@@ -38,6 +38,10 @@ class NumpyOps:
     def synchronize(self):
         pass
 
+    def stream_context(self):
+        import contextlib
+        return contextlib.nullcontext()
+
     @staticmethod
     def _mat(A, col_off, m_tot, ncols):
         return A.numpy()[col_off * m_tot:(col_off + ncols) * m_tot].reshape(ncols, m_tot).T  # view (m_tot, ncols)
