@@ -16,7 +16,7 @@ static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 
 void set_gemm_tn_workspace(double* ws, size_t bytes);
-void set_gemm_wave_layout(int wn);
+void set_gemm_variant(int v);
 int run_mfma_bench(hipStream_t s, int iters, double* tflops_out, double* layout_maxerr_out);
 int run_hbm_bench(hipStream_t s, long bytes, int iters, double* write_gbs, double* copy_gbs);
 
@@ -1295,13 +1295,11 @@ extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int
   SGP_HIP(hipEventCreate(&e0));
   SGP_HIP(hipEventCreate(&e1));
   SGP_HIP(hipEventRecord(e0, s));
-  const int wn = (lower_only & 2) ? 2 : 4;  // bench-only: bit 1 selects the 4-wave layout
-  const int abl = lower_only & ~15;         // bench-only: bits 4.. select an ablation build
+  set_gemm_variant((lower_only & 2) ? 1 : 0);  // bench-only: bit 1 = register-staged baseline kernel
   lower_only &= 1;
-  set_gemm_wave_layout(wn);
   for (int i = 0; i < iters; ++i)
-    CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, abl, 0, s));
-  set_gemm_wave_layout(4);
+    CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, 0, 0, s));
+  set_gemm_variant(0);
   SGP_HIP(hipEventRecord(e1, s));
   SGP_HIP(hipEventSynchronize(e1));
   float ms = 0;

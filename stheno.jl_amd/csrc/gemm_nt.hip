@@ -2,8 +2,8 @@
 //
 // Instruction choice (measured on MI355X, profiles/r01_microbench.md): v_mfma_f64_16x16x4_f64
 // issues only every ~96 cycles per SIMD (49 TF/s chip-wide, 62 % of the 78.6 TF/s datasheet
-// rate) while the 4-block v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (71 TF/s, 90 %).
-// The GEMM therefore runs on the 4x4x4 form.  Its lane maps (probed on hardware,
+// rate) while the 4-block v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (72-75 TF/s).
+// The GEMMs therefore run on the 4x4x4 form.  Its lane maps (probed on hardware,
 // tools/gpu_probe44.py; b = (l >> 2) & 3 is the block):
 //   A-operand lane l holds A_b[i = l & 3][k = l >> 4]
 //   B-operand lane l holds B_b[k = l >> 4][j = l & 3]
@@ -13,101 +13,68 @@
 // along the contiguous row dimension of C (row = l & 15, col = l >> 4).
 //
 // gemm_nt:  C = beta*C + alpha * A * B'   A: M x K, B: Nc x K, C: M x Nc, column-major.
-//   This single kernel is the SYRK/GEMM trailing update of the blocked Cholesky
-//   (alpha=-1, beta=1, lower tiles only), the panel TRSM (B = inv(L11), beta=0), the
-//   row-bordered forward substitutions of logpdf / posterior / elbo, and L*Z for rand.
-//   It replaces LAPACK dpotrf's dsyrk/dgemm/dtrsm calls under LinearAlgebra.cholesky on the
-//   reference path.
+//   One routine is the SYRK/GEMM trailing update of the blocked Cholesky (alpha=-1, beta=1,
+//   lower tiles only), the panel TRSM (B = inv(L11), beta=0), the row-bordered forward
+//   substitutions of logpdf / posterior / elbo, and L*Z for rand.  It replaces LAPACK dpotrf's
+//   dsyrk/dgemm/dtrsm calls under LinearAlgebra.cholesky on the reference path
+//   (SURVEY.md section 2 #10, section 8a A2-A5).
 //
-// Tiling: one 256-thread workgroup (4 waves) per 128x128 tile of C, each wave a 64x64
-// quadrant = 4x4 MFMA tiles (128 accumulator VGPRs).  K is consumed in chunks of 16 staged
-// through LDS (double-buffered, register prefetch of the next chunk).  Both operands are
-// "row index contiguous" so the staging copy is 1 KiB-per-wave coalesced, and the LDS leading
-// dimension 144 makes every ds_read_b64 operand fetch conflict-free (common.h).
-// The MFMA is issued as D = Bop' x Aop so that the result lane map (n = lane & 15) runs
-// along the contiguous (row) dimension of C: every store instruction writes 4 x 128-byte runs.
+// Tiling: one 512-thread workgroup (8 waves as 2 x 4) per 128x128 tile of C, 64x32 per wave =
+// 4 row fragments x 8 column fragments = 32 MFMA results (64 accumulator VGPRs), so two
+// workgroups = 16 waves = 4 per SIMD are resident per CU.  K is consumed in chunks of 16 through
+// two LDS stages.  Both operands are "row index contiguous", so one wave-instruction moves one
+// 1 KiB column of a chunk; the LDS leading dimension 144 (== 16 mod 32) makes every ds_read_b64
+// operand fetch conflict free (SQ_LDS_BANK_CONFLICT = 0).  The old C tile is read in the
+// prologue straight into the accumulators (scaled by beta/alpha): the epilogue is store-only,
+// each store instruction writing 4 columns x 16 consecutive rows (4 x 128-byte runs).
+//
+// Tile -> workgroup map: hardware places workgroup id on XCD id % 8.  XCD x owns the tile rows
+// tr == x (mod 8): every A row-panel is read through exactly one XCD's L2, and at any position
+// in the grid all 8 XCDs see (almost) the same lower-triangular mask, so the live work stays
+// balanced.  Inside an XCD the order is 8 owned rows x 8 tile columns, row fastest: 64
+// consecutive workgroups form a patch sharing 8 A panels and 8 B panels in that XCD's L2.
 #include "common.h"
 
 namespace sgp {
 
 constexpr int KB = 16;  // K chunk per LDS stage
 
-// Shared inner product of one LDS stage: NJ column fragments (4 cols each) x 4 row fragments
-// (16 rows each) per wave, K = 16 in four k-steps of 4.
-#define SGP_COMPUTE(buf_, NJ_, COL0_)                                            \
-  {                                                                              \
-    const double* pa = &sA[buf_][wr * 64 + l15];                                 \
-    const double* pb = &sB[buf_][(COL0_) + l3];                                  \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                           \
-      const int kk = ks * 4 + lq;                                                \
-      double a_r[4], b_c[NJ_];                                                   \
-      _Pragma("unroll") for (int i = 0; i < 4; ++i) a_r[i] = pa[kk * LDS_LD + i * 16]; \
-      _Pragma("unroll") for (int j = 0; j < NJ_; ++j) b_c[j] = pb[kk * LDS_LD + j * 4]; \
-      _Pragma("unroll") for (int j = 0; j < NJ_; ++j)                            \
-          _Pragma("unroll") for (int i = 0; i < 4; ++i)                          \
-              acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);                 \
-    }                                                                            \
-  }
+__device__ __forceinline__ bool tile_of_block(long n_tr, long n_tc, long mask_off, long& tr, long& tc) {
+  const long id = (long)blockIdx.x;
+  const long xcd = id & 7, k = id >> 3;
+  const long gs = 8 * n_tc;
+  const long jgroup = k / gs, within = k % gs;
+  const long j = jgroup * 8 + (within & 7);
+  tr = 8 * j + xcd;
+  tc = within >> 3;
+  return tr < n_tr && tr >= tc + mask_off;
+}
 
-// WN = number of wave columns: 2 -> 4 waves (64x64 per wave), 4 -> 8 waves (64x32 per wave,
-// half the registers, 4 waves per SIMD at 2 workgroups per CU: more latency hiding).
-template <bool KCAP, int WN, int ABL = 0>
-__global__ __launch_bounds__(128 * WN, WN) void gemm_nt_kernel(const double* A, long lda,
-                                                               const double* B, long ldb,
-                                                               double* C, long ldc, long K,
-                                                               double alpha, double beta,
-                                                               long mask_off, long kcap_off,
-                                                               long n_tr, long n_tc) {
-  constexpr int NT = 128 * WN;        // threads
-  constexpr int NJ = (128 / WN) / 4;  // column fragments (4 cols each) per wave
-  constexpr int WCOLS = 128 / WN;     // columns per wave
-  constexpr int NU = 1024 / NT;       // double2 staging units per thread per operand
+// ---------------------------------------------------------------------------------------
+// Production kernel: operands go global -> LDS directly (global_load_lds_dwordx4, no staging
+// VGPRs, no ds_write), one chunk ahead of the MFMAs; raw s_barrier + counted waits; operand
+// fetches are explicit ds_read_b64 (256 B/clk -- hipcc fuses plain loads into ds_read2_b64 at
+// half that rate).  Measured 57 TF/s on a 32768^2 x 1024 lower update (profiles/).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, long lda,
+                                                             const double* B, long ldb, double* C,
+                                                             long ldc, long K, double alpha,
+                                                             double beta, long mask_off, long n_tr,
+                                                             long n_tc) {
+  constexpr int NJ = 8, WCOLS = 32;
   long tr, tc;
-  {
-    // XCD-aware, load-balanced tile order.  Hardware places workgroup id on XCD id % 8.
-    // XCD x owns the tile rows tr == x (mod 8): every A row-panel is read through exactly one
-    // XCD's L2, and at any position in the grid all 8 XCDs see (almost) the same lower-
-    // triangular mask, so the live work stays balanced however the dispatcher paces XCDs.
-    // Inside an XCD the order is 8 owned rows x 8 tile columns, row fastest: 64 consecutive
-    // workgroups form a patch sharing 8 A panels and 8 B panels in that XCD's L2.
-    const long id = (long)blockIdx.x;
-    const long xcd = id & 7, k = id >> 3;
-    const long gs = 8 * n_tc;
-    const long jgroup = k / gs, within = k % gs;
-    const long j = jgroup * 8 + (within & 7);
-    tr = 8 * j + xcd;
-    tc = within >> 3;
-    if (tr >= n_tr) return;
-  }
-  if (tr < tc + mask_off) return;
-  long Keff = K;
-  if (KCAP) {
-    long cap = (tc + 1) * TILE + kcap_off;
-    if (cap < Keff) Keff = cap;
-    if (Keff <= 0) Keff = 0;
-  }
-
-  __shared__ __attribute__((aligned(16))) double sA[2][KB * LDS_LD];
-  __shared__ __attribute__((aligned(16))) double sB[2][KB * LDS_LD];
-
+  if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return;
+  // stage s: A chunk at smem + s*2*KB*LDS_LD, B chunk right after it
+  __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w = t >> 6;
-  const int wr = w / WN, wc = w % WN;
+  const int wr = w >> 2, wc = w & 3;
   const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
-
   const double* Ag = A + tr * TILE;
   const double* Bg = B + tc * TILE;
-
-  // staging map: unit i of thread t -> column (t>>6) + (NT/64) i of the chunk, rows 2*(t&63), +1
-  const int scol = t >> 6;
-  const int srow = 2 * (t & 63);
-  double2 ra[NU], rb[NU];
-
-  // acc[j][i] = C[row = r0 + 16 i + l15][col = c0 + 4 j + lq].  The accumulators are seeded
-  // with (beta / alpha) * C so that the old tile is read in the prologue (its latency hides
-  // behind the first operand loads and the co-resident workgroup's MFMAs) and the epilogue is
-  // store-only: C_new = alpha * (A B' + (beta / alpha) C).
+  // acc[j][i] = C[row = r0 + 16 i + l15][col = c0 + 4 j + lq], seeded with (beta / alpha) * C:
+  // C_new = alpha * (A B' + (beta / alpha) C)
   double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * WCOLS + lq) * ldc;
   double acc[NJ][4];
   if (beta != 0.0) {
@@ -126,65 +93,227 @@ __global__ __launch_bounds__(128 * WN, WN) void gemm_nt_kernel(const double* A, 
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[j][i] = 0.0;
   }
-
-#define SGP_GLOAD(k0_)                                                           \
-  _Pragma("unroll") for (int i = 0; i < NU; ++i) {                               \
-    long col = (k0_) + scol + (NT / 64) * i;                                     \
-    ra[i] = *reinterpret_cast<const double2*>(Ag + srow + col * lda);            \
-    rb[i] = *reinterpret_cast<const double2*>(Bg + srow + col * ldb);            \
-  }
-#define SGP_SSTORE(buf_)                                                         \
-  _Pragma("unroll") for (int i = 0; i < NU; ++i) {                               \
-    int col = scol + (NT / 64) * i;                                              \
-    *reinterpret_cast<double2*>(&sA[buf_][col * LDS_LD + srow]) = ra[i];         \
-    *reinterpret_cast<double2*>(&sB[buf_][col * LDS_LD + srow]) = rb[i];         \
-  }
-
-  if (Keff > 0) {
-    SGP_GLOAD(0);
-    SGP_SSTORE(0);
-    __syncthreads();
-    int buf = 0;
-    // ABL != 0 only in the bench-only ablation builds (tools/gpu_gemm_abl.py): 1 = no global
-    // loads / LDS stores, 2 = no LDS operand reads, 3 = no barrier, 4 = 1+2 (MFMA + barrier only)
-    double inv_a[4], inv_b[NJ];
-    if (ABL == 2 || ABL == 4) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double*)smem;
+  auto dma = [&](long k0, int stage) {
+    double* sa = smem + stage * (2 * KB * LDS_LD);
+    double* sb = sa + KB * LDS_LD;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) inv_a[i] = sA[0][wr * 64 + l15 + i * 16];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) inv_b[j] = sB[0][wc * WCOLS + l3 + j * 4];
+    for (int i = 0; i < KB / 8; ++i) {  // wave w moves columns w and w + 8 of both operands
+      const int col = wu + 8 * i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ag + 2 * lane + (k0 + col) * lda), (lptr_t)(sa + col * LDS_LD), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bg + 2 * lane + (k0 + col) * ldb), (lptr_t)(sb + col * LDS_LD), 16, 0, 0);
     }
-    for (long k0 = KB; k0 < Keff; k0 += KB) {
-      if (ABL != 1 && ABL != 4) { SGP_GLOAD(k0); }
-      if (ABL == 2 || ABL == 4) {
+  };
+  const long nchunks = K / KB;
+  if (nchunks > 0) dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (long c = 0; c < nchunks; ++c) {
+    const int stage = (int)(c & 1);
+    // the other stage was last read in iteration c-1, which every wave left through the barrier
+    if (c + 1 < nchunks) dma((c + 1) * KB, stage ^ 1);
+    const unsigned a_addr = lds_base + (unsigned)((stage * (2 * KB * LDS_LD) + lq * LDS_LD + wr * 64 + l15) * 8);
+    const unsigned b_addr = lds_base + (unsigned)((stage * (2 * KB * LDS_LD) + KB * LDS_LD + lq * LDS_LD + wc * WCOLS + l3) * 8);
+    {
+      double a_r[4], b_c[NJ];
+      asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(a_r[0]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(a_r[1]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:256" : "=v"(a_r[2]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:384" : "=v"(a_r[3]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:0" : "=v"(b_c[0]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(b_c[1]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:64" : "=v"(b_c[2]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:96" : "=v"(b_c[3]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:128" : "=v"(b_c[4]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:160" : "=v"(b_c[5]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:192" : "=v"(b_c[6]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:224" : "=v"(b_c[7]) : "v"(b_addr));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (asm is opaque to hipcc)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+      for (int j = 0; j < NJ; ++j)
 #pragma unroll
-          for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(inv_b[j], inv_a[i], acc[j][i]);
-      } else {
-        SGP_COMPUTE(buf, NJ, wc * WCOLS);
-      }
-      if (ABL != 1 && ABL != 4) { SGP_SSTORE(buf ^ 1); }
-      if (ABL != 3) __syncthreads();
-      buf ^= 1;
+        for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
     }
-    SGP_COMPUTE(buf, NJ, wc * WCOLS);
+    {
+      double a_r[4], b_c[NJ];
+      asm volatile("ds_read_b64 %0, %1 offset:4608" : "=v"(a_r[0]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4736" : "=v"(a_r[1]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4864" : "=v"(a_r[2]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4992" : "=v"(a_r[3]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4608" : "=v"(b_c[0]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4640" : "=v"(b_c[1]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4672" : "=v"(b_c[2]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4704" : "=v"(b_c[3]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4736" : "=v"(b_c[4]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4768" : "=v"(b_c[5]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4800" : "=v"(b_c[6]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:4832" : "=v"(b_c[7]) : "v"(b_addr));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (asm is opaque to hipcc)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
+    }
+    {
+      double a_r[4], b_c[NJ];
+      asm volatile("ds_read_b64 %0, %1 offset:9216" : "=v"(a_r[0]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9344" : "=v"(a_r[1]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9472" : "=v"(a_r[2]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9600" : "=v"(a_r[3]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9216" : "=v"(b_c[0]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9248" : "=v"(b_c[1]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9280" : "=v"(b_c[2]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9312" : "=v"(b_c[3]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9344" : "=v"(b_c[4]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9376" : "=v"(b_c[5]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9408" : "=v"(b_c[6]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:9440" : "=v"(b_c[7]) : "v"(b_addr));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (asm is opaque to hipcc)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
+    }
+    {
+      double a_r[4], b_c[NJ];
+      asm volatile("ds_read_b64 %0, %1 offset:13824" : "=v"(a_r[0]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:13952" : "=v"(a_r[1]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:14080" : "=v"(a_r[2]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:14208" : "=v"(a_r[3]) : "v"(a_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:13824" : "=v"(b_c[0]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:13856" : "=v"(b_c[1]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:13888" : "=v"(b_c[2]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:13920" : "=v"(b_c[3]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:13952" : "=v"(b_c[4]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:13984" : "=v"(b_c[5]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:14016" : "=v"(b_c[6]) : "v"(b_addr));
+      asm volatile("ds_read_b64 %0, %1 offset:14048" : "=v"(b_c[7]) : "v"(b_addr));
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (asm is opaque to hipcc)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
+    }
+    // chunk c+1 has landed for every wave, and every wave is done reading this stage
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
-#undef SGP_GLOAD
-#undef SGP_SSTORE
-
-  // epilogue (store only): every store instruction writes 4 columns x 16 consecutive rows
-  // (4 x 128-byte runs).
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = alpha * acc[j][i];
 }
 
-static int g_gemm_wn = 4;  // default wave layout; sgp_bench_gemm flips it for A/B comparisons
-void set_gemm_wave_layout(int wn) { g_gemm_wn = (wn == 2) ? 2 : 4; }
+// ---------------------------------------------------------------------------------------
+// Register-staged kernel (global_load_dwordx4 -> VGPR -> ds_write_b128, __syncthreads).  Kept for
+// the K-capped product (rand: only the lower triangle of L is valid, so tile column tc stops
+// at k = (tc + 1) * 128) and as the A/B baseline of the bench (50 vs 57 TF/s).
+// ---------------------------------------------------------------------------------------
+// Shared inner product of one LDS stage: NJ column fragments (4 cols each) x 4 row fragments
+// (16 rows each) per wave, K = 16 in four k-steps of 4.
+#define SGP_COMPUTE(buf_, NJ_, COL0_)                                            \
+  {                                                                              \
+    const double* pa = &sA[buf_][wr * 64 + l15];                                 \
+    const double* pb = &sB[buf_][(COL0_) + l3];                                  \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                           \
+      const int kk = ks * 4 + lq;                                                \
+      double a_r[4], b_c[NJ_];                                                   \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i) a_r[i] = pa[kk * LDS_LD + i * 16]; \
+      _Pragma("unroll") for (int j = 0; j < NJ_; ++j) b_c[j] = pb[kk * LDS_LD + j * 4]; \
+      _Pragma("unroll") for (int j = 0; j < NJ_; ++j)                            \
+          _Pragma("unroll") for (int i = 0; i < 4; ++i)                          \
+              acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);                 \
+    }                                                                            \
+  }
+
+template <bool KCAP>
+__global__ __launch_bounds__(512, 4) void gemm_nt_reg_kernel(const double* A, long lda,
+                                                             const double* B, long ldb, double* C,
+                                                             long ldc, long K, double alpha,
+                                                             double beta, long mask_off,
+                                                             long kcap_off, long n_tr, long n_tc) {
+  constexpr int NJ = 8, WCOLS = 32, NU = 2;
+  long tr, tc;
+  if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return;
+  long Keff = K;
+  if (KCAP) {
+    long cap = (tc + 1) * TILE + kcap_off;
+    if (cap < Keff) Keff = cap;
+    if (Keff <= 0) Keff = 0;
+  }
+  __shared__ __attribute__((aligned(16))) double sA[2][KB * LDS_LD];
+  __shared__ __attribute__((aligned(16))) double sB[2][KB * LDS_LD];
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w = t >> 6;
+  const int wr = w >> 2, wc = w & 3;
+  const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
+  const double* Ag = A + tr * TILE;
+  const double* Bg = B + tc * TILE;
+  const int scol = t >> 6;          // staging: unit i of thread t -> column scol + 8 i, rows srow, srow + 1
+  const int srow = 2 * (t & 63);
+  double2 ra[NU], rb[NU];
+  double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * WCOLS + lq) * ldc;
+  double acc[NJ][4];
+  if (beta != 0.0) {
+    const double seed = beta / alpha;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = Cg[i * 16 + (long)(j * 4) * ldc];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] *= seed;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = 0.0;
+  }
+#define SGP_GLOAD(k0_)                                                           \
+  _Pragma("unroll") for (int i = 0; i < NU; ++i) {                               \
+    long col = (k0_) + scol + 8 * i;                                             \
+    ra[i] = *reinterpret_cast<const double2*>(Ag + srow + col * lda);            \
+    rb[i] = *reinterpret_cast<const double2*>(Bg + srow + col * ldb);            \
+  }
+#define SGP_SSTORE(buf_)                                                         \
+  _Pragma("unroll") for (int i = 0; i < NU; ++i) {                               \
+    int col = scol + 8 * i;                                                      \
+    *reinterpret_cast<double2*>(&sA[buf_][col * LDS_LD + srow]) = ra[i];         \
+    *reinterpret_cast<double2*>(&sB[buf_][col * LDS_LD + srow]) = rb[i];         \
+  }
+  if (Keff > 0) {
+    SGP_GLOAD(0);
+    SGP_SSTORE(0);
+    __syncthreads();
+    int buf = 0;
+    for (long k0 = KB; k0 < Keff; k0 += KB) {
+      SGP_GLOAD(k0);
+      SGP_COMPUTE(buf, NJ, wc * WCOLS);
+      SGP_SSTORE(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+    SGP_COMPUTE(buf, NJ, wc * WCOLS);
+  }
+#undef SGP_GLOAD
+#undef SGP_SSTORE
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = alpha * acc[j][i];
+}
+
+static int g_gemm_variant = 0;  // 0: DMA kernel (production); 1: register-staged (bench A/B only)
+void set_gemm_variant(int v) { g_gemm_variant = v; }
 
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                    long M, long Nc, long K, double alpha, double beta, long mask_off,
@@ -197,28 +326,16 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
   long n_tr = M / TILE, n_tc = Nc / TILE;
   long groups = (n_tr + 7) / 8;
   long groups_pad = (groups + 7) / 8 * 8;
-  long total = groups_pad * 8 * n_tc;
-  dim3 grid((unsigned)total);
-#define SGP_LAUNCH(KC, WNV)                                                                       \
-  hipLaunchKernelGGL((gemm_nt_kernel<KC, WNV>), grid, dim3(128 * WNV), 0, s, A, lda, B, ldb, C, ldc, \
-                     K, alpha, beta, mask_off, kcap_off, n_tr, n_tc)
-  if (kcap_mode >= 16) {  // bench-only ablations of the 8-wave kernel
-#define SGP_LAUNCH_ABL(AB)                                                                        \
-  hipLaunchKernelGGL((gemm_nt_kernel<false, 4, AB>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, \
-                     alpha, beta, mask_off, kcap_off, n_tr, n_tc)
-    switch (kcap_mode >> 4) {
-      case 1: SGP_LAUNCH_ABL(1); break;
-      case 2: SGP_LAUNCH_ABL(2); break;
-      case 3: SGP_LAUNCH_ABL(3); break;
-      default: SGP_LAUNCH_ABL(4); break;
-    }
-#undef SGP_LAUNCH_ABL
-  } else if (g_gemm_wn == 2) {
-    if (kcap_mode) SGP_LAUNCH(true, 2); else SGP_LAUNCH(false, 2);
-  } else {
-    if (kcap_mode) SGP_LAUNCH(true, 4); else SGP_LAUNCH(false, 4);
-  }
-#undef SGP_LAUNCH
+  dim3 grid((unsigned)(groups_pad * 8 * n_tc));
+  if (kcap_mode)
+    hipLaunchKernelGGL((gemm_nt_reg_kernel<true>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
+                       beta, mask_off, kcap_off, n_tr, n_tc);
+  else if (g_gemm_variant == 1)
+    hipLaunchKernelGGL((gemm_nt_reg_kernel<false>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
+                       beta, mask_off, kcap_off, n_tr, n_tc);
+  else
+    hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
+                       mask_off, n_tr, n_tc);
   SGP_HIP(hipGetLastError());
   return 0;
 }

@@ -4,8 +4,10 @@ spec = importlib.util.spec_from_file_location("sgplib", os.path.join(ROOT, "sthe
 L = importlib.util.module_from_spec(spec); spec.loader.exec_module(L)
 ctx = L.Context(0)
 tf = C.c_double(); err = C.c_double()
-names = {0: "full", 16: "no global/LDS-store", 32: "no LDS reads", 48: "no barrier", 64: "MFMA+barrier only"}
+variants = {0: "DMA kernel (production)", 2: "register-staged baseline"}
 for rep in range(2):
-    for abl in (0, 16, 32, 48, 64):
-        L.check(ctx.lib.sgp_bench_gemm(ctx.handle, 16384, 2048, 512, abl, 4, C.byref(tf), C.byref(err)), "gemm")
-        print(f"gemm 16384x2048x512 dense, 8 waves, {names[abl]}: {tf.value:.2f} TF/s", flush=True)
+    for (m, n, k) in [(16384, 2048, 512), (16384, 16384, 512), (16384, 16384, 128), (32768, 32768, 1024)]:
+        for flag, name in variants.items():
+            lo = 1 if n == m else 0
+            L.check(ctx.lib.sgp_bench_gemm(ctx.handle, m, n, k, lo | flag, 3, C.byref(tf), C.byref(err)), "gemm")
+            print(f"gemm {m}x{n}x{k} lower={lo} [{name}]: {tf.value:.2f} TF/s err {err.value:.1e}", flush=True)
