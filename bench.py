@@ -36,10 +36,12 @@ sys.path.insert(0, ROOT)
 PEAK_FP64_MFMA_TFLOPS = 78.6   # MI355X datasheet FP64 matrix rate; measured
                                # instruction ceilings are in DESIGN.md section 5
 CONFIGS = {
-    # name: (kernel, N, D)
+    # name: (kernel, N, D)        BASELINE.json configs[0..4] = c1..c5
     "c5": ("matern52", 65536, 8),
     "c2": ("se", 16384, 8),
     "c1": ("se", 2048, 2),
+    "c3": ("gppp3", 32768, 4),     # @gppp f3 = f1 + f2 over BlockData (:f1,10923),(:f2,10923),(:f3,10922)
+    "c4": ("elbo", 262144, 8),     # sparse ELBO, M = 4096 inducing points (host-buffer C-ABI call)
     "n32k": ("matern52", 32768, 8),
     "n4k": ("matern52", 4096, 8),
 }
@@ -129,8 +131,26 @@ def main():
 
     kernel, N, D = CONFIGS[args.config]
     X, y = make_inputs(N, D)
-    f = pkg.stretch(build_model(pkg, kernel), 1.0 / math.sqrt(D))
-    spec, _, _ = pkg.build_spec(f, pkg.ColVecs(X))
+    elbo_step = None
+    if kernel == "gppp3":
+        F = pkg.gppp_sum_model()
+        n1 = (N + 2) // 3
+        cuts = [0, n1, 2 * n1, N]
+        xb = pkg.BlockData([pkg.GPPPInput(k, pkg.ColVecs(np.asfortranarray(X[:, cuts[i]:cuts[i + 1]] / math.sqrt(D))))
+                            for i, k in enumerate(("f1", "f2", "f3"))])
+        spec, _, _ = pkg.build_spec(F, xb)
+    elif kernel == "elbo":
+        if world > 1:
+            raise SystemExit("config c4 (ELBO) is a single-GPU bench line")
+        f = pkg.stretch(build_model(pkg, "se"), 1.0 / math.sqrt(D))
+        M = 4096
+        Z = np.asfortranarray(X[:, np.random.default_rng(7).permutation(N)[:M]])
+        fx, fz = f(pkg.ColVecs(X), 0.1), f(pkg.ColVecs(Z), 1e-6)
+        elbo_step = lambda: pkg.elbo(pkg.VFE(fz), fx, y)   # noqa: E731
+        spec, _, _ = pkg.build_spec(f, pkg.ColVecs(Z))
+    else:
+        f = pkg.stretch(build_model(pkg, kernel), 1.0 / math.sqrt(D))
+        spec, _, _ = pkg.build_spec(f, pkg.ColVecs(X))
     ctx = L.Context(local_rank)
     lib = ctx.lib
     sigma2 = 0.1
@@ -141,7 +161,10 @@ def main():
         torch.cuda.synchronize()
 
     timings = np.zeros(8)
-    if world == 1:
+    if elbo_step is not None:
+        def step(tm=None):
+            return elbo_step()
+    elif world == 1:
         ds = C.c_void_p()
         L.check(lib.sgp_dspec_create(ctx.handle, spec.ref(), C.byref(ds)), "sgp_dspec_create")
         npad, mtot = C.c_int64(), C.c_int64()
@@ -183,7 +206,7 @@ def main():
     # one extra (untimed) instrumented step on 1 GPU: stage split + per-launch GEMM timing
     roofline = None
     stages = None
-    if world == 1:
+    if world == 1 and elbo_step is None:
         step(timings)
         upd_ms, n_launch, upd_flops = timings[3], int(timings[4]), timings[5]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
@@ -194,23 +217,35 @@ def main():
             "launches": n_launch, "avg_launch_ms": upd_ms / max(1, n_launch),
             "algorithmic_flops_per_launch_avg": upd_flops / max(1, n_launch),
         }
+        # HBM traffic cannot be read without rocprofv3; the committed PMC passes of one
+        # representative launch of this kernel (tools/gpu_gemm_one.py, separate --pmc runs) are
+        # attached for reference -- `traffic` itself stays null in the live line.
+        pmc = os.path.join(ROOT, "profiles", "r01_gemm_pmc.json")
+        if os.path.exists(pmc):
+            roofline["traffic_profiled"] = json.load(open(pmc))
         stages = {"assemble_ms": timings[0], "cholesky_ms": timings[1], "finalize_ms": timings[2],
                   "kernelmatrix_GBps": (8.0 * N * (N + 1) / 2 + 8.0 * D * N) / (timings[0] * 1e-3) / 1e9}
     chol_tflops = (N ** 3 / 3.0) / (ms_per_step * 1e-3) / 1e12
+    if elbo_step is not None:   # 2 M^2 N + 2 M^3/3 + 2 D M N flops
+        M = 4096
+        chol_tflops = (2.0 * M * M * N + 2.0 * M ** 3 / 3.0 + 2.0 * D * M * N) / (ms_per_step * 1e-3) / 1e12
 
     if rank == 0:
         cpu = None
-        if args.cpu_sample > 0 and world == 1:
+        if args.cpu_sample > 0 and world == 1 and kernel in ("se", "matern52"):
             cpu = cpu_baseline(kernel, D, min(args.cpu_sample, N), N)
         line = {
-            "metric": "logpdf_per_sec", "value": 1e3 / ms_per_step, "unit": "logpdf/s", "n_gpus": world,
+            "metric": "elbo_per_sec" if elbo_step is not None else "logpdf_per_sec",
+            "value": 1e3 / ms_per_step, "unit": "elbo/s" if elbo_step is not None else "logpdf/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"single GP, {kernel}, N={N}, D={D}, lengthscale sqrt(D), sigma2=0.1 "
-                                   f"(BASELINE config '{args.config}')",
+            "config": {"workload": ({"gppp3": f"@gppp f3=f1+f2 (SE + Matern52) over 3 BlockData blocks, total N={N}, D={D}",
+                                     "elbo": f"sparse ELBO, SE, M=4096 inducing points, N={N}, D={D}, host-buffer C-ABI"}
+                                    .get(kernel, f"single GP, {kernel}, N={N}, D={D}") +
+                                    f", lengthscale sqrt(D), sigma2=0.1 (BASELINE config '{args.config}')"),
                        "N": N, "D": D, "kernel": kernel, "parallelism": f"column-panel x{world}" if world > 1 else "1 GPU",
                        "panel_width": args.panel if world > 1 else None},
-            "cholesky_tflops_whole_step": chol_tflops,
+            "cholesky_tflops_whole_step": chol_tflops,  # (c4: ELBO flops of SURVEY 8d)
             "cholesky_frac_of_fp64_matrix_peak": chol_tflops / (PEAK_FP64_MFMA_TFLOPS * world),
             "logpdf": val, "stages": stages, "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -346,50 +346,47 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
 // bordered rows (N x M) and N is huge.  Staging transposes through
 // LDS: chunk of 16 k-rows x 128 columns per operand.
 // ---------------------------------------------------------------------------------------
-constexpr int TN_LD = 130;  // LDS ld for [col][k] layout: element (k, c) at c*... see below
-
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const double* A, long lda,
+__global__ __launch_bounds__(512, 4) void gemm_tn_kernel(const double* A, long lda,
                                                          const double* B, long ldb, double* C,
                                                          long ldc, long K, double alpha,
                                                          double beta, int lower_only,
                                                          long k_per_split, double* Cpart,
                                                          long part_stride) {
+  constexpr int NJ = 8, WCOLS = 32;
   const long tr = blockIdx.x, tc = blockIdx.y;
   const long ksplit = blockIdx.z;
   if (lower_only && tr < tc) return;
-  // LDS layout [k][row] with ld LDS_LD, same as gemm_nt, so the compute loop is identical;
-  // the global read is the transposing part: thread reads along k (contiguous) for one column.
+  // LDS layout [k][row] with ld LDS_LD, same as gemm_nt, so the compute loop is identical; the
+  // global read is the transposing part: a thread reads along k (contiguous) for one column.
   __shared__ __attribute__((aligned(16))) double sA[2][KB * LDS_LD];
   __shared__ __attribute__((aligned(16))) double sB[2][KB * LDS_LD];
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
-  const int wr = w >> 1, wc = w & 1;
+  const int wr = w >> 2, wc = w & 3;
   const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
   const long kbeg = ksplit * k_per_split;
   long kend = kbeg + k_per_split;
   if (kend > K) kend = K;
-
-  // staging: chunk = 16 (k) x 128 (cols) per operand = 2048 doubles; thread t handles
-  // column c = t & 127 and k-half h = t >> 7 (8 consecutive k) -> 4 double2 loads.
-  const int sc = t & 127, sh = t >> 7;
+  // staging: chunk = 16 (k) x 128 (cols) per operand; thread t handles column t & 127 and the
+  // 4 consecutive k of quarter t >> 7 -> 2 double2 loads per operand.
+  const int sc = t & 127, sq = t >> 7;
   const double* Ag = A + (tr * TILE + sc) * lda;
   const double* Bg = B + (tc * TILE + sc) * ldb;
-  double2 ra[4], rb[4];
-  double acc[16][4];  // acc[j][i] = C[row = r0 + 16 i + l15][col = c0 + 4 j + lq]
+  double2 ra[2], rb[2];
+  double acc[NJ][4];
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) acc[j][i] = 0.0;
-
 #define SGP_TN_GLOAD(k0_)                                                        \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
-    long k = (k0_) + sh * 8 + 2 * i;                                             \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
+    long k = (k0_) + sq * 4 + 2 * i;                                             \
     ra[i] = *reinterpret_cast<const double2*>(Ag + k);                           \
     rb[i] = *reinterpret_cast<const double2*>(Bg + k);                           \
   }
 #define SGP_TN_SSTORE(buf_)                                                      \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                \
-    int k = sh * 8 + 2 * i;                                                      \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
+    int k = sq * 4 + 2 * i;                                                      \
     sA[buf_][k * LDS_LD + sc] = ra[i].x;                                         \
     sA[buf_][(k + 1) * LDS_LD + sc] = ra[i].y;                                   \
     sB[buf_][k * LDS_LD + sc] = rb[i].x;                                         \
@@ -402,26 +399,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const double* A, long l
     int buf = 0;
     for (long k0 = kbeg + KB; k0 < kend; k0 += KB) {
       SGP_TN_GLOAD(k0);
-      SGP_COMPUTE(buf, 16, wc * 64);
+      SGP_COMPUTE(buf, NJ, wc * WCOLS);
       SGP_TN_SSTORE(buf ^ 1);
       __syncthreads();
       buf ^= 1;
     }
-    SGP_COMPUTE(buf, 16, wc * 64);
+    SGP_COMPUTE(buf, NJ, wc * WCOLS);
   }
+#undef SGP_TN_GLOAD
+#undef SGP_TN_SSTORE
   if (Cpart) {
     // split-K: write the partial tile; a second kernel reduces in fixed order (deterministic)
     double* P = Cpart + ksplit * part_stride + (tr * TILE + wr * 64 + l15) +
-                (tc * TILE + wc * 64 + lq) * ldc;
+                (tc * TILE + wc * WCOLS + lq) * ldc;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int i = 0; i < 4; ++i) P[i * 16 + (long)(j * 4) * ldc] = acc[j][i];
     return;
   }
-  double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * 64 + lq) * ldc;
+  double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * WCOLS + lq) * ldc;
 #pragma unroll
-  for (int j = 0; j < 16; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       double* p = Cg + i * 16 + (long)(j * 4) * ldc;
@@ -488,7 +487,7 @@ int launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double*
       part = g_tn_ws;
     }
   }
-  dim3 grid((unsigned)n_tr, (unsigned)n_tc, (unsigned)nsplit), block(256);
+  dim3 grid((unsigned)n_tr, (unsigned)n_tc, (unsigned)nsplit), block(512);
   hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
                      lower_only, k_per, part, stride);
   SGP_HIP(hipGetLastError());

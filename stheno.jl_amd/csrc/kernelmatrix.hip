@@ -21,28 +21,49 @@ namespace sgp {
 
 enum { K_SE = 0, K_M12 = 1, K_M32 = 2, K_M52 = 3, K_WHITE = 4, K_CONST = 5 };
 
+template <int KIND>
+__device__ __forceinline__ double kern_eval_t(double d2, double param) {
+  if (KIND == K_SE) return exp(-0.5 * d2);
+  if (KIND == K_M12) return exp(-sqrt(d2));
+  if (KIND == K_M32) {
+    double l = 1.7320508075688772 * sqrt(d2);
+    return (1.0 + l) * exp(-l);
+  }
+  if (KIND == K_M52) {
+    double l = 2.23606797749979 * sqrt(d2);
+    return (1.0 + l + l * l / 3.0) * exp(-l);
+  }
+  if (KIND == K_WHITE) return d2 == 0.0 ? 1.0 : 0.0;
+  return param;
+}
+
 __device__ __forceinline__ double kern_eval(int kind, double d2, double param) {
   switch (kind) {
-    case K_SE:
-      return exp(-0.5 * d2);
-    case K_M12:
-      return exp(-sqrt(d2));
-    case K_M32: {
-      double l = 1.7320508075688772 * sqrt(d2);
-      return (1.0 + l) * exp(-l);
-    }
-    case K_M52: {
-      double l = 2.23606797749979 * sqrt(d2);
-      return (1.0 + l + l * l / 3.0) * exp(-l);
-    }
-    case K_WHITE:
-      return d2 == 0.0 ? 1.0 : 0.0;
-    default:
-      return param;
+    case K_SE: return kern_eval_t<K_SE>(d2, param);
+    case K_M12: return kern_eval_t<K_M12>(d2, param);
+    case K_M32: return kern_eval_t<K_M32>(d2, param);
+    case K_M52: return kern_eval_t<K_M52>(d2, param);
+    case K_WHITE: return kern_eval_t<K_WHITE>(d2, param);
+    default: return param;
   }
 }
 
 constexpr int CCHUNK = 8;  // columns processed per accumulator chunk
+
+template <int DMAX, int KIND>
+__device__ __forceinline__ void term_chunk(double (&acc)[CCHUNK], const double (&xi)[DMAX],
+                                           const double* sp, const double (&cw)[CCHUNK], double param) {
+#pragma unroll
+  for (int q = 0; q < CCHUNK; ++q) {
+    double d2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+      double df = xi[d] - sp[q * DMAX + d];
+      d2 = fma(df, df, d2);
+    }
+    acc[q] = fma(kern_eval_t<KIND>(d2, param), cw[q], acc[q]);
+  }
+}
 
 template <int DMAX>
 __global__ __launch_bounds__(256) void assemble_block_kernel(
@@ -103,21 +124,22 @@ __global__ __launch_bounds__(256) void assemble_block_kernel(
       }
       const double rsv = T.coef * (T.rs ? T.rs[lrow] : 1.0);
       const double* sp = &smem[(tm * TILE + pbase) * DMAX];
+      double cw[CCHUNK];
 #pragma unroll
       for (int q = 0; q < CCHUNK; ++q) {
-        double d2 = 0.0;
-#pragma unroll
-        for (int d = 0; d < DMAX; ++d) {
-          double df = xi[d] - sp[q * DMAX + d];
-          d2 = fma(df, df, d2);
-        }
-        double kv = kern_eval(T.kind, d2, T.param) * rsv;
-        if (T.cs) {
-          long gc = gtc * TILE + pbase + q;
-          long lc = gc - c0;
-          kv *= (gc >= cbeg && gc < cend) ? T.cs[lc] : 0.0;
-        }
-        acc[q] += kv;
+        long gc = gtc * TILE + pbase + q;
+        cw[q] = rsv;
+        if (T.cs) cw[q] = (gc >= cbeg && gc < cend) ? rsv * T.cs[gc - c0] : 0.0;
+      }
+      // the kind switch is hoisted out of the element loop: each case is straight-line code over
+      // the CCHUNK independent entries, so their exp/sqrt chains interleave (ILP)
+      switch (T.kind) {
+        case K_SE: term_chunk<DMAX, K_SE>(acc, xi, sp, cw, T.param); break;
+        case K_M12: term_chunk<DMAX, K_M12>(acc, xi, sp, cw, T.param); break;
+        case K_M32: term_chunk<DMAX, K_M32>(acc, xi, sp, cw, T.param); break;
+        case K_M52: term_chunk<DMAX, K_M52>(acc, xi, sp, cw, T.param); break;
+        case K_WHITE: term_chunk<DMAX, K_WHITE>(acc, xi, sp, cw, T.param); break;
+        default: term_chunk<DMAX, K_CONST>(acc, xi, sp, cw, T.param); break;
       }
     }
 #pragma unroll
@@ -253,10 +275,10 @@ __global__ void diag_terms_kernel(double* out, long n, const DevTerm* terms, int
       double df = T.xr[i * T.ldr + d] - T.xc[i * T.ldc + d];
       d2 = fma(df, df, d2);
     }
-    double kv = kern_eval(T.kind, d2, T.param) * T.coef;
-    if (T.rs) kv *= T.rs[i];
-    if (T.cs) kv *= T.cs[i];
-    acc += kv;
+    // same operation order as assemble_block_kernel, so var(f, x) == diag(cov(f, x)) bit for bit
+    double cw = T.coef * (T.rs ? T.rs[i] : 1.0);
+    if (T.cs) cw = cw * T.cs[i];
+    acc = fma(kern_eval(T.kind, d2, T.param), cw, acc);
   }
   out[i] = acc;
 }

@@ -347,3 +347,47 @@ def test_golden_sklearn_vectors():
         Xs = P.ColVecs(np.asfortranarray(np.array(case["Xs"]).T))
         m, v = post.mean_and_var(Xs)
         assert rel(m, case["mean"]) < 1e-8 and np.abs(np.sqrt(v) - np.array(case["std"])).max() < 1e-8
+
+
+# ---- edge cases: empty / single-point / ragged blocks, many right-hand sides -----------------------
+def test_ragged_and_empty_blocks():
+    rng = np.random.default_rng(11)
+    Fo, Fp, fo, fp = both(models.gppp_docstring)
+    xs = [rng.standard_normal(1), np.zeros(0), rng.standard_normal(257)]
+    xo, xp = blockdata(["f1", "f2", "f3"], xs, False)
+    N = 258
+    y = rng.standard_normal(N)
+    lo, lp = oagp.logpdf(Fo(xo, 0.3), y), P.logpdf(Fp(xp, 0.3), y)
+    assert abs(lp - lo) <= REL * abs(lo)
+    Ko, Kp = Fo.cov(xo), P.prior_cov(Fp, xp)
+    assert Kp.shape == (N, N) and np.abs(Kp - Ko).max() < 1e-12
+    post_o, post_p = oagp.posterior(Fo(xo, 0.3), y), P.posterior(Fp(xp, 0.3), y)
+    t = rng.standard_normal(3)
+    mo, vo = post_o.mean_and_var(ost.GPPPInput("f2", t))
+    mp, vp = post_p.mean_and_var(P.GPPPInput("f2", t))
+    assert rel(mp, mo) < 1e-9 and np.abs(vp - vo).max() < 1e-10
+
+
+@pytest.mark.parametrize("S", [1, 5, 130])
+def test_many_right_hand_sides(S):
+    rng = np.random.default_rng(S)
+    N = 333
+    fo = ost.atomic(oagp.GP(okf.Matern32Kernel()), ost.GPC())
+    fp = P.atomic(P.GP(P.Matern32Kernel()), P.GPC())
+    x = rng.standard_normal(N)
+    Y = rng.standard_normal((N, S))
+    Lo, Lp = oagp.logpdf(fo(x, 0.2), Y), P.logpdf(fp(x, 0.2), Y)
+    assert Lp.shape == (S,) and rel(Lp, Lo) < REL
+    Z = rng.standard_normal((N, S))
+    assert rel(P.rand(None, fp(x, 0.2), S, Z=Z), oagp.rand(fo(x, 0.2), Z)) < 1e-11
+
+
+def test_input_dimension_limit_is_reported():
+    f = P.atomic(P.GP(P.SEKernel()), P.GPC())
+    X = P.ColVecs(np.zeros((65, 4)))
+    with pytest.raises(P.SthenoMIError) as ei:
+        P.prior_cov(f, X)
+    assert "dimension" in str(ei.value)
+    X64 = P.ColVecs(np.random.default_rng(0).standard_normal((64, 40)))
+    K = P.prior_cov(f, X64)
+    assert np.abs(K - okf.kernelmatrix(okf.SEKernel(), okf.ColVecs(X64.X), faithful=False)).max() < 1e-13
