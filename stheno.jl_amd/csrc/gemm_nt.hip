@@ -28,10 +28,10 @@
 // prologue straight into the accumulators (scaled by beta/alpha): the epilogue is store-only,
 // each store instruction writing 4 columns x 16 consecutive rows (4 x 128-byte runs).
 //
-// Tile -> workgroup map: hardware places workgroup id on XCD id % 8.  XCD x owns the tile rows
-// tr == x (mod 8): every A row-panel is read through exactly one XCD's L2, and at any position
-// in the grid all 8 XCDs see (almost) the same lower-triangular mask, so the live work stays
-// balanced.  Inside an XCD the order is 8 owned rows x 8 tile columns, row fastest: 64
+// Tile -> workgroup map: hardware places workgroup id on XCD id % 8.  XCD x owns one tile row
+// out of every 8 (row 8j + x for even j, 8j + 7 - x for odd j, so that the live-tile counts under
+// the lower-triangular mask are equal): every A row-panel is read through exactly one XCD's L2,
+// and at any position in the grid all 8 XCDs see (almost) the same mask.  Inside an XCD the order is 8 owned rows x 8 tile columns, row fastest: 64
 // consecutive workgroups form a patch sharing 8 A panels and 8 B panels in that XCD's L2.
 #include "common.h"
 
@@ -39,15 +39,74 @@ namespace sgp {
 
 constexpr int KB = 16;  // K chunk per LDS stage
 
+// Workgroup -> tile enumeration.  Rectangular launches enumerate (8 owned rows) x n_tc per group
+// of 8 owned rows.  Lower-triangular launches (mask_off == 0) enumerate ONLY live tiles wherever
+// that has a closed form: dead workgroups above the diagonal cost ~1 us of dispatcher time each
+// and a 128^2-tile lower update lost 20 % to them.  Per XCD, group G (tile rows 64G .. 64G+63)
+// has 512 G tiles strictly left of its diagonal 64-block plus exactly 260 live tiles inside it
+// (the boustrophedon row ownership makes that count independent of the XCD).
+struct TriShape {
+  long Gn, r_last, Ga, sA, sB, t_last, n_tc;
+};
+__host__ __device__ __forceinline__ TriShape tri_shape(long n_tr, long n_tc) {
+  TriShape t;
+  const long J = (n_tr + 7) / 8;  // owned rows per XCD
+  t.n_tc = n_tc;
+  t.Gn = J / 8;
+  t.r_last = J % 8;
+  const long g_full = n_tc / 64;
+  t.Ga = t.Gn < g_full ? t.Gn : g_full;              // groups enumerated exactly
+  t.sA = 256 * t.Ga * (t.Ga - 1) + 260 * t.Ga;
+  t.sB = (t.Gn - t.Ga) * 8 * n_tc;                   // groups enumerated as 8 x n_tc rectangles
+  t.t_last = (64 * (t.Gn + 1) < n_tc) ? 64 * (t.Gn + 1) : n_tc;
+  return t;
+}
+__host__ __device__ __forceinline__ long tri_ids_per_xcd(const TriShape& t) {
+  return t.sA + t.sB + t.r_last * t.t_last;
+}
+
 __device__ __forceinline__ bool tile_of_block(long n_tr, long n_tc, long mask_off, long& tr, long& tc) {
   const long id = (long)blockIdx.x;
   const long xcd = id & 7, k = id >> 3;
-  const long gs = 8 * n_tc;
-  const long jgroup = k / gs, within = k % gs;
-  const long j = jgroup * 8 + (within & 7);
-  tr = 8 * j + xcd;
-  tc = within >> 3;
-  return tr < n_tr && tr >= tc + mask_off;
+  long j;
+  if (mask_off == 0) {
+    const TriShape t = tri_shape(n_tr, n_tc);
+    if (k < t.sA) {
+      // S(G) = 256 G (G - 1) + 260 G = 256 G^2 + 4 G
+      long G = (long)((sqrt(16.0 + 1024.0 * (double)k) - 4.0) / 512.0);
+      while (256 * G * G + 4 * G > k) --G;
+      while (256 * (G + 1) * (G + 1) + 4 * (G + 1) <= k) ++G;
+      const long within = k - (256 * G * G + 4 * G);
+      if (within < 512 * G) {
+        j = G * 8 + (within & 7);
+        tc = within >> 3;
+      } else {
+        long d = within - 512 * G, jj = 0, cum = 0;
+        for (; jj < 8; ++jj) {
+          const long cnt = 8 * jj + ((jj & 1) ? 7 - xcd : xcd) + 1;
+          if (d < cum + cnt) break;
+          cum += cnt;
+        }
+        j = G * 8 + jj;
+        tc = 64 * G + (d - cum);
+      }
+    } else if (k < t.sA + t.sB) {
+      const long kk = k - t.sA;
+      const long within = kk % (8 * n_tc);
+      j = (t.Ga + kk / (8 * n_tc)) * 8 + (within & 7);
+      tc = within >> 3;
+    } else {  // partial last group: r_last owned rows
+      const long within = k - t.sA - t.sB;
+      j = t.Gn * 8 + within % t.r_last;
+      tc = within / t.r_last;
+    }
+  } else {
+    const long gs = 8 * n_tc;
+    j = (k / gs) * 8 + ((k % gs) & 7);
+    tc = (k % gs) >> 3;
+  }
+  tr = 8 * j + ((j & 1) ? 7 - xcd : xcd);  // boustrophedon: equal live-tile counts per XCD
+  return tr < n_tr && tc < n_tc && tr >= tc + mask_off;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -77,22 +136,6 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
   // C_new = alpha * (A B' + (beta / alpha) C)
   double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * WCOLS + lq) * ldc;
   double acc[NJ][4];
-  if (beta != 0.0) {
-    const double seed = beta / alpha;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = Cg[i * 16 + (long)(j * 4) * ldc];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] *= seed;
-  } else {
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = 0.0;
-  }
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int wu = __builtin_amdgcn_readfirstlane(w);
@@ -108,7 +151,25 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
     }
   };
   const long nchunks = K / KB;
+  // prologue: the first operand chunk and the old C tile are requested together, so their
+  // latencies overlap (one wait for both)
   if (nchunks > 0) dma(0, 0);
+  if (beta != 0.0) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = Cg[i * 16 + (long)(j * 4) * ldc];
+    const double seed = beta / alpha;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] *= seed;
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = 0.0;
+  }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   for (long c = 0; c < nchunks; ++c) {
@@ -324,9 +385,9 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
     return -1;
   }
   long n_tr = M / TILE, n_tc = Nc / TILE;
-  long groups = (n_tr + 7) / 8;
-  long groups_pad = (groups + 7) / 8 * 8;
-  dim3 grid((unsigned)(groups_pad * 8 * n_tc));
+  long groups = ((n_tr + 7) / 8 + 7) / 8;  // groups of 8 owned rows per XCD
+  long per_xcd = (mask_off == 0) ? tri_ids_per_xcd(tri_shape(n_tr, n_tc)) : groups * 8 * n_tc;
+  dim3 grid((unsigned)(per_xcd * 8));
   if (kcap_mode)
     hipLaunchKernelGGL((gemm_nt_reg_kernel<true>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
                        beta, mask_off, kcap_off, n_tr, n_tc);
