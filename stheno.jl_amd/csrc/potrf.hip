@@ -65,20 +65,31 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(double* A, long 
     }
     __syncthreads();
 
-    // (2) wave 0: 16x16 micro-Cholesky + its inverse, in registers
+    // (2) wave 0: 16x16 micro-Cholesky in registers; lanes 16..31 carry the rows of the identity
+    // through the same right-looking updates (X <- X L^-T), so inv(L)^T falls out for free.
     if (w == 0) {
       const int i = l15;
+      const bool lrow = lane < 16;       // lanes holding rows of the block itself
       double row[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) row[c] = T[(cb * 16 + c) * LDS_LD + cb * 16 + i];
+      for (int c = 0; c < 16; ++c) {
+        double a = T[(cb * 16 + c) * LDS_LD + cb * 16 + i];
+        row[c] = lrow ? a : ((c == i) ? 1.0 : 0.0);
+      }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double djj = bcast_lane(row[j], j);
         if (!(djj > 0.0) && firstbad < 0) firstbad = cb * 16 + j;
-        double d = sqrt(djj);
-        double rinv = 1.0 / d;
+        // sqrt and reciprocal from one v_rsq_f64 + Newton steps: this chain is the serial
+        // critical path of the whole factorisation (128 dependent pivots per diagonal block)
+        double r = __builtin_amdgcn_rsq(djj);
+        r = r * fma(-0.5 * djj, r * r, 1.5);
+        r = r * fma(-0.5 * djj, r * r, 1.5);
+        double d = djj * r;
+        d = fma(0.5 * r, fma(-d, d, djj), d);      // d = sqrt(djj)
+        double rinv = fma(r, fma(-d, r, 1.0), r);  // 1 / d
         double lij = row[j] * rinv;
-        row[j] = (i == j) ? d : lij;
+        row[j] = (lrow && i == j) ? d : lij;
 #pragma unroll
         for (int c2 = j + 1; c2 < 16; ++c2) {
           double lcj = bcast_lane(row[j], c2);  // L[c2][j] lives in lane c2
@@ -88,35 +99,22 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(double* A, long 
       double dii = 0.0;
 #pragma unroll
       for (int c = 0; c < 16; ++c) dii = (c == i) ? row[c] : dii;
-      if (lane < 16) {
+      if (lrow) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) T[(cb * 16 + c) * LDS_LD + cb * 16 + i] = (c <= i) ? row[c] : 0.0;
+      } else if (lane < 32) {
+        // lane 16 + i holds row i of inv(L)^T, i.e. column i of inv(L): Inv[c][i] = row[c], c >= i
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          double v = (c >= i) ? row[c] : 0.0;
+          sInv[i * 16 + c] = v;  // col-major: Inv[r = c][col = i]
+          invd[cb * 256 + i * 16 + c] = v;
+        }
       }
-      double lg = (lane < 16) ? log(dii) : 0.0;
+      double lg = lrow ? log(dii) : 0.0;
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) lg += __shfl_xor(lg, off, 64);
       logacc += lg;
-      // inverse: lane c holds column c of X = inv(L): x[r], r = 0..15
-      double x[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double s = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) {
-          double lrk = bcast_lane(row[k], r);  // L[r][k] lives in lane r
-          s = fma(-lrk, x[k], s);
-        }
-        double lrr = bcast_lane(row[r], r);
-        x[r] = s / lrr;
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          double v = (r >= i) ? x[r] : 0.0;
-          sInv[i * 16 + r] = v;  // Inv[r][c=i], col-major
-          invd[cb * 256 + i * 16 + r] = v;
-        }
-      }
     }
     __syncthreads();
 
