@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--config", default=os.environ.get("SGP_BENCH_CONFIG", "c5"), choices=sorted(CONFIGS))
     ap.add_argument("--cpu-sample", type=int, default=8192, help="N of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--panel", type=int, default=1024, help="column-panel width of the multi-GPU path")
+    ap.add_argument("--force-dist", action="store_true", help="use the sharded (multi-GPU) driver even at 1 GPU")
     args = ap.parse_args()
 
     import torch
@@ -113,6 +114,8 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "SGP_FORCE_DEVICE" in os.environ:      # test hook: several ranks on one GPU (gloo backend)
+        local_rank = int(os.environ["SGP_FORCE_DEVICE"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
     if args.gpus != world and world > 1:
@@ -164,7 +167,7 @@ def main():
     if elbo_step is not None:
         def step(tm=None):
             return elbo_step()
-    elif world == 1:
+    elif world == 1 and not args.force_dist:
         ds = C.c_void_p()
         L.check(lib.sgp_dspec_create(ctx.handle, spec.ref(), C.byref(ds)), "sgp_dspec_create")
         npad, mtot = C.c_int64(), C.c_int64()
@@ -206,7 +209,7 @@ def main():
     # one extra (untimed) instrumented step on 1 GPU: stage split + per-launch GEMM timing
     roofline = None
     stages = None
-    if world == 1 and elbo_step is None:
+    if world == 1 and elbo_step is None and not args.force_dist:
         step(timings)
         upd_ms, n_launch, upd_flops = timings[3], int(timings[4]), timings[5]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0

@@ -1,0 +1,137 @@
+"""Builds profiles/r01_summary.md and copies the committed artefacts from gpurun_out/final
+(collected by tools/collect_profiles.sh on the MI355X box)."""
+import csv
+import collections
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "final")
+DST = os.path.join(ROOT, "profiles")
+
+
+def jload(name):
+    p = os.path.join(SRC, name)
+    try:
+        return json.loads(open(p).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+def pmc(tag):
+    path = glob.glob(os.path.join(SRC, f"pmc_gemm1_{tag}", "*counter_collection.csv"))[0]
+    d = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if "gemm_nt_dma" in r["Kernel_Name"]:
+            d[r["Counter_Name"]].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    out = {}
+    for c, v in d.items():
+        v = v[1:]  # the first launch is the correctness run
+        out[c] = (sum(x[0] for x in v) / len(v), sum(x[1] for x in v) / len(v) / 1e6)
+    return out
+
+
+def main():
+    os.makedirs(DST, exist_ok=True)
+    lines = ["# Round 1 — measurements on one MI355X (gfx950, ROCm 7.2, gpurun box: 256 host cores)", "",
+             "All numbers come from `tools/collect_profiles.sh` (one gpurun call); raw files next to this one.", ""]
+    b = {c: jload(f"bench_{c}.json") for c in ("c1", "c2", "c3", "c4", "c5")}
+    for c, j in b.items():
+        if j:
+            json.dump(j, open(os.path.join(DST, f"r01_bench_{c}.json"), "w"), indent=1)
+    lines += ["## bench.py lines (fp64, synthetic inputs resident in HBM, `python bench.py --config <c>`)", "",
+              "| config | workload | ms / step | value | whole-step TFLOP/s (N³/3) | frac of 78.6 | assembly GB/s (alg.) |",
+              "|---|---|---|---|---|---|---|"]
+    for c in ("c5", "c2", "c3", "c1", "c4"):
+        j = b[c]
+        if not j:
+            continue
+        st = j.get("stages") or {}
+        lines.append(f"| {c} | {j['config']['workload'][:70]} | {j['ms_per_step']:.2f} | {j['value']:.4g} {j['unit']} | "
+                     f"{j['cholesky_tflops_whole_step']:.1f} | {j['cholesky_tflops_whole_step']/78.6:.2f} | "
+                     f"{st.get('kernelmatrix_GBps', float('nan')):.0f} |")
+    j5 = b["c5"]
+    if j5:
+        r, cpu = j5["roofline"], j5["cpu_baseline"]
+        lines += ["", "### Default line (c5 = BASELINE configs[4] on one GPU)", "",
+                  f"* roofline (dominant kernel `{r['kernel'].split(' ')[0]}`): achieved **{r['achieved']:.1f} TFLOP/s** over "
+                  f"{r['launches']} trailing-update launches (avg {r['avg_launch_ms']:.2f} ms, HIP events on the launch streams), "
+                  f"peak {r['peak']} -> frac **{r['frac']:.2f}**.",
+                  f"* stages: assembly {j5['stages']['assemble_ms']:.2f} ms, Cholesky (+forward solve) {j5['stages']['cholesky_ms']:.1f} ms, "
+                  f"finalize {j5['stages']['finalize_ms']:.2f} ms."]
+        if cpu:
+            lines.append(f"* cpu_baseline ({cpu['kind']}, {cpu['cores']} OpenBLAS threads): {cpu['sample']} -> "
+                         f"{cpu['value']:.3g} logpdf/s, i.e. the GPU step is ~{j5['value']/cpu['value']:.0f}x the CPU restatement "
+                         f"(reported baseline, not a target).")
+    # rocprof kernel stats
+    for tag in ("c5", "c2"):
+        src = os.path.join(SRC, f"prof_{tag}", f"{tag}_kernel_stats.csv")
+        if os.path.exists(src):
+            shutil.copy(src, os.path.join(DST, f"r01_bench_{tag}_kernel_stats.csv"))
+            rows = list(csv.DictReader(open(src)))
+            lines += ["", f"## rocprofv3 --kernel-trace --stats of `bench.py` ({tag}): top kernels", "",
+                      "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
+            for rr in rows[:6]:
+                lines.append(f"| `{rr['Name'].split('(')[0]}` | {rr['Calls']} | {float(rr['TotalDurationNs'])/1e6:.1f} | "
+                             f"{float(rr['AverageNs'])/1e3:.1f} | {float(rr['Percentage']):.2f} |")
+            jb = jload(f"prof_{tag}_bench.json")
+            if jb and jb.get("roofline"):
+                lines.append("")
+                lines.append(f"Same run, bench's own HIP-event figure: {jb['roofline']['achieved']:.1f} TFLOP/s over "
+                             f"{jb['roofline']['launches']} trailing updates (avg {jb['roofline']['avg_launch_ms']:.2f} ms); "
+                             f"the kernel-trace average above also contains the many small panel TRSM / inner-update launches "
+                             f"of the same kernel, and kernels of the two look-ahead streams overlap in time "
+                             f"(sum of kernel time > wall time; `potrf_diag`'s long average is queueing behind the update stream).")
+    # PMC on the representative launch
+    try:
+        f, w, sq, tcc = pmc("FETCH_SIZE"), pmc("WRITE_SIZE"), pmc("SQ"), pmc("TCC")
+        m, k = 32768, 1024
+        alg_b = 8.0 * m * (m + 1) / 2 * 2 + 8.0 * m * k
+        alg_f = k * m * (m + 1.0)
+        fetch, write = f["FETCH_SIZE"][0] * 1024, w["WRITE_SIZE"][0] * 1024
+        g = sq["GRBM_GUI_ACTIVE"]
+        ms = g[1]
+        util = sq["SQ_VALU_MFMA_BUSY_CYCLES"][0] / (1024 * g[0] / 8)
+        rec = {"launch": "C(32768^2 lower) -= P P', K = 1024 (tools/gpu_gemm_one.py), average of 3 timed launches",
+               "avg_launch_ms": ms, "achieved_tflops": alg_f / (ms * 1e-3) / 1e12,
+               "FETCH_SIZE_KiB": f["FETCH_SIZE"][0], "WRITE_SIZE_KiB": w["WRITE_SIZE"][0],
+               "hbm_bytes_per_launch": 2 * fetch + write,
+               "hbm_bytes_note": "(2*FETCH_SIZE + WRITE_SIZE)*1024; FETCH_SIZE doubled per the gfx950 correction for "
+                                 "16 B/lane streaming reads (MI355X_MICROARCH.md, HBM); WRITE_SIZE calibrated at 1.004x on "
+                                 "the assembly kernel; Infinity-Cache hits are counted, so this is an upper bound on HBM bytes",
+               "algorithmic_bytes_per_launch": alg_b, "algorithmic_flops_per_launch": alg_f,
+               "mfma_busy_frac": util, "clock_ghz": g[0] / 8 / (ms * 1e-3) / 1e9,
+               "lds_idx_active_frac": sq["SQ_LDS_IDX_ACTIVE"][0] / (256 * g[0] / 8),
+               "lds_bank_conflict": sq["SQ_LDS_BANK_CONFLICT"][0],
+               "l2_hit": tcc["TCC_HIT_sum"][0] / (tcc["TCC_HIT_sum"][0] + tcc["TCC_MISS_sum"][0])}
+        json.dump(rec, open(os.path.join(DST, "r01_gemm_pmc.json"), "w"), indent=1)
+        lines += ["", "## PMC passes on one representative launch of the dominant kernel", "",
+                  f"`{rec['launch']}`: {ms:.2f} ms -> **{rec['achieved_tflops']:.1f} TFLOP/s** "
+                  f"({rec['achieved_tflops']/78.6:.2f} of peak).", "",
+                  f"* `SQ_VALU_MFMA_BUSY_CYCLES` / (1024 SIMDs x `GRBM_GUI_ACTIVE`/8) = **{util:.2f}** MFMA pipe utilisation at "
+                  f"{rec['clock_ghz']:.2f} GHz (clock-adjusted MFMA peak = {1024*32*rec['clock_ghz']/1e3:.1f} TFLOP/s).",
+                  f"* `SQ_LDS_BANK_CONFLICT` = {rec['lds_bank_conflict']:.0f}; LDS busy {rec['lds_idx_active_frac']:.2f} of CU cycles; "
+                  f"L2 hit rate {rec['l2_hit']:.2f}.",
+                  f"* fabric traffic: FETCH_SIZE {fetch/1e9:.1f} GB (x2 corrected {2*fetch/1e9:.1f} GB) + WRITE_SIZE {write/1e9:.1f} GB per "
+                  f"launch vs {alg_b/1e9:.2f} GB algorithmic (C tile read + write once, panel once).  The excess is operand-panel "
+                  f"re-reads that miss the 4 MiB XCD L2s (the 268 MB panel lives in the 256 MiB Infinity Cache, whose hits these "
+                  f"counters include); at {(2*fetch+write)/ms/1e9*1e3/1e3:.1f} TB/s it is far from the HBM bound of this MFMA-bound kernel."]
+    except Exception as e:  # pragma: no cover
+        lines += ["", f"(PMC summary unavailable: {e})"]
+    for name in ("mfma_variants.log", "gemm_variants.log"):
+        p = os.path.join(SRC, name)
+        if os.path.exists(p):
+            txt = [ln for ln in open(p).read().splitlines() if ln.startswith("[") or ln.startswith("gemm")]
+            open(os.path.join(DST, "r01_" + name.replace(".log", ".txt")), "w").write("\n".join(txt) + "\n")
+    lines += ["", "## Other committed evidence", "",
+              "* `r01_microbench.md` — fp64 issue-form ceilings (16x16x4 vs 4x4x4 MFMA vs VALU), HBM stream rates, the GEMM kernel's evolution.",
+              "* `r01_mfma_variants.txt`, `r01_gemm_variants.txt` — raw lines of the final micro-benchmark / GEMM A-B run.",
+              "* `r01_bench_*.json` — the bench lines above, verbatim."]
+    open(os.path.join(DST, "r01_summary.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
