@@ -68,10 +68,50 @@ class HipOps:
         # every kernel of this rank (torch copies, libsthenomi kernels, collectives' stream
         # dependencies) is ordered on ONE explicit non-default stream: the HIP null stream (handle
         # 0) cannot be named through the C-ABI, where NULL means "the ctx's own stream".
-        self._stream = torch.cuda.Stream(self.device)
+        self._stream = torch.cuda.Stream(self.device)                  # trailing updates
+        self._pstream = torch.cuda.Stream(self.device, priority=-1)   # panel factorisation (look-ahead)
+        self._events = {}
 
     def stream_context(self):
         return self.torch.cuda.stream(self._stream)
+
+    def panel_context(self):
+        """High-priority stream for the look-ahead panel (update + factor + pack + broadcast)."""
+        return self.torch.cuda.stream(self._pstream)
+
+    # A rank's trailing panels are updated by one launch each; issuing them round-robin on a few
+    # streams lets the tail of one launch overlap the head of the next (a panel always uses the
+    # same stream, so successive updates of one panel stay ordered).
+    N_POOL = 3
+
+    def fork_updates(self):
+        if not hasattr(self, "_pool"):
+            self._pool = [self.torch.cuda.Stream(self.device) for _ in range(self.N_POOL)]
+            self._pool_ev = [self.torch.cuda.Event() for _ in range(self.N_POOL)]
+            self._fork_ev = self.torch.cuda.Event()
+        self._fork_ev.record(self.torch.cuda.current_stream(self.device))
+        for st in self._pool:
+            st.wait_event(self._fork_ev)
+
+    def pool_context(self, idx):
+        return self.torch.cuda.stream(self._pool[idx % self.N_POOL])
+
+    def join_updates(self):
+        cur = self.torch.cuda.current_stream(self.device)
+        for st, ev in zip(self._pool, self._pool_ev):
+            ev.record(st)
+            cur.wait_event(ev)
+
+    def record(self, name):
+        ev = self._events.get(name)
+        if ev is None:
+            ev = self._events[name] = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+
+    def wait(self, name):
+        ev = self._events.get(name)
+        if ev is not None:
+            self.torch.cuda.current_stream(self.device).wait_event(ev)
 
     # -- memory ---------------------------------------------------------------------------
     def empty(self, n):
@@ -192,23 +232,54 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats):
         ops.panel_update(bufs[J % 2], lay.col0(J), lay.width(J), A, lay.local_index(Jp) * W, m_tot,
                          lay.col0(Jp), lay.width(Jp))
 
-    # 2. right-looking factorisation with one-panel look-ahead
+    # 2. right-looking factorisation with one-panel look-ahead.  Two streams per rank: the owner of
+    # the next panel updates + factors + packs + broadcasts it on the panel stream while its other
+    # trailing panels are still being updated with the current panel on the update stream.
+    #   "upd"   : update-stream work of the previous step (and the assembly) is complete
+    #   "panel" : the panel this rank just factored is packed in its buffer
+    ops.record("upd")
+    work = None
     if lay.owner(0) == rank:
-        factor_and_pack(0)
-    work = bcast(0)
-    if work is not None:
-        work.wait()
+        with ops.panel_context():
+            ops.wait("upd")
+            factor_and_pack(0)
+            ops.record("panel")
+            work = bcast(0)
+    else:
+        work = bcast(0)
     for J in range(lay.n_panels):
         nxt = J + 1
-        if nxt < lay.n_panels and lay.owner(nxt) == rank:
-            update(J, nxt)          # look-ahead: bring the next panel up to date first,
-            factor_and_pack(nxt)    # factor it and get its broadcast going
-        work = bcast(nxt) if nxt < lay.n_panels else None
-        for Jp in lay.mine:         # the rest of this rank's trailing panels
-            if Jp > nxt:
-                update(J, Jp)
+        # (a) the update stream needs panel J in bufs[J % 2]
         if work is not None:
             work.wait()
+        if lay.owner(J) == rank:
+            ops.wait("panel")
+        # (b) look-ahead on the owner of the next panel
+        work_next = None
+        if nxt < lay.n_panels:
+            if lay.owner(nxt) == rank:
+                with ops.panel_context():
+                    ops.wait("upd")            # step J-1's updates of panel nxt are done
+                    if work is not None:
+                        work.wait()            # panel J has landed (also for this stream)
+                    update(J, nxt)
+                    factor_and_pack(nxt)
+                    ops.record("panel")
+                    work_next = bcast(nxt)     # ordered after the pack on the panel stream
+            else:
+                work_next = bcast(nxt)         # receive: ordered after step J-1's readers of that buffer
+        # (c) the rest of this rank's trailing panels
+        ops.fork_updates()
+        for Jp in lay.mine:
+            if Jp > nxt:
+                with ops.pool_context(lay.local_index(Jp)):
+                    update(J, Jp)
+        ops.join_updates()
+        ops.record("upd")
+        work = work_next
+    with ops.panel_context():
+        pass
+    ops.wait("panel")   # join: everything the panel stream did is visible to the update stream
 
     # 3. scalars: |L^-1 (y - m)|^2 from the bordered row, logdet, info
     for J in lay.mine:

@@ -42,6 +42,26 @@ class NumpyOps:
         import contextlib
         return contextlib.nullcontext()
 
+    def panel_context(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def fork_updates(self):
+        pass
+
+    def join_updates(self):
+        pass
+
+    def pool_context(self, idx):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def record(self, name):
+        self.calls.append(("record", name, None))
+
+    def wait(self, name):
+        self.calls.append(("wait", name, None))
+
     @staticmethod
     def _mat(A, col_off, m_tot, ncols):
         return A.numpy()[col_off * m_tot:(col_off + ncols) * m_tot].reshape(ncols, m_tot).T  # view (m_tot, ncols)
