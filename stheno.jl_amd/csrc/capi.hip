@@ -15,7 +15,6 @@ namespace sgp {
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 
-void set_gemm_tn_workspace(double* ws, size_t bytes);
 void set_gemm_variant(int v);
 int run_mfma_bench(hipStream_t s, int iters, double* tflops_out, double* layout_maxerr_out);
 int run_hbm_bench(hipStream_t s, long bytes, int iters, double* write_gbs, double* copy_gbs);
@@ -43,8 +42,6 @@ struct sgp_ctx {
   double* d_scal = nullptr;    // [0] logdet, [1] misc, [16 ..] per-rhs sums
   long n_scal = 0;
   int* d_info = nullptr;
-  double* d_tn_ws = nullptr;
-  size_t tn_ws_bytes = 0;
   std::mutex mu;
   // optional per-launch timing of the trailing updates (roofline evidence for bench.py)
   bool time_updates = false;
@@ -141,7 +138,6 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   hipFree(c->d_slots);
   hipFree(c->d_scal);
   hipFree(c->d_info);
-  if (c->d_tn_ws) hipFree(c->d_tn_ws);
   hipStreamSynchronize(c->stream2);
   hipEventDestroy(c->ev_panel);
   hipEventDestroy(c->ev_rest);
@@ -1056,20 +1052,26 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
     dG = dG_local.p;
   }
   SGP_HIP(hipMemsetAsync(dG, 0, sizeof(double) * ldg * m_pad, s));
-  // split-K workspace
+  // G = A A' with the contraction over the N data points.  The rows hold A' (N x M, row index
+  // contiguous = data point), so A (M x N) is formed by one coalesced transpose and the Gram
+  // matrix runs on the NT MFMA kernel, split over K to fill the chip (few output tiles, huge K),
+  // then reduced in fixed order.
   {
-    size_t need = (size_t)64 * ldg * m_pad * sizeof(double);
-    size_t cap = (size_t)4 << 30;
-    if (need > cap) need = cap;
-    if (ctx->tn_ws_bytes < need) {
-      if (ctx->d_tn_ws) hipFree(ctx->d_tn_ws);
-      ctx->d_tn_ws = nullptr;
-      ctx->tn_ws_bytes = 0;
-      if (hipMalloc(&ctx->d_tn_ws, need) == hipSuccess) ctx->tn_ws_bytes = need;
-    }
-    set_gemm_tn_workspace(ctx->d_tn_ws, ctx->tn_ws_bytes);
+    DevBuf dAt, dPart;
+    CHECK_RC(dAt.alloc((size_t)m_pad * n_rows));
+    CHECK_RC(launch_transpose_add(R, ld, n_rows, m_pad, dAt.p, m_pad, nullptr, s));
+    long tiles = (m_pad / TILE) * (m_pad / TILE + 1) / 2;
+    int nsplit = 1;
+    while (tiles * nsplit < 4096 && nsplit < 64 && (n_rows % (16L * nsplit * 2)) == 0 &&
+           n_rows / (nsplit * 2) >= 2048)
+      nsplit *= 2;
+    long stride = ldg * m_pad;
+    CHECK_RC(dPart.alloc((size_t)nsplit * stride));
+    CHECK_RC(launch_gemm_nt_splitk(dAt.p, m_pad, dAt.p, m_pad, dPart.p, ldg, m_pad, m_pad, n_rows, nsplit,
+                                   stride, 1, s));
+    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, 0.0, 1, s));
+    SGP_HIP(hipStreamSynchronize(s));  // dAt / dPart are freed at scope exit
   }
-  CHECK_RC(launch_gemm_tn(R, ld, R, ld, dG, ldg, m_pad, m_pad, n_rows, 1.0, 0.0, 1, s));
   hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG,
                      ldg, m_pad);
   hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg,

@@ -76,12 +76,11 @@ int launch_mirror_lower(double* K, long ld, long N, hipStream_t s);
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                    long M, long Nc, long K, double alpha, double beta, long mask_off,
                    int kcap_mode, long kcap_off, hipStream_t s);
-// gemm_tn: C(M x Nc) = beta*C + alpha * A' B with A: K x M, B: K x Nc (K is the contiguous dim)
-int launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                   long M, long Nc, long K, double alpha, double beta, int lower_only,
-                   hipStream_t s);
-
-void set_gemm_tn_workspace(double* ws, size_t bytes);
+int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
+                          long M, long Nc, long K, int nsplit, long part_stride, int lower_only,
+                          hipStream_t s);
+int launch_splitk_reduce(const double* part, long part_stride, int nsplit, double* C, long ldc, long M,
+                         long Nc, double alpha, double beta, int lower_only, hipStream_t s);
 
 // potrf.hip
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,

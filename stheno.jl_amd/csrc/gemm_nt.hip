@@ -119,10 +119,15 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
                                                              const double* B, long ldb, double* C,
                                                              long ldc, long K, double alpha,
                                                              double beta, long mask_off, long n_tr,
-                                                             long n_tc) {
+                                                             long n_tc, long c_slice_stride) {
   constexpr int NJ = 8, WCOLS = 32;
   long tr, tc;
   if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return;
+  // split-K (blockIdx.y > 0 only in launch_gemm_nt_splitk): slice s contracts columns
+  // [s K, (s + 1) K) of A and B into its own slab of C
+  A += (long)blockIdx.y * K * lda;
+  B += (long)blockIdx.y * K * ldb;
+  C += (long)blockIdx.y * c_slice_stride;
   // stage s: A chunk at smem + s*2*KB*LDS_LD, B chunk right after it
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   const int t = threadIdx.x;
@@ -396,100 +401,37 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
                        beta, mask_off, kcap_off, n_tr, n_tc);
   else
     hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
-                       mask_off, n_tr, n_tc);
+                       mask_off, n_tr, n_tc, 0L);
   SGP_HIP(hipGetLastError());
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------
-// gemm_tn: C(M x Nc) = beta*C + alpha * A' * B,  A: K x M, B: K x Nc  (contraction over the
-// contiguous dimension).  Used for the VFE/ELBO Gram matrix A A' + I where A' is stored as
-// bordered rows (N x M) and N is huge.  Staging transposes through
-// LDS: chunk of 16 k-rows x 128 columns per operand.
-// ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void gemm_tn_kernel(const double* A, long lda,
-                                                         const double* B, long ldb, double* C,
-                                                         long ldc, long K, double alpha,
-                                                         double beta, int lower_only,
-                                                         long k_per_split, double* Cpart,
-                                                         long part_stride) {
-  constexpr int NJ = 8, WCOLS = 32;
-  const long tr = blockIdx.x, tc = blockIdx.y;
-  const long ksplit = blockIdx.z;
-  if (lower_only && tr < tc) return;
-  // LDS layout [k][row] with ld LDS_LD, same as gemm_nt, so the compute loop is identical; the
-  // global read is the transposing part: a thread reads along k (contiguous) for one column.
-  __shared__ __attribute__((aligned(16))) double sA[2][KB * LDS_LD];
-  __shared__ __attribute__((aligned(16))) double sB[2][KB * LDS_LD];
-  const int t = threadIdx.x;
-  const int lane = t & 63, w = t >> 6;
-  const int wr = w >> 2, wc = w & 3;
-  const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
-  const long kbeg = ksplit * k_per_split;
-  long kend = kbeg + k_per_split;
-  if (kend > K) kend = K;
-  // staging: chunk = 16 (k) x 128 (cols) per operand; thread t handles column t & 127 and the
-  // 4 consecutive k of quarter t >> 7 -> 2 double2 loads per operand.
-  const int sc = t & 127, sq = t >> 7;
-  const double* Ag = A + (tr * TILE + sc) * lda;
-  const double* Bg = B + (tc * TILE + sc) * ldb;
-  double2 ra[2], rb[2];
-  double acc[NJ][4];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = 0.0;
-#define SGP_TN_GLOAD(k0_)                                                        \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
-    long k = (k0_) + sq * 4 + 2 * i;                                             \
-    ra[i] = *reinterpret_cast<const double2*>(Ag + k);                           \
-    rb[i] = *reinterpret_cast<const double2*>(Bg + k);                           \
+// Cpart[s] = A[:, sK' : (s+1)K'] B[:, sK' : (s+1)K']'  for s < nsplit (K' = K / nsplit, a multiple of
+// 16), slabs `part_stride` doubles apart: one launch, nsplit x the tiles -- for Gram matrices
+// with a huge contraction dimension and few output tiles (VFE: A A', M = 4096, K = 262144).
+int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
+                          long M, long Nc, long K, int nsplit, long part_stride, int lower_only,
+                          hipStream_t s) {
+  if (M % TILE || Nc % TILE || nsplit < 1 || K % (KB * (long)nsplit)) {
+    set_error("gemm_nt_splitk: bad sizes");
+    return -1;
   }
-#define SGP_TN_SSTORE(buf_)                                                      \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                \
-    int k = sq * 4 + 2 * i;                                                      \
-    sA[buf_][k * LDS_LD + sc] = ra[i].x;                                         \
-    sA[buf_][(k + 1) * LDS_LD + sc] = ra[i].y;                                   \
-    sB[buf_][k * LDS_LD + sc] = rb[i].x;                                         \
-    sB[buf_][(k + 1) * LDS_LD + sc] = rb[i].y;                                   \
-  }
-  if (kbeg < kend) {
-    SGP_TN_GLOAD(kbeg);
-    SGP_TN_SSTORE(0);
-    __syncthreads();
-    int buf = 0;
-    for (long k0 = kbeg + KB; k0 < kend; k0 += KB) {
-      SGP_TN_GLOAD(k0);
-      SGP_COMPUTE(buf, NJ, wc * WCOLS);
-      SGP_TN_SSTORE(buf ^ 1);
-      __syncthreads();
-      buf ^= 1;
-    }
-    SGP_COMPUTE(buf, NJ, wc * WCOLS);
-  }
-#undef SGP_TN_GLOAD
-#undef SGP_TN_SSTORE
-  if (Cpart) {
-    // split-K: write the partial tile; a second kernel reduces in fixed order (deterministic)
-    double* P = Cpart + ksplit * part_stride + (tr * TILE + wr * 64 + l15) +
-                (tc * TILE + wc * WCOLS + lq) * ldc;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) P[i * 16 + (long)(j * 4) * ldc] = acc[j][i];
-    return;
-  }
-  double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * WCOLS + lq) * ldc;
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      double* p = Cg + i * 16 + (long)(j * 4) * ldc;
-      double old = (beta == 0.0) ? 0.0 : beta * (*p);
-      *p = old + alpha * acc[j][i];
-    }
+  long n_tr = M / TILE, n_tc = Nc / TILE;
+  long groups = ((n_tr + 7) / 8 + 7) / 8;
+  long mask_off = lower_only ? 0 : -(1L << 40);
+  long per_xcd = lower_only ? tri_ids_per_xcd(tri_shape(n_tr, n_tc)) : groups * 8 * n_tc;
+  dim3 grid((unsigned)(per_xcd * 8), (unsigned)nsplit);
+  hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc, K / nsplit, 1.0,
+                     0.0, mask_off, n_tr, n_tc, part_stride);
+  SGP_HIP(hipGetLastError());
+  return 0;
 }
 
+// C = beta C + alpha sum_s part[s]   (fixed order: deterministic)
+int launch_splitk_reduce(const double* part, long part_stride, int nsplit, double* C, long ldc, long M,
+                         long Nc, double alpha, double beta, int lower_only, hipStream_t s);
+
+// fixed-order reduction of split-K slabs (deterministic)
 __global__ void splitk_reduce_kernel(const double* part, long part_stride, int nsplit, double* C,
                                      long ldc, long M, long Nc, double alpha, double beta,
                                      int lower_only) {
@@ -504,60 +446,12 @@ __global__ void splitk_reduce_kernel(const double* part, long part_stride, int n
   *p = old + alpha * s;
 }
 
-// workspace for split-K partials is provided by the caller through a static hook
-static double* g_tn_ws = nullptr;
-static size_t g_tn_ws_bytes = 0;
-void set_gemm_tn_workspace(double* ws, size_t bytes) {
-  g_tn_ws = ws;
-  g_tn_ws_bytes = bytes;
-}
-
-int launch_gemm_tn(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
-                   long M, long Nc, long K, double alpha, double beta, int lower_only,
-                   hipStream_t s) {
-  if (M <= 0 || Nc <= 0) return 0;
-  if (M % TILE || Nc % TILE || K % KB) {
-    set_error("gemm_tn: M, Nc must be multiples of 128 and K of 16");
-    return -1;
-  }
-  long n_tr = M / TILE, n_tc = Nc / TILE;
-  long tiles = lower_only ? n_tr * (n_tr + 1) / 2 : n_tr * n_tc;
-  // split K so that there are >= ~1024 workgroups when the output is small and K is huge
-  int nsplit = 1;
-  if (tiles < 1024 && K >= 8192) {
-    nsplit = (int)((1024 + tiles - 1) / tiles);
-    long maxsplit = K / 2048;
-    if (nsplit > maxsplit) nsplit = (int)maxsplit;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 64) nsplit = 64;
-  }
-  long k_per = ((K + nsplit - 1) / nsplit + KB - 1) / KB * KB;
-  nsplit = (int)((K + k_per - 1) / k_per);
-  double* part = nullptr;
-  long stride = 0;
-  if (nsplit > 1) {
-    if (ldc != M) {
-      // partial slabs reuse C's layout (ldc x Nc)
-    }
-    stride = ldc * Nc;
-    size_t need = (size_t)nsplit * stride * sizeof(double);
-    if (need > g_tn_ws_bytes) {
-      nsplit = 1;
-      k_per = K;
-    } else {
-      part = g_tn_ws;
-    }
-  }
-  dim3 grid((unsigned)n_tr, (unsigned)n_tc, (unsigned)nsplit), block(512);
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
-                     lower_only, k_per, part, stride);
+int launch_splitk_reduce(const double* part, long part_stride, int nsplit, double* C, long ldc, long M,
+                         long Nc, double alpha, double beta, int lower_only, hipStream_t s) {
+  long tot = M * Nc;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, part,
+                     part_stride, nsplit, C, ldc, M, Nc, alpha, beta, lower_only);
   SGP_HIP(hipGetLastError());
-  if (part) {
-    long tot = M * Nc;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s,
-                       part, stride, nsplit, C, ldc, M, Nc, alpha, beta, lower_only);
-    SGP_HIP(hipGetLastError());
-  }
   return 0;
 }
 
