@@ -115,6 +115,22 @@ int sgp_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, double* out);
 int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                const double* noise, const double* Y, int64_t ldy, int64_t ncols, double* out);
 
+/* ---- logpdf and its reverse-mode gradient -------------------------------
+ * What Zygote derives through `logpdf(f(x, s2), y)` on the reference path for hyper-parameter
+ * learning (examples/getting_started/script.jl:154-213; AD glue: SURVEY.md section 2 #11).
+ * With alpha = C^-1 (y - m) and G = (alpha alpha' - C^-1)/2 = d logpdf / d C:
+ *   grad_y[N]    = -alpha          grad_mean[N] = +alpha
+ *   grad_noise   = tr G (SCALAR, 1 value)  or  diag G (DIAG, N values)
+ *   grad_coef[t]    = sum_{i,j in block pair of term t} G_ij rs_i k_t(x_i, x_j) cs_j      = d/d coef_t
+ *   grad_inscale[t] = sum G_ij coef_t rs_i cs_j d k_t(g x_i, g x_j)/dg at g = 1  (both inputs of the
+ *                     term scaled by g: the derivative w.r.t. an inverse lengthscale / stretch)
+ * one entry per element of spec->terms, in that order (mirror-image block pairs (I,J), (J,I) each
+ * report their own term; the host adds what belongs to one parameter).  Any output may be NULL.
+ * noise_kind must be SCALAR or DIAG. */
+int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                    const double* noise, const double* y, double* logpdf_out, double* grad_y,
+                    double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale);
+
 /* ---- rand(rng, fx, S) (A3; App. A.4): out = mean .+ L * Z, Z = randn(rng, N, S) drawn by
  * the caller's RNG (column-major fill order), so the integer RNG stream stays the caller's. */
 int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,

@@ -276,3 +276,18 @@ def posterior_vfe(vfe, fx, y):
     m_eps = sla.cho_solve((Le, True), A @ delta, check_finite=False)
     alpha = sla.solve_triangular(Lz, m_eps, lower=True, trans="T", check_finite=False)
     return ApproxPosteriorGP(fx.f, vfe.fz.x, alpha, Lz, Le)
+
+
+# ---- gradient of logpdf (what Zygote derives through the reference:
+# examples/getting_started/script.jl:154-213) ---------------------------------------------------
+def logpdf_gradient_wrt_cov(fx, y):
+    """(logpdf, alpha, G) with G = d logpdf / d C = (alpha alpha' - C^-1) / 2, alpha = C^-1 (y - m).
+    d logpdf / d y = -alpha, d logpdf / d m = +alpha, d logpdf / d theta = sum_ij G_ij dC_ij/dtheta."""
+    m, Cm = mean_and_cov(fx)
+    L = cholesky_lower(Cm)
+    delta = np.asarray(y, dtype=np.float64) - m
+    alpha = sla.cho_solve((L, True), delta, check_finite=False)
+    Cinv = sla.cho_solve((L, True), np.eye(len(m)), check_finite=False)
+    z = sla.solve_triangular(L, delta, lower=True, check_finite=False)
+    lp = -0.5 * (len(m) * LOG2PI + 2.0 * np.log(np.diag(L)).sum() + z @ z)
+    return float(lp), alpha, 0.5 * (np.outer(alpha, alpha) - Cinv)

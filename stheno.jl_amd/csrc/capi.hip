@@ -674,6 +674,109 @@ extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* me
 }
 
 // ---------------------------------------------------------------------------------------
+// logpdf + reverse-mode gradient
+// ---------------------------------------------------------------------------------------
+extern "C" int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                               const double* noise, const double* y, double* logpdf_out, double* grad_y,
+                               double* grad_mean, double* grad_noise, double* grad_coef,
+                               double* grad_inscale) {
+  CHECK_ARG(ctx && spec && noise && y && logpdf_out, "sgp_logpdf_grad: NULL argument");
+  CHECK_ARG(spec->symmetric, "sgp_logpdf_grad: spec must be symmetric");
+  CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+            "sgp_logpdf_grad: noise kind must be SCALAR or DIAG");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard g;
+  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  const sgp_dspec* ds = g.ds;
+  long N = ds->N;
+  CHECK_ARG(N >= 1, "sgp_logpdf_grad: empty data");
+  long n_pad = rup(N, TILE);
+  long nrows = n_pad + TILE;            // identity rows, then the (y - m)' row (+ zero padding)
+  long m_tot = n_pad + nrows;
+  hipStream_t s = ctx->stream;
+  DevBuf dA, dKinv, dmean, dy, dalpha, dpart, dgc, dgs, dgn;
+  NoiseDev nd;
+  CHECK_RC(dA.alloc((size_t)m_tot * n_pad));
+  CHECK_RC(dKinv.alloc((size_t)n_pad * n_pad));
+  if (mean) CHECK_RC(dmean.upload(mean, N));
+  CHECK_RC(dy.upload(y, N));
+  CHECK_RC(upload_noise(nd, noise_kind, noise, N));
+  CHECK_RC(dalpha.alloc(n_pad));
+  size_t nterms_total = ds->h_terms.size();
+  CHECK_RC(dgc.alloc(std::max<size_t>(1, nterms_total)));
+  CHECK_RC(dgs.alloc(std::max<size_t>(1, nterms_total)));
+  CHECK_RC(dgn.alloc(n_pad));
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  SGP_HIP(hipMemsetAsync(dalpha.p, 0, sizeof(double) * n_pad, s));
+  SGP_HIP(hipMemsetAsync(dgc.p, 0, sizeof(double) * std::max<size_t>(1, nterms_total), s));
+  SGP_HIP(hipMemsetAsync(dgs.p, 0, sizeof(double) * std::max<size_t>(1, nterms_total), s));
+  // K + Sigma_y, identity padding, bordered rows [I ; (y - m)']
+  CHECK_RC(assemble(ds, dA.p, m_tot, 0, n_pad / TILE, 0, n_pad / TILE, 1, nd.kind, nd.sigma2, nd.diag.p, s));
+  CHECK_RC(launch_fill_pad(dA.p, m_tot, N, n_pad, 0, n_pad, m_tot, 0, s));
+  CHECK_RC(launch_grad_border(dA.p, m_tot, n_pad, N, dy.p, mean ? dmean.p : nullptr, nrows, s));
+  CHECK_RC(chol_bordered(ctx, dA.p, m_tot, n_pad, m_tot, nullptr, s));
+  // rows n_pad .. 2 n_pad now hold inv(L)' ; row 2 n_pad holds z' = (inv(L) (y - m))'
+  const double* Rinv = dA.p + n_pad;
+  const double* zrow = dA.p + 2 * n_pad;
+  double* d_logdet = ctx->d_scal;
+  double* d_sq = ctx->d_scal + 16;
+  double* d_out = ctx->d_scal + 17;
+  CHECK_RC(launch_rowsumsq(zrow, m_tot, N, 1, d_sq, 0, s));
+  CHECK_RC(launch_sum_array(ctx->d_slots, n_pad / TILE, d_logdet, s));
+  CHECK_RC(launch_logpdf_final(d_logdet, d_sq, N, 1, d_out, s));
+  // alpha = inv(L)' z
+  CHECK_RC(launch_gemv_rows(Rinv, m_tot, N, n_pad, zrow, m_tot, nullptr, dalpha.p, s));
+  // C^-1 = inv(L)' inv(L): lower tiles on the MFMA GEMM, then mirrored
+  CHECK_RC(launch_gemm_nt(Rinv, m_tot, Rinv, m_tot, dKinv.p, n_pad, n_pad, n_pad, n_pad, 1.0, 0.0, 0, 0, 0, s));
+  CHECK_RC(launch_mirror_lower(dKinv.p, n_pad, n_pad, s));
+  if (grad_noise) CHECK_RC(launch_grad_noise(dKinv.p, n_pad, dalpha.p, N, nd.kind == SGP_NOISE_DIAG, dgn.p, s));
+  if (grad_coef || grad_inscale) {
+    // per block pair, per group of <= GRAD_MAXT terms
+    long max_blocks = (n_pad / TILE) * (n_pad / TILE);
+    CHECK_RC(dpart.alloc((size_t)max_blocks * 16));
+    for (int I = 0; I < ds->nrb; ++I) {
+      if (ds->row_len[I] == 0) continue;
+      for (int J = 0; J < ds->ncb; ++J) {
+        if (ds->col_len[J] == 0) continue;
+        long r0 = ds->row_off[I], nr = ds->row_len[I], c0 = ds->col_off[J], nc = ds->col_len[J];
+        long trf = r0 / TILE, trl = (r0 + nr - 1) / TILE + 1, tcf = c0 / TILE, tcl = (c0 + nc - 1) / TILE + 1;
+        int p = I * ds->ncb + J;
+        int t0 = ds->term_ptr[p], t1 = ds->term_ptr[p + 1];
+        int dmax = ds->pair_dmax[p];
+        int per = std::min(8, std::max(1, 64 / dmax));
+        for (int t = t0; t < t1; t += per) {
+          int cnt = std::min(per, t1 - t);
+          CHECK_RC(launch_grad_block(dKinv.p, n_pad, dalpha.p, r0, nr, c0, nc, ds->d_terms + t, cnt, dmax, trf,
+                                     tcf, trl - trf, tcl - tcf, dpart.p, dgc.p + t, dgs.p + t, s));
+        }
+      }
+    }
+  }
+  int info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
+              std::to_string(info));
+    return info;
+  }
+  SGP_HIP(hipMemcpy(logpdf_out, d_out, sizeof(double), hipMemcpyDeviceToHost));
+  std::vector<double> ha(N);
+  SGP_HIP(hipMemcpy(ha.data(), dalpha.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  if (grad_y)
+    for (long i = 0; i < N; ++i) grad_y[i] = -ha[i];
+  if (grad_mean)
+    for (long i = 0; i < N; ++i) grad_mean[i] = ha[i];
+  if (grad_noise)
+    SGP_HIP(hipMemcpy(grad_noise, dgn.p, sizeof(double) * (nd.kind == SGP_NOISE_DIAG ? N : 1),
+                      hipMemcpyDeviceToHost));
+  if (grad_coef && nterms_total)
+    SGP_HIP(hipMemcpy(grad_coef, dgc.p, sizeof(double) * nterms_total, hipMemcpyDeviceToHost));
+  if (grad_inscale && nterms_total)
+    SGP_HIP(hipMemcpy(grad_inscale, dgs.p, sizeof(double) * nterms_total, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
 // posterior
 // ---------------------------------------------------------------------------------------
 struct sgp_post {

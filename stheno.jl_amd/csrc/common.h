@@ -82,6 +82,15 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
 int launch_splitk_reduce(const double* part, long part_stride, int nsplit, double* C, long ldc, long M,
                          long Nc, double alpha, double beta, int lower_only, hipStream_t s);
 
+// grad.hip
+int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0, long nc,
+                      const DevTerm* d_terms, int nterms, int dmax, long trf, long tcf, long trc, long tcc,
+                      double* partials, double* out_coef, double* out_scale, hipStream_t s);
+int launch_grad_border(double* A, long ld, long n_pad, long N, const double* y, const double* mean,
+                       long nrows, hipStream_t s);
+int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N, int diag, double* out,
+                      hipStream_t s);
+
 // potrf.hip
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,
                       long gcol0, hipStream_t s);

@@ -1,0 +1,246 @@
+// Reverse-mode gradient of logpdf: the contraction
+//   d logpdf / d theta = sum_ij G_ij dC_ij / d theta,   G = (alpha alpha' - C^-1) / 2
+// against the flattened covariance terms.  On the reference path this is what Zygote derives
+// through cholesky / kernelmatrix for hyper-parameter learning
+// (examples/getting_started/script.jl:154-213; AD glue sites SURVEY.md section 2 #11).
+//
+// For every term t of a block pair the kernel accumulates
+//   gc[t] = sum_ij G_ij rs_i k_t(x_i, x_j) cs_j                     (d / d coef_t)
+//   gs[t] = sum_ij G_ij coef_t rs_i cs_j  d k_t(g x_i, g x_j)/dg |_{g=1}   (d / d input scale)
+// with the same tiling as the assembly kernel (kernelmatrix.hip): 128x128 tiles, thread = one row
+// x 64 columns, column points broadcast from LDS.  Partials per workgroup are reduced in fixed
+// order by a second kernel (deterministic).
+#include "common.h"
+#include <algorithm>
+
+namespace sgp {
+
+enum { G_SE = 0, G_M12 = 1, G_M32 = 2, G_M52 = 3, G_WHITE = 4, G_CONST = 5 };
+constexpr int GRAD_MAXT = 8;  // terms per launch
+
+// k and d k / d g (input scale, at g = 1) from the squared distance
+__device__ __forceinline__ void kern_and_dscale(int kind, double d2, double param, double& k, double& dk) {
+  switch (kind) {
+    case G_SE:
+      k = exp(-0.5 * d2);
+      dk = -d2 * k;
+      return;
+    case G_M12: {
+      double d = sqrt(d2);
+      k = exp(-d);
+      dk = -d * k;
+      return;
+    }
+    case G_M32: {
+      double l = 1.7320508075688772 * sqrt(d2);
+      double e = exp(-l);
+      k = (1.0 + l) * e;
+      dk = -3.0 * d2 * e;
+      return;
+    }
+    case G_M52: {
+      double l = 2.23606797749979 * sqrt(d2);
+      double e = exp(-l);
+      k = (1.0 + l + l * l / 3.0) * e;
+      dk = -(5.0 * d2 / 3.0) * (1.0 + l) * e;
+      return;
+    }
+    case G_WHITE:
+      k = d2 == 0.0 ? 1.0 : 0.0;
+      dk = 0.0;
+      return;
+    default:
+      k = param;
+      dk = 0.0;
+  }
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, long ldk, const double* alpha,
+                                                         long r0, long nr, long c0, long nc,
+                                                         const DevTerm* terms, int nterms,
+                                                         long tile_r_first, long tile_c_first,
+                                                         double* partials /*[blocks][GRAD_MAXT][2]*/) {
+  const long gtr = tile_r_first + blockIdx.x;
+  const long gtc = tile_c_first + blockIdx.y;
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [nterms][128][DMAX] + reduction scratch
+  const int t = threadIdx.x;
+  const int trow = t & 127, th = t >> 7;
+  long cbeg = gtc * TILE, cend = cbeg + TILE;
+  if (cbeg < c0) cbeg = c0;
+  if (cend > c0 + nc) cend = c0 + nc;
+  long rbeg = gtr * TILE, rend = rbeg + TILE;
+  if (rbeg < r0) rbeg = r0;
+  if (rend > r0 + nr) rend = r0 + nr;
+  const bool live_tile = cbeg < cend && rbeg < rend;
+
+  for (int tm = 0; tm < nterms; ++tm) {
+    const DevTerm T = terms[tm];
+    for (int idx = t; idx < TILE * DMAX; idx += 256) {
+      int p = idx / DMAX, d = idx % DMAX;
+      long gc = gtc * TILE + p;
+      double v = 0.0;
+      if (live_tile && d < T.dim && gc >= cbeg && gc < cend) v = T.xc[(gc - c0) * T.ldc + d];
+      smem[(tm * TILE + p) * DMAX + d] = v;
+    }
+  }
+  __syncthreads();
+
+  double gc_acc[GRAD_MAXT], gs_acc[GRAD_MAXT];
+#pragma unroll
+  for (int q = 0; q < GRAD_MAXT; ++q) gc_acc[q] = gs_acc[q] = 0.0;
+
+  const long grow = gtr * TILE + trow;
+  if (live_tile && grow >= rbeg && grow < rend) {
+    const long lrow = grow - r0;
+    const double ai = alpha[grow];
+    for (int p = th * 64; p < th * 64 + 64; ++p) {
+      const long gc = gtc * TILE + p;
+      if (gc < cbeg || gc >= cend) continue;
+      const double g = 0.5 * (ai * alpha[gc] - Kinv[grow + gc * ldk]);
+#pragma unroll
+      for (int tm = 0; tm < GRAD_MAXT; ++tm) {
+        if (tm >= nterms) break;
+        const DevTerm T = terms[tm];
+        const double* xr = T.xr + lrow * T.ldr;
+        const double* sp = &smem[(tm * TILE + p) * DMAX];
+        double d2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+          double df = ((d < T.dim) ? xr[d] : 0.0) - sp[d];
+          d2 = fma(df, df, d2);
+        }
+        double k, dk;
+        kern_and_dscale(T.kind, d2, T.param, k, dk);
+        double w = g * (T.rs ? T.rs[lrow] : 1.0) * (T.cs ? T.cs[gc - c0] : 1.0);
+        gc_acc[tm] = fma(w, k, gc_acc[tm]);
+        gs_acc[tm] = fma(w * T.coef, dk, gs_acc[tm]);
+      }
+    }
+  }
+  // block reduction (fixed order): wave shuffle, then 4 partials through LDS
+  __syncthreads();
+  double* red = smem;  // reuse: [4 waves][GRAD_MAXT][2]
+#pragma unroll
+  for (int tm = 0; tm < GRAD_MAXT; ++tm) {
+    double a = gc_acc[tm], b = gs_acc[tm];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      a += __shfl_xor(a, off, 64);
+      b += __shfl_xor(b, off, 64);
+    }
+    if ((t & 63) == 0) {
+      red[((t >> 6) * GRAD_MAXT + tm) * 2 + 0] = a;
+      red[((t >> 6) * GRAD_MAXT + tm) * 2 + 1] = b;
+    }
+  }
+  __syncthreads();
+  if (t < GRAD_MAXT * 2) {
+    double s = 0.0;
+    for (int wv = 0; wv < 4; ++wv) s += red[wv * GRAD_MAXT * 2 + t];
+    const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    partials[blk * GRAD_MAXT * 2 + t] = s;
+  }
+}
+
+// out[t*2 + c] = sum_b partials[b][t][c]  (one thread per output, sequential: deterministic)
+__global__ void grad_reduce_kernel(const double* partials, long nblocks, int nterms, double* out_coef,
+                                   double* out_scale) {
+  int idx = threadIdx.x;
+  if (idx >= nterms * 2) return;
+  double s = 0.0;
+  for (long b = 0; b < nblocks; ++b) s += partials[b * GRAD_MAXT * 2 + idx];
+  if (idx & 1)
+    out_scale[idx >> 1] = s;
+  else
+    out_coef[idx >> 1] = s;
+}
+
+template <int DMAX>
+static int launch_grad_t(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0,
+                         long nc, const DevTerm* d_terms, int nterms, long trf, long tcf, long trc, long tcc,
+                         double* partials, hipStream_t s) {
+  size_t lds = (size_t)std::max<long>((long)nterms * TILE * DMAX, 4 * GRAD_MAXT * 2) * sizeof(double);
+  dim3 grid((unsigned)trc, (unsigned)tcc), block(256);
+  hipLaunchKernelGGL(grad_block_kernel<DMAX>, grid, block, lds, s, Kinv, ldk, alpha, r0, nr, c0, nc, d_terms,
+                     nterms, trf, tcf, partials);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0, long nc,
+                      const DevTerm* d_terms, int nterms, int dmax, long trf, long tcf, long trc, long tcc,
+                      double* partials, double* out_coef, double* out_scale, hipStream_t s) {
+  if (nterms <= 0 || trc <= 0 || tcc <= 0) return 0;
+  if (nterms > GRAD_MAXT) {
+    set_error("grad: too many terms in one launch");
+    return -1;
+  }
+  int rc = -1;
+#define SGP_GR(DM) rc = launch_grad_t<DM>(Kinv, ldk, alpha, r0, nr, c0, nc, d_terms, nterms, trf, tcf, trc, tcc, partials, s)
+  if (dmax <= 1) SGP_GR(1);
+  else if (dmax <= 2) SGP_GR(2);
+  else if (dmax <= 4) SGP_GR(4);
+  else if (dmax <= 8) SGP_GR(8);
+  else if (dmax <= 16) SGP_GR(16);
+  else if (dmax <= 32) SGP_GR(32);
+  else if (dmax <= 64) SGP_GR(64);
+  else {
+    set_error("grad: input dimension > 64 is not supported on device");
+    return -1;
+  }
+#undef SGP_GR
+  if (rc) return rc;
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3(1), dim3(64), 0, s, partials, trc * tcc, nterms, out_coef, out_scale);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// bordered rows of the gradient factorisation: rows [n_pad, 2 n_pad) = identity (for i < N),
+// row 2 n_pad = (y - m)', rows after it zero
+__global__ void grad_border_kernel(double* A, long ld, long n_pad, long N, const double* y,
+                                   const double* mean, long nrows) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nrows * n_pad) return;
+  long r = idx % nrows, c = idx / nrows;
+  double v = 0.0;
+  if (r < n_pad)
+    v = (r == c && c < N) ? 1.0 : 0.0;
+  else if (r == n_pad && c < N)
+    v = y[c] - (mean ? mean[c] : 0.0);
+  A[n_pad + r + c * ld] = v;
+}
+
+int launch_grad_border(double* A, long ld, long n_pad, long N, const double* y, const double* mean,
+                       long nrows, hipStream_t s) {
+  long tot = nrows * n_pad;
+  hipLaunchKernelGGL(grad_border_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, ld, n_pad, N,
+                     y, mean, nrows);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// noise gradients: scalar -> out[0] = (alpha'alpha - tr Kinv)/2 ; diag -> out[i] = (alpha_i^2 - Kinv_ii)/2
+__global__ void grad_noise_kernel(const double* Kinv, long ldk, const double* alpha, long N, int diag,
+                                  double* out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < N; i += blockDim.x) {
+    double g = 0.5 * (alpha[i] * alpha[i] - Kinv[i + i * ldk]);
+    if (diag) out[i] = g;
+    acc += g;
+  }
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0 && !diag) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N, int diag, double* out,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(grad_noise_kernel, dim3(1), dim3(256), 0, s, Kinv, ldk, alpha, N, diag, out);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sgp

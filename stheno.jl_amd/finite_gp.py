@@ -176,6 +176,56 @@ def logpdf(fx, y):
     return float(out[0]) if vec else out
 
 
+def logpdf_and_gradient(fx, y):
+    """logpdf(fx, y) and its reverse-mode gradient (what Zygote derives on the reference path).
+
+    Returns a dict: logpdf; y, mean (d/dy, d/d mean, N each); noise (scalar for f(x, s2), vector for
+    f(x, v)); terms: one record per flattened covariance term of the lower block pairs
+    {I, J, kind, coef, row_input, col_input, d_coef, d_inscale} where d_coef / d_inscale already
+    include the mirror-image pair (J, I).  d_inscale is the derivative w.r.t. a common scale g of the
+    term's inputs (stretch(f, g)); a lengthscale l = 1/g gives d/dl = -g^2 d_inscale."""
+    if not _is_prior(fx.f):
+        raise NotImplementedError("gradients are implemented for prior Stheno processes")
+    n = len(fx)
+    yv = _f64(np.asarray(y, dtype=np.float64).ravel())
+    spec = _prior_spec(fx.f, fx.x)
+    m = _f64(mean_vector(fx.f, fx.x))
+    kind, nbuf = _lib._noise_args(fx.noise, n)
+    if kind == _lib.NOISE_DENSE:
+        raise NotImplementedError("gradient with dense observation noise")
+    lp = np.zeros(1)
+    gy, gm = np.zeros(n), np.zeros(n)
+    gn = np.zeros(n if kind == _lib.NOISE_DIAG else 1)
+    nt = max(1, spec.n_terms)
+    gc, gs = np.zeros(nt), np.zeros(nt)
+    rc = _ctx().lib.sgp_logpdf_grad(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(yv),
+                                    _lib.dptr(lp), _lib.dptr(gy), _lib.dptr(gm), _lib.dptr(gn), _lib.dptr(gc),
+                                    _lib.dptr(gs))
+    _lib.check(rc, "sgp_logpdf_grad")
+    terms, nrb = [], len(spec.row_len)
+    tp = spec._term_ptr
+    index = {}
+    for I in range(nrb):
+        for J in range(nrb):
+            for t in range(tp[I * nrb + J], tp[I * nrb + J + 1]):
+                T = spec._terms[t]
+                if I >= J:
+                    key = (I, J, T.kind, T.row_input, T.col_input, T.param)
+                    index[key] = len(terms)
+                    terms.append(dict(I=I, J=J, kind=T.kind, coef=T.coef, row_input=T.row_input,
+                                      col_input=T.col_input, d_coef=float(gc[t]), d_inscale=float(gs[t])))
+    for I in range(nrb):            # fold the mirror-image pairs in
+        for J in range(I + 1, nrb):
+            for t in range(tp[I * nrb + J], tp[I * nrb + J + 1]):
+                T = spec._terms[t]
+                k = index.get((J, I, T.kind, T.col_input, T.row_input, T.param))
+                if k is not None:
+                    terms[k]["d_coef"] += float(gc[t])
+                    terms[k]["d_inscale"] += float(gs[t])
+    return dict(logpdf=float(lp[0]), y=gy, mean=gm, noise=(gn if kind == _lib.NOISE_DIAG else float(gn[0])),
+                terms=terms, _raw=(gc, gs), _spec=spec)
+
+
 def _draw(rng, n, s):
     """Z = randn(rng, n, s) in Julia's column-major fill order, from the caller's RNG."""
     if hasattr(rng, "standard_normal"):

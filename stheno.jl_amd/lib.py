@@ -66,6 +66,7 @@ _SIGS = {
     "sgp_kernelmatrix_diag": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D]),
     "sgp_logpdf": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64,
                              C.c_int64, _D]),
+    "sgp_logpdf_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D]),
     "sgp_rand": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64, C.c_int64,
                            _D, C.c_int64]),
     "sgp_posterior_create": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D,

@@ -391,3 +391,76 @@ def test_input_dimension_limit_is_reported():
     X64 = P.ColVecs(np.random.default_rng(0).standard_normal((64, 40)))
     K = P.prior_cov(f, X64)
     assert np.abs(K - okf.kernelmatrix(okf.SEKernel(), okf.ColVecs(X64.X), faithful=False)).max() < 1e-13
+
+
+# ---- reverse-mode gradient of logpdf -------------------------------------------
+def _oracle_term_grads(spec, G):
+    """sum_ij G_ij d C_ij / d theta for every raw spec term, with NumPy (tests/np_terms.py kernels)."""
+    import np_terms
+    roff = np.concatenate([[0], np.cumsum(spec.row_len)])
+    out = []
+    for (I, J, kind, ri, ci, coef, param, rs, cs) in np_terms.spec_terms(spec):
+        X, Y = spec.inputs[ri], spec.inputs[ci]
+        d2 = ((X[:, :, None] - Y[:, None, :]) ** 2).sum(0)
+        k = np_terms._kern(kind, d2, param)
+        h = 1e-6
+        dk = (np_terms._kern(kind, d2 * (1 + h) ** 2, param) - np_terms._kern(kind, d2 * (1 - h) ** 2, param)) / (2 * h)
+        w = G[roff[I]:roff[I + 1], roff[J]:roff[J + 1]]
+        if rs is not None:
+            w = w * rs[:, None]
+        if cs is not None:
+            w = w * cs[None, :]
+        out.append(((w * k).sum(), coef * (w * dk).sum()))
+    return out
+
+
+@pytest.mark.parametrize("recipe", [models.gppp_docstring, models.scaled, models.composite_kernels],
+                         ids=lambda r: r.__name__)
+def test_logpdf_gradient_terms_noise_y_mean(recipe):
+    rng = np.random.default_rng(5)
+    Fo, Fp, fo, fp = both(recipe)
+    names = list(fo)[:3]
+    D = 2
+    xs = [np.asfortranarray(rng.standard_normal((D, n))) for n in (150, 70, 131)][:len(names)]
+    xo, xp = blockdata(names, xs, True)
+    N = sum(x.shape[1] for x in xs)
+    y = rng.standard_normal(N)
+    for noise in (0.3, 0.1 + rng.random(N)):
+        lp_o, alpha, G = oagp.logpdf_gradient_wrt_cov(Fo(xo, noise), y)
+        g = P.logpdf_and_gradient(Fp(xp, noise), y)
+        assert abs(g["logpdf"] - lp_o) <= REL * abs(lp_o)
+        assert rel(g["y"], -alpha) < 1e-9 and rel(g["mean"], alpha) < 1e-9
+        if np.ndim(noise) == 0:
+            assert abs(g["noise"] - np.trace(G)) <= 1e-9 * max(1.0, abs(np.trace(G)))
+        else:
+            assert rel(g["noise"], np.diag(G)) < 1e-9
+        gc, gs = g["_raw"]
+        exp = _oracle_term_grads(g["_spec"], G)
+        assert len(exp) == g["_spec"].n_terms
+        for t, (ec, es) in enumerate(exp):
+            assert abs(gc[t] - ec) <= 1e-8 * max(1.0, abs(ec)), (t, gc[t], ec)
+            assert abs(gs[t] - es) <= 2e-6 * max(1.0, abs(es)), (t, gs[t], es)   # FD reference for dk/dg
+
+
+def test_logpdf_gradient_matches_finite_differences_of_hyperparameters():
+    """End to end: variance, lengthscale and noise of s * stretch(GP(Matern52), 1/l) -- the
+    getting_started example's parameters -- against central differences of the GPU logpdf itself."""
+    rng = np.random.default_rng(9)
+    X = P.ColVecs(rng.standard_normal((3, 400)))
+    y = rng.standard_normal(400)
+
+    def model(v, l):
+        return np.sqrt(v) * P.stretch(P.atomic(P.GP(P.Matern52Kernel()), P.GPC()), 1.0 / l)
+
+    v, l, s2 = 1.7, 0.8, 0.25
+    g = P.logpdf_and_gradient(model(v, l)(X, s2), y)
+    (term,) = g["terms"]
+    d_v = term["d_coef"]                       # K = v * k  ->  coef == v
+    d_l = -(1.0 / l) * term["d_inscale"]       # inputs X / l = g X with g = 1/l: d/dl = -(g/l) d/dg... d/dg at g=1 of (g X/l)
+    h = 1e-5
+    fd_v = (P.logpdf(model(v + h, l)(X, s2), y) - P.logpdf(model(v - h, l)(X, s2), y)) / (2 * h)
+    fd_l = (P.logpdf(model(v, l + h)(X, s2), y) - P.logpdf(model(v, l - h)(X, s2), y)) / (2 * h)
+    fd_s = (P.logpdf(model(v, l)(X, s2 + h), y) - P.logpdf(model(v, l)(X, s2 - h), y)) / (2 * h)
+    assert abs(d_v - fd_v) <= 1e-6 * max(1.0, abs(fd_v))
+    assert abs(d_l - fd_l) <= 1e-6 * max(1.0, abs(fd_l))
+    assert abs(g["noise"] - fd_s) <= 1e-6 * max(1.0, abs(fd_s))

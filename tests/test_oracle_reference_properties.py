@@ -280,3 +280,26 @@ def test_faithful_vs_direct_distances():
         assert np.abs(k.matrix(X, Y, True) - k.matrix(X, Y, False)).max() < 1e-13
         assert np.abs(k.matrix(X, None, True) - k.matrix(X, None, False)).max() < 1e-13
     assert np.array_equal(np.diag(kf.SEKernel().matrix(X)), np.ones(300))
+
+
+def test_oracle_logpdf_gradient_against_finite_differences():
+    """Pins oracle.abstractgps.logpdf_gradient_wrt_cov (the checker of the HIP gradient path) with
+    central differences of the oracle's own logpdf -- the way the reference validates AD
+    (test/test_util.jl:78-96, FiniteDifferences central_fdm)."""
+    r = rng()
+    x, y = r.standard_normal(40), r.standard_normal(40)
+
+    def lp(s2, c, l, dy=None, dm=0.0):
+        f = c * st.stretch(st.atomic(agp.GP(dm, kf.Matern52Kernel()), st.GPC()), 1.0 / l)
+        return agp.logpdf(f(x, s2), y if dy is None else y + dy)
+
+    s2, c, l = 0.3, 1.7, 0.8
+    f = c * st.stretch(st.atomic(agp.GP(kf.Matern52Kernel()), st.GPC()), 1.0 / l)
+    val, alpha, G = agp.logpdf_gradient_wrt_cov(f(x, s2), y)
+    assert val == pytest.approx(lp(s2, c, l), rel=1e-13)
+    h = 1e-6
+    assert np.trace(G) == pytest.approx((lp(s2 + h, c, l) - lp(s2 - h, c, l)) / (2 * h), rel=1e-6)
+    assert (G * f.cov(x)).sum() * 2 / c == pytest.approx((lp(s2, c + h, l) - lp(s2, c - h, l)) / (2 * h), rel=1e-6)
+    e3 = np.zeros(40)
+    e3[3] = h
+    assert -alpha[3] == pytest.approx((lp(s2, c, l, e3) - lp(s2, c, l, -e3)) / (2 * h), rel=1e-6)
