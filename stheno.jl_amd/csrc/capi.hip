@@ -37,6 +37,9 @@ struct sgp_ctx {
   long wout = 0;  // 0 = automatic
   double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
   double* d_w = nullptr;       // 128 x 128 scratch inverse
+  double* d_solve = nullptr;   // rows x 128 scratch of the refined panel solve (grown on demand)
+  long n_solve_rows = 0;
+  int refine = 1;              // SGP_REFINE=0: plain explicit-inverse panel solve (A/B timing only)
   double* d_slots = nullptr;   // per-128-block logdet contributions
   long n_slots = 0;
   double* d_scal = nullptr;    // [0] logdet, [1] misc, [16 ..] per-rhs sums
@@ -116,6 +119,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (la) c->lookahead = atoi(la);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
+    const char* rf = getenv("SGP_REFINE");
+    if (rf) c->refine = atoi(rf);
   }
   SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
   SGP_HIP(hipMalloc(&c->d_w, sizeof(double) * TILE * TILE));
@@ -135,6 +140,7 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   for (auto e : c->ev) hipEventDestroy(e);
   hipFree(c->d_invd);
   hipFree(c->d_w);
+  if (c->d_solve) hipFree(c->d_solve);
   hipFree(c->d_slots);
   hipFree(c->d_scal);
   hipFree(c->d_info);
@@ -303,6 +309,36 @@ static int assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, lo
 // ---------------------------------------------------------------------------------------
 // blocked Cholesky on the bordered matrix
 // ---------------------------------------------------------------------------------------
+// X <- X inv(Lkk)' for `rows` (multiple of 128) rows at X: the panel TRSM as MFMA GEMMs.
+// A product with the explicit inverse W = inv(Lkk) alone is not backward stable -- on the
+// ill-conditioned covariances smooth kernels produce it loses 2+ digits against LAPACK dtrsm and
+// can push the Schur complement indefinite (tools/gpu_illcond.py) -- so it is followed by one
+// step of iterative refinement against Lkk itself:
+//   S = B W',  R = B - S Lkk',  X = S + R W'
+// which restores substitution-level accuracy for 2 more K = 128 GEMMs per block column.
+static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double* W, const double* Lkk,
+                      long ldl, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (!ctx->refine)
+    return launch_gemm_nt(X, ldx, W, TILE, X, ldx, rows, TILE, TILE, 1.0, 0.0, NOMASK, 0, 0, s);
+  if (rows > ctx->n_solve_rows) {
+    SGP_HIP(hipDeviceSynchronize());
+    if (ctx->d_solve) hipFree(ctx->d_solve);
+    ctx->d_solve = nullptr;
+    ctx->n_solve_rows = 0;
+    if (hipMalloc(&ctx->d_solve, sizeof(double) * rows * TILE) != hipSuccess) {
+      set_error("panel solve: hipMalloc failed (refinement scratch)");
+      return -2;
+    }
+    ctx->n_solve_rows = rows;
+  }
+  double* S = ctx->d_solve;
+  CHECK_RC(launch_gemm_nt(X, ldx, W, TILE, S, rows, rows, TILE, TILE, 1.0, 0.0, NOMASK, 0, 0, s));
+  CHECK_RC(launch_gemm_nt(S, rows, Lkk, ldl, X, ldx, rows, TILE, TILE, -1.0, 1.0, NOMASK, 0, 0, s));
+  // in place: every workgroup owns complete rows of X (Nc == K == 128)
+  return launch_gemm_nt_cin(X, ldx, W, TILE, S, rows, X, ldx, rows, TILE, TILE, 1.0, 1.0, s);
+}
+
 // Factor one column panel in place (inner right-looking loop, nb = 128).
 // P: m x w, top w x w block is the diagonal block.  d_wstore: optional array of 128x128
 // inverse diagonal blocks to keep (indexed by block within the panel), else ctx scratch.
@@ -316,8 +352,7 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
     if (mrest > 0 || d_wstore) CHECK_RC(launch_trtri(D, ld, ctx->d_invd, W, s));
     if (mrest > 0) {
       double* A21 = P + (j + TILE) + j * ld;
-      // L21 = A21 * inv(L11)^T  (in place: every workgroup owns full rows of the panel)
-      CHECK_RC(launch_gemm_nt(A21, ld, W, TILE, A21, ld, mrest, TILE, TILE, 1.0, 0.0, NOMASK, 0, 0, s));
+      CHECK_RC(solve_rows(ctx, A21, ld, mrest, W, D, ld, s));  // L21 = A21 * L11^-T
       long wrest = w - j - TILE;
       if (wrest > 0)
         CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest,
@@ -792,8 +827,7 @@ static int row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double*
                     const double* d_wall, long n_pad, hipStream_t s) {
   for (long k = 0; k < n_pad; k += TILE) {
     double* Rk = R + k * ldr;
-    CHECK_RC(launch_gemm_nt(Rk, ldr, d_wall + (k / TILE) * (TILE * TILE), TILE, Rk, ldr, nrows, TILE,
-                            TILE, 1.0, 0.0, NOMASK, 0, 0, s));
+    CHECK_RC(solve_rows(ctx, Rk, ldr, nrows, d_wall + (k / TILE) * (TILE * TILE), L + k + k * ldl, ldl, s));
     long rest = n_pad - k - TILE;
     if (rest > 0)
       CHECK_RC(launch_gemm_nt(Rk, ldr, L + (k + TILE) + k * ldl, ldl, R + (k + TILE) * ldr, ldr, nrows,
@@ -816,15 +850,25 @@ __global__ void backsolve_gemvt_kernel(const double* L, long ld, long k0, long n
   __syncthreads();
   if (threadIdx.x == 0) z[k0 + j] -= (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ void backsolve_diag_kernel(const double* W, const double* z, double* alpha, long k0) {
-  // alpha[k0 + j] = sum_i W[i][j] z[k0 + i]   (W = inv(L_kk), so this is L_kk^-T z_k)
-  __shared__ double zs[TILE];
+__global__ void backsolve_diag_kernel(const double* W, const double* Lkk, long ld, const double* z,
+                                      double* alpha, long k0) {
+  // alpha[k0 + j] = (L_kk^-T z_k)[j]: product with W = inv(L_kk), then one refinement step against
+  // L_kk itself (same reason as solve_rows)
+  __shared__ double zs[TILE], as[TILE], rs[TILE];
   int j = threadIdx.x;
   zs[j] = z[k0 + j];
   __syncthreads();
   double acc = 0.0;
   for (int i = j; i < TILE; ++i) acc = fma(W[i + j * TILE], zs[i], acc);
-  alpha[k0 + j] = acc;
+  as[j] = acc;
+  __syncthreads();
+  double r = zs[j];
+  for (int i = j; i < TILE; ++i) r = fma(-Lkk[i + (long)j * ld], as[i], r);  // z - L_kk' a
+  rs[j] = r;
+  __syncthreads();
+  double d = 0.0;
+  for (int i = j; i < TILE; ++i) d = fma(W[i + j * TILE], rs[i], d);
+  alpha[k0 + j] = acc + d;
 }
 
 static int back_substitute(const sgp_post* post, double* d_z /*n_pad, overwritten*/,
@@ -836,7 +880,8 @@ static int back_substitute(const sgp_post* post, double* d_z /*n_pad, overwritte
       SGP_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(backsolve_diag_kernel, dim3(1), dim3(TILE), 0, s,
-                       post->d_wall + (k0 / TILE) * (TILE * TILE), d_z, d_alpha, k0);
+                       post->d_wall + (k0 / TILE) * (TILE * TILE), post->dA + k0 + k0 * post->m_tot,
+                       post->m_tot, d_z, d_alpha, k0);
     SGP_HIP(hipGetLastError());
   }
   return 0;

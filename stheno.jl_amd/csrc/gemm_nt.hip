@@ -119,7 +119,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
                                                              const double* B, long ldb, double* C,
                                                              long ldc, long K, double alpha,
                                                              double beta, long mask_off, long n_tr,
-                                                             long n_tc, long c_slice_stride) {
+                                                             long n_tc, long c_slice_stride,
+                                                             const double* Cin, long ldcin) {
   constexpr int NJ = 8, WCOLS = 32;
   long tr, tc;
   if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return;
@@ -140,6 +141,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
   // acc[j][i] = C[row = r0 + 16 i + l15][col = c0 + 4 j + lq], seeded with (beta / alpha) * C:
   // C_new = alpha * (A B' + (beta / alpha) C)
   double* Cg = C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * WCOLS + lq) * ldc;
+  // the seed may come from a different matrix than the one written (C_out = alpha A B' + beta C_in)
+  const double* Cs = Cin + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * WCOLS + lq) * ldcin;
   double acc[NJ][4];
   typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = Cg[i * 16 + (long)(j * 4) * ldc];
+      for (int i = 0; i < 4; ++i) acc[j][i] = Cs[i * 16 + (long)(j * 4) * ldcin];
     const double seed = beta / alpha;
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -401,7 +404,27 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
                        beta, mask_off, kcap_off, n_tr, n_tc);
   else
     hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
-                       mask_off, n_tr, n_tc, 0L);
+                       mask_off, n_tr, n_tc, 0L, (const double*)C, ldc);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// C_out = alpha A B' + beta C_in with C_in a different matrix than C_out (full rectangle).  C_out may
+// alias A when Nc == K == 128 (every workgroup then owns complete rows of A and has read them all
+// before its store-only epilogue) -- the refinement step of the panel solve uses exactly that.
+int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,
+                       double* C, long ldc, long M, long Nc, long K, double alpha, double beta,
+                       hipStream_t s) {
+  if (M <= 0 || Nc <= 0) return 0;
+  if (M % TILE || Nc % TILE || K % KB) {
+    set_error("gemm_nt_cin: M, Nc must be multiples of 128 and K of 16");
+    return -1;
+  }
+  long n_tr = M / TILE, n_tc = Nc / TILE;
+  long groups = ((n_tr + 7) / 8 + 7) / 8;
+  dim3 grid((unsigned)(groups * 8 * n_tc * 8));
+  hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
+                     -(1L << 40), n_tr, n_tc, 0L, Cin, ldcin);
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -422,7 +445,7 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
   long per_xcd = lower_only ? tri_ids_per_xcd(tri_shape(n_tr, n_tc)) : groups * 8 * n_tc;
   dim3 grid((unsigned)(per_xcd * 8), (unsigned)nsplit);
   hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc, K / nsplit, 1.0,
-                     0.0, mask_off, n_tr, n_tc, part_stride);
+                     0.0, mask_off, n_tr, n_tc, part_stride, (const double*)Cpart, ldc);
   SGP_HIP(hipGetLastError());
   return 0;
 }

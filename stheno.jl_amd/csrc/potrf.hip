@@ -131,8 +131,29 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(double* A, long 
           acc = mfma_f64(aop, bop, acc);
         }
         // acc[r] = sum_k Inv[lq+4r][k] * T[rb16+l15][cb16+k] = X[rb16+l15][cb16 + lq+4r]
+        // A product with an explicit inverse is not backward stable (covariances of smooth kernels
+        // cancel massively here), so one step of iterative refinement against Lcc itself follows:
+        //   R = B - X Lcc',  X += R inv(Lcc)'
+        // which restores substitution-level (LAPACK dtrsm) accuracy.  The accumulator lane map of one
+        // product is the B-operand map of the next, so both extra products stay in registers.
+        d4 nres;  // -(R)[rb16+l15][cb16 + lq+4r]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(cb * 16 + lq + 4 * r) * LDS_LD + rb * 16 + l15] = acc[r];
+        for (int r = 0; r < 4; ++r) nres[r] = -T[(cb * 16 + lq + 4 * r) * LDS_LD + rb * 16 + l15];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          double aop = T[(cb * 16 + ks * 4 + lq) * LDS_LD + cb * 16 + l15];  // Lcc[m=l15][k]
+          nres = mfma_f64(aop, acc[ks], nres);                               // acc[ks] == X[n=l15][k=4ks+lq]
+        }
+        d4 nx;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nx[r] = -acc[r];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          double aop = sInv[(ks * 4 + lq) * 16 + l15];  // Inv[m=l15][k]
+          nx = mfma_f64(aop, nres[ks], nx);             // -(X + R Inv')
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(cb * 16 + lq + 4 * r) * LDS_LD + rb * 16 + l15] = -nx[r];
       }
     }
     __syncthreads();
