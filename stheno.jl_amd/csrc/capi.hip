@@ -309,16 +309,21 @@ static int assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, lo
 // ---------------------------------------------------------------------------------------
 // blocked Cholesky on the bordered matrix
 // ---------------------------------------------------------------------------------------
-// X <- X inv(Lkk)' for `rows` (multiple of 128) rows at X: the panel TRSM as MFMA GEMMs.
+// X <- X inv(Lkk)' for `rows` (multiple of 128) rows at X: the panel TRSM.
 // A product with the explicit inverse W = inv(Lkk) alone is not backward stable -- on the
 // ill-conditioned covariances smooth kernels produce it loses 2+ digits against LAPACK dtrsm and
-// can push the Schur complement indefinite (tools/gpu_illcond.py) -- so it is followed by one
-// step of iterative refinement against Lkk itself:
-//   S = B W',  R = B - S Lkk',  X = S + R W'
-// which restores substitution-level accuracy for 2 more K = 128 GEMMs per block column.
+// can push the Schur complement indefinite (tools/gpu_illcond.py).  SGP_REFINE selects
+//   1 (default): panel_solve_kernel -- blocked substitution over 16-column blocks, each diagonal
+//                solve = inverse product + one refinement step; one launch, no inv(Lkk) needed;
+//   2: three K = 128 GEMMs  S = B W',  R = B - S Lkk',  X = S + R W'  (128-level refinement);
+//   0: X = B W' only (fast, unstable; A/B timing).
+// `inv` points at the eight 16x16 inverse diagonal blocks (block c at inv + c * inv_cstride,
+// element [m][k] at + k * inv_kstride + m): ctx->d_invd right after potrf_diag, or the diagonal of W.
 static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double* W, const double* Lkk,
-                      long ldl, hipStream_t s) {
+                      long ldl, const double* inv, long inv_cstride, long inv_kstride, hipStream_t s) {
   if (rows <= 0) return 0;
+  // default: the fused blocked-substitution kernel (potrf.hip), refined at the 16x16 level
+  if (ctx->refine == 1) return launch_panel_solve(X, ldx, rows, Lkk, ldl, inv, inv_cstride, inv_kstride, s);
   if (!ctx->refine)
     return launch_gemm_nt(X, ldx, W, TILE, X, ldx, rows, TILE, TILE, 1.0, 0.0, NOMASK, 0, 0, s);
   if (rows > ctx->n_solve_rows) {
@@ -349,10 +354,10 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
     double* W = d_wstore ? d_wstore + (j / TILE) * (TILE * TILE) : ctx->d_w;
     CHECK_RC(launch_potrf_diag(D, ld, ctx->d_invd, d_slots + j / TILE, d_info, g0 + j, s));
     long mrest = m - j - TILE;
-    if (mrest > 0 || d_wstore) CHECK_RC(launch_trtri(D, ld, ctx->d_invd, W, s));
+    if ((mrest > 0 && ctx->refine != 1) || d_wstore) CHECK_RC(launch_trtri(D, ld, ctx->d_invd, W, s));
     if (mrest > 0) {
       double* A21 = P + (j + TILE) + j * ld;
-      CHECK_RC(solve_rows(ctx, A21, ld, mrest, W, D, ld, s));  // L21 = A21 * L11^-T
+      CHECK_RC(solve_rows(ctx, A21, ld, mrest, W, D, ld, ctx->d_invd, 256, 16, s));  // L21 = A21 * L11^-T
       long wrest = w - j - TILE;
       if (wrest > 0)
         CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest,
@@ -827,7 +832,8 @@ static int row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double*
                     const double* d_wall, long n_pad, hipStream_t s) {
   for (long k = 0; k < n_pad; k += TILE) {
     double* Rk = R + k * ldr;
-    CHECK_RC(solve_rows(ctx, Rk, ldr, nrows, d_wall + (k / TILE) * (TILE * TILE), L + k + k * ldl, ldl, s));
+    const double* Wk = d_wall + (k / TILE) * (TILE * TILE);
+    CHECK_RC(solve_rows(ctx, Rk, ldr, nrows, Wk, L + k + k * ldl, ldl, Wk, 16 * TILE + 16, TILE, s));
     long rest = n_pad - k - TILE;
     if (rest > 0)
       CHECK_RC(launch_gemm_nt(Rk, ldr, L + (k + TILE) + k * ldl, ldl, R + (k + TILE) * ldr, ldr, nrows,

@@ -6,11 +6,12 @@
 // (LinearAlgebra.cholesky under AbstractGPs.logpdf/posterior/rand/elbo [EXT]).
 //
 // potrf_diag: left-looking over 16-column sub-panels.  The rank-k updates and the sub-panel
-// solves run on v_mfma_f64_16x16x4_f64 straight out of LDS (ld 144: conflict-free operand
-// reads); the 16x16 micro-Cholesky and its inverse run in the registers of one wave with
+// solves run on v_mfma_f64_16x16x4_f64 straight out of LDS (packed 16x16 blocks, k-major:
+// conflict-free operand reads); the 16x16 micro-Cholesky and its inverse run in the registers of one wave with
 // v_readlane broadcasts (no LDS round trips, no barriers) -- "wavefront shuffles for the
 // diagonal panel" in north-star terms.
 #include "common.h"
+#include <algorithm>
 
 namespace sgp {
 
@@ -22,25 +23,36 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {
 }
 
 constexpr int PD_THREADS = 512;
-constexpr size_t PD_LDS = (size_t)(TILE * LDS_LD + 256) * sizeof(double);
+// LDS: the 36 lower 16x16 blocks of the tile, block (rb, cb) at boff(rb, cb), element (m, k) of a
+// block at [k * 16 + m] (k-major: one MFMA operand k-step = 64 consecutive doubles, conflict-free),
+// plus the 16x16 inverse of the current diagonal block.  75.8 KB and <= 128 VGPRs: the workgroup
+// fits into the slot one trailing-update GEMM workgroup (73.7 KB, 8 waves x 128 VGPRs) leaves on a
+// CU, so the high-priority panel stream gets onto the chip while the update of the previous panel
+// is still running (a 149 KB tile had to wait for an entirely idle CU, i.e. for the update's tail).
+constexpr size_t PD_LDS = (size_t)(36 * 256 + 256) * sizeof(double);
+__device__ __forceinline__ int boff(int rb, int cb) { return (rb * (rb + 1) / 2 + cb) * 256; }
 
-__global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(double* A, long ld, double* invd,
-                                                                double* logdet_slot, int* info,
-                                                                long gcol0) {
+__global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_kernel(double* A, long ld, double* invd,
+                                                                   double* logdet_slot, int* info,
+                                                                   long gcol0) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  double* T = smem;                      // [128 cols][144]
-  double* sInv = smem + TILE * LDS_LD;   // 16x16 col-major
+  double* T = smem;               // packed lower blocks
+  double* sInv = smem + 36 * 256; // [k][m]
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
+  const int aoff = lq * 16 + l15;  // operand element of k-step ks: + ks * 64
 
-  for (int idx = t; idx < TILE * TILE; idx += PD_THREADS) {
-    int r = idx & 127, c = idx >> 7;
-    T[c * LDS_LD + r] = (r >= c) ? A[r + (long)c * ld] : 0.0;
+  for (int idx = t; idx < 36 * 256; idx += PD_THREADS) {
+    int blk = idx >> 8, e = idx & 255, k = e >> 4, m = e & 15;
+    int rb = 0;
+    while ((rb + 1) * (rb + 2) / 2 <= blk) ++rb;
+    int cb = blk - rb * (rb + 1) / 2;
+    int r = rb * 16 + m, c = cb * 16 + k;
+    T[idx] = (r >= c) ? A[r + (long)c * ld] : 0.0;
   }
   __syncthreads();
 
-  double logacc = 0.0;
   int firstbad = -1;
 
   for (int cb = 0; cb < 8; ++cb) {
@@ -50,36 +62,35 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(double* A, long 
       if (rb < 8) {
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
         for (int p = 0; p < cb; ++p) {
+          const double* pa = T + boff(cb, p) + aoff;  // L[cb16+m][p16+k]
+          const double* pb = T + boff(rb, p) + aoff;  // L[rb16+n][p16+k]
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            int kcol = p * 16 + ks * 4 + lq;
-            double aop = T[kcol * LDS_LD + cb * 16 + l15];  // L[cb16+m][k]
-            double bop = T[kcol * LDS_LD + rb * 16 + l15];  // L[rb16+n][k]
-            acc = mfma_f64(aop, bop, acc);
-          }
+          for (int ks = 0; ks < 4; ++ks) acc = mfma_f64(pa[ks * 64], pb[ks * 64], acc);
         }
         // acc[r] = sum_k L[cb16 + lq+4r][k] * L[rb16 + l15][k]
+        double* pc = T + boff(rb, cb) + aoff;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) T[(cb * 16 + lq + 4 * r) * LDS_LD + rb * 16 + l15] -= acc[r];
+        for (int r = 0; r < 4; ++r) pc[r * 64] -= acc[r];
       }
     }
     __syncthreads();
 
     // (2) wave 0: 16x16 micro-Cholesky in registers; lanes 16..31 carry the rows of the identity
     // through the same right-looking updates (X <- X L^-T), so inv(L)^T falls out for free.
+    double* Dcc = T + boff(cb, cb);
     if (w == 0) {
       const int i = l15;
       const bool lrow = lane < 16;       // lanes holding rows of the block itself
       double row[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        double a = T[(cb * 16 + c) * LDS_LD + cb * 16 + i];
+        double a = Dcc[c * 16 + i];
         row[c] = lrow ? a : ((c == i) ? 1.0 : 0.0);
       }
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         double djj = bcast_lane(row[j], j);
-        if (!(djj > 0.0) && firstbad < 0) firstbad = cb * 16 + j;
+        firstbad = (!(djj > 0.0) && firstbad < 0) ? cb * 16 + j : firstbad;
         // sqrt and reciprocal from one v_rsq_f64 + Newton steps: this chain is the serial
         // critical path of the whole factorisation (128 dependent pivots per diagonal block)
         double r = __builtin_amdgcn_rsq(djj);
@@ -96,25 +107,18 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(double* A, long 
           row[c2] = fma(-lij, lcj, row[c2]);
         }
       }
-      double dii = 0.0;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) dii = (c == i) ? row[c] : dii;
       if (lrow) {
 #pragma unroll
-        for (int c = 0; c < 16; ++c) T[(cb * 16 + c) * LDS_LD + cb * 16 + i] = (c <= i) ? row[c] : 0.0;
+        for (int c = 0; c < 16; ++c) Dcc[c * 16 + i] = (c <= i) ? row[c] : 0.0;
       } else if (lane < 32) {
         // lane 16 + i holds row i of inv(L)^T, i.e. column i of inv(L): Inv[c][i] = row[c], c >= i
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           double v = (c >= i) ? row[c] : 0.0;
-          sInv[i * 16 + c] = v;  // col-major: Inv[r = c][col = i]
+          sInv[i * 16 + c] = v;  // k-major: Inv[m = c][k = i]
           invd[cb * 256 + i * 16 + c] = v;
         }
       }
-      double lg = lrow ? log(dii) : 0.0;
-#pragma unroll
-      for (int off = 32; off >= 1; off >>= 1) lg += __shfl_xor(lg, off, 64);
-      logacc += lg;
     }
     __syncthreads();
 
@@ -122,38 +126,29 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(double* A, long 
     {
       int rb = cb + 1 + w;
       if (rb < 8) {
+        double* pc = T + boff(rb, cb) + aoff;  // element [row rb16 + l15][col cb16 + 4 ks + lq] at pc[ks * 64]
+        const double* pi = sInv + aoff;        // Inv[m = l15][k = 4 ks + lq]
+        const double* pl = Dcc + aoff;         // Lcc[m = l15][k = 4 ks + lq]
+        d4 b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) b[r] = pc[r * 64];
         d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          int kk = ks * 4 + lq;
-          double aop = sInv[kk * 16 + l15];                         // Inv[m=l15][k]
-          double bop = T[(cb * 16 + kk) * LDS_LD + rb * 16 + l15];  // T[rb16+n][cb16+k]
-          acc = mfma_f64(aop, bop, acc);
-        }
+        for (int ks = 0; ks < 4; ++ks) acc = mfma_f64(pi[ks * 64], b[ks], acc);
         // acc[r] = sum_k Inv[lq+4r][k] * T[rb16+l15][cb16+k] = X[rb16+l15][cb16 + lq+4r]
         // A product with an explicit inverse is not backward stable (covariances of smooth kernels
         // cancel massively here), so one step of iterative refinement against Lcc itself follows:
         //   R = B - X Lcc',  X += R inv(Lcc)'
         // which restores substitution-level (LAPACK dtrsm) accuracy.  The accumulator lane map of one
         // product is the B-operand map of the next, so both extra products stay in registers.
-        d4 nres;  // -(R)[rb16+l15][cb16 + lq+4r]
+        d4 nres = -b;  // -(R)[rb16+l15][cb16 + lq+4r]
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nres[r] = -T[(cb * 16 + lq + 4 * r) * LDS_LD + rb * 16 + l15];
+        for (int ks = 0; ks < 4; ++ks) nres = mfma_f64(pl[ks * 64], acc[ks], nres);
+        d4 nx = -acc;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          double aop = T[(cb * 16 + ks * 4 + lq) * LDS_LD + cb * 16 + l15];  // Lcc[m=l15][k]
-          nres = mfma_f64(aop, acc[ks], nres);                               // acc[ks] == X[n=l15][k=4ks+lq]
-        }
-        d4 nx;
+        for (int ks = 0; ks < 4; ++ks) nx = mfma_f64(pi[ks * 64], nres[ks], nx);  // -(X + R Inv')
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nx[r] = -acc[r];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          double aop = sInv[(ks * 4 + lq) * 16 + l15];  // Inv[m=l15][k]
-          nx = mfma_f64(aop, nres[ks], nx);             // -(X + R Inv')
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T[(cb * 16 + lq + 4 * r) * LDS_LD + rb * 16 + l15] = -nx[r];
+        for (int r = 0; r < 4; ++r) pc[r * 64] = -nx[r];
       }
     }
     __syncthreads();
@@ -161,10 +156,19 @@ __global__ __launch_bounds__(PD_THREADS) void potrf_diag_kernel(double* A, long 
 
   for (int idx = t; idx < TILE * TILE; idx += PD_THREADS) {
     int r = idx & 127, c = idx >> 7;
-    A[r + (long)c * ld] = (r >= c) ? T[c * LDS_LD + r] : 0.0;
+    double v = 0.0;
+    if (r >= c) v = T[boff(r >> 4, c >> 4) + (c & 15) * 16 + (r & 15)];
+    A[r + (long)c * ld] = v;
   }
+  // log-determinant from the finished diagonal (kept off the per-sub-panel critical path)
+  double lg = 0.0;
+  if (t < TILE) lg = log(T[boff(t >> 4, t >> 4) + (t & 15) * 17]);
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) lg += __shfl_xor(lg, off, 64);
+  if (t < TILE && lane == 0) sInv[w] = lg;
+  __syncthreads();
   if (t == 0) {
-    *logdet_slot = 2.0 * logacc;
+    *logdet_slot = 2.0 * (sInv[0] + sInv[1]);
     if (firstbad >= 0 && *info == 0) *info = (int)(gcol0 + firstbad + 1);
   }
 }
@@ -179,6 +183,105 @@ int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot,
   }
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PD_THREADS), PD_LDS, s, A, ld, d_invd,
                      d_logdet_slot, d_info, gcol0);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// panel_solve_kernel: X <- X inv(L11)' for a strip of rows (the panel TRSM; dtrsm on the reference
+// path), blocked substitution over the eight 16-column blocks of L11:
+//   T_c = B_c - sum_{p<c} X_p L_cp',   X_c = T_c inv(L_cc)' + one refinement step against L_cc
+// (the refinement makes the inverse products backward stable, see potrf_diag step 3 and
+// tools/emul_chol.py).  One wave owns 16 rows and all 128 columns, transposed into the f64 MFMA
+// accumulator layout (m = column, n = row): the accumulator lane map equals the B-operand lane map,
+// so every product consumes the previous one's registers -- no LDS round trips, no barriers after
+// the operand fill.  The 36 lower 16x16 blocks of L11 sit in LDS k-major (each k-step one contiguous
+// 512-byte read), the 8 inverse diagonal blocks in registers.  73.7 KB of LDS and 4 waves: the
+// workgroup fits into the slot one trailing-update GEMM workgroup leaves on a CU (see potrf_diag).
+// ---------------------------------------------------------------------------------------
+constexpr int PS_ROWS = 64;  // rows per workgroup (4 waves)
+constexpr size_t PS_LDS = (size_t)36 * 256 * sizeof(double);  // == one GEMM workgroup's LDS
+
+__global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx, const double* L, long ldl,
+                                                          const double* inv, long inv_cstride,
+                                                          long inv_kstride, int strips, long rows) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sL = smem;  // block (c, p), c >= p at (c (c + 1) / 2 + p) * 256, [k][m]
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  for (int idx = t; idx < 36 * 256; idx += 256) {
+    int blk = idx >> 8, e = idx & 255, k = e >> 4, m = e & 15;
+    int c = 0;
+    while ((c + 1) * (c + 2) / 2 <= blk) ++c;
+    int p = blk - c * (c + 1) / 2;
+    sL[idx] = L[(16 * c + m) + (long)(16 * p + k) * ldl];
+  }
+  __syncthreads();
+  const int aoff = lq * 16 + l15;  // A operand of k-step ks: [k = 4 ks + lq][m = l15]
+  const int ioff = (int)(lq * inv_kstride + l15);
+  // `strips` 64-row strips per workgroup: under the look-ahead overlap CU slots are the scarce
+  // resource (they free up at the rate trailing-update workgroups retire), so a slot once taken
+  // amortises its operand fill over several strips
+#pragma unroll 1
+  for (int st = 0; st < strips; ++st) {
+    __builtin_amdgcn_sched_barrier(0);
+    const long row0 = ((long)blockIdx.x * strips + st) * PS_ROWS;
+    if (row0 >= rows) break;
+    // uniform column base (scalar registers) + one 32-bit lane offset: keeps the 32 column
+    // addresses out of the vector registers
+    const int loff = (int)(row0 + w * 16 + l15 + lq * ldx);
+    d4 nb[8];  // nb[c][r] = -(B - sum X_p L_cp')[row l15][col 16 c + lq + 4 r]
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) nb[c][r] = -(X + (long)(16 * c + 4 * r) * ldx)[loff];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const double* Lcc = sL + (c * (c + 1) / 2 + c) * 256 + aoff;
+      // inverse diagonal block: operand registers straight from global (16 KB in all, L1/L2-resident)
+      double icc[4];  // inv_c[m = l15][k = 4 ks + lq]
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) icc[ks] = (inv + c * inv_cstride + ks * 4 * inv_kstride)[ioff];
+      d4 nx1 = (d4){0.0, 0.0, 0.0, 0.0};  // -(T inv(L_cc)')
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) nx1 = mfma_f64(icc[ks], nb[c][ks], nx1);
+      d4 rr = -nb[c];  // T - X1 L_cc'
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) rr = mfma_f64(Lcc[ks * 64], nx1[ks], rr);
+      d4 x = -nx1;  // X1 + R inv(L_cc)'
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) x = mfma_f64(icc[ks], rr[ks], x);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) (X + (long)(16 * c + 4 * r) * ldx)[loff] = x[r];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int c2 = c + 1; c2 < 8; ++c2)
+          nb[c2] = mfma_f64(sL[(c2 * (c2 + 1) / 2 + c) * 256 + aoff + ks * 64], x[ks], nb[c2]);
+    }
+  }
+}
+
+int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
+                       long inv_cstride, long inv_kstride, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (rows % PS_ROWS) {
+    set_error("panel_solve: rows must be a multiple of 64");
+    return -1;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    SGP_HIP(hipFuncSetAttribute((const void*)panel_solve_kernel,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS));
+    attr_set = true;
+  }
+  // one strip per workgroup until the chip is full (256 CUs), then fatter workgroups
+  long nstrips = rows / PS_ROWS;
+  int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + 255) / 256));
+  long nwg = (nstrips + strips - 1) / strips;
+  hipLaunchKernelGGL(panel_solve_kernel, dim3((unsigned)nwg), dim3(256), PS_LDS, s, X, ldx, L, ldl, inv,
+                     inv_cstride, inv_kstride, strips, rows);
   SGP_HIP(hipGetLastError());
   return 0;
 }

@@ -303,3 +303,17 @@ def test_oracle_logpdf_gradient_against_finite_differences():
     e3 = np.zeros(40)
     e3[3] = h
     assert -alpha[3] == pytest.approx((lp(s2, c, l, e3) - lp(s2, c, l, -e3)) / (2 * h), rel=1e-6)
+
+
+def test_oracle_logpdf_on_ill_conditioned_covariances_tracks_60_digit_values():
+    """tests/golden/illcond_truth.json (mpmath, 60 digits; generator committed next to it): the
+    oracle's LAPACK path loses about cond(C) * eps and no more."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "illcond_truth.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        x, y, s2 = np.array(c["x"]), np.array(c["y"]), c["noise"]
+        lo = agp.logpdf(st.atomic(agp.GP(kf.SEKernel()), st.GPC())(x, s2), y)
+        truth = float(c["logpdf"])
+        assert abs(lo - truth) / abs(truth) < 50 * 2.2e-16 / s2, (c["N"], s2)
