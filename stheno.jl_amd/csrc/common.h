@@ -79,6 +79,7 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,
                        double* C, long ldc, long M, long Nc, long K, double alpha, double beta,
                        hipStream_t s);
+int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, hipStream_t s);
 int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
                           long M, long Nc, long K, int nsplit, long part_stride, int lower_only,
                           hipStream_t s);
@@ -110,7 +111,7 @@ int launch_logpdf_final(const double* d_logdet, const double* d_sq, long N, long
 int launch_colsumsq_sub(const double* V, long ld, long nrows, long ncols, const double* prior,
                         double* out, double sign, hipStream_t s);
 int launch_gemv_rows(const double* rows, long ld, long nrows, long nc, const double* z, long ldz,
-                     const double* add, double* out, hipStream_t s);
+                     const double* add, double* out, hipStream_t s, int upper_tri = 0);
 int launch_transpose_add(const double* src, long lds, long nr, long nc, double* dst, long ldd,
                          const double* add_vec, hipStream_t s);
 int launch_scale_rows(double* rows, long ld, long nrows, long nc, const double* scale,

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
                                                              long ldc, long K, double alpha,
                                                              double beta, long mask_off, long n_tr,
                                                              long n_tc, long c_slice_stride,
-                                                             const double* Cin, long ldcin) {
+                                                             const double* Cin, long ldcin, int klo) {
   constexpr int NJ = 8, WCOLS = 32;
   long tr, tc;
   if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return;
@@ -159,9 +159,12 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
     }
   };
   const long nchunks = K / KB;
+  // klo: both operands are upper-triangular-by-tile (rows of inv(L)'), so tile row tr (>= tc)
+  // contracts only columns k >= tr * 128  (C^-1 = inv(L)' inv(L) at a third of the dense flops)
+  const long cbeg = klo ? tr * (TILE / KB) : 0;
   // prologue: the first operand chunk and the old C tile are requested together, so their
   // latencies overlap (one wait for both)
-  if (nchunks > 0) dma(0, 0);
+  if (cbeg < nchunks) dma(cbeg * KB, 0);
   if (beta != 0.0) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  for (long c = 0; c < nchunks; ++c) {
+  for (long c = cbeg; c < nchunks; ++c) {
     const int stage = (int)(c & 1);
     // the other stage was last read in iteration c-1, which every wave left through the barrier
     if (c + 1 < nchunks) dma((c + 1) * KB, stage ^ 1);
@@ -404,7 +407,7 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
                        beta, mask_off, kcap_off, n_tr, n_tc);
   else
     hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
-                       mask_off, n_tr, n_tc, 0L, (const double*)C, ldc);
+                       mask_off, n_tr, n_tc, 0L, (const double*)C, ldc, 0);
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -424,7 +427,23 @@ int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, con
   long groups = ((n_tr + 7) / 8 + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * n_tc * 8));
   hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
-                     -(1L << 40), n_tr, n_tc, 0L, Cin, ldcin);
+                     -(1L << 40), n_tr, n_tc, 0L, Cin, ldcin, 0);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// C[lower tiles] = X X' for X upper-triangular by 128-tile (n x n, X[i][k] = 0 for k < 128 floor(i/128)):
+// tile (tr, tc), tr >= tc, contracts k >= tr * 128 only.
+int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, hipStream_t s) {
+  if (n <= 0) return 0;
+  if (n % TILE) {
+    set_error("gemm_nt_uut: n must be a multiple of 128");
+    return -1;
+  }
+  long n_t = n / TILE;
+  long per_xcd = tri_ids_per_xcd(tri_shape(n_t, n_t));
+  hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
+                     1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 1);
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -445,7 +464,7 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
   long per_xcd = lower_only ? tri_ids_per_xcd(tri_shape(n_tr, n_tc)) : groups * 8 * n_tc;
   dim3 grid((unsigned)(per_xcd * 8), (unsigned)nsplit);
   hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc, K / nsplit, 1.0,
-                     0.0, mask_off, n_tr, n_tc, part_stride, (const double*)Cpart, ldc);
+                     0.0, mask_off, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 0);
   SGP_HIP(hipGetLastError());
   return 0;
 }

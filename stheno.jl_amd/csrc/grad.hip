@@ -61,9 +61,13 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
                                                          const DevTerm* terms, int nterms,
                                                          long tile_r_first, long tile_c_first,
                                                          double* partials /*[blocks][GRAD_MAXT][2]*/) {
+  // terms per launch: nterms * DMAX <= 64 (the launcher groups them so), at most GRAD_MAXT
+  constexpr int TMAX = (64 / DMAX < GRAD_MAXT) ? 64 / DMAX : GRAD_MAXT;
   const long gtr = tile_r_first + blockIdx.x;
   const long gtc = tile_c_first + blockIdx.y;
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // [nterms][128][DMAX] + reduction scratch
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sx = smem;                           // [nterms][128][DMAX] column points
+  double* scs = smem + TMAX * TILE * DMAX;     // [nterms][128] column scales
   const int t = threadIdx.x;
   const int trow = t & 127, th = t >> 7;
   long cbeg = gtc * TILE, cend = cbeg + TILE;
@@ -81,7 +85,11 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
       long gc = gtc * TILE + p;
       double v = 0.0;
       if (live_tile && d < T.dim && gc >= cbeg && gc < cend) v = T.xc[(gc - c0) * T.ldc + d];
-      smem[(tm * TILE + p) * DMAX + d] = v;
+      sx[(tm * TILE + p) * DMAX + d] = v;
+    }
+    if (t < TILE) {
+      long gc = gtc * TILE + t;
+      scs[tm * TILE + t] = (live_tile && T.cs && gc >= cbeg && gc < cend) ? T.cs[gc - c0] : 1.0;
     }
   }
   __syncthreads();
@@ -94,27 +102,46 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
   if (live_tile && grow >= rbeg && grow < rend) {
     const long lrow = grow - r0;
     const double ai = alpha[grow];
-    for (int p = th * 64; p < th * 64 + 64; ++p) {
-      const long gc = gtc * TILE + p;
+    // per-term row data in registers: the row point, its scale, the term constants
+    double xr[TMAX * DMAX], rsv[TMAX], coef[TMAX], param[TMAX];
+    int kind[TMAX];
+#pragma unroll
+    for (int tm = 0; tm < TMAX; ++tm) {
+      kind[tm] = G_CONST;
+      rsv[tm] = coef[tm] = param[tm] = 0.0;
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) xr[tm * DMAX + d] = 0.0;
+      if (tm < nterms) {
+        const DevTerm T = terms[tm];
+        kind[tm] = T.kind;
+        coef[tm] = T.coef;
+        param[tm] = T.param;
+        rsv[tm] = T.rs ? T.rs[lrow] : 1.0;
+        const double* xp = T.xr + lrow * T.ldr;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) xr[tm * DMAX + d] = (d < T.dim) ? xp[d] : 0.0;
+      }
+    }
+    const long pbeg = th * 64, gcol0 = gtc * TILE;
+    for (int p = (int)pbeg; p < (int)pbeg + 64; ++p) {
+      const long gc = gcol0 + p;
       if (gc < cbeg || gc >= cend) continue;
       const double g = 0.5 * (ai * alpha[gc] - Kinv[grow + gc * ldk]);
 #pragma unroll
-      for (int tm = 0; tm < GRAD_MAXT; ++tm) {
+      for (int tm = 0; tm < TMAX; ++tm) {
         if (tm >= nterms) break;
-        const DevTerm T = terms[tm];
-        const double* xr = T.xr + lrow * T.ldr;
-        const double* sp = &smem[(tm * TILE + p) * DMAX];
+        const double* sp = &sx[(tm * TILE + p) * DMAX];
         double d2 = 0.0;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
-          double df = ((d < T.dim) ? xr[d] : 0.0) - sp[d];
+          double df = xr[tm * DMAX + d] - sp[d];
           d2 = fma(df, df, d2);
         }
         double k, dk;
-        kern_and_dscale(T.kind, d2, T.param, k, dk);
-        double w = g * (T.rs ? T.rs[lrow] : 1.0) * (T.cs ? T.cs[gc - c0] : 1.0);
+        kern_and_dscale(kind[tm], d2, param[tm], k, dk);
+        double w = g * rsv[tm] * scs[tm * TILE + p];
         gc_acc[tm] = fma(w, k, gc_acc[tm]);
-        gs_acc[tm] = fma(w * T.coef, dk, gs_acc[tm]);
+        gs_acc[tm] = fma(w * coef[tm], dk, gs_acc[tm]);
       }
     }
   }
@@ -143,25 +170,45 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
   }
 }
 
-// out[t*2 + c] = sum_b partials[b][t][c]  (one thread per output, sequential: deterministic)
-__global__ void grad_reduce_kernel(const double* partials, long nblocks, int nterms, double* out_coef,
-                                   double* out_scale) {
-  int idx = threadIdx.x;
-  if (idx >= nterms * 2) return;
+// out[t*2 + c] = sum_b partials[b][t][c]: one workgroup per output, 256 strided partial sums
+// combined by a fixed tree (deterministic)
+__global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partials, long nblocks, int nterms,
+                                                          double* out_coef, double* out_scale) {
+  __shared__ double sh[256];
+  const int idx = blockIdx.x;  // term * 2 + component
   double s = 0.0;
-  for (long b = 0; b < nblocks; ++b) s += partials[b * GRAD_MAXT * 2 + idx];
-  if (idx & 1)
-    out_scale[idx >> 1] = s;
-  else
-    out_coef[idx >> 1] = s;
+  for (long b = threadIdx.x; b < nblocks; b += 256) s += partials[b * GRAD_MAXT * 2 + idx];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (idx & 1)
+      out_scale[idx >> 1] = sh[0];
+    else
+      out_coef[idx >> 1] = sh[0];
+  }
 }
 
 template <int DMAX>
 static int launch_grad_t(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0,
                          long nc, const DevTerm* d_terms, int nterms, long trf, long tcf, long trc, long tcc,
                          double* partials, hipStream_t s) {
-  size_t lds = (size_t)std::max<long>((long)nterms * TILE * DMAX, 4 * GRAD_MAXT * 2) * sizeof(double);
+  constexpr int TMAX = (64 / DMAX < GRAD_MAXT) ? 64 / DMAX : GRAD_MAXT;
+  if (nterms > TMAX) {
+    set_error("grad: too many terms in one launch for this input dimension");
+    return -1;
+  }
+  size_t lds = (size_t)(TMAX * TILE * DMAX + TMAX * TILE) * sizeof(double);
   dim3 grid((unsigned)trc, (unsigned)tcc), block(256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SGP_HIP(hipFuncSetAttribute((const void*)grad_block_kernel<DMAX>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
+    attr_set = true;
+  }
   hipLaunchKernelGGL(grad_block_kernel<DMAX>, grid, block, lds, s, Kinv, ldk, alpha, r0, nr, c0, nc, d_terms,
                      nterms, trf, tcf, partials);
   SGP_HIP(hipGetLastError());
@@ -191,22 +238,23 @@ int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0
   }
 #undef SGP_GR
   if (rc) return rc;
-  hipLaunchKernelGGL(grad_reduce_kernel, dim3(1), dim3(64), 0, s, partials, trc * tcc, nterms, out_coef, out_scale);
+  hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(nterms * 2)), dim3(256), 0, s, partials, trc * tcc, nterms, out_coef,
+                     out_scale);
   SGP_HIP(hipGetLastError());
   return 0;
 }
 
-// bordered rows of the gradient factorisation: rows [n_pad, 2 n_pad) = identity (for i < N),
-// row 2 n_pad = (y - m)', rows after it zero
+// bordered rows of the gradient factorisation: row n_pad = (y - m)' (+ 127 zero rows),
+// rows [n_pad + 128, 2 n_pad + 128) = identity (for i < N)
 __global__ void grad_border_kernel(double* A, long ld, long n_pad, long N, const double* y,
                                    const double* mean, long nrows) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= nrows * n_pad) return;
   long r = idx % nrows, c = idx / nrows;
   double v = 0.0;
-  if (r < n_pad)
-    v = (r == c && c < N) ? 1.0 : 0.0;
-  else if (r == n_pad && c < N)
+  if (r >= TILE)
+    v = (r - TILE == c && c < N) ? 1.0 : 0.0;
+  else if (r == 0 && c < N)
     v = y[c] - (mean ? mean[c] : 0.0);
   A[n_pad + r + c * ld] = v;
 }

@@ -93,22 +93,47 @@ int launch_colsumsq_sub(const double* V, long ld, long nrows, long ncols, const 
   return 0;
 }
 
-// out[j] = add[j] + sum_{c<nc} rows[j + c*ld] * z[c*ldz]   (posterior mean m* + V' z)
-__global__ void gemv_rows_kernel(const double* rows, long ld, long nc, const double* z, long ldz,
-                                 const double* add, double* out) {
-  __shared__ double sh[4];
-  const long j = blockIdx.x;
+// out[j] = add[j] + sum_{c<nc} rows[j + c*ld] * z[c*ldz]   (posterior mean m* + V' z; alpha = inv(L)' z)
+// Column-oriented: a workgroup owns 32 consecutive rows, its 8 k-lanes stride over the columns, so
+// every wave load is two contiguous 256-byte row segments of the column-major matrix; the k-lanes
+// are combined through LDS in fixed order (deterministic).  upper_tri: row j is zero left of column
+// 128 * floor(j / 128) (rows of inv(L)'), those columns are skipped.
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const double* rows, long ld, long nrows, long nc,
+                                                        const double* z, long ldz, const double* add,
+                                                        double* out, int upper_tri) {
+  __shared__ double sh[8][33];
+  const int r = threadIdx.x & 31, kq = threadIdx.x >> 5;
+  const long j0 = (long)blockIdx.x * 32, j = j0 + r;
+  const long cbeg = upper_tri ? (j0 / TILE) * TILE : 0;
   double acc = 0.0;
-  for (long c = threadIdx.x; c < nc; c += blockDim.x) acc = fma(rows[j + c * ld], z[c * ldz], acc);
-  double tot = block_sum_256(acc, sh);
-  if (threadIdx.x == 0) out[j] = (add ? add[j] : 0.0) + tot;
+  if (j < nrows) {
+    const double* p = rows + j;
+    long c = cbeg + kq;
+    for (; c + 24 < nc; c += 32) {
+      double a0 = p[c * ld], a1 = p[(c + 8) * ld], a2 = p[(c + 16) * ld], a3 = p[(c + 24) * ld];
+      double z0 = z[c * ldz], z1 = z[(c + 8) * ldz], z2 = z[(c + 16) * ldz], z3 = z[(c + 24) * ldz];
+      acc = fma(a0, z0, acc);
+      acc = fma(a1, z1, acc);
+      acc = fma(a2, z2, acc);
+      acc = fma(a3, z3, acc);
+    }
+    for (; c < nc; c += 8) acc = fma(p[c * ld], z[c * ldz], acc);
+  }
+  sh[kq][r] = acc;
+  __syncthreads();
+  if (kq == 0 && j < nrows) {
+    double tot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) tot += sh[q][r];
+    out[j] = (add ? add[j] : 0.0) + tot;
+  }
 }
 
 int launch_gemv_rows(const double* rows, long ld, long nrows, long nc, const double* z, long ldz,
-                     const double* add, double* out, hipStream_t s) {
+                     const double* add, double* out, hipStream_t s, int upper_tri) {
   if (nrows <= 0) return 0;
-  hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)nrows), dim3(256), 0, s, rows, ld, nc, z, ldz,
-                     add, out);
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3((unsigned)((nrows + 31) / 32)), dim3(256), 0, s, rows, ld, nrows, nc,
+                     z, ldz, add, out, upper_tri);
   SGP_HIP(hipGetLastError());
   return 0;
 }
