@@ -153,6 +153,28 @@ int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross, const sgp_c
                           double* cov_out, int64_t ldcov);
 int sgp_posterior_destroy(sgp_post* post);
 
+/* ---- elbo and its reverse-mode gradient -----------------------------------
+ * What Zygote derives through `elbo(VFE(f(z)), f(x, s2), y)` on the reference path
+ * (AbstractGPs.elbo [EXT], App. A.6; src/gp/sparse_finite_gp.jl:37-62).  Arguments as sgp_elbo
+ * (Sigma_y and Sigma_z scalar or diagonal).  Outputs (any but elbo_out may be NULL):
+ *   grad_y[N], grad_mean[N] = -grad_y, grad_noise[1 | N], grad_var_x[N] = -1/(2 sy),
+ *   grad_z_noise[1 | M] (tr / diag of d elbo / d (Kzz + Sigma_z)),
+ *   grad_coef_zz / grad_inscale_zz: one entry per term of zz (every block pair reports its own term),
+ *   grad_coef_xz / grad_inscale_xz: one entry per term of xz;  meaning as in sgp_logpdf_grad.
+ * The dependence on the prior variances var_x is returned as grad_var_x; chain it through
+ * sgp_kernelmatrix_diag_grad for the parameters of the diagonal spec. */
+int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                  const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                  const double* z_noise, const double* y, double* elbo_out, double* grad_y,
+                  double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
+                  double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
+                  double* grad_inscale_xz);
+/* sum_i w[i] d var_i / d theta for var = sgp_kernelmatrix_diag(spec): per term of the diagonal block
+ * pairs (I, I), grad_coef[t] = sum_i w_i rs_i cs_i k_t(x_i, x'_i), grad_inscale[t] likewise with
+ * coef_t dk_t/dg; entries of other terms are set to 0.  Both outputs have spec->term_ptr[last] entries. */
+int sgp_kernelmatrix_diag_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
+                               double* grad_inscale);
+
 /* ---- elbo(VFE(fz), fx, y) (A5; App. A.6; src/gp/sparse_finite_gp.jl:52-58) -----------
  * zz: symmetric spec at the inducing inputs z (M);  xz: cross spec rows = x (N), cols = z;
  * var_x: prior var(f, x) (N) -- obtain with sgp_kernelmatrix_diag;  mean_x (N; NULL==0);

@@ -291,3 +291,39 @@ def logpdf_gradient_wrt_cov(fx, y):
     z = sla.solve_triangular(L, delta, lower=True, check_finite=False)
     lp = -0.5 * (len(m) * LOG2PI + 2.0 * np.log(np.diag(L)).sum() + z @ z)
     return float(lp), alpha, 0.5 * (np.outer(alpha, alpha) - Cinv)
+
+
+def elbo_gradient_wrt_cov(vfe, fx, y):
+    """elbo (A.6) and its reverse-mode gradient w.r.t. the matrices it is built from -- what Zygote
+    derives through AbstractGPs.elbo on the reference path.  With
+    Lambda = diag(sy)^-1/2, A = Lz^-1 Kzx Lambda, B = A A' + I, delta = Lambda (y - m),
+    u = B^-1 A delta, J = Lz^-T:
+        dA     = (I - B^-1 - u u') A + u delta'
+        dKxz   = Lambda dA' Lz^-1                                (N x M)
+        dKzz   = -1/2 J (B + B^-1 - 2 I + u u') J'               (M x M, w.r.t. Kzz + Sigma_z)
+        ddelta = -delta + A' u ;  dy = Lambda ddelta = -dmean
+        dvar   = -1/(2 sy)
+        dsy    = -1/(2 sy) + var/(2 sy^2) - (ddelta delta + diag(A' dA)) / (2 sy)
+    Returns dict(elbo, Kzz, Kxz, var, noise, y, mean); noise is summed for scalar noise."""
+    Lz, A, Le, delta, sy = _vfe_parts(vfe, fx, y)
+    M, N = A.shape
+    I = np.eye(M)
+    B = A @ A.T + I
+    c = A @ delta
+    u = sla.cho_solve((Le, True), c, check_finite=False)
+    Binv = sla.cho_solve((Le, True), I, check_finite=False)
+    Z = I - Binv - np.outer(u, u)
+    S = B + Binv - 2.0 * I + np.outer(u, u)
+    J = sla.solve_triangular(Lz, I, lower=True, check_finite=False).T       # Lz^-T
+    rsig = 1.0 / np.sqrt(sy)
+    dA_T = A.T @ Z + np.outer(delta, u)                                       # N x M
+    dKxz = rsig[:, None] * (dA_T @ J.T)
+    dKzz = -0.5 * J @ S @ J.T
+    ddelta = -delta + A.T @ u
+    dy = ddelta * rsig
+    v = fx.f.var(fx.x)
+    diagdot = (A.T * dA_T).sum(1)
+    dsy = -0.5 / sy + 0.5 * v / sy ** 2 - 0.5 * (ddelta * delta + diagdot) / sy
+    scalar_noise = np.asarray(fx.noise).ndim == 0
+    return dict(elbo=elbo(vfe, fx, y), Kzz=dKzz, Kxz=dKxz, var=-0.5 / sy,
+                noise=float(dsy.sum()) if scalar_noise else dsy, y=dy, mean=-dy)

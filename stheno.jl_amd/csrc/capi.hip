@@ -548,6 +548,10 @@ struct DevBuf {
     if (p) hipFree(p);
   }
   int alloc(size_t n) {
+    if (p) {
+      hipFree(p);
+      p = nullptr;
+    }
     if (hipMalloc(&p, sizeof(double) * std::max<size_t>(1, n)) != hipSuccess) {
       set_error("hipMalloc failed (" + std::to_string(n * 8) + " bytes)");
       p = nullptr;
@@ -717,6 +721,31 @@ extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* me
   return 0;
 }
 
+// sum_ij G_ij dC_ij / d theta per flattened term of every block pair of `ds` (grad.hip):
+// G = (alpha alpha' - Kinv) / 2 when alpha != nullptr, else G = the matrix at `Gm` itself.
+static int contract_spec(const sgp_dspec* ds, const double* Gm, long ldg, const double* alpha, long n_tr,
+                         long n_tc, DevBuf& dpart, double* dgc, double* dgs, hipStream_t s) {
+  CHECK_RC(dpart.alloc((size_t)std::max<long>(1, n_tr * n_tc) * 16));
+  for (int I = 0; I < ds->nrb; ++I) {
+    if (ds->row_len[I] == 0) continue;
+    for (int J = 0; J < ds->ncb; ++J) {
+      if (ds->col_len[J] == 0) continue;
+      long r0 = ds->row_off[I], nr = ds->row_len[I], c0 = ds->col_off[J], nc = ds->col_len[J];
+      long trf = r0 / TILE, trl = (r0 + nr - 1) / TILE + 1, tcf = c0 / TILE, tcl = (c0 + nc - 1) / TILE + 1;
+      int p = I * ds->ncb + J;
+      int t0 = ds->term_ptr[p], t1 = ds->term_ptr[p + 1];
+      int dmax = ds->pair_dmax[p];
+      int per = std::min(8, std::max(1, 64 / dmax));
+      for (int t = t0; t < t1; t += per) {
+        int cnt = std::min(per, t1 - t);
+        CHECK_RC(launch_grad_block(Gm, ldg, alpha, r0, nr, c0, nc, ds->d_terms + t, cnt, dmax, trf, tcf,
+                                   trl - trf, tcl - tcf, dpart.p, dgc + t, dgs + t, s));
+      }
+    }
+  }
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // logpdf + reverse-mode gradient
 // ---------------------------------------------------------------------------------------
@@ -777,28 +806,8 @@ extern "C" int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
   CHECK_RC(launch_gemm_nt_uut(Rinv, m_tot, dKinv.p, n_pad, n_pad, s));
   CHECK_RC(launch_mirror_lower(dKinv.p, n_pad, n_pad, s));
   if (grad_noise) CHECK_RC(launch_grad_noise(dKinv.p, n_pad, dalpha.p, N, nd.kind == SGP_NOISE_DIAG, dgn.p, s));
-  if (grad_coef || grad_inscale) {
-    // per block pair, per group of <= GRAD_MAXT terms
-    long max_blocks = (n_pad / TILE) * (n_pad / TILE);
-    CHECK_RC(dpart.alloc((size_t)max_blocks * 16));
-    for (int I = 0; I < ds->nrb; ++I) {
-      if (ds->row_len[I] == 0) continue;
-      for (int J = 0; J < ds->ncb; ++J) {
-        if (ds->col_len[J] == 0) continue;
-        long r0 = ds->row_off[I], nr = ds->row_len[I], c0 = ds->col_off[J], nc = ds->col_len[J];
-        long trf = r0 / TILE, trl = (r0 + nr - 1) / TILE + 1, tcf = c0 / TILE, tcl = (c0 + nc - 1) / TILE + 1;
-        int p = I * ds->ncb + J;
-        int t0 = ds->term_ptr[p], t1 = ds->term_ptr[p + 1];
-        int dmax = ds->pair_dmax[p];
-        int per = std::min(8, std::max(1, 64 / dmax));
-        for (int t = t0; t < t1; t += per) {
-          int cnt = std::min(per, t1 - t);
-          CHECK_RC(launch_grad_block(dKinv.p, n_pad, dalpha.p, r0, nr, c0, nc, ds->d_terms + t, cnt, dmax, trf,
-                                     tcf, trl - trf, tcl - tcf, dpart.p, dgc.p + t, dgs.p + t, s));
-        }
-      }
-    }
-  }
+  if (grad_coef || grad_inscale)
+    CHECK_RC(contract_spec(ds, dKinv.p, n_pad, dalpha.p, n_pad / TILE, n_pad / TILE, dpart, dgc.p, dgs.p, s));
   int info = fetch_info(ctx, s);
   if (info > 0) {
     set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
@@ -1277,6 +1286,246 @@ extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   double tmp = h[0] + h[4] + h[1] - h[5];
   double dtc = -0.5 * ((double)N * 1.8378770664093453 + tmp);
   out[0] = dtc - 0.5 * (h[2] - h[3]);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// elbo + reverse-mode gradient (second half).  Formulas: oracle/abstractgps.py
+// elbo_gradient_wrt_cov (checked against finite differences there).  Both factorisations carry
+// identity rows (row-limited, `grow`) so that J = Lz^-T and Le^-T come out of the panel solves:
+//   dA' = R Z + delta u'          (R = A', Z = I - B^-1 - u u')
+//   G_xz = Lambda (R Z J' + delta (J u)')                      -> contraction over the xz spec
+//   G_zz = -1/2 J (B + B^-1 - 2 I + u u') J'                   -> contraction over the zz spec
+// ---------------------------------------------------------------------------------------
+extern "C" int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                             const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                             const double* z_noise, const double* y, double* elbo_out, double* grad_y,
+                             double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
+                             double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
+                             double* grad_inscale_xz) {
+  CHECK_ARG(ctx && zz && xz && var_x && noise_x && z_noise && y && elbo_out, "sgp_elbo_grad: NULL argument");
+  CHECK_ARG(zz->symmetric, "sgp_elbo_grad: zz spec must be symmetric");
+  CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+            "sgp_elbo_grad: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
+  CHECK_ARG(z_noise_kind == SGP_NOISE_SCALAR || z_noise_kind == SGP_NOISE_DIAG,
+            "sgp_elbo_grad: Sigma_z must be isotropic or diagonal");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard gz, gx;
+  CHECK_RC(sgp_dspec_create(ctx, zz, &gz.ds));
+  CHECK_RC(sgp_dspec_create(ctx, xz, &gx.ds));
+  const long M = gz.ds->N, N = gx.ds->N;
+  CHECK_ARG(gx.ds->M == M, "sgp_elbo_grad: xz spec columns != number of inducing points");
+  CHECK_ARG(M >= 1 && N >= 1, "sgp_elbo_grad: empty inputs");
+  const long m_pad = rup(M, TILE), n_rows = rup(N, TILE);
+  const long ld = m_pad + n_rows + m_pad;   // [Kzz + Sigma_z ; K(x,z) Lambda ; I]
+  const long ldg = m_pad + TILE + m_pad;    // [A A' + I ; (A delta)' ; I]
+  hipStream_t s = ctx->stream;
+  DevBuf dA, dG, dB, dBinv, dZ, dS, dRZ, dT1, dGzz, dy, dmean, dvar, ddelta, drsig, dots, sq, du, dut, dgy, dgsy,
+      dpart, dgcz, dgsz, dgcx, dgsx;
+  NoiseDev ndx, ndz;
+  CHECK_RC(dA.alloc((size_t)ld * m_pad));
+  CHECK_RC(dG.alloc((size_t)ldg * m_pad));
+  CHECK_RC(dB.alloc((size_t)m_pad * m_pad));
+  CHECK_RC(dBinv.alloc((size_t)m_pad * m_pad));
+  CHECK_RC(dZ.alloc((size_t)m_pad * m_pad));
+  CHECK_RC(dS.alloc((size_t)m_pad * m_pad));
+  CHECK_RC(dT1.alloc((size_t)m_pad * m_pad));
+  CHECK_RC(dGzz.alloc((size_t)m_pad * m_pad));
+  CHECK_RC(dRZ.alloc((size_t)n_rows * m_pad));
+  CHECK_RC(dy.upload(y, N));
+  if (mean_x) CHECK_RC(dmean.upload(mean_x, N));
+  CHECK_RC(dvar.upload(var_x, N));
+  CHECK_RC(upload_noise(ndx, noise_kind, noise_x, N));
+  CHECK_RC(upload_noise(ndz, z_noise_kind, z_noise, M));
+  CHECK_RC(ddelta.alloc(n_rows));
+  CHECK_RC(drsig.alloc(n_rows));
+  CHECK_RC(dots.alloc(m_pad));
+  CHECK_RC(sq.alloc(m_pad));
+  CHECK_RC(du.alloc(m_pad));
+  CHECK_RC(dut.alloc(m_pad));
+  CHECK_RC(dgy.alloc(N));
+  CHECK_RC(dgsy.alloc(N));
+  const size_t ntz = std::max<size_t>(1, gz.ds->h_terms.size()), ntx = std::max<size_t>(1, gx.ds->h_terms.size());
+  CHECK_RC(dgcz.alloc(ntz));
+  CHECK_RC(dgsz.alloc(ntz));
+  CHECK_RC(dgcx.alloc(ntx));
+  CHECK_RC(dgsx.alloc(ntx));
+  SGP_HIP(hipMemsetAsync(dgcz.p, 0, sizeof(double) * ntz, s));
+  SGP_HIP(hipMemsetAsync(dgsz.p, 0, sizeof(double) * ntz, s));
+  SGP_HIP(hipMemsetAsync(dgcx.p, 0, sizeof(double) * ntx, s));
+  SGP_HIP(hipMemsetAsync(dgsx.p, 0, sizeof(double) * ntx, s));
+  double* d_o = ctx->d_scal + 1;  // h[0..2]; h[3] at +4, h[4] at +5, h[5] at +6
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  SGP_HIP(hipMemsetAsync(ddelta.p, 0, sizeof(double) * n_rows, s));
+  SGP_HIP(hipMemsetAsync(drsig.p, 0, sizeof(double) * n_rows, s));
+  hipLaunchKernelGGL(elbo_scalars_kernel, dim3(1), dim3(256), 0, s, dy.p, mean_x ? dmean.p : nullptr, dvar.p,
+                     ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_o);
+  SGP_HIP(hipGetLastError());
+  // ---- factor 1: [Kzz + Sigma_z ; K(x,z) Lambda ; I]  ->  Lz, R = A', J = Lz^-T
+  CHECK_RC(assemble(gz.ds, dA.p, ld, 0, m_pad / TILE, 0, m_pad / TILE, 1, ndz.kind, ndz.sigma2, ndz.diag.p, s));
+  CHECK_RC(launch_fill_pad(dA.p, ld, M, m_pad, 0, m_pad, ld, 0, s));
+  if (n_rows > N)
+    SGP_HIP(hipMemset2DAsync(dA.p + m_pad + N, sizeof(double) * ld, 0, sizeof(double) * (n_rows - N), (size_t)m_pad,
+                             s));
+  CHECK_RC(assemble(gx.ds, dA.p + m_pad, ld, 0, n_rows / TILE, 0, m_pad / TILE, 0, -1, 0.0, nullptr, s));
+  CHECK_RC(launch_scale_rows(dA.p + m_pad, ld, N, m_pad, drsig.p, s));
+  double* Jm = dA.p + m_pad + n_rows;
+  SGP_HIP(hipMemset2DAsync(Jm, sizeof(double) * ld, 0, sizeof(double) * m_pad, (size_t)m_pad, s));
+  hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, Jm, ld, m_pad);
+  SGP_HIP(hipGetLastError());
+  CHECK_RC(chol_bordered(ctx, dA.p, ld, m_pad, ld, nullptr, s, m_pad + n_rows));
+  int info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("vfe: Kzz + Sigma_z is not positive definite (leading minor " + std::to_string(info) + ")");
+    return info;
+  }
+  const double* R = dA.p + m_pad;
+  hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, R, ld, n_rows, ddelta.p, dots.p, sq.p);
+  SGP_HIP(hipGetLastError());
+  CHECK_RC(launch_sum_array(sq.p, m_pad, ctx->d_scal + 4, s));
+  // ---- B = A A' + I (transpose + split-K Gram, as in the forward pass), kept full in dB
+  SGP_HIP(hipMemsetAsync(dG.p, 0, sizeof(double) * ldg * m_pad, s));
+  {
+    DevBuf dAt, dPart;
+    CHECK_RC(dAt.alloc((size_t)m_pad * n_rows));
+    CHECK_RC(launch_transpose_add(R, ld, n_rows, m_pad, dAt.p, m_pad, nullptr, s));
+    long tiles = (m_pad / TILE) * (m_pad / TILE + 1) / 2;
+    int nsplit = 1;
+    while (tiles * nsplit < 4096 && nsplit < 64 && (n_rows % (16L * nsplit * 2)) == 0 &&
+           n_rows / (nsplit * 2) >= 2048)
+      nsplit *= 2;
+    long stride = ldg * m_pad;
+    CHECK_RC(dPart.alloc((size_t)nsplit * stride));
+    CHECK_RC(launch_gemm_nt_splitk(dAt.p, m_pad, dAt.p, m_pad, dPart.p, ldg, m_pad, m_pad, n_rows, nsplit, stride, 1,
+                                   s));
+    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG.p, ldg, m_pad, m_pad, 1.0, 0.0, 1, s));
+    SGP_HIP(hipStreamSynchronize(s));
+  }
+  hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG.p, ldg, m_pad);
+  SGP_HIP(hipMemcpy2DAsync(dB.p, sizeof(double) * m_pad, dG.p, sizeof(double) * ldg, sizeof(double) * m_pad,
+                           (size_t)m_pad, hipMemcpyDeviceToDevice, s));
+  CHECK_RC(launch_mirror_lower(dB.p, m_pad, m_pad, s));
+  hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG.p, ldg, m_pad, dots.p,
+                     m_pad);
+  double* Je = dG.p + m_pad + TILE;
+  hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, Je, ldg, m_pad);
+  SGP_HIP(hipGetLastError());
+  // ---- factor 2: [B ; (A delta)' ; I]  ->  Le, b' = (Le^-1 A delta)', Je = Le^-T
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  CHECK_RC(chol_bordered(ctx, dG.p, ldg, m_pad, ldg, nullptr, s, m_pad + TILE));
+  CHECK_RC(launch_sum_array(ctx->d_slots, m_pad / TILE, ctx->d_scal + 5, s));
+  CHECK_RC(launch_rowsumsq(dG.p + m_pad, ldg, m_pad, 1, ctx->d_scal + 6, 0, s));
+  double h[6];
+  SGP_HIP(hipMemcpyAsync(h, ctx->d_scal + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
+  info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("vfe: A A' + I is not positive definite (leading minor " + std::to_string(info) + ")");
+    return info;
+  }
+  {
+    double tmp = h[0] + h[4] + h[1] - h[5];
+    double dtc = -0.5 * ((double)N * 1.8378770664093453 + tmp);
+    elbo_out[0] = dtc - 0.5 * (h[2] - h[3]);
+  }
+  // ---- M x M stage
+  CHECK_RC(launch_gemv_rows(Je, ldg, m_pad, m_pad, dG.p + m_pad, ldg, nullptr, du.p, s, 1));   // u = Le^-T b
+  CHECK_RC(launch_gemm_nt_uut(Je, ldg, dBinv.p, m_pad, m_pad, s));                               // B^-1
+  CHECK_RC(launch_mirror_lower(dBinv.p, m_pad, m_pad, s));
+  CHECK_RC(launch_vfe_zs(dB.p, dBinv.p, du.p, dZ.p, dS.p, m_pad, s));
+  CHECK_RC(launch_gemv_rows(Jm, ld, m_pad, m_pad, du.p, 1, nullptr, dut.p, s, 1));               // J u
+  // ---- data-point stage: R Z, row statistics, G_xz
+  CHECK_RC(launch_gemm_nt(R, ld, dZ.p, m_pad, dRZ.p, n_rows, n_rows, m_pad, m_pad, 1.0, 0.0, NOMASK, 0, 0, s));
+  CHECK_RC(launch_vfe_rowstats(R, ld, dRZ.p, n_rows, du.p, ddelta.p, drsig.p, dvar.p, N, m_pad, dgy.p, dgsy.p, s));
+  // E = (R Z) J' overwrites R's storage?  no: keep R intact, reuse the Gram scratch-sized dRZ -> new buffer
+  DevBuf dE;
+  CHECK_RC(dE.alloc((size_t)n_rows * m_pad));
+  CHECK_RC(launch_gemm_nt(dRZ.p, n_rows, Jm, ld, dE.p, n_rows, n_rows, m_pad, m_pad, 1.0, 0.0, NOMASK, 0, 0, s));
+  CHECK_RC(launch_vfe_gxz(dE.p, n_rows, ddelta.p, dut.p, drsig.p, n_rows, m_pad, s));
+  // ---- G_zz = -1/2 J S J'
+  CHECK_RC(launch_gemm_nt(Jm, ld, dS.p, m_pad, dT1.p, m_pad, m_pad, m_pad, m_pad, 1.0, 0.0, NOMASK, 0, 0, s));
+  CHECK_RC(launch_gemm_nt(dT1.p, m_pad, Jm, ld, dGzz.p, m_pad, m_pad, m_pad, m_pad, -0.5, 0.0, NOMASK, 0, 0, s));
+  // ---- contractions against the flattened terms
+  if (grad_coef_xz || grad_inscale_xz)
+    CHECK_RC(contract_spec(gx.ds, dE.p, n_rows, nullptr, n_rows / TILE, m_pad / TILE, dpart, dgcx.p, dgsx.p, s));
+  if (grad_coef_zz || grad_inscale_zz)
+    CHECK_RC(contract_spec(gz.ds, dGzz.p, m_pad, nullptr, m_pad / TILE, m_pad / TILE, dpart, dgcz.p, dgsz.p, s));
+  SGP_HIP(hipStreamSynchronize(s));
+  // ---- results
+  std::vector<double> hy(N), hs(N);
+  SGP_HIP(hipMemcpy(hy.data(), dgy.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  SGP_HIP(hipMemcpy(hs.data(), dgsy.p, sizeof(double) * N, hipMemcpyDeviceToHost));
+  if (grad_y)
+    for (long i = 0; i < N; ++i) grad_y[i] = hy[i];
+  if (grad_mean)
+    for (long i = 0; i < N; ++i) grad_mean[i] = -hy[i];
+  if (grad_noise) {
+    if (noise_kind == SGP_NOISE_DIAG) {
+      for (long i = 0; i < N; ++i) grad_noise[i] = hs[i];
+    } else {
+      double acc = 0.0;
+      for (long i = 0; i < N; ++i) acc += hs[i];  // fixed order
+      grad_noise[0] = acc;
+    }
+  }
+  if (grad_var_x) {
+    for (long i = 0; i < N; ++i) {
+      double s2 = noise_kind == SGP_NOISE_SCALAR ? noise_x[0] : noise_x[i];
+      grad_var_x[i] = -0.5 / s2;
+    }
+  }
+  if (grad_z_noise) {
+    std::vector<double> dg(M);
+    SGP_HIP(hipMemcpy2D(dg.data(), sizeof(double), dGzz.p, sizeof(double) * (m_pad + 1), sizeof(double), (size_t)M,
+                        hipMemcpyDeviceToHost));
+    if (z_noise_kind == SGP_NOISE_DIAG) {
+      for (long i = 0; i < M; ++i) grad_z_noise[i] = dg[i];
+    } else {
+      double acc = 0.0;
+      for (long i = 0; i < M; ++i) acc += dg[i];
+      grad_z_noise[0] = acc;
+    }
+  }
+  if (grad_coef_zz) SGP_HIP(hipMemcpy(grad_coef_zz, dgcz.p, sizeof(double) * gz.ds->h_terms.size(), hipMemcpyDeviceToHost));
+  if (grad_inscale_zz)
+    SGP_HIP(hipMemcpy(grad_inscale_zz, dgsz.p, sizeof(double) * gz.ds->h_terms.size(), hipMemcpyDeviceToHost));
+  if (grad_coef_xz) SGP_HIP(hipMemcpy(grad_coef_xz, dgcx.p, sizeof(double) * gx.ds->h_terms.size(), hipMemcpyDeviceToHost));
+  if (grad_inscale_xz)
+    SGP_HIP(hipMemcpy(grad_inscale_xz, dgsx.p, sizeof(double) * gx.ds->h_terms.size(), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// sum_i w[i] d var_i / d theta over the diagonal of `spec` (the blocks (I, I) kernelmatrix_diag reads)
+extern "C" int sgp_kernelmatrix_diag_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w,
+                                          double* grad_coef, double* grad_inscale) {
+  CHECK_ARG(ctx && spec && w && grad_coef && grad_inscale, "sgp_kernelmatrix_diag_grad: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  SpecGuard g;
+  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  const sgp_dspec* ds = g.ds;
+  CHECK_ARG(ds->nrb == ds->ncb, "kernelmatrix_diag_grad: row / col block counts differ");
+  size_t nt = ds->h_terms.size();
+  for (size_t t = 0; t < nt; ++t) grad_coef[t] = grad_inscale[t] = 0.0;
+  if (ds->N == 0 || nt == 0) return 0;
+  DevBuf dw, dgc, dgs;
+  CHECK_RC(dw.upload(w, ds->N));
+  CHECK_RC(dgc.alloc(nt));
+  CHECK_RC(dgs.alloc(nt));
+  hipStream_t s = ctx->stream;
+  SGP_HIP(hipMemsetAsync(dgc.p, 0, sizeof(double) * nt, s));
+  SGP_HIP(hipMemsetAsync(dgs.p, 0, sizeof(double) * nt, s));
+  for (int I = 0; I < ds->nrb; ++I) {
+    CHECK_ARG(ds->row_len[I] == ds->col_len[I], "kernelmatrix_diag_grad: block lengths differ");
+    int p = I * ds->ncb + I;
+    int t0 = ds->term_ptr[p], t1 = ds->term_ptr[p + 1];
+    if (ds->row_len[I] == 0 || t1 == t0) continue;
+    CHECK_RC(launch_diag_grad(dw.p + ds->row_off[I], ds->row_len[I], ds->d_terms + t0, t1 - t0, dgc.p + t0,
+                              dgs.p + t0, s));
+  }
+  SGP_HIP(hipStreamSynchronize(s));
+  SGP_HIP(hipMemcpy(grad_coef, dgc.p, sizeof(double) * nt, hipMemcpyDeviceToHost));
+  SGP_HIP(hipMemcpy(grad_inscale, dgs.p, sizeof(double) * nt, hipMemcpyDeviceToHost));
   return 0;
 }
 

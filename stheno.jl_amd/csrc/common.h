@@ -90,6 +90,15 @@ int launch_splitk_reduce(const double* part, long part_stride, int nsplit, doubl
 int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0, long nc,
                       const DevTerm* d_terms, int nterms, int dmax, long trf, long tcf, long trc, long tcc,
                       double* partials, double* out_coef, double* out_scale, hipStream_t s);
+int launch_diag_grad(const double* w, long n, const DevTerm* d_terms, int nterms, double* out_coef,
+                     double* out_scale, hipStream_t s);
+int launch_vfe_zs(const double* B, const double* Binv, const double* u, double* Z, double* S, long m,
+                  hipStream_t s);
+int launch_vfe_rowstats(const double* R, long ld, const double* RZ, long ldrz, const double* u,
+                        const double* delta, const double* rsig, const double* var_x, long N, long m,
+                        double* gy, double* gsy, hipStream_t s);
+int launch_vfe_gxz(double* E, long ld, const double* delta, const double* ut, const double* rsig, long nrows,
+                   long m, hipStream_t s);
 int launch_grad_border(double* A, long ld, long n_pad, long N, const double* y, const double* mean,
                        long nrows, hipStream_t s);
 int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N, int diag, double* out,

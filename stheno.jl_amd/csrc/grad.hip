@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
   const long grow = gtr * TILE + trow;
   if (live_tile && grow >= rbeg && grow < rend) {
     const long lrow = grow - r0;
-    const double ai = alpha[grow];
+    const double ai = alpha ? alpha[grow] : 0.0;
     // per-term row data in registers: the row point, its scale, the term constants
     double xr[TMAX * DMAX], rsv[TMAX], coef[TMAX], param[TMAX];
     int kind[TMAX];
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
     for (int p = (int)pbeg; p < (int)pbeg + 64; ++p) {
       const long gc = gcol0 + p;
       if (gc < cbeg || gc >= cend) continue;
-      const double g = 0.5 * (ai * alpha[gc] - Kinv[grow + gc * ldk]);
+      // alpha == nullptr: `Kinv` holds the cotangent matrix G itself (ELBO gradient)
+      const double g = alpha ? 0.5 * (ai * alpha[gc] - Kinv[grow + gc * ldk]) : Kinv[grow + gc * ldk];
 #pragma unroll
       for (int tm = 0; tm < TMAX; ++tm) {
         if (tm >= nterms) break;
@@ -287,6 +288,116 @@ __global__ void grad_noise_kernel(const double* Kinv, long ldk, const double* al
 int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N, int diag, double* out,
                       hipStream_t s) {
   hipLaunchKernelGGL(grad_noise_kernel, dim3(1), dim3(256), 0, s, Kinv, ldk, alpha, N, diag, out);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// sum_i w[i] d var_i / d theta for the diagonal of a block (kernelmatrix_diag): per term
+//   out_coef[t] = sum_i w_i rs_i cs_i k_t(x_i, x'_i),  out_scale[t] = sum_i w_i coef rs_i cs_i dk_t/dg
+__global__ __launch_bounds__(256) void diag_grad_kernel(const double* w, long n, const DevTerm* terms,
+                                                        double* out_coef, double* out_scale) {
+  __shared__ double sh[2][256];
+  const DevTerm T = terms[blockIdx.x];
+  double a = 0.0, b = 0.0;
+  for (long i = threadIdx.x; i < n; i += 256) {
+    double d2 = 0.0;
+    for (int d = 0; d < T.dim; ++d) {
+      double df = T.xr[i * T.ldr + d] - T.xc[i * T.ldc + d];
+      d2 = fma(df, df, d2);
+    }
+    double k, dk;
+    kern_and_dscale(T.kind, d2, T.param, k, dk);
+    double ww = w[i] * (T.rs ? T.rs[i] : 1.0) * (T.cs ? T.cs[i] : 1.0);
+    a = fma(ww, k, a);
+    b = fma(ww * T.coef, dk, b);
+  }
+  sh[0][threadIdx.x] = a;
+  sh[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int off = 128; off >= 1; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out_coef[blockIdx.x] = sh[0][0];
+    out_scale[blockIdx.x] = sh[1][0];
+  }
+}
+
+int launch_diag_grad(const double* w, long n, const DevTerm* d_terms, int nterms, double* out_coef,
+                     double* out_scale, hipStream_t s) {
+  if (nterms <= 0) return 0;
+  hipLaunchKernelGGL(diag_grad_kernel, dim3((unsigned)nterms), dim3(256), 0, s, w, n, d_terms, out_coef, out_scale);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ELBO gradient, M x M stage:  Z = I - B^-1 - u u',  S = B + B^-1 - 2 I + u u'  (all full, ld = m)
+__global__ void vfe_zs_kernel(const double* B, const double* Binv, const double* u, double* Z, double* S,
+                              long m) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= m * m) return;
+  long r = idx % m, c = idx / m;
+  double uu = u[r] * u[c], id = (r == c) ? 1.0 : 0.0, bi = Binv[idx];
+  Z[idx] = id - bi - uu;
+  S[idx] = B[idx] + bi - 2.0 * id + uu;
+}
+
+int launch_vfe_zs(const double* B, const double* Binv, const double* u, double* Z, double* S, long m,
+                  hipStream_t s) {
+  long tot = m * m;
+  hipLaunchKernelGGL(vfe_zs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, B, Binv, u, Z, S, m);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ELBO gradient, per data point i (rows of R = A', RZ = A' Z):
+//   ru = R[i,:] u,  ddelta = -delta + ru,  diagdot = R[i,:] . RZ[i,:] + delta ru
+//   gy[i] = ddelta rsig ;  gsy[i] = rsig^2 (-1/2 + var rsig^2 / 2 - (ddelta delta + diagdot) / 2)
+__global__ void vfe_rowstats_kernel(const double* R, long ld, const double* RZ, long ldrz, const double* u,
+                                    const double* delta, const double* rsig, const double* var_x, long N,
+                                    long m, double* gy, double* gsy) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double ru = 0.0, dd = 0.0;
+  for (long k = 0; k < m; ++k) {
+    double r = R[i + k * ld];
+    ru = fma(r, u[k], ru);
+    dd = fma(r, RZ[i + k * ldrz], dd);
+  }
+  double d = delta[i], rs = rsig[i], is2 = rs * rs;
+  double ddelta = ru - d;
+  dd = fma(d, ru, dd);
+  gy[i] = ddelta * rs;
+  gsy[i] = is2 * (-0.5 + 0.5 * var_x[i] * is2 - 0.5 * (ddelta * d + dd));
+}
+
+int launch_vfe_rowstats(const double* R, long ld, const double* RZ, long ldrz, const double* u,
+                        const double* delta, const double* rsig, const double* var_x, long N, long m,
+                        double* gy, double* gsy, hipStream_t s) {
+  hipLaunchKernelGGL(vfe_rowstats_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, R, ld, RZ, ldrz, u,
+                     delta, rsig, var_x, N, m, gy, gsy);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// G_xz[i, j] = rsig_i (E[i, j] + delta_i ut_j), in place on E (nrows x m, ld)
+__global__ void vfe_gxz_kernel(double* E, long ld, const double* delta, const double* ut, const double* rsig,
+                               long nrows, long m) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nrows * m) return;
+  long i = idx % nrows, j = idx / nrows;
+  E[i + j * ld] = rsig[i] * fma(delta[i], ut[j], E[i + j * ld]);
+}
+
+int launch_vfe_gxz(double* E, long ld, const double* delta, const double* ut, const double* rsig, long nrows,
+                   long m, hipStream_t s) {
+  long tot = nrows * m;
+  hipLaunchKernelGGL(vfe_gxz_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, E, ld, delta, ut, rsig,
+                     nrows, m);
   SGP_HIP(hipGetLastError());
   return 0;
 }

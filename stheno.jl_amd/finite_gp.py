@@ -389,6 +389,72 @@ def elbo(vfe, fx, y=None):
     return float(out[0])
 
 
+def _term_records(spec, gc, gs, symmetric):
+    """One record per flattened term.  For a symmetric spec the mirror-image pair (J, I) is folded
+    into the lower pair (I >= J), as in logpdf_and_gradient."""
+    nrb, ncb = len(spec.row_len), len(spec.col_len)
+    tp, out, index = spec._term_ptr, [], {}
+    for I in range(nrb):
+        for J in range(ncb):
+            for t in range(tp[I * ncb + J], tp[I * ncb + J + 1]):
+                T = spec._terms[t]
+                if symmetric and I < J:
+                    continue
+                index[(I, J, T.kind, T.row_input, T.col_input, T.param)] = len(out)
+                out.append(dict(I=I, J=J, kind=T.kind, coef=T.coef, row_input=T.row_input, col_input=T.col_input,
+                                d_coef=float(gc[t]), d_inscale=float(gs[t])))
+    if symmetric:
+        for I in range(nrb):
+            for J in range(I + 1, ncb):
+                for t in range(tp[I * ncb + J], tp[I * ncb + J + 1]):
+                    T = spec._terms[t]
+                    k = index.get((J, I, T.kind, T.col_input, T.row_input, T.param))
+                    if k is not None:
+                        out[k]["d_coef"] += float(gc[t])
+                        out[k]["d_inscale"] += float(gs[t])
+    return out
+
+
+def elbo_and_gradient(vfe, fx, y=None):
+    """elbo(VFE(fz), fx, y) and its reverse-mode gradient (what Zygote derives through
+    AbstractGPs.elbo on the reference path; sgp_elbo_grad).
+
+    Returns a dict: elbo; y, mean (N each); noise (scalar or N); z_noise (scalar or M: d/d Sigma_z);
+    zz_terms / xz_terms / xx_terms: per flattened covariance term of K(z,z), K(x,z) and diag K(x,x)
+    {I, J, kind, coef, row_input, col_input, d_coef, d_inscale} (see logpdf_and_gradient)."""
+    if isinstance(vfe, SparseFiniteGP):
+        return elbo_and_gradient(VFE(vfe.finducing), vfe.fobs, fx)
+    zz, xz, mean_x, nk, nbuf, zk, zbuf = _vfe_args(vfe, fx)
+    if zk == _lib.NOISE_DENSE:
+        raise NotImplementedError("elbo gradient with dense Sigma_z")
+    n, m = len(fx), len(vfe.fz)
+    yv = _f64(np.asarray(y, dtype=np.float64).ravel())
+    xx = _prior_spec(fx.f, fx.x)
+    var_x = _f64(_kernelmatrix_diag(xx))
+    out = np.zeros(1)
+    gy, gm, gv = np.zeros(n), np.zeros(n), np.zeros(n)
+    gn = np.zeros(n if nk == _lib.NOISE_DIAG else 1)
+    gzn = np.zeros(m if zk == _lib.NOISE_DIAG else 1)
+    gcz, gsz = np.zeros(max(1, zz.n_terms)), np.zeros(max(1, zz.n_terms))
+    gcx, gsx = np.zeros(max(1, xz.n_terms)), np.zeros(max(1, xz.n_terms))
+    lib = _ctx().lib
+    rc = lib.sgp_elbo_grad(_ctx().handle, zz.ref(), xz.ref(), _lib.dptr(var_x), _lib.dptr(mean_x), nk,
+                           _lib.dptr(nbuf), zk, _lib.dptr(zbuf), _lib.dptr(yv), _lib.dptr(out), _lib.dptr(gy),
+                           _lib.dptr(gm), _lib.dptr(gn), _lib.dptr(gv), _lib.dptr(gzn), _lib.dptr(gcz),
+                           _lib.dptr(gsz), _lib.dptr(gcx), _lib.dptr(gsx))
+    _lib.check(rc, "sgp_elbo_grad")
+    gcd, gsd = np.zeros(max(1, xx.n_terms)), np.zeros(max(1, xx.n_terms))
+    rc = lib.sgp_kernelmatrix_diag_grad(_ctx().handle, xx.ref(), _lib.dptr(gv), _lib.dptr(gcd), _lib.dptr(gsd))
+    _lib.check(rc, "sgp_kernelmatrix_diag_grad")
+    nb = len(xx.row_len)
+    xx_terms = [r for r in _term_records(xx, gcd, gsd, False) if r["I"] == r["J"]] if nb else []
+    return dict(elbo=float(out[0]), y=gy, mean=gm, noise=(gn if nk == _lib.NOISE_DIAG else float(gn[0])),
+                z_noise=(gzn if zk == _lib.NOISE_DIAG else float(gzn[0])), var=gv,
+                zz_terms=_term_records(zz, gcz, gsz, True), xz_terms=_term_records(xz, gcx, gsx, False),
+                xx_terms=xx_terms, _raw=dict(zz=(gcz, gsz), xz=(gcx, gsx), xx=(gcd, gsd)),
+                _specs=dict(zz=zz, xz=xz, xx=xx))
+
+
 class ApproxPosteriorGP:
     def __init__(self, prior, z, handle):
         self.prior, self.z, self._h = prior, z, handle

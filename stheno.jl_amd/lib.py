@@ -74,6 +74,9 @@ _SIGS = {
     "sgp_posterior_predict": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D,
                                         _D, _D, _D, C.c_int64]),
     "sgp_posterior_destroy": (C.c_int, [_P]),
+    "sgp_elbo_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D, C.c_int,
+                                _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D]),
+    "sgp_kernelmatrix_diag_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, _D, _D]),
     "sgp_elbo": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int,
                            _D, C.c_int, _D, _D, _D]),
     "sgp_sparse_posterior_create": (C.c_int, [_P, C.POINTER(sgp_cov_spec),

@@ -398,6 +398,7 @@ def _oracle_term_grads(spec, G):
     """sum_ij G_ij d C_ij / d theta for every raw spec term, with NumPy (tests/np_terms.py kernels)."""
     import np_terms
     roff = np.concatenate([[0], np.cumsum(spec.row_len)])
+    coff = np.concatenate([[0], np.cumsum(spec.col_len)])
     out = []
     for (I, J, kind, ri, ci, coef, param, rs, cs) in np_terms.spec_terms(spec):
         X, Y = spec.inputs[ri], spec.inputs[ci]
@@ -405,7 +406,7 @@ def _oracle_term_grads(spec, G):
         k = np_terms._kern(kind, d2, param)
         h = 1e-6
         dk = (np_terms._kern(kind, d2 * (1 + h) ** 2, param) - np_terms._kern(kind, d2 * (1 - h) ** 2, param)) / (2 * h)
-        w = G[roff[I]:roff[I + 1], roff[J]:roff[J + 1]]
+        w = G[roff[I]:roff[I + 1], coff[J]:coff[J + 1]]
         if rs is not None:
             w = w * rs[:, None]
         if cs is not None:
@@ -464,6 +465,86 @@ def test_logpdf_gradient_matches_finite_differences_of_hyperparameters():
     assert abs(d_v - fd_v) <= 1e-6 * max(1.0, abs(fd_v))
     assert abs(d_l - fd_l) <= 1e-6 * max(1.0, abs(fd_l))
     assert abs(g["noise"] - fd_s) <= 1e-6 * max(1.0, abs(fd_s))
+
+
+# ---- reverse-mode gradient of the elbo --------------------------------------
+@pytest.mark.parametrize("recipe", [models.gppp_docstring, models.composite_kernels], ids=lambda r: r.__name__)
+def test_elbo_gradient_against_oracle_cotangents(recipe):
+    """sgp_elbo_grad against oracle.abstractgps.elbo_gradient_wrt_cov (itself checked against finite
+    differences on the CPU): y / noise / Sigma_z cotangents directly, the per-term numbers by
+    contracting the oracle's dKzz, dKxz, dvar with the NumPy term kernels."""
+    import np_terms
+    rng = np.random.default_rng(11)
+    Fo, Fp, fo, fp = both(recipe)
+    names = list(fo)[:3]
+    D = 2
+    xs = [np.asfortranarray(rng.standard_normal((D, n))) for n in (260, 90, 131)][:len(names)]
+    zs = [np.asfortranarray(rng.standard_normal((D, n))) for n in (40, 33, 70)][:len(names)]
+    xo, xp = blockdata(names, xs, True)
+    zo, zp = blockdata(names, zs, True)
+    N, M = sum(x.shape[1] for x in xs), sum(z.shape[1] for z in zs)
+    y = rng.standard_normal(N)
+    for noise in (0.3, 0.1 + rng.random(N)):
+        go = oagp.elbo_gradient_wrt_cov(oagp.VFE(Fo(zo, 1e-6)), Fo(xo, noise), y)
+        g = P.elbo_and_gradient(P.VFE(Fp(zp, 1e-6)), Fp(xp, noise), y)
+        assert abs(g["elbo"] - go["elbo"]) <= 1e-9 * abs(go["elbo"])
+        assert abs(g["elbo"] - P.elbo(P.VFE(Fp(zp, 1e-6)), Fp(xp, noise), y)) <= 1e-12 * abs(g["elbo"])
+        assert rel(g["y"], go["y"]) < 1e-7 and rel(g["mean"], go["mean"]) < 1e-7
+        assert rel(g["noise"], go["noise"]) < 1e-7
+        assert rel(g["var"], go["var"]) < 1e-12
+        # Sigma_z = 1e-6 I makes Kzz ill-conditioned (cond ~ 1e6): cotangents carry ~1e-6 relative noise
+        scale = np.abs(go["Kzz"]).max()
+        assert abs(g["z_noise"] - np.trace(go["Kzz"])) <= 1e-5 * scale * M
+        specs, raw = g["_specs"], g["_raw"]
+        for key, G in (("zz", go["Kzz"]), ("xz", go["Kxz"])):
+            exp = _oracle_term_grads(specs[key], G)
+            gc, gs = raw[key]
+            ref = max(1.0, max(abs(e[0]) for e in exp), max(abs(e[1]) for e in exp))
+            for t, (ec, es) in enumerate(exp):
+                assert abs(gc[t] - ec) <= 2e-5 * ref, (key, t, gc[t], ec)
+                assert abs(gs[t] - es) <= 2e-5 * ref, (key, t, gs[t], es)
+        # diagonal terms: sum_i dvar_i rs_i cs_i k(x_i, x_i)
+        gcd, gsd = raw["xx"]
+        roff = np.concatenate([[0], np.cumsum(specs["xx"].row_len)])
+        for t, (I, J, kind, ri, ci, coef, param, rs, cs) in enumerate(np_terms.spec_terms(specs["xx"])):
+            if I != J:
+                assert gcd[t] == 0.0 and gsd[t] == 0.0
+                continue
+            X, Y = specs["xx"].inputs[ri], specs["xx"].inputs[ci]
+            k = np_terms._kern(kind, ((X - Y) ** 2).sum(0), param)
+            w = go["var"][roff[I]:roff[I + 1]] * (1.0 if rs is None else rs) * (1.0 if cs is None else cs)
+            assert abs(gcd[t] - (w * k).sum()) <= 1e-10 * max(1.0, abs((w * k).sum()))
+
+
+def test_elbo_gradient_matches_finite_differences_of_hyperparameters():
+    """End to end: variance, lengthscale and noise of s * stretch(GP(Matern52), 1/l) through the
+    VFE bound, against central differences of the GPU elbo itself."""
+    rng = np.random.default_rng(13)
+    X = P.ColVecs(rng.standard_normal((2, 700)))
+    Z = P.ColVecs(rng.standard_normal((2, 60)))
+    y = rng.standard_normal(700)
+
+    def model(v, l):
+        return np.sqrt(v) * P.stretch(P.atomic(P.GP(P.Matern52Kernel()), P.GPC()), 1.0 / l)
+
+    def bound(v, l, s2):
+        f = model(v, l)
+        return P.elbo(P.VFE(f(Z, 1e-4)), f(X, s2), y)
+
+    v, l, s2 = 1.7, 0.8, 0.25
+    f = model(v, l)
+    g = P.elbo_and_gradient(P.VFE(f(Z, 1e-4)), f(X, s2), y)
+    allt = g["zz_terms"] + g["xz_terms"] + g["xx_terms"]
+    assert len(g["zz_terms"]) == 1 and len(g["xz_terms"]) == 1 and len(g["xx_terms"]) == 1
+    d_v = sum(t["d_coef"] for t in allt)
+    d_l = -(1.0 / l) * sum(t["d_inscale"] for t in allt)
+    h = 1e-5
+    fd_v = (bound(v + h, l, s2) - bound(v - h, l, s2)) / (2 * h)
+    fd_l = (bound(v, l + h, s2) - bound(v, l - h, s2)) / (2 * h)
+    fd_s = (bound(v, l, s2 + h) - bound(v, l, s2 - h)) / (2 * h)
+    assert abs(d_v - fd_v) <= 1e-5 * max(1.0, abs(fd_v)), (d_v, fd_v)
+    assert abs(d_l - fd_l) <= 1e-5 * max(1.0, abs(fd_l)), (d_l, fd_l)
+    assert abs(g["noise"] - fd_s) <= 1e-5 * max(1.0, abs(fd_s)), (g["noise"], fd_s)
 
 
 # ---- ill-conditioned covariances: the panel solves must be as accurate as LAPACK's ---------------

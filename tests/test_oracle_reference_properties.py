@@ -317,3 +317,56 @@ def test_oracle_logpdf_on_ill_conditioned_covariances_tracks_60_digit_values():
         lo = agp.logpdf(st.atomic(agp.GP(kf.SEKernel()), st.GPC())(x, s2), y)
         truth = float(c["logpdf"])
         assert abs(lo - truth) / abs(truth) < 50 * 2.2e-16 / s2, (c["N"], s2)
+
+
+def test_oracle_elbo_gradient_matches_finite_differences():
+    """oracle.abstractgps.elbo_gradient_wrt_cov against central differences of an explicit
+    matrix restatement of the same bound (which is itself checked against oracle elbo)."""
+    import scipy.linalg as sla
+    rng = np.random.default_rng(5)
+    N, M = 23, 7
+    x, z = np.sort(rng.uniform(-2, 2, N)), np.linspace(-1.8, 1.8, M)
+    y = rng.standard_normal(N)
+    f = st.atomic(agp.GP(0.3, 1.7 * kf.with_lengthscale(kf.Matern52Kernel(), 0.8)), st.GPC())
+    sy = 0.05 + rng.random(N)
+
+    def bound(Kzz, Kxz, var, s, yy):
+        Lz = np.linalg.cholesky(Kzz)
+        A = sla.solve_triangular(Lz, Kxz.T, lower=True) / np.sqrt(s)[None, :]
+        Le = np.linalg.cholesky(A @ A.T + np.eye(M))
+        d = (yy - 0.3) / np.sqrt(s)
+        b = sla.solve_triangular(Le, A @ d, lower=True)
+        return (-0.5 * (N * np.log(2 * np.pi) + np.log(s).sum() + 2 * np.log(np.diag(Le)).sum() + d @ d - b @ b)
+                - 0.5 * ((var / s).sum() - (A * A).sum()))
+
+    for noise in (sy, 0.1):
+        fx, fz = f(x, noise), f(z, 1e-6)
+        g = agp.elbo_gradient_wrt_cov(agp.VFE(fz), fx, y)
+        Kzz = f.cov(z) + 1e-6 * np.eye(M)
+        Kxz = f.cov_cross(f, x, z) if hasattr(f, "cov_cross") else f.cov(x, z)
+        var = f.var(x)
+        s = agp.noise_diag(noise, N)
+        assert abs(bound(Kzz, Kxz, var, s, y) - g["elbo"]) < 1e-9 * abs(g["elbo"])
+        h = 1e-6
+        for _ in range(6):
+            i, j = rng.integers(M), rng.integers(M)
+            E = np.zeros((M, M)); E[i, j] += 0.5; E[j, i] += 0.5
+            fd = (bound(Kzz + h * E, Kxz, var, s, y) - bound(Kzz - h * E, Kxz, var, s, y)) / (2 * h)
+            an = 0.5 * (g["Kzz"][i, j] + g["Kzz"][j, i])
+            assert abs(fd - an) < 1e-5 * max(1.0, abs(an)), (fd, an)
+            i, j = rng.integers(N), rng.integers(M)
+            E = np.zeros((N, M)); E[i, j] = 1.0
+            fd = (bound(Kzz, Kxz + h * E, var, s, y) - bound(Kzz, Kxz - h * E, var, s, y)) / (2 * h)
+            assert abs(fd - g["Kxz"][i, j]) < 1e-5 * max(1.0, abs(fd)), (fd, g["Kxz"][i, j])
+            i = rng.integers(N)
+            e = np.zeros(N); e[i] = 1.0
+            fd = (bound(Kzz, Kxz, var, s, y + h * e) - bound(Kzz, Kxz, var, s, y - h * e)) / (2 * h)
+            assert abs(fd - g["y"][i]) < 1e-5 * max(1.0, abs(fd))
+            fd = (bound(Kzz, Kxz, var + h * e, s, y) - bound(Kzz, Kxz, var - h * e, s, y)) / (2 * h)
+            assert abs(fd - g["var"][i]) < 1e-5 * max(1.0, abs(fd))
+            if np.ndim(noise) == 1:
+                fd = (bound(Kzz, Kxz, var, s + h * e, y) - bound(Kzz, Kxz, var, s - h * e, y)) / (2 * h)
+                assert abs(fd - g["noise"][i]) < 1e-5 * max(1.0, abs(fd)), (fd, g["noise"][i])
+        if np.ndim(noise) == 0:
+            fd = (bound(Kzz, Kxz, var, s + h, y) - bound(Kzz, Kxz, var, s - h, y)) / (2 * h)
+            assert abs(fd - g["noise"]) < 1e-5 * max(1.0, abs(fd)), (fd, g["noise"])
