@@ -21,6 +21,7 @@ int run_hbm_bench(hipStream_t s, long bytes, int iters, double* write_gbs, doubl
 
 static inline long rup(long x, long m) { return (x + m - 1) / m * m; }
 constexpr long NOMASK = -(1L << 40);
+constexpr long INVD_STRIDE = 8 * 256;  // eight 16x16 inverse diagonal blocks per 128-block
 constexpr long WOUT_SMALL = 512;   // outer panel width of the two-level blocked Cholesky
 constexpr long WOUT_LARGE = 1024;  // ... for n_pad >= 32768 (halves the C-tile traffic per flop)
 
@@ -318,7 +319,7 @@ static int assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, lo
 //   2: three K = 128 GEMMs  S = B W',  R = B - S Lkk',  X = S + R W'  (128-level refinement);
 //   0: X = B W' only (fast, unstable; A/B timing).
 // `inv` points at the eight 16x16 inverse diagonal blocks (block c at inv + c * inv_cstride,
-// element [m][k] at + k * inv_kstride + m): ctx->d_invd right after potrf_diag, or the diagonal of W.
+// element [m][k] at + k * inv_kstride + m): what potrf_diag just wrote (ctx scratch or a kept copy).
 static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double* W, const double* Lkk,
                       long ldl, const double* inv, long inv_cstride, long inv_kstride, hipStream_t s) {
   if (rows <= 0) return 0;
@@ -345,19 +346,20 @@ static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double
 }
 
 // Factor one column panel in place (inner right-looking loop, nb = 128).
-// P: m x w, top w x w block is the diagonal block.  d_wstore: optional array of 128x128
-// inverse diagonal blocks to keep (indexed by block within the panel), else ctx scratch.
+// P: m x w, top w x w block is the diagonal block.  d_invstore: optional array that keeps the
+// eight 16x16 inverse diagonal blocks of every 128-block (INVD_STRIDE doubles per block, the
+// layout potrf_diag writes) for later solves against the factor; else ctx scratch.
 static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_slots,
-                        int* d_info, double* d_wstore, hipStream_t s) {
+                        int* d_info, double* d_invstore, hipStream_t s) {
   for (long j = 0; j < w; j += TILE) {
     double* D = P + j + j * ld;
-    double* W = d_wstore ? d_wstore + (j / TILE) * (TILE * TILE) : ctx->d_w;
-    CHECK_RC(launch_potrf_diag(D, ld, ctx->d_invd, d_slots + j / TILE, d_info, g0 + j, s));
+    double* invd = d_invstore ? d_invstore + (j / TILE) * INVD_STRIDE : ctx->d_invd;
+    CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s));
     long mrest = m - j - TILE;
-    if ((mrest > 0 && ctx->refine != 1) || d_wstore) CHECK_RC(launch_trtri(D, ld, ctx->d_invd, W, s));
+    if (mrest > 0 && ctx->refine != 1) CHECK_RC(launch_trtri(D, ld, invd, ctx->d_w, s));  // A/B modes only
     if (mrest > 0) {
       double* A21 = P + (j + TILE) + j * ld;
-      CHECK_RC(solve_rows(ctx, A21, ld, mrest, W, D, ld, ctx->d_invd, 256, 16, s));  // L21 = A21 * L11^-T
+      CHECK_RC(solve_rows(ctx, A21, ld, mrest, ctx->d_w, D, ld, invd, 256, 16, s));  // L21 = A21 * L11^-T
       long wrest = w - j - TILE;
       if (wrest > 0)
         CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest,
@@ -415,7 +417,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
     long wj = std::min(WOUT, n_pad - J0);
     const long m_eff = grow > 0 ? std::min(m_tot, grow + J0 + wj) : m_tot;  // rows this panel touches
     CHECK_RC(panel_factor(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
-                          ctx->d_info, d_wall ? d_wall + (J0 / TILE) * (TILE * TILE) : nullptr, s));
+                          ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s));
     long c0 = J0 + wj;
     if (c0 >= n_pad) break;
     long w1 = std::min(WOUT, n_pad - c0);   // width of the next panel
@@ -838,17 +840,17 @@ struct sgp_post {
   sgp_ctx* ctx = nullptr;
   long N = 0, n_pad = 0, m_tot = 0;
   double* dA = nullptr;     // L (lower tiles) + row n_pad = (L^-1 (y - m))'
-  double* d_wall = nullptr; // inverse diagonal blocks
+  double* d_wall = nullptr; // inverse 16x16 diagonal blocks (INVD_STRIDE per 128-block)
 };
 
 // rows <- rows * L^-T for `nrows` (multiple of 128) bordered rows stored at R (ld = ldr),
-// against the factor L (ld = ldl) with stored inverse diagonal blocks.  Right-looking.
+// against the factor L (ld = ldl) with its stored inverse 16x16 diagonal blocks.  Right-looking.
 static int row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl,
-                    const double* d_wall, long n_pad, hipStream_t s) {
+                    const double* d_invall, long n_pad, hipStream_t s) {
   for (long k = 0; k < n_pad; k += TILE) {
     double* Rk = R + k * ldr;
-    const double* Wk = d_wall + (k / TILE) * (TILE * TILE);
-    CHECK_RC(solve_rows(ctx, Rk, ldr, nrows, Wk, L + k + k * ldl, ldl, Wk, 16 * TILE + 16, TILE, s));
+    CHECK_RC(launch_panel_solve(Rk, ldr, nrows, L + k + k * ldl, ldl, d_invall + (k / TILE) * INVD_STRIDE, 256, 16,
+                                s));
     long rest = n_pad - k - TILE;
     if (rest > 0)
       CHECK_RC(launch_gemm_nt(Rk, ldr, L + (k + TILE) + k * ldl, ldl, R + (k + TILE) * ldr, ldr, nrows,
@@ -871,25 +873,40 @@ __global__ void backsolve_gemvt_kernel(const double* L, long ld, long k0, long n
   __syncthreads();
   if (threadIdx.x == 0) z[k0 + j] -= (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
-__global__ void backsolve_diag_kernel(const double* W, const double* Lkk, long ld, const double* z,
-                                      double* alpha, long k0) {
-  // alpha[k0 + j] = (L_kk^-T z_k)[j]: product with W = inv(L_kk), then one refinement step against
-  // L_kk itself (same reason as solve_rows)
-  __shared__ double zs[TILE], as[TILE], rs[TILE];
-  int j = threadIdx.x;
-  zs[j] = z[k0 + j];
+// alpha_k = L_kk^-T z_k for one 128-block: blocked back substitution over its eight 16x16
+// sub-blocks, each diagonal solve an inverse product + one refinement step (as panel_solve_kernel).
+// Thread (m, q): element m of the current sub-block, q = contraction lane (16 aligned lanes).
+__global__ __launch_bounds__(256) void backsolve_diag_kernel(const double* invd, const double* Lkk, long ld,
+                                                            const double* z, double* alpha, long k0) {
+  __shared__ double zs[TILE], as[TILE], ts[16], a1s[16], rs[16];
+  const int t = threadIdx.x, m = t >> 4, q = t & 15;
+  if (t < TILE) zs[t] = z[k0 + t];
   __syncthreads();
-  double acc = 0.0;
-  for (int i = j; i < TILE; ++i) acc = fma(W[i + j * TILE], zs[i], acc);
-  as[j] = acc;
-  __syncthreads();
-  double r = zs[j];
-  for (int i = j; i < TILE; ++i) r = fma(-Lkk[i + (long)j * ld], as[i], r);  // z - L_kk' a
-  rs[j] = r;
-  __syncthreads();
-  double d = 0.0;
-  for (int i = j; i < TILE; ++i) d = fma(W[i + j * TILE], rs[i], d);
-  alpha[k0 + j] = acc + d;
+  for (int c = 7; c >= 0; --c) {
+    double acc = 0.0;  // sum_{p > c} L[16p + q][16c + m] a[16p + q]
+    for (int p = c + 1; p < 8; ++p) acc = fma(Lkk[(16 * p + q) + (long)(16 * c + m) * ld], as[16 * p + q], acc);
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (q == 0) ts[m] = zs[16 * c + m] - acc;
+    __syncthreads();
+    const double iv = invd[c * 256 + m * 16 + q];  // inv(L_cc)[q][m]
+    double v = iv * ts[q];
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (q == 0) a1s[m] = v;
+    __syncthreads();
+    double w = (q >= m) ? Lkk[(16 * c + q) + (long)(16 * c + m) * ld] * a1s[q] : 0.0;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) w += __shfl_xor(w, off, 64);
+    if (q == 0) rs[m] = ts[m] - w;  // t - L_cc' a1
+    __syncthreads();
+    double d = iv * rs[q];
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
+    if (q == 0) as[16 * c + m] = a1s[m] + d;
+    __syncthreads();
+  }
+  if (t < TILE) alpha[k0 + t] = as[t];
 }
 
 static int back_substitute(const sgp_post* post, double* d_z /*n_pad, overwritten*/,
@@ -900,8 +917,8 @@ static int back_substitute(const sgp_post* post, double* d_z /*n_pad, overwritte
                          k0, post->n_pad, d_alpha, d_z);
       SGP_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(backsolve_diag_kernel, dim3(1), dim3(TILE), 0, s,
-                       post->d_wall + (k0 / TILE) * (TILE * TILE), post->dA + k0 + k0 * post->m_tot,
+    hipLaunchKernelGGL(backsolve_diag_kernel, dim3(1), dim3(256), 0, s,
+                       post->d_wall + (k0 / TILE) * INVD_STRIDE, post->dA + k0 + k0 * post->m_tot,
                        post->m_tot, d_z, d_alpha, k0);
     SGP_HIP(hipGetLastError());
   }
@@ -950,7 +967,7 @@ extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, cons
     return rc;
   };
   if (hipMalloc(&post->dA, sizeof(double) * m_tot * n_pad) != hipSuccess ||
-      hipMalloc(&post->d_wall, sizeof(double) * (n_pad / TILE) * TILE * TILE) != hipSuccess) {
+      hipMalloc(&post->d_wall, sizeof(double) * (n_pad / TILE) * INVD_STRIDE) != hipSuccess) {
     set_error("sgp_posterior_create: hipMalloc failed");
     return fail(-2);
   }
@@ -1194,7 +1211,7 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   CHECK_RC(launch_scale_rows(dA.p + m_pad, ld, N, m_pad, drsig.p, s));
   double* d_wz = nullptr;
   if (keep) {
-    SGP_HIP(hipMalloc(&keep->d_wz, sizeof(double) * (m_pad / TILE) * TILE * TILE));
+    SGP_HIP(hipMalloc(&keep->d_wz, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
     d_wz = keep->d_wz;
   }
   CHECK_RC(chol_bordered(ctx, dA.p, ld, m_pad, ld, d_wz, s));
@@ -1214,7 +1231,7 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   double* dG = nullptr;
   if (keep) {
     SGP_HIP(hipMalloc(&keep->dG, sizeof(double) * ldg * m_pad));
-    SGP_HIP(hipMalloc(&keep->d_wg, sizeof(double) * (m_pad / TILE) * TILE * TILE));
+    SGP_HIP(hipMalloc(&keep->d_wg, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
     dG = keep->dG;
   } else {
     CHECK_RC(dG_local.alloc((size_t)ldg * m_pad));
