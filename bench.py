@@ -219,6 +219,12 @@ def main():
             "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
             "launches": n_launch, "avg_launch_ms": upd_ms / max(1, n_launch),
             "algorithmic_flops_per_launch_avg": upd_flops / max(1, n_launch),
+            # The look-ahead keeps update launches of two streams (and the panel kernels) on the chip at
+            # once, so the per-launch durations above overlap and include the CU slots lent to the panel
+            # stream.  busy_ms = union of the launch intervals (same HIP events); achieved_while_busy =
+            # the launches' algorithmic flops / busy_ms = what the kernel delivers while it is running.
+            "busy_ms": timings[6],
+            "achieved_while_busy": (upd_flops / (timings[6] * 1e-3) / 1e12) if timings[6] > 0 else None,
         }
         # HBM traffic cannot be read without rocprofv3; the committed PMC passes of one
         # representative launch of this kernel (tools/gpu_gemm_one.py, separate --pmc runs) are

@@ -216,7 +216,8 @@ int sgp_geometry(int64_t N, int64_t S, int64_t* n_pad, int64_t* m_tot);
  * d_noise: SCALAR -> host value *noise_host is used, DIAG -> d_noise[N];
  * d_Y: N x ncols (ld = ldy); out_host[ncols].  timings (may be NULL) receives
  * {assemble_ms, cholesky_ms, finalize_ms, trailing_update_ms_sum, n_trailing_update_launches,
- *  trailing_update_algorithmic_flops} (6 doubles). */
+ *  trailing_update_algorithmic_flops, trailing_update_busy_ms (union of the launch intervals: the
+ *  look-ahead runs launches of two streams concurrently), 0} (8 doubles). */
 int sgp_dev_logpdf(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, const double* d_mean,
                    int noise_kind, const double* noise_host, const double* d_noise,
                    const double* d_Y, int64_t ldy, int64_t ncols, double* out_host,

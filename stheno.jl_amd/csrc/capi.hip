@@ -517,6 +517,34 @@ static int dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, const 
     timings[3] = ms_sum;
     timings[4] = (double)(ctx->ev.size() / 2);
     timings[5] = fl;
+    // the look-ahead runs update launches of two streams concurrently, so their durations overlap:
+    // [6] = length of the union of the launch intervals (ms), the time the kernel was on the chip
+    {
+      std::vector<std::pair<float, float>> iv;
+      for (size_t i = 0; i + 1 < ctx->ev.size(); i += 2) {
+        float t0 = 0, t1 = 0;
+        SGP_HIP(hipEventElapsedTime(&t0, ev[0], ctx->ev[i]));
+        SGP_HIP(hipEventElapsedTime(&t1, ev[0], ctx->ev[i + 1]));
+        iv.emplace_back(t0, t1);
+      }
+      std::sort(iv.begin(), iv.end());
+      double uni = 0;
+      if (!iv.empty()) {
+        float cs = iv[0].first, ce = iv[0].second;
+        for (size_t i = 1; i < iv.size(); ++i) {
+          if (iv[i].first > ce) {
+            uni += ce - cs;
+            cs = iv[i].first;
+            ce = iv[i].second;
+          } else {
+            ce = std::max(ce, iv[i].second);
+          }
+        }
+        uni += ce - cs;
+      }
+      timings[6] = uni;
+      timings[7] = 0.0;
+    }
     for (auto& e : ev) hipEventDestroy(e);
   }
   if (info > 0) {

@@ -18,6 +18,11 @@ timeout 120 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_LDS_IDX_
 timeout 120 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_gemm1_TCC -o g -- python $R/tools/gpu_gemm_one.py > $OUT/pmc_gemm1_TCC.log 2>&1
 timeout 120 python $R/tools/gpu_sustained.py 400000 2> $OUT/mfma_variants.log
 timeout 120 python $R/tools/gpu_gemm_abl.py > $OUT/gemm_variants.log 2>&1
+for c in c5 c2; do f=$(find $OUT/prof_$c -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && timeout 60 python $R/tools/timeline_busy.py $f > $OUT/timeline_$c.txt 2>&1; done
+timeout 120 python $R/tools/gpu_gemm_sizes.py > $OUT/gemm_sizes.log 2>&1
+timeout 200 python $R/tools/gpu_grad_time.py 16384 > $OUT/grad_time.log 2>&1
+timeout 120 python $R/tools/gpu_predict_time.py 16384x16384 > $OUT/predict_time.log 2>&1
+timeout 200 python $R/tools/gpu_illcond.py > $OUT/illcond.log 2>&1
 rm -f $OUT/*/*kernel_trace.csv   # large; the stats CSV is what gets committed
 grep -h gemm $OUT/pmc_gemm1_FETCH_SIZE.log | head -2
 head -c 400 $OUT/bench_c5.json

@@ -58,7 +58,10 @@ def main():
         lines += ["", "### Default line (c5 = BASELINE configs[4] on one GPU)", "",
                   f"* roofline (dominant kernel `{r['kernel'].split(' ')[0]}`): achieved **{r['achieved']:.1f} TFLOP/s** over "
                   f"{r['launches']} trailing-update launches (avg {r['avg_launch_ms']:.2f} ms, HIP events on the launch streams), "
-                  f"peak {r['peak']} -> frac **{r['frac']:.2f}**.",
+                  f"peak {r['peak']} -> frac **{r['frac']:.2f}**." +
+                  (f"  The look-ahead overlaps launches of two streams: the union of their intervals is {r['busy_ms']:.0f} ms, "
+                   f"i.e. **{r['achieved_while_busy']:.1f} TFLOP/s** ({r['achieved_while_busy']/r['peak']:.2f}) while the kernel is on the chip."
+                   if r.get("achieved_while_busy") else ""),
                   f"* stages: assembly {j5['stages']['assemble_ms']:.2f} ms, Cholesky (+forward solve) {j5['stages']['cholesky_ms']:.1f} ms, "
                   f"finalize {j5['stages']['finalize_ms']:.2f} ms."]
         if cpu:
@@ -81,9 +84,10 @@ def main():
                 lines.append("")
                 lines.append(f"Same run, bench's own HIP-event figure: {jb['roofline']['achieved']:.1f} TFLOP/s over "
                              f"{jb['roofline']['launches']} trailing updates (avg {jb['roofline']['avg_launch_ms']:.2f} ms); "
-                             f"the kernel-trace average above also contains the many small panel TRSM / inner-update launches "
+                             f"the kernel-trace average above also contains the many small inner-update launches "
                              f"of the same kernel, and kernels of the two look-ahead streams overlap in time "
-                             f"(sum of kernel time > wall time; `potrf_diag`'s long average is queueing behind the update stream).")
+                             f"(sum of kernel time > wall time; the panel kernels' averages include waiting for a CU slot, "
+                             f"see the stream-occupancy section).")
     # PMC on the representative launch
     try:
         f, w, sq, tcc = pmc("FETCH_SIZE"), pmc("WRITE_SIZE"), pmc("SQ"), pmc("TCC")
@@ -125,6 +129,18 @@ def main():
         if os.path.exists(p):
             txt = [ln for ln in open(p).read().splitlines() if ln.startswith("[") or ln.startswith("gemm")]
             open(os.path.join(DST, "r01_" + name.replace(".log", ".txt")), "w").write("\n".join(txt) + "\n")
+    extras = [("timeline_c5.txt", "Stream occupancy of one N = 65 536 step (`tools/timeline_busy.py` on the kernel trace; queue of the "
+               "62 big launches = trailing-update stream, the other = panel stream of the look-ahead)"),
+              ("timeline_c2.txt", "Same at N = 16 384: here the panel stream is the critical path"),
+              ("gemm_sizes.log", "Isolated trailing-update launches by size and depth (`tools/gpu_gemm_sizes.py`)"),
+              ("grad_time.log", "Reverse-mode gradients (`tools/gpu_grad_time.py`; host API incl. uploads)"),
+              ("predict_time.log", "Prediction side (`tools/gpu_predict_time.py`)"),
+              ("illcond.log", "Ill-conditioned covariances against 60-digit values (`tools/gpu_illcond.py`)")]
+    for name, title in extras:
+        p = os.path.join(SRC, name)
+        if os.path.exists(p):
+            txt = [ln for ln in open(p).read().splitlines() if ln.strip() and "amdgpu.ids" not in ln]
+            lines += ["", f"## {title}", "", "```"] + txt + ["```"]
     lines += ["", "## Other committed evidence", "",
               "* `r01_microbench.md` — fp64 issue-form ceilings (16x16x4 vs 4x4x4 MFMA vs VALU), HBM stream rates, the GEMM kernel's evolution.",
               "* `r01_mfma_variants.txt`, `r01_gemm_variants.txt` — raw lines of the final micro-benchmark / GEMM A-B run.",
