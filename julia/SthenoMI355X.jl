@@ -173,4 +173,40 @@ function elbo(v::VFE, fx::SthenoFGP, y::AbstractVector{<:Real})
     return out[1]
 end
 
+# ---- reverse mode (what an rrule for logpdf / elbo on Stheno FiniteGPs would call) -----------------
+# Returns the value and the raw per-term gradients of include/sthenomi.h (d/d coef, d/d input scale
+# of every flattened term, in spec order); mapping them back onto the kernel parameters of the
+# programme is the pullback's job.
+function logpdf_and_gradient(fx::SthenoFGP, y::AbstractVector{<:Real})
+    sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
+    @assert kind != 2 "dense observation noise has no device gradient"
+    yd = collect(Float64, y); n = length(yd); nt = max(1, length(sp.keep[5]))
+    lp = zeros(1); gy = zeros(n); gm = zeros(n); gn = zeros(kind == 1 ? n : 1); gc = zeros(nt); gs = zeros(nt)
+    GC.@preserve sp m nz yd check(ccall((:sgp_logpdf_grad, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx(), sp.c, m, kind, nz, yd, lp, gy, gm, gn, gc, gs))
+    return (logpdf = lp[1], y = gy, mean = gm, noise = gn, coef = gc, inscale = gs)
+end
+
+function elbo_and_gradient(v::VFE, fx::SthenoFGP, y::AbstractVector{<:Real})
+    fz = v.fz; @assert fz.f === fx.f
+    zz = build_spec(fz.f, fz.x); xz = build_spec(fx.f, fx.x, fz.f, fz.x); xx = build_spec(fx.f, fx.x)
+    varx = collect(Float64, var(fx.f, fx.x)); m = collect(Float64, mean(fx.f, fx.x))
+    kx, nx = noise_args(fx.Σy); kz, nz = noise_args(fz.Σy); yd = collect(Float64, y)
+    n = length(yd); mz = length(fz)
+    out = zeros(1); gy = zeros(n); gm = zeros(n); gv = zeros(n); gn = zeros(kx == 1 ? n : 1); gzn = zeros(kz == 1 ? mz : 1)
+    ntz = max(1, length(zz.keep[5])); ntx = max(1, length(xz.keep[5])); ntd = max(1, length(xx.keep[5]))
+    gcz = zeros(ntz); gsz = zeros(ntz); gcx = zeros(ntx); gsx = zeros(ntx); gcd = zeros(ntd); gsd = zeros(ntd)
+    GC.@preserve zz xz varx m nx nz yd check(ccall((:sgp_elbo_grad, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ref{CSpec}, Ptr{Float64}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx(), zz.c, xz.c, varx, m, kx, nx, kz, nz, yd, out, gy, gm, gn, gv, gzn, gcz, gsz, gcx, gsx))
+    GC.@preserve xx gv check(ccall((:sgp_kernelmatrix_diag_grad, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx(), xx.c, gv, gcd, gsd))
+    return (elbo = out[1], y = gy, mean = gm, noise = gn, z_noise = gzn,
+            zz = (coef = gcz, inscale = gsz), xz = (coef = gcx, inscale = gsx), xx = (coef = gcd, inscale = gsd))
+end
+
 end # module
