@@ -54,6 +54,20 @@ void set_error(const std::string& s);
     }                                                                                     \
   } while (0)
 
+// Raise a kernel's dynamic-LDS limit once per device (function attributes are per device; a process
+// may hold contexts on several GPUs).
+#define SGP_LDS_ATTR_ONCE(func, bytes)                                                              \
+  do {                                                                                             \
+    static bool done_[64] = {};                                                                    \
+    int dev_ = 0;                                                                                  \
+    SGP_HIP(hipGetDevice(&dev_));                                                                  \
+    if (dev_ >= 0 && dev_ < 64 && !done_[dev_]) {                                                  \
+      SGP_HIP(hipFuncSetAttribute((const void*)(func), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)(bytes)));                                                  \
+      done_[dev_] = true;                                                                          \
+    }                                                                                              \
+  } while (0)
+
 // ---- launchers implemented in the .hip files -------------------------------------------
 // kernelmatrix.hip
 int launch_assemble_block(double* K, long ld, long r0, long nr, long c0, long nc,

@@ -204,12 +204,7 @@ static int launch_grad_t(const double* Kinv, long ldk, const double* alpha, long
   }
   size_t lds = (size_t)(TMAX * TILE * DMAX + TMAX * TILE) * sizeof(double);
   dim3 grid((unsigned)trc, (unsigned)tcc), block(256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SGP_HIP(hipFuncSetAttribute((const void*)grad_block_kernel<DMAX>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
-    attr_set = true;
-  }
+  SGP_LDS_ATTR_ONCE(grad_block_kernel<DMAX>, lds);
   hipLaunchKernelGGL(grad_block_kernel<DMAX>, grid, block, lds, s, Kinv, ldk, alpha, r0, nr, c0, nc, d_terms,
                      nterms, trf, tcf, partials);
   SGP_HIP(hipGetLastError());

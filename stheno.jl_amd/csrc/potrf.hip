@@ -175,12 +175,7 @@ __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_kernel(double* A, lo
 
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,
                       long gcol0, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    SGP_HIP(hipFuncSetAttribute((const void*)potrf_diag_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PD_LDS));
-    attr_set = true;
-  }
+  SGP_LDS_ATTR_ONCE(potrf_diag_kernel, PD_LDS);
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PD_THREADS), PD_LDS, s, A, ld, d_invd,
                      d_logdet_slot, d_info, gcol0);
   SGP_HIP(hipGetLastError());
@@ -270,12 +265,7 @@ int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl
     set_error("panel_solve: rows must be a multiple of 64");
     return -1;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    SGP_HIP(hipFuncSetAttribute((const void*)panel_solve_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)PS_LDS));
-    attr_set = true;
-  }
+  SGP_LDS_ATTR_ONCE(panel_solve_kernel, PS_LDS);
   // one strip per workgroup until the chip is full (256 CUs), then fatter workgroups
   long nstrips = rows / PS_ROWS;
   int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + 255) / 256));
@@ -335,12 +325,7 @@ __global__ __launch_bounds__(512) void trtri_kernel(const double* L, long ld, co
 }
 
 int launch_trtri(const double* L, long ld, const double* d_invd, double* d_w, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
-    SGP_HIP(hipFuncSetAttribute((const void*)trtri_kernel,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)TT_LDS));
-    attr_set = true;
-  }
+  SGP_LDS_ATTR_ONCE(trtri_kernel, TT_LDS);
   hipLaunchKernelGGL(trtri_kernel, dim3(1), dim3(512), TT_LDS, s, L, ld, d_invd, d_w);
   SGP_HIP(hipGetLastError());
   return 0;
