@@ -704,6 +704,14 @@ extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
                          nd.dense.p, nd.ld_dense, dY.p, N, ncols, out, nullptr);
 }
 
+// dst[i + c * ld] = mean[i] (i < N) else 0, for an nrows x ncols block
+__global__ void fill_mean_cols_kernel(double* dst, long ld, long nrows, long ncols, long N, const double* mean) {
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nrows * ncols) return;
+  long i = idx % nrows, c = idx / nrows;
+  dst[i + c * ld] = (mean && i < N) ? mean[i] : 0.0;
+}
+
 extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                         const double* noise, const double* Z, int64_t ldz, int64_t S, double* out,
                         int64_t ldo) {
@@ -719,15 +727,14 @@ extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* me
   sgp_geometry(N, 0, &n_pad, &m_tot);
   long s_pad = rup(S, TILE);
   hipStream_t s = ctx->stream;
-  DevBuf dA, dmean, dZ, dZt, dOt, dOut;
+  DevBuf dA, dmean, dZ, dZt, dOut;
   NoiseDev nd;
   CHECK_RC(dA.alloc((size_t)m_tot * n_pad));
   if (mean) CHECK_RC(dmean.upload(mean, N));
   CHECK_RC(upload_noise(nd, noise_kind, noise, N));
   CHECK_RC(upload_matrix(dZ, Z, ldz, N, S));
   CHECK_RC(dZt.alloc((size_t)s_pad * n_pad));
-  CHECK_RC(dOt.alloc((size_t)s_pad * n_pad));
-  CHECK_RC(dOut.alloc((size_t)N * S));
+  CHECK_RC(dOut.alloc((size_t)n_pad * s_pad));
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
   CHECK_RC(build_bordered(ctx, g.ds, dA.p, n_pad, m_tot, nullptr, nd.kind, nd.sigma2, nd.diag.p,
                           nd.dense.p, nd.ld_dense, nullptr, 0, 0, s));
@@ -735,18 +742,18 @@ extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* me
   SGP_HIP(hipMemsetAsync(dZt.p, 0, sizeof(double) * s_pad * n_pad, s));
   // Zt[s, k] = Z[k, s]
   CHECK_RC(launch_transpose_add(dZ.p, N, N, S, dZt.p, s_pad, nullptr, s));
-  // Ot[s, i] = sum_{k <= i} Zt[s, k] L[i, k]
-  CHECK_RC(launch_gemm_nt(dZt.p, s_pad, dA.p, m_tot, dOt.p, s_pad, s_pad, n_pad, n_pad, 1.0, 0.0,
-                          NOMASK, 1, 0, s));
-  // out[i, s] = Ot[s, i] + mean[i]
-  CHECK_RC(launch_transpose_add(dOt.p, s_pad, S, N, dOut.p, N, mean ? dmean.p : nullptr, s));
+  // out[i, s] = mean[i] + sum_{k <= i} L[i, k] Zt[s, k]   (n_pad x s_pad, column-major like the result)
+  hipLaunchKernelGGL(fill_mean_cols_kernel, dim3((unsigned)((n_pad * s_pad + 255) / 256)), dim3(256), 0, s, dOut.p,
+                     (long)n_pad, (long)n_pad, s_pad, N, mean ? dmean.p : nullptr);
+  SGP_HIP(hipGetLastError());
+  CHECK_RC(launch_gemm_nt_lz(dA.p, m_tot, dZt.p, s_pad, dOut.p, n_pad, n_pad, s_pad, 1.0, s));
   int info = fetch_info(ctx, s);
   if (info > 0) {
     set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
               std::to_string(info));
     return info;
   }
-  SGP_HIP(hipMemcpy2D(out, sizeof(double) * ldo, dOut.p, sizeof(double) * N, sizeof(double) * N,
+  SGP_HIP(hipMemcpy2D(out, sizeof(double) * ldo, dOut.p, sizeof(double) * n_pad, sizeof(double) * N,
                       (size_t)S, hipMemcpyDeviceToHost));
   return 0;
 }

@@ -158,10 +158,13 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
       __builtin_amdgcn_global_load_lds((gptr_t)(Bg + 2 * lane + (k0 + col) * ldb), (lptr_t)(sb + col * LDS_LD), 16, 0, 0);
     }
   };
-  const long nchunks = K / KB;
-  // klo: both operands are upper-triangular-by-tile (rows of inv(L)'), so tile row tr (>= tc)
-  // contracts only columns k >= tr * 128  (C^-1 = inv(L)' inv(L) at a third of the dense flops)
-  const long cbeg = klo ? tr * (TILE / KB) : 0;
+  long nchunks = K / KB;
+  // klo == 1: both operands are upper-triangular-by-tile (rows of inv(L)'), so tile row tr (>= tc)
+  // contracts only columns k >= tr * 128  (C^-1 = inv(L)' inv(L) at a third of the dense flops).
+  // klo == 2: A is lower-triangular-by-tile (the Cholesky factor in L Z): tile row tr stops at
+  // k < (tr + 1) * 128.
+  const long cbeg = klo == 1 ? tr * (TILE / KB) : 0;
+  if (klo == 2 && (tr + 1) * (TILE / KB) < nchunks) nchunks = (tr + 1) * (TILE / KB);
   // prologue: the first operand chunk and the old C tile are requested together, so their
   // latencies overlap (one wait for both)
   if (cbeg < nchunks) dma(cbeg * KB, 0);
@@ -444,6 +447,25 @@ int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, h
   long per_xcd = tri_ids_per_xcd(tri_shape(n_t, n_t));
   hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
                      1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 1);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// C (n x ns) = beta C + L Zt' for the lower-triangular-by-tile factor L (n x n, ld ldl) and Zt (ns x n,
+// ld ldz): rand's m + L Z, with every tile row contracting only the columns left of its diagonal
+// tile's right edge.  Tile rows are spread over all XCDs (n / 128 of them) -- the transposed
+// arrangement (ns / 128 tile rows) would leave most of the chip idle for a few hundred samples.
+int launch_gemm_nt_lz(const double* L, long ldl, const double* Zt, long ldz, double* C, long ldc, long n,
+                      long ns, double beta, hipStream_t s) {
+  if (n <= 0 || ns <= 0) return 0;
+  if (n % TILE || ns % TILE) {
+    set_error("gemm_nt_lz: n, ns must be multiples of 128");
+    return -1;
+  }
+  long n_tr = n / TILE, n_tc = ns / TILE;
+  long groups = ((n_tr + 7) / 8 + 7) / 8;
+  hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3((unsigned)(groups * 8 * n_tc * 8)), dim3(512), 0, s, L, ldl, Zt, ldz, C,
+                     ldc, n, 1.0, beta, -(1L << 40), n_tr, n_tc, 0L, (const double*)C, ldc, 2);
   SGP_HIP(hipGetLastError());
   return 0;
 }

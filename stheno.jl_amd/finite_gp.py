@@ -314,7 +314,10 @@ def _concat(xs, zs):
     return BlockData(list(xs.X) + list(zb))
 
 
-def posterior(fx, y):
+def posterior(fx, y, y_vfe=None):
+    """posterior(fx, y)  |  posterior(VFE(fz), fx, y)  |  posterior(SparseFiniteGP, y)"""
+    if isinstance(fx, VFE):                  # posterior(VFE(fz), fx, y)  (sparse_finite_gp.jl:60-62)
+        return posterior_vfe(fx, y, y_vfe)
     if isinstance(fx, SparseFiniteGP):
         return posterior_vfe(VFE(fx.finducing), fx.fobs, y)
     if not _is_prior(fx.f):

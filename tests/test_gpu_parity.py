@@ -264,7 +264,7 @@ def test_sparse_finite_gp_reference_properties():
     assert abs(e1 - e_o) <= 1e-9 * abs(e_o)
     yy = P.rand(np.random.default_rng(3), fxu, 10)
     assert np.all(P.logpdf(fx, yy) > P.logpdf(fxu, yy))                       # ELBO is a lower bound
-    p1 = P.finite_gp.posterior_vfe(P.VFE(fxu.finducing), fxu.fobs, y)
+    p1 = P.posterior(P.VFE(fxu.finducing), fxu.fobs, y)      # the 3-argument AbstractGPs form
     p2 = P.posterior(fxu, y)
     m1, v1 = p1.mean_and_var(x)
     m2, v2 = p2.mean_and_var(x)
