@@ -130,6 +130,17 @@ int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int n
 int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                     const double* noise, const double* y, double* logpdf_out, double* grad_y,
                     double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale);
+/* Same, plus the gradient w.r.t. the input points: grad_inputs[k] (may be NULL) receives a packed
+ * dim_k x n_k column-major array for spec->inputs[k] -- d logpdf / d (the points the terms read, i.e.
+ * after whatever Stretch / Select / Periodic transformation the host applied; chaining back to the
+ * user's x is the host's job).  Stationary kernels only depend on x - x', so this is
+ * sum_j 2 G_ij coef rs_i cs_j kappa'(d2_ij) 2 (x_i - x'_j) over every term that reads input k.
+ * Input dimension <= 16.  Matern-1/2 is not differentiable at coincident points: those pairs
+ * contribute 0.  Row / column scale vectors (function-scaled processes) are held fixed. */
+int sgp_logpdf_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                      const double* noise, const double* y, double* logpdf_out, double* grad_y,
+                      double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
+                      double* const* grad_inputs);
 
 /* ---- rand(rng, fx, S) (A3; App. A.4): out = mean .+ L * Z, Z = randn(rng, N, S) drawn by
  * the caller's RNG (column-major fill order), so the integer RNG stream stays the caller's. */

@@ -63,6 +63,9 @@ struct sgp_dspec {
   std::vector<DevTerm> h_terms;         // host copy (device pointers inside)
   DevTerm* d_terms = nullptr;
   std::vector<int> pair_dmax;
+  std::vector<int> term_row_input;     // spec input index each term reads its row points from
+  std::vector<int> in_dim;             // per spec input
+  std::vector<long> in_n;
 };
 
 #define CHECK_ARG(cond, msg)       \
@@ -209,6 +212,8 @@ extern "C" int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec*
         return fail("spec: input upload failed");
     }
     d_in[k] = d;
+    ds->in_dim.push_back((int)in.dim);
+    ds->in_n.push_back((long)in.n);
   }
   int npairs = ds->nrb * ds->ncb;
   ds->term_ptr.assign(sp->term_ptr, sp->term_ptr + npairs + 1);
@@ -250,6 +255,7 @@ extern "C" int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec*
         if (!up(T.row_scale, ds->row_len[I], &D.rs) || !up(T.col_scale, ds->col_len[J], &D.cs))
           return fail("spec: scale upload failed");
         ds->h_terms.push_back(D);
+        ds->term_row_input.push_back(T.row_input);
         ds->pair_dmax[p] = std::max(ds->pair_dmax[p], pow2ceil(D.dim));
       }
     }
@@ -786,10 +792,10 @@ static int contract_spec(const sgp_dspec* ds, const double* Gm, long ldg, const 
 // ---------------------------------------------------------------------------------------
 // logpdf + reverse-mode gradient
 // ---------------------------------------------------------------------------------------
-extern "C" int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
-                               const double* noise, const double* y, double* logpdf_out, double* grad_y,
-                               double* grad_mean, double* grad_noise, double* grad_coef,
-                               double* grad_inscale) {
+static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                            const double* noise, const double* y, double* logpdf_out, double* grad_y,
+                            double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
+                            double* const* grad_inputs) {
   CHECK_ARG(ctx && spec && noise && y && logpdf_out, "sgp_logpdf_grad: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_logpdf_grad: spec must be symmetric");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
@@ -845,6 +851,29 @@ extern "C" int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
   if (grad_noise) CHECK_RC(launch_grad_noise(dKinv.p, n_pad, dalpha.p, N, nd.kind == SGP_NOISE_DIAG, dgn.p, s));
   if (grad_coef || grad_inscale)
     CHECK_RC(contract_spec(ds, dKinv.p, n_pad, dalpha.p, n_pad / TILE, n_pad / TILE, dpart, dgc.p, dgs.p, s));
+  // gradient w.r.t. the input points: row-side contraction over every block pair; the spec is
+  // symmetric (block (J, I) mirrors (I, J)) and so is G, hence the column side equals the row side of
+  // the mirror block and the total is twice the row-side sum
+  std::vector<DevBuf> dgx(grad_inputs ? spec->n_inputs : 0);
+  if (grad_inputs) {
+    for (int k = 0; k < spec->n_inputs; ++k) {
+      size_t cnt = (size_t)std::max<long>(1, (long)ds->in_dim[k] * ds->in_n[k]);
+      CHECK_RC(dgx[k].alloc(cnt));
+      SGP_HIP(hipMemsetAsync(dgx[k].p, 0, sizeof(double) * cnt, s));
+    }
+    for (int I = 0; I < ds->nrb; ++I) {
+      for (int J = 0; J < ds->ncb; ++J) {
+        if (ds->row_len[I] == 0 || ds->col_len[J] == 0) continue;
+        int p = I * ds->ncb + J;
+        for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t) {
+          int a = ds->term_row_input[t];
+          CHECK_ARG(ds->in_dim[a] <= 16, "input gradients: input dimension > 16 is not supported on device");
+          CHECK_RC(launch_grad_inputs(dKinv.p, n_pad, dalpha.p, ds->row_off[I], ds->row_len[I], ds->col_off[J],
+                                      ds->col_len[J], ds->h_terms[t], ds->pair_dmax[p], 2.0, dgx[a].p, s));
+        }
+      }
+    }
+  }
   int info = fetch_info(ctx, s);
   if (info > 0) {
     set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
@@ -865,7 +894,31 @@ extern "C" int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
     SGP_HIP(hipMemcpy(grad_coef, dgc.p, sizeof(double) * nterms_total, hipMemcpyDeviceToHost));
   if (grad_inscale && nterms_total)
     SGP_HIP(hipMemcpy(grad_inscale, dgs.p, sizeof(double) * nterms_total, hipMemcpyDeviceToHost));
+  if (grad_inputs) {
+    for (int k = 0; k < spec->n_inputs; ++k) {
+      const sgp_input& in = spec->inputs[k];
+      if (!grad_inputs[k] || in.n == 0) continue;
+      SGP_HIP(hipMemcpy(grad_inputs[k], dgx[k].p, sizeof(double) * in.dim * in.n, hipMemcpyDeviceToHost));
+    }
+  }
   return 0;
+}
+
+extern "C" int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                               const double* noise, const double* y, double* logpdf_out, double* grad_y,
+                               double* grad_mean, double* grad_noise, double* grad_coef,
+                               double* grad_inscale) {
+  return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
+                          grad_coef, grad_inscale, nullptr);
+}
+
+extern "C" int sgp_logpdf_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                                 const double* noise, const double* y, double* logpdf_out, double* grad_y,
+                                 double* grad_mean, double* grad_noise, double* grad_coef,
+                                 double* grad_inscale, double* const* grad_inputs) {
+  CHECK_ARG(grad_inputs != nullptr, "sgp_logpdf_grad_x: grad_inputs is NULL");
+  return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
+                          grad_coef, grad_inscale, grad_inputs);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -397,4 +397,114 @@ int launch_vfe_gxz(double* E, long ld, const double* delta, const double* ut, co
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// Gradient w.r.t. the input points of a term's row input ("inputs"):
+//   gx[d, i] += scale * sum_j G_ij coef rs_i cs_j kappa'(|x_i - x'_j|^2) 2 (x_i - x'_j)[d]
+// for the stationary kernels kappa(d^2) of kern_and_dscale (dk/dg = 2 d^2 kappa').  One workgroup
+// owns one 128-row tile of the block pair and walks over all its column tiles, so every output
+// row is written by exactly one workgroup -- no atomics, deterministic; launches that add into the
+// same input array are ordered on one stream.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double kern_dd2(int kind, double d2, double param) {
+  switch (kind) {
+    case G_SE:
+      return -0.5 * exp(-0.5 * d2);
+    case G_M12: {
+      double d = sqrt(d2);
+      return d > 0.0 ? -0.5 * exp(-d) / d : 0.0;  // not differentiable at coincident points: subgradient 0
+    }
+    case G_M32:
+      return -1.5 * exp(-1.7320508075688772 * sqrt(d2));
+    case G_M52: {
+      double l = 2.23606797749979 * sqrt(d2);
+      return -(5.0 / 6.0) * (1.0 + l) * exp(-l);
+    }
+    default:
+      return 0.0;  // white noise (a.e.), constant
+  }
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long ldg, const double* alpha,
+                                                          long r0, long nr, long c0, long nc, DevTerm T,
+                                                          double scale, double* gx /* DMAX-padded? no: ld = T.dim */) {
+  __shared__ double sx[TILE * DMAX];
+  __shared__ double scs[TILE];
+  __shared__ double comb[TILE * DMAX];
+  const int t = threadIdx.x;
+  const int trow = t & 127, th = t >> 7;
+  const long lrow = (long)blockIdx.x * TILE + trow;  // row within the block
+  const bool live = lrow < nr;
+  const long grow = r0 + lrow;
+  double xr[DMAX], acc[DMAX];
+#pragma unroll
+  for (int d = 0; d < DMAX; ++d) {
+    xr[d] = (live && d < T.dim) ? T.xr[lrow * T.ldr + d] : 0.0;
+    acc[d] = 0.0;
+  }
+  const double ai = (alpha && live) ? alpha[grow] : 0.0;
+  const double wrow = live ? T.coef * (T.rs ? T.rs[lrow] : 1.0) : 0.0;
+  for (long ct = 0; ct * TILE < nc; ++ct) {
+    __syncthreads();
+    for (int idx = t; idx < TILE * DMAX; idx += 256) {
+      int p = idx / DMAX, d = idx % DMAX;
+      long lc = ct * TILE + p;
+      sx[idx] = (lc < nc && d < T.dim) ? T.xc[lc * T.ldc + d] : 0.0;
+    }
+    if (t < TILE) {
+      long lc = ct * TILE + t;
+      scs[t] = (lc < nc) ? (T.cs ? T.cs[lc] : 1.0) : 0.0;  // 0 kills the padding columns
+    }
+    __syncthreads();
+    if (live) {
+      for (int p = th * 64; p < th * 64 + 64; ++p) {
+        const long lc = ct * TILE + p;
+        if (lc >= nc) break;
+        const long gc = c0 + lc;
+        const double g = alpha ? 0.5 * (ai * alpha[gc] - Gm[grow + gc * ldg]) : Gm[grow + gc * ldg];
+        double df[DMAX], d2 = 0.0;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+          df[d] = xr[d] - sx[p * DMAX + d];
+          d2 = fma(df[d], df[d], d2);
+        }
+        const double w = 2.0 * g * wrow * scs[p] * kern_dd2(T.kind, d2, T.param);
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) acc[d] = fma(w, df[d], acc[d]);
+      }
+    }
+  }
+  // combine the two column halves in fixed order, then add into the input's gradient
+  __syncthreads();
+  if (th == 1) {
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) comb[trow * DMAX + d] = acc[d];
+  }
+  __syncthreads();
+  if (th == 0 && live) {
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d)
+      if (d < T.dim) gx[lrow * T.dim + d] += scale * (acc[d] + comb[trow * DMAX + d]);
+  }
+}
+
+int launch_grad_inputs(const double* Gm, long ldg, const double* alpha, long r0, long nr, long c0, long nc,
+                       const DevTerm& T, int dmax, double scale, double* gx, hipStream_t s) {
+  if (nr <= 0 || nc <= 0) return 0;
+  dim3 grid((unsigned)((nr + TILE - 1) / TILE)), block(256);
+#define SGP_GI(DM) hipLaunchKernelGGL(grad_inputs_kernel<DM>, grid, block, 0, s, Gm, ldg, alpha, r0, nr, c0, nc, T, scale, gx)
+  if (dmax <= 1) SGP_GI(1);
+  else if (dmax <= 2) SGP_GI(2);
+  else if (dmax <= 4) SGP_GI(4);
+  else if (dmax <= 8) SGP_GI(8);
+  else if (dmax <= 16) SGP_GI(16);
+  else {
+    set_error("input gradients: input dimension > 16 is not supported on device");
+    return -1;
+  }
+#undef SGP_GI
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace sgp

@@ -176,8 +176,11 @@ def logpdf(fx, y):
     return float(out[0]) if vec else out
 
 
-def logpdf_and_gradient(fx, y):
+def logpdf_and_gradient(fx, y, inputs=False):
     """logpdf(fx, y) and its reverse-mode gradient (what Zygote derives on the reference path).
+    inputs=True adds `inputs`: one (dim, n) array per spec input (g["_spec"].inputs[k]) with
+    d logpdf / d (the points the terms read -- after Stretch / Select / Periodic; for
+    stretch(f, a) the gradient w.r.t. the user's x is a * that array).
 
     Returns a dict: logpdf; y, mean (d/dy, d/d mean, N each); noise (scalar for f(x, s2), vector for
     f(x, v)); terms: one record per flattened covariance term of the lower block pairs
@@ -198,10 +201,19 @@ def logpdf_and_gradient(fx, y):
     gn = np.zeros(n if kind == _lib.NOISE_DIAG else 1)
     nt = max(1, spec.n_terms)
     gc, gs = np.zeros(nt), np.zeros(nt)
-    rc = _ctx().lib.sgp_logpdf_grad(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(yv),
-                                    _lib.dptr(lp), _lib.dptr(gy), _lib.dptr(gm), _lib.dptr(gn), _lib.dptr(gc),
-                                    _lib.dptr(gs))
-    _lib.check(rc, "sgp_logpdf_grad")
+    gx = None
+    if inputs:
+        gx = [np.zeros(np.asarray(a).shape, order="F") for a in spec.inputs]
+        ptrs = (C.POINTER(C.c_double) * len(gx))(*[_lib.dptr(a) for a in gx])
+        rc = _ctx().lib.sgp_logpdf_grad_x(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf),
+                                          _lib.dptr(yv), _lib.dptr(lp), _lib.dptr(gy), _lib.dptr(gm), _lib.dptr(gn),
+                                          _lib.dptr(gc), _lib.dptr(gs), ptrs)
+        _lib.check(rc, "sgp_logpdf_grad_x")
+    else:
+        rc = _ctx().lib.sgp_logpdf_grad(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf),
+                                        _lib.dptr(yv), _lib.dptr(lp), _lib.dptr(gy), _lib.dptr(gm), _lib.dptr(gn),
+                                        _lib.dptr(gc), _lib.dptr(gs))
+        _lib.check(rc, "sgp_logpdf_grad")
     terms, nrb = [], len(spec.row_len)
     tp = spec._term_ptr
     index = {}
@@ -223,7 +235,7 @@ def logpdf_and_gradient(fx, y):
                     terms[k]["d_coef"] += float(gc[t])
                     terms[k]["d_inscale"] += float(gs[t])
     return dict(logpdf=float(lp[0]), y=gy, mean=gm, noise=(gn if kind == _lib.NOISE_DIAG else float(gn[0])),
-                terms=terms, _raw=(gc, gs), _spec=spec)
+                terms=terms, inputs=gx, _raw=(gc, gs), _spec=spec)
 
 
 def _draw(rng, n, s):

@@ -467,6 +467,72 @@ def test_logpdf_gradient_matches_finite_differences_of_hyperparameters():
     assert abs(g["noise"] - fd_s) <= 1e-6 * max(1.0, abs(fd_s))
 
 
+def _kappa_prime(kind, d2):
+    """d kappa / d (d^2) of the stationary kernels (independent restatement for the test)."""
+    d = np.sqrt(d2)
+    if kind == P.lib.SE:
+        return -0.5 * np.exp(-0.5 * d2)
+    if kind == P.lib.MATERN12:
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where(d > 0, -0.5 * np.exp(-d) / d, 0.0)
+    if kind == P.lib.MATERN32:
+        return -1.5 * np.exp(-np.sqrt(3.0) * d)
+    if kind == P.lib.MATERN52:
+        return -(5.0 / 6.0) * (1.0 + np.sqrt(5.0) * d) * np.exp(-np.sqrt(5.0) * d)
+    return np.zeros_like(d2)
+
+
+@pytest.mark.parametrize("recipe", [models.gppp_docstring, models.composite_kernels], ids=lambda r: r.__name__)
+def test_logpdf_gradient_wrt_input_points(recipe):
+    """sgp_logpdf_grad_x against a NumPy contraction of the oracle's G with the analytic kernel
+    derivatives, per spec input (the transformed points the terms read)."""
+    import np_terms
+    rng = np.random.default_rng(21)
+    Fo, Fp, fo, fp = both(recipe)
+    names = list(fo)[:3]
+    D = 2
+    xs = [np.asfortranarray(rng.standard_normal((D, n))) for n in (150, 70, 131)][:len(names)]
+    xo, xp = blockdata(names, xs, True)
+    N = sum(x.shape[1] for x in xs)
+    y = rng.standard_normal(N)
+    _, _, G = oagp.logpdf_gradient_wrt_cov(Fo(xo, 0.3), y)
+    g = P.logpdf_and_gradient(Fp(xp, 0.3), y, inputs=True)
+    spec = g["_spec"]
+    roff = np.concatenate([[0], np.cumsum(spec.row_len)])
+    exp = [np.zeros_like(a) for a in spec.inputs]
+    for (I, J, kind, ri, ci, coef, param, rs, cs) in np_terms.spec_terms(spec):
+        X, Y = spec.inputs[ri], spec.inputs[ci]
+        df = X[:, :, None] - Y[:, None, :]
+        w = G[roff[I]:roff[I + 1], roff[J]:roff[J + 1]] * coef * _kappa_prime(kind, (df ** 2).sum(0))
+        if rs is not None:
+            w = w * rs[:, None]
+        if cs is not None:
+            w = w * cs[None, :]
+        exp[ri] += 2.0 * 2.0 * (w[None, :, :] * df).sum(2)      # d(d2)/dx = 2 (x - x'), mirror block doubles
+    assert len(g["inputs"]) == len(exp)
+    for k, (a, e) in enumerate(zip(g["inputs"], exp)):
+        assert a.shape == e.shape
+        assert np.abs(a - e).max() <= 1e-8 * max(1.0, np.abs(e).max()), (k, np.abs(a - e).max())
+
+
+def test_logpdf_input_gradient_matches_finite_differences():
+    rng = np.random.default_rng(23)
+    Xm = np.asfortranarray(rng.standard_normal((3, 300)))
+    y = rng.standard_normal(300)
+    v, l, s2 = 1.7, 0.8, 0.25
+    f = np.sqrt(v) * P.stretch(P.atomic(P.GP(P.Matern52Kernel()), P.GPC()), 1.0 / l)
+    g = P.logpdf_and_gradient(f(P.ColVecs(Xm), s2), y, inputs=True)
+    (gx,) = g["inputs"]
+    dX = gx / l                                   # the term reads X / l
+    h = 1e-6
+    for (d, i) in [(0, 0), (1, 17), (2, 299), (0, 150)]:
+        Xp, Xn = Xm.copy(), Xm.copy()
+        Xp[d, i] += h
+        Xn[d, i] -= h
+        fd = (P.logpdf(f(P.ColVecs(Xp), s2), y) - P.logpdf(f(P.ColVecs(Xn), s2), y)) / (2 * h)
+        assert abs(dX[d, i] - fd) <= 1e-5 * max(1.0, abs(fd)), (d, i, dX[d, i], fd)
+
+
 # ---- reverse-mode gradient of the elbo (SURVEY.md 8f item 1) --------------------------------------
 @pytest.mark.parametrize("recipe", [models.gppp_docstring, models.composite_kernels], ids=lambda r: r.__name__)
 def test_elbo_gradient_against_oracle_cotangents(recipe):
