@@ -185,6 +185,17 @@ int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, 
  * coef_t dk_t/dg; entries of other terms are set to 0.  Both outputs have spec->term_ptr[last] entries. */
 int sgp_kernelmatrix_diag_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
                                double* grad_inscale);
+/* sgp_elbo_grad plus the gradient w.r.t. the input points (see sgp_logpdf_grad_x):
+ * grad_inputs_zz[k] for zz->inputs[k] (inducing points, through K(z,z)) and grad_inputs_xz[k] for
+ * xz->inputs[k] (data points on the row side, inducing points on the column side, through K(x,z)).
+ * The inducing points appear in both tables: add the matching arrays.  The dependence of var(f, x)
+ * on x is not included (it vanishes for stationary kernels read at one input). */
+int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                    const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                    const double* z_noise, const double* y, double* elbo_out, double* grad_y,
+                    double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
+                    double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
+                    double* grad_inscale_xz, double* const* grad_inputs_zz, double* const* grad_inputs_xz);
 
 /* ---- elbo(VFE(fz), fx, y) (A5; App. A.6; src/gp/sparse_finite_gp.jl:52-58) -----------
  * zz: symmetric spec at the inducing inputs z (M);  xz: cross spec rows = x (N), cols = z;

@@ -63,7 +63,8 @@ struct sgp_dspec {
   std::vector<DevTerm> h_terms;         // host copy (device pointers inside)
   DevTerm* d_terms = nullptr;
   std::vector<int> pair_dmax;
-  std::vector<int> term_row_input;     // spec input index each term reads its row points from
+  std::vector<int> term_row_input;     // spec input index each term reads its row / column points from
+  std::vector<int> term_col_input;
   std::vector<int> in_dim;             // per spec input
   std::vector<long> in_n;
 };
@@ -256,6 +257,7 @@ extern "C" int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec*
           return fail("spec: scale upload failed");
         ds->h_terms.push_back(D);
         ds->term_row_input.push_back(T.row_input);
+        ds->term_col_input.push_back(T.col_input);
         ds->pair_dmax[p] = std::max(ds->pair_dmax[p], pow2ceil(D.dim));
       }
     }
@@ -868,7 +870,7 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
         for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t) {
           int a = ds->term_row_input[t];
           CHECK_ARG(ds->in_dim[a] <= 16, "input gradients: input dimension > 16 is not supported on device");
-          CHECK_RC(launch_grad_inputs(dKinv.p, n_pad, dalpha.p, ds->row_off[I], ds->row_len[I], ds->col_off[J],
+          CHECK_RC(launch_grad_inputs(dKinv.p, 1, n_pad, dalpha.p, ds->row_off[I], ds->row_len[I], ds->col_off[J],
                                       ds->col_len[J], ds->h_terms[t], ds->pair_dmax[p], 2.0, dgx[a].p, s));
         }
       }
@@ -1402,12 +1404,12 @@ extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
 //   G_xz = Lambda (R Z J' + delta (J u)')                      -> contraction over the xz spec
 //   G_zz = -1/2 J (B + B^-1 - 2 I + u u') J'                   -> contraction over the zz spec
 // ---------------------------------------------------------------------------------------
-extern "C" int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
-                             const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
-                             const double* z_noise, const double* y, double* elbo_out, double* grad_y,
-                             double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
-                             double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
-                             double* grad_inscale_xz) {
+static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                          const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                          const double* z_noise, const double* y, double* elbo_out, double* grad_y,
+                          double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
+                          double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
+                          double* grad_inscale_xz, double* const* grad_inputs_zz, double* const* grad_inputs_xz) {
   CHECK_ARG(ctx && zz && xz && var_x && noise_x && z_noise && y && elbo_out, "sgp_elbo_grad: NULL argument");
   CHECK_ARG(zz->symmetric, "sgp_elbo_grad: zz spec must be symmetric");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
@@ -1555,6 +1557,54 @@ extern "C" int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov
     CHECK_RC(contract_spec(gx.ds, dE.p, n_rows, nullptr, n_rows / TILE, m_pad / TILE, dpart, dgcx.p, dgsx.p, s));
   if (grad_coef_zz || grad_inscale_zz)
     CHECK_RC(contract_spec(gz.ds, dGzz.p, m_pad, nullptr, m_pad / TILE, m_pad / TILE, dpart, dgcz.p, dgsz.p, s));
+  // ---- input points: zz is symmetric (twice the row side, as in logpdf_grad_core); xz is
+  // rectangular: row side for the x inputs, and the transposed contraction for the z inputs
+  std::vector<DevBuf> dgz(grad_inputs_zz ? zz->n_inputs : 0), dgxz(grad_inputs_xz ? xz->n_inputs : 0);
+  auto zero_inputs = [&](std::vector<DevBuf>& v, const sgp_dspec* ds) -> int {
+    for (size_t k = 0; k < v.size(); ++k) {
+      CHECK_ARG(ds->in_dim[k] <= 16, "input gradients: input dimension > 16 is not supported on device");
+      size_t cnt = (size_t)std::max<long>(1, (long)ds->in_dim[k] * ds->in_n[k]);
+      CHECK_RC(v[k].alloc(cnt));
+      SGP_HIP(hipMemsetAsync(v[k].p, 0, sizeof(double) * cnt, s));
+    }
+    return 0;
+  };
+  if (grad_inputs_zz) {
+    CHECK_RC(zero_inputs(dgz, gz.ds));
+    const sgp_dspec* ds = gz.ds;
+    for (int I = 0; I < ds->nrb; ++I)
+      for (int J = 0; J < ds->ncb; ++J) {
+        if (ds->row_len[I] == 0 || ds->col_len[J] == 0) continue;
+        int p = I * ds->ncb + J;
+        for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t)
+          CHECK_RC(launch_grad_inputs(dGzz.p, 1, m_pad, nullptr, ds->row_off[I], ds->row_len[I], ds->col_off[J],
+                                      ds->col_len[J], ds->h_terms[t], ds->pair_dmax[p], 2.0,
+                                      dgz[ds->term_row_input[t]].p, s));
+      }
+  }
+  if (grad_inputs_xz) {
+    CHECK_RC(zero_inputs(dgxz, gx.ds));
+    const sgp_dspec* ds = gx.ds;
+    for (int I = 0; I < ds->nrb; ++I)
+      for (int J = 0; J < ds->ncb; ++J) {
+        if (ds->row_len[I] == 0 || ds->col_len[J] == 0) continue;
+        int p = I * ds->ncb + J;
+        for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t) {
+          const DevTerm& T = ds->h_terms[t];
+          CHECK_RC(launch_grad_inputs(dE.p, 1, n_rows, nullptr, ds->row_off[I], ds->row_len[I], ds->col_off[J],
+                                      ds->col_len[J], T, ds->pair_dmax[p], 1.0, dgxz[ds->term_row_input[t]].p, s));
+          DevTerm Tt = T;  // the same term seen from its column points
+          Tt.xr = T.xc;
+          Tt.ldr = T.ldc;
+          Tt.xc = T.xr;
+          Tt.ldc = T.ldr;
+          Tt.rs = T.cs;
+          Tt.cs = T.rs;
+          CHECK_RC(launch_grad_inputs(dE.p, n_rows, 1, nullptr, ds->col_off[J], ds->col_len[J], ds->row_off[I],
+                                      ds->row_len[I], Tt, ds->pair_dmax[p], 1.0, dgxz[ds->term_col_input[t]].p, s));
+        }
+      }
+  }
   SGP_HIP(hipStreamSynchronize(s));
   // ---- results
   std::vector<double> hy(N), hs(N);
@@ -1597,7 +1647,39 @@ extern "C" int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov
   if (grad_coef_xz) SGP_HIP(hipMemcpy(grad_coef_xz, dgcx.p, sizeof(double) * gx.ds->h_terms.size(), hipMemcpyDeviceToHost));
   if (grad_inscale_xz)
     SGP_HIP(hipMemcpy(grad_inscale_xz, dgsx.p, sizeof(double) * gx.ds->h_terms.size(), hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < dgz.size(); ++k)
+    if (grad_inputs_zz[k] && zz->inputs[k].n > 0)
+      SGP_HIP(hipMemcpy(grad_inputs_zz[k], dgz[k].p, sizeof(double) * zz->inputs[k].dim * zz->inputs[k].n,
+                        hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < dgxz.size(); ++k)
+    if (grad_inputs_xz[k] && xz->inputs[k].n > 0)
+      SGP_HIP(hipMemcpy(grad_inputs_xz[k], dgxz[k].p, sizeof(double) * xz->inputs[k].dim * xz->inputs[k].n,
+                        hipMemcpyDeviceToHost));
   return 0;
+}
+
+extern "C" int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                             const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                             const double* z_noise, const double* y, double* elbo_out, double* grad_y,
+                             double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
+                             double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
+                             double* grad_inscale_xz) {
+  return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
+                        grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
+                        grad_inscale_xz, nullptr, nullptr);
+}
+
+extern "C" int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                               const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                               const double* z_noise, const double* y, double* elbo_out, double* grad_y,
+                               double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
+                               double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
+                               double* grad_inscale_xz, double* const* grad_inputs_zz,
+                               double* const* grad_inputs_xz) {
+  CHECK_ARG(grad_inputs_zz && grad_inputs_xz, "sgp_elbo_grad_x: grad_inputs_* is NULL");
+  return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
+                        grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
+                        grad_inscale_xz, grad_inputs_zz, grad_inputs_xz);
 }
 
 // sum_i w[i] d var_i / d theta over the diagonal of `spec` (the blocks (I, I) kernelmatrix_diag reads)

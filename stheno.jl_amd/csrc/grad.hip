@@ -425,9 +425,12 @@ __device__ __forceinline__ double kern_dd2(int kind, double d2, double param) {
 }
 
 template <int DMAX>
-__global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long ldg, const double* alpha,
+__global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long sr, long sc, const double* alpha,
                                                           long r0, long nr, long c0, long nc, DevTerm T,
-                                                          double scale, double* gx /* DMAX-padded? no: ld = T.dim */) {
+                                                          double scale, double* gx /* T.dim x nr, packed */) {
+  // G(i, j) of this launch's (row point i, column point j) lives at Gm[(r0 + i) * sr + (c0 + j) * sc]:
+  // (sr, sc) = (1, ld) for the matrix as stored, (ld, 1) to contract its transpose (column-side
+  // gradients of a rectangular block: the caller swaps the term's row / column data).
   __shared__ double sx[TILE * DMAX];
   __shared__ double scs[TILE];
   __shared__ double comb[TILE * DMAX];
@@ -461,7 +464,8 @@ __global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long
         const long lc = ct * TILE + p;
         if (lc >= nc) break;
         const long gc = c0 + lc;
-        const double g = alpha ? 0.5 * (ai * alpha[gc] - Gm[grow + gc * ldg]) : Gm[grow + gc * ldg];
+        const double gm = Gm[grow * sr + gc * sc];
+        const double g = alpha ? 0.5 * (ai * alpha[gc] - gm) : gm;
         double df[DMAX], d2 = 0.0;
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) {
@@ -488,11 +492,11 @@ __global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long
   }
 }
 
-int launch_grad_inputs(const double* Gm, long ldg, const double* alpha, long r0, long nr, long c0, long nc,
+int launch_grad_inputs(const double* Gm, long sr, long sc, const double* alpha, long r0, long nr, long c0, long nc,
                        const DevTerm& T, int dmax, double scale, double* gx, hipStream_t s) {
   if (nr <= 0 || nc <= 0) return 0;
   dim3 grid((unsigned)((nr + TILE - 1) / TILE)), block(256);
-#define SGP_GI(DM) hipLaunchKernelGGL(grad_inputs_kernel<DM>, grid, block, 0, s, Gm, ldg, alpha, r0, nr, c0, nc, T, scale, gx)
+#define SGP_GI(DM) hipLaunchKernelGGL(grad_inputs_kernel<DM>, grid, block, 0, s, Gm, sr, sc, alpha, r0, nr, c0, nc, T, scale, gx)
   if (dmax <= 1) SGP_GI(1);
   else if (dmax <= 2) SGP_GI(2);
   else if (dmax <= 4) SGP_GI(4);

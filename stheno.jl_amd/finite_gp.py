@@ -430,15 +430,17 @@ def _term_records(spec, gc, gs, symmetric):
     return out
 
 
-def elbo_and_gradient(vfe, fx, y=None):
+def elbo_and_gradient(vfe, fx, y=None, inputs=False):
     """elbo(VFE(fz), fx, y) and its reverse-mode gradient (what Zygote derives through
     AbstractGPs.elbo on the reference path; sgp_elbo_grad).
 
     Returns a dict: elbo; y, mean (N each); noise (scalar or N); z_noise (scalar or M: d/d Sigma_z);
     zz_terms / xz_terms / xx_terms: per flattened covariance term of K(z,z), K(x,z) and diag K(x,x)
-    {I, J, kind, coef, row_input, col_input, d_coef, d_inscale} (see logpdf_and_gradient)."""
+    {I, J, kind, coef, row_input, col_input, d_coef, d_inscale} (see logpdf_and_gradient).
+    inputs=True adds zz_inputs / xz_inputs: d elbo / d (input points) per entry of
+    g["_specs"]["zz"].inputs and g["_specs"]["xz"].inputs (the inducing points appear in both)."""
     if isinstance(vfe, SparseFiniteGP):
-        return elbo_and_gradient(VFE(vfe.finducing), vfe.fobs, fx)
+        return elbo_and_gradient(VFE(vfe.finducing), vfe.fobs, fx, inputs=inputs)
     zz, xz, mean_x, nk, nbuf, zk, zbuf = _vfe_args(vfe, fx)
     if zk == _lib.NOISE_DENSE:
         raise NotImplementedError("elbo gradient with dense Sigma_z")
@@ -453,11 +455,18 @@ def elbo_and_gradient(vfe, fx, y=None):
     gcz, gsz = np.zeros(max(1, zz.n_terms)), np.zeros(max(1, zz.n_terms))
     gcx, gsx = np.zeros(max(1, xz.n_terms)), np.zeros(max(1, xz.n_terms))
     lib = _ctx().lib
-    rc = lib.sgp_elbo_grad(_ctx().handle, zz.ref(), xz.ref(), _lib.dptr(var_x), _lib.dptr(mean_x), nk,
-                           _lib.dptr(nbuf), zk, _lib.dptr(zbuf), _lib.dptr(yv), _lib.dptr(out), _lib.dptr(gy),
-                           _lib.dptr(gm), _lib.dptr(gn), _lib.dptr(gv), _lib.dptr(gzn), _lib.dptr(gcz),
-                           _lib.dptr(gsz), _lib.dptr(gcx), _lib.dptr(gsx))
-    _lib.check(rc, "sgp_elbo_grad")
+    gxz = gxx = None
+    args = (_ctx().handle, zz.ref(), xz.ref(), _lib.dptr(var_x), _lib.dptr(mean_x), nk, _lib.dptr(nbuf), zk,
+            _lib.dptr(zbuf), _lib.dptr(yv), _lib.dptr(out), _lib.dptr(gy), _lib.dptr(gm), _lib.dptr(gn), _lib.dptr(gv),
+            _lib.dptr(gzn), _lib.dptr(gcz), _lib.dptr(gsz), _lib.dptr(gcx), _lib.dptr(gsx))
+    if inputs:
+        gxz = [np.zeros(a.shape, order="F") for a in zz.inputs]
+        gxx = [np.zeros(a.shape, order="F") for a in xz.inputs]
+        pz = (C.POINTER(C.c_double) * max(1, len(gxz)))(*[_lib.dptr(a) for a in gxz])
+        px = (C.POINTER(C.c_double) * max(1, len(gxx)))(*[_lib.dptr(a) for a in gxx])
+        _lib.check(lib.sgp_elbo_grad_x(*args, pz, px), "sgp_elbo_grad_x")
+    else:
+        _lib.check(lib.sgp_elbo_grad(*args), "sgp_elbo_grad")
     gcd, gsd = np.zeros(max(1, xx.n_terms)), np.zeros(max(1, xx.n_terms))
     rc = lib.sgp_kernelmatrix_diag_grad(_ctx().handle, xx.ref(), _lib.dptr(gv), _lib.dptr(gcd), _lib.dptr(gsd))
     _lib.check(rc, "sgp_kernelmatrix_diag_grad")
@@ -466,7 +475,7 @@ def elbo_and_gradient(vfe, fx, y=None):
     return dict(elbo=float(out[0]), y=gy, mean=gm, noise=(gn if nk == _lib.NOISE_DIAG else float(gn[0])),
                 z_noise=(gzn if zk == _lib.NOISE_DIAG else float(gzn[0])), var=gv,
                 zz_terms=_term_records(zz, gcz, gsz, True), xz_terms=_term_records(xz, gcx, gsx, False),
-                xx_terms=xx_terms, _raw=dict(zz=(gcz, gsz), xz=(gcx, gsx), xx=(gcd, gsd)),
+                xx_terms=xx_terms, zz_inputs=gxz, xz_inputs=gxx, _raw=dict(zz=(gcz, gsz), xz=(gcx, gsx), xx=(gcd, gsd)),
                 _specs=dict(zz=zz, xz=xz, xx=xx))
 
 

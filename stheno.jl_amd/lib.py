@@ -78,6 +78,8 @@ _SIGS = {
     "sgp_posterior_destroy": (C.c_int, [_P]),
     "sgp_elbo_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D, C.c_int,
                                 _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D]),
+    "sgp_elbo_grad_x": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D, C.c_int,
+                                  _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, C.POINTER(_D), C.POINTER(_D)]),
     "sgp_kernelmatrix_diag_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, _D, _D]),
     "sgp_elbo": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int,
                            _D, C.c_int, _D, _D, _D]),

@@ -613,6 +613,42 @@ def test_elbo_gradient_matches_finite_differences_of_hyperparameters():
     assert abs(g["noise"] - fd_s) <= 1e-5 * max(1.0, abs(fd_s)), (g["noise"], fd_s)
 
 
+def test_elbo_input_gradients_match_finite_differences():
+    """d elbo / d (data points) and d elbo / d (inducing points): sgp_elbo_grad_x against central
+    differences of the GPU elbo (Matern-5/2, stretched inputs: the terms read X / l and Z / l)."""
+    rng = np.random.default_rng(29)
+    Xm = np.asfortranarray(rng.standard_normal((2, 500)))
+    Zm = np.asfortranarray(rng.standard_normal((2, 40)))
+    y = rng.standard_normal(500)
+    v, l, s2 = 1.7, 0.8, 0.25
+    f = np.sqrt(v) * P.stretch(P.atomic(P.GP(P.Matern52Kernel()), P.GPC()), 1.0 / l)
+
+    def bound(Xa, Za):
+        return P.elbo(P.VFE(f(P.ColVecs(Za), 1e-4)), f(P.ColVecs(Xa), s2), y)
+
+    g = P.elbo_and_gradient(P.VFE(f(P.ColVecs(Zm), 1e-4)), f(P.ColVecs(Xm), s2), y, inputs=True)
+    specs = g["_specs"]
+    (gzz,) = g["zz_inputs"]
+    assert len(g["xz_inputs"]) == 2
+    (t,) = g["xz_terms"]
+    gx_x, gx_z = g["xz_inputs"][t["row_input"]], g["xz_inputs"][t["col_input"]]
+    assert gx_x.shape == Xm.shape and gx_z.shape == Zm.shape and gzz.shape == Zm.shape
+    dX, dZ = gx_x / l, (gx_z + gzz) / l
+    h = 1e-6
+    for (d, i) in [(0, 0), (1, 250), (0, 499)]:
+        Xp, Xn = Xm.copy(), Xm.copy()
+        Xp[d, i] += h
+        Xn[d, i] -= h
+        fd = (bound(Xp, Zm) - bound(Xn, Zm)) / (2 * h)
+        assert abs(dX[d, i] - fd) <= 2e-5 * max(1.0, abs(fd)), ("x", d, i, dX[d, i], fd)
+    for (d, j) in [(0, 0), (1, 20), (0, 39)]:
+        Zp, Zn = Zm.copy(), Zm.copy()
+        Zp[d, j] += h
+        Zn[d, j] -= h
+        fd = (bound(Xm, Zp) - bound(Xm, Zn)) / (2 * h)
+        assert abs(dZ[d, j] - fd) <= 2e-5 * max(1.0, abs(fd)), ("z", d, j, dZ[d, j], fd)
+
+
 # ---- ill-conditioned covariances: the panel solves must be as accurate as LAPACK's ---------------
 def _illcond_cases():
     import json
