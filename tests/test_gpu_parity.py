@@ -649,6 +649,43 @@ def test_elbo_input_gradients_match_finite_differences():
         assert abs(dZ[d, j] - fd) <= 2e-5 * max(1.0, abs(fd)), ("z", d, j, dZ[d, j], fd)
 
 
+@pytest.mark.parametrize("N,M", [(1, 1), (5, 2), (128, 128), (129, 3)])
+def test_gradients_at_tiny_and_tile_boundary_sizes(N, M):
+    """logpdf / elbo gradients where the 128-padding dominates: against finite differences."""
+    rng = np.random.default_rng(100 + N)
+    Xm = np.asfortranarray(rng.standard_normal((2, N)))
+    Zm = np.asfortranarray(rng.standard_normal((2, M)))
+    y = rng.standard_normal(N)
+    s2, h = 0.3, 1e-6
+
+    def model(v):
+        return np.sqrt(v) * P.atomic(P.GP(P.SEKernel()), P.GPC())
+
+    g = P.logpdf_and_gradient(model(1.3)(P.ColVecs(Xm), s2), y, inputs=True)
+    fd_v = (P.logpdf(model(1.3 + h)(P.ColVecs(Xm), s2), y) - P.logpdf(model(1.3 - h)(P.ColVecs(Xm), s2), y)) / (2 * h)
+    fd_s = (P.logpdf(model(1.3)(P.ColVecs(Xm), s2 + h), y) - P.logpdf(model(1.3)(P.ColVecs(Xm), s2 - h), y)) / (2 * h)
+    assert abs(g["terms"][0]["d_coef"] - fd_v) <= 1e-6 * max(1.0, abs(fd_v))
+    assert abs(g["noise"] - fd_s) <= 1e-6 * max(1.0, abs(fd_s))
+    Xp, Xn = Xm.copy(), Xm.copy()
+    Xp[1, N - 1] += h
+    Xn[1, N - 1] -= h
+    fd_x = (P.logpdf(model(1.3)(P.ColVecs(Xp), s2), y) - P.logpdf(model(1.3)(P.ColVecs(Xn), s2), y)) / (2 * h)
+    assert abs(g["inputs"][0][1, N - 1] - fd_x) <= 1e-6 * max(1.0, abs(fd_x))
+
+    def bound(v, s):
+        f = model(v)
+        return P.elbo(P.VFE(f(P.ColVecs(Zm), 1e-3)), f(P.ColVecs(Xm), s), y)
+
+    f = model(1.3)
+    ge = P.elbo_and_gradient(P.VFE(f(P.ColVecs(Zm), 1e-3)), f(P.ColVecs(Xm), s2), y)
+    assert abs(ge["elbo"] - bound(1.3, s2)) <= 1e-12 * max(1.0, abs(ge["elbo"]))
+    d_v = sum(t["d_coef"] for t in ge["zz_terms"] + ge["xz_terms"] + ge["xx_terms"])
+    fd_v = (bound(1.3 + h, s2) - bound(1.3 - h, s2)) / (2 * h)
+    fd_s = (bound(1.3, s2 + h) - bound(1.3, s2 - h)) / (2 * h)
+    assert abs(d_v - fd_v) <= 1e-5 * max(1.0, abs(fd_v)), (d_v, fd_v)
+    assert abs(ge["noise"] - fd_s) <= 1e-5 * max(1.0, abs(fd_s)), (ge["noise"], fd_s)
+
+
 # ---- ill-conditioned covariances: the panel solves must be as accurate as LAPACK's ---------------
 def _illcond_cases():
     import json
