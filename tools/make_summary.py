@@ -135,6 +135,7 @@ def main():
               ("gemm_sizes.log", "Isolated trailing-update launches by size and depth (`tools/gpu_gemm_sizes.py`)"),
               ("grad_time.log", "Reverse-mode gradients (`tools/gpu_grad_time.py`; host API incl. uploads)"),
               ("predict_time.log", "Prediction side (`tools/gpu_predict_time.py`)"),
+              ("misc_time.log", "Other host-API rows (`tools/gpu_misc_time.py`)"),
               ("illcond.log", "Ill-conditioned covariances against 60-digit values (`tools/gpu_illcond.py`)")]
     for name, title in extras:
         p = os.path.join(SRC, name)
