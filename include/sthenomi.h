@@ -185,11 +185,15 @@ int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, 
  * coef_t dk_t/dg; entries of other terms are set to 0.  Both outputs have spec->term_ptr[last] entries. */
 int sgp_kernelmatrix_diag_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
                                double* grad_inscale);
+/* Same, plus d (sum_i w_i var_i) / d (input points) per spec input (see sgp_logpdf_grad_x): non-zero
+ * only for diagonal terms that read two different inputs (e.g. var of f(a x) + f(b x)). */
+int sgp_kernelmatrix_diag_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
+                                 double* grad_inscale, double* const* grad_inputs);
 /* sgp_elbo_grad plus the gradient w.r.t. the input points (see sgp_logpdf_grad_x):
  * grad_inputs_zz[k] for zz->inputs[k] (inducing points, through K(z,z)) and grad_inputs_xz[k] for
  * xz->inputs[k] (data points on the row side, inducing points on the column side, through K(x,z)).
  * The inducing points appear in both tables: add the matching arrays.  The dependence of var(f, x)
- * on x is not included (it vanishes for stationary kernels read at one input). */
+ * on x goes through grad_var_x and sgp_kernelmatrix_diag_grad_x. */
 int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
                     const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
                     const double* z_noise, const double* y, double* elbo_out, double* grad_y,

@@ -1683,8 +1683,8 @@ extern "C" int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_c
 }
 
 // sum_i w[i] d var_i / d theta over the diagonal of `spec` (the blocks (I, I) kernelmatrix_diag reads)
-extern "C" int sgp_kernelmatrix_diag_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w,
-                                          double* grad_coef, double* grad_inscale) {
+static int diag_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
+                          double* grad_inscale, double* const* grad_inputs) {
   CHECK_ARG(ctx && spec && w && grad_coef && grad_inscale, "sgp_kernelmatrix_diag_grad: NULL argument");
   std::lock_guard<std::mutex> lk(ctx->mu);
   SGP_HIP(hipSetDevice(ctx->device));
@@ -1710,10 +1710,41 @@ extern "C" int sgp_kernelmatrix_diag_grad(sgp_ctx* ctx, const sgp_cov_spec* spec
     CHECK_RC(launch_diag_grad(dw.p + ds->row_off[I], ds->row_len[I], ds->d_terms + t0, t1 - t0, dgc.p + t0,
                               dgs.p + t0, s));
   }
+  std::vector<DevBuf> dgx(grad_inputs ? spec->n_inputs : 0);
+  if (grad_inputs) {
+    for (int k = 0; k < spec->n_inputs; ++k) {
+      size_t cnt = (size_t)std::max<long>(1, (long)ds->in_dim[k] * ds->in_n[k]);
+      CHECK_RC(dgx[k].alloc(cnt));
+      SGP_HIP(hipMemsetAsync(dgx[k].p, 0, sizeof(double) * cnt, s));
+    }
+    for (int I = 0; I < ds->nrb; ++I) {
+      int p = I * ds->ncb + I;
+      if (ds->row_len[I] == 0) continue;
+      for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t)
+        CHECK_RC(launch_diag_grad_inputs(dw.p + ds->row_off[I], ds->row_len[I], ds->h_terms[t],
+                                         dgx[ds->term_row_input[t]].p, dgx[ds->term_col_input[t]].p, s));
+    }
+  }
   SGP_HIP(hipStreamSynchronize(s));
   SGP_HIP(hipMemcpy(grad_coef, dgc.p, sizeof(double) * nt, hipMemcpyDeviceToHost));
   SGP_HIP(hipMemcpy(grad_inscale, dgs.p, sizeof(double) * nt, hipMemcpyDeviceToHost));
+  for (size_t k = 0; k < dgx.size(); ++k)
+    if (grad_inputs[k] && spec->inputs[k].n > 0)
+      SGP_HIP(hipMemcpy(grad_inputs[k], dgx[k].p, sizeof(double) * spec->inputs[k].dim * spec->inputs[k].n,
+                        hipMemcpyDeviceToHost));
   return 0;
+}
+
+extern "C" int sgp_kernelmatrix_diag_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w,
+                                          double* grad_coef, double* grad_inscale) {
+  return diag_grad_core(ctx, spec, w, grad_coef, grad_inscale, nullptr);
+}
+
+extern "C" int sgp_kernelmatrix_diag_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w,
+                                            double* grad_coef, double* grad_inscale,
+                                            double* const* grad_inputs) {
+  CHECK_ARG(grad_inputs != nullptr, "sgp_kernelmatrix_diag_grad_x: grad_inputs is NULL");
+  return diag_grad_core(ctx, spec, w, grad_coef, grad_inscale, grad_inputs);
 }
 
 extern "C" int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz,

@@ -511,4 +511,31 @@ int launch_grad_inputs(const double* Gm, long sr, long sc, const double* alpha, 
   return 0;
 }
 
+// d / d(input points) of sum_i w_i var_i for one diagonal term: the row input gets
+// +w_i coef rs_i cs_i kappa'(d2_i) 2 (xr_i - xc_i), the column input the negative (zero whenever the
+// term reads one input on both sides).  One thread per point; launches into one array are ordered
+// on the stream.
+__global__ void diag_grad_inputs_kernel(const double* w, long n, DevTerm T, double* gxr, double* gxc) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double d2 = 0.0;
+  for (int d = 0; d < T.dim; ++d) {
+    double df = T.xr[i * T.ldr + d] - T.xc[i * T.ldc + d];
+    d2 = fma(df, df, d2);
+  }
+  double c = 2.0 * w[i] * T.coef * (T.rs ? T.rs[i] : 1.0) * (T.cs ? T.cs[i] : 1.0) * kern_dd2(T.kind, d2, T.param);
+  for (int d = 0; d < T.dim; ++d) {
+    double df = T.xr[i * T.ldr + d] - T.xc[i * T.ldc + d];
+    gxr[i * T.dim + d] += c * df;
+    if (gxc != gxr) gxc[i * T.dim + d] -= c * df;
+  }
+}
+
+int launch_diag_grad_inputs(const double* w, long n, const DevTerm& T, double* gxr, double* gxc, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(diag_grad_inputs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, T, gxr, gxc);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 }  // namespace sgp

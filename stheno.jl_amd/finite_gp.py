@@ -12,7 +12,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .flatten import build_spec, zero_spec
+from .flatten import build_spec, chain_input_gradients, zero_spec
 from .gp import SthenoAbstractGP, mean_vector
 from .gppp import GPPP
 from .inputs import BlockData
@@ -234,8 +234,12 @@ def logpdf_and_gradient(fx, y, inputs=False):
                 if k is not None:
                     terms[k]["d_coef"] += float(gc[t])
                     terms[k]["d_inscale"] += float(gs[t])
+    # x: the same gradient mapped back through the model's input transformations onto the blocks of
+    # fx.x (one (D, n) array per block; blocks sharing one input object get their joint gradient in
+    # the first of them)
+    xb = chain_input_gradients(spec, gx)[0] if inputs else None
     return dict(logpdf=float(lp[0]), y=gy, mean=gm, noise=(gn if kind == _lib.NOISE_DIAG else float(gn[0])),
-                terms=terms, inputs=gx, _raw=(gc, gs), _spec=spec)
+                terms=terms, inputs=gx, x=xb, _raw=(gc, gs), _spec=spec)
 
 
 def _draw(rng, n, s):
@@ -468,11 +472,23 @@ def elbo_and_gradient(vfe, fx, y=None, inputs=False):
     else:
         _lib.check(lib.sgp_elbo_grad(*args), "sgp_elbo_grad")
     gcd, gsd = np.zeros(max(1, xx.n_terms)), np.zeros(max(1, xx.n_terms))
-    rc = lib.sgp_kernelmatrix_diag_grad(_ctx().handle, xx.ref(), _lib.dptr(gv), _lib.dptr(gcd), _lib.dptr(gsd))
+    gdx = None
+    if inputs:      # var(f, x) depends on x wherever a diagonal term reads two different views of x
+        gdx = [np.zeros(a.shape, order="F") for a in xx.inputs]
+        pd = (C.POINTER(C.c_double) * max(1, len(gdx)))(*[_lib.dptr(a) for a in gdx])
+        rc = lib.sgp_kernelmatrix_diag_grad_x(_ctx().handle, xx.ref(), _lib.dptr(gv), _lib.dptr(gcd), _lib.dptr(gsd), pd)
+    else:
+        rc = lib.sgp_kernelmatrix_diag_grad(_ctx().handle, xx.ref(), _lib.dptr(gv), _lib.dptr(gcd), _lib.dptr(gsd))
     _lib.check(rc, "sgp_kernelmatrix_diag_grad")
     nb = len(xx.row_len)
     xx_terms = [r for r in _term_records(xx, gcd, gsd, False) if r["I"] == r["J"]] if nb else []
-    return dict(elbo=float(out[0]), y=gy, mean=gm, noise=(gn if nk == _lib.NOISE_DIAG else float(gn[0])),
+    xb = zb = None
+    if inputs:   # chain rule back onto the blocks of fx.x and fz.x
+        zr, _ = chain_input_gradients(zz, gxz)
+        xr, zc = chain_input_gradients(xz, gxx)
+        xd, _ = chain_input_gradients(xx, gdx)
+        xb, zb = [a + b for a, b in zip(xr, xd)], [a + b for a, b in zip(zr, zc)]
+    return dict(elbo=float(out[0]), y=gy, mean=gm, noise=(gn if nk == _lib.NOISE_DIAG else float(gn[0])), x=xb, z=zb,
                 z_noise=(gzn if zk == _lib.NOISE_DIAG else float(gzn[0])), var=gv,
                 zz_terms=_term_records(zz, gcz, gsz, True), xz_terms=_term_records(xz, gcx, gsx, False),
                 xx_terms=xx_terms, zz_inputs=gxz, xz_inputs=gxx, _raw=dict(zz=(gcz, gsz), xz=(gcx, gsx), xx=(gcd, gsd)),

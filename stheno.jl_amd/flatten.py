@@ -30,10 +30,11 @@ from .inputs import BlockData, ColVecs, GPPPInput, as_matrix, blocks
 
 
 class _Path:
-    __slots__ = ("key", "atom", "c", "r", "X")
+    __slots__ = ("key", "atom", "c", "r", "X", "chain")
 
-    def __init__(self, key, atom, c, r, X):
-        self.key, self.atom, self.c, self.r, self.X = key, atom, c, r, X
+    def __init__(self, key, atom, c, r, X, chain=()):
+        # chain: the input warps applied on the way down, outermost first, as (warp, inputs before it)
+        self.key, self.atom, self.c, self.r, self.X, self.chain = key, atom, c, r, X, chain
 
 
 class _MatCache:
@@ -66,30 +67,30 @@ def block_list(f, x):
     return [(f, x)]
 
 
-def _paths(f, x, c, r, key, mat):
+def _paths(f, x, c, r, key, mat, chain=()):
     if isinstance(f, GPPP):  # a GPPP wrapped in atomic(...) (nested programmes, test gppp.jl:107-120)
         node, v = extract_components(f, x)
         if isinstance(node, _gp.DerivedGP) and node.args[0] == "cross":
             raise NotImplementedError("a nested GPPP must be indexed one process at a time")
-        return _paths(node, v, c, r, key, mat)
+        return _paths(node, v, c, r, key, mat, chain)
     if isinstance(f, _gp.AtomicGP):
         k2 = key + (id(f),)
         if isinstance(f.gp, _gp.GP):
-            return [_Path(k2, f, c, r, mat(x))]
-        return _paths(f.gp, x, c, r, k2, mat)
+            return [_Path(k2, f, c, r, mat(x), chain)]
+        return _paths(f.gp, x, c, r, k2, mat, chain)
     op = f.args[0]
     if op == "+":
-        return _paths(f.args[1], x, c, r, key, mat) + _paths(f.args[2], x, c, r, key, mat)
+        return _paths(f.args[1], x, c, r, key, mat, chain) + _paths(f.args[2], x, c, r, key, mat, chain)
     if op == "+known":
-        return _paths(f.args[2], x, c, r, key, mat)
+        return _paths(f.args[2], x, c, r, key, mat, chain)
     if op == "*":
         s = f.args[1]
         if _gp._is_real(s):
-            return _paths(f.args[2], x, c * float(s), r, key, mat)
+            return _paths(f.args[2], x, c * float(s), r, key, mat, chain)
         sx = _gp._map_points(s, x)
-        return _paths(f.args[2], x, c, sx if r is None else r * sx, key, mat)
+        return _paths(f.args[2], x, c, sx if r is None else r * sx, key, mat, chain)
     if op == "o":
-        return _paths(f.args[1], _gp.warp(f.args[2], x), c, r, key, mat)
+        return _paths(f.args[1], _gp.warp(f.args[2], x), c, r, key, mat, chain + ((f.args[2], x),))
     if op == "cross":
         raise ValueError("cross(...) can only appear at block level")
     raise ValueError(op)
@@ -102,7 +103,7 @@ def _merge_paths(ps):
         if k in index:
             index[k].c += p.c
         else:
-            q = _Path(p.key, p.atom, p.c, p.r, p.X)
+            q = _Path(p.key, p.atom, p.c, p.r, p.X, p.chain)
             index[k] = q
             out.append(q)
     return out
@@ -110,13 +111,16 @@ def _merge_paths(ps):
 
 class _InputTable:
     def __init__(self):
-        self.arrays, self.index = [], {}
+        self.arrays, self.index, self.origin = [], {}, []
 
-    def get(self, X, scale):
+    def get(self, X, scale, origin=None):
+        """origin = (side, block index, warp chain): where the points came from (for the chain rule
+        of input gradients); the first path that registers an array names it."""
         k = (id(X), float(scale))
         if k not in self.index:
             self.index[k] = len(self.arrays)
             self.arrays.append(X if scale == 1.0 else np.asfortranarray(scale * X))
+            self.origin.append(origin + (float(scale),) if origin is not None else None)
         return self.index[k]
 
 
@@ -146,7 +150,8 @@ def build_spec(f, x, f2=None, x2=None):
                     if p.X.shape[0] != q.X.shape[0]:
                         raise ValueError("input dimension mismatch between two views of one process")
                     for (kind, kc, param, s) in p.atom.gp.kernel.leaf_terms():
-                        ri, ci = table.get(p.X, s), table.get(q.X, s)
+                        ri = table.get(p.X, s, ("row", I, p.chain))
+                        ci = table.get(q.X, s, ("row" if symmetric else "col", J, q.chain))
                         k = (kind, param, ri, ci, id(p.r) if p.r is not None else None,
                              id(q.r) if q.r is not None else None)
                         if k in merged:
@@ -158,9 +163,62 @@ def build_spec(f, x, f2=None, x2=None):
                 pairs[(I, J)] = [tuple(merged[k]) for k in order]
     spec = _lib.Spec([len(v) for _, v in rows], [len(v) for _, v in cols], table.arrays, pairs, symmetric)
     spec._mat_keep = mat  # keep the source arrays alive (ids are identity keys)
+    spec.input_origin = table.origin   # per spec input: (side, block, warp chain, kernel input scale)
+    spec.block_shapes = ([_leaf_shape(v) for _, v in rows], [_leaf_shape(v) for _, v in cols])
     return spec, rows, cols
+
+
+def _leaf_shape(v):
+    while isinstance(v, GPPPInput):   # nested programmes index a process of the inner GPPP
+        v = v.x
+    return as_matrix(v).shape
 
 
 def zero_spec(n):
     """A spec with no terms: K == 0 exactly (used to feed an explicit covariance as dense noise)."""
     return _lib.Spec([n], [n], [], {}, True)
+
+
+# ---- chain rule of input gradients through the host-side transformations ------------------------
+def _warp_vjp(g, x_in, gout):
+    """Cotangent of the warp's input given the cotangent `gout` (dim_out x n) of its output."""
+    if isinstance(g, _gp.Stretch):
+        if np.ndim(g.l) == 0:
+            return float(g.l) * gout
+        return np.asarray(g.l, dtype=np.float64).T @ gout
+    if isinstance(g, _gp.Shift):
+        return gout
+    if isinstance(g, _gp.Select):
+        X = as_matrix(x_in)
+        gin = np.zeros(X.shape)
+        if isinstance(g.idx, (int, np.integer)):
+            gin[g.idx, :] += gout.reshape(-1)
+        else:
+            np.add.at(gin, np.asarray(g.idx), gout)
+        return gin
+    if isinstance(g, _gp.Periodic):
+        t = (2.0 * np.pi * g.f) * as_matrix(x_in)          # 1 x n; output rows are [cos t; sin t]
+        return (2.0 * np.pi * g.f) * (-np.sin(t) * gout[0:1, :] + np.cos(t) * gout[1:2, :])
+    raise NotImplementedError("input gradients through an arbitrary point-wise warp: supply its Jacobian yourself")
+
+
+def chain_input_gradients(spec, grads):
+    """Map gradients w.r.t. the spec inputs (the transformed points the terms read, as returned by
+    sgp_*_grad_x) back onto the blocks the spec was built from: the kernel's input scale
+    (ScaleTransform / with_lengthscale) and the Stretch / Select / Periodic / Shift warps of the
+    model are undone in reverse.  Returns (row_block_grads, col_block_grads): lists of (D, n) arrays
+    aligned with the blocks of x (and of x2 for a cross spec; for a symmetric spec the second list
+    is the first)."""
+    rshapes, cshapes = spec.block_shapes
+    rows = [np.zeros(sh) for sh in rshapes]
+    cols = rows if spec.symmetric else [np.zeros(sh) for sh in cshapes]
+    for k, g in enumerate(grads):
+        org = spec.input_origin[k]
+        if org is None or g is None:
+            continue
+        side, I, chain, scale = org
+        gg = scale * np.asarray(g, dtype=np.float64)
+        for (w, x_in) in reversed(chain):
+            gg = _warp_vjp(w, x_in, gg)
+        (rows if side == "row" else cols)[I] += gg.reshape((rows if side == "row" else cols)[I].shape)
+    return rows, cols

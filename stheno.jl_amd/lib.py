@@ -81,6 +81,7 @@ _SIGS = {
     "sgp_elbo_grad_x": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D, C.c_int,
                                   _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, C.POINTER(_D), C.POINTER(_D)]),
     "sgp_kernelmatrix_diag_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, _D, _D]),
+    "sgp_kernelmatrix_diag_grad_x": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, _D, _D, C.POINTER(_D)]),
     "sgp_elbo": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int,
                            _D, C.c_int, _D, _D, _D]),
     "sgp_sparse_posterior_create": (C.c_int, [_P, C.POINTER(sgp_cov_spec),
@@ -209,6 +210,7 @@ class Spec:
         self.col_len = np.asarray(col_len, dtype=np.int64)
         self.N = int(self.row_len.sum())
         self.M = int(self.col_len.sum())
+        self.symmetric = bool(symmetric)
         self._keep = []
         self.inputs = []
         for x in inputs:

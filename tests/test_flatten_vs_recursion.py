@@ -144,3 +144,48 @@ def test_gpc_mismatch_is_rejected():
         P.build_spec(a["f1"], np.arange(3.0), b["f1"], np.arange(3.0))
     with pytest.raises(ValueError):
         a["f1"] * a["f2"]
+
+
+def test_chain_rule_of_input_gradients_through_warps_and_kernel_scales():
+    """flatten.chain_input_gradients (the host half of the input-gradient path): for a model whose
+    terms read stretched / selected / periodic / shifted / length-scaled views of the block inputs,
+    the chained gradient of Phi(x) = sum_k <W_k, spec.inputs[k](x)> must match central differences
+    (Phi is linear in the spec inputs, so its gradient w.r.t. them is W_k itself)."""
+    from stheno_jl_amd.flatten import chain_input_gradients
+    rng = np.random.default_rng(31)
+    gpc = P.GPC()
+    a = P.atomic(P.GP(P.with_lengthscale(P.SEKernel(), 0.7)), gpc)
+    b = P.atomic(P.GP(P.Matern52Kernel()), gpc)
+    f1 = P.stretch(a, 1.9)                                        # 3-D inputs, scalar stretch + kernel scale
+    f2 = P.stretch(P.shift(a, np.array([0.3, -0.2, 0.1])), np.array([0.5, 2.0, 1.5]))   # diag stretch o shift
+    f3 = P.periodic(b, 0.8)                                       # 1-D -> [cos, sin]
+    f4 = P.select(P.stretch(a, 0.9), [2, 0, 1])                   # row permutation of a 3-D input
+    F = P.GPPP({"f1": f1, "f2": f2, "f3": f3, "f4": f4, "f5": f1 + f4}, gpc)
+    xs = [P.ColVecs(rng.standard_normal((3, 5))), P.ColVecs(rng.standard_normal((3, 4))), rng.standard_normal(6),
+          P.ColVecs(rng.standard_normal((3, 3))), P.ColVecs(rng.standard_normal((3, 4)))]
+    names = ["f1", "f2", "f3", "f4", "f5"]
+
+    def spec_of(mats):
+        blocks = [P.GPPPInput(k, (P.ColVecs(m) if m.shape[0] == 3 else m.reshape(-1))) for k, m in zip(names, mats)]
+        return P.build_spec(F, P.BlockData(blocks))[0]
+
+    mats = [np.array(P.inputs.as_matrix(x), dtype=float) for x in xs]
+    spec = spec_of(mats)
+    W = [rng.standard_normal(np.asarray(v).shape) for v in spec.inputs]
+
+    def phi(ms):
+        sp = spec_of(ms)
+        assert len(sp.inputs) == len(W)
+        return sum(float((w * np.asarray(v)).sum()) for w, v in zip(W, sp.inputs))
+
+    rows, cols = chain_input_gradients(spec, W)
+    assert cols is rows and len(rows) == len(xs)
+    h = 1e-6
+    for I, m in enumerate(mats):
+        assert rows[I].shape == m.shape
+        for (d, i) in itertools.product(range(m.shape[0]), range(m.shape[1])):
+            mp_, mn_ = [q.copy() for q in mats], [q.copy() for q in mats]
+            mp_[I][d, i] += h
+            mn_[I][d, i] -= h
+            fd = (phi(mp_) - phi(mn_)) / (2 * h)
+            assert abs(rows[I][d, i] - fd) <= 1e-7 * max(1.0, abs(fd)), (I, d, i, rows[I][d, i], fd)

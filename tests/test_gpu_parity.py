@@ -686,6 +686,57 @@ def test_gradients_at_tiny_and_tile_boundary_sizes(N, M):
     assert abs(ge["noise"] - fd_s) <= 1e-5 * max(1.0, abs(fd_s)), (ge["noise"], fd_s)
 
 
+def test_input_gradients_chain_through_model_transformations():
+    """g["x"] / g["z"]: gradients w.r.t. the user's own inputs (host chain rule through kernel
+    length-scales, stretch, periodic, select over the device gradient), against central
+    differences of the GPU logpdf / elbo."""
+    rng = np.random.default_rng(37)
+    gpc = P.GPC()
+    a = P.atomic(P.GP(P.with_lengthscale(P.Matern52Kernel(), 0.7)), gpc)
+    b = P.atomic(P.GP(P.SEKernel()), gpc)
+    F = P.GPPP({"f1": P.stretch(a, np.array([0.5, 2.0])), "f2": P.periodic(b, 0.6),
+                "f3": P.stretch(a, 1.3) + P.select(P.stretch(a, 0.8), [1, 0])}, gpc)
+    mats = [rng.standard_normal((2, 60)), rng.standard_normal((1, 45)), rng.standard_normal((2, 50))]
+    names = ["f1", "f2", "f3"]
+
+    def data(ms):
+        return P.BlockData([P.GPPPInput(k, P.ColVecs(m) if m.shape[0] == 2 else m.reshape(-1))
+                            for k, m in zip(names, ms)])
+
+    N = sum(m.shape[1] for m in mats)
+    y = rng.standard_normal(N)
+    g = P.logpdf_and_gradient(F(data(mats), 0.2), y, inputs=True)
+    h = 1e-6
+    for I, (d, i) in [(0, (1, 7)), (1, (0, 30)), (2, (0, 49)), (2, (1, 0))]:
+        mp_, mn_ = [q.copy() for q in mats], [q.copy() for q in mats]
+        mp_[I][d, i] += h
+        mn_[I][d, i] -= h
+        fd = (P.logpdf(F(data(mp_), 0.2), y) - P.logpdf(F(data(mn_), 0.2), y)) / (2 * h)
+        assert abs(g["x"][I][d, i] - fd) <= 2e-5 * max(1.0, abs(fd)), (I, d, i, g["x"][I][d, i], fd)
+    # elbo: inducing points on f1 and f3
+    zm = [rng.standard_normal((2, 12)), rng.standard_normal((2, 9))]
+
+    def zdata(zs):
+        return P.BlockData([P.GPPPInput("f1", P.ColVecs(zs[0])), P.GPPPInput("f3", P.ColVecs(zs[1]))])
+
+    def bound(ms, zs):
+        return P.elbo(P.VFE(F(zdata(zs), 1e-4)), F(data(ms), 0.2), y)
+
+    ge = P.elbo_and_gradient(P.VFE(F(zdata(zm), 1e-4)), F(data(mats), 0.2), y, inputs=True)
+    for J, (d, j) in [(0, (0, 3)), (1, (1, 8))]:
+        zp, zn = [q.copy() for q in zm], [q.copy() for q in zm]
+        zp[J][d, j] += h
+        zn[J][d, j] -= h
+        fd = (bound(mats, zp) - bound(mats, zn)) / (2 * h)
+        assert abs(ge["z"][J][d, j] - fd) <= 5e-5 * max(1.0, abs(fd)), ("z", J, d, j, ge["z"][J][d, j], fd)
+    for I, (d, i) in [(0, (0, 0)), (1, (0, 10)), (2, (1, 25))]:
+        mp_, mn_ = [q.copy() for q in mats], [q.copy() for q in mats]
+        mp_[I][d, i] += h
+        mn_[I][d, i] -= h
+        fd = (bound(mp_, zm) - bound(mn_, zm)) / (2 * h)
+        assert abs(ge["x"][I][d, i] - fd) <= 5e-5 * max(1.0, abs(fd)), ("x", I, d, i, ge["x"][I][d, i], fd)
+
+
 # ---- ill-conditioned covariances: the panel solves must be as accurate as LAPACK's ---------------
 def _illcond_cases():
     import json
