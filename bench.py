@@ -214,7 +214,7 @@ def main():
         upd_ms, n_launch, upd_flops = timings[3], int(timings[4]), timings[5]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
         roofline = {
-            "kernel": "sgp::gemm_nt_dma_kernel (fp64 MFMA trailing update of the blocked Cholesky, v_mfma_f64_4x4x4_4b_f64)",
+            "kernel": "sgp::gemm_nt_dma_kernel<1> (fp64 MFMA trailing update of the blocked Cholesky, v_mfma_f64_4x4x4_4b_f64; <0> = the same code in its auxiliary uses)",
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
             "launches": n_launch, "avg_launch_ms": upd_ms / max(1, n_launch),

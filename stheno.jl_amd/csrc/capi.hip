@@ -393,14 +393,14 @@ static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long
     SGP_HIP(hipEventCreate(&e0));
     SGP_HIP(hipEventCreate(&e1));
     SGP_HIP(hipEventRecord(e0, s));
-    CHECK_RC(launch_gemm_nt(P, ld, P, ld, C, ld, M, Nc, K, -1.0, 1.0, 0, 0, 0, s));
+    CHECK_RC(launch_gemm_nt_update(P, ld, C, ld, M, Nc, K, s));
     SGP_HIP(hipEventRecord(e1, s));
     ctx->ev.push_back(e0);
     ctx->ev.push_back(e1);
     ctx->ev_flops.push_back(update_flops(M, Nc, K));
     return 0;
   }
-  return launch_gemm_nt(P, ld, P, ld, C, ld, M, Nc, K, -1.0, 1.0, 0, 0, 0, s);
+  return launch_gemm_nt_update(P, ld, C, ld, M, Nc, K, s);
 }
 
 // Two-level right-looking Cholesky of the bordered matrix with one-panel look-ahead:
@@ -1856,7 +1856,7 @@ extern "C" int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   const double* A = d_P + (c0 - p_row0);  // panel rows c0.. (global)
   // d_C column 0 == global column c0; rows are global
-  CHECK_RC(launch_gemm_nt(A, ldp, A, ldp, d_C + c0, ldc, m_tot - c0, nc, w, -1.0, 1.0, 0, 0, 0, s));
+  CHECK_RC(launch_gemm_nt_update(A, ldp, d_C + c0, ldc, m_tot - c0, nc, w, s));
   return 0;
 }
 
@@ -1927,7 +1927,10 @@ extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int
   set_gemm_variant((lower_only & 2) ? 1 : 0);  // bench-only: bit 1 = register-staged baseline kernel
   lower_only &= 1;
   for (int i = 0; i < iters; ++i)
-    CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, 0, 0, s));
+    if (lower_only)
+      CHECK_RC(launch_gemm_nt_update(A.p, m, C.p, m, m, n, k, s));  // the production trailing-update symbol
+    else
+      CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, NOMASK, 0, 0, s));
   set_gemm_variant(0);
   SGP_HIP(hipEventRecord(e1, s));
   SGP_HIP(hipEventSynchronize(e1));

@@ -90,6 +90,7 @@ int launch_mirror_lower(double* K, long ld, long N, hipStream_t s);
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                    long M, long Nc, long K, double alpha, double beta, long mask_off,
                    int kcap_mode, long kcap_off, hipStream_t s);
+int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, hipStream_t s);
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,
                        double* C, long ldc, long M, long Nc, long K, double alpha, double beta,
                        hipStream_t s);

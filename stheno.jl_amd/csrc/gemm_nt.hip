@@ -115,6 +115,10 @@ __device__ __forceinline__ bool tile_of_block(long n_tr, long n_tc, long mask_of
 // fetches are explicit ds_read_b64 (256 B/clk -- hipcc fuses plain loads into ds_read2_b64 at
 // half that rate).  Measured 57 TF/s on a 32768^2 x 1024 lower update (profiles/).
 // ---------------------------------------------------------------------------------------
+// TAG only changes the symbol: <1> = the outer trailing updates of the blocked Cholesky (the launches
+// bench.py times and the roofline line is about), <0> = every other use (inner K = 128 updates,
+// solves' updates, Gram / inverse / L Z products), so that rocprofv3 --stats lists them apart.
+template <int TAG>
 __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, long lda,
                                                              const double* B, long ldb, double* C,
                                                              long ldc, long K, double alpha,
@@ -409,8 +413,24 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
     hipLaunchKernelGGL((gemm_nt_reg_kernel<false>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
                        beta, mask_off, kcap_off, n_tr, n_tc);
   else
-    hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
+    hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
                        mask_off, n_tr, n_tc, 0L, (const double*)C, ldc, 0);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// The outer trailing update C[lower] -= P P' (K = outer panel width): same kernel under its own symbol.
+int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, hipStream_t s) {
+  if (M <= 0 || Nc <= 0) return 0;
+  if (M % TILE || Nc % TILE || K % KB) {
+    set_error("gemm_nt_update: M, Nc must be multiples of 128 and K of 16");
+    return -1;
+  }
+  if (g_gemm_variant == 1) return launch_gemm_nt(P, ldp, P, ldp, C, ldc, M, Nc, K, -1.0, 1.0, 0, 0, 0, s);
+  long n_tr = M / TILE, n_tc = Nc / TILE;
+  long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc));
+  hipLaunchKernelGGL(gemm_nt_dma_kernel<1>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, P, ldp, C, ldc, K,
+                     -1.0, 1.0, 0L, n_tr, n_tc, 0L, (const double*)C, ldc, 0);
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -429,7 +449,7 @@ int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, con
   long n_tr = M / TILE, n_tc = Nc / TILE;
   long groups = ((n_tr + 7) / 8 + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * n_tc * 8));
-  hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
+  hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
                      -(1L << 40), n_tr, n_tc, 0L, Cin, ldcin, 0);
   SGP_HIP(hipGetLastError());
   return 0;
@@ -445,7 +465,7 @@ int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, h
   }
   long n_t = n / TILE;
   long per_xcd = tri_ids_per_xcd(tri_shape(n_t, n_t));
-  hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
+  hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
                      1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 1);
   SGP_HIP(hipGetLastError());
   return 0;
@@ -464,7 +484,7 @@ int launch_gemm_nt_lz(const double* L, long ldl, const double* Zt, long ldz, dou
   }
   long n_tr = n / TILE, n_tc = ns / TILE;
   long groups = ((n_tr + 7) / 8 + 7) / 8;
-  hipLaunchKernelGGL(gemm_nt_dma_kernel, dim3((unsigned)(groups * 8 * n_tc * 8)), dim3(512), 0, s, L, ldl, Zt, ldz, C,
+  hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(groups * 8 * n_tc * 8)), dim3(512), 0, s, L, ldl, Zt, ldz, C,
                      ldc, n, 1.0, beta, -(1L << 40), n_tr, n_tc, 0L, (const double*)C, ldc, 2);
   SGP_HIP(hipGetLastError());
   return 0;
@@ -485,7 +505,7 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
   long mask_off = lower_only ? 0 : -(1L << 40);
   long per_xcd = lower_only ? tri_ids_per_xcd(tri_shape(n_tr, n_tc)) : groups * 8 * n_tc;
   dim3 grid((unsigned)(per_xcd * 8), (unsigned)nsplit);
-  hipLaunchKernelGGL(gemm_nt_dma_kernel, grid, dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc, K / nsplit, 1.0,
+  hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, grid, dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc, K / nsplit, 1.0,
                      0.0, mask_off, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 0);
   SGP_HIP(hipGetLastError());
   return 0;

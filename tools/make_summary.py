@@ -77,17 +77,21 @@ def main():
             lines += ["", f"## rocprofv3 --kernel-trace --stats of `bench.py` ({tag}): top kernels", "",
                       "| kernel | calls | total ms | avg us | % |", "|---|---|---|---|---|"]
             for rr in rows[:6]:
-                lines.append(f"| `{rr['Name'].split('(')[0]}` | {rr['Calls']} | {float(rr['TotalDurationNs'])/1e6:.1f} | "
+                lines.append(f"| `{rr['Name'].split('(')[0].replace('void ', '')}` | {rr['Calls']} | {float(rr['TotalDurationNs'])/1e6:.1f} | "
                              f"{float(rr['AverageNs'])/1e3:.1f} | {float(rr['Percentage']):.2f} |")
             jb = jload(f"prof_{tag}_bench.json")
             if jb and jb.get("roofline"):
                 lines.append("")
+                upd = [rr for rr in rows if "gemm_nt_dma_kernel<1>" in rr["Name"]]
+                agree = ""
+                if upd:
+                    agree = (f"  rocprof's average for `gemm_nt_dma_kernel<1>` (the trailing updates only, {upd[0]['Calls']} calls over "
+                             f"all steps of the run): {float(upd[0]['AverageNs'])/1e6:.2f} ms.")
                 lines.append(f"Same run, bench's own HIP-event figure: {jb['roofline']['achieved']:.1f} TFLOP/s over "
-                             f"{jb['roofline']['launches']} trailing updates (avg {jb['roofline']['avg_launch_ms']:.2f} ms); "
-                             f"the kernel-trace average above also contains the many small inner-update launches "
-                             f"of the same kernel, and kernels of the two look-ahead streams overlap in time "
-                             f"(sum of kernel time > wall time; the panel kernels' averages include waiting for a CU slot, "
-                             f"see the stream-occupancy section).")
+                             f"{jb['roofline']['launches']} trailing updates (avg {jb['roofline']['avg_launch_ms']:.2f} ms)." + agree +
+                             f"  `gemm_nt_dma_kernel<0>` is the same code in its auxiliary uses (inner K = 128 updates etc.); "
+                             f"kernels of the two look-ahead streams overlap in time (sum of kernel time > wall time; the panel "
+                             f"kernels' averages include waiting for a CU slot, see the stream-occupancy section).")
     # PMC on the representative launch
     try:
         f, w, sq, tcc = pmc("FETCH_SIZE"), pmc("WRITE_SIZE"), pmc("SQ"), pmc("TCC")
