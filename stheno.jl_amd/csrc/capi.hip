@@ -933,18 +933,31 @@ struct sgp_post {
   double* d_wall = nullptr; // inverse 16x16 diagonal blocks (INVD_STRIDE per 128-block)
 };
 
-// rows <- rows * L^-T for `nrows` (multiple of 128) bordered rows stored at R (ld = ldr),
-// against the factor L (ld = ldl) with its stored inverse 16x16 diagonal blocks.  Right-looking.
+// rows <- rows * L^-T for `nrows` (multiple of 128) rows stored at R (ld = ldr), against the factor L
+// (ld = ldl) with its stored inverse 16x16 diagonal blocks.  Blocked left-looking: a 512-column
+// block first receives everything left of it in ONE deep GEMM (K = its column offset: the efficient
+// shape of the MFMA kernel), then is solved in place in 128-column steps with K = 128 updates inside
+// the block only.  Same flops as the right-looking sweep, a fraction of its C-tile traffic.
 static int row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl,
                     const double* d_invall, long n_pad, hipStream_t s) {
-  for (long k = 0; k < n_pad; k += TILE) {
-    double* Rk = R + k * ldr;
-    CHECK_RC(launch_panel_solve(Rk, ldr, nrows, L + k + k * ldl, ldl, d_invall + (k / TILE) * INVD_STRIDE, 256, 16,
-                                s));
-    long rest = n_pad - k - TILE;
-    if (rest > 0)
-      CHECK_RC(launch_gemm_nt(Rk, ldr, L + (k + TILE) + k * ldl, ldl, R + (k + TILE) * ldr, ldr, nrows,
-                              rest, TILE, -1.0, 1.0, NOMASK, 0, 0, s));
+  const long WB = 4 * TILE;
+  for (long c0 = 0; c0 < n_pad; c0 += WB) {
+    long wb = std::min(WB, n_pad - c0);
+    // (with a leading dimension beyond ~64k rows every operand column sits in its own page and a deep
+    // contraction thrashes the TLB: fall back to 512-column slices there)
+    const long KC = (ldr > 65536 || ldl > 65536) ? WB : c0;
+    for (long k0 = 0; k0 < c0; k0 += KC)
+      CHECK_RC(launch_gemm_nt(R + k0 * ldr, ldr, L + c0 + k0 * ldl, ldl, R + c0 * ldr, ldr, nrows, wb,
+                              std::min(KC, c0 - k0), -1.0, 1.0, NOMASK, 0, 0, s));
+    for (long k = c0; k < c0 + wb; k += TILE) {
+      double* Rk = R + k * ldr;
+      CHECK_RC(launch_panel_solve(Rk, ldr, nrows, L + k + k * ldl, ldl, d_invall + (k / TILE) * INVD_STRIDE, 256, 16,
+                                  s));
+      long rest = c0 + wb - k - TILE;
+      if (rest > 0)
+        CHECK_RC(launch_gemm_nt(Rk, ldr, L + (k + TILE) + k * ldl, ldl, R + (k + TILE) * ldr, ldr, nrows, rest, TILE,
+                                -1.0, 1.0, NOMASK, 0, 0, s));
+    }
   }
   return 0;
 }
@@ -1304,6 +1317,10 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
     SGP_HIP(hipMalloc(&keep->d_wz, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
     d_wz = keep->d_wz;
   }
+  // The N rows K(x,z) Lambda ride along as bordered rows of the factorisation (K = 512 updates).
+  // Factoring Kzz alone and solving the rows with the deep-K row_trsm was tried: with a leading
+  // dimension of 270 000 doubles every operand column lies in its own 2 MiB page and a K = 3584 GEMM
+  // thrashes the TLB (N = 262 144, M = 4096: 225 -> 700 ms).
   CHECK_RC(chol_bordered(ctx, dA.p, ld, m_pad, ld, d_wz, s));
   int info = fetch_info(ctx, s);
   if (info > 0) {
@@ -1470,14 +1487,14 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
                      ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_o);
   SGP_HIP(hipGetLastError());
   // ---- factor 1: [Kzz + Sigma_z ; K(x,z) Lambda ; I]  ->  Lz, R = A', J = Lz^-T
+  double* Rw = dA.p + m_pad;
+  double* Jm = dA.p + m_pad + n_rows;
   CHECK_RC(assemble(gz.ds, dA.p, ld, 0, m_pad / TILE, 0, m_pad / TILE, 1, ndz.kind, ndz.sigma2, ndz.diag.p, s));
   CHECK_RC(launch_fill_pad(dA.p, ld, M, m_pad, 0, m_pad, ld, 0, s));
   if (n_rows > N)
-    SGP_HIP(hipMemset2DAsync(dA.p + m_pad + N, sizeof(double) * ld, 0, sizeof(double) * (n_rows - N), (size_t)m_pad,
-                             s));
-  CHECK_RC(assemble(gx.ds, dA.p + m_pad, ld, 0, n_rows / TILE, 0, m_pad / TILE, 0, -1, 0.0, nullptr, s));
-  CHECK_RC(launch_scale_rows(dA.p + m_pad, ld, N, m_pad, drsig.p, s));
-  double* Jm = dA.p + m_pad + n_rows;
+    SGP_HIP(hipMemset2DAsync(Rw + N, sizeof(double) * ld, 0, sizeof(double) * (n_rows - N), (size_t)m_pad, s));
+  CHECK_RC(assemble(gx.ds, Rw, ld, 0, n_rows / TILE, 0, m_pad / TILE, 0, -1, 0.0, nullptr, s));
+  CHECK_RC(launch_scale_rows(Rw, ld, N, m_pad, drsig.p, s));
   SGP_HIP(hipMemset2DAsync(Jm, sizeof(double) * ld, 0, sizeof(double) * m_pad, (size_t)m_pad, s));
   hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, Jm, ld, m_pad);
   SGP_HIP(hipGetLastError());
@@ -1487,7 +1504,7 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
     set_error("vfe: Kzz + Sigma_z is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
   }
-  const double* R = dA.p + m_pad;
+  const double* R = Rw;
   hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, R, ld, n_rows, ddelta.p, dots.p, sq.p);
   SGP_HIP(hipGetLastError());
   CHECK_RC(launch_sum_array(sq.p, m_pad, ctx->d_scal + 4, s));
