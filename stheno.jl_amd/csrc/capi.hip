@@ -1206,7 +1206,7 @@ __global__ void elbo_scalars_kernel(const double* y, const double* mean, const d
 // per column j of the bordered rows R (nrows x ncols): dots[j] = sum_n R[n, j] delta[n],
 // sq[j] = sum_n R[n, j]^2
 __global__ void coldot_kernel(const double* R, long ld, long nrows, const double* delta,
-                              double* dots, double* sq) {
+                              double* dots, double* sq, int accumulate = 0) {
   __shared__ double sh[2][4];
   const long j = blockIdx.x;
   const double* col = R + j * ld;
@@ -1227,8 +1227,10 @@ __global__ void coldot_kernel(const double* R, long ld, long nrows, const double
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    dots[j] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-    sq[j] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    double a0 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    double b0 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    dots[j] = accumulate ? dots[j] + a0 : a0;
+    sq[j] = accumulate ? sq[j] + b0 : b0;
   }
 }
 __global__ void add_identity_kernel(double* G, long ld, long n) {
@@ -1261,6 +1263,133 @@ extern "C" int sgp_sparse_posterior_destroy(sgp_sparse_post* p) {
   return 0;
 }
 
+// The same pipeline for very many data points: K(z,z) is factored on its own and
+// the rows K(x,z) Lambda go through in chunks of rows, each chunk a buffer of its own
+// (leading dimension = chunk rows, so operand columns share pages and the TLB survives deep
+// contractions): assemble -> scale -> blocked left-looking row solve (deep-K GEMMs against Lz) ->
+// A delta / |A|^2 partials -> transpose -> split-K Gram partial, accumulated into G in chunk order
+// (deterministic).  Nothing of size N x M is ever resident.
+// Measured (N = 262 144, M = 4096): 223 ms monolithic vs 230-245 ms chunked (16k .. 128k rows per
+// chunk) -- no faster, but the footprint falls from 2 x 8 N M bytes to two chunk buffers, so the
+// chunked path takes over where the monolithic buffers would not be reasonable (N > 524 288 rows by
+// default).  SGP_VFE_CHUNK=<rows> forces chunks of that many rows for any larger N (tests).
+constexpr long VFE_CHUNK_ROWS = 131072;
+constexpr long VFE_CHUNK_ABOVE = 524288;
+static void vfe_chunking(long* chunk_rows, long* above) {
+  const char* e = getenv("SGP_VFE_CHUNK");
+  long v = e ? atol(e) / TILE * TILE : 0;
+  *chunk_rows = v >= TILE ? v : VFE_CHUNK_ROWS;
+  *above = v >= TILE ? v : VFE_CHUNK_ABOVE;
+}
+
+static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* dx, const double* var_x,
+                                const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                                const double* z_noise, const double* y, double* h, sgp_sparse_post* keep) {
+  const long M = dz->N, N = dx->N;
+  const long m_pad = rup(M, TILE), n_rows = rup(N, TILE);
+  long CH, ch_above;
+  vfe_chunking(&CH, &ch_above);
+  hipStream_t s = ctx->stream;
+  DevBuf dLz_local, dinv_local, dR, dAt, dPart, dy, dmean, dvar, ddelta, drsig, dots, sq, dG_local;
+  NoiseDev ndx, ndz;
+  CHECK_RC(dy.upload(y, N));
+  if (mean_x) CHECK_RC(dmean.upload(mean_x, N));
+  if (var_x) CHECK_RC(dvar.upload(var_x, N));
+  CHECK_RC(upload_noise(ndx, noise_kind, noise_x, N));
+  CHECK_RC(upload_noise(ndz, z_noise_kind, z_noise, M));
+  CHECK_RC(ddelta.alloc(n_rows));
+  CHECK_RC(drsig.alloc(n_rows));
+  CHECK_RC(dots.alloc(m_pad));
+  CHECK_RC(sq.alloc(m_pad));
+  double* d_o = ctx->d_scal + 1;
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  SGP_HIP(hipMemsetAsync(ddelta.p, 0, sizeof(double) * n_rows, s));
+  SGP_HIP(hipMemsetAsync(drsig.p, 0, sizeof(double) * n_rows, s));
+  hipLaunchKernelGGL(elbo_scalars_kernel, dim3(1), dim3(256), 0, s, dy.p, mean_x ? dmean.p : nullptr,
+                     var_x ? dvar.p : nullptr, ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_o);
+  SGP_HIP(hipGetLastError());
+  // ---- Lz
+  double* dLz = nullptr;
+  double* d_wz = nullptr;
+  if (keep) {
+    SGP_HIP(hipMalloc(&keep->dLz, sizeof(double) * m_pad * m_pad));
+    SGP_HIP(hipMalloc(&keep->d_wz, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
+    dLz = keep->dLz;
+    d_wz = keep->d_wz;
+  } else {
+    CHECK_RC(dLz_local.alloc((size_t)m_pad * m_pad));
+    CHECK_RC(dinv_local.alloc((size_t)(m_pad / TILE) * INVD_STRIDE));
+    dLz = dLz_local.p;
+    d_wz = dinv_local.p;
+  }
+  int nkz = ndz.kind == SGP_NOISE_DENSE ? -1 : ndz.kind;
+  CHECK_RC(assemble(dz, dLz, m_pad, 0, m_pad / TILE, 0, m_pad / TILE, 1, nkz, ndz.sigma2, ndz.diag.p, s));
+  if (ndz.kind == SGP_NOISE_DENSE) CHECK_RC(launch_add_dense(dLz, m_pad, ndz.dense.p, M, M, 1, s));
+  CHECK_RC(launch_fill_pad(dLz, m_pad, M, m_pad, 0, m_pad, m_pad, 0, s));
+  CHECK_RC(chol_bordered(ctx, dLz, m_pad, m_pad, m_pad, d_wz, s));
+  int info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("vfe: Kzz + Sigma_z is not positive definite (leading minor " + std::to_string(info) + ")");
+    return info;
+  }
+  // ---- G accumulator
+  long ldg = m_pad + TILE;
+  double* dG = nullptr;
+  if (keep) {
+    SGP_HIP(hipMalloc(&keep->dG, sizeof(double) * ldg * m_pad));
+    SGP_HIP(hipMalloc(&keep->d_wg, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
+    dG = keep->dG;
+  } else {
+    CHECK_RC(dG_local.alloc((size_t)ldg * m_pad));
+    dG = dG_local.p;
+  }
+  SGP_HIP(hipMemsetAsync(dG, 0, sizeof(double) * ldg * m_pad, s));
+  const int nsplit = 4;
+  const long stride = ldg * m_pad;
+  CHECK_RC(dR.alloc((size_t)CH * m_pad));
+  CHECK_RC(dAt.alloc((size_t)m_pad * CH));
+  CHECK_RC(dPart.alloc((size_t)nsplit * stride));
+  // ---- row chunks
+  for (long r0 = 0; r0 < n_rows; r0 += CH) {
+    const long ch = std::min(CH, n_rows - r0);            // rows of this chunk (multiple of 128)
+    const long nv = std::max<long>(0, std::min(N - r0, ch));  // of which real data points
+    SGP_HIP(hipMemsetAsync(dR.p, 0, sizeof(double) * ch * m_pad, s));
+    // global row r of K(x,z) lands at dR[(r - r0) + c * ch]
+    CHECK_RC(assemble(dx, dR.p - r0, ch, r0 / TILE, (r0 + ch) / TILE, 0, m_pad / TILE, 0, -1, 0.0, nullptr, s));
+    CHECK_RC(launch_scale_rows(dR.p, ch, nv, m_pad, drsig.p + r0, s));
+    CHECK_RC(row_trsm(ctx, dR.p, ch, ch, dLz, m_pad, d_wz, m_pad, s));
+    hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, dR.p, ch, ch, ddelta.p + r0, dots.p, sq.p,
+                       r0 > 0 ? 1 : 0);
+    SGP_HIP(hipGetLastError());
+    CHECK_RC(launch_transpose_add(dR.p, ch, ch, m_pad, dAt.p, m_pad, nullptr, s));
+    CHECK_RC(launch_gemm_nt_splitk(dAt.p, m_pad, dAt.p, m_pad, dPart.p, ldg, m_pad, m_pad, ch, nsplit, stride, 1, s));
+    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, r0 > 0 ? 1.0 : 0.0, 1, s));
+  }
+  CHECK_RC(launch_sum_array(sq.p, m_pad, ctx->d_scal + 4, s));
+  hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg, m_pad);
+  hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg, m_pad, dots.p,
+                     m_pad);
+  SGP_HIP(hipGetLastError());
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  CHECK_RC(chol_bordered(ctx, dG, ldg, m_pad, ldg, keep ? keep->d_wg : nullptr, s));
+  CHECK_RC(launch_sum_array(ctx->d_slots, m_pad / TILE, ctx->d_scal + 5, s));
+  CHECK_RC(launch_rowsumsq(dG + m_pad, ldg, m_pad, 1, ctx->d_scal + 6, 0, s));
+  SGP_HIP(hipMemcpyAsync(h, ctx->d_scal + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
+  info = fetch_info(ctx, s);
+  if (info > 0) {
+    set_error("vfe: A A' + I is not positive definite (leading minor " + std::to_string(info) + ")");
+    return info;
+  }
+  if (keep) {
+    keep->ctx = ctx;
+    keep->M = M;
+    keep->m_pad = m_pad;
+    keep->ldg = ldg;
+  }
+  SGP_HIP(hipStreamSynchronize(s));  // chunk buffers are freed at scope exit
+  return 0;
+}
+
 // shared VFE pipeline.  Returns elbo terms in h[0..5]:
 //  h[0]=sum log s2, h[1]=delta'delta, h[2]=sum var/s2, h[3]=|A|_F^2, h[4]=logdet Le, h[5]=|Le^-1 A delta|^2
 static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
@@ -1277,6 +1406,11 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   CHECK_ARG(gx.ds->M == M, "vfe: xz spec columns != number of inducing points");
   CHECK_ARG(M >= 1 && N >= 1, "vfe: empty inputs");
   long m_pad = rup(M, TILE), n_rows = rup(N, TILE);
+  long ch_rows, ch_above;
+  vfe_chunking(&ch_rows, &ch_above);
+  if (n_rows > ch_above)
+    return vfe_pipeline_chunked(ctx, gz.ds, gx.ds, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, h,
+                                keep);
   long ld = m_pad + n_rows;
   hipStream_t s = ctx->stream;
   DevBuf dA, dy, dmean, dvar, ddelta, drsig, dots, sq, dG_local;
