@@ -1344,7 +1344,7 @@ static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dsp
     dG = dG_local.p;
   }
   SGP_HIP(hipMemsetAsync(dG, 0, sizeof(double) * ldg * m_pad, s));
-  const int nsplit = 4;
+  const int nsplit = 8;  // one K slice per XCD (gemm_nt.hip, klo == 3)
   const long stride = ldg * m_pad;
   CHECK_RC(dR.alloc((size_t)CH * m_pad));
   CHECK_RC(dAt.alloc((size_t)m_pad * CH));

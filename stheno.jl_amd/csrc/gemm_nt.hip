@@ -127,12 +127,28 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
                                                              const double* Cin, long ldcin, int klo) {
   constexpr int NJ = 8, WCOLS = 32;
   long tr, tc;
-  if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return;
-  // split-K (blockIdx.y > 0 only in launch_gemm_nt_splitk): slice s contracts columns
-  // [s K, (s + 1) K) of A and B into its own slab of C
-  A += (long)blockIdx.y * K * lda;
-  B += (long)blockIdx.y * K * ldb;
-  C += (long)blockIdx.y * c_slice_stride;
+  if (klo == 3) {
+    // Gram product split over K by XCD: workgroup id % 8 is the XCD the hardware puts it on, and that is
+    // the K slice it contracts, so each XCD's L2 only ever holds its own slice of the operands (all
+    // slices on all XCDs made the per-chunk working set 8 x 512 KB = the whole 4 MiB L2).  id / 8
+    // enumerates the lower tiles linearly.
+    const long sl = (long)blockIdx.x & 7, k = (long)blockIdx.x >> 3;
+    tr = (long)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
+    while (tr * (tr + 1) / 2 > k) --tr;
+    while ((tr + 1) * (tr + 2) / 2 <= k) ++tr;
+    tc = k - tr * (tr + 1) / 2;
+    if (tr >= n_tr) return;
+    A += sl * K * lda;
+    B += sl * K * ldb;
+    C += sl * c_slice_stride;
+  } else {
+    if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return;
+    // split-K (blockIdx.y > 0 only in launch_gemm_nt_splitk): slice s contracts columns
+    // [s K, (s + 1) K) of A and B into its own slab of C
+    A += (long)blockIdx.y * K * lda;
+    B += (long)blockIdx.y * K * ldb;
+    C += (long)blockIdx.y * c_slice_stride;
+  }
   // stage s: A chunk at smem + s*2*KB*LDS_LD, B chunk right after it
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   const int t = threadIdx.x;
@@ -501,6 +517,13 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
     return -1;
   }
   long n_tr = M / TILE, n_tc = Nc / TILE;
+  if (lower_only && nsplit == 8 && M == Nc) {  // one K slice per XCD (see the kernel, klo == 3)
+    long tiles = n_tr * (n_tr + 1) / 2;
+    hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(tiles * 8)), dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc,
+                       K / nsplit, 1.0, 0.0, 0L, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 3);
+    SGP_HIP(hipGetLastError());
+    return 0;
+  }
   long groups = ((n_tr + 7) / 8 + 7) / 8;
   long mask_off = lower_only ? 0 : -(1L << 40);
   long per_xcd = lower_only ? tri_ids_per_xcd(tri_shape(n_tr, n_tc)) : groups * 8 * n_tc;
