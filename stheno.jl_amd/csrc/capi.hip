@@ -1269,12 +1269,13 @@ extern "C" int sgp_sparse_posterior_destroy(sgp_sparse_post* p) {
 // contractions): assemble -> scale -> blocked left-looking row solve (deep-K GEMMs against Lz) ->
 // A delta / |A|^2 partials -> transpose -> split-K Gram partial, accumulated into G in chunk order
 // (deterministic).  Nothing of size N x M is ever resident.
-// Measured (N = 262 144, M = 4096): 223 ms monolithic vs 230-245 ms chunked (16k .. 128k rows per
-// chunk) -- no faster, but the footprint falls from 2 x 8 N M bytes to two chunk buffers, so the
-// chunked path takes over where the monolithic buffers would not be reasonable (N > 524 288 rows by
-// default).  SGP_VFE_CHUNK=<rows> forces chunks of that many rows for any larger N (tests).
-constexpr long VFE_CHUNK_ROWS = 131072;
-constexpr long VFE_CHUNK_ABOVE = 524288;
+// Chunks of 65 536 rows (512 KB between operand columns, like the N = 65 536 factorisation) are as fast
+// as the monolithic buffers on a good day (N = 262 144, M = 4096: 174 vs 177 ms) and three times
+// faster on boxes where the monolithic 270 000-row leading dimension (2.1 MB between columns, every
+// column in its own page) runs into the TLB: 628 ms there, same code, same inputs.  So anything
+// beyond one chunk is chunked.  SGP_VFE_CHUNK=<rows> overrides both numbers (tests).
+constexpr long VFE_CHUNK_ROWS = 65536;
+constexpr long VFE_CHUNK_ABOVE = 65536;
 static void vfe_chunking(long* chunk_rows, long* above) {
   const char* e = getenv("SGP_VFE_CHUNK");
   long v = e ? atol(e) / TILE * TILE : 0;
