@@ -99,6 +99,21 @@ int sgp_abi_version(void);
 /* device: HIP ordinal.  Fails (<0) when no gfx950 device is present: there is no CPU path. */
 int sgp_ctx_create(int device, sgp_ctx** out);
 int sgp_ctx_destroy(sgp_ctx* ctx);
+/* A ctx keeps the device workspaces of finished calls (the m_tot x n_pad factor buffer of
+ * sgp_logpdf etc.) in a grow-only cache so that repeated calls of one shape do not pay
+ * hipMalloc / hipFree of N^2 doubles each time (hyper-parameter optimisation loops call
+ * logpdf hundreds of times: examples/getting_started/script.jl:154-213).  sgp_ctx_trim
+ * returns every cached, unused block to the driver.  SGP_POOL=0 disables the cache. */
+int sgp_ctx_trim(sgp_ctx* ctx);
+/* Optional per-stage device timing (HIP events on the ctx stream) of pipelines a caller cannot time
+ * from outside; enable != 0 switches it on and clears the accumulators, sgp_ctx_stage_ms copies the
+ * 16 accumulated stage times (ms).  Stage ids of sgp_elbo / sgp_sparse_posterior_create for more
+ * than 65536 data points (row-chunked pipeline): 0 K(z,z) assembly + factorisation, 1 K(x,z)
+ * assembly (the HBM-bound stage: 8 M N bytes written), 2 Lambda scaling + row solve against Lz
+ * (M^2 N flops), 3 A delta / |A|^2 reductions + transpose, 4 Gram product A A' (M^2 N flops) +
+ * reduction, 5 factorisation of A A' + I and scalars. */
+int sgp_ctx_stage_timing(sgp_ctx* ctx, int enable);
+int sgp_ctx_stage_ms(sgp_ctx* ctx, double* out16);
 const char* sgp_last_error(void); /* thread-local */
 
 /* ---- covariance assembly (K1-K3, S2-S7) --------------------------------------------

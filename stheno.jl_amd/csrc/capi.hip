@@ -1,7 +1,6 @@
 // libsthenomi.so host driver + C ABI (include/sthenomi.h).  gfx950 only; no CPU fallback:
 // every numerical result is produced by the HIP kernels in this directory.
-#include "common.h"
-#include "../../include/sthenomi.h"
+#include "ctx.h"
 
 #include <algorithm>
 #include <cmath>
@@ -15,7 +14,6 @@ namespace sgp {
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 
-void set_gemm_variant(int v);
 int run_mfma_bench(hipStream_t s, int iters, double* tflops_out, double* layout_maxerr_out);
 int run_hbm_bench(hipStream_t s, long bytes, int iters, double* write_gbs, double* copy_gbs);
 
@@ -28,46 +26,6 @@ constexpr long WOUT_LARGE = 1024;  // ... for n_pad >= 32768 (halves the C-tile 
 }  // namespace sgp
 
 using namespace sgp;
-
-struct sgp_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;   // panel / critical-path stream (high priority)
-  hipStream_t stream2 = nullptr;  // trailing-update stream (look-ahead overlap)
-  hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
-  int lookahead = 1;
-  long wout = 0;  // 0 = automatic
-  double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
-  double* d_w = nullptr;       // 128 x 128 scratch inverse
-  double* d_solve = nullptr;   // rows x 128 scratch of the refined panel solve (grown on demand)
-  long n_solve_rows = 0;
-  int refine = 1;              // SGP_REFINE=0: plain explicit-inverse panel solve (A/B timing only)
-  double* d_slots = nullptr;   // per-128-block logdet contributions
-  long n_slots = 0;
-  double* d_scal = nullptr;    // [0] logdet, [1] misc, [16 ..] per-rhs sums
-  long n_scal = 0;
-  int* d_info = nullptr;
-  std::mutex mu;
-  // optional per-launch timing of the trailing updates (roofline evidence for bench.py)
-  bool time_updates = false;
-  std::vector<hipEvent_t> ev;
-  std::vector<double> ev_flops;
-};
-
-struct sgp_dspec {
-  sgp_ctx* ctx = nullptr;
-  int nrb = 0, ncb = 0, symmetric = 0;
-  std::vector<long> row_len, col_len, row_off, col_off;
-  long N = 0, M = 0;
-  std::vector<double*> d_bufs;          // everything to free
-  std::vector<int> term_ptr;            // CSR over pairs
-  std::vector<DevTerm> h_terms;         // host copy (device pointers inside)
-  DevTerm* d_terms = nullptr;
-  std::vector<int> pair_dmax;
-  std::vector<int> term_row_input;     // spec input index each term reads its row / column points from
-  std::vector<int> term_col_input;
-  std::vector<int> in_dim;             // per spec input
-  std::vector<long> in_n;
-};
 
 #define CHECK_ARG(cond, msg)       \
   do {                             \
@@ -94,6 +52,99 @@ extern "C" int sgp_geometry(int64_t N, int64_t S, int64_t* n_pad, int64_t* m_tot
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// device-memory cache of a context
+// ---------------------------------------------------------------------------------------
+namespace sgp {
+thread_local sgp_ctx* tl_ctx = nullptr;
+
+void* pool_alloc(sgp_ctx* ctx, size_t bytes) {
+  bytes = (bytes + 255) / 256 * 256;
+  if (ctx->pool_enabled) {
+    // best fit among the unused blocks that are not wastefully large for the request
+    const size_t cap = bytes < (1u << 20) ? (4u << 20) : bytes + bytes / 4;
+    long best = -1;
+    for (size_t i = 0; i < ctx->pool.size(); ++i) {
+      const sgp_pool_block& b = ctx->pool[i];
+      if (b.used || b.bytes < bytes || b.bytes > cap) continue;
+      if (best < 0 || b.bytes < ctx->pool[best].bytes) best = (long)i;
+    }
+    if (best >= 0) {
+      ctx->pool[best].used = true;
+      return ctx->pool[best].p;
+    }
+  }
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e != hipSuccess && ctx->pool_enabled) {  // give cached blocks back to the driver and retry once
+    (void)hipGetLastError();
+    pool_trim(ctx);
+    e = hipMalloc(&p, bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    set_error("hipMalloc failed (" + std::to_string(bytes) + " bytes)");
+    return nullptr;
+  }
+  if (ctx->pool_enabled) {
+    sgp_pool_block b;
+    b.p = p;
+    b.bytes = bytes;
+    b.used = true;
+    ctx->pool.push_back(b);
+    ctx->pool_bytes += bytes;
+  }
+  return p;
+}
+
+void pool_free(sgp_ctx* ctx, void* p) {
+  if (!p) return;
+  for (auto& b : ctx->pool)
+    if (b.p == p) {
+      b.used = false;
+      return;
+    }
+  hipFree(p);  // not a cached block (cache disabled)
+}
+
+void pool_trim(sgp_ctx* ctx) {
+  hipStreamSynchronize(ctx->stream);
+  hipStreamSynchronize(ctx->stream2);
+  std::vector<sgp_pool_block> keep;
+  for (auto& b : ctx->pool) {
+    if (b.used) {
+      keep.push_back(b);
+    } else {
+      hipFree(b.p);
+      ctx->pool_bytes -= b.bytes;
+    }
+  }
+  ctx->pool.swap(keep);
+}
+}  // namespace sgp
+
+extern "C" int sgp_ctx_trim(sgp_ctx* ctx) {
+  CHECK_ARG(ctx != nullptr, "sgp_ctx_trim: NULL argument");
+  CtxScope scope(ctx);
+  pool_trim(ctx);
+  return 0;
+}
+
+extern "C" int sgp_ctx_stage_timing(sgp_ctx* ctx, int enable) {
+  CHECK_ARG(ctx != nullptr, "sgp_ctx_stage_timing: NULL argument");
+  CtxScope scope(ctx);
+  ctx->stage_timing = enable ? 1 : 0;
+  for (double& v : ctx->stage_ms) v = 0.0;
+  return 0;
+}
+
+extern "C" int sgp_ctx_stage_ms(sgp_ctx* ctx, double* out16) {
+  CHECK_ARG(ctx && out16, "sgp_ctx_stage_ms: NULL argument");
+  CtxScope scope(ctx);
+  for (int i = 0; i < 16; ++i) out16[i] = ctx->stage_ms[i];
+  return 0;
+}
+
 extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
   CHECK_ARG(out != nullptr, "sgp_ctx_create: out is NULL");
   int ndev = 0;
@@ -113,7 +164,7 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
   }
   sgp_ctx* c = new sgp_ctx();
   c->device = device;
-  {
+  auto init = [&]() -> int {
     int lo = 0, hi = 0;
     SGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     SGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
@@ -126,14 +177,22 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* rf = getenv("SGP_REFINE");
     if (rf) c->refine = atoi(rf);
+    const char* po = getenv("SGP_POOL");
+    if (po) c->pool_enabled = atoi(po);
+    SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
+    SGP_HIP(hipMalloc(&c->d_w, sizeof(double) * TILE * TILE));
+    c->n_slots = 1 << 15;
+    SGP_HIP(hipMalloc(&c->d_slots, sizeof(double) * c->n_slots));
+    c->n_scal = 16 + (1 << 16);
+    SGP_HIP(hipMalloc(&c->d_scal, sizeof(double) * c->n_scal));
+    SGP_HIP(hipMalloc(&c->d_info, sizeof(int)));
+    return 0;
+  };
+  int rc = init();
+  if (rc) {
+    sgp_ctx_destroy(c);
+    return rc;
   }
-  SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
-  SGP_HIP(hipMalloc(&c->d_w, sizeof(double) * TILE * TILE));
-  c->n_slots = 1 << 15;
-  SGP_HIP(hipMalloc(&c->d_slots, sizeof(double) * c->n_slots));
-  c->n_scal = 16 + (1 << 16);
-  SGP_HIP(hipMalloc(&c->d_scal, sizeof(double) * c->n_scal));
-  SGP_HIP(hipMalloc(&c->d_info, sizeof(int)));
   *out = c;
   return 0;
 }
@@ -141,19 +200,21 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
 extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (!c) return 0;
   hipSetDevice(c->device);
-  hipStreamSynchronize(c->stream);
+  if (c->stream) hipStreamSynchronize(c->stream);
+  if (c->stream2) hipStreamSynchronize(c->stream2);
   for (auto e : c->ev) hipEventDestroy(e);
-  hipFree(c->d_invd);
-  hipFree(c->d_w);
+  for (auto& b : c->pool) hipFree(b.p);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->d_invd) hipFree(c->d_invd);
+  if (c->d_w) hipFree(c->d_w);
   if (c->d_solve) hipFree(c->d_solve);
-  hipFree(c->d_slots);
-  hipFree(c->d_scal);
-  hipFree(c->d_info);
-  hipStreamSynchronize(c->stream2);
-  hipEventDestroy(c->ev_panel);
-  hipEventDestroy(c->ev_rest);
-  hipStreamDestroy(c->stream2);
-  hipStreamDestroy(c->stream);
+  if (c->d_slots) hipFree(c->d_slots);
+  if (c->d_scal) hipFree(c->d_scal);
+  if (c->d_info) hipFree(c->d_info);
+  if (c->ev_panel) hipEventDestroy(c->ev_panel);
+  if (c->ev_rest) hipEventDestroy(c->ev_rest);
+  if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;
 }
@@ -167,10 +228,13 @@ static int pow2ceil(int d) {
   return p;
 }
 
-extern "C" int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out) {
+// Uploads a spec with ONE host -> device copy: inputs (packed to ld == dim), row / column scale
+// vectors and the term table are laid out in a pinned staging buffer of the context and moved in
+// one piece into one cached device block.  Caller holds the context (CtxScope / ctx->mu).
+static void dspec_free(sgp_dspec* ds);
+static int dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out) {
   CHECK_ARG(ctx && sp && out, "sgp_dspec_create: NULL argument");
   CHECK_ARG(sp->n_row_blocks >= 1 && sp->n_col_blocks >= 1, "spec: need >= 1 block");
-  SGP_HIP(hipSetDevice(ctx->device));
   sgp_dspec* ds = new sgp_dspec();
   ds->ctx = ctx;
   ds->nrb = sp->n_row_blocks;
@@ -192,33 +256,33 @@ extern "C" int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec*
   ds->M = off;
   auto fail = [&](const char* msg) {
     set_error(msg);
-    sgp_dspec_destroy(ds);
+    dspec_free(ds);
     return -1;
   };
   if (ds->symmetric && (ds->nrb != ds->ncb || ds->row_len != ds->col_len))
     return fail("spec: symmetric spec needs identical row / col blocks");
-  // inputs -> HBM, packed with ld == dim
-  std::vector<double*> d_in(sp->n_inputs, nullptr);
+  // ---- pass 1: validate, lay everything out (byte offsets into one block, 256-byte aligned)
+  size_t total = 0;
+  auto place = [&](size_t bytes) {
+    size_t at = total;
+    total += (std::max<size_t>(bytes, 8) + 255) / 256 * 256;
+    return at;
+  };
+  std::vector<size_t> in_off(sp->n_inputs);
   for (int k = 0; k < sp->n_inputs; ++k) {
     const sgp_input& in = sp->inputs[k];
     if (in.dim < 1 || in.dim > 64) return fail("spec: input dimension must be in [1, 64]");
     if (in.n < 0 || in.ld < in.dim) return fail("spec: bad input n / ld");
-    size_t bytes = sizeof(double) * (size_t)std::max<long>(1, in.dim * in.n);
-    double* d = nullptr;
-    if (hipMalloc(&d, bytes) != hipSuccess) return fail("spec: hipMalloc failed (input)");
-    ds->d_bufs.push_back(d);
-    if (in.n > 0) {
-      if (hipMemcpy2D(d, sizeof(double) * in.dim, in.x, sizeof(double) * in.ld,
-                      sizeof(double) * in.dim, (size_t)in.n, hipMemcpyHostToDevice) != hipSuccess)
-        return fail("spec: input upload failed");
-    }
-    d_in[k] = d;
+    in_off[k] = place(sizeof(double) * (size_t)(in.dim * in.n));
     ds->in_dim.push_back((int)in.dim);
     ds->in_n.push_back((long)in.n);
   }
   int npairs = ds->nrb * ds->ncb;
   ds->term_ptr.assign(sp->term_ptr, sp->term_ptr + npairs + 1);
   ds->pair_dmax.assign(npairs, 1);
+  const int nterms = sp->term_ptr[npairs];
+  std::vector<size_t> rs_off(nterms, (size_t)-1), cs_off(nterms, (size_t)-1);
+  std::vector<long> rs_len(nterms, 0), cs_len(nterms, 0);
   for (int I = 0; I < ds->nrb; ++I)
     for (int J = 0; J < ds->ncb; ++J) {
       int p = I * ds->ncb + J;
@@ -233,49 +297,110 @@ extern "C" int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec*
         if (ri.dim != ci.dim) return fail("spec: row / col input dimension mismatch");
         if (ri.n != ds->row_len[I] || ci.n != ds->col_len[J])
           return fail("spec: input length does not match block length");
+        if (T.row_scale && ds->row_len[I] > 0) {
+          rs_len[t] = ds->row_len[I];
+          rs_off[t] = place(sizeof(double) * (size_t)rs_len[t]);
+        }
+        if (T.col_scale && ds->col_len[J] > 0) {
+          cs_len[t] = ds->col_len[J];
+          cs_off[t] = place(sizeof(double) * (size_t)cs_len[t]);
+        }
+        ds->pair_dmax[p] = std::max(ds->pair_dmax[p], pow2ceil((int)ri.dim));
+      }
+    }
+  const size_t terms_off = place(sizeof(DevTerm) * (size_t)std::max(1, nterms));
+  // ---- one cached device block, one pinned staging buffer
+  char* d_base = (char*)pool_alloc(ctx, total);
+  if (!d_base) {
+    dspec_free(ds);
+    return -2;
+  }
+  ds->d_bufs.push_back((double*)d_base);
+  if (total > ctx->stage_cap) {
+    if (ctx->h_stage) hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
+    ctx->stage_cap = 0;
+    size_t cap = std::max<size_t>(total + total / 2, 1u << 20);
+    if (hipHostMalloc((void**)&ctx->h_stage, cap, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      return fail("spec: hipHostMalloc failed (staging buffer)");
+    }
+    ctx->stage_cap = cap;
+  }
+  char* h_base = ctx->h_stage;
+  // ---- pass 2: fill the staging buffer
+  for (int k = 0; k < sp->n_inputs; ++k) {
+    const sgp_input& in = sp->inputs[k];
+    double* dst = (double*)(h_base + in_off[k]);
+    if (in.ld == in.dim) {
+      if (in.n > 0) memcpy(dst, in.x, sizeof(double) * (size_t)(in.dim * in.n));
+    } else {
+      for (long j = 0; j < in.n; ++j) memcpy(dst + j * in.dim, in.x + j * in.ld, sizeof(double) * (size_t)in.dim);
+    }
+  }
+  DevTerm* h_terms = (DevTerm*)(h_base + terms_off);
+  for (int I = 0; I < ds->nrb; ++I)
+    for (int J = 0; J < ds->ncb; ++J) {
+      int p = I * ds->ncb + J;
+      for (int t = sp->term_ptr[p]; t < sp->term_ptr[p + 1]; ++t) {
+        const sgp_term& T = sp->terms[t];
+        const sgp_input& ri = sp->inputs[T.row_input];
+        const sgp_input& ci = sp->inputs[T.col_input];
         DevTerm D;
         D.kind = T.kind;
         D.dim = (int)ri.dim;
         D.coef = T.coef;
         D.param = T.param;
-        D.xr = d_in[T.row_input];
+        D.xr = (const double*)(d_base + in_off[T.row_input]);
         D.ldr = ri.dim;
-        D.xc = d_in[T.col_input];
+        D.xc = (const double*)(d_base + in_off[T.col_input]);
         D.ldc = ci.dim;
         D.rs = nullptr;
         D.cs = nullptr;
-        auto up = [&](const double* h, long n, const double** dst) -> bool {
-          if (!h || n == 0) return true;
-          double* d = nullptr;
-          if (hipMalloc(&d, sizeof(double) * n) != hipSuccess) return false;
-          ds->d_bufs.push_back(d);
-          if (hipMemcpy(d, h, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) return false;
-          *dst = d;
-          return true;
-        };
-        if (!up(T.row_scale, ds->row_len[I], &D.rs) || !up(T.col_scale, ds->col_len[J], &D.cs))
-          return fail("spec: scale upload failed");
+        if (rs_len[t]) {
+          memcpy(h_base + rs_off[t], T.row_scale, sizeof(double) * (size_t)rs_len[t]);
+          D.rs = (const double*)(d_base + rs_off[t]);
+        }
+        if (cs_len[t]) {
+          memcpy(h_base + cs_off[t], T.col_scale, sizeof(double) * (size_t)cs_len[t]);
+          D.cs = (const double*)(d_base + cs_off[t]);
+        }
+        h_terms[t] = D;
         ds->h_terms.push_back(D);
         ds->term_row_input.push_back(T.row_input);
         ds->term_col_input.push_back(T.col_input);
-        ds->pair_dmax[p] = std::max(ds->pair_dmax[p], pow2ceil(D.dim));
       }
     }
-  size_t tb = sizeof(DevTerm) * std::max<size_t>(1, ds->h_terms.size());
-  if (hipMalloc(&ds->d_terms, tb) != hipSuccess) return fail("spec: hipMalloc failed (terms)");
-  if (!ds->h_terms.empty() &&
-      hipMemcpy(ds->d_terms, ds->h_terms.data(), sizeof(DevTerm) * ds->h_terms.size(),
-                hipMemcpyHostToDevice) != hipSuccess)
-    return fail("spec: term upload failed");
+  ds->d_terms = (DevTerm*)(d_base + terms_off);
+  if (hipMemcpy(d_base, h_base, total, hipMemcpyHostToDevice) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail("spec: upload failed");
+  }
   *out = ds;
   return 0;
 }
 
+extern "C" int sgp_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out) {
+  CHECK_ARG(ctx && sp && out, "sgp_dspec_create: NULL argument");
+  CtxScope scope(ctx);
+  return dspec_create(ctx, sp, out);
+}
+
+// Internal: caller already holds ds->ctx (or is tearing it down from a failed create).
+static void dspec_free(sgp_dspec* ds) {
+  if (!ds) return;
+  for (double* p : ds->d_bufs) pool_free(ds->ctx, p);
+  delete ds;
+}
+
 extern "C" int sgp_dspec_destroy(sgp_dspec* ds) {
   if (!ds) return 0;
-  for (double* p : ds->d_bufs) hipFree(p);
-  if (ds->d_terms) hipFree(ds->d_terms);
-  delete ds;
+  if (tl_ctx == ds->ctx) {  // called from inside an entry point of the same context
+    dspec_free(ds);
+    return 0;
+  }
+  CtxScope scope(ds->ctx);
+  dspec_free(ds);
   return 0;
 }
 
@@ -570,8 +695,7 @@ extern "C" int sgp_dev_logpdf(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, co
   CHECK_ARG(ctx && ds && d_A && d_Y && out_host, "sgp_dev_logpdf: NULL argument");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
             "sgp_dev_logpdf: noise kind must be SCALAR or DIAG");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   double s2 = noise_host ? noise_host[0] : 0.0;
   return dev_logpdf_impl(ctx, ds, d_A, d_mean, noise_kind, s2, d_noise, nullptr, 0, d_Y, ldy, ncols,
                          out_host, timings);
@@ -580,35 +704,9 @@ extern "C" int sgp_dev_logpdf(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, co
 // ---------------------------------------------------------------------------------------
 // host-buffer helpers
 // ---------------------------------------------------------------------------------------
-struct DevBuf {
-  double* p = nullptr;
-  ~DevBuf() {
-    if (p) hipFree(p);
-  }
-  int alloc(size_t n) {
-    if (p) {
-      hipFree(p);
-      p = nullptr;
-    }
-    if (hipMalloc(&p, sizeof(double) * std::max<size_t>(1, n)) != hipSuccess) {
-      set_error("hipMalloc failed (" + std::to_string(n * 8) + " bytes)");
-      p = nullptr;
-      return -2;
-    }
-    return 0;
-  }
-  int upload(const double* h, size_t n) {
-    CHECK_RC(alloc(n));
-    if (n && hipMemcpy(p, h, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) {
-      set_error("hipMemcpy H2D failed");
-      return -2;
-    }
-    return 0;
-  }
-};
 struct SpecGuard {
   sgp_dspec* ds = nullptr;
-  ~SpecGuard() { sgp_dspec_destroy(ds); }
+  ~SpecGuard() { dspec_free(ds); }
 };
 
 static int upload_matrix(DevBuf& b, const double* h, long ldh, long nr, long nc) {
@@ -643,10 +741,9 @@ static int upload_noise(NoiseDev& nd, int kind, const double* noise, long N) {
 
 extern "C" int sgp_kernelmatrix(sgp_ctx* ctx, const sgp_cov_spec* spec, double* K, int64_t ldk) {
   CHECK_ARG(ctx && spec && K, "sgp_kernelmatrix: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard g;
-  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N, M = g.ds->M;
   CHECK_ARG(ldk >= N, "sgp_kernelmatrix: ldk < N");
   if (N == 0 || M == 0) return 0;
@@ -675,10 +772,9 @@ static int diag_of_spec(sgp_ctx* ctx, const sgp_dspec* ds, double* d_out, hipStr
 
 extern "C" int sgp_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, double* out) {
   CHECK_ARG(ctx && spec && out, "sgp_kernelmatrix_diag: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard g;
-  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
   if (N == 0) return 0;
   DevBuf d;
@@ -694,10 +790,9 @@ extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
                           double* out) {
   CHECK_ARG(ctx && spec && Y && out, "sgp_logpdf: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_logpdf: spec must be symmetric");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard g;
-  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
   CHECK_ARG(N >= 1 && ncols >= 1 && ldy >= N, "sgp_logpdf: bad sizes");
   int64_t n_pad, m_tot;
@@ -725,10 +820,9 @@ extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* me
                         int64_t ldo) {
   CHECK_ARG(ctx && spec && Z && out, "sgp_rand: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_rand: spec must be symmetric");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard g;
-  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
   CHECK_ARG(N >= 1 && S >= 1 && ldz >= N && ldo >= N, "sgp_rand: bad sizes");
   int64_t n_pad, m_tot;
@@ -802,10 +896,9 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   CHECK_ARG(spec->symmetric, "sgp_logpdf_grad: spec must be symmetric");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
             "sgp_logpdf_grad: noise kind must be SCALAR or DIAG");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard g;
-  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  CHECK_RC(dspec_create(ctx, spec, &g.ds));
   const sgp_dspec* ds = g.ds;
   long N = ds->N;
   CHECK_ARG(N >= 1, "sgp_logpdf_grad: empty data");
@@ -1046,10 +1139,9 @@ extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, cons
                                     double* alpha_out, sgp_post** out) {
   CHECK_ARG(ctx && spec && y && out, "sgp_posterior_create: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_posterior_create: spec must be symmetric");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard g;
-  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
   CHECK_ARG(N >= 1, "sgp_posterior_create: empty data");
   int64_t n_pad, m_tot;
@@ -1065,10 +1157,13 @@ extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, cons
   post->N = N;
   post->n_pad = n_pad;
   post->m_tot = m_tot;
-  auto fail = [&](int rc) {
-    sgp_posterior_destroy(post);
-    return rc;
-  };
+  struct PostGuard {  // every error exit (incl. the SGP_HIP early returns) frees the 8 N^2-byte factor
+    sgp_post* p;
+    ~PostGuard() {
+      if (p) sgp_posterior_destroy(p);
+    }
+  } guard{post};
+  auto fail = [&](int rc) { return rc; };
   if (hipMalloc(&post->dA, sizeof(double) * m_tot * n_pad) != hipSuccess ||
       hipMalloc(&post->d_wall, sizeof(double) * (n_pad / TILE) * INVD_STRIDE) != hipSuccess) {
     set_error("sgp_posterior_create: hipMalloc failed");
@@ -1096,6 +1191,7 @@ extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, cons
               std::to_string(info));
     return fail(info);
   }
+  guard.p = nullptr;
   *out = post;
   return 0;
 }
@@ -1145,11 +1241,10 @@ extern "C" int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross,
                                      int64_t ldcov) {
   CHECK_ARG(post && cross, "sgp_posterior_predict: NULL argument");
   sgp_ctx* ctx = post->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard gc, gp;
-  CHECK_RC(sgp_dspec_create(ctx, cross, &gc.ds));
-  if (prior_ss) CHECK_RC(sgp_dspec_create(ctx, prior_ss, &gp.ds));
+  CHECK_RC(dspec_create(ctx, cross, &gc.ds));
+  if (prior_ss) CHECK_RC(dspec_create(ctx, prior_ss, &gp.ds));
   long Ns = gc.ds->N;
   CHECK_ARG(gc.ds->M == post->N, "sgp_posterior_predict: cross spec columns != training size");
   CHECK_ARG(!gp.ds || gp.ds->N == Ns, "sgp_posterior_predict: prior_ss size != number of x*");
@@ -1303,6 +1398,8 @@ static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dsp
   CHECK_RC(dots.alloc(m_pad));
   CHECK_RC(sq.alloc(m_pad));
   double* d_o = ctx->d_scal + 1;
+  StageTimer tm(ctx, s);
+  tm.mark(0);
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
   SGP_HIP(hipMemsetAsync(ddelta.p, 0, sizeof(double) * n_rows, s));
   SGP_HIP(hipMemsetAsync(drsig.p, 0, sizeof(double) * n_rows, s));
@@ -1354,18 +1451,23 @@ static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dsp
   for (long r0 = 0; r0 < n_rows; r0 += CH) {
     const long ch = std::min(CH, n_rows - r0);            // rows of this chunk (multiple of 128)
     const long nv = std::max<long>(0, std::min(N - r0, ch));  // of which real data points
+    tm.mark(1);
     SGP_HIP(hipMemsetAsync(dR.p, 0, sizeof(double) * ch * m_pad, s));
     // global row r of K(x,z) lands at dR[(r - r0) + c * ch]
     CHECK_RC(assemble(dx, dR.p - r0, ch, r0 / TILE, (r0 + ch) / TILE, 0, m_pad / TILE, 0, -1, 0.0, nullptr, s));
+    tm.mark(2);
     CHECK_RC(launch_scale_rows(dR.p, ch, nv, m_pad, drsig.p + r0, s));
     CHECK_RC(row_trsm(ctx, dR.p, ch, ch, dLz, m_pad, d_wz, m_pad, s));
+    tm.mark(3);
     hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, dR.p, ch, ch, ddelta.p + r0, dots.p, sq.p,
                        r0 > 0 ? 1 : 0);
     SGP_HIP(hipGetLastError());
     CHECK_RC(launch_transpose_add(dR.p, ch, ch, m_pad, dAt.p, m_pad, nullptr, s));
+    tm.mark(4);
     CHECK_RC(launch_gemm_nt_splitk(dAt.p, m_pad, dAt.p, m_pad, dPart.p, ldg, m_pad, m_pad, ch, nsplit, stride, 1, s));
     CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, r0 > 0 ? 1.0 : 0.0, 1, s));
   }
+  tm.mark(5);
   CHECK_RC(launch_sum_array(sq.p, m_pad, ctx->d_scal + 4, s));
   hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg, m_pad);
   hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg, m_pad, dots.p,
@@ -1376,6 +1478,7 @@ static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dsp
   CHECK_RC(launch_sum_array(ctx->d_slots, m_pad / TILE, ctx->d_scal + 5, s));
   CHECK_RC(launch_rowsumsq(dG + m_pad, ldg, m_pad, 1, ctx->d_scal + 6, 0, s));
   SGP_HIP(hipMemcpyAsync(h, ctx->d_scal + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
+  tm.finish();
   info = fetch_info(ctx, s);
   if (info > 0) {
     set_error("vfe: A A' + I is not positive definite (leading minor " + std::to_string(info) + ")");
@@ -1401,8 +1504,8 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
             "vfe: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
   SpecGuard gz, gx;
-  CHECK_RC(sgp_dspec_create(ctx, zz, &gz.ds));
-  CHECK_RC(sgp_dspec_create(ctx, xz, &gx.ds));
+  CHECK_RC(dspec_create(ctx, zz, &gz.ds));
+  CHECK_RC(dspec_create(ctx, xz, &gx.ds));
   long M = gz.ds->N, N = gx.ds->N;
   CHECK_ARG(gx.ds->M == M, "vfe: xz spec columns != number of inducing points");
   CHECK_ARG(M >= 1 && N >= 1, "vfe: empty inputs");
@@ -1534,8 +1637,7 @@ extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
                         const double* noise_x, int z_noise_kind, const double* z_noise,
                         const double* y, double* out) {
   CHECK_ARG(ctx && zz && xz && var_x && noise_x && z_noise && y && out, "sgp_elbo: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   double h[6];
   CHECK_RC(vfe_pipeline(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, h,
                         nullptr));
@@ -1568,11 +1670,10 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
             "sgp_elbo_grad: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
   CHECK_ARG(z_noise_kind == SGP_NOISE_SCALAR || z_noise_kind == SGP_NOISE_DIAG,
             "sgp_elbo_grad: Sigma_z must be isotropic or diagonal");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard gz, gx;
-  CHECK_RC(sgp_dspec_create(ctx, zz, &gz.ds));
-  CHECK_RC(sgp_dspec_create(ctx, xz, &gx.ds));
+  CHECK_RC(dspec_create(ctx, zz, &gz.ds));
+  CHECK_RC(dspec_create(ctx, xz, &gx.ds));
   const long M = gz.ds->N, N = gx.ds->N;
   CHECK_ARG(gx.ds->M == M, "sgp_elbo_grad: xz spec columns != number of inducing points");
   CHECK_ARG(M >= 1 && N >= 1, "sgp_elbo_grad: empty inputs");
@@ -1838,10 +1939,9 @@ extern "C" int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_c
 static int diag_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
                           double* grad_inscale, double* const* grad_inputs) {
   CHECK_ARG(ctx && spec && w && grad_coef && grad_inscale, "sgp_kernelmatrix_diag_grad: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard g;
-  CHECK_RC(sgp_dspec_create(ctx, spec, &g.ds));
+  CHECK_RC(dspec_create(ctx, spec, &g.ds));
   const sgp_dspec* ds = g.ds;
   CHECK_ARG(ds->nrb == ds->ncb, "kernelmatrix_diag_grad: row / col block counts differ");
   size_t nt = ds->h_terms.size();
@@ -1905,8 +2005,7 @@ extern "C" int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz,
                                            const double* z_noise, const double* y,
                                            sgp_sparse_post** out) {
   CHECK_ARG(ctx && zz && xz && noise_x && z_noise && y && out, "sgp_sparse_posterior_create: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   sgp_sparse_post* p = new sgp_sparse_post();
   double h[6];
   int rc = vfe_pipeline(ctx, zz, xz, nullptr, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y,
@@ -1925,11 +2024,10 @@ extern "C" int sgp_sparse_posterior_predict(sgp_sparse_post* post, const sgp_cov
                                             int64_t ldcov) {
   CHECK_ARG(post && cross, "sgp_sparse_posterior_predict: NULL argument");
   sgp_ctx* ctx = post->ctx;
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   SpecGuard gc, gp;
-  CHECK_RC(sgp_dspec_create(ctx, cross, &gc.ds));
-  if (prior_ss) CHECK_RC(sgp_dspec_create(ctx, prior_ss, &gp.ds));
+  CHECK_RC(dspec_create(ctx, cross, &gc.ds));
+  if (prior_ss) CHECK_RC(dspec_create(ctx, prior_ss, &gp.ds));
   long Ns = gc.ds->N;
   CHECK_ARG(gc.ds->M == post->M, "sparse predict: cross spec columns != number of inducing points");
   CHECK_ARG(!gp.ds || gp.ds->N == Ns, "sparse predict: prior_ss size != number of x*");
@@ -1971,6 +2069,7 @@ extern "C" int sgp_dev_assemble_cols(sgp_ctx* ctx, const sgp_dspec* ds, int64_t 
   CHECK_ARG(ds->symmetric && ds->N == N, "sgp_dev_assemble_cols: spec must be symmetric of size N");
   CHECK_ARG(c0 % TILE == 0 && nc % TILE == 0, "sgp_dev_assemble_cols: c0, nc must be multiples of 128");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG, "bad noise kind");
+  std::lock_guard<std::mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int64_t n_pad, mt;
@@ -1989,6 +2088,7 @@ extern "C" int sgp_dev_panel_factor(sgp_ctx* ctx, double* d_P, int64_t ld, int64
                                     int64_t g0, double* d_logdet, int* d_info, void* stream) {
   CHECK_ARG(ctx && d_P && d_logdet && d_info, "sgp_dev_panel_factor: NULL argument");
   CHECK_ARG(w % TILE == 0 && m % TILE == 0 && m >= w, "sgp_dev_panel_factor: bad sizes");
+  std::lock_guard<std::mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   // per-block logdet slots live in ctx scratch; accumulate their sum into d_logdet[0]
@@ -2004,6 +2104,7 @@ extern "C" int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp
                                     int64_t m_tot, void* stream) {
   CHECK_ARG(ctx && d_P && d_C, "sgp_dev_panel_update: NULL argument");
   CHECK_ARG(c0 % TILE == 0 && nc % TILE == 0 && w % 16 == 0 && c0 >= p_row0, "sgp_dev_panel_update: bad sizes");
+  std::lock_guard<std::mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   const double* A = d_P + (c0 - p_row0);  // panel rows c0.. (global)
@@ -2015,6 +2116,7 @@ extern "C" int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp
 extern "C" int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nc,
                                 int64_t nrows, double* d_out, void* stream) {
   CHECK_ARG(ctx && d_rows && d_out, "sgp_dev_rowsumsq: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   return launch_rowsumsq(d_rows, ld, nc, nrows, d_out, 1, s);
@@ -2025,14 +2127,12 @@ extern "C" int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, 
 // ---------------------------------------------------------------------------------------
 extern "C" int sgp_bench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops_out, double* layout_maxerr_out) {
   CHECK_ARG(ctx && tflops_out && layout_maxerr_out, "sgp_bench_mfma_f64: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   return run_mfma_bench(ctx->stream, iters, tflops_out, layout_maxerr_out);
 }
 extern "C" int sgp_bench_hbm(sgp_ctx* ctx, int64_t bytes, int iters, double* write_gbs_out, double* copy_gbs_out) {
   CHECK_ARG(ctx && write_gbs_out && copy_gbs_out, "sgp_bench_hbm: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   return run_hbm_bench(ctx->stream, bytes, iters, write_gbs_out, copy_gbs_out);
 }
 
@@ -2048,8 +2148,7 @@ extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int
                               int iters, double* tflops_out, double* maxerr_out) {
   CHECK_ARG(ctx && tflops_out && maxerr_out, "sgp_bench_gemm: NULL argument");
   CHECK_ARG(m % TILE == 0 && n % TILE == 0 && k % 16 == 0 && m >= n, "sgp_bench_gemm: bad sizes");
-  std::lock_guard<std::mutex> lk(ctx->mu);
-  SGP_HIP(hipSetDevice(ctx->device));
+  CtxScope scope(ctx);
   hipStream_t s = ctx->stream;
   DevBuf A, C;
   CHECK_RC(A.alloc((size_t)m * k));
@@ -2076,14 +2175,16 @@ extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int
   SGP_HIP(hipEventCreate(&e0));
   SGP_HIP(hipEventCreate(&e1));
   SGP_HIP(hipEventRecord(e0, s));
-  set_gemm_variant((lower_only & 2) ? 1 : 0);  // bench-only: bit 1 = register-staged baseline kernel
+  const bool reg_baseline = (lower_only & 2) != 0;  // bench-only: bit 1 = register-staged baseline kernel
+  const long REG_BASELINE = -(1L << 50);            // (an argument of this one call: no process-global switch)
   lower_only &= 1;
   for (int i = 0; i < iters; ++i)
-    if (lower_only)
+    if (reg_baseline)
+      CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, 0, REG_BASELINE, s));
+    else if (lower_only)
       CHECK_RC(launch_gemm_nt_update(A.p, m, C.p, m, m, n, k, s));  // the production trailing-update symbol
     else
       CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, NOMASK, 0, 0, s));
-  set_gemm_variant(0);
   SGP_HIP(hipEventRecord(e1, s));
   SGP_HIP(hipEventSynchronize(e1));
   float ms = 0;

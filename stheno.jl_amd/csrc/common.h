@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 namespace sgp {
@@ -58,7 +59,7 @@ void set_error(const std::string& s);
 // may hold contexts on several GPUs).
 #define SGP_LDS_ATTR_ONCE(func, bytes)                                                              \
   do {                                                                                             \
-    static bool done_[64] = {};                                                                    \
+    static std::atomic<bool> done_[64];                                                                  \
     int dev_ = 0;                                                                                  \
     SGP_HIP(hipGetDevice(&dev_));                                                                  \
     if (dev_ >= 0 && dev_ < 64 && !done_[dev_]) {                                                  \

@@ -1,0 +1,172 @@
+// Host-side state shared by the translation units of libsthenomi.so: the context (one GPU, its
+// streams, scratch and a grow-only device-memory cache), device-resident specs, RAII buffers.
+#pragma once
+#include "common.h"
+#include "../../include/sthenomi.h"
+
+#include <mutex>
+#include <vector>
+
+// Grow-only cache of device allocations of one context.  The host-buffer entry points
+// (sgp_logpdf, sgp_rand, sgp_posterior_predict, ...) used to hipMalloc / hipFree their N x N
+// workspace on every call; now a released block goes back to the cache and the next call of the
+// same shape gets it without touching the driver.  Blocks are only handed out again after the
+// context's streams have been drained (sgp::CtxScope), so reuse is safe across calls.
+struct sgp_pool_block {
+  void* p = nullptr;
+  size_t bytes = 0;
+  bool used = false;
+};
+
+struct sgp_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;   // panel / critical-path stream (high priority)
+  hipStream_t stream2 = nullptr;  // trailing-update stream (look-ahead overlap)
+  hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
+  int lookahead = 1;
+  long wout = 0;  // 0 = automatic
+  double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
+  double* d_w = nullptr;       // 128 x 128 scratch inverse
+  double* d_solve = nullptr;   // rows x 128 scratch of the refined panel solve (grown on demand)
+  long n_solve_rows = 0;
+  int refine = 1;              // SGP_REFINE=0: plain explicit-inverse panel solve (A/B timing only)
+  double* d_slots = nullptr;   // per-128-block logdet contributions
+  long n_slots = 0;
+  double* d_scal = nullptr;    // [0] logdet, [1] misc, [16 ..] per-rhs sums
+  long n_scal = 0;
+  int* d_info = nullptr;
+  std::mutex mu;
+  // optional per-launch timing of the trailing updates (roofline evidence for bench.py)
+  bool time_updates = false;
+  std::vector<hipEvent_t> ev;
+  std::vector<double> ev_flops;
+  // optional per-stage HIP-event timing of the pipelines that bench.py cannot time from outside
+  // (sgp_ctx_stage_timing / sgp_ctx_stage_ms; stage ids are documented in sthenomi.h)
+  int stage_timing = 0;
+  double stage_ms[16] = {0};
+  // device-memory cache (see sgp_pool_block); guarded by mu
+  std::vector<sgp_pool_block> pool;
+  size_t pool_bytes = 0;
+  int pool_enabled = 1;        // SGP_POOL=0: plain hipMalloc / hipFree per call (A/B timing)
+  // pinned staging area for small host -> device uploads (spec inputs, y, mean): one async copy
+  // per call instead of one blocking hipMemcpy per array
+  char* h_stage = nullptr;
+  char* d_stage = nullptr;
+  size_t stage_cap = 0;
+};
+
+namespace sgp {
+
+extern thread_local sgp_ctx* tl_ctx;  // the context whose entry point this thread is inside
+
+void* pool_alloc(sgp_ctx* ctx, size_t bytes);   // nullptr on failure (error text set)
+void pool_free(sgp_ctx* ctx, void* p);
+void pool_trim(sgp_ctx* ctx);                   // release every unused block to the driver
+
+// RAII: lock the context, make its device current, route DevBuf through its cache; on exit drain
+// the context's streams so that cached blocks can be reused by the next call.
+struct CtxScope {
+  sgp_ctx* ctx;
+  sgp_ctx* prev;
+  std::unique_lock<std::mutex> lk;
+  explicit CtxScope(sgp_ctx* c) : ctx(c), prev(tl_ctx), lk(c->mu) {
+    hipSetDevice(c->device);
+    tl_ctx = c;
+  }
+  ~CtxScope() {
+    hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->stream2);
+    tl_ctx = prev;
+  }
+};
+
+// Attributes the time between successive mark() calls on one stream to the stage id of the earlier
+// mark (HIP events); finish() drains the stream and adds the intervals to ctx->stage_ms.  A no-op
+// unless the context has stage timing switched on.
+struct StageTimer {
+  sgp_ctx* ctx;
+  hipStream_t s;
+  std::vector<hipEvent_t> ev;
+  std::vector<int> id;
+  StageTimer(sgp_ctx* c, hipStream_t st) : ctx(c), s(st) {}
+  ~StageTimer() {
+    for (auto e : ev) hipEventDestroy(e);
+  }
+  void mark(int stage) {
+    if (!ctx->stage_timing) return;
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    ev.push_back(e);
+    id.push_back(stage);
+    hipEventRecord(e, s);
+  }
+  void finish() {
+    if (!ctx->stage_timing || ev.empty()) return;
+    mark(-1);
+    hipEventSynchronize(ev.back());
+    for (size_t i = 0; i + 1 < ev.size(); ++i) {
+      float ms = 0;
+      if (id[i] >= 0 && id[i] < 16 && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) ctx->stage_ms[id[i]] += ms;
+    }
+  }
+};
+
+struct DevBuf {
+  double* p = nullptr;
+  sgp_ctx* owner = nullptr;
+  DevBuf() = default;
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), owner(o.owner) { o.p = nullptr; }
+  ~DevBuf() { release(); }
+  void release() {
+    if (!p) return;
+    if (owner)
+      pool_free(owner, p);
+    else
+      hipFree(p);
+    p = nullptr;
+  }
+  int alloc(size_t n) {
+    release();
+    size_t bytes = sizeof(double) * (n ? n : 1);
+    owner = tl_ctx;
+    if (owner) {
+      p = (double*)pool_alloc(owner, bytes);
+      return p ? 0 : -2;
+    }
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+      set_error("hipMalloc failed (" + std::to_string(bytes) + " bytes)");
+      p = nullptr;
+      return -2;
+    }
+    return 0;
+  }
+  int upload(const double* h, size_t n) {
+    int rc = alloc(n);
+    if (rc) return rc;
+    if (n && hipMemcpy(p, h, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess) {
+      set_error("hipMemcpy H2D failed");
+      return -2;
+    }
+    return 0;
+  }
+};
+
+}  // namespace sgp
+
+struct sgp_dspec {
+  sgp_ctx* ctx = nullptr;
+  int nrb = 0, ncb = 0, symmetric = 0;
+  std::vector<long> row_len, col_len, row_off, col_off;
+  long N = 0, M = 0;
+  std::vector<double*> d_bufs;          // everything to free (cache blocks of ctx)
+  std::vector<int> term_ptr;            // CSR over pairs
+  std::vector<sgp::DevTerm> h_terms;    // host copy (device pointers inside)
+  sgp::DevTerm* d_terms = nullptr;
+  std::vector<int> pair_dmax;
+  std::vector<int> term_row_input;     // spec input index each term reads its row / column points from
+  std::vector<int> term_col_input;
+  std::vector<int> in_dim;             // per spec input
+  std::vector<long> in_n;
+};

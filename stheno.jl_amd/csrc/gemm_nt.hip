@@ -407,12 +407,10 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_reg_kernel(const double* A, lo
     for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = alpha * acc[j][i];
 }
 
-static int g_gemm_variant = 0;  // 0: DMA kernel (production); 1: register-staged (bench A/B only)
-void set_gemm_variant(int v) { g_gemm_variant = v; }
-
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                    long M, long Nc, long K, double alpha, double beta, long mask_off,
                    int kcap_mode, long kcap_off, hipStream_t s) {
+  constexpr long REG_BASELINE = -(1L << 50);  // kcap_mode == 0 and this kcap_off: see below
   if (M <= 0 || Nc <= 0) return 0;
   if (M % TILE || Nc % TILE || K % KB) {
     set_error("gemm_nt: M, Nc must be multiples of 128 and K of 16");
@@ -425,9 +423,9 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
   if (kcap_mode)
     hipLaunchKernelGGL((gemm_nt_reg_kernel<true>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
                        beta, mask_off, kcap_off, n_tr, n_tc);
-  else if (g_gemm_variant == 1)
+  else if (kcap_off == REG_BASELINE)  // bench A/B only (sgp_bench_gemm): the register-staged kernel
     hipLaunchKernelGGL((gemm_nt_reg_kernel<false>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
-                       beta, mask_off, kcap_off, n_tr, n_tc);
+                       beta, mask_off, 0L, n_tr, n_tc);
   else
     hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
                        mask_off, n_tr, n_tc, 0L, (const double*)C, ldc, 0);
@@ -442,7 +440,6 @@ int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M
     set_error("gemm_nt_update: M, Nc must be multiples of 128 and K of 16");
     return -1;
   }
-  if (g_gemm_variant == 1) return launch_gemm_nt(P, ldp, P, ldp, C, ldc, M, Nc, K, -1.0, 1.0, 0, 0, 0, s);
   long n_tr = M / TILE, n_tc = Nc / TILE;
   long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc));
   hipLaunchKernelGGL(gemm_nt_dma_kernel<1>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, P, ldp, C, ldc, K,

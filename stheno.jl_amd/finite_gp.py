@@ -98,10 +98,14 @@ def prior_var(f, x):
 
 
 def mean(fx):
+    if isinstance(fx, SparseFiniteGP):     # sparse_finite_gp.jl:37
+        return mean(fx.fobs)
     return prior_mean(fx.f, fx.x)
 
 
 def cov(fx, gx=None):
+    if isinstance(fx, SparseFiniteGP):     # sparse_finite_gp.jl:39-43: explicit error, use cov(f.fobs)
+        raise RuntimeError(_COV_ERR)
     if gx is None:
         return prior_cov(fx.f, fx.x) + _noise_dense(fx.noise, len(fx))
     # src/gp/util.jl:12-14: cov(fx, gx) = cov(fx.f, gx.f, fx.x, gx.x) -- no noise
@@ -112,6 +116,8 @@ def cov(fx, gx=None):
 
 
 def var(fx):
+    if isinstance(fx, SparseFiniteGP):
+        return var(fx.fobs)
     return prior_var(fx.f, fx.x) + _noise_diag(fx.noise, len(fx))
 
 
@@ -120,6 +126,8 @@ def mean_and_cov(fx):
 
 
 def mean_and_var(fx):
+    if isinstance(fx, SparseFiniteGP):
+        return mean_and_var(fx.fobs)
     if isinstance(fx.f, (PosteriorGP, ApproxPosteriorGP)):
         m, v = fx.f.mean_and_var(fx.x)
         return m, v + _noise_diag(fx.noise, len(fx))
@@ -214,26 +222,7 @@ def logpdf_and_gradient(fx, y, inputs=False):
                                         _lib.dptr(yv), _lib.dptr(lp), _lib.dptr(gy), _lib.dptr(gm), _lib.dptr(gn),
                                         _lib.dptr(gc), _lib.dptr(gs))
         _lib.check(rc, "sgp_logpdf_grad")
-    terms, nrb = [], len(spec.row_len)
-    tp = spec._term_ptr
-    index = {}
-    for I in range(nrb):
-        for J in range(nrb):
-            for t in range(tp[I * nrb + J], tp[I * nrb + J + 1]):
-                T = spec._terms[t]
-                if I >= J:
-                    key = (I, J, T.kind, T.row_input, T.col_input, T.param)
-                    index[key] = len(terms)
-                    terms.append(dict(I=I, J=J, kind=T.kind, coef=T.coef, row_input=T.row_input,
-                                      col_input=T.col_input, d_coef=float(gc[t]), d_inscale=float(gs[t])))
-    for I in range(nrb):            # fold the mirror-image pairs in
-        for J in range(I + 1, nrb):
-            for t in range(tp[I * nrb + J], tp[I * nrb + J + 1]):
-                T = spec._terms[t]
-                k = index.get((J, I, T.kind, T.col_input, T.row_input, T.param))
-                if k is not None:
-                    terms[k]["d_coef"] += float(gc[t])
-                    terms[k]["d_inscale"] += float(gs[t])
+    terms = _term_records(spec, gc, gs, True)
     # x: the same gradient mapped back through the model's input transformations onto the blocks of
     # fx.x (one (D, n) array per block; blocks sharing one input object get their joint gradient in
     # the first of them)
@@ -410,27 +399,34 @@ def elbo(vfe, fx, y=None):
 
 def _term_records(spec, gc, gs, symmetric):
     """One record per flattened term.  For a symmetric spec the mirror-image pair (J, I) is folded
-    into the lower pair (I >= J), as in logpdf_and_gradient."""
+    into the lower pair (I >= J).  The mirror of a term with row / column scale vectors (rs, cs) is
+    the term of (J, I) with the inputs AND the scales swapped -- several terms of one block pair may
+    differ only in their scales (f3 = f1 + sin * f1 over two blocks), so the scale identities are
+    part of the match."""
     nrb, ncb = len(spec.row_len), len(spec.col_len)
     tp, out, index = spec._term_ptr, [], {}
+    sid = spec.term_scale_ids
     for I in range(nrb):
         for J in range(ncb):
             for t in range(tp[I * ncb + J], tp[I * ncb + J + 1]):
                 T = spec._terms[t]
                 if symmetric and I < J:
                     continue
-                index[(I, J, T.kind, T.row_input, T.col_input, T.param)] = len(out)
+                index[(I, J, T.kind, T.row_input, T.col_input, T.param, sid[t][0], sid[t][1])] = len(out)
                 out.append(dict(I=I, J=J, kind=T.kind, coef=T.coef, row_input=T.row_input, col_input=T.col_input,
-                                d_coef=float(gc[t]), d_inscale=float(gs[t])))
+                                row_scaled=sid[t][0] is not None, col_scaled=sid[t][1] is not None,
+                                t=t, mirror_t=None, d_coef=float(gc[t]), d_inscale=float(gs[t])))
     if symmetric:
         for I in range(nrb):
             for J in range(I + 1, ncb):
                 for t in range(tp[I * ncb + J], tp[I * ncb + J + 1]):
                     T = spec._terms[t]
-                    k = index.get((J, I, T.kind, T.col_input, T.row_input, T.param))
-                    if k is not None:
-                        out[k]["d_coef"] += float(gc[t])
-                        out[k]["d_inscale"] += float(gs[t])
+                    k = index.get((J, I, T.kind, T.col_input, T.row_input, T.param, sid[t][1], sid[t][0]))
+                    if k is None:
+                        raise AssertionError("symmetric spec without a mirror term: flattener invariant broken")
+                    out[k]["mirror_t"] = t
+                    out[k]["d_coef"] += float(gc[t])
+                    out[k]["d_inscale"] += float(gs[t])
     return out
 
 

@@ -64,6 +64,13 @@ def block_list(f, x):
         for g, b in zip(f.args[1], blocks(x)):
             out.extend(block_list(g, b))
         return out
+    if isinstance(x, BlockData):
+        # BlockData is an ordinary AbstractVector for any GP (input_collection_types.jl:61-95): the
+        # same process evaluated on each block
+        out = []
+        for b in blocks(x):
+            out.extend(block_list(f, b))
+        return out
     return [(f, x)]
 
 

@@ -219,6 +219,9 @@ def mean_vector(f, x):
     if isinstance(f, GPPP):
         node, v = extract_components(f, x)
         return mean_vector(node, v)
+    if isinstance(x, BlockData) and not (isinstance(f, DerivedGP) and f.args[0] == "cross"):
+        # BlockData is an ordinary AbstractVector for any GP: the same process on each block
+        return np.concatenate([mean_vector(f, b) for b in blocks(x)]) if len(blocks(x)) else np.zeros(0)
     if isinstance(f, AtomicGP):
         if isinstance(f.gp, GP):
             return f.gp.mean_vector(x)

@@ -61,6 +61,9 @@ _SIGS = {
     "sgp_abi_version": (C.c_int, []),
     "sgp_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
     "sgp_ctx_destroy": (C.c_int, [_P]),
+    "sgp_ctx_trim": (C.c_int, [_P]),
+    "sgp_ctx_stage_timing": (C.c_int, [_P, C.c_int]),
+    "sgp_ctx_stage_ms": (C.c_int, [_P, _D]),
     "sgp_last_error": (C.c_char_p, []),
     "sgp_kernelmatrix": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int64]),
     "sgp_kernelmatrix_diag": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D]),
@@ -235,6 +238,11 @@ class Spec:
         self.n_terms = len(terms)
         self._term_ptr = np.asarray(term_ptr, dtype=np.int32)
         self._terms = (sgp_term * max(1, len(terms)))()
+        # identity of each term's scale vectors (the flattener's own merge key): a term of pair (I, J)
+        # with scales (rs, cs) is mirrored in pair (J, I) by the term with (cs, rs)
+        self.term_scale_ids = [(None if rs is None else id(rs), None if cs is None else id(cs))
+                               for (_, _, _, _, _, rs, cs) in terms]
+        self._keep.extend(terms)
         for k, (kind, ri, ci, coef, param, rs, cs) in enumerate(terms):
             t = self._terms[k]
             t.kind, t.row_input, t.col_input, t.reserved = int(kind), int(ri), int(ci), 0

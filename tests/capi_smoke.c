@@ -1,0 +1,55 @@
+/* Compiled by tests/test_capi_symbols.py with `gcc -std=c99 -pedantic -Wall -Werror`: proves that
+ * include/sthenomi.h is valid plain C (what a Julia `ccall` / cgo / any FFI consumer needs) and
+ * prints the size and the offset of every field of every struct that crosses the boundary, which
+ * the test compares with the ctypes mirror in stheno.jl_amd/lib.py.  With a library path as
+ * argv[1] it also dlopens it and resolves every entry point through the C prototypes. */
+#include <stddef.h>
+#include <stdio.h>
+#include <dlfcn.h>
+
+#include "../include/sthenomi.h"
+
+#define OFF(T, f) printf("offset " #T "." #f " %zu\n", offsetof(T, f))
+
+/* sizeof(&f) is unevaluated (nothing to link) but makes the compiler check that f is declared */
+static const struct { const char* name; size_t fnptr_size; } table[] = {
+#define E(f) {#f, sizeof(&f)}
+  E(sgp_abi_version), E(sgp_ctx_create), E(sgp_ctx_destroy), E(sgp_ctx_trim), E(sgp_ctx_stage_timing), E(sgp_ctx_stage_ms), E(sgp_last_error),
+  E(sgp_kernelmatrix), E(sgp_kernelmatrix_diag), E(sgp_logpdf), E(sgp_logpdf_grad), E(sgp_logpdf_grad_x),
+  E(sgp_rand), E(sgp_posterior_create), E(sgp_posterior_predict), E(sgp_posterior_destroy),
+  E(sgp_elbo), E(sgp_elbo_grad), E(sgp_elbo_grad_x), E(sgp_kernelmatrix_diag_grad),
+  E(sgp_kernelmatrix_diag_grad_x), E(sgp_sparse_posterior_create), E(sgp_sparse_posterior_predict),
+  E(sgp_sparse_posterior_destroy), E(sgp_dspec_create), E(sgp_dspec_destroy), E(sgp_geometry),
+  E(sgp_dev_logpdf), E(sgp_dev_assemble_cols), E(sgp_dev_panel_factor), E(sgp_dev_panel_update),
+  E(sgp_dev_rowsumsq), E(sgp_bench_mfma_f64), E(sgp_bench_hbm), E(sgp_bench_gemm),
+#undef E
+};
+
+int main(int argc, char** argv) {
+  size_t i, n = sizeof(table) / sizeof(table[0]);
+  printf("abi %d\n", SGP_ABI_VERSION);
+  printf("sizeof sgp_input %zu\n", sizeof(sgp_input));
+  OFF(sgp_input, dim); OFF(sgp_input, n); OFF(sgp_input, ld); OFF(sgp_input, x);
+  printf("sizeof sgp_term %zu\n", sizeof(sgp_term));
+  OFF(sgp_term, kind); OFF(sgp_term, row_input); OFF(sgp_term, col_input); OFF(sgp_term, reserved);
+  OFF(sgp_term, coef); OFF(sgp_term, param); OFF(sgp_term, row_scale); OFF(sgp_term, col_scale);
+  printf("sizeof sgp_cov_spec %zu\n", sizeof(sgp_cov_spec));
+  OFF(sgp_cov_spec, n_row_blocks); OFF(sgp_cov_spec, n_col_blocks); OFF(sgp_cov_spec, row_len);
+  OFF(sgp_cov_spec, col_len); OFF(sgp_cov_spec, n_inputs); OFF(sgp_cov_spec, inputs);
+  OFF(sgp_cov_spec, term_ptr); OFF(sgp_cov_spec, terms); OFF(sgp_cov_spec, symmetric);
+  OFF(sgp_cov_spec, reserved);
+  printf("enum SGP_SE %d SGP_CONST %d SGP_NOISE_DENSE %d\n", SGP_SE, SGP_CONST, SGP_NOISE_DENSE);
+  if (argc > 1) {
+    void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);
+    if (!h) { printf("dlopen failed: %s\n", dlerror()); return 2; }
+    for (i = 0; i < n; ++i) {
+      if (!dlsym(h, table[i].name)) { printf("missing %s\n", table[i].name); return 3; }
+    }
+    {
+      int (*ver)(void);
+      *(void**)(&ver) = dlsym(h, "sgp_abi_version");
+      printf("loaded abi %d symbols %zu\n", ver(), n);
+    }
+  }
+  return 0;
+}

@@ -55,3 +55,31 @@ def test_spec_struct_layout_matches_header():
     assert ctypes.sizeof(P.lib.sgp_input) == 32
     assert ctypes.sizeof(P.lib.sgp_term) == 48
     assert ctypes.sizeof(P.lib.sgp_cov_spec) == 64
+
+
+def test_header_is_plain_c_and_struct_offsets_match_ctypes(tmp_path):
+    """tests/capi_smoke.c built by gcc as C99 (-pedantic -Werror) against include/sthenomi.h: the
+    header is valid C, every declared entry point is in its table (and resolvable in the .so via
+    dlsym), and sizeof / offsetof of every boundary struct equal the ctypes mirror's."""
+    import subprocess
+    exe = str(tmp_path / "capi_smoke")
+    src = os.path.join(ROOT, "tests", "capi_smoke.c")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-o", exe, src, "-ldl"])
+    out = subprocess.check_output([exe, P.lib.LIB_PATH], text=True)
+    mirror = {"sgp_input": P.lib.sgp_input, "sgp_term": P.lib.sgp_term, "sgp_cov_spec": P.lib.sgp_cov_spec}
+    seen = 0
+    for ln in out.splitlines():
+        w = ln.split()
+        if w[0] == "sizeof":
+            assert ctypes.sizeof(mirror[w[1]]) == int(w[2]), ln
+        elif w[0] == "offset":
+            st, field = w[1].split(".")
+            assert getattr(mirror[st], field).offset == int(w[2]), ln
+            seen += 1
+        elif w[0] == "loaded":
+            assert int(w[2]) == P.lib.load().sgp_abi_version()
+            assert int(w[4]) == len(header_symbols()), "tests/capi_smoke.c's table misses a declared entry point"
+    assert seen == sum(len(m._fields_) for m in mirror.values())
+    src_txt = open(src).read()
+    for s in header_symbols():
+        assert f"E({s})" in src_txt, f"{s} missing from tests/capi_smoke.c"

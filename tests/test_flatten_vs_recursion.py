@@ -189,3 +189,79 @@ def test_chain_rule_of_input_gradients_through_warps_and_kernel_scales():
             mn_[I][d, i] -= h
             fd = (phi(mp_) - phi(mn_)) / (2 * h)
             assert abs(rows[I][d, i] - fd) <= 1e-7 * max(1.0, abs(fd)), (I, d, i, rows[I][d, i], fd)
+
+
+def test_gradient_records_fold_each_mirror_term_into_its_own_lower_term():
+    """f3 = f1 + sin * f1 over two blocks gives four terms per block pair that differ only
+    in their row / column scale vectors; the mirror of (rs = a, cs = b) in pair (I, J) is (rs = b,
+    cs = a) in pair (J, I).  Checked numerically: the mirror term's matrix is the transpose of the
+    lower term's, and every upper term is folded exactly once."""
+    import np_terms
+    from stheno_jl_amd import finite_gp as fg
+    rng = np.random.default_rng(11)
+    gpc = P.GPC()
+    f1 = P.atomic(P.GP(P.SEKernel()), gpc)
+    f3 = f1 + (lambda x: float(np.sum(np.sin(x)))) * f1
+    F = P.GPPP({"f1": f1, "f3": f3}, gpc)
+    x = P.BlockData([P.GPPPInput("f3", rng.standard_normal(7)), P.GPPPInput("f3", rng.standard_normal(5)),
+                     P.GPPPInput("f1", rng.standard_normal(4))])
+    spec = P.build_spec(F, x)[0]
+    terms = np_terms.spec_terms(spec)
+    nt = len(terms)
+    assert nt == 4 * 4 + 2 * 2 * 2 + 1      # (f3,f3) pairs: 4 terms each; (f3,f1): 2; (f1,f1): 1
+    gc = np.arange(1.0, nt + 1.0)
+    gs = 100.0 + gc
+    recs = fg._term_records(spec, gc, gs, True)
+
+    def mat(t):
+        I, J, kind, ri, ci, coef, param, rs, cs = terms[t]
+        X, Y = spec.inputs[ri], spec.inputs[ci]
+        d2 = (X[0][:, None] - Y[0][None, :]) ** 2
+        blk = coef * np_terms._kern(kind, d2, param)
+        if rs is not None:
+            blk = rs[:, None] * blk
+        if cs is not None:
+            blk = blk * cs[None, :]
+        return blk
+
+    folded = set()
+    for r in recs:
+        t = r["t"]
+        if r["I"] == r["J"]:
+            assert r["mirror_t"] is None and r["d_coef"] == gc[t]
+            continue
+        m = r["mirror_t"]
+        assert m is not None and m not in folded
+        folded.add(m)
+        assert np.allclose(mat(m), mat(t).T, rtol=1e-14, atol=0)   # (a k) b vs (b k) a: rounding only
+        assert r["d_coef"] == gc[t] + gc[m] and r["d_inscale"] == gs[t] + gs[m]
+    n_upper = sum(1 for (I, J, *_) in terms if I < J)
+    assert len(folded) == n_upper
+
+
+def test_plain_gp_indexed_with_blockdata_is_an_ordinary_vector():
+    """BlockData is an AbstractVector for any GP (input_collection_types.jl:61-95), not only
+    for cross / GPPP nodes: cov(f, BlockData([a, b])) == cov(f, vcat(a, b))."""
+    import np_terms
+    rng = np.random.default_rng(5)
+    f = P.stretch(P.atomic(P.GP(np.sin, P.Matern32Kernel()), P.GPC()), 0.7)
+    a, b = rng.standard_normal(6), rng.standard_normal(9)
+    Kb = np_terms.dense_from_spec(P.build_spec(f, P.BlockData([a, b]))[0])
+    Kv = np_terms.dense_from_spec(P.build_spec(f, np.concatenate([a, b]))[0])
+    assert np.allclose(Kb, Kv, rtol=0, atol=1e-15)
+    assert np.array_equal(P.mean_vector(f, P.BlockData([a, b])), P.mean_vector(f, np.concatenate([a, b])))
+    Kc = np_terms.dense_from_spec(P.build_spec(f, P.BlockData([a, b]), f, a)[0])
+    assert np.allclose(Kc, Kv[:, :6], rtol=0, atol=1e-15)
+
+
+def test_sparse_finite_gp_dispatch_matches_reference():
+    """sparse_finite_gp.jl:37-43: mean(f) = mean(f.fobs); cov(f) raises the explicit dense-covariance
+    error.  (mean needs no GPU: prior means are host-side.)"""
+    import pytest
+    rng = np.random.default_rng(6)
+    f = P.atomic(P.GP(np.cos, P.SEKernel()), P.GPC())
+    x, z = rng.standard_normal(11), rng.standard_normal(4)
+    sf = P.SparseFiniteGP(f(x, 0.1), f(z, 1e-6))
+    assert np.array_equal(P.mean(sf), np.cos(x))
+    with pytest.raises(RuntimeError, match="covariance matrix of a sparse GP"):
+        P.cov(sf)
