@@ -12,6 +12,7 @@
 // diagonal panel" in north-star terms.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace sgp {
 
@@ -20,6 +21,22 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {
   lo = __builtin_amdgcn_readlane(lo, srclane);
   hi = __builtin_amdgcn_readlane(hi, srclane);
   return __hiloint2double(hi, lo);
+}
+
+// SGP_PANEL_PRIO=<0..3> (read once): s_setprio level of the latency-critical panel kernels' waves.  Under
+// the look-ahead they share CUs with trailing-update GEMM waves issuing MFMAs back to back; a raised
+// wave priority wins the issue arbitration for the serial pivot / substitution chains.
+static int panel_prio() {
+  static const int v = [] {
+    const char* e = getenv("SGP_PANEL_PRIO");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+__device__ __forceinline__ void set_wave_prio(int p) {
+  if (p == 1) __builtin_amdgcn_s_setprio(1);
+  if (p == 2) __builtin_amdgcn_s_setprio(2);
+  if (p >= 3) __builtin_amdgcn_s_setprio(3);
 }
 
 constexpr int PD_THREADS = 512;
@@ -34,8 +51,9 @@ __device__ __forceinline__ int boff(int rb, int cb) { return (rb * (rb + 1) / 2 
 
 __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_kernel(double* A, long ld, double* invd,
                                                                    double* logdet_slot, int* info,
-                                                                   long gcol0) {
+                                                                   long gcol0, int prio) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  set_wave_prio(prio);
   double* T = smem;               // packed lower blocks
   double* sInv = smem + 36 * 256; // [k][m]
   const int t = threadIdx.x;
@@ -177,7 +195,7 @@ int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot,
                       long gcol0, hipStream_t s) {
   SGP_LDS_ATTR_ONCE(potrf_diag_kernel, PD_LDS);
   hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PD_THREADS), PD_LDS, s, A, ld, d_invd,
-                     d_logdet_slot, d_info, gcol0);
+                     d_logdet_slot, d_info, gcol0, panel_prio());
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -199,8 +217,9 @@ constexpr size_t PS_LDS = (size_t)36 * 256 * sizeof(double);  // == one GEMM wor
 
 __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx, const double* L, long ldl,
                                                           const double* inv, long inv_cstride,
-                                                          long inv_kstride, int strips, long rows) {
+                                                          long inv_kstride, int strips, long rows, int prio) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  set_wave_prio(prio);
   double* sL = smem;  // block (c, p), c >= p at (c (c + 1) / 2 + p) * 256, [k][m]
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
@@ -271,7 +290,7 @@ int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl
   int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + 255) / 256));
   long nwg = (nstrips + strips - 1) / strips;
   hipLaunchKernelGGL(panel_solve_kernel, dim3((unsigned)nwg), dim3(256), PS_LDS, s, X, ldx, L, ldl, inv,
-                     inv_cstride, inv_kstride, strips, rows);
+                     inv_cstride, inv_kstride, strips, rows, panel_prio());
   SGP_HIP(hipGetLastError());
   return 0;
 }

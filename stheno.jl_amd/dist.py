@@ -180,22 +180,25 @@ class HipOps:
         self.torch.cuda.synchronize(self.device)
 
 
-def dist_logpdf(ops, spec, y, mean, sigma2, world=1, rank=0, group=None, W=1024, A=None, stats=None):
+def dist_logpdf(ops, spec, y, mean, sigma2, world=1, rank=0, group=None, W=1024, A=None, stats=None,
+                always_collective=False):
     """logpdf(f(X, sigma2), y) with the covariance sharded over `world` ranks.
 
     spec : lib.Spec (symmetric) of the prior covariance, identical on every rank
     y    : (N,) observations, mean: (N,) prior mean or None
     A    : optional preallocated local panel storage (m_tot * n_local_cols doubles)
+    always_collective : issue the panel broadcasts / final all-reduces even when world == 1 (a
+           one-rank RCCL communicator executes them as self-copies: exercises the backend calls)
     Every rank returns the same float.  Raises lib.PosDefException like the single-GPU path."""
     ds = ops.make_dspec(spec)
     try:
         with ops.stream_context():
-            return _dist_logpdf(ops, ds, spec.N, y, mean, sigma2, world, rank, group, W, A, stats)
+            return _dist_logpdf(ops, ds, spec.N, y, mean, sigma2, world, rank, group, W, A, stats, always_collective)
     finally:
         ops.free_dspec(ds)
 
 
-def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats):
+def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, always_collective=False):
     import torch
     import torch.distributed as dist
 
@@ -217,7 +220,7 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats):
 
     def bcast(J):
         J0, w = lay.col0(J), lay.width(J)
-        if world == 1:
+        if world == 1 and not always_collective:
             return None
         t = bufs[J % 2][: w * (m_tot - J0)]
         return dist.broadcast(t, src=_global_rank(group, lay.owner(J)), group=group, async_op=True)
@@ -290,7 +293,7 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats):
     inf = info.to(torch.float64)
     big = float(2 ** 52)
     inf = torch.where(inf > 0, inf, torch.full_like(inf, big))
-    if world > 1:
+    if world > 1 or always_collective:
         dist.all_reduce(red, op=dist.ReduceOp.SUM, group=group)
         dist.all_reduce(inf, op=dist.ReduceOp.MIN, group=group)
     red_h = ops.to_host(red)

@@ -91,3 +91,55 @@ def test_two_ranks_on_one_gpu_over_gloo(N, W):
     ref = orm.gppp_sum_logpdf(xs, y, 0.1)
     assert res[0][2] == res[1][2]
     assert abs(res[0][2] - ref) <= 1e-10 * abs(ref)
+
+
+def _nccl_worker(port, N, W, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        import torch
+        import torch.distributed as dist
+        import __graft_entry__ as entry
+        P = entry.load_package()
+        from stheno_jl_amd import dist as sdist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        # the collectives the sharded driver issues, on HIP tensors, through RCCL
+        t = torch.arange(1024, dtype=torch.float64, device="cuda")
+        dist.broadcast(t, src=0)
+        w = dist.broadcast(t, src=0, async_op=True)
+        w.wait()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        assert float(t[5]) == 5.0
+        F, x, xs, y = _problem(N)
+        spec, _, _ = P.build_spec(F, x)
+        ops = sdist.HipOps(P.lib.Context(0))
+        val = sdist.dist_logpdf(ops, spec, y, None, 0.1, world=1, rank=0, W=W, always_collective=True)
+        q.put((0, "ok", val))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((0, "error", traceback.format_exc()))
+
+
+def test_rccl_backend_executes_the_sharded_drivers_collectives():
+    """backend "nccl" == RCCL: a one-rank communicator on the single GPU runs every collective the
+    sharded driver issues (async panel broadcasts on the panel stream, final SUM / MIN all-reduces)
+    with HIP tensors -- the same calls an 8-GPU run makes, with a trivial communicator."""
+    import torch.multiprocessing as mp
+    from oracle import reference_model as orm
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    N, W = 3000, 512
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), N, W, q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert res[1] == "ok", res[2]
+    F, x, xs, y = _problem(N)
+    ref = orm.gppp_sum_logpdf(xs, y, 0.1)
+    assert abs(res[2] - ref) <= 1e-10 * abs(ref)
