@@ -289,6 +289,22 @@ int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp, int64_t p
 int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nc, int64_t nrows,
                      double* d_out, void* stream);
 
+/* ---- N-sharded ELBO (reference entry /root/reference/src/gp/sparse_finite_gp.jl:52-58) --
+ * The bound is a sum over data points up to one M x M factorisation: every rank turns ITS slice of the
+ * data (rows of xz, var_x, mean_x, noise_x, y: host pointers, as in sgp_elbo) into a "part" -- a
+ * contiguous device array of sgp_elbo_part_len(M) doubles holding  sum_n a_n a_n' (lower 128-tiles,
+ * ld = m_pad + 128), A delta and four scalars -- the parts are summed across ranks with ONE all-reduce
+ * (M^2 + M + 2 meaningful doubles; RCCL over xGMI), and any rank finishes: A A' + I, its Cholesky,
+ * the bound.  K(z,z) + Sigma_z is factored redundantly by every rank (M^3 / 3 flops, no traffic).
+ * d_part: HBM address on the ctx device, caller-owned (e.g. a torch tensor handed to all_reduce). */
+int sgp_elbo_part_len(int64_t M, int64_t* len);
+int sgp_dev_elbo_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz_slice,
+                         const double* var_x_slice, const double* mean_x_slice, int noise_kind,
+                         const double* noise_x_slice, int z_noise_kind, const double* z_noise,
+                         const double* y_slice, double* d_part, int64_t part_len);
+/* N_total: number of data points over all ranks; d_part is overwritten (factor of A A' + I) */
+int sgp_dev_elbo_finish(sgp_ctx* ctx, int64_t M, int64_t N_total, double* d_part, double* out);
+
 /* micro-benchmarks used to pin the roofline peaks on the box */
 int sgp_bench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops_out, double* layout_maxerr_out);
 int sgp_bench_hbm(sgp_ctx* ctx, int64_t bytes, int iters, double* write_gbs_out, double* copy_gbs_out);

@@ -177,6 +177,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* rf = getenv("SGP_REFINE");
     if (rf) c->refine = atoi(rf);
+    const char* il = getenv("SGP_INNER_LL");
+    if (il) c->inner_ll = atoi(il);
     const char* po = getenv("SGP_POOL");
     if (po) c->pool_enabled = atoi(po);
     SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
@@ -484,9 +486,17 @@ static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double
 // layout potrf_diag writes) for later solves against the factor; else ctx scratch.
 static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_slots,
                         int* d_info, double* d_invstore, hipStream_t s) {
+  // ctx->inner_ll: LEFT-looking inside the panel -- block column j first receives the updates of all
+  // earlier block columns of the panel in ONE product of depth K = 128 j, then is factored and solved.
+  // Same flops as the right-looking sweep (one K = 128 update of every later block column per step),
+  // but every C tile of the panel is read and written once per block column instead of once per
+  // (earlier block, block) pair and the products are deep enough for the MFMA kernel to be efficient:
+  // the K = 128 updates ran at ~25 TFLOP/s and held ~10 % of an N = 65536 step's chip time.
   for (long j = 0; j < w; j += TILE) {
     double* D = P + j + j * ld;
     double* invd = d_invstore ? d_invstore + (j / TILE) * INVD_STRIDE : ctx->d_invd;
+    if (ctx->inner_ll && j > 0)
+      CHECK_RC(launch_gemm_nt(P + j, ld, P + j, ld, D, ld, m - j, TILE, j, -1.0, 1.0, 0, 0, 0, s));
     CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s));
     long mrest = m - j - TILE;
     if (mrest > 0 && ctx->refine != 1) CHECK_RC(launch_trtri(D, ld, invd, ctx->d_w, s));  // A/B modes only
@@ -494,7 +504,7 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
       double* A21 = P + (j + TILE) + j * ld;
       CHECK_RC(solve_rows(ctx, A21, ld, mrest, ctx->d_w, D, ld, invd, 256, 16, s));  // L21 = A21 * L11^-T
       long wrest = w - j - TILE;
-      if (wrest > 0)
+      if (wrest > 0 && !ctx->inner_ll)
         CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest,
                                 TILE, -1.0, 1.0, 0, 0, 0, s));
     }
@@ -1378,15 +1388,30 @@ static void vfe_chunking(long* chunk_rows, long* above) {
   *above = v >= TILE ? v : VFE_CHUNK_ABOVE;
 }
 
-static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* dx, const double* var_x,
-                                const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
-                                const double* z_noise, const double* y, double* h, sgp_sparse_post* keep) {
+// The row-chunked pipeline is split in two so that the data points can be sharded (one
+// exchange of M^2 + M + 2 doubles): `vfe_rows_partial` turns a slice of the data into its partial
+// sums, `vfe_finish` consumes the (reduced) sums.  Layout of a "part" (device, contiguous):
+//   G    (m_pad + 128) x m_pad, ld = m_pad + 128: lower tiles of sum_n a_n a_n' (no identity yet);
+//        row m_pad is reserved for (A delta)'
+//   dots m_pad: A delta
+//   scal 8: [0] sum log s2_n, [1] delta' delta, [2] sum var_n / s2_n, [3] |A|_F^2
+static long vfe_part_len(long m_pad) { return (m_pad + TILE) * m_pad + m_pad + 8; }
+
+static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* dx, const double* var_x,
+                            const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                            const double* z_noise, const double* y, double* dLz, double* d_wz, double* d_part,
+                            StageTimer& tm) {
   const long M = dz->N, N = dx->N;
   const long m_pad = rup(M, TILE), n_rows = rup(N, TILE);
+  const long ldg = m_pad + TILE;
+  double* dG = d_part;
+  double* d_dots = d_part + ldg * m_pad;
+  double* d_sc = d_dots + m_pad;
   long CH, ch_above;
   vfe_chunking(&CH, &ch_above);
+  CH = std::min(CH, n_rows);
   hipStream_t s = ctx->stream;
-  DevBuf dLz_local, dinv_local, dR, dAt, dPart, dy, dmean, dvar, ddelta, drsig, dots, sq, dG_local;
+  DevBuf dR, dAt, dPart, dy, dmean, dvar, ddelta, drsig, sq;
   NoiseDev ndx, ndz;
   CHECK_RC(dy.upload(y, N));
   if (mean_x) CHECK_RC(dmean.upload(mean_x, N));
@@ -1395,31 +1420,17 @@ static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dsp
   CHECK_RC(upload_noise(ndz, z_noise_kind, z_noise, M));
   CHECK_RC(ddelta.alloc(n_rows));
   CHECK_RC(drsig.alloc(n_rows));
-  CHECK_RC(dots.alloc(m_pad));
   CHECK_RC(sq.alloc(m_pad));
-  double* d_o = ctx->d_scal + 1;
-  StageTimer tm(ctx, s);
   tm.mark(0);
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  SGP_HIP(hipMemsetAsync(d_part, 0, sizeof(double) * vfe_part_len(m_pad), s));
+  SGP_HIP(hipMemsetAsync(sq.p, 0, sizeof(double) * m_pad, s));
   SGP_HIP(hipMemsetAsync(ddelta.p, 0, sizeof(double) * n_rows, s));
   SGP_HIP(hipMemsetAsync(drsig.p, 0, sizeof(double) * n_rows, s));
   hipLaunchKernelGGL(elbo_scalars_kernel, dim3(1), dim3(256), 0, s, dy.p, mean_x ? dmean.p : nullptr,
-                     var_x ? dvar.p : nullptr, ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_o);
+                     var_x ? dvar.p : nullptr, ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_sc);
   SGP_HIP(hipGetLastError());
-  // ---- Lz
-  double* dLz = nullptr;
-  double* d_wz = nullptr;
-  if (keep) {
-    SGP_HIP(hipMalloc(&keep->dLz, sizeof(double) * m_pad * m_pad));
-    SGP_HIP(hipMalloc(&keep->d_wz, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
-    dLz = keep->dLz;
-    d_wz = keep->d_wz;
-  } else {
-    CHECK_RC(dLz_local.alloc((size_t)m_pad * m_pad));
-    CHECK_RC(dinv_local.alloc((size_t)(m_pad / TILE) * INVD_STRIDE));
-    dLz = dLz_local.p;
-    d_wz = dinv_local.p;
-  }
+  // ---- Lz (replicated on every rank of a sharded run: M^3 / 3 flops, no communication)
   int nkz = ndz.kind == SGP_NOISE_DENSE ? -1 : ndz.kind;
   CHECK_RC(assemble(dz, dLz, m_pad, 0, m_pad / TILE, 0, m_pad / TILE, 1, nkz, ndz.sigma2, ndz.diag.p, s));
   if (ndz.kind == SGP_NOISE_DENSE) CHECK_RC(launch_add_dense(dLz, m_pad, ndz.dense.p, M, M, 1, s));
@@ -1430,18 +1441,7 @@ static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dsp
     set_error("vfe: Kzz + Sigma_z is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
   }
-  // ---- G accumulator
-  long ldg = m_pad + TILE;
-  double* dG = nullptr;
-  if (keep) {
-    SGP_HIP(hipMalloc(&keep->dG, sizeof(double) * ldg * m_pad));
-    SGP_HIP(hipMalloc(&keep->d_wg, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
-    dG = keep->dG;
-  } else {
-    CHECK_RC(dG_local.alloc((size_t)ldg * m_pad));
-    dG = dG_local.p;
-  }
-  SGP_HIP(hipMemsetAsync(dG, 0, sizeof(double) * ldg * m_pad, s));
+  if (N == 0) return 0;
   const int nsplit = 8;  // one K slice per XCD (gemm_nt.hip, klo == 3)
   const long stride = ldg * m_pad;
   CHECK_RC(dR.alloc((size_t)CH * m_pad));
@@ -1459,38 +1459,126 @@ static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dsp
     CHECK_RC(launch_scale_rows(dR.p, ch, nv, m_pad, drsig.p + r0, s));
     CHECK_RC(row_trsm(ctx, dR.p, ch, ch, dLz, m_pad, d_wz, m_pad, s));
     tm.mark(3);
-    hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, dR.p, ch, ch, ddelta.p + r0, dots.p, sq.p,
+    hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, dR.p, ch, ch, ddelta.p + r0, d_dots, sq.p,
                        r0 > 0 ? 1 : 0);
     SGP_HIP(hipGetLastError());
     CHECK_RC(launch_transpose_add(dR.p, ch, ch, m_pad, dAt.p, m_pad, nullptr, s));
     tm.mark(4);
+    // (the split-K slices need ch to be a multiple of 16 * nsplit = 128: it is)
     CHECK_RC(launch_gemm_nt_splitk(dAt.p, m_pad, dAt.p, m_pad, dPart.p, ldg, m_pad, m_pad, ch, nsplit, stride, 1, s));
     CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, r0 > 0 ? 1.0 : 0.0, 1, s));
   }
   tm.mark(5);
-  CHECK_RC(launch_sum_array(sq.p, m_pad, ctx->d_scal + 4, s));
+  CHECK_RC(launch_sum_array(sq.p, m_pad, d_sc + 3, s));
+  SGP_HIP(hipStreamSynchronize(s));  // chunk buffers go back to the cache at scope exit
+  return 0;
+}
+
+// h[0..5] as documented at vfe_pipeline; d_wg (optional) keeps the inverse diagonal blocks of Le
+static int vfe_finish(sgp_ctx* ctx, double* d_part, long m_pad, double* d_wg, double* h, StageTimer& tm) {
+  hipStream_t s = ctx->stream;
+  const long ldg = m_pad + TILE;
+  double* dG = d_part;
+  double* d_dots = d_part + ldg * m_pad;
+  double* d_sc = d_dots + m_pad;
+  tm.mark(5);
   hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg, m_pad);
-  hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg, m_pad, dots.p,
+  hipLaunchKernelGGL(set_row_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG, ldg, m_pad, d_dots,
                      m_pad);
   SGP_HIP(hipGetLastError());
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
-  CHECK_RC(chol_bordered(ctx, dG, ldg, m_pad, ldg, keep ? keep->d_wg : nullptr, s));
-  CHECK_RC(launch_sum_array(ctx->d_slots, m_pad / TILE, ctx->d_scal + 5, s));
-  CHECK_RC(launch_rowsumsq(dG + m_pad, ldg, m_pad, 1, ctx->d_scal + 6, 0, s));
-  SGP_HIP(hipMemcpyAsync(h, ctx->d_scal + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
+  CHECK_RC(chol_bordered(ctx, dG, ldg, m_pad, ldg, d_wg, s));
+  CHECK_RC(launch_sum_array(ctx->d_slots, m_pad / TILE, d_sc + 4, s));
+  CHECK_RC(launch_rowsumsq(dG + m_pad, ldg, m_pad, 1, d_sc + 5, 0, s));
+  SGP_HIP(hipMemcpyAsync(h, d_sc, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
   tm.finish();
-  info = fetch_info(ctx, s);
+  int info = fetch_info(ctx, s);
   if (info > 0) {
     set_error("vfe: A A' + I is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
   }
+  return 0;
+}
+
+static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* dx, const double* var_x,
+                                const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                                const double* z_noise, const double* y, double* h, sgp_sparse_post* keep) {
+  const long M = dz->N;
+  const long m_pad = rup(M, TILE);
+  DevBuf dLz_local, dinv_local, dG_local;
+  double *dLz = nullptr, *d_wz = nullptr, *d_part = nullptr;
+  if (keep) {
+    SGP_HIP(hipMalloc(&keep->dLz, sizeof(double) * m_pad * m_pad));
+    SGP_HIP(hipMalloc(&keep->d_wz, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
+    SGP_HIP(hipMalloc(&keep->dG, sizeof(double) * vfe_part_len(m_pad)));
+    SGP_HIP(hipMalloc(&keep->d_wg, sizeof(double) * (m_pad / TILE) * INVD_STRIDE));
+    dLz = keep->dLz;
+    d_wz = keep->d_wz;
+    d_part = keep->dG;
+  } else {
+    CHECK_RC(dLz_local.alloc((size_t)m_pad * m_pad));
+    CHECK_RC(dinv_local.alloc((size_t)(m_pad / TILE) * INVD_STRIDE));
+    CHECK_RC(dG_local.alloc((size_t)vfe_part_len(m_pad)));
+    dLz = dLz_local.p;
+    d_wz = dinv_local.p;
+    d_part = dG_local.p;
+  }
+  StageTimer tm(ctx, ctx->stream);
+  CHECK_RC(vfe_rows_partial(ctx, dz, dx, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, dLz, d_wz,
+                            d_part, tm));
+  CHECK_RC(vfe_finish(ctx, d_part, m_pad, keep ? keep->d_wg : nullptr, h, tm));
   if (keep) {
     keep->ctx = ctx;
     keep->M = M;
     keep->m_pad = m_pad;
-    keep->ldg = ldg;
+    keep->ldg = m_pad + TILE;
   }
-  SGP_HIP(hipStreamSynchronize(s));  // chunk buffers are freed at scope exit
+  return 0;
+}
+
+// ---- N-sharded ELBO building blocks (device pointers, see sthenomi.h) ---------------
+extern "C" int sgp_elbo_part_len(int64_t M, int64_t* len) {
+  CHECK_ARG(M >= 1 && len, "sgp_elbo_part_len: bad argument");
+  *len = vfe_part_len(rup(M, TILE));
+  return 0;
+}
+
+extern "C" int sgp_dev_elbo_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
+                                    const double* var_x, const double* mean_x, int noise_kind,
+                                    const double* noise_x, int z_noise_kind, const double* z_noise,
+                                    const double* y, double* d_part, int64_t part_len) {
+  CHECK_ARG(ctx && zz && xz && noise_x && z_noise && d_part, "sgp_dev_elbo_partial: NULL argument");
+  CHECK_ARG(zz->symmetric, "vfe: zz spec must be symmetric");
+  CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+            "vfe: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
+  CtxScope scope(ctx);
+  SpecGuard gz, gx;
+  CHECK_RC(dspec_create(ctx, zz, &gz.ds));
+  CHECK_RC(dspec_create(ctx, xz, &gx.ds));
+  const long M = gz.ds->N, N = gx.ds->N;
+  CHECK_ARG(gx.ds->M == M && M >= 1, "vfe: xz spec columns != number of inducing points");
+  CHECK_ARG(N == 0 || (var_x && y), "sgp_dev_elbo_partial: NULL data");
+  const long m_pad = rup(M, TILE);
+  CHECK_ARG(part_len >= vfe_part_len(m_pad), "sgp_dev_elbo_partial: part buffer too small (sgp_elbo_part_len)");
+  DevBuf dLz, dwz;
+  CHECK_RC(dLz.alloc((size_t)m_pad * m_pad));
+  CHECK_RC(dwz.alloc((size_t)(m_pad / TILE) * INVD_STRIDE));
+  StageTimer tm(ctx, ctx->stream);
+  CHECK_RC(vfe_rows_partial(ctx, gz.ds, gx.ds, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, dLz.p,
+                            dwz.p, d_part, tm));
+  tm.finish();
+  return 0;
+}
+
+extern "C" int sgp_dev_elbo_finish(sgp_ctx* ctx, int64_t M, int64_t N_total, double* d_part, double* out) {
+  CHECK_ARG(ctx && d_part && out && M >= 1 && N_total >= 1, "sgp_dev_elbo_finish: bad argument");
+  CtxScope scope(ctx);
+  double h[6];
+  StageTimer tm(ctx, ctx->stream);
+  CHECK_RC(vfe_finish(ctx, d_part, rup(M, TILE), nullptr, h, tm));
+  double tmp = h[0] + h[4] + h[1] - h[5];
+  double dtc = -0.5 * ((double)N_total * 1.8378770664093453 + tmp);
+  out[0] = dtc - 0.5 * (h[2] - h[3]);
   return 0;
 }
 

@@ -29,6 +29,44 @@ __device__ __forceinline__ double mfma44_f64(double a, double b, double c) {
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 
+// ---- fp64 elementary functions of the covariance kernels -----------------------------------------
+// The assembly kernel is fp64-VALU bound: libm's exp / sqrt / a true division
+// cost it ~100 issue slots per Matern-5/2 entry.  These straight-line versions (no special-case
+// branches; arguments are known to be <= 0 resp. >= 0) are accurate to ~1 ulp, which is far inside
+// the 1e-12 entry-wise parity the tests hold against the CPU oracle.
+// exp(x) for x <= 0: n = rint(x log2 e), r = x - n ln2 (two-part), degree-13 Taylor on |r| <= 0.347
+// (remainder 4e-18), scaled by 2^n with v_ldexp_f64 (correct down to denormals / 0).
+__device__ __forceinline__ double exp_nonpos(double x) {
+  x = fmax(x, -800.0);
+  const double n = __builtin_rint(x * 1.4426950408889634);
+  double r = fma(n, -6.93147180369123816490e-01, x);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = 1.6059043836821613e-10;          // 1/13!
+  p = fma(p, r, 2.08767569878681e-09);        // 1/12!
+  p = fma(p, r, 2.505210838544172e-08);       // 1/11!
+  p = fma(p, r, 2.755731922398589e-07);       // 1/10!
+  p = fma(p, r, 2.7557319223985893e-06);      // 1/9!
+  p = fma(p, r, 2.48015873015873e-05);        // 1/8!
+  p = fma(p, r, 0.0001984126984126984);       // 1/7!
+  p = fma(p, r, 0.001388888888888889);        // 1/6!
+  p = fma(p, r, 0.008333333333333333);        // 1/5!
+  p = fma(p, r, 0.041666666666666664);        // 1/4!
+  p = fma(p, r, 0.16666666666666666);         // 1/3!
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return __builtin_ldexp(p, (int)n);
+}
+// sqrt(a) for a >= 0 (0 -> 0): v_rsq_f64 seed, two Newton steps on 1/sqrt, one correction of the root
+__device__ __forceinline__ double sqrt_nonneg(double a) {
+  double r = __builtin_amdgcn_rsq(a);
+  r = r * fma(-0.5 * a, r * r, 1.5);
+  r = r * fma(-0.5 * a, r * r, 1.5);
+  double d = a * r;
+  d = fma(0.5 * r, fma(-d, d, a), d);
+  return a > 0.0 ? d : 0.0;
+}
+
 // device-side description of one covariance term of one block pair
 struct DevTerm {
   int kind;

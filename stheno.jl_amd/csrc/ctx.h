@@ -29,6 +29,7 @@ struct sgp_ctx {
   double* d_w = nullptr;       // 128 x 128 scratch inverse
   double* d_solve = nullptr;   // rows x 128 scratch of the refined panel solve (grown on demand)
   long n_solve_rows = 0;
+  int inner_ll = 0;            // SGP_INNER_LL=1: left-looking block columns inside an outer panel
   int refine = 1;              // SGP_REFINE=0: plain explicit-inverse panel solve (A/B timing only)
   double* d_slots = nullptr;   // per-128-block logdet contributions
   long n_slots = 0;

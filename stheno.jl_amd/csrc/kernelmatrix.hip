@@ -23,15 +23,15 @@ enum { K_SE = 0, K_M12 = 1, K_M32 = 2, K_M52 = 3, K_WHITE = 4, K_CONST = 5 };
 
 template <int KIND>
 __device__ __forceinline__ double kern_eval_t(double d2, double param) {
-  if (KIND == K_SE) return exp(-0.5 * d2);
-  if (KIND == K_M12) return exp(-sqrt(d2));
+  if (KIND == K_SE) return exp_nonpos(-0.5 * d2);
+  if (KIND == K_M12) return exp_nonpos(-sqrt_nonneg(d2));
   if (KIND == K_M32) {
-    double l = 1.7320508075688772 * sqrt(d2);
-    return (1.0 + l) * exp(-l);
+    double l = 1.7320508075688772 * sqrt_nonneg(d2);
+    return (1.0 + l) * exp_nonpos(-l);
   }
   if (KIND == K_M52) {
-    double l = 2.23606797749979 * sqrt(d2);
-    return (1.0 + l + l * l / 3.0) * exp(-l);
+    double l = 2.23606797749979 * sqrt_nonneg(d2);
+    return fma(l, fma(l, 0.3333333333333333, 1.0), 1.0) * exp_nonpos(-l);   // 1 + l + l^2 / 3
   }
   if (KIND == K_WHITE) return d2 == 0.0 ? 1.0 : 0.0;
   return param;

@@ -49,6 +49,70 @@ constexpr int PD_THREADS = 512;
 constexpr size_t PD_LDS = (size_t)(36 * 256 + 256) * sizeof(double);
 __device__ __forceinline__ int boff(int rb, int cb) { return (rb * (rb + 1) / 2 + cb) * 256; }
 
+// wave-uniform (rb, cb) of packed lower block `blk` (blk = rb (rb + 1) / 2 + cb)
+__device__ __forceinline__ void block_rc(int blk, int& rb, int& cb) {
+  rb = 0;
+#pragma unroll
+  for (int q = 1; q < 8; ++q) rb += (q * (q + 1) / 2 <= blk) ? 1 : 0;
+  cb = blk - rb * (rb + 1) / 2;
+}
+
+// 16x16 micro-Cholesky of the packed block Dcc in the registers of ONE wave (lanes 0..15 hold the rows
+// of the block, lanes 16..31 carry the rows of the identity through the same right-looking updates,
+// so inv(L)' falls out for free).  128 dependent pivots per diagonal block are the serial critical path
+// of the whole factorisation, hence: sqrt and reciprocal from one v_rsq_f64 + two Newton steps (the
+// reciprocal goes into the updates as soon as it exists; the correctly rounded root is finished off
+// the chain), and lane c2 = j + 1 is updated first so the next pivot is available early.
+__device__ __forceinline__ void micro_cholesky(double* Dcc, double* sInv, double* invd_g, int cb, int lane,
+                                               int& firstbad) {
+  const int i = lane & 15;
+  const bool lrow = lane < 16;
+  double row[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    double a = Dcc[c * 16 + i];
+    row[c] = lrow ? a : ((c == i) ? 1.0 : 0.0);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const double djj = bcast_lane(row[j], j);
+    firstbad = (!(djj > 0.0) && firstbad < 0) ? cb * 16 + j : firstbad;
+    const double h = -0.5 * djj;
+    double r = __builtin_amdgcn_rsq(djj);
+    r = r * fma(h * r, r, 1.5);
+    r = r * fma(h * r, r, 1.5);                  // 1 / sqrt(djj) to rounding level
+    const double lij = row[j] * r;
+#pragma unroll
+    for (int c2 = j + 1; c2 < 16; ++c2) {
+      const double lcj = bcast_lane(lij, c2);    // L[c2][j] lives in lane c2
+      row[c2] = fma(-lij, lcj, row[c2]);
+    }
+    double d = djj * r;
+    d = fma(0.5 * r, fma(-d, d, djj), d);        // sqrt(djj), off the dependency chain
+    row[j] = (lrow && i == j) ? d : lij;
+  }
+  if (lrow) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) Dcc[c * 16 + i] = (c <= i) ? row[c] : 0.0;
+  } else if (lane < 32) {
+    // lane 16 + i holds row i of inv(L)^T, i.e. column i of inv(L): Inv[c][i] = row[c], c >= i
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      double v = (c >= i) ? row[c] : 0.0;
+      sInv[i * 16 + c] = v;  // k-major: Inv[m = c][k = i]
+      invd_g[cb * 256 + i * 16 + c] = v;
+    }
+  }
+}
+
+// Right-looking over the eight 16-column sub-panels, software-pipelined so that the serial pivot chain
+// of sub-panel cb + 1 (wave 0) runs under the trailing updates of sub-panel cb (waves 1..7):
+//   A: wave 0: micro-Cholesky of block (cb, cb) + its inverse             | barrier
+//   B: waves:  X = T[rb][cb] inv(L_cc)' (+ one refinement step), rb > cb  | barrier
+//   C: wave 0: T[cb+1][cb+1] -= X X'  and straight on to A of cb + 1;
+//      waves 1..7: every other trailing block T[rb][cc] -= X_rb X_cc', cb < cc <= rb
+// Every MFMA chain on the critical path is 4 (update) or 12 (refined solve) instructions deep; the
+// left-looking form this replaces accumulated up to 28 dependent MFMAs per sub-panel (44 -> ~27 us).
 __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_kernel(double* A, long ld, double* invd,
                                                                    double* logdet_slot, int* info,
                                                                    long gcol0, int prio) {
@@ -57,92 +121,35 @@ __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_kernel(double* A, lo
   double* T = smem;               // packed lower blocks
   double* sInv = smem + 36 * 256; // [k][m]
   const int t = threadIdx.x;
-  const int lane = t & 63, w = t >> 6;
+  const int lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int aoff = lq * 16 + l15;  // operand element of k-step ks: + ks * 64
 
-  for (int idx = t; idx < 36 * 256; idx += PD_THREADS) {
-    int blk = idx >> 8, e = idx & 255, k = e >> 4, m = e & 15;
-    int rb = 0;
-    while ((rb + 1) * (rb + 2) / 2 <= blk) ++rb;
-    int cb = blk - rb * (rb + 1) / 2;
-    int r = rb * 16 + m, c = cb * 16 + k;
-    T[idx] = (r >= c) ? A[r + (long)c * ld] : 0.0;
+  // one wave per packed block, four elements per lane: all loads of a wave are independent
+  for (int blk = w; blk < 36; blk += 8) {
+    int rb, cb;
+    block_rc(blk, rb, cb);
+    double v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = lane + 64 * q, k = e >> 4, m = e & 15;
+      const int r = rb * 16 + m, c = cb * 16 + k;
+      v[q] = (r >= c) ? A[r + (long)c * ld] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) T[blk * 256 + lane + 64 * q] = v[q];
   }
   __syncthreads();
 
   int firstbad = -1;
+  if (w == 0) micro_cholesky(T + boff(0, 0), sInv, invd, 0, lane, firstbad);
+  __syncthreads();
 
   for (int cb = 0; cb < 8; ++cb) {
-    // (1) left-looking update of sub-panel cb, row-blocks rb >= cb (one per wave)
-    if (cb > 0) {
-      int rb = cb + w;
-      if (rb < 8) {
-        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int p = 0; p < cb; ++p) {
-          const double* pa = T + boff(cb, p) + aoff;  // L[cb16+m][p16+k]
-          const double* pb = T + boff(rb, p) + aoff;  // L[rb16+n][p16+k]
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) acc = mfma_f64(pa[ks * 64], pb[ks * 64], acc);
-        }
-        // acc[r] = sum_k L[cb16 + lq+4r][k] * L[rb16 + l15][k]
-        double* pc = T + boff(rb, cb) + aoff;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pc[r * 64] -= acc[r];
-      }
-    }
-    __syncthreads();
-
-    // (2) wave 0: 16x16 micro-Cholesky in registers; lanes 16..31 carry the rows of the identity
-    // through the same right-looking updates (X <- X L^-T), so inv(L)^T falls out for free.
     double* Dcc = T + boff(cb, cb);
-    if (w == 0) {
-      const int i = l15;
-      const bool lrow = lane < 16;       // lanes holding rows of the block itself
-      double row[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        double a = Dcc[c * 16 + i];
-        row[c] = lrow ? a : ((c == i) ? 1.0 : 0.0);
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        double djj = bcast_lane(row[j], j);
-        firstbad = (!(djj > 0.0) && firstbad < 0) ? cb * 16 + j : firstbad;
-        // sqrt and reciprocal from one v_rsq_f64 + Newton steps: this chain is the serial
-        // critical path of the whole factorisation (128 dependent pivots per diagonal block)
-        double r = __builtin_amdgcn_rsq(djj);
-        r = r * fma(-0.5 * djj, r * r, 1.5);
-        r = r * fma(-0.5 * djj, r * r, 1.5);
-        double d = djj * r;
-        d = fma(0.5 * r, fma(-d, d, djj), d);      // d = sqrt(djj)
-        double rinv = fma(r, fma(-d, r, 1.0), r);  // 1 / d
-        double lij = row[j] * rinv;
-        row[j] = (lrow && i == j) ? d : lij;
-#pragma unroll
-        for (int c2 = j + 1; c2 < 16; ++c2) {
-          double lcj = bcast_lane(row[j], c2);  // L[c2][j] lives in lane c2
-          row[c2] = fma(-lij, lcj, row[c2]);
-        }
-      }
-      if (lrow) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) Dcc[c * 16 + i] = (c <= i) ? row[c] : 0.0;
-      } else if (lane < 32) {
-        // lane 16 + i holds row i of inv(L)^T, i.e. column i of inv(L): Inv[c][i] = row[c], c >= i
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          double v = (c >= i) ? row[c] : 0.0;
-          sInv[i * 16 + c] = v;  // k-major: Inv[m = c][k = i]
-          invd[cb * 256 + i * 16 + c] = v;
-        }
-      }
-    }
-    __syncthreads();
-
-    // (3) sub-panel solve: X = T[rb][cb] * inv(Lcc)^T for rb > cb
+    // (B) sub-panel solve: X = T[rb][cb] * inv(Lcc)^T for rb > cb, one row block per wave
     {
-      int rb = cb + 1 + w;
+      const int rb = cb + 1 + w;
       if (rb < 8) {
         double* pc = T + boff(rb, cb) + aoff;  // element [row rb16 + l15][col cb16 + 4 ks + lq] at pc[ks * 64]
         const double* pi = sInv + aoff;        // Inv[m = l15][k = 4 ks + lq]
@@ -170,6 +177,31 @@ __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_kernel(double* A, lo
       }
     }
     __syncthreads();
+    if (cb == 7) break;
+    // (C) trailing updates T[rb][cc] -= X_rb X_cc' (cb < cc <= rb).  Enumeration e = 0 is the next
+    // diagonal block: wave 0 takes it alone and goes on to the next micro-Cholesky; blocks e >= 1 are
+    // dealt round-robin to waves 1..7.
+    {
+      const int nrem = 7 - cb;                  // remaining block rows / columns
+      const int nblk = nrem * (nrem + 1) / 2;
+      for (int e = (w == 0 ? 0 : w); e < (w == 0 ? 1 : nblk); e += 7) {
+        int rr, cc;
+        block_rc(e, rr, cc);                    // lower-triangular enumeration of the trailing blocks
+        const int rb = cb + 1 + rr, cn = cb + 1 + cc;
+        const double* pa = T + boff(cn, cb) + aoff;  // A operand: X_cc[m = l15][k]
+        const double* pb = T + boff(rb, cb) + aoff;  // B operand: X_rb[n = l15][k]
+        d4 acc = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) acc = mfma_f64(pa[ks * 64], pb[ks * 64], acc);
+        // acc[r] = sum_k X[cn16 + lq + 4r][k] X[rb16 + l15][k]  ->  block (rb, cn), row l15, col lq + 4r
+        double* pc = T + boff(rb, cn) + aoff;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pc[r * 64] -= acc[r];
+      }
+      // (A) of the next sub-panel: block (cb + 1, cb + 1) was updated by this very wave
+      if (w == 0) micro_cholesky(T + boff(cb + 1, cb + 1), sInv, invd, cb + 1, lane, firstbad);
+    }
+    __syncthreads();
   }
 
   for (int idx = t; idx < TILE * TILE; idx += PD_THREADS) {
@@ -183,6 +215,7 @@ __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_kernel(double* A, lo
   if (t < TILE) lg = log(T[boff(t >> 4, t >> 4) + (t & 15) * 17]);
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) lg += __shfl_xor(lg, off, 64);
+  __syncthreads();  // sInv is reused below
   if (t < TILE && lane == 0) sInv[w] = lg;
   __syncthreads();
   if (t == 0) {
@@ -224,12 +257,20 @@ __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
-  for (int idx = t; idx < 36 * 256; idx += 256) {
-    int blk = idx >> 8, e = idx & 255, k = e >> 4, m = e & 15;
-    int c = 0;
-    while ((c + 1) * (c + 2) / 2 <= blk) ++c;
-    int p = blk - c * (c + 1) / 2;
-    sL[idx] = L[(16 * c + m) + (long)(16 * p + k) * ldl];
+  {  // one wave per packed block of L11, four elements per lane: every load of a wave is independent
+    const int wu = __builtin_amdgcn_readfirstlane(w);
+    for (int blk = wu; blk < 36; blk += 4) {
+      int c, p;
+      block_rc(blk, c, p);
+      double v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = lane + 64 * q, k = e >> 4, m = e & 15;
+        v[q] = L[(16 * c + m) + (long)(16 * p + k) * ldl];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sL[blk * 256 + lane + 64 * q] = v[q];
+    }
   }
   __syncthreads();
   const int aoff = lq * 16 + l15;  // A operand of k-step ks: [k = 4 ks + lq][m = l15]

@@ -105,6 +105,10 @@ _SIGS = {
     "sgp_dev_panel_update": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64,
                                        C.c_int64, C.c_int64, C.c_int64, _P]),
     "sgp_dev_rowsumsq": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
+    "sgp_elbo_part_len": (C.c_int, [C.c_int64, C.POINTER(C.c_int64)]),
+    "sgp_dev_elbo_partial": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D,
+                                       C.c_int, _D, _D, _P, C.c_int64]),
+    "sgp_dev_elbo_finish": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _D]),
     "sgp_bench_mfma_f64": (C.c_int, [_P, C.c_int, _D, _D]),
     "sgp_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D]),
     "sgp_bench_gemm": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _D, _D]),

@@ -120,3 +120,43 @@ class NumpyOps:
         M = self._mat(A, col_off, m_tot, nc)
         for s in range(nrows):
             out[s] += float((M[n_pad + s, :nc] ** 2).sum())
+
+    # -- sharded ELBO: same "part" contract as sgp_dev_elbo_partial / sgp_dev_elbo_finish (sums over the
+    # rank's data slice that add up across ranks), stated with dense NumPy algebra (App. A.6)
+    def prior_var(self, f, x):
+        import stheno_jl_amd as P
+        if len(x) == 0:
+            return np.zeros(0)
+        return np.diag(np_terms.dense_from_spec(P.build_spec(f, x)[0])).copy()
+
+    def elbo_part(self, M):
+        return torch.zeros(M * M + M + 4, dtype=torch.float64)
+
+    def elbo_partial(self, zz, xz, var_x, mean_x, nk, nbuf, zk, zbuf, y, part):
+        self.calls.append(("elbo_partial", xz.N, xz.M))
+        M = zz.N
+        Kzz = np_terms.dense_from_spec(zz)
+        Sz = (float(zbuf[0]) * np.eye(M)) if zk == 0 else (np.diag(zbuf) if zk == 1 else np.asarray(zbuf).reshape(M, M))
+        Lz = np.linalg.cholesky(Kzz + Sz)
+        n = xz.N
+        p = part.numpy()
+        p[:] = 0.0
+        if n == 0:
+            return
+        s2 = np.full(n, float(nbuf[0])) if nk == 0 else np.asarray(nbuf)
+        Kxz = np_terms.dense_from_spec(xz)
+        A = np.linalg.solve(Lz, (Kxz / np.sqrt(s2)[:, None]).T)          # M x n
+        delta = (np.asarray(y) - (mean_x if mean_x is not None else 0.0)) / np.sqrt(s2)
+        p[:M * M] = (A @ A.T).ravel()
+        p[M * M:M * M + M] = A @ delta
+        p[M * M + M:] = [np.log(s2).sum(), delta @ delta, (var_x / s2).sum(), (A * A).sum()]
+
+    def elbo_finish(self, M, N_total, part):
+        p = part.numpy()
+        B = p[:M * M].reshape(M, M) + np.eye(M)
+        Ad = p[M * M:M * M + M]
+        h0, h1, h2, h3 = p[M * M + M:]
+        Le = np.linalg.cholesky(B)
+        w = np.linalg.solve(Le, Ad)
+        tmp = h0 + 2.0 * np.log(np.diag(Le)).sum() + h1 - w @ w
+        return float(-0.5 * (N_total * np.log(2.0 * np.pi) + tmp) - 0.5 * (h2 - h3))

@@ -124,3 +124,78 @@ def test_posdef_failure_reaches_every_rank():
     res = _run(2, 400, 128, bad=True)
     assert all(r[1] == "posdef" for r in res), res
     assert len({r[2] for r in res}) == 1 and res[0][2] >= 1
+
+
+# ---- sparse ELBO sharded over the data points (one all-reduce of the partial sums) --------------------
+def _elbo_problem(N, M, diag_noise):
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(2468)
+    F = P.gppp_sum_model()
+    n1 = N // 3
+    xs = [np.asfortranarray(rng.standard_normal((2, n))) for n in (n1, 0, N - n1)]     # one empty block
+    Z = np.asfortranarray(rng.standard_normal((2, M)))
+    y = rng.standard_normal(N)
+    noise = (0.05 + rng.random(N)) if diag_noise else 0.1
+    return F, xs, Z, y, noise
+
+
+def _elbo_worker(rank, world, port, N, M, diag_noise, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        import __graft_entry__ as entry
+        P = entry.load_package()
+        from stheno_jl_amd import dist as sdist
+        import np_ops
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        F, xs, Z, y, noise = _elbo_problem(N, M, diag_noise)
+        x = P.BlockData([P.GPPPInput(k, P.ColVecs(v)) for k, v in zip(("f3", "f1", "f3"), xs)])
+        fx, fz = F(x, noise), F(P.GPPPInput("f3", P.ColVecs(Z)), 1e-6)
+        ops = np_ops.NumpyOps()
+        val = sdist.dist_elbo(ops, P.VFE(fz), fx, y, world=world, rank=rank)
+        q.put((rank, "ok", val, {}, ops.calls))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc(), {}, []))
+
+
+@pytest.mark.parametrize("world,N,M,diag_noise", [(2, 301, 17, False), (3, 500, 40, True), (3, 2, 5, False)])
+def test_sharded_elbo_matches_oracle(world, N, M, diag_noise):
+    import oracle.abstractgps as oagp
+    import oracle.kernelfunctions as okf
+    import oracle.stheno as ost
+    from oracle import reference_model as orm
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_elbo_worker, args=(r, world, port, N, M, diag_noise, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    F, xs, Z, y, noise = _elbo_problem(N, M, diag_noise)
+    Fo = orm.gppp_sum()
+    xo = ost.BlockData([ost.GPPPInput(k, okf.ColVecs(v)) for k, v in zip(("f3", "f1", "f3"), xs)])
+    ref = oagp.elbo(oagp.VFE(Fo(ost.GPPPInput("f3", okf.ColVecs(Z)), 1e-6)), Fo(xo, noise), y)
+    vals = [r[2] for r in res]
+    assert all(v == vals[0] for v in vals)                    # the all-reduce leaves identical sums everywhere
+    assert abs(vals[0] - ref) <= 1e-9 * abs(ref)
+    # every data point is in exactly one rank's slice
+    assert sum(c[1] for r in res for c in r[4] if c[0] == "elbo_partial") == N
+
+
+def test_slice_inputs_and_row_shards():
+    import stheno_jl_amd as P
+    from stheno_jl_amd import dist as sdist
+    x = P.BlockData([P.GPPPInput("f1", np.arange(5.0)), P.GPPPInput("f2", P.ColVecs(np.arange(12.0).reshape(2, 6)))])
+    s = sdist.slice_inputs(x, 3, 8)
+    assert [len(b) for b in P.blocks(s)] == [2, 3]
+    assert np.array_equal(P.blocks(s)[0].x, [3.0, 4.0]) and np.array_equal(P.blocks(s)[1].x.X, np.arange(12.0).reshape(2, 6)[:, :3])
+    cover = [sdist.shard_rows(10, 3, r) for r in range(3)]
+    assert cover == [(0, 3), (3, 6), (6, 10)]

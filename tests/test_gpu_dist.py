@@ -143,3 +143,72 @@ def test_rccl_backend_executes_the_sharded_drivers_collectives():
     F, x, xs, y = _problem(N)
     ref = orm.gppp_sum_logpdf(xs, y, 0.1)
     assert abs(res[2] - ref) <= 1e-10 * abs(ref)
+
+
+# ---- sparse ELBO sharded over the data points ----------------------------------------------------------
+def _elbo_problem(N, M, D=3):
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(97531)
+    F = P.gppp_sum_model()
+    n1 = N // 2
+    xs = [np.asfortranarray(rng.standard_normal((D, n))) for n in (n1, N - n1)]
+    Z = np.asfortranarray(rng.standard_normal((D, M)))
+    x = P.BlockData([P.GPPPInput(k, P.ColVecs(v)) for k, v in zip(("f3", "f1"), xs)])
+    y = rng.standard_normal(N)
+    noise = 0.05 + rng.random(N)
+    return F, x, Z, y, noise
+
+
+def test_sharded_elbo_world1_equals_host_elbo():
+    import stheno_jl_amd as P
+    from stheno_jl_amd import dist as sdist
+    for N, M in [(700, 60), (3000, 256)]:
+        F, x, Z, y, noise = _elbo_problem(N, M)
+        fx, fz = F(x, noise), F(P.GPPPInput("f3", P.ColVecs(Z)), 1e-6)
+        e0 = P.elbo(P.VFE(fz), fx, y)
+        e1 = sdist.dist_elbo(sdist.HipOps(), P.VFE(fz), fx, y, world=1, rank=0)
+        assert abs(e1 - e0) <= 1e-11 * abs(e0), (e0, e1)
+
+
+def _elbo_worker(rank, world, port, N, M, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        import torch
+        import torch.distributed as dist
+        import __graft_entry__ as entry
+        P = entry.load_package()
+        from stheno_jl_amd import dist as sdist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        F, x, Z, y, noise = _elbo_problem(N, M)
+        fx, fz = F(x, noise), F(P.GPPPInput("f3", P.ColVecs(Z)), 1e-6)
+        val = sdist.dist_elbo(sdist.HipOps(P.lib.Context(0)), P.VFE(fz), fx, y, world=world, rank=rank)
+        q.put((rank, "ok", val))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+def test_sharded_elbo_two_ranks_on_one_gpu_over_gloo():
+    import torch.multiprocessing as mp
+    import stheno_jl_amd as P
+    N, M = 2500, 200
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_elbo_worker, args=(r, 2, port, N, M, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    F, x, Z, y, noise = _elbo_problem(N, M)
+    e0 = P.elbo(P.VFE(F(P.GPPPInput("f3", P.ColVecs(Z)), 1e-6)), F(x, noise), y)
+    assert res[0][2] == res[1][2]
+    assert abs(res[0][2] - e0) <= 1e-10 * abs(e0)
