@@ -98,6 +98,18 @@ typedef struct sgp_sparse_post sgp_sparse_post;
 int sgp_abi_version(void);
 /* device: HIP ordinal.  Fails (<0) when no gfx950 device is present: there is no CPU path. */
 int sgp_ctx_create(int device, sgp_ctx** out);
+/* One context over several GPUs of the node (BASELINE.json north_star): sgp_logpdf on
+ * such a context shards the N x N covariance in column panels, block-cyclic over devices[0..ndev),
+ * right-looking blocked Cholesky with one-panel look-ahead; factored panels travel by RCCL
+ * (ncclCommInitAll inside, one grouped ncclBroadcast per panel over xGMI) or peer copies
+ * (SGP_MULTI_TRANSPORT=rccl|p2p|auto), logdet and |L^-1 (y - m)|^2 by ncclAllReduce.  One host thread, one
+ * `ccall`: the Julia side is unchanged.  Every other entry point runs on devices[0].  A device listed
+ * several times gives that many ranks on one GPU (test configuration).  SGP_MULTI_PANEL=<cols> sets the
+ * panel width (default 1024).  sgp_ctx_ndev -> number of ranks (1 for an ordinary context);
+ * sgp_ctx_transport -> "single" | "rccl" | "p2p" | "loopback". */
+int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out);
+int sgp_ctx_ndev(sgp_ctx* ctx);
+const char* sgp_ctx_transport(sgp_ctx* ctx);
 int sgp_ctx_destroy(sgp_ctx* ctx);
 /* A ctx keeps the device workspaces of finished calls (the m_tot x n_pad factor buffer of
  * sgp_logpdf etc.) in a grow-only cache so that repeated calls of one shape do not pay

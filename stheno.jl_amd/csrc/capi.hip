@@ -177,6 +177,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* rf = getenv("SGP_REFINE");
     if (rf) c->refine = atoi(rf);
+    const char* wm = getenv("SGP_WMID");
+    if (wm) c->wmid = atol(wm) / TILE * TILE;
     const char* il = getenv("SGP_INNER_LL");
     if (il) c->inner_ll = atoi(il);
     const char* po = getenv("SGP_POOL");
@@ -201,6 +203,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
 
 extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (!c) return 0;
+  if (c->multi) sgp_multi_destroy(c->multi);
+  c->multi = nullptr;
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) hipStreamSynchronize(c->stream2);
@@ -424,7 +428,7 @@ static int assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, lo
       int p = I * ds->ncb + J;
       int t0 = ds->term_ptr[p], t1 = ds->term_ptr[p + 1];
       int dmax = ds->pair_dmax[p];
-      int per = std::max(1, 64 / dmax);  // terms per launch: <= 64 KiB of LDS
+      int per = assemble_terms_per_launch(dmax);  // terms per launch: <= 64 KiB of LDS
       int nk = (ds->symmetric && I == J) ? noise_kind : -1;
       if (t0 == t1) {
         CHECK_RC(launch_assemble_block(Kv, ld, r0, nr, c0, nc, ds->d_terms, 0, 1, lower_only, 0, nk,
@@ -486,6 +490,27 @@ static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double
 // layout potrf_diag writes) for later solves against the factor; else ctx scratch.
 static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_slots,
                         int* d_info, double* d_invstore, hipStream_t s) {
+  // ctx->wmid (multiple of 128, < w): one more blocking level -- the panel is factored in sub-panels of
+  // wmid columns (128-column steps inside), each followed by ONE K = wmid update of the rest of the
+  // panel, so that only wmid / w of the in-panel flops run as shallow K = 128 products.
+  if (ctx->wmid >= TILE && ctx->wmid < w) {
+    const long wm = ctx->wmid;
+    for (long j = 0; j < w; j += wm) {
+      const long wj = std::min(wm, w - j);
+      double* Pj = P + j + j * ld;
+      const long saved = ctx->wmid;
+      ctx->wmid = 0;
+      int rc = panel_factor(ctx, Pj, ld, m - j, wj, g0 + j, d_slots + j / TILE, d_info,
+                            d_invstore ? d_invstore + (j / TILE) * INVD_STRIDE : nullptr, s);
+      ctx->wmid = saved;
+      if (rc) return rc;
+      const long rest = w - j - wj;
+      if (rest > 0)   // rows below the sub-panel x remaining columns of the panel, lower tiles only
+        CHECK_RC(launch_gemm_nt(P + (j + wj) + j * ld, ld, P + (j + wj) + j * ld, ld, P + (j + wj) + (j + wj) * ld, ld,
+                                m - j - wj, rest, wj, -1.0, 1.0, 0, 0, 0, s));
+    }
+    return 0;
+  }
   // ctx->inner_ll: LEFT-looking inside the panel -- block column j first receives the updates of all
   // earlier block columns of the panel in ONE product of depth K = 128 j, then is factored and solved.
   // Same flops as the right-looking sweep (one K = 128 update of every later block column per step),
@@ -801,6 +826,9 @@ extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
   CHECK_ARG(ctx && spec && Y && out, "sgp_logpdf: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_logpdf: spec must be symmetric");
   CtxScope scope(ctx);
+  // a multi-GPU context (sgp_ctx_create_multi) shards the covariance over its devices
+  if (ctx->multi && ncols == 1 && noise_kind != SGP_NOISE_DENSE && noise)
+    return sgp_multi_logpdf(ctx, spec, mean, noise_kind, noise, Y, out);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
@@ -2162,7 +2190,9 @@ extern "C" int sgp_dev_assemble_cols(sgp_ctx* ctx, const sgp_dspec* ds, int64_t 
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int64_t n_pad, mt;
   sgp_geometry(N, ncols, &n_pad, &mt);
-  CHECK_ARG(mt == m_tot && ldd >= m_tot, "sgp_dev_assemble_cols: geometry mismatch");
+  // ldd >= m_tot - c0: a panel may be stored packed (rows c0 .. m_tot only); the caller then passes the
+  // virtual address of global row 0 (first stored row minus c0), which is never dereferenced above row c0
+  CHECK_ARG(mt == m_tot && ldd >= m_tot - c0, "sgp_dev_assemble_cols: geometry mismatch");
   double* Kv = d_dst - c0 * ldd;  // virtual base: global column index
   double s2 = noise_host ? noise_host[0] : 0.0;
   CHECK_RC(assemble(ds, Kv, ldd, c0 / TILE, n_pad / TILE, c0 / TILE, (c0 + nc) / TILE, 1, noise_kind,

@@ -57,14 +57,15 @@ __device__ __forceinline__ double exp_nonpos(double x) {
   p = fma(p, r, 1.0);
   return __builtin_ldexp(p, (int)n);
 }
-// sqrt(a) for a >= 0 (0 -> 0): v_rsq_f64 seed, two Newton steps on 1/sqrt, one correction of the root
+// sqrt(a) for a >= 0: v_rsq_f64 seed (~2^-26), one Newton step on 1/sqrt, then one Newton step on the
+// root itself (quadratic: rounding-level result).  a is clamped to 1e-300 so that a == 0 needs no
+// branch: the result is then 1e-150, which every kernel maps to exactly kappa(0) (1 + 1e-150 == 1).
 __device__ __forceinline__ double sqrt_nonneg(double a) {
+  a = fmax(a, 1e-300);
   double r = __builtin_amdgcn_rsq(a);
   r = r * fma(-0.5 * a, r * r, 1.5);
-  r = r * fma(-0.5 * a, r * r, 1.5);
   double d = a * r;
-  d = fma(0.5 * r, fma(-d, d, a), d);
-  return a > 0.0 ? d : 0.0;
+  return fma(0.5 * r, fma(-d, d, a), d);
 }
 
 // device-side description of one covariance term of one block pair
@@ -114,6 +115,7 @@ int launch_assemble_block(double* K, long ld, long r0, long nr, long c0, long nc
                           int accumulate, int noise_kind, double sigma2, const double* d_noise_diag,
                           long tile_r_first, long tile_c_first, long tile_r_cnt, long tile_c_cnt,
                           hipStream_t s);
+int assemble_terms_per_launch(int dmax);  // how many terms one launch_assemble_block may carry (LDS)
 int launch_fill_pad(double* K, long ld, long N, long n_pad, long c0, long nc, long m_tot,
                     long row_lo, hipStream_t s);
 int launch_border_rows(double* A, long ld, long n_pad, long N, long c0, long nc, const double* dY,

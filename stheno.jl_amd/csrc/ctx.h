@@ -18,8 +18,14 @@ struct sgp_pool_block {
   bool used = false;
 };
 
+struct sgp_multi;   // multi.hip: the ranks of a multi-GPU context
+void sgp_multi_destroy(sgp_multi* m);
+int sgp_multi_logpdf(struct sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                     const double* noise, const double* y, double* out);
+
 struct sgp_ctx {
   int device = 0;
+  sgp_multi* multi = nullptr;     // non-null: sgp_logpdf shards over several GPUs (sgp_ctx_create_multi)
   hipStream_t stream = nullptr;   // panel / critical-path stream (high priority)
   hipStream_t stream2 = nullptr;  // trailing-update stream (look-ahead overlap)
   hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
@@ -29,6 +35,7 @@ struct sgp_ctx {
   double* d_w = nullptr;       // 128 x 128 scratch inverse
   double* d_solve = nullptr;   // rows x 128 scratch of the refined panel solve (grown on demand)
   long n_solve_rows = 0;
+  long wmid = 0;               // SGP_WMID=<cols>: middle blocking level inside an outer panel (0 = none)
   int inner_ll = 0;            // SGP_INNER_LL=1: left-looking block columns inside an outer panel
   int refine = 1;              // SGP_REFINE=0: plain explicit-inverse panel solve (A/B timing only)
   double* d_slots = nullptr;   // per-128-block logdet contributions

@@ -16,6 +16,7 @@
 // registers.  Distances are the direct sum_d (a_d - b_d)^2 (exactly 0 on coincident points, so
 // SE diagonals are exactly 1: test/gp/atomic_gp.jl:34), not the GEMM trick.
 #include "common.h"
+#include <algorithm>
 
 namespace sgp {
 
@@ -156,6 +157,173 @@ __global__ __launch_bounds__(256) void assemble_block_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// Two-rows-per-thread variant (input dimension <= 16): thread (lane, wave) owns rows 2 lane, 2 lane + 1
+// of the tile and the 32 columns of quarter `wave`, so
+//   * every store is 16 bytes per lane: one wave instruction writes 128 consecutive rows of a column
+//     (1 KiB contiguous) -- stores are issue-bound, and 8-byte stores needed twice as many;
+//   * each column point fetched from LDS serves two rows (half the LDS traffic per entry).
+// Everything a term needs inside the column loop sits in LDS -- column points, ROW points, coef * row
+// scale, column scale -- staged once per tile: the first version re-read the row points and scales
+// from global memory in every column chunk (they cannot be hoisted: the term loop is inside, and K may
+// alias them), and the counters showed the waves parked in s_waitcnt half of the time
+// (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.51, VALU 53 % busy).  Interior tiles take a path without any
+// bounds checks.
+// tri != 0: 1-D grid over the live tiles of a square diagonal window only (tile id -> (tr, tc) of the
+// lower triangle); the 2-D grid of the general case launches the dead upper tiles just to exit.
+// ---------------------------------------------------------------------------------------
+constexpr int CC2 = 4;  // columns per chunk (x 2 rows = 8 independent exp / sqrt chains)
+
+// LDS doubles per term: column points, row points, row weights (coef * rs), column weights (cs)
+__host__ __device__ constexpr int asm2_term_doubles(int dmax) { return 2 * TILE * dmax + 2 * TILE; }
+int assemble_terms_per_launch(int dmax) {
+  if (dmax > 16) return std::max(1, 64 / dmax);                    // one-row kernel: column points only
+  return std::max(1, (int)((60 * 1024) / (sizeof(double) * asm2_term_doubles(dmax))));
+}
+
+template <int DMAX, int KIND>
+__device__ __forceinline__ void term_chunk2(double (&acc0)[CC2], double (&acc1)[CC2], const double (&xi0)[DMAX],
+                                            const double (&xi1)[DMAX], const double* sp, const double* scq, double rs0,
+                                            double rs1, double param) {
+#pragma unroll
+  for (int q = 0; q < CC2; ++q) {
+    double d2a = 0.0, d2b = 0.0;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+      const double c = sp[q * DMAX + d];
+      const double da = xi0[d] - c, db = xi1[d] - c;
+      d2a = fma(da, da, d2a);
+      d2b = fma(db, db, d2b);
+    }
+    const double cq = scq[q];
+    acc0[q] = fma(kern_eval_t<KIND>(d2a, param), rs0 * cq, acc0[q]);
+    acc1[q] = fma(kern_eval_t<KIND>(d2b, param), rs1 * cq, acc1[q]);
+  }
+}
+
+template <int DMAX>
+__global__ __launch_bounds__(256) void assemble_block2_kernel(
+    double* __restrict__ K, long ld, long r0, long nr, long c0, long nc, const DevTerm* __restrict__ terms,
+    int nterms, int lower_only, int accumulate, int noise_kind, double sigma2,
+    const double* __restrict__ noise_diag, long tile_r_first, long tile_c_first, int tri) {
+  long gtr, gtc;
+  if (tri) {
+    const long id = blockIdx.x;
+    long tr = (long)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+    while (tr * (tr + 1) / 2 > id) --tr;
+    while ((tr + 1) * (tr + 2) / 2 <= id) ++tr;
+    gtr = tile_r_first + tr;
+    gtc = tile_c_first + (id - tr * (tr + 1) / 2);
+  } else {
+    gtr = tile_r_first + blockIdx.x;
+    gtc = tile_c_first + blockIdx.y;
+    if (lower_only && gtr < gtc) return;
+  }
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  constexpr int TD = asm2_term_doubles(DMAX);  // per term: [128][DMAX] cols | [128][DMAX] rows | rw[128] | cw[128]
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6;
+
+  long cbeg = gtc * TILE, cend = cbeg + TILE;
+  if (cbeg < c0) cbeg = c0;
+  if (cend > c0 + nc) cend = c0 + nc;
+  long rbeg = gtr * TILE, rend = rbeg + TILE;
+  if (rbeg < r0) rbeg = r0;
+  if (rend > r0 + nr) rend = r0 + nr;
+  if (cbeg >= cend || rbeg >= rend) return;
+
+  for (int tm = 0; tm < nterms; ++tm) {
+    const DevTerm T = terms[tm];
+    const int D = T.dim;
+    double* sc = smem + tm * TD;
+    double* sr = sc + TILE * DMAX;
+    for (int idx = t; idx < TILE * DMAX; idx += 256) {
+      const int p = idx / DMAX, d = idx % DMAX;
+      const long gc = gtc * TILE + p, gr = gtr * TILE + p;
+      sc[idx] = (d < D && gc >= cbeg && gc < cend) ? T.xc[(gc - c0) * T.ldc + d] : 0.0;
+      sr[d * TILE + p] = (d < D && gr >= rbeg && gr < rend) ? T.xr[(gr - r0) * T.ldr + d] : 0.0;  // [d][row]
+    }
+    if (t < TILE) {
+      const long gr = gtr * TILE + t;
+      sr[TILE * DMAX + t] = (gr >= rbeg && gr < rend) ? T.coef * (T.rs ? T.rs[gr - r0] : 1.0) : 0.0;
+    } else {
+      const int p = t - TILE;
+      const long gc = gtc * TILE + p;
+      sr[TILE * DMAX + TILE + p] = (gc >= cbeg && gc < cend) ? (T.cs ? T.cs[gc - c0] : 1.0) : 0.0;
+    }
+  }
+  __syncthreads();
+
+  const long g0 = gtr * TILE + 2 * lane, g1 = g0 + 1;
+  const bool ok0 = g0 >= rbeg && g0 < rend, ok1 = g1 >= rbeg && g1 < rend;
+  const bool diag_noise = noise_kind >= 0 && gtr == gtc;  // only tiles on the diagonal carry Sigma_y entries
+  double nv0 = 0.0, nv1 = 0.0;
+  if (diag_noise) {
+    nv0 = (noise_kind == 0) ? sigma2 : (ok0 ? noise_diag[g0] : 0.0);
+    nv1 = (noise_kind == 0) ? sigma2 : (ok1 ? noise_diag[g1] : 0.0);
+  }
+  // interior tile: all 128 x 128 entries belong to the block pair, and 16-byte stores are aligned
+  const bool full = (cend - cbeg == TILE) && (rend - rbeg == TILE) && !accumulate &&
+                    ((((unsigned long long)(K + g0)) & 15ull) == 0) && ((ld & 1) == 0);
+
+  for (int jc = 0; jc < 32; jc += CC2) {
+    const int pbase = wv * 32 + jc;  // point index within the tile
+    double acc0[CC2], acc1[CC2];
+#pragma unroll
+    for (int q = 0; q < CC2; ++q) acc0[q] = acc1[q] = 0.0;
+    for (int tm = 0; tm < nterms; ++tm) {
+      const DevTerm T = terms[tm];
+      const double* sc = smem + tm * TD;
+      const double* sr = sc + TILE * DMAX;
+      double xi0[DMAX], xi1[DMAX];
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) {  // row points are stored [d][row]: one conflict-free 16-byte read per d
+        const double2 x2 = *reinterpret_cast<const double2*>(sr + d * TILE + 2 * lane);
+        xi0[d] = x2.x;
+        xi1[d] = x2.y;
+      }
+      const double rs0 = sr[TILE * DMAX + 2 * lane], rs1 = sr[TILE * DMAX + 2 * lane + 1];
+      const double* sp = sc + pbase * DMAX;
+      const double* scq = sr + TILE * DMAX + TILE + pbase;
+      switch (T.kind) {
+        case K_SE: term_chunk2<DMAX, K_SE>(acc0, acc1, xi0, xi1, sp, scq, rs0, rs1, T.param); break;
+        case K_M12: term_chunk2<DMAX, K_M12>(acc0, acc1, xi0, xi1, sp, scq, rs0, rs1, T.param); break;
+        case K_M32: term_chunk2<DMAX, K_M32>(acc0, acc1, xi0, xi1, sp, scq, rs0, rs1, T.param); break;
+        case K_M52: term_chunk2<DMAX, K_M52>(acc0, acc1, xi0, xi1, sp, scq, rs0, rs1, T.param); break;
+        case K_WHITE: term_chunk2<DMAX, K_WHITE>(acc0, acc1, xi0, xi1, sp, scq, rs0, rs1, T.param); break;
+        default: term_chunk2<DMAX, K_CONST>(acc0, acc1, xi0, xi1, sp, scq, rs0, rs1, T.param); break;
+      }
+    }
+    if (full && !diag_noise) {
+      double* kp = K + g0 + (gtc * TILE + pbase) * ld;
+#pragma unroll
+      for (int q = 0; q < CC2; ++q) *reinterpret_cast<double2*>(kp + q * ld) = make_double2(acc0[q], acc1[q]);
+    } else if (full) {
+#pragma unroll
+      for (int q = 0; q < CC2; ++q) {
+        const long gc = gtc * TILE + pbase + q;
+        double v0 = acc0[q], v1 = acc1[q];
+        if (gc == g0) v0 += nv0;
+        if (gc == g1) v1 += nv1;
+        *reinterpret_cast<double2*>(K + g0 + gc * ld) = make_double2(v0, v1);
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < CC2; ++q) {
+        const long gc = gtc * TILE + pbase + q;
+        if (gc >= cbeg && gc < cend) {
+          double v0 = acc0[q], v1 = acc1[q];
+          if (diag_noise && gc == g0) v0 += nv0;
+          if (diag_noise && gc == g1) v1 += nv1;
+          double* p = K + g0 + gc * ld;
+          if (ok0) p[0] = accumulate ? p[0] + v0 : v0;
+          if (ok1) p[1] = accumulate ? p[1] + v1 : v1;
+        }
+      }
+    }
+  }
+}
+
 template <int DMAX>
 static int launch_assemble_t(double* K, long ld, long r0, long nr, long c0, long nc,
                              const DevTerm* d_terms, int nterms, int lower_only, int accumulate,
@@ -163,11 +331,21 @@ static int launch_assemble_t(double* K, long ld, long r0, long nr, long c0, long
                              long tile_r_first, long tile_c_first, long tile_r_cnt,
                              long tile_c_cnt, hipStream_t s) {
   size_t lds = (size_t)nterms * TILE * DMAX * sizeof(double);
+  if (DMAX <= 16) lds = (size_t)nterms * asm2_term_doubles(DMAX <= 16 ? DMAX : 16) * sizeof(double);
   if (lds == 0) lds = 16;
   dim3 grid((unsigned)tile_r_cnt, (unsigned)tile_c_cnt), block(256);
-  hipLaunchKernelGGL(assemble_block_kernel<DMAX>, grid, block, lds, s, K, ld, r0, nr, c0, nc,
-                     d_terms, nterms, lower_only, accumulate, noise_kind, sigma2, d_noise_diag,
-                     tile_r_first, tile_c_first);
+  if (DMAX <= 16) {
+    // square window on the diagonal in lower mode: launch the live tiles only
+    const int tri = lower_only && tile_r_first == tile_c_first && tile_r_cnt == tile_c_cnt;
+    if (tri) grid = dim3((unsigned)(tile_r_cnt * (tile_r_cnt + 1) / 2));
+    hipLaunchKernelGGL(assemble_block2_kernel<(DMAX <= 16 ? DMAX : 16)>, grid, block, lds, s, K, ld, r0, nr, c0, nc,
+                       d_terms, nterms, lower_only, accumulate, noise_kind, sigma2, d_noise_diag, tile_r_first,
+                       tile_c_first, tri);
+  } else {
+    hipLaunchKernelGGL(assemble_block_kernel<DMAX>, grid, block, lds, s, K, ld, r0, nr, c0, nc,
+                       d_terms, nterms, lower_only, accumulate, noise_kind, sigma2, d_noise_diag,
+                       tile_r_first, tile_c_first);
+  }
   SGP_HIP(hipGetLastError());
   return 0;
 }

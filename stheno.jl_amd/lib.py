@@ -60,6 +60,9 @@ _D = C.POINTER(C.c_double)
 _SIGS = {
     "sgp_abi_version": (C.c_int, []),
     "sgp_ctx_create": (C.c_int, [C.c_int, C.POINTER(_P)]),
+    "sgp_ctx_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
+    "sgp_ctx_ndev": (C.c_int, [_P]),
+    "sgp_ctx_transport": (C.c_char_p, [_P]),
     "sgp_ctx_destroy": (C.c_int, [_P]),
     "sgp_ctx_trim": (C.c_int, [_P]),
     "sgp_ctx_stage_timing": (C.c_int, [_P, C.c_int]),
@@ -166,13 +169,28 @@ def dptr(a):
 class Context:
     """One sgp_ctx (one GPU, one stream).  `default_context()` gives a process-wide one."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, devices=None):
+        """device: one GPU.  devices=[...]: a multi-GPU context (sgp_ctx_create_multi): logpdf is sharded
+        over the listed GPUs inside the library; everything else runs on devices[0]."""
         lib = load()
         h = _P()
-        check(lib.sgp_ctx_create(int(device), C.byref(h)), "sgp_ctx_create")
+        if devices is not None:
+            arr = (C.c_int * len(devices))(*[int(d) for d in devices])
+            check(lib.sgp_ctx_create_multi(arr, len(devices), C.byref(h)), "sgp_ctx_create_multi")
+            device = int(devices[0])
+        else:
+            check(lib.sgp_ctx_create(int(device), C.byref(h)), "sgp_ctx_create")
         self.handle = h
         self.device = device
         self.lib = lib
+
+    @property
+    def ndev(self):
+        return int(self.lib.sgp_ctx_ndev(self.handle))
+
+    @property
+    def transport(self):
+        return self.lib.sgp_ctx_transport(self.handle).decode()
 
     def close(self):
         if getattr(self, "handle", None):
@@ -189,9 +207,21 @@ class Context:
 _default_ctx = None
 
 
+def set_default_context(ctx):
+    """Route the host mirror's calls (logpdf, posterior, ...) through `ctx`; returns the previous one.
+    With a multi-GPU context (Context(devices=[...])) logpdf is sharded over its GPUs."""
+    global _default_ctx
+    prev, _default_ctx = _default_ctx, ctx
+    return prev
+
+
 def default_context():
     global _default_ctx
     if _default_ctx is None:
+        devs = os.environ.get("SGP_DEVICES")         # e.g. "0,1,2,3,4,5,6,7": one process, all GPUs
+        if devs:
+            _default_ctx = Context(devices=[int(d) for d in devs.split(",") if d.strip() != ""])
+            return _default_ctx
         dev = int(os.environ.get("LOCAL_RANK", "0"))
         try:
             import torch
