@@ -149,8 +149,8 @@ def main():
     else:
         ops = sdist.HipOps(ctx)
         n_pad, m_tot = sdist.geometry(N, 1)
-        lay = sdist.PanelLayout(n_pad, min(args.panel, n_pad), world, rank)
-        A = ops.empty(max(1, m_tot * lay.n_local_cols()))
+        lay = sdist.PanelLayout(n_pad, min(args.panel, n_pad), world, rank, m_tot)
+        A = ops.empty(lay.n_local_doubles())
 
         def step(tm=None):
             return sdist.dist_logpdf(ops, spec, y, None, sigma2, world=world, rank=rank, W=args.panel, A=A)

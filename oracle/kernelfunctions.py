@@ -70,6 +70,9 @@ def pairwise_sqeuclidean(X, Y=None, faithful=True):
 
 # ---- kernels ---------------------------------------------------------------------------------
 class Kernel:
+    def __matmul__(self, transform):
+        return TransformedKernel(self, transform)
+
     def __add__(self, other):
         return KernelSum([self, other])
 
@@ -207,6 +210,42 @@ class ScaleTransformedKernel(Kernel):
 
 def with_lengthscale(kernel, l):
     return ScaleTransformedKernel(kernel, 1.0 / float(l))
+
+
+class ScaleTransform:
+    """KernelFunctions.ScaleTransform(s) [EXT]: x -> s x."""
+
+    def __init__(self, s):
+        self.s = float(s)
+
+    def __call__(self, X):
+        return self.s * X
+
+
+class PeriodicTransform:
+    """KernelFunctions.PeriodicTransform(f) [EXT]: 1-D x -> [sin(2 pi f x), cos(2 pi f x)]
+    (/root/reference/examples/extended_mauna_loa/script.jl:129)."""
+
+    def __init__(self, f):
+        self.f = float(f)
+
+    def __call__(self, X):
+        assert X.shape[0] == 1
+        t = 2.0 * np.pi * self.f * X
+        return np.vstack([np.sin(t), np.cos(t)])
+
+
+class TransformedKernel(Kernel):
+    """k o t: k(t(x), t(y)) (KernelFunctions.TransformedKernel [EXT])."""
+
+    def __init__(self, kernel, transform):
+        self.kernel, self.transform = kernel, transform
+
+    def matrix(self, X, Y=None, faithful=True):
+        return self.kernel.matrix(self.transform(X), None if Y is None else self.transform(Y), faithful)
+
+    def diag(self, X, Y=None):
+        return self.kernel.diag(self.transform(X), None if Y is None else self.transform(Y))
 
 
 def kernelmatrix(k, x, y=None, faithful=True):

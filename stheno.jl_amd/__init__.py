@@ -9,7 +9,8 @@ from . import lib  # noqa: F401
 from .lib import PosDefException, SthenoMIError  # noqa: F401
 from .inputs import BlockData, ColVecs, GPPPInput, blocks, split, vcat  # noqa: F401
 from .kernels import (ConstantKernel, ExponentialKernel, KernelSum, Matern12Kernel,  # noqa: F401
-                      Matern32Kernel, Matern52Kernel, ScaledKernel, ScaleTransformedKernel,
+                      Matern32Kernel, Matern52Kernel, PeriodicTransform, ScaledKernel, ScaleTransform,
+                      ScaleTransformedKernel, TransformedKernel,
                       SEKernel, SqExponentialKernel, WhiteKernel, with_lengthscale)
 from .gp import (GP, GPC, AtomicGP, DerivedGP, Periodic, Select, Shift, Stretch,  # noqa: F401
                  additive_gp, atomic, compose, cross, mean_vector, periodic, select, shift,

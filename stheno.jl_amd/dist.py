@@ -32,13 +32,22 @@ def geometry(N, ncols):
 
 
 class PanelLayout:
-    """Block-cyclic ownership of the column panels of the bordered matrix."""
+    """Block-cyclic ownership of the column panels of the bordered matrix.  A rank stores its panels
+    PACKED: panel J holds rows J0 .. m_tot only, as a contiguous (m_tot - J0) x W column-major block
+    (leading dimension ld(J)), one after the other -- a factored panel is broadcast straight out of
+    its storage, with no packing copy."""
 
-    def __init__(self, n_pad, W, world, rank):
+    def __init__(self, n_pad, W, world, rank, m_tot=None):
         assert W % TILE == 0
         self.n_pad, self.W, self.world, self.rank = n_pad, W, world, rank
+        self.m_tot = n_pad if m_tot is None else m_tot
         self.n_panels = (n_pad + W - 1) // W
         self.mine = [J for J in range(self.n_panels) if J % world == rank]
+        self._off, tot = {}, 0
+        for J in self.mine:
+            self._off[J] = tot
+            tot += self.ld(J) * self.width(J)
+        self.n_local = tot
 
     def owner(self, J):
         return J % self.world
@@ -49,11 +58,24 @@ class PanelLayout:
     def width(self, J):
         return min(self.W, self.n_pad - J * self.W)
 
+    def ld(self, J):
+        return self.m_tot - J * self.W
+
+    def offset(self, J):
+        """offset (in doubles) of owned panel J in the rank's storage"""
+        return self._off[J]
+
+    def count(self, J):
+        return self.ld(J) * self.width(J)
+
     def local_index(self, J):
         return J // self.world
 
     def n_local_cols(self):
         return len(self.mine) * self.W
+
+    def n_local_doubles(self):
+        return max(1, self.n_local)
 
 
 class HipOps:
@@ -145,35 +167,32 @@ class HipOps:
         self.lib.sgp_dspec_destroy(h)
 
     # -- kernels --------------------------------------------------------------------------
-    def assemble_cols(self, ds, N, c0, nc, A, col_off, m_tot, mean, sigma2, Y, ncols):
+    # Panels are packed (PanelLayout): `off` is the offset of the panel's first stored element (its row
+    # J0) in the rank's storage tensor, `ld` its leading dimension m_tot - J0.  The C-ABI building blocks
+    # index rows globally, so they get the (virtual) address of global row 0 = first stored row - J0.
+    def assemble_cols(self, ds, N, c0, nc, A, off, ld, m_tot, mean, sigma2, Y, ncols):
         nz = np.array([sigma2], dtype=np.float64)
-        rc = self.lib.sgp_dev_assemble_cols(self.ctx.handle, ds, N, c0, nc, A.data_ptr() + 8 * col_off * m_tot,
-                                            m_tot, m_tot, mean.data_ptr() if mean is not None else None,
+        rc = self.lib.sgp_dev_assemble_cols(self.ctx.handle, ds, N, c0, nc, A.data_ptr() + 8 * (off - c0), ld, m_tot,
+                                            mean.data_ptr() if mean is not None else None,
                                             _lib.NOISE_SCALAR, _lib.dptr(nz), None,
                                             Y.data_ptr() if Y is not None else None, N, ncols, self.stream())
         _lib.check(rc, "sgp_dev_assemble_cols")
 
-    def panel_factor(self, A, col_off, m_tot, J0, w, logdet, info):
-        ptr = A.data_ptr() + 8 * (col_off * m_tot + J0)
-        rc = self.lib.sgp_dev_panel_factor(self.ctx.handle, ptr, m_tot, m_tot - J0, w, J0, logdet.data_ptr(),
+    def panel_factor(self, A, off, ld, m, J0, w, logdet, info):
+        rc = self.lib.sgp_dev_panel_factor(self.ctx.handle, A.data_ptr() + 8 * off, ld, m, w, J0, logdet.data_ptr(),
                                            info.data_ptr(), self.stream())
         _lib.check(rc, "sgp_dev_panel_factor")
 
-    def pack_panel(self, A, col_off, m_tot, J0, w, buf):
-        """buf[(m_tot - J0) x w contiguous] <- A[J0:, panel cols]"""
-        t = self.torch
-        src = t.as_strided(A, (w, m_tot - J0), (m_tot, 1), col_off * m_tot + J0)
-        dst = buf[: w * (m_tot - J0)].view(w, m_tot - J0)
-        dst.copy_(src)
-
-    def panel_update(self, buf, J0, w, A, col_off, m_tot, c0, nc):
-        rc = self.lib.sgp_dev_panel_update(self.ctx.handle, buf.data_ptr(), m_tot - J0, J0, w,
-                                           A.data_ptr() + 8 * col_off * m_tot, m_tot, c0, nc, m_tot, self.stream())
+    def panel_update(self, Pt, p_off, ldp, J0, w, A, off, ld, c0, nc, m_tot):
+        """panel at A[off..] (first stored row c0, leading dimension ld) -= P[rows >= c0] P[rows c0..c0+nc]',
+        P = the factored panel J at Pt[p_off..] (first stored row J0, leading dimension ldp)"""
+        rc = self.lib.sgp_dev_panel_update(self.ctx.handle, Pt.data_ptr() + 8 * p_off, ldp, J0, w,
+                                           A.data_ptr() + 8 * (off - c0), ld, c0, nc, m_tot, self.stream())
         _lib.check(rc, "sgp_dev_panel_update")
 
-    def rowsumsq(self, A, col_off, m_tot, n_pad, nc, nrows, out):
-        rc = self.lib.sgp_dev_rowsumsq(self.ctx.handle, A.data_ptr() + 8 * (col_off * m_tot + n_pad), m_tot, nc,
-                                       nrows, out.data_ptr(), self.stream())
+    def rowsumsq(self, A, off, ld, nc, nrows, out):
+        rc = self.lib.sgp_dev_rowsumsq(self.ctx.handle, A.data_ptr() + 8 * off, ld, nc, nrows, out.data_ptr(),
+                                       self.stream())
         _lib.check(rc, "sgp_dev_rowsumsq")
 
     def synchronize(self):
@@ -208,7 +227,7 @@ def dist_logpdf(ops, spec, y, mean, sigma2, world=1, rank=0, group=None, W=1024,
 
     spec : lib.Spec (symmetric) of the prior covariance, identical on every rank
     y    : (N,) observations, mean: (N,) prior mean or None
-    A    : optional preallocated local panel storage (m_tot * n_local_cols doubles)
+    A    : optional preallocated local panel storage (PanelLayout(...).n_local_doubles() doubles)
     always_collective : issue the panel broadcasts / final all-reduces even when world == 1 (a
            one-rank RCCL communicator executes them as self-copies: exercises the backend calls)
     Every rank returns the same float.  Raises lib.PosDefException like the single-GPU path."""
@@ -226,55 +245,63 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, a
 
     n_pad, m_tot = geometry(N, 1)
     W = min(W, n_pad)
-    lay = PanelLayout(n_pad, W, world, rank)
+    lay = PanelLayout(n_pad, W, world, rank, m_tot)
     if A is None:
-        A = ops.empty(max(1, m_tot * lay.n_local_cols()))
+        A = ops.empty(lay.n_local_doubles())
     dY = ops.from_host(np.asarray(y, dtype=np.float64))
     dmean = ops.from_host(mean) if mean is not None else None
     logdet = ops.zeros(1)
     sq = ops.zeros(1)
     info = ops.izeros(1)
-    bufs = [ops.empty(m_tot * W), ops.empty(m_tot * W)]
+    need_bufs = world > 1 or always_collective
+    bufs = [ops.empty(m_tot * W), ops.empty(m_tot * W)] if need_bufs else [None, None]
 
     # 1. every rank assembles its own column panels (no communication)
     for J in lay.mine:
-        ops.assemble_cols(ds, N, lay.col0(J), lay.width(J), A, lay.local_index(J) * W, m_tot, dmean, sigma2, dY, 1)
+        ops.assemble_cols(ds, N, lay.col0(J), lay.width(J), A, lay.offset(J), lay.ld(J), m_tot, dmean, sigma2, dY, 1)
+
+    def panel(J):
+        """(tensor, offset) of factored panel J on this rank: its own storage, or the receive buffer"""
+        if lay.owner(J) == rank:
+            return A, lay.offset(J)
+        return bufs[J % 2], 0
 
     def bcast(J):
-        J0, w = lay.col0(J), lay.width(J)
-        if world == 1 and not always_collective:
+        if not need_bufs:
             return None
-        t = bufs[J % 2][: w * (m_tot - J0)]
+        if lay.owner(J) == rank:     # straight out of the packed storage: no packing copy
+            t = A[lay.offset(J): lay.offset(J) + lay.count(J)]
+        else:
+            t = bufs[J % 2][: lay.count(J)]
         return dist.broadcast(t, src=_global_rank(group, lay.owner(J)), group=group, async_op=True)
 
-    def factor_and_pack(J):
-        J0, w = lay.col0(J), lay.width(J)
-        ops.panel_factor(A, lay.local_index(J) * W, m_tot, J0, w, logdet, info)
-        ops.pack_panel(A, lay.local_index(J) * W, m_tot, J0, w, bufs[J % 2])
+    def factor(J):
+        ops.panel_factor(A, lay.offset(J), lay.ld(J), lay.ld(J), lay.col0(J), lay.width(J), logdet, info)
 
     def update(J, Jp):
         """local panel Jp (> J) -= P_J[rows] P_J[cols Jp]'"""
-        ops.panel_update(bufs[J % 2], lay.col0(J), lay.width(J), A, lay.local_index(Jp) * W, m_tot,
-                         lay.col0(Jp), lay.width(Jp))
+        Pt, p_off = panel(J)
+        ops.panel_update(Pt, p_off, lay.ld(J), lay.col0(J), lay.width(J), A, lay.offset(Jp), lay.ld(Jp),
+                         lay.col0(Jp), lay.width(Jp), m_tot)
 
     # 2. right-looking factorisation with one-panel look-ahead.  Two streams per rank: the owner of
-    # the next panel updates + factors + packs + broadcasts it on the panel stream while its other
+    # the next panel updates + factors + broadcasts it on the panel stream while its other
     # trailing panels are still being updated with the current panel on the update stream.
     #   "upd"   : update-stream work of the previous step (and the assembly) is complete
-    #   "panel" : the panel this rank just factored is packed in its buffer
+    #   "panel" : the panel this rank just factored is final in its (packed) storage
     ops.record("upd")
     work = None
     if lay.owner(0) == rank:
         with ops.panel_context():
             ops.wait("upd")
-            factor_and_pack(0)
+            factor(0)
             ops.record("panel")
             work = bcast(0)
     else:
         work = bcast(0)
     for J in range(lay.n_panels):
         nxt = J + 1
-        # (a) the update stream needs panel J in bufs[J % 2]
+        # (a) the update stream needs panel J (own storage on its owner, bufs[J % 2] elsewhere)
         if work is not None:
             work.wait()
         if lay.owner(J) == rank:
@@ -288,9 +315,9 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, a
                     if work is not None:
                         work.wait()            # panel J has landed (also for this stream)
                     update(J, nxt)
-                    factor_and_pack(nxt)
+                    factor(nxt)
                     ops.record("panel")
-                    work_next = bcast(nxt)     # ordered after the pack on the panel stream
+                    work_next = bcast(nxt)     # ordered after the factorisation on the panel stream
             else:
                 work_next = bcast(nxt)         # receive: ordered after step J-1's readers of that buffer
         # (c) the rest of this rank's trailing panels
@@ -310,7 +337,7 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, a
     for J in lay.mine:
         nc = min(lay.width(J), max(0, N - lay.col0(J)))
         if nc > 0:
-            ops.rowsumsq(A, lay.local_index(J) * W, m_tot, n_pad, nc, 1, sq)
+            ops.rowsumsq(A, lay.offset(J) + (n_pad - lay.col0(J)), lay.ld(J), nc, 1, sq)
     red = torch.stack([logdet.reshape(()), sq.reshape(())])
     inf = info.to(torch.float64)
     big = float(2 ** 52)

@@ -24,6 +24,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import gp as _gp
+from . import kernels as _kernels
 from . import lib as _lib
 from .gppp import GPPP, extract_components
 from .inputs import BlockData, ColVecs, GPPPInput, as_matrix, blocks
@@ -120,14 +121,15 @@ class _InputTable:
     def __init__(self):
         self.arrays, self.index, self.origin = [], {}, []
 
-    def get(self, X, scale, origin=None):
-        """origin = (side, block index, warp chain): where the points came from (for the chain rule
-        of input gradients); the first path that registers an array names it."""
-        k = (id(X), float(scale))
+    def get(self, X, chain, origin=None):
+        """chain: the kernel-level input transformation (kernels.apply_chain); origin = (side, block
+        index, warp chain): where the points came from (for the chain rule of input gradients); the
+        first path that registers an array names it."""
+        k = (id(X), chain)
         if k not in self.index:
             self.index[k] = len(self.arrays)
-            self.arrays.append(X if scale == 1.0 else np.asfortranarray(scale * X))
-            self.origin.append(origin + (float(scale),) if origin is not None else None)
+            self.arrays.append(X if not chain else _kernels.apply_chain(chain, X))
+            self.origin.append(origin + (chain, X) if origin is not None else None)
         return self.index[k]
 
 
@@ -170,7 +172,7 @@ def build_spec(f, x, f2=None, x2=None):
                 pairs[(I, J)] = [tuple(merged[k]) for k in order]
     spec = _lib.Spec([len(v) for _, v in rows], [len(v) for _, v in cols], table.arrays, pairs, symmetric)
     spec._mat_keep = mat  # keep the source arrays alive (ids are identity keys)
-    spec.input_origin = table.origin   # per spec input: (side, block, warp chain, kernel input scale)
+    spec.input_origin = table.origin   # per spec input: (side, block, warp chain, kernel input chain, raw points)
     spec.block_shapes = ([_leaf_shape(v) for _, v in rows], [_leaf_shape(v) for _, v in cols])
     return spec, rows, cols
 
@@ -223,8 +225,8 @@ def chain_input_gradients(spec, grads):
         org = spec.input_origin[k]
         if org is None or g is None:
             continue
-        side, I, chain, scale = org
-        gg = scale * np.asarray(g, dtype=np.float64)
+        side, I, chain, kchain, X_raw = org
+        gg = _kernels.chain_vjp(kchain, X_raw, g) if kchain else np.asarray(g, dtype=np.float64)
         for (w, x_in) in reversed(chain):
             gg = _warp_vjp(w, x_in, gg)
         (rows if side == "row" else cols)[I] += gg.reshape((rows if side == "row" else cols)[I].shape)

@@ -15,7 +15,8 @@ def oracle_api():
                  "additive_gp", "GPPP", "GPPPInput", "BlockData"):
         setattr(ns, name, getattr(st, name))
     for name in ("SEKernel", "Matern12Kernel", "Matern32Kernel", "Matern52Kernel", "WhiteKernel",
-                 "ConstantKernel", "ScaledKernel", "KernelSum", "with_lengthscale", "ColVecs"):
+                 "ConstantKernel", "ScaledKernel", "KernelSum", "with_lengthscale", "ColVecs", "PeriodicTransform",
+                 "ScaleTransform", "TransformedKernel"):
         setattr(ns, name, getattr(kf, name))
     ns.GP = agp.GP
     ns.is_oracle = True
@@ -28,7 +29,8 @@ def product_api():
     for name in ("GPC", "atomic", "stretch", "select", "periodic", "shift", "compose", "cross",
                  "additive_gp", "GPPP", "GPPPInput", "BlockData", "SEKernel", "Matern12Kernel",
                  "Matern32Kernel", "Matern52Kernel", "WhiteKernel", "ConstantKernel", "ScaledKernel",
-                 "KernelSum", "with_lengthscale", "ColVecs", "GP"):
+                 "KernelSum", "with_lengthscale", "ColVecs", "GP", "PeriodicTransform", "ScaleTransform",
+                 "TransformedKernel"):
         setattr(ns, name, getattr(p, name))
     ns.is_oracle = False
     return ns
@@ -126,5 +128,18 @@ def periodic_model(api):
     return {"g": g, "p": api.periodic(f, 2.0), "s": api.periodic(f, 0.5) + g, "pp": api.periodic(f, 0.5) + api.periodic(f, 2.0)}, gpc
 
 
-RECIPES_1D = [gppp_docstring, toy_gppp, correlated_sums, warped, composite_kernels, periodic_model]
+def mauna_loa(api):
+    """examples/extended_mauna_loa/script.jl:118-137: shared trend, kernel-level PeriodicTransform,
+    ConstantKernel offsets, two output processes."""
+    gpc = api.GPC()
+    trend = api.stretch(api.atomic(api.GP(api.SEKernel()), gpc), 0.3)
+    wig = 0.4 * api.stretch(api.atomic(api.GP(api.SEKernel()), gpc), 3.0)
+    per = 0.8 * api.atomic(api.GP(api.SEKernel() @ api.PeriodicTransform(1.3)), gpc)
+    per2 = api.atomic(api.GP(api.with_lengthscale(api.Matern32Kernel() @ api.PeriodicTransform(0.5), 2.0)), gpc)
+    co2 = 1.7 * trend + wig + per + 0.6 * api.atomic(api.GP(api.ConstantKernel()), gpc)
+    temp = 0.9 * trend + 0.5 * api.stretch(api.atomic(api.GP(api.SEKernel()), gpc), 2.0) + per2
+    return {"trend": trend, "co2": co2, "T": temp, "per": per, "per2": per2}, gpc
+
+
+RECIPES_1D = [gppp_docstring, toy_gppp, correlated_sums, warped, composite_kernels, periodic_model, mauna_loa]
 RECIPES_ND = [gppp_docstring, correlated_sums, scaled, warped_colvecs, composite_kernels]

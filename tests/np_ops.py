@@ -63,13 +63,15 @@ class NumpyOps:
         self.calls.append(("wait", name, None))
 
     @staticmethod
-    def _mat(A, col_off, m_tot, ncols):
-        return A.numpy()[col_off * m_tot:(col_off + ncols) * m_tot].reshape(ncols, m_tot).T  # view (m_tot, ncols)
+    def _mat(A, off, ld, ncols):
+        """view (ld, ncols) of a packed panel: row index = global row - first stored row"""
+        return A.numpy()[off:off + ld * ncols].reshape(ncols, ld).T
 
-    def assemble_cols(self, ds, N, c0, nc, A, col_off, m_tot, mean, sigma2, Y, ncols):
+    def assemble_cols(self, ds, N, c0, nc, A, off, ld, m_tot, mean, sigma2, Y, ncols):
         self.calls.append(("assemble", c0, nc))
+        assert ld == m_tot - c0
         n_pad = m_tot - 128 * ((ncols + 127) // 128)
-        M = self._mat(A, col_off, m_tot, nc)
+        M = self._mat(A, off, ld, nc)
         K = ds["K"]
         for lc in range(nc):
             gc = c0 + lc
@@ -81,12 +83,12 @@ class NumpyOps:
                     col[n_pad + s] = Y.numpy().reshape(-1)[gc + s * N] - (mean.numpy()[gc] if mean is not None else 0.0)
             else:
                 col[gc] = 1.0
-            M[c0:, lc] = col[c0:]     # rows above c0 are never touched (stay NaN: catches misuse)
+            M[:, lc] = col[c0:]       # rows above c0 are not stored at all
 
-    def panel_factor(self, A, col_off, m_tot, J0, w, logdet, info):
+    def panel_factor(self, A, off, ld, m, J0, w, logdet, info):
         self.calls.append(("factor", J0, w))
-        M = self._mat(A, col_off, m_tot, w)
-        P = M[J0:, :]
+        assert m == ld
+        P = self._mat(A, off, ld, w)
         D = np.tril(P[:w, :w]) + np.tril(P[:w, :w], -1).T
         try:
             L = np.linalg.cholesky(D)
@@ -105,21 +107,17 @@ class NumpyOps:
         P[w:, :] = np.linalg.solve(L, P[w:, :].T).T
         logdet[0] += 2.0 * np.log(np.diag(L)).sum()
 
-    def pack_panel(self, A, col_off, m_tot, J0, w, buf):
-        M = self._mat(A, col_off, m_tot, w)
-        buf.numpy()[: w * (m_tot - J0)].reshape(w, m_tot - J0)[:] = M[J0:, :].T
-
-    def panel_update(self, buf, J0, w, A, col_off, m_tot, c0, nc):
+    def panel_update(self, Pt, p_off, ldp, J0, w, A, off, ld, c0, nc, m_tot):
         self.calls.append(("update", J0, c0))
-        P = buf.numpy()[: w * (m_tot - J0)].reshape(w, m_tot - J0).T     # rows J0..m_tot
-        M = self._mat(A, col_off, m_tot, nc)
+        assert ldp == m_tot - J0 and ld == m_tot - c0
+        P = self._mat(Pt, p_off, ldp, w)                 # rows J0..m_tot
+        M = self._mat(A, off, ld, nc)                    # rows c0..m_tot
         rows = P[c0 - J0:, :]
-        M[c0:, :] -= rows @ P[c0 - J0:c0 - J0 + nc, :].T
+        M[:, :] -= rows @ P[c0 - J0:c0 - J0 + nc, :].T
 
-    def rowsumsq(self, A, col_off, m_tot, n_pad, nc, nrows, out):
-        M = self._mat(A, col_off, m_tot, nc)
+    def rowsumsq(self, A, off, ld, nc, nrows, out):
         for s in range(nrows):
-            out[s] += float((M[n_pad + s, :nc] ** 2).sum())
+            out[s] += float((A.numpy()[off + s: off + s + ld * nc: ld] ** 2).sum())
 
     # -- sharded ELBO: same "part" contract as sgp_dev_elbo_partial / sgp_dev_elbo_finish (sums over the
     # rank's data slice that add up across ranks), stated with dense NumPy algebra (App. A.6)

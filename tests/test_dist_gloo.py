@@ -111,8 +111,11 @@ def test_single_rank_path_and_layout():
     import np_ops
     from oracle import reference_model as orm
     from stheno_jl_amd import dist as sdist
-    lay = sdist.PanelLayout(1024, 256, 3, 1)
+    lay = sdist.PanelLayout(1024, 256, 3, 1, 1152)
     assert lay.n_panels == 4 and lay.mine == [1] and lay.owner(3) == 0 and lay.local_index(3) == 1
+    assert lay.ld(1) == 1152 - 256 and lay.offset(1) == 0 and lay.n_local_doubles() == (1152 - 256) * 256
+    lay0 = sdist.PanelLayout(1024, 256, 3, 0, 1152)          # owns panels 0 and 3, packed back to back
+    assert lay0.mine == [0, 3] and lay0.offset(3) == 1152 * 256 and lay0.ld(3) == 1152 - 768
     assert sdist.geometry(1000, 1) == (1024, 1152) and sdist.geometry(128, 0) == (128, 128)
     spec, xs, y, s2 = _problem(300)
     val = sdist.dist_logpdf(np_ops.NumpyOps(), spec, y, None, s2, world=1, rank=0, W=128)

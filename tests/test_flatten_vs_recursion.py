@@ -265,3 +265,26 @@ def test_sparse_finite_gp_dispatch_matches_reference():
     assert np.array_equal(P.mean(sf), np.cos(x))
     with pytest.raises(RuntimeError, match="covariance matrix of a sparse GP"):
         P.cov(sf)
+
+
+def test_kernel_level_transform_chain_and_its_vjp():
+    """TransformedKernel chains (ScaleTransform / PeriodicTransform / with_lengthscale): composition order
+    (outer transforms act on the raw input first), merging of adjacent scalings, and the chain rule used
+    by the input gradients, against finite differences."""
+    from stheno_jl_amd import kernels as K
+    k = P.with_lengthscale(P.SEKernel() @ P.PeriodicTransform(0.7), 2.0) @ P.ScaleTransform(3.0)
+    (kind, coef, param, chain), = k.leaf_terms()
+    assert chain == (("scale", 1.5), ("periodic", 0.7))           # x -> 3 x -> x / 2 -> periodic
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((1, 9))
+    Y = K.apply_chain(chain, X)
+    t = 2 * np.pi * 0.7 * 1.5 * X
+    assert np.allclose(Y, np.vstack([np.sin(t), np.cos(t)]), rtol=0, atol=1e-15)
+    G = rng.standard_normal(Y.shape)
+    g = K.chain_vjp(chain, X, G)
+    h = 1e-6
+    fd = np.array([(np.sum(G * K.apply_chain(chain, X + h * np.eye(1, 9, j))) -
+                    np.sum(G * K.apply_chain(chain, X - h * np.eye(1, 9, j)))) / (2 * h) for j in range(9)])
+    assert np.allclose(g.ravel(), fd, rtol=1e-7, atol=1e-8)
+    assert K.chain_scale(P.with_lengthscale(P.SEKernel(), 4.0).leaf_terms()[0][3]) == 0.25
+    assert K.chain_scale(chain) is None
