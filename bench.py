@@ -67,6 +67,13 @@ def main():
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer C-ABI leg")
     args = ap.parse_args()
 
+    # The contract is ONE JSON line on stdout.  Native libraries may write there too (RCCL prints a
+    # version banner on rank 0): route file descriptor 1 to stderr for the whole run and keep the real
+    # stdout for the result line.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -264,7 +271,7 @@ def main():
             "logpdf": val, "golden": gval, "parity_rel": parity,
             "stages": stages, "roofline": roofline, "host_api": host_api, "cpu_baseline": cpu,
         }
-        print(json.dumps(line), flush=True)
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -29,9 +29,18 @@ struct CSpec
 end
 
 const CTX = Ref{Ptr{Cvoid}}(C_NULL)
+# One context per process.  ENV["STHENOMI_DEVICES"] = "0,1,2,3,4,5,6,7" makes it a multi-GPU context
+# (sgp_ctx_create_multi): `logpdf(fx, y)` is then sharded over the listed GPUs inside the library (RCCL
+# over xGMI), everything else runs on the first device -- the Julia side does not change.
 function ctx()
     if CTX[] == C_NULL
-        rc = ccall((:sgp_ctx_create, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}), 0, CTX)
+        devs = get(ENV, "STHENOMI_DEVICES", "")
+        rc = if isempty(devs)
+            ccall((:sgp_ctx_create, LIB), Cint, (Cint, Ptr{Ptr{Cvoid}}), 0, CTX)
+        else
+            d = Cint[parse(Cint, t) for t in split(devs, ",")]
+            ccall((:sgp_ctx_create_multi, LIB), Cint, (Ptr{Cint}, Cint, Ptr{Ptr{Cvoid}}), d, length(d), CTX)
+        end
         rc == 0 || error(unsafe_string(ccall((:sgp_last_error, LIB), Cstring, ())))
     end
     return CTX[]
@@ -72,6 +81,17 @@ leaf(k::ScaledKernel) = [(a, c * only(k.σ²), p, s) for (a, c, p, s) in leaf(k.
 leaf(k::KernelSum) = reduce(vcat, leaf.(k.kernels))
 leaf(k::TransformedKernel{<:Any,<:ScaleTransform}) =
     [(a, c, p, s * only(k.transform.s)) for (a, c, p, s) in leaf(k.kernel)]
+# k ∘ PeriodicTransform(f) (examples/extended_mauna_loa/script.jl:129): the 1-D points are mapped to
+# [sin(2πfx); cos(2πfx)] on the host before upload; expressed as a negative "scale" tag carrying f so
+# that build_spec's input!(X, s) applies the map (stheno.jl_amd/kernels.py: apply_chain).
+struct PeriodicTag; f::Float64; s::Float64; end
+leaf(k::TransformedKernel{<:Any,<:PeriodicTransform}) =
+    [(a, c, p, PeriodicTag(only(k.transform.f), s)) for (a, c, p, s) in leaf(k.kernel)]
+apply_input(X, s::Real) = s == 1.0 ? X : s .* X
+function apply_input(X, t::PeriodicTag)
+    θ = (2π * t.f) .* X
+    return t.s .* vcat(sin.(θ), cos.(θ))
+end
 
 blocks_of(f::GPPP, x) = blocks_of(extract_components(f, x)...)
 blocks_of(f::DerivedGP, x::BlockData) = f.args[1] === cross ?
@@ -89,8 +109,9 @@ function build_spec(f, x, f2 = f, x2 = nothing)
     cp = sym ? rp : [paths(n, v, 1.0, nothing, ()) for (n, v) in cols]
     inputs = Matrix{Float64}[]; cin = CInput[]; terms = CTerm[]; tptr = Int32[0]
     function input!(X, s)
-        push!(inputs, s == 1.0 ? X : s .* X)
-        push!(cin, CInput(size(X, 1), size(X, 2), size(X, 1), pointer(inputs[end])))
+        Xt = apply_input(X, s)
+        push!(inputs, Xt)
+        push!(cin, CInput(size(Xt, 1), size(Xt, 2), size(Xt, 1), pointer(inputs[end])))
         return Int32(length(inputs) - 1)
     end
     for pi in rp, pj in cp
@@ -207,6 +228,158 @@ function elbo_and_gradient(v::VFE, fx::SthenoFGP, y::AbstractVector{<:Real})
         (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}), ctx(), xx.c, gv, gcd, gsd))
     return (elbo = out[1], y = gy, mean = gm, noise = gn, z_noise = gzn,
             zz = (coef = gcz, inscale = gsz), xz = (coef = gcx, inscale = gsx), xx = (coef = gcd, inscale = gsd))
+end
+
+# ---- statistics of FiniteGPs: cov(fx), cov(fx, gx), var, mean_and_*, marginals -------------------------
+# replaces src/gp/util.jl:12-14 and the AbstractGPs FiniteGP defaults that call cov(f::GPPP, x)
+# (gaussian_process_probabilistic_programme.jl:51-64) -> sgp_kernelmatrix / sgp_kernelmatrix_diag
+function kernelmatrix_of(sp::Spec)
+    K = zeros(sp.N, sp.M)
+    (sp.N == 0 || sp.M == 0) && return K
+    GC.@preserve sp K check(ccall((:sgp_kernelmatrix, LIB), Cint, (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Int64),
+        ctx(), sp.c, K, sp.N))
+    return K
+end
+function kernelmatrix_diag_of(sp::Spec)
+    v = zeros(sp.N)
+    sp.N == 0 && return v
+    GC.@preserve sp v check(ccall((:sgp_kernelmatrix_diag, LIB), Cint, (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}),
+        ctx(), sp.c, v))
+    return v
+end
+AbstractGPs.cov(fx::SthenoFGP, gx::SthenoFGP) = kernelmatrix_of(build_spec(fx.f, fx.x, gx.f, gx.x))  # no noise
+AbstractGPs.cov(fx::SthenoFGP) = kernelmatrix_of(build_spec(fx.f, fx.x)) + fx.Σy
+AbstractGPs.var(fx::SthenoFGP) = kernelmatrix_diag_of(build_spec(fx.f, fx.x)) .+ diag(fx.Σy)
+AbstractGPs.mean_and_cov(fx::SthenoFGP) = (mean(fx.f, fx.x), cov(fx))
+AbstractGPs.mean_and_var(fx::SthenoFGP) = (mean(fx.f, fx.x), var(fx))
+AbstractGPs.marginals(fx::SthenoFGP) = ((m, v) = mean_and_var(fx); AbstractGPs.Normal.(m, sqrt.(v)))
+
+# ---- posterior(VFE(fz), fx, y) (src/gp/sparse_finite_gp.jl:60-62) ------------------------------------------
+# Stheno's SparseFiniteGP methods (sparse_finite_gp.jl:52-62) call elbo(VFE(f.finducing), f.fobs, y) and
+# posterior(VFE(f.finducing), f.fobs, y): both land on the overloads of this module, nothing to add.
+mutable struct MI355XSparsePosterior{Tf,Tz} <: AbstractGPs.AbstractGP
+    prior::Tf; z::Tz; handle::Ptr{Cvoid}
+end
+function posterior(v::VFE, fx::SthenoFGP, y::AbstractVector{<:Real})
+    fz = v.fz; @assert fz.f === fx.f
+    zz = build_spec(fz.f, fz.x); xz = build_spec(fx.f, fx.x, fz.f, fz.x)
+    m = collect(Float64, mean(fx.f, fx.x)); kx, nx = noise_args(fx.Σy); kz, nz = noise_args(fz.Σy)
+    yd = collect(Float64, y); h = Ref{Ptr{Cvoid}}(C_NULL)
+    GC.@preserve zz xz m nx nz yd check(ccall((:sgp_sparse_posterior_create, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64},
+         Ptr{Ptr{Cvoid}}), ctx(), zz.c, xz.c, m, kx, nx, kz, nz, yd, h))
+    post = MI355XSparsePosterior(fx.f, fz.x, h[])
+    finalizer(p -> ccall((:sgp_sparse_posterior_destroy, LIB), Cint, (Ptr{Cvoid},), p.handle), post)
+    return post
+end
+function predict(p::MI355XSparsePosterior, xs; want_cov = false)
+    cr = build_spec(p.prior, xs, p.prior, p.z); ss = build_spec(p.prior, xs)
+    ms = collect(Float64, mean(p.prior, xs)); n = length(ms)
+    μ = zeros(n); v = zeros(n); C = want_cov ? zeros(n, n) : zeros(0, 0)
+    GC.@preserve cr ss ms μ v C check(ccall((:sgp_sparse_posterior_predict, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ref{CSpec}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int64),
+        p.handle, cr.c, ss.c, ms, μ, v, want_cov ? pointer(C) : C_NULL, max(n, 1)))
+    return μ, v, C
+end
+AbstractGPs.mean(p::MI355XSparsePosterior, xs::AbstractVector) = predict(p, xs)[1]
+AbstractGPs.var(p::MI355XSparsePosterior, xs::AbstractVector) = predict(p, xs)[2]
+AbstractGPs.cov(p::MI355XSparsePosterior, xs::AbstractVector) = predict(p, xs; want_cov = true)[3]
+AbstractGPs.mean_and_var(p::MI355XSparsePosterior, xs::AbstractVector) = predict(p, xs)[1:2]
+
+# ---- ChainRulesCore.rrule for logpdf(fx, y): what `Zygote.gradient(θ -> logpdf(build_gp(θ)(x, σ²), y), θ)`
+# needs (reference contract: test/gaussian_process_probabilistic_programme.jl:99-104 "does not error";
+# training loops: examples/getting_started/script.jl:154-213).  The device returns d/dy, d/dmean, d/dΣy,
+# per-term d/dcoef and the gradient w.r.t. every uploaded input array (sgp_logpdf_grad_x); the pullback
+# walks the GP tree once more, in the same order as `paths`, and turns them into a structural tangent:
+#   (*, σ::Real, f)      ∂σ  = Σ_{terms through this node} d_coef_t · coef_t · (#times the node is on the term's two paths) / σ
+#   (∘, f, Stretch(l))   ∂l  = ⟨∂X_out, X_in⟩ (scalar l) ;  ∂X_in = l · ∂X_out
+#   leaf ScaledKernel σ² ∂σ² = Σ d_coef_t · coef_t / σ² ;  leaf ScaleTransform s: ∂s = ⟨∂X_out, X_in⟩
+#   AtomicGP inputs      ∂x  = what is left of ∂X at the leaf
+# Function-valued scales σ(x) and custom warps are treated as constants (as on the device).
+using ChainRulesCore
+function logpdf_and_gradient_x(fx::SthenoFGP, y::AbstractVector{<:Real})
+    sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
+    @assert kind != 2 "dense observation noise has no device gradient"
+    yd = collect(Float64, y); n = length(yd); nt = max(1, length(sp.keep[5]))
+    lp = zeros(1); gy = zeros(n); gm = zeros(n); gn = zeros(kind == 1 ? n : 1); gc = zeros(nt); gs = zeros(nt)
+    gx = [zeros(size(X)) for X in sp.keep[3]]; px = [pointer(g) for g in gx]
+    GC.@preserve sp m nz yd gx px check(ccall((:sgp_logpdf_grad_x, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Float64}}),
+        ctx(), sp.c, m, kind, nz, yd, lp, gy, gm, gn, gc, gs, px))
+    return (logpdf = lp[1], y = gy, mean = gm, noise = gn, coef = gc, inscale = gs, inputs = gx, spec = sp)
+end
+
+# parameter bookkeeping of one path: the real-scale nodes it passed (with their σ) and the Stretch warps
+# (with the inputs they were applied to), collected by `trace`, a twin of `paths`
+struct Trace; scales::Vector{Any}; warps::Vector{Any}; atom::AtomicGP; end
+trace(f::AtomicGP, x, sc, wp) = f.gp isa GP ? [Trace(copy(sc), copy(wp), f)] : trace(f.gp, x, sc, wp)
+trace(f::GPPP, x, sc, wp) = trace(extract_components(f, x)..., sc, wp)
+trace(f::DerivedGP, x, sc, wp) = trace(f.args, f, x, sc, wp)
+trace((_, fa, fb)::Tuple{typeof(+),AbstractGP,AbstractGP}, node, x, sc, wp) = vcat(trace(fa, x, sc, wp), trace(fb, x, sc, wp))
+trace((_, b, f)::Tuple{typeof(+),Any,AbstractGP}, node, x, sc, wp) = trace(f, x, sc, wp)
+trace((_, s, f)::Tuple{typeof(*),Real,AbstractGP}, node, x, sc, wp) = trace(f, x, vcat(sc, Any[(node, Float64(s))]), wp)
+trace((_, s, f)::Tuple{typeof(*),Any,AbstractGP}, node, x, sc, wp) = trace(f, x, sc, wp)
+trace((_, f, g)::Tuple{typeof(∘),AbstractGP,Any}, node, x, sc, wp) = trace(f, g.(x), sc, vcat(wp, Any[(node, g, x)]))
+
+function ChainRulesCore.rrule(::typeof(logpdf), fx::SthenoFGP, y::AbstractVector{<:Real})
+    g = logpdf_and_gradient_x(fx, y)
+    function logpdf_pullback(Δ̄)
+        Δ = unthunk(Δ̄)
+        sp = g.spec; rp = sp.keep[1]; terms = sp.keep[5]; tptr = sp.keep[6]
+        rows = blocks_of(fx.f, fx.x)
+        tr = [trace(n, v, Any[], Any[]) for (n, v) in rows]          # same order as rp
+        dσ = IdDict{Any,Float64}(); dl = IdDict{Any,Any}(); dX = [zeros(size(mat(v))) for (_, v) in rows]
+        # coefficients: term t of block pair (I, J) pairs path p of I with path q of J, in `build_spec` order
+        t = 0
+        for I in eachindex(rp), J in eachindex(rp), (ip, p) in enumerate(rp[I]), (iq, q) in enumerate(rp[J])
+            p.key == q.key || continue
+            for _ in leaf(p.atom.gp.kernel)
+                t += 1
+                for (node, σ) in vcat(tr[I][ip].scales, tr[J][iq].scales)
+                    dσ[node] = get(dσ, node, 0.0) + g.coef[t] * terms[t].coef / σ
+                end
+            end
+        end
+        # inputs: spec input k was registered by term order as well (row input, then column input)
+        k = 0
+        for I in eachindex(rp), J in eachindex(rp), (ip, p) in enumerate(rp[I]), (iq, q) in enumerate(rp[J])
+            p.key == q.key || continue
+            for (_, _, _, s) in leaf(p.atom.gp.kernel)
+                for (B, ib) in ((I, ip), (J, iq))
+                    k += 1
+                    G = (s isa Real ? s : 1.0) .* g.inputs[k]          # undo the kernel's ScaleTransform
+                    for (node, w, xin) in reverse(tr[B][ib].warps)
+                        if w isa Stheno.Stretch{<:Real}
+                            dl[node] = get(dl, node, 0.0) + sum(G .* mat(xin))
+                            G = w.l .* G
+                        end                                            # other warps: held fixed
+                    end
+                    size(G) == size(dX[B]) && (dX[B] .+= G)
+                end
+            end
+        end
+        tangent(f::AtomicGP) = NoTangent()
+        tangent(f::GPPP) = Tangent{typeof(f)}(fs = map(tangent, f.fs))
+        function tangent(f::DerivedGP)
+            a = f.args
+            if a[1] === (*) && a[2] isa Real
+                return Tangent{typeof(f)}(args = (NoTangent(), Δ * get(dσ, f, 0.0), tangent(a[3])))
+            elseif a[1] === (∘) && a[3] isa Stheno.Stretch{<:Real}
+                return Tangent{typeof(f)}(args = (NoTangent(), tangent(a[2]), Tangent{typeof(a[3])}(l = Δ * get(dl, f, 0.0))))
+            elseif a[1] === (+) && a[2] isa AbstractGP
+                return Tangent{typeof(f)}(args = (NoTangent(), tangent(a[2]), tangent(a[3])))
+            elseif length(a) == 3 && a[3] isa AbstractGP
+                return Tangent{typeof(f)}(args = (NoTangent(), NoTangent(), tangent(a[3])))
+            end
+            return NoTangent()
+        end
+        ∂Σ = g.noise isa Vector && length(g.noise) == 1 ? Tangent{typeof(fx.Σy)}(value = Δ * g.noise[1]) :
+             Tangent{typeof(fx.Σy)}(diag = Δ .* g.noise)
+        ∂fx = Tangent{typeof(fx)}(f = tangent(fx.f), x = Δ .* dX, Σy = ∂Σ)
+        return NoTangent(), ∂fx, Δ .* g.y
+    end
+    return g.logpdf, logpdf_pullback
 end
 
 end # module

@@ -167,8 +167,13 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
   auto init = [&]() -> int {
     int lo = 0, hi = 0;
     SGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    SGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
-    SGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
+    // SGP_STREAM_PRIO=swap|equal: A/B knobs for the look-ahead's stream priorities (default: panel stream high)
+    const char* sp = getenv("SGP_STREAM_PRIO");
+    int p1 = hi, p2 = lo;
+    if (sp && !strcmp(sp, "swap")) { p1 = lo; p2 = hi; }
+    if (sp && !strcmp(sp, "equal")) { p1 = lo; p2 = lo; }
+    SGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p1));
+    SGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, p2));
     SGP_HIP(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     SGP_HIP(hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming));
     const char* la = getenv("SGP_LOOKAHEAD");
@@ -572,7 +577,15 @@ static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long
 static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
                          hipStream_t s, long grow = 0) {
   CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
-  const long WOUT = ctx->wout > 0 ? ctx->wout : (n_pad >= 32768 ? WOUT_LARGE : WOUT_SMALL);
+  // outer panel width, measured (profiles/r02_summary.md): one panel for n_pad <= 2048 (the outer level only
+  // adds launches there: 1.52 -> 1.30 ms at N = 2048), 1024 up to 8192 (3.35 -> 3.16 ms at N = 4096), 512 in the
+  // mid range where the panel stream is the critical path (N = 16384: 34.8 vs 35.4 ms), 1024 from 32768 on
+  // (halves the C-tile traffic per flop of the big trailing updates).
+  const long WOUT = ctx->wout > 0 ? ctx->wout
+                    : n_pad <= 2048 ? n_pad
+                    : n_pad <= 8192 ? WOUT_LARGE
+                    : n_pad >= 32768 ? WOUT_LARGE
+                                     : WOUT_SMALL;
   const bool la = ctx->lookahead && s == ctx->stream;
   hipStream_t sB = la ? ctx->stream2 : s;
   bool rest_pending = false;

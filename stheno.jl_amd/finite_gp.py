@@ -263,8 +263,9 @@ def rand(rng, fx, S=None, Z=None):
 class PosteriorGP:
     """posterior(fx, y): keeps L and L^-1 (y - m) in HBM (sgp_post); data = (alpha, x, delta)."""
 
-    def __init__(self, prior, x, handle, alpha, delta):
+    def __init__(self, prior, x, handle, alpha, delta, noise=None, y=None):
         self.prior, self.x, self._h, self.alpha, self.delta = prior, x, handle, alpha, delta
+        self.noise, self.y = noise, y      # kept for sequential conditioning (posterior of a posterior)
 
     def __del__(self):  # pragma: no cover
         try:
@@ -325,8 +326,27 @@ def posterior(fx, y, y_vfe=None):
         return posterior_vfe(fx, y, y_vfe)
     if isinstance(fx, SparseFiniteGP):
         return posterior_vfe(VFE(fx.finducing), fx.fobs, y)
+    if isinstance(fx.f, PosteriorGP):
+        # Sequential conditioning (AbstractGPs: posterior(f_post(x2, s2), y2) is again a PosteriorGP): the
+        # posterior given (x1, y1) and then (x2, y2) IS the prior conditioned on the stacked data, which is
+        # one factorisation of the joint covariance on the device instead of a Schur-complement update.
+        p1 = fx.f
+        if p1.noise is None:
+            raise NotImplementedError("this posterior does not carry its observation model")
+        n1, n2 = len(p1.x), len(fx)
+        a1, a2 = np.asarray(p1.noise, dtype=np.float64), np.asarray(fx.noise, dtype=np.float64)
+        if a1.ndim > 1 or a2.ndim > 1:
+            raise NotImplementedError("sequential conditioning with dense observation noise")
+        if a1.ndim == 0 and a2.ndim == 0 and float(a1) == float(a2):
+            noise = float(a1)
+        else:
+            noise = np.concatenate([_noise_diag(a1, n1), _noise_diag(a2, n2)])
+        x1 = p1.x if isinstance(p1.x, BlockData) else BlockData([p1.x])
+        xx = _concat(x1, fx.x)
+        yy = np.concatenate([p1.y, np.asarray(y, dtype=np.float64).ravel()])
+        return posterior(FiniteGP(p1.prior, xx, noise), yy)
     if not _is_prior(fx.f):
-        raise NotImplementedError("posterior of a posterior: condition the prior on the stacked data instead")
+        raise NotImplementedError("posterior on top of an approximate (VFE) posterior")
     y = _f64(np.asarray(y, dtype=np.float64).ravel())
     n = len(fx)
     if y.shape[0] != n:
@@ -339,7 +359,7 @@ def posterior(fx, y, y_vfe=None):
     rc = _ctx().lib.sgp_posterior_create(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(y),
                                          _lib.dptr(alpha), C.byref(h))
     _lib.check(rc, "sgp_posterior_create")
-    return PosteriorGP(fx.f, fx.x, h, alpha, y - m)
+    return PosteriorGP(fx.f, fx.x, h, alpha, y - m, fx.noise, y.copy())
 
 
 # ---- VFE / sparse --------------------------------------------------------------------------------

@@ -210,6 +210,34 @@ def test_posterior_external_consistency():
     assert np.array_equal(P.cov(a), P.cov(b))
 
 
+def test_sequential_conditioning_posterior_of_posterior():
+    """AbstractGPs allows posterior(f_post(x2, s2), y2); the oracle does it as a second conditioning on the
+    first posterior's mean / cov, the product as ONE conditioning of the prior on the stacked data."""
+    rng = np.random.default_rng(31)
+    Fo, Fp, fo, fp = both(models.gppp_docstring)
+    D = 2
+    x1 = np.asfortranarray(rng.standard_normal((D, 70)))
+    x2 = np.asfortranarray(rng.standard_normal((D, 40)))
+    xs = np.asfortranarray(rng.standard_normal((D, 25)))
+    y1, y2 = rng.standard_normal(70), rng.standard_normal(40)
+    po1 = oagp.posterior(Fo(ost.GPPPInput("f3", okf.ColVecs(x1)), 0.1), y1)
+    po2 = oagp.posterior(po1(ost.GPPPInput("f1", okf.ColVecs(x2)), 0.3), y2)
+    pp1 = P.posterior(Fp(P.GPPPInput("f3", P.ColVecs(x1)), 0.1), y1)
+    pp2 = P.posterior(pp1(P.GPPPInput("f1", P.ColVecs(x2)), 0.3), y2)
+    for name in ("f1", "f2", "f3"):
+        mo, vo = po2.mean_and_var(ost.GPPPInput(name, okf.ColVecs(xs)))
+        mp, vp = pp2.mean_and_var(P.GPPPInput(name, P.ColVecs(xs)))
+        assert np.max(np.abs(mp - mo)) < 1e-9 and np.max(np.abs(vp - vo)) < 1e-9, name
+    # plain (non-GPPP) prior, equal scalar noises
+    f_o, f_p = ost.atomic(oagp.GP(okf.Matern32Kernel()), ost.GPC()), P.atomic(P.GP(P.Matern32Kernel()), P.GPC())
+    a, b, c = rng.standard_normal(30), rng.standard_normal(20), rng.standard_normal(9)
+    ya, yb = rng.standard_normal(30), rng.standard_normal(20)
+    qo = oagp.posterior(oagp.posterior(f_o(a, 0.2), ya)(b, 0.2), yb)
+    qp = P.posterior(P.posterior(f_p(a, 0.2), ya)(b, 0.2), yb)
+    assert np.max(np.abs(qp.mean(c) - qo.mean(c))) < 1e-9
+    assert np.max(np.abs(qp.cov(c) - qo.cov(c))) < 1e-9
+
+
 def test_non_positive_definite_raises_posdef():
     f = P.atomic(P.GP(P.SEKernel()), P.GPC())
     x = np.zeros(10)                       # rank-one covariance, negative "noise"
