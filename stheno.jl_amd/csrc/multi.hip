@@ -78,6 +78,12 @@ struct Rank {
   int dev = 0;
   sgp_ctx* ctx = nullptr;        // child context (kernels + scratch of this rank)
   hipStream_t s_upd = nullptr, s_panel = nullptr, s_comm = nullptr;
+  // A rank's trailing panels are separate (packed) matrices, one update launch each; issued round-robin
+  // on a small pool of streams the tail of one launch overlaps the head of the next (a panel always uses
+  // the same pool stream, so its successive updates stay ordered).
+  static constexpr int NPOOL = 3;
+  hipStream_t s_pool[NPOOL] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_pool[NPOOL] = {nullptr, nullptr, nullptr}, ev_fork = nullptr;
   hipEvent_t ev_upd = nullptr, ev_fact = nullptr, ev_recv[2] = {nullptr, nullptr}, ev_done = nullptr;
   bool factored_once = false;
   double* store = nullptr;       // owned panels, packed
@@ -155,8 +161,14 @@ void sgp_multi_destroy(sgp_multi* m) {
       if (b) hipFree(b);
     if (k.d_small) hipFree(k.d_small);
     if (k.d_info) hipFree(k.d_info);
-    for (hipEvent_t e : {k.ev_upd, k.ev_fact, k.ev_recv[0], k.ev_recv[1], k.ev_done})
+    for (hipEvent_t e : {k.ev_upd, k.ev_fact, k.ev_recv[0], k.ev_recv[1], k.ev_done, k.ev_fork, k.ev_pool[0], k.ev_pool[1],
+                         k.ev_pool[2]})
       if (e) hipEventDestroy(e);
+    for (auto st : k.s_pool)
+      if (st) {
+        hipStreamSynchronize(st);
+        hipStreamDestroy(st);
+      }
     if (k.s_comm) hipStreamDestroy(k.s_comm);
     if (k.ctx) sgp_ctx_destroy(k.ctx);   // owns s_upd / s_panel
   }
@@ -204,8 +216,11 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     k.s_upd = k.ctx->stream2;
     if (hipSetDevice(k.dev) != hipSuccess) return fail(-2);
     if (hipStreamCreateWithFlags(&k.s_comm, hipStreamNonBlocking) != hipSuccess) return fail(-2);
-    for (hipEvent_t* e : {&k.ev_upd, &k.ev_fact, &k.ev_recv[0], &k.ev_recv[1], &k.ev_done})
+    for (hipEvent_t* e : {&k.ev_upd, &k.ev_fact, &k.ev_recv[0], &k.ev_recv[1], &k.ev_done, &k.ev_fork, &k.ev_pool[0],
+                          &k.ev_pool[1], &k.ev_pool[2]})
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(-2);
+    for (auto& st : k.s_pool)
+      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(-2);
     if (hipMalloc(&k.d_info, sizeof(int)) != hipSuccess) return fail(-2);
   }
   if (m->transport == TR_P2P || m->transport == TR_RCCL) {
@@ -354,6 +369,7 @@ int sgp_multi_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
       hipStreamSynchronize(m->r[i].s_upd);
       hipStreamSynchronize(m->r[i].s_panel);
       hipStreamSynchronize(m->r[i].s_comm);
+      for (auto st : m->r[i].s_pool) hipStreamSynchronize(st);
       if (ds[i]) sgp_dspec_destroy(ds[i]);
     }
     hipSetDevice(ctx->device);
@@ -445,11 +461,17 @@ int sgp_multi_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
         M_RC(factor(nxt));
         M_RC(broadcast_panel(m, g, nxt));
       }
-      for (int i = 0; i < P; ++i) {   // (c) the rest of every rank's trailing panels
+      for (int i = 0; i < P; ++i) {   // (c) the rest of every rank's trailing panels, fanned over the stream pool
         Rank& k = m->r[i];
         M_HIP(hipSetDevice(k.dev));
+        M_HIP(hipEventRecord(k.ev_fork, k.s_upd));
+        for (auto st : k.s_pool) M_HIP(hipStreamWaitEvent(st, k.ev_fork, 0));
         for (long Jp = i; Jp < g.npan; Jp += P)
-          if (Jp > nxt) M_RC(update_panel(m, g, J, Jp, i, k.s_upd));
+          if (Jp > nxt) M_RC(update_panel(m, g, J, Jp, i, k.s_pool[(Jp / P) % Rank::NPOOL]));
+        for (int q = 0; q < Rank::NPOOL; ++q) {
+          M_HIP(hipEventRecord(k.ev_pool[q], k.s_pool[q]));
+          M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_pool[q], 0));
+        }
         M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
       }
     }
