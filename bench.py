@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--panel", type=int, default=1024, help="column-panel width of the multi-GPU path")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded (multi-GPU) driver even at 1 GPU")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer C-ABI leg")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
+                    help="f32: the fp32 instantiation (sgp_logpdf_f32, host-buffer entry point; 1 GPU, dense configs)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout.  Native libraries may write there too (RCCL prints a
@@ -128,6 +130,17 @@ def main():
         def step(tm=None):
             L.check(lib.sgp_elbo(ctx.handle, zz.ref(), xz.ref(), L.dptr(var_x), L.dptr(mean_x), nk, L.dptr(nbuf), zk,
                                  L.dptr(zbuf), L.dptr(y), L.dptr(out)), "sgp_elbo")
+            return float(out[0])
+    elif args.dtype == "f32":
+        if use_dist:
+            raise SystemExit("--dtype f32 is a single-GPU line")
+        yh = np.ascontiguousarray(y)
+        out = np.zeros(1)
+        nz = np.array([sigma2])
+
+        def step(tm=None):
+            L.check(lib.sgp_logpdf_f32(ctx.handle, spec.ref(), None, L.NOISE_SCALAR, L.dptr(nz), L.dptr(yh), L.dptr(out)),
+                    "sgp_logpdf_f32")
             return float(out[0])
     elif not use_dist:
         ds = C.c_void_p()
@@ -210,7 +223,13 @@ def main():
         whole_tflops = flops / (ms_per_step * 1e-3) / 1e12
     else:
         whole_tflops = (N ** 3 / 3.0) / (ms_per_step * 1e-3) / 1e12
-    if not use_dist and not is_elbo:
+    if args.dtype == "f32" and not is_elbo:
+        PEAK_F32 = 157.3   # v_mfma_f32_32x32x2_f32 / fp32 vector peak (guide section 3)
+        roofline = {"kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32 trailing updates; untuned second instantiation)",
+                    "bound": "mfma", "achieved": whole_tflops, "peak": PEAK_F32, "unit": "TFLOP/s",
+                    "frac": whole_tflops / PEAK_F32, "traffic": None,
+                    "note": "whole-step N^3/3 rate of the fp32 path (host-buffer entry point, single stream, no look-ahead)"}
+    if not use_dist and not is_elbo and args.dtype == "f64":
         step(timings)
         upd_ms, n_launch, upd_flops = timings[3], int(timings[4]), timings[5]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
@@ -259,7 +278,7 @@ def main():
     if rank == 0:
         g = bc.golden(args.config)
         gval = None if g is None else g.get("elbo" if is_elbo else "logpdf")
-        parity = None if gval is None else abs(val - gval) / abs(gval)
+        parity = None if gval is None else abs(val - gval) / abs(gval)   # (fp32 lines: fp32 accuracy, ~1e-6)
         cpu = None
         if args.cpu_sample > 0 and world == 1:
             cpu = cpu_baseline(args.config, args.cpu_sample * (2 if is_elbo else 1))
@@ -267,13 +286,13 @@ def main():
             "metric": "elbo_per_sec" if is_elbo else "logpdf_per_sec",
             "value": 1e3 / ms_per_step, "unit": "elbo/s" if is_elbo else "logpdf/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": bc.describe(args.config) + (", host-buffer C-ABI" if is_elbo else ""),
                        "N": N, "D": D, "kernel": kind,
                        "parallelism": f"column-panel x{world}" if use_dist else "1 GPU",
                        "panel_width": args.panel if use_dist else None},
             "cholesky_tflops_whole_step": whole_tflops,  # (c4: ELBO flops of SURVEY 8d)
-            "cholesky_frac_of_fp64_matrix_peak": whole_tflops / (PEAK_FP64_MFMA_TFLOPS * world),
+            "cholesky_frac_of_fp64_matrix_peak": whole_tflops / (PEAK_FP64_MFMA_TFLOPS * world) if args.dtype == "f64" else None,
             "logpdf": val, "golden": gval, "parity_rel": parity,
             "stages": stages, "roofline": roofline, "host_api": host_api, "cpu_baseline": cpu,
         }

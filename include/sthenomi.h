@@ -142,6 +142,15 @@ int sgp_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, double* out);
 int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                const double* noise, const double* Y, int64_t ldy, int64_t ncols, double* out);
 
+/* ---- fp32 instantiation (the reference is type-stable in Float32:
+ * /root/reference/test/gp/util.jl:76-88).  Same spec (the fp64 inputs are rounded to fp32 once on the
+ * device), covariance assembly, blocked Cholesky (v_mfma_f32_32x32x2_f32 updates) and forward substitution
+ * in single precision; the scalar result is returned as a double holding the fp32-accurate value.
+ * y is one vector (N); noise SCALAR or DIAG.  sgp_kernelmatrix_f32: cov(f, x) / cov(f, x, x') as fp32. */
+int sgp_logpdf_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                   const double* noise, const double* y, double* out);
+int sgp_kernelmatrix_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, float* K, int64_t ldk);
+
 /* ---- logpdf and its reverse-mode gradient -------------------------------
  * What Zygote derives through `logpdf(f(x, s2), y)` on the reference path for hyper-parameter
  * learning (examples/getting_started/script.jl:154-213; AD glue: SURVEY.md section 2 #11).
@@ -320,6 +329,8 @@ int sgp_dev_elbo_finish(sgp_ctx* ctx, int64_t M, int64_t N_total, double* d_part
 /* micro-benchmarks used to pin the roofline peaks on the box */
 int sgp_bench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops_out, double* layout_maxerr_out);
 int sgp_bench_hbm(sgp_ctx* ctx, int64_t bytes, int iters, double* write_gbs_out, double* copy_gbs_out);
+/* one potrf_diag launch (128 x 128 diagonal block) timed by HIP events, plus s_memtime stamps of its phases */
+int sgp_bench_potrf(sgp_ctx* ctx, int iters, double* us_out, long long* stamps_out /* [64] */);
 /* raw GEMM-NT kernel timing: C(m x n) -= A(m x k) B(n x k)' on random data */
 int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only, int iters,
                    double* tflops_out, double* maxerr_out);

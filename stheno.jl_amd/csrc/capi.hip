@@ -404,6 +404,10 @@ static void dspec_free(sgp_dspec* ds) {
   delete ds;
 }
 
+// for the other translation units (f32.hip): the caller holds the context
+int sgp_dspec_create_nolock(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out) { return dspec_create(ctx, sp, out); }
+void sgp_dspec_free_nolock(sgp_dspec* ds) { dspec_free(ds); }
+
 extern "C" int sgp_dspec_destroy(sgp_dspec* ds) {
   if (!ds) return 0;
   if (tl_ctx == ds->ctx) {  // called from inside an entry point of the same context
@@ -2273,6 +2277,47 @@ __global__ void fill_rand_kernel(double* p, long n, unsigned long long seed) {
   unsigned long long x = seed + (unsigned long long)i * 0x9E3779B97F4A7C15ULL;
   x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31;
   p[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
+}
+
+// one potrf_diag launch on a well-conditioned 128 x 128 tile with s_memtime stamps of wave 0 at its phase
+// boundaries (stamps_out[64], ticks; 0-terminated) and the launch time by HIP events (us_out)
+extern "C" int sgp_bench_potrf(sgp_ctx* ctx, int iters, double* us_out, long long* stamps_out) {
+  CHECK_ARG(ctx && us_out && stamps_out, "sgp_bench_potrf: NULL argument");
+  CtxScope scope(ctx);
+  hipStream_t s = ctx->stream;
+  DevBuf A, A0;
+  CHECK_RC(A.alloc((size_t)TILE * TILE));
+  CHECK_RC(A0.alloc((size_t)TILE * TILE));
+  std::vector<double> h((size_t)TILE * TILE);
+  for (int c = 0; c < TILE; ++c)
+    for (int r = 0; r < TILE; ++r) h[r + (size_t)c * TILE] = (r == c ? 2.0 : 0.0) + std::exp(-0.02 * (r - c) * (r - c));
+  SGP_HIP(hipMemcpy(A0.p, h.data(), sizeof(double) * TILE * TILE, hipMemcpyHostToDevice));
+  long long* d_dbg = nullptr;
+  SGP_HIP(hipMalloc(&d_dbg, sizeof(long long) * 64));
+  SGP_HIP(hipMemset(d_dbg, 0, sizeof(long long) * 64));
+  hipEvent_t e0, e1;
+  SGP_HIP(hipEventCreate(&e0));
+  SGP_HIP(hipEventCreate(&e1));
+  double tot = 0;
+  for (int it = 0; it < iters + 1; ++it) {
+    SGP_HIP(hipMemcpyAsync(A.p, A0.p, sizeof(double) * TILE * TILE, hipMemcpyDeviceToDevice, s));
+    SGP_HIP(hipEventRecord(e0, s));
+    if (it == iters)
+      CHECK_RC(launch_potrf_diag_dbg(A.p, TILE, ctx->d_invd, ctx->d_slots, ctx->d_info, d_dbg, s));
+    else
+      CHECK_RC(launch_potrf_diag(A.p, TILE, ctx->d_invd, ctx->d_slots, ctx->d_info, 0, s));
+    SGP_HIP(hipEventRecord(e1, s));
+    SGP_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    SGP_HIP(hipEventElapsedTime(&ms, e0, e1));
+    if (it > 0 && it < iters) tot += ms;
+  }
+  *us_out = tot / std::max(1, iters - 1) * 1e3;
+  SGP_HIP(hipMemcpy(stamps_out, d_dbg, sizeof(long long) * 64, hipMemcpyDeviceToHost));
+  hipFree(d_dbg);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  return 0;
 }
 
 extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only,

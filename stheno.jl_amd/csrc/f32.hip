@@ -1,0 +1,533 @@
+// fp32 instantiation of the hot path: covariance assembly + blocked Cholesky logpdf in single precision
+// (the reference is type-stable in Float32: /root/reference/test/gp/util.jl:76-88).
+//
+// A second, smaller set of kernels -- the fp64 kernels are designs around the f64 MFMA forms and their
+// lane maps, not templates -- sharing the data layout (bordered m_tot x n_pad matrix, 128-tile grid,
+// (y - m)' as a bordered row so that the forward substitution rides along) and the flattened spec:
+//   assemble_f32_kernel     fused distance + kappa + scales + sum of terms + noise, fp32 arithmetic
+//                           (inputs stay fp64 in HBM and are rounded once while staged into LDS)
+//   gemm_nt_f32_kernel      C -= A B' on v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s peak): 128 x 128 tile,
+//                           4 waves x (2 x 2) MFMA tiles, K chunks of 16 through two LDS stages
+//   potrf_f32_kernel        128 x 128 diagonal block in LDS: 16-column sub-panels, wave-0 micro-Cholesky
+//                           (v_readlane broadcasts), row-per-thread sub-panel solve, VALU trailing update
+//   trsm_f32_kernel         X <- X inv(L11)' by substitution, one row per thread, L11 through scalar loads
+// Driver: two-level right-looking Cholesky (outer panels of 512, 128-column steps inside), one stream.
+// Entry points: sgp_logpdf_f32, sgp_kernelmatrix_f32 (include/sthenomi.h).  Accuracy is fp32's: the
+// tests hold 1e-4 relative on logpdf against the fp64 oracle at N <= 3000.
+#include "ctx.h"
+
+#include <algorithm>
+#include <cmath>
+
+using namespace sgp;
+
+namespace {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+constexpr int KBF = 16;          // K chunk of the fp32 GEMM
+constexpr int LDF = 128 + 4;     // LDS leading dimension (floats) of a 128-row operand chunk
+
+enum { K_SE = 0, K_M12 = 1, K_M32 = 2, K_M52 = 3, K_WHITE = 4, K_CONST = 5 };
+
+__device__ __forceinline__ float kern_f32(int kind, float d2, float param) {
+  switch (kind) {
+    case K_SE: return __expf(-0.5f * d2);
+    case K_M12: return __expf(-sqrtf(d2));
+    case K_M32: {
+      float l = 1.7320508f * sqrtf(d2);
+      return (1.0f + l) * __expf(-l);
+    }
+    case K_M52: {
+      float l = 2.236068f * sqrtf(d2);
+      return fmaf(l, fmaf(l, 0.33333334f, 1.0f), 1.0f) * __expf(-l);
+    }
+    case K_WHITE: return d2 == 0.0f ? 1.0f : 0.0f;
+    default: return param;
+  }
+}
+
+// one 256-thread workgroup per 128 x 128 tile; thread t owns row (t & 127) and 64 columns of half t >> 7
+template <int DMAX>
+__global__ __launch_bounds__(256) void assemble_f32_kernel(float* K, long ld, long r0, long nr, long c0, long nc,
+                                                           const DevTerm* terms, int nterms, int lower_only,
+                                                           int noise_kind, float sigma2, const double* noise_diag,
+                                                           long tile_r_first, long tile_c_first) {
+  const long gtr = tile_r_first + blockIdx.x, gtc = tile_c_first + blockIdx.y;
+  if (lower_only && gtr < gtc) return;
+  extern __shared__ __attribute__((aligned(16))) float smf[];  // [nterms][128][DMAX] column points
+  const int t = threadIdx.x, trow = t & 127, th = t >> 7;
+  long cbeg = std::max(gtc * TILE, c0), cend = std::min(gtc * TILE + TILE, c0 + nc);
+  long rbeg = std::max(gtr * TILE, r0), rend = std::min(gtr * TILE + TILE, r0 + nr);
+  if (cbeg >= cend || rbeg >= rend) return;
+  for (int tm = 0; tm < nterms; ++tm) {
+    const DevTerm T = terms[tm];
+    for (int idx = t; idx < TILE * DMAX; idx += 256) {
+      const int p = idx / DMAX, d = idx % DMAX;
+      const long gc = gtc * TILE + p;
+      smf[(tm * TILE + p) * DMAX + d] = (d < T.dim && gc >= cbeg && gc < cend) ? (float)T.xc[(gc - c0) * T.ldc + d] : 0.0f;
+    }
+  }
+  __syncthreads();
+  const long grow = gtr * TILE + trow;
+  if (grow < rbeg || grow >= rend) return;
+  const long lrow = grow - r0;
+  for (int jc = 0; jc < 64; jc += 8) {
+    const int pbase = th * 64 + jc;
+    if (gtc * TILE + pbase >= cend) break;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.0f;
+    for (int tm = 0; tm < nterms; ++tm) {
+      const DevTerm T = terms[tm];
+      float xi[DMAX];
+#pragma unroll
+      for (int d = 0; d < DMAX; ++d) xi[d] = (d < T.dim) ? (float)T.xr[lrow * T.ldr + d] : 0.0f;
+      const float rsv = (float)(T.coef * (T.rs ? T.rs[lrow] : 1.0));
+      const float* sp = &smf[(tm * TILE + pbase) * DMAX];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const long gc = gtc * TILE + pbase + q;
+        float d2 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) {
+          const float df = xi[d] - sp[q * DMAX + d];
+          d2 = fmaf(df, df, d2);
+        }
+        float cw = rsv;
+        if (T.cs) cw = (gc >= cbeg && gc < cend) ? rsv * (float)T.cs[gc - c0] : 0.0f;
+        acc[q] = fmaf(kern_f32(T.kind, d2, (float)T.param), cw, acc[q]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const long gc = gtc * TILE + pbase + q;
+      if (gc >= cbeg && gc < cend) {
+        float v = acc[q];
+        if (noise_kind >= 0 && gc == grow) v += (noise_kind == 0) ? sigma2 : (float)noise_diag[grow];
+        K[grow + gc * ld] = v;
+      }
+    }
+  }
+}
+
+// identity padding of rows / columns N .. n_pad, zeros below the square part of padded columns
+__global__ void fill_pad_f32_kernel(float* K, long ld, long N, long n_pad, long m_tot) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long h = n_pad - N;
+  if (h <= 0) return;
+  if (idx < h * n_pad) {                       // rows [N, n_pad) of every column
+    const long r = N + idx % h, c = idx / h;
+    K[r + c * ld] = (r == c) ? 1.0f : 0.0f;
+  }
+  if (idx < h * m_tot) {                       // columns [N, n_pad), all rows
+    const long c = N + idx % h, r = idx / h;
+    K[r + c * ld] = (r == c) ? 1.0f : 0.0f;
+  }
+}
+
+// bordered rows: A[n_pad + s, c] = y[c] - mean[c] (s == 0, c < N), 0 otherwise (128 rows)
+__global__ void border_f32_kernel(float* A, long ld, long n_pad, long N, const double* y, const double* mean) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)TILE * n_pad) return;
+  const long s = idx % TILE, c = idx / TILE;
+  A[n_pad + s + c * ld] = (s == 0 && c < N) ? (float)(y[c] - (mean ? mean[c] : 0.0)) : 0.0f;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// C (M x Nc, lower 128-tiles when lower != 0) -= A (M x K) B (Nc x K)', all column-major fp32.
+// MFMA 32x32x2 f32 (guide section 3): a-operand lane l = Aop[i = l & 31][k = l >> 5], b-operand lane l =
+// Bop[k = l >> 5][j = l & 31], result reg r = D[i = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][j = l & 31].  The tile is
+// computed TRANSPOSED (Aop = rows of B, Bop = rows of A), so j = l & 31 runs along the contiguous row index
+// of C: one store instruction writes 32 consecutive rows of two columns.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* A, long lda, const float* B, long ldb, float* C,
+                                                          long ldc, long K, int lower, long n_tr, long n_tc) {
+  const long tr = blockIdx.x, tc = blockIdx.y;
+  if (tr >= n_tr || tc >= n_tc || (lower && tr < tc)) return;
+  __shared__ __attribute__((aligned(16))) float sA[2][KBF * LDF];
+  __shared__ __attribute__((aligned(16))) float sB[2][KBF * LDF];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wr = w >> 1, wc = w & 1;       // wave tile: rows wr * 64 .., cols wc * 64 ..
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* Ag = A + tr * TILE;
+  const float* Bg = B + tc * TILE;
+  // staging: thread t moves rows 4 (t & 31) .. +3 of columns (t >> 5) and (t >> 5) + 8 of both operands
+  const int srow = 4 * (t & 31), scol = t >> 5;
+  f16v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  float4 ra[2], rb[2];
+  auto gload = [&](long k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = *reinterpret_cast<const float4*>(Ag + srow + (k0 + scol + 8 * i) * lda);
+      rb[i] = *reinterpret_cast<const float4*>(Bg + srow + (k0 + scol + 8 * i) * ldb);
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&sA[buf][(scol + 8 * i) * LDF + srow]) = ra[i];
+      *reinterpret_cast<float4*>(&sB[buf][(scol + 8 * i) * LDF + srow]) = rb[i];
+    }
+  };
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int ks = 0; ks < KBF / 2; ++ks) {
+      const int kk = 2 * ks + lh;
+      float av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = sA[buf][kk * LDF + wr * 64 + a * 32 + l31];   // rows of the C tile
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bv[b] = sB[buf][kk * LDF + wc * 64 + b * 32 + l31];   // columns of the C tile
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[b], av[a], acc[a][b], 0, 0, 0);
+    }
+  };
+  gload(0);
+  sstore(0);
+  __syncthreads();
+  int buf = 0;
+  for (long k0 = KBF; k0 < K; k0 += KBF) {
+    gload(k0);
+    compute(buf);
+    sstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+  }
+  compute(buf);
+  // acc[a][b][r]: row = wr * 64 + a * 32 + l31, column = wc * 64 + b * 32 + (r & 3) + 8 (r >> 2) + 4 lh
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long row = tr * TILE + wr * 64 + a * 32 + l31;
+        const long col = tc * TILE + wc * 64 + b * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* p = C + row + col * ldc;
+        *p -= acc[a][b][r];
+      }
+}
+
+int launch_gemm_f32(const float* A, long lda, const float* B, long ldb, float* C, long ldc, long M, long Nc, long K,
+                    int lower, hipStream_t s) {
+  if (M <= 0 || Nc <= 0 || K <= 0) return 0;
+  hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((unsigned)(M / TILE), (unsigned)(Nc / TILE)), dim3(256), 0, s, A, lda, B,
+                     ldb, C, ldc, K, lower, M / TILE, Nc / TILE);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// 128 x 128 diagonal block Cholesky, fp32, one 256-thread workgroup, tile in LDS (column-major, ld 129).
+// Per 16-column sub-panel: wave 0 factors the 16 x 16 diagonal block in registers (lane i = row i, v_readlane
+// broadcasts); threads 0..127 solve their row of the sub-panel by substitution; all threads apply the
+// rank-16 update to the trailing block.  logdet partial in fp64.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int LDP = TILE + 1;
+__global__ __launch_bounds__(256) void potrf_f32_kernel(float* A, long ld, float* Lt, double* logdet_slot, int* info,
+                                                        long gcol0) {
+  extern __shared__ __attribute__((aligned(16))) float sT[];  // 128 x 129
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  for (int idx = t; idx < TILE * TILE; idx += 256) {
+    const int r = idx & 127, c = idx >> 7;
+    sT[r + c * LDP] = (r >= c) ? A[r + (long)c * ld] : 0.0f;
+  }
+  __syncthreads();
+  int firstbad = 1 << 20;
+  for (int cb = 0; cb < 8; ++cb) {
+    const int c0 = cb * 16;
+    if (w == 0) {          // micro-Cholesky of the 16 x 16 diagonal block
+      const int i = lane & 15;
+      float row[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) row[c] = sT[(c0 + i) + (c0 + c) * LDP];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row[j]), j));
+        firstbad = (djj > 0.0f) ? firstbad : min(firstbad, c0 + j);
+        const float r = rsqrtf(djj);
+        const float lij = (i == j) ? djj * r : row[j] * r;
+        row[j] = lij;
+#pragma unroll
+        for (int c2 = j + 1; c2 < 16; ++c2) {
+          const float lcj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lij), c2));
+          row[c2] = fmaf(-lij, lcj, row[c2]);
+        }
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) sT[(c0 + i) + (c0 + c) * LDP] = (c <= i) ? row[c] : 0.0f;
+      }
+    }
+    __syncthreads();
+    // sub-panel solve: row r > c0 + 15: x_j = (x_j - sum_{k<j} x_k L[j][k]) / L[j][j]
+    if (t < TILE && t >= c0 + 16) {
+      float x[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) x[j] = sT[t + (c0 + j) * LDP];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        float v = x[j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) v = fmaf(-x[k], sT[(c0 + j) + (c0 + k) * LDP], v);
+        x[j] = v / sT[(c0 + j) + (c0 + j) * LDP];
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) sT[t + (c0 + j) * LDP] = x[j];
+    }
+    __syncthreads();
+    // trailing update: T[r][c] -= sum_k X[r][k] X[c][k] for c0 + 16 <= c <= r
+    const int n = TILE - c0 - 16;
+    for (int idx = t; idx < n * n; idx += 256) {
+      const int r = c0 + 16 + idx % n, c = c0 + 16 + idx / n;
+      if (r < c) continue;
+      float v = sT[r + c * LDP];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v = fmaf(-sT[r + (c0 + k) * LDP], sT[c + (c0 + k) * LDP], v);
+      sT[r + c * LDP] = v;
+    }
+    __syncthreads();
+  }
+  for (int idx = t; idx < TILE * TILE; idx += 256) {
+    const int r = idx & 127, c = idx >> 7;
+    A[r + (long)c * ld] = (r >= c) ? sT[r + c * LDP] : 0.0f;
+  }
+  for (int idx = t; idx < TILE * TILE; idx += 256) {   // row-major copy for the scalar loads of trsm_f32_kernel
+    const int k = idx & 127, j = idx >> 7;
+    Lt[j * TILE + k] = (k <= j) ? sT[j + k * LDP] : 0.0f;
+  }
+  // logdet partial (fp64 accumulation of the fp32 diagonal)
+  __shared__ double sh[4];
+  double lg = (t < TILE) ? log((double)sT[t + t * LDP]) : 0.0;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) lg += __shfl_xor(lg, off, 64);
+  if (lane == 0) sh[w] = lg;
+  __syncthreads();
+  if (t == 0) {
+    *logdet_slot = 2.0 * ((sh[0] + sh[1]) + (sh[2] + sh[3]));
+    if (firstbad < (1 << 20) && *info == 0) *info = (int)(gcol0 + firstbad + 1);
+  }
+}
+
+// X <- X inv(L)' for `rows` rows: substitution, one row per thread (its 128 values in registers).  The
+// factor comes as Lt = a contiguous row-major copy of L11 written by potrf_f32_kernel (Lt[j * 128 + k] =
+// L[j][k]): every L[j][k] is wave-uniform, so the fully unrolled loops read it with scalar loads straight
+// into the SGPR operand of the FMA -- one VALU instruction per multiply-add, no LDS traffic.
+__global__ __launch_bounds__(64) void trsm_f32_kernel(float* X, long ldx, long rows, const float* __restrict__ Lt) {
+  const long r = (long)blockIdx.x * 64 + threadIdx.x;
+  if (r >= rows) return;
+  float x[TILE];
+#pragma unroll
+  for (int j = 0; j < TILE; ++j) x[j] = X[r + (long)j * ldx];
+#pragma unroll
+  for (int j = 0; j < TILE; ++j) {
+    float v = x[j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) v = fmaf(-x[k], Lt[j * TILE + k], v);
+    x[j] = v / Lt[j * TILE + j];
+  }
+#pragma unroll
+  for (int j = 0; j < TILE; ++j) X[r + (long)j * ldx] = x[j];
+}
+
+__global__ void rowsumsq_f32_kernel(const float* row, long ld, long nc, double* out) {
+  __shared__ double sh[4];
+  double acc = 0.0;
+  for (long c = threadIdx.x; c < nc; c += blockDim.x) {
+    const double v = (double)row[c * ld];
+    acc = fma(v, v, acc);
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ void mirror_cast_f32_kernel(const float* K, long ld, long N, long M, int symmetric, float* out, long ldo) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * M) return;
+  const long r = idx % N, c = idx / N;
+  out[r + c * ldo] = (symmetric && r < c) ? K[c + r * ld] : K[r + c * ld];
+}
+
+template <int DMAX>
+int launch_assemble_f32_t(float* K, long ld, long r0, long nr, long c0, long nc, const DevTerm* d_terms, int nterms,
+                          int lower_only, int noise_kind, float sigma2, const double* d_noise, long trf, long tcf,
+                          long trc, long tcc, hipStream_t s) {
+  size_t lds = std::max<size_t>(16, (size_t)nterms * TILE * DMAX * sizeof(float));
+  hipLaunchKernelGGL(assemble_f32_kernel<DMAX>, dim3((unsigned)trc, (unsigned)tcc), dim3(256), lds, s, K, ld, r0, nr, c0,
+                     nc, d_terms, nterms, lower_only, noise_kind, sigma2, d_noise, trf, tcf);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+int assemble_f32(const sgp_dspec* ds, float* K, long ld, int lower_only, int noise_kind, float sigma2,
+                 const double* d_noise, hipStream_t s) {
+  for (int I = 0; I < ds->nrb; ++I)
+    for (int J = 0; J < ds->ncb; ++J) {
+      if (ds->row_len[I] == 0 || ds->col_len[J] == 0 || (lower_only && I < J)) continue;
+      const long r0 = ds->row_off[I], nr = ds->row_len[I], c0 = ds->col_off[J], nc = ds->col_len[J];
+      const long trf = r0 / TILE, trl = (r0 + nr - 1) / TILE + 1, tcf = c0 / TILE, tcl = (c0 + nc - 1) / TILE + 1;
+      const int p = I * ds->ncb + J;
+      const int t0 = ds->term_ptr[p], t1 = ds->term_ptr[p + 1];
+      const int dmax = ds->pair_dmax[p];
+      if (dmax > 16 || (t1 - t0) * dmax > 64) {
+        set_error("fp32 path: input dimension <= 16 and (terms per block pair) x dimension <= 64");
+        return -1;
+      }
+      const int nk = (ds->symmetric && I == J) ? noise_kind : -1;
+#define SGP_A32(DM) \
+  return_code = launch_assemble_f32_t<DM>(K, ld, r0, nr, c0, nc, ds->d_terms + t0, t1 - t0, lower_only, nk, sigma2, d_noise, trf, tcf, trl - trf, tcl - tcf, s)
+      int return_code = 0;
+      if (dmax <= 1) SGP_A32(1);
+      else if (dmax <= 2) SGP_A32(2);
+      else if (dmax <= 4) SGP_A32(4);
+      else if (dmax <= 8) SGP_A32(8);
+      else SGP_A32(16);
+#undef SGP_A32
+      if (return_code) return return_code;
+    }
+  return 0;
+}
+
+// two-level right-looking Cholesky of the bordered fp32 matrix (m_tot x n_pad, ld), one stream
+int chol_f32(sgp_ctx* ctx, float* A, long ld, long n_pad, long m_tot, hipStream_t s) {
+  const long W = n_pad <= 2048 ? n_pad : 512;
+  static const size_t PD = (size_t)TILE * LDP * sizeof(float);
+  SGP_LDS_ATTR_ONCE(potrf_f32_kernel, PD);
+  float* Lt = reinterpret_cast<float*>(ctx->d_w);   // 128 x 128 scratch (fp64-sized: twice what is needed)
+  for (long J0 = 0; J0 < n_pad; J0 += W) {
+    const long wj = std::min(W, n_pad - J0);
+    for (long j = J0; j < J0 + wj; j += TILE) {
+      float* D = A + j + j * ld;
+      hipLaunchKernelGGL(potrf_f32_kernel, dim3(1), dim3(256), PD, s, D, ld, Lt, ctx->d_slots + j / TILE, ctx->d_info, j);
+      const long mrest = m_tot - j - TILE;
+      if (mrest > 0) {
+        float* A21 = A + (j + TILE) + j * ld;
+        hipLaunchKernelGGL(trsm_f32_kernel, dim3((unsigned)((mrest + 63) / 64)), dim3(64), 0, s, A21, ld, mrest, Lt);
+        const long wrest = J0 + wj - j - TILE;
+        if (wrest > 0)
+          if (int rc = launch_gemm_f32(A21, ld, A21, ld, A + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, 1, s)) return rc;
+      }
+      SGP_HIP(hipGetLastError());
+    }
+    const long c0 = J0 + wj;
+    if (c0 < n_pad)
+      if (int rc = launch_gemm_f32(A + c0 + J0 * ld, ld, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, ld, m_tot - c0, n_pad - c0,
+                                   wj, 1, s))
+        return rc;
+  }
+  return 0;
+}
+
+}  // namespace
+
+#define F_CHECK_ARG(cond, msg) \
+  do {                         \
+    if (!(cond)) {             \
+      sgp::set_error(msg);     \
+      return -1;               \
+    }                          \
+  } while (0)
+
+int sgp_dspec_create_nolock(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out);
+void sgp_dspec_free_nolock(sgp_dspec* ds);
+
+extern "C" int sgp_logpdf_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                              const double* noise, const double* y, double* out) {
+  F_CHECK_ARG(ctx && spec && noise && y && out, "sgp_logpdf_f32: NULL argument");
+  F_CHECK_ARG(spec->symmetric, "sgp_logpdf_f32: spec must be symmetric");
+  F_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+              "sgp_logpdf_f32: noise kind must be SCALAR or DIAG");
+  CtxScope scope(ctx);
+  sgp_dspec* ds = nullptr;
+  if (int rc = sgp_dspec_create_nolock(ctx, spec, &ds)) return rc;
+  struct G {
+    sgp_dspec* d;
+    ~G() { sgp_dspec_free_nolock(d); }
+  } g{ds};
+  const long N = ds->N;
+  F_CHECK_ARG(N >= 1, "sgp_logpdf_f32: empty data");
+  int64_t n_pad, m_tot;
+  sgp_geometry(N, 1, &n_pad, &m_tot);
+  F_CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
+  hipStream_t s = ctx->stream;
+  DevBuf dA, dy, dm, dn;
+  if (int rc = dA.alloc((size_t)(m_tot * n_pad + 1) / 2 + 64)) return rc;   // floats in a double-typed buffer
+  if (int rc = dy.upload(y, N)) return rc;
+  if (mean)
+    if (int rc = dm.upload(mean, N)) return rc;
+  if (noise_kind == SGP_NOISE_DIAG)
+    if (int rc = dn.upload(noise, N)) return rc;
+  float* A = reinterpret_cast<float*>(dA.p);
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  if (int rc = assemble_f32(ds, A, m_tot, 1, noise_kind, noise_kind == SGP_NOISE_SCALAR ? (float)noise[0] : 0.0f,
+                            dn.p, s))
+    return rc;
+  {
+    const long h = n_pad - N;
+    if (h > 0) {
+      const long tot = h * m_tot;
+      hipLaunchKernelGGL(fill_pad_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, (long)m_tot, N,
+                         (long)n_pad, (long)m_tot);
+    }
+    const long totb = (long)TILE * n_pad;
+    hipLaunchKernelGGL(border_f32_kernel, dim3((unsigned)((totb + 255) / 256)), dim3(256), 0, s, A, (long)m_tot, (long)n_pad, N,
+                       dy.p, mean ? dm.p : nullptr);
+    SGP_HIP(hipGetLastError());
+  }
+  if (int rc = chol_f32(ctx, A, m_tot, n_pad, m_tot, s)) return rc;
+  double* d_logdet = ctx->d_scal;
+  double* d_sq = ctx->d_scal + 16;
+  hipLaunchKernelGGL(rowsumsq_f32_kernel, dim3(1), dim3(256), 0, s, A + n_pad, (long)m_tot, N, d_sq);
+  if (int rc = launch_sum_array(ctx->d_slots, n_pad / TILE, d_logdet, s)) return rc;
+  double h2[17];
+  SGP_HIP(hipMemcpyAsync(h2, ctx->d_scal, sizeof(double) * 17, hipMemcpyDeviceToHost, s));
+  int info = 0;
+  SGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  SGP_HIP(hipStreamSynchronize(s));
+  if (info > 0) {
+    set_error("matrix is not positive definite (fp32); Cholesky factorization failed at leading minor " +
+              std::to_string(info));
+    return info;
+  }
+  out[0] = -0.5 * ((double)N * 1.8378770664093453 + h2[0] + h2[16]);
+  return 0;
+}
+
+extern "C" int sgp_kernelmatrix_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, float* K, int64_t ldk) {
+  F_CHECK_ARG(ctx && spec && K, "sgp_kernelmatrix_f32: NULL argument");
+  CtxScope scope(ctx);
+  sgp_dspec* ds = nullptr;
+  if (int rc = sgp_dspec_create_nolock(ctx, spec, &ds)) return rc;
+  struct G {
+    sgp_dspec* d;
+    ~G() { sgp_dspec_free_nolock(d); }
+  } g{ds};
+  const long N = ds->N, M = ds->M;
+  F_CHECK_ARG(ldk >= N, "sgp_kernelmatrix_f32: ldk < N");
+  if (N == 0 || M == 0) return 0;
+  hipStream_t s = ctx->stream;
+  DevBuf dK, dO;
+  if (int rc = dK.alloc((size_t)(N * M + 1) / 2 + 64)) return rc;
+  if (int rc = dO.alloc((size_t)(N * M + 1) / 2 + 64)) return rc;
+  float* Kd = reinterpret_cast<float*>(dK.p);
+  float* Od = reinterpret_cast<float*>(dO.p);
+  SGP_HIP(hipMemsetAsync(Kd, 0, sizeof(float) * N * M, s));
+  if (int rc = assemble_f32(ds, Kd, N, ds->symmetric, -1, 0.0f, nullptr, s)) return rc;
+  hipLaunchKernelGGL(mirror_cast_f32_kernel, dim3((unsigned)((N * M + 255) / 256)), dim3(256), 0, s, Kd, N, N, M,
+                     ds->symmetric, Od, N);
+  SGP_HIP(hipGetLastError());
+  SGP_HIP(hipStreamSynchronize(s));
+  SGP_HIP(hipMemcpy2D(K, sizeof(float) * ldk, Od, sizeof(float) * N, sizeof(float) * N, (size_t)M, hipMemcpyDeviceToHost));
+  return 0;
+}

@@ -15,7 +15,7 @@ from . import lib as _lib
 from .flatten import build_spec, chain_input_gradients, zero_spec
 from .gp import SthenoAbstractGP, mean_vector
 from .gppp import GPPP
-from .inputs import BlockData
+from .inputs import BlockData, eltype as _eltype
 
 
 def _ctx():
@@ -53,6 +53,22 @@ def _kernelmatrix(spec):
     return K
 
 
+def _kernelmatrix_f32(spec):
+    K = np.zeros((spec.N, spec.M), dtype=np.float32, order="F")
+    if spec.N and spec.M:
+        rc = _ctx().lib.sgp_kernelmatrix_f32(_ctx().handle, spec.ref(), K.ctypes.data_as(C.POINTER(C.c_float)), spec.N)
+        _lib.check(rc, "sgp_kernelmatrix_f32")
+    return K
+
+
+def _is_f32(fx, y=None):
+    """Float32 model (the reference is type-stable in Float32, test/gp/util.jl:76-88): inputs given in
+    Float32 (and, where there are observations, y in Float32) select the fp32 device path."""
+    if _eltype(fx.x) != np.float32:
+        return False
+    return y is None or getattr(y, "dtype", None) == np.float32
+
+
 def _kernelmatrix_diag(spec):
     out = np.zeros(spec.N)
     if spec.N:
@@ -87,6 +103,8 @@ def prior_mean(f, x):
 
 def prior_cov(f, x, x2=None):
     if _is_prior(f):
+        if _eltype(x) == np.float32 and (x2 is None or _eltype(x2) == np.float32):
+            return _kernelmatrix_f32(_prior_spec(f, x, x2))      # fp32 assembly on the device
         return _kernelmatrix(_prior_spec(f, x, x2))
     return f.cov(x, x2)
 
@@ -100,14 +118,16 @@ def prior_var(f, x):
 def mean(fx):
     if isinstance(fx, SparseFiniteGP):     # sparse_finite_gp.jl:37
         return mean(fx.fobs)
-    return prior_mean(fx.f, fx.x)
+    m = prior_mean(fx.f, fx.x)
+    return m.astype(np.float32) if _eltype(fx.x) == np.float32 else m
 
 
 def cov(fx, gx=None):
     if isinstance(fx, SparseFiniteGP):     # sparse_finite_gp.jl:39-43: explicit error, use cov(f.fobs)
         raise RuntimeError(_COV_ERR)
     if gx is None:
-        return prior_cov(fx.f, fx.x) + _noise_dense(fx.noise, len(fx))
+        K = prior_cov(fx.f, fx.x)
+        return K + _noise_dense(fx.noise, len(fx)).astype(K.dtype)
     # src/gp/util.jl:12-14: cov(fx, gx) = cov(fx.f, gx.f, fx.x, gx.x) -- no noise
     if _is_prior(fx.f) and _is_prior(gx.f):
         spec, _, _ = build_spec(fx.f, fx.x, gx.f, gx.x)
@@ -170,6 +190,8 @@ def logpdf(fx, y):
         if Y.ndim == 2:
             return np.array([elbo(VFE(fx.finducing), fx.fobs, Y[:, j]) for j in range(Y.shape[1])])
         return elbo(VFE(fx.finducing), fx.fobs, Y)
+    if _is_prior(fx.f) and _is_f32(fx, y) and np.ndim(y) == 1 and np.ndim(fx.noise) <= 1:
+        return logpdf_f32(fx, y)
     Y = np.asarray(y, dtype=np.float64)
     vec = Y.ndim == 1
     Y = _f64(Y.reshape(len(fx), -1))
@@ -182,6 +204,25 @@ def logpdf(fx, y):
                                Y.shape[0], Y.shape[1], _lib.dptr(out))
     _lib.check(rc, "sgp_logpdf")
     return float(out[0]) if vec else out
+
+
+def logpdf_f32(fx, y):
+    """logpdf(fx, y) on the fp32 device path (sgp_logpdf_f32: fp32 assembly, fp32 blocked Cholesky on
+    v_mfma_f32_32x32x2_f32, fp32 forward substitution) -> np.float32.  Selected automatically by `logpdf`
+    when the inputs and y are Float32."""
+    n = len(fx)
+    yv = _f64(np.asarray(y, dtype=np.float64).ravel())
+    if yv.shape[0] != n:
+        raise ValueError("length(y) != length(fx)")
+    spec = _prior_spec(fx.f, fx.x)
+    m = _f64(mean_vector(fx.f, fx.x))
+    kind, nbuf = _lib._noise_args(fx.noise, n)
+    if kind == _lib.NOISE_DENSE:
+        raise NotImplementedError("fp32 path with dense observation noise")
+    out = np.zeros(1)
+    rc = _ctx().lib.sgp_logpdf_f32(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(yv), _lib.dptr(out))
+    _lib.check(rc, "sgp_logpdf_f32")
+    return np.float32(out[0])
 
 
 def logpdf_and_gradient(fx, y, inputs=False):

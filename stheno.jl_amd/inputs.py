@@ -12,6 +12,10 @@ import numpy as np
 
 class ColVecs:
     def __init__(self, X):
+        # Float32 inputs keep their element type as a tag (type stability of the reference in Float32:
+        # test/gp/util.jl:76-88 -- the FiniteGP operators then run the fp32 device path); the host algebra
+        # (warps, flattening) works on the exactly converted fp64 copy.
+        self.eltype = np.float32 if getattr(X, "dtype", None) == np.float32 else np.float64
         X = np.asarray(X, dtype=np.float64)
         if X.ndim != 2:
             raise ValueError("ColVecs needs a D x N matrix")
@@ -34,6 +38,7 @@ class GPPPInput:
 
     def __init__(self, p, x):
         self.p = p
+        self.eltype = np.float32 if getattr(x, "dtype", None) == np.float32 else None   # raw 1-D vectors only
         self.x = x if isinstance(x, (ColVecs, GPPPInput, BlockData)) else np.asarray(x, dtype=np.float64)
 
     def __len__(self):
@@ -101,3 +106,15 @@ def as_matrix(x):
     if a.ndim == 1:
         return a.reshape(1, -1)
     raise TypeError("inputs must be a 1-D real vector or ColVecs")
+
+
+def eltype(x):
+    """np.float32 if every block of the input collection was given in Float32, else np.float64."""
+    if isinstance(x, BlockData):
+        ts = [eltype(b) for b in x.X]
+        return np.float32 if ts and all(t == np.float32 for t in ts) else np.float64
+    if isinstance(x, GPPPInput):
+        return np.float32 if x.eltype == np.float32 else eltype(x.x)
+    if isinstance(x, ColVecs):
+        return x.eltype
+    return np.float32 if getattr(x, "dtype", None) == np.float32 else np.float64

@@ -72,6 +72,8 @@ _SIGS = {
     "sgp_kernelmatrix_diag": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D]),
     "sgp_logpdf": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64,
                              C.c_int64, _D]),
+    "sgp_logpdf_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D]),
+    "sgp_kernelmatrix_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(C.c_float), C.c_int64]),
     "sgp_logpdf_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D]),
     "sgp_logpdf_grad_x": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D,
                                     C.POINTER(_D)]),
@@ -114,6 +116,7 @@ _SIGS = {
     "sgp_dev_elbo_finish": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _D]),
     "sgp_bench_mfma_f64": (C.c_int, [_P, C.c_int, _D, _D]),
     "sgp_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D]),
+    "sgp_bench_potrf": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_longlong)]),
     "sgp_bench_gemm": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _D, _D]),
 }
 

@@ -1,0 +1,81 @@
+"""GPU tests of the fp32 instantiation (sgp_logpdf_f32 / sgp_kernelmatrix_f32, stheno.jl_amd/csrc/f32.hip):
+the reference is type-stable in Float32 (/root/reference/test/gp/util.jl:76-88): Float32 inputs and
+observations give Float32 results.  Values are compared with the fp64 oracle at fp32 tolerances."""
+import numpy as np
+import pytest
+
+import models
+import oracle.abstractgps as oagp
+import oracle.kernelfunctions as okf
+import oracle.stheno as ost
+import stheno_jl_amd as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(recipe):
+    fo, go = recipe(models.oracle_api())
+    fp, gp = recipe(models.product_api())
+    return ost.GPPP(fo, go), P.GPPP(fp, gp)
+
+
+@pytest.mark.parametrize("kind", ["se", "matern52", "matern32", "matern12"])
+@pytest.mark.parametrize("N", [1, 127, 128, 129, 700, 2500])
+def test_logpdf_f32_single_gp(N, kind):
+    rng = np.random.default_rng(N + len(kind))
+    D = 3
+    ko = {"se": okf.SEKernel, "matern52": okf.Matern52Kernel, "matern32": okf.Matern32Kernel,
+          "matern12": okf.Matern12Kernel}[kind]()
+    kp = {"se": P.SEKernel, "matern52": P.Matern52Kernel, "matern32": P.Matern32Kernel,
+          "matern12": P.Matern12Kernel}[kind]()
+    X32 = rng.standard_normal((D, N)).astype(np.float32)
+    y32 = rng.standard_normal(N).astype(np.float32)
+    fo = ost.atomic(oagp.GP(0.3, ko), ost.GPC())
+    fp = P.atomic(P.GP(0.3, kp), P.GPC())
+    ref = oagp.logpdf(fo(okf.ColVecs(X32.astype(np.float64)), 0.1), y32.astype(np.float64))
+    lp = P.logpdf(fp(P.ColVecs(X32), np.float32(0.1)), y32)
+    assert isinstance(lp, np.float32)                       # type stability (test/gp/util.jl:76-88)
+    assert abs(float(lp) - ref) <= 1e-4 * max(1.0, abs(ref)), (lp, ref)
+    # the same call with Float64 data stays on the fp64 path
+    lp64 = P.logpdf(fp(P.ColVecs(X32.astype(np.float64)), 0.1), y32.astype(np.float64))
+    assert isinstance(lp64, float) and abs(lp64 - ref) <= 1e-10 * max(1.0, abs(ref))
+
+
+def test_logpdf_f32_gppp_blocks_diag_noise_and_means():
+    rng = np.random.default_rng(8)
+    Fo, Fp = _both(models.toy_gppp)
+    xs = [rng.standard_normal(n).astype(np.float32) for n in (300, 257, 411)]
+    names = ("f1", "f2", "f3")
+    xo = ost.BlockData([ost.GPPPInput(k, v.astype(np.float64)) for k, v in zip(names, xs)])
+    xp = P.BlockData([P.GPPPInput(k, v) for k, v in zip(names, xs)])
+    N = len(xp)
+    y = rng.standard_normal(N).astype(np.float32)
+    noise = (0.05 + rng.random(N)).astype(np.float32)
+    ref = oagp.logpdf(Fo(xo, noise.astype(np.float64)), y.astype(np.float64))
+    lp = P.logpdf(Fp(xp, noise), y)
+    assert isinstance(lp, np.float32) and abs(float(lp) - ref) <= 1e-4 * abs(ref)
+
+
+def test_cov_and_mean_f32():
+    rng = np.random.default_rng(9)
+    Fo, Fp = _both(models.composite_kernels)
+    X = rng.standard_normal((2, 190)).astype(np.float32)
+    xo = ost.GPPPInput("s", okf.ColVecs(X.astype(np.float64)))
+    xp = P.GPPPInput("s", P.ColVecs(X))
+    Kp = P.prior_cov(Fp, xp)
+    assert Kp.dtype == np.float32 and np.array_equal(Kp, Kp.T)
+    assert np.abs(Kp - Fo.cov(xo)).max() < 5e-6 * np.abs(Fo.cov(xo)).max()
+    Z = rng.standard_normal((2, 33)).astype(np.float32)
+    Kc = P.prior_cov(Fp, xp, P.GPPPInput("f1", P.ColVecs(Z)))
+    assert Kc.dtype == np.float32 and Kc.shape == (190, 33)
+    assert np.abs(Kc - Fo.cov(xo, ost.GPPPInput("f1", okf.ColVecs(Z.astype(np.float64))))).max() < 1e-5
+    fx = Fp(xp, np.float32(0.1))
+    assert P.mean(fx).dtype == np.float32 and P.cov(fx).dtype == np.float32
+
+
+def test_posdef_failure_f32():
+    rng = np.random.default_rng(2)
+    f = P.atomic(P.GP(P.SEKernel()), P.GPC())
+    X = rng.standard_normal((2, 300)).astype(np.float32)
+    with pytest.raises(P.PosDefException):
+        P.logpdf(f(P.ColVecs(X), np.float32(-5.0)), rng.standard_normal(300).astype(np.float32))
