@@ -288,3 +288,18 @@ def test_kernel_level_transform_chain_and_its_vjp():
     assert np.allclose(g.ravel(), fd, rtol=1e-7, atol=1e-8)
     assert K.chain_scale(P.with_lengthscale(P.SEKernel(), 4.0).leaf_terms()[0][3]) == 0.25
     assert K.chain_scale(chain) is None
+
+
+def test_float32_inputs_are_tagged_for_the_fp32_path():
+    """Float32 type stability (reference: test/gp/util.jl:76-88) starts on the host: input collections given in
+    Float32 keep that element type as a tag (the host algebra itself runs on the exact fp64 copy)."""
+    from stheno_jl_amd.inputs import eltype
+    X32 = np.ones((2, 5), dtype=np.float32)
+    assert eltype(P.ColVecs(X32)) == np.float32 and eltype(P.ColVecs(X32.astype(np.float64))) == np.float64
+    assert P.ColVecs(X32).X.dtype == np.float64
+    assert eltype(np.zeros(3, dtype=np.float32)) == np.float32 and eltype(np.zeros(3)) == np.float64
+    assert eltype(P.GPPPInput("f1", np.zeros(3, dtype=np.float32))) == np.float32
+    assert eltype(P.GPPPInput("f1", P.ColVecs(X32))) == np.float32
+    mixed = P.BlockData([P.GPPPInput("f1", P.ColVecs(X32)), P.GPPPInput("f2", P.ColVecs(X32.astype(np.float64)))])
+    assert eltype(mixed) == np.float64
+    assert eltype(P.BlockData([P.GPPPInput("f1", P.ColVecs(X32)), P.GPPPInput("f2", P.ColVecs(X32))])) == np.float32

@@ -191,6 +191,8 @@ def main():
               ("timeline_c1.txt", "Same at N = 2048 (one outer panel, single stream)"),
               ("gemm_sizes.log", "Isolated trailing-update launches by size and depth (`tools/gpu_gemm_sizes.py`)"),
               ("multi_time.log", "In-process multi-rank context on the one GPU (`tools/gpu_multi_time.py`)"),
+              ("potrf_phases.log", "`potrf_diag_kernel` phase by phase (s_memtime ticks of wave 0, `tools/gpu_potrf_phases.py`)"),
+              ("f32_time.log", "fp32 instantiation against the fp64 path (`tools/gpu_f32_time.py`; host API incl. uploads)"),
               ("grad_time.log", "Reverse-mode gradients (`tools/gpu_grad_time.py`; host API incl. uploads)"),
               ("predict_time.log", "Prediction side (`tools/gpu_predict_time.py`)"),
               ("misc_time.log", "Other host-API rows (`tools/gpu_misc_time.py`)"),
@@ -201,6 +203,12 @@ def main():
             txt = [ln for ln in open(p).read().splitlines()
                    if ln.strip() and "amdgpu.ids" not in ln and not ln.startswith(("RCCL version", "HIP version", "ROCm version", "Hostname", "Librccl"))]
             L += ["", f"## {title}", "", "```"] + txt + ["```"]
+    j32 = jload("bench_c5_f32.json")
+    if j32:
+        json.dump(j32, open(os.path.join(DST, f"{TAG}_bench_c5_f32.json"), "w"), indent=1)
+        L += ["", f"* `bench.py --config c5 --dtype f32` (fp32 instantiation, `sgp_logpdf_f32`): {j32['ms_per_step']:.1f} ms = "
+              f"{j32['cholesky_tflops_whole_step']:.1f} TFLOP/s ({j32['roofline']['frac']:.2f} of the 157.3 TFLOP/s fp32 MFMA peak), "
+              f"|value - fp64 golden| / |golden| = {j32['parity_rel']:.1e}."]
     for c in ("c2_dist1", "c5_dist1"):
         j = jload(f"bench_{c}.json")
         if j:
