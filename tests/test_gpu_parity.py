@@ -89,6 +89,35 @@ def test_cov_colvecs(recipe, D):
     assert np.abs(Kp - Ko).max() < 2e-12 * max(1.0, np.abs(Ko).max())
 
 
+@pytest.mark.parametrize("D", [12, 16])
+def test_cov_many_terms_per_block_pair_accumulate_path(D):
+    """More terms per block pair than one assembly launch can stage in LDS (D = 16: one term per launch): the
+    following launches accumulate into the tile (read-modify-write path of assemble_block2_kernel), with row /
+    column scales and ragged, tile-misaligned blocks."""
+    rng = np.random.default_rng(40 + D)
+
+    def recipe(api):
+        gpc = api.GPC()
+        k = api.KernelSum([api.SEKernel(), api.with_lengthscale(api.Matern52Kernel(), 2.0),
+                           api.ScaledKernel(api.Matern32Kernel(), 0.3), api.ConstantKernel(0.2)])
+        f1 = api.atomic(api.GP(k), gpc)
+        # (no Matern-1/2 here: the oracle's GEMM-trick distances make exp(-sqrt(d2)) 1e-8 off at coincident points
+        # of a cross-covariance, SURVEY.md App. A.1 -- the device's direct differences are exact there)
+        f2 = api.atomic(api.GP(api.Matern32Kernel()), gpc)
+        return {"f1": f1, "f2": f2, "s": models._sumsin * f1 + 0.5 * f2 + api.stretch(f1, 0.7)}, gpc
+
+    Fo, Fp, fo, fp = both(recipe)
+    names = ["s", "f1", "s"]
+    xs = [np.asfortranarray(rng.standard_normal((D, n)) / np.sqrt(D)) for n in (150, 131, 77)]
+    xo, xp = blockdata(names, xs, True)
+    Ko, Kp = Fo.cov(xo), P.prior_cov(Fp, xp)
+    assert np.abs(Kp - Ko).max() < 5e-12 * max(1.0, np.abs(Ko).max())
+    assert np.array_equal(Kp, Kp.T)
+    y = rng.standard_normal(len(xp))
+    lo, lp = oagp.logpdf(Fo(xo, 0.1), y), P.logpdf(Fp(xp, 0.1), y)
+    assert abs(lp - lo) <= 1e-10 * abs(lo)
+
+
 def test_warps_colvecs():
     rng = np.random.default_rng(99)
     Fo, Fp, fo, fp = both(models.warped_colvecs)
