@@ -11,7 +11,8 @@
 //   potrf_f32_kernel        128 x 128 diagonal block in LDS: 16-column sub-panels, wave-0 micro-Cholesky
 //                           (v_readlane broadcasts), row-per-thread sub-panel solve, VALU trailing update
 //   trsm_f32_kernel         X <- X inv(L11)' by substitution, one row per thread, L11 through scalar loads
-// Driver: two-level right-looking Cholesky (outer panels of 512, 128-column steps inside), one stream.
+// Driver: two-level right-looking Cholesky (outer panels, 128-column steps inside) with the fp64 driver's
+// one-panel look-ahead on two streams.
 // Entry points: sgp_logpdf_f32, sgp_kernelmatrix_f32 (include/sthenomi.h).  Accuracy is fp32's: the
 // tests hold 1e-4 relative on logpdf against the fp64 oracle at N <= 3000.
 #include "ctx.h"
@@ -142,8 +143,23 @@ __global__ void border_f32_kernel(float* A, long ld, long n_pad, long N, const d
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* A, long lda, const float* B, long ldb, float* C,
                                                           long ldc, long K, int lower, long n_tr, long n_tc) {
-  const long tr = blockIdx.x, tc = blockIdx.y;
-  if (tr >= n_tr || tc >= n_tc || (lower && tr < tc)) return;
+  long tr, tc;
+  if (lower) {   // 1-D grid over the live tiles only: the lower triangle of the n_tc x n_tc square, then full rows
+    const long id = blockIdx.x, tri = n_tc * (n_tc + 1) / 2;
+    if (id < tri) {
+      tr = (long)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
+      while (tr * (tr + 1) / 2 > id) --tr;
+      while ((tr + 1) * (tr + 2) / 2 <= id) ++tr;
+      tc = id - tr * (tr + 1) / 2;
+    } else {
+      tr = n_tc + (id - tri) / n_tc;
+      tc = (id - tri) % n_tc;
+    }
+  } else {
+    tr = blockIdx.x;
+    tc = blockIdx.y;
+  }
+  if (tr >= n_tr || tc >= n_tc) return;
   __shared__ __attribute__((aligned(16))) float sA[2][KBF * LDF];
   __shared__ __attribute__((aligned(16))) float sB[2][KBF * LDF];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -219,8 +235,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* A, lon
 int launch_gemm_f32(const float* A, long lda, const float* B, long ldb, float* C, long ldc, long M, long Nc, long K,
                     int lower, hipStream_t s) {
   if (M <= 0 || Nc <= 0 || K <= 0) return 0;
-  hipLaunchKernelGGL(gemm_nt_f32_kernel, dim3((unsigned)(M / TILE), (unsigned)(Nc / TILE)), dim3(256), 0, s, A, lda, B,
-                     ldb, C, ldc, K, lower, M / TILE, Nc / TILE);
+  const long n_tr = M / TILE, n_tc = Nc / TILE;
+  dim3 grid((unsigned)n_tr, (unsigned)n_tc);
+  if (lower) grid = dim3((unsigned)(n_tc * (n_tc + 1) / 2 + (n_tr - n_tc) * n_tc));   // (M >= Nc for every lower update)
+  hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, lower, n_tr, n_tc);
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -399,33 +417,63 @@ int assemble_f32(const sgp_dspec* ds, float* K, long ld, int lower_only, int noi
   return 0;
 }
 
-// two-level right-looking Cholesky of the bordered fp32 matrix (m_tot x n_pad, ld), one stream
+// factor one column panel in place (128-column steps: diagonal block, row solve, K = 128 update of the rest
+// of the panel)
+int panel_factor_f32(sgp_ctx* ctx, float* P, long ld, long m, long w, long g0, float* Lt, size_t pd_lds, hipStream_t s) {
+  for (long j = 0; j < w; j += TILE) {
+    float* D = P + j + j * ld;
+    hipLaunchKernelGGL(potrf_f32_kernel, dim3(1), dim3(256), pd_lds, s, D, ld, Lt, ctx->d_slots + (g0 + j) / TILE,
+                       ctx->d_info, g0 + j);
+    const long mrest = m - j - TILE;
+    if (mrest > 0) {
+      float* A21 = P + (j + TILE) + j * ld;
+      hipLaunchKernelGGL(trsm_f32_kernel, dim3((unsigned)((mrest + 63) / 64)), dim3(64), 0, s, A21, ld, mrest, Lt);
+      const long wrest = w - j - TILE;
+      if (wrest > 0)
+        if (int rc = launch_gemm_f32(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, 1, s)) return rc;
+    }
+    SGP_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+// two-level right-looking Cholesky of the bordered fp32 matrix (m_tot x n_pad, ld) with the fp64 driver's
+// one-panel look-ahead (capi.hip: chol_bordered): the next panel is updated and factored on the panel stream
+// while the rest of the trailing matrix is updated with the current panel on the update stream
 int chol_f32(sgp_ctx* ctx, float* A, long ld, long n_pad, long m_tot, hipStream_t s) {
-  const long W = n_pad <= 2048 ? n_pad : 512;
+  const long W = n_pad <= 2048 ? n_pad : (n_pad <= 8192 ? 1024 : 512);
   static const size_t PD = (size_t)TILE * LDP * sizeof(float);
   SGP_LDS_ATTR_ONCE(potrf_f32_kernel, PD);
   float* Lt = reinterpret_cast<float*>(ctx->d_w);   // 128 x 128 scratch (fp64-sized: twice what is needed)
+  const bool la = ctx->lookahead && s == ctx->stream;
+  hipStream_t sB = la ? ctx->stream2 : s;
+  bool rest_pending = false;
+  if (la) {
+    SGP_HIP(hipEventRecord(ctx->ev_panel, s));
+    SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
+  }
   for (long J0 = 0; J0 < n_pad; J0 += W) {
     const long wj = std::min(W, n_pad - J0);
-    for (long j = J0; j < J0 + wj; j += TILE) {
-      float* D = A + j + j * ld;
-      hipLaunchKernelGGL(potrf_f32_kernel, dim3(1), dim3(256), PD, s, D, ld, Lt, ctx->d_slots + j / TILE, ctx->d_info, j);
-      const long mrest = m_tot - j - TILE;
-      if (mrest > 0) {
-        float* A21 = A + (j + TILE) + j * ld;
-        hipLaunchKernelGGL(trsm_f32_kernel, dim3((unsigned)((mrest + 63) / 64)), dim3(64), 0, s, A21, ld, mrest, Lt);
-        const long wrest = J0 + wj - j - TILE;
-        if (wrest > 0)
-          if (int rc = launch_gemm_f32(A21, ld, A21, ld, A + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, 1, s)) return rc;
-      }
-      SGP_HIP(hipGetLastError());
-    }
+    if (int rc = panel_factor_f32(ctx, A + J0 + J0 * ld, ld, m_tot - J0, wj, J0, Lt, PD, s)) return rc;
     const long c0 = J0 + wj;
-    if (c0 < n_pad)
-      if (int rc = launch_gemm_f32(A + c0 + J0 * ld, ld, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, ld, m_tot - c0, n_pad - c0,
-                                   wj, 1, s))
-        return rc;
+    if (c0 >= n_pad) break;
+    const long w1 = std::min(W, n_pad - c0), c1 = c0 + w1;
+    const float* Pj = A + J0 * ld;
+    if (la) {
+      SGP_HIP(hipEventRecord(ctx->ev_panel, s));
+      if (rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
+      if (int rc = launch_gemm_f32(Pj + c0, ld, Pj + c0, ld, A + c0 + c0 * ld, ld, m_tot - c0, w1, wj, 1, s)) return rc;
+      if (c1 < n_pad) {
+        SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
+        if (int rc = launch_gemm_f32(Pj + c1, ld, Pj + c1, ld, A + c1 + c1 * ld, ld, m_tot - c1, n_pad - c1, wj, 1, sB)) return rc;
+        SGP_HIP(hipEventRecord(ctx->ev_rest, sB));
+        rest_pending = true;
+      }
+    } else {
+      if (int rc = launch_gemm_f32(Pj + c0, ld, Pj + c0, ld, A + c0 + c0 * ld, ld, m_tot - c0, n_pad - c0, wj, 1, s)) return rc;
+    }
   }
+  if (la && rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
   return 0;
 }
 
