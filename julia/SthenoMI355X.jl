@@ -145,6 +145,19 @@ function logpdf(fx::SthenoFGP, Y::AbstractMatrix{<:Real})
 end
 logpdf(fx::SthenoFGP, y::AbstractVector{<:Real}) = only(logpdf(fx, reshape(y, :, 1)))
 
+# Float32 models (test/gp/util.jl:76-88: `logpdf(fx, y) isa Float32`): fp32 assembly + fp32 Cholesky on the device
+# (sgp_logpdf_f32).  The spec is passed in Float64 (an exact conversion); the library rounds it to fp32 once.
+function logpdf(fx::FiniteGP{<:Union{GPPP,SthenoAbstractGP},<:AbstractVector{<:Union{Float32,AbstractVector{Float32}}}},
+                y::AbstractVector{Float32})
+    sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
+    kind == 2 && return Float32(invoke(logpdf, Tuple{SthenoFGP,AbstractVector{<:Real}}, fx, y))
+    yd = collect(Float64, y); out = zeros(1)
+    GC.@preserve sp m nz yd out check(ccall((:sgp_logpdf_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        ctx(), sp.c, m, kind, collect(Float64, nz), yd, out))
+    return Float32(out[1])
+end
+
 function rand(rng::AbstractRNG, fx::SthenoFGP, S::Int)
     sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
     Z = randn(rng, Float64, length(fx), S)      # the caller's integer RNG stream, column-major fill

@@ -193,8 +193,8 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   std::string want = tr ? tr : "auto";
   if (!distinct) {
     m->transport = TR_LOOPBACK;   // several ranks on one GPU: same-device copies (test configuration)
-  } else if (want == "p2p") {
-    m->transport = TR_P2P;
+  } else if (want == "p2p" || (ndev == 1 && want != "rccl")) {
+    m->transport = TR_P2P;   // (one device: nothing to exchange unless RCCL is asked for explicitly)
   } else {
     if (m->rccl.load())
       m->transport = TR_RCCL;
