@@ -54,6 +54,31 @@ def cpu_baseline(name, n_sample):
                       elbo_m=bc.ELBO_M, elbo_znoise=bc.ELBO_ZNOISE)
 
 
+def update_bytes_avg(N):
+    """Algorithmic bytes of an average trailing-update launch of one logpdf: every launch reads and writes the
+    lower 128-tiles of its C block once and reads its panel rows once (the driver's panel rule: capi.hip)."""
+    n_pad = (N + 127) // 128 * 128
+    m_tot = n_pad + 128
+    W = n_pad if n_pad <= 2048 else (1024 if n_pad <= 8192 or n_pad >= 32768 else 512)
+    tot, cnt = 0.0, 0
+    J0 = 0
+    while J0 < n_pad:
+        wj = min(W, n_pad - J0)
+        c0 = J0 + wj
+        if c0 >= n_pad:
+            break
+        w1 = min(W, n_pad - c0)
+        for (c, nc) in ((c0, w1), (c0 + w1, n_pad - c0 - w1)):
+            if nc <= 0:
+                continue
+            m = m_tot - c
+            entries = nc * (nc + 128) / 2 + (m - nc) * nc          # lower tiles of the square part + rows below
+            tot += 2 * 8.0 * entries + 8.0 * m * wj
+            cnt += 1
+        J0 += W
+    return tot / max(1, cnt)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,8 +277,17 @@ def main():
             "busy_ms": timings[6],
             "achieved_while_busy": (upd_flops / (timings[6] * 1e-3) / 1e12) if timings[6] > 0 else None,
         }
-        # HBM traffic cannot be read without rocprofv3; the committed PMC passes of one representative
-        # launch of this kernel (separate --pmc runs) are attached -- `traffic` itself stays null live.
+        # HBM traffic cannot be read from inside the process (it needs rocprofv3 --pmc passes): `traffic` is the
+        # committed per-launch average of exactly this command under the FETCH_SIZE / WRITE_SIZE passes
+        # (tools/collect_traffic.sh -> profiles/r02_update_traffic.json), null for configurations not profiled;
+        # the PMC passes of one representative launch shape are attached as well.
+        tr_file = os.path.join(ROOT, "profiles", "r02_update_traffic.json")
+        if os.path.exists(tr_file):
+            rec = json.load(open(tr_file)).get(args.config)
+            if rec:
+                roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = rec
+        roofline["algorithmic_bytes_per_launch_avg"] = update_bytes_avg(N)
         for pmc_name in ("r02_gemm_pmc.json", "r01_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc):

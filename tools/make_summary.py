@@ -90,6 +90,20 @@ def main():
                   f"* HBM-bound stage: K(x,z) assembly {r['hbm_stage']['stage_ms']:.2f} ms for {r['hbm_stage']['algorithmic_bytes']/1e9:.2f} GB -> "
                   f"**{r['hbm_stage']['achieved']:.0f} GB/s** ({r['hbm_stage']['frac']:.2f} of 8 TB/s).  {r['binding']}.",
                   "* stages (ms): " + ", ".join(f"{k} {v:.1f}" for k, v in st.items())]
+        trp = os.path.join(DST, f"{TAG}_update_traffic.json")
+        if c != "c4" and os.path.exists(trp) and c in json.load(open(trp)):
+            t = json.load(open(trp))[c]
+            import importlib.util
+            sp = importlib.util.spec_from_file_location("benchmod", os.path.join(ROOT, "bench.py"))
+            bm = importlib.util.module_from_spec(sp)
+            sp.loader.exec_module(bm)
+            alg = bm.update_bytes_avg(j["config"]["N"])
+            L.append(f"* `roofline.traffic` (rocprofv3 `--pmc FETCH_SIZE` / `WRITE_SIZE`, separate passes over the same command, "
+                     f"{t['launches_profiled']} launches of `gemm_nt_dma_kernel<1>`; tools/collect_traffic.sh): FETCH_SIZE "
+                     f"{t['FETCH_SIZE_KiB_avg_per_launch']*1024/1e9:.2f} GB (x2 corrected), WRITE_SIZE {t['WRITE_SIZE_KiB_avg_per_launch']*1024/1e9:.2f} GB "
+                     f"per launch -> **{t['hbm_bytes_per_launch']/1e9:.1f} GB per launch** against {alg/1e9:.2f} GB algorithmic "
+                     f"(C block read + written once, panel rows once) = {t['hbm_bytes_per_launch']/alg:.2f}x: WRITE_SIZE is the algorithmic "
+                     f"write volume exactly; the reads are operand panels re-fetched past the 4 MiB XCD L2s (Infinity-Cache hits included).")
         if cpu:
             L.append(f"* cpu_baseline ({cpu['kind']}, {cpu['cores']} threads): {cpu['sample']} -> {cpu['value']:.3g} {cpu['unit']}; "
                      f"GPU / CPU = {j['value']/cpu['value']:.0f}x (reported baseline, not a target).  Thread sweep of the blocked "
