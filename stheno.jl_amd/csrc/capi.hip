@@ -558,15 +558,22 @@ static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long
                          hipStream_t s) {
   if (M <= 0 || Nc <= 0) return 0;
   if (ctx->time_updates) {
-    hipEvent_t e0, e1;
+    // the context owns both events from the moment they exist (destroyed with the next timed call or the
+    // context), whatever happens below
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     SGP_HIP(hipEventCreate(&e0));
-    SGP_HIP(hipEventCreate(&e1));
+    ctx->ev.push_back(e0);
+    if (hipEventCreate(&e1) != hipSuccess) {
+      ctx->ev.pop_back();
+      hipEventDestroy(e0);
+      set_error("hipEventCreate failed");
+      return -2;
+    }
+    ctx->ev.push_back(e1);
+    ctx->ev_flops.push_back(update_flops(M, Nc, K));
     SGP_HIP(hipEventRecord(e0, s));
     CHECK_RC(launch_gemm_nt_update(P, ld, C, ld, M, Nc, K, s));
     SGP_HIP(hipEventRecord(e1, s));
-    ctx->ev.push_back(e0);
-    ctx->ev.push_back(e1);
-    ctx->ev_flops.push_back(update_flops(M, Nc, K));
     return 0;
   }
   return launch_gemm_nt_update(P, ld, C, ld, M, Nc, K, s);
@@ -658,9 +665,16 @@ static int dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, const 
   long N = ds->N;
   int64_t n_pad, m_tot;
   sgp_geometry(N, ncols, &n_pad, &m_tot);
-  hipEvent_t ev[4];
+  struct StageEvents {   // destroyed on every exit path
+    hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+    ~StageEvents() {
+      for (auto x : e)
+        if (x) hipEventDestroy(x);
+    }
+  } stage_events;
+  hipEvent_t* ev = stage_events.e;
   if (timings)
-    for (auto& e : ev) SGP_HIP(hipEventCreate(&e));
+    for (int q = 0; q < 4; ++q) SGP_HIP(hipEventCreate(&ev[q]));
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
   if (timings) SGP_HIP(hipEventRecord(ev[0], s));
   CHECK_RC(build_bordered(ctx, ds, dA, n_pad, m_tot, d_mean, noise_kind, sigma2, d_noise, d_dense,
@@ -730,7 +744,6 @@ static int dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, const 
       timings[6] = uni;
       timings[7] = 0.0;
     }
-    for (auto& e : ev) hipEventDestroy(e);
   }
   if (info > 0) {
     set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
