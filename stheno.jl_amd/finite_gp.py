@@ -150,8 +150,12 @@ def mean_and_var(fx):
         return mean_and_var(fx.fobs)
     if isinstance(fx.f, (PosteriorGP, ApproxPosteriorGP)):
         m, v = fx.f.mean_and_var(fx.x)
-        return m, v + _noise_diag(fx.noise, len(fx))
-    return mean(fx), var(fx)
+        v = v + _noise_diag(fx.noise, len(fx))
+        if _eltype(fx.x) == np.float32:
+            return m.astype(np.float32), v.astype(np.float32)
+        return m, v
+    m, v = mean(fx), var(fx)
+    return m, (v.astype(np.float32) if _eltype(fx.x) == np.float32 else v)
 
 
 class Normal:
@@ -297,6 +301,8 @@ def rand(rng, fx, S=None, Z=None):
     rc = _ctx().lib.sgp_rand(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(Z), n, s,
                              _lib.dptr(out), n)
     _lib.check(rc, "sgp_rand")
+    if _eltype(fx.x) == np.float32:      # Float32 model: computed in fp64 on the device, returned in the model's type
+        out = out.astype(np.float32)
     return out[:, 0].copy() if S is None else out
 
 
