@@ -331,6 +331,14 @@ int sgp_bench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops_out, double* layo
 int sgp_bench_hbm(sgp_ctx* ctx, int64_t bytes, int iters, double* write_gbs_out, double* copy_gbs_out);
 /* one potrf_diag launch (128 x 128 diagonal block) timed by HIP events, plus s_memtime stamps of its phases */
 int sgp_bench_potrf(sgp_ctx* ctx, int iters, double* us_out, long long* stamps_out /* [64] */);
+/* potrf_diag while `gemm_launches` trailing updates (m^2 lower, depth k) run on the update stream: per launch the
+ * HIP-event time (incl. the wait for a workgroup slot), the kernel's own s_memtime span, and whether the updates
+ * were still running. */
+/* which CUs a stream created with the CU mask `mask` (`words` 32-bit words; NULL = no mask) runs on:
+ * out[xcc << 8 | HW_ID[15:8]] = workgroups seen there (tools/gpu_cumask.py decodes it) */
+int sgp_bench_cumask(sgp_ctx* ctx, const uint32_t* mask, int words, int nwg, unsigned* out /* [4096] */);
+int sgp_bench_potrf_contended(sgp_ctx* ctx, int64_t m, int64_t k, int gemm_launches, int n, double* us_out /* [n] */,
+                              long long* ticks_out /* [n] */, int* busy_out /* [n] */);
 /* raw GEMM-NT kernel timing: C(m x n) -= A(m x k) B(n x k)' on random data */
 int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only, int iters,
                    double* tflops_out, double* maxerr_out);

@@ -110,6 +110,7 @@ void pool_free(sgp_ctx* ctx, void* p) {
 void pool_trim(sgp_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   hipStreamSynchronize(ctx->stream2);
+  if (ctx->stream2m) hipStreamSynchronize(ctx->stream2m);
   std::vector<sgp_pool_block> keep;
   for (auto& b : ctx->pool) {
     if (b.used) {
@@ -174,10 +175,29 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (sp && !strcmp(sp, "equal")) { p1 = lo; p2 = lo; }
     SGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p1));
     SGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, p2));
+    // SGP_RESERVE_CU = CUs per XCD kept free of trailing-update workgroups (0 = off), SGP_RESERVE_MAX_N = largest
+    // n_pad it is used for.  Mask bit i is CU i / 8 of XCD i % 8 (the driver deals the bits round-robin over the
+    // XCDs), so clearing the first 8 r bits takes r CUs from every XCD and the update's per-XCD tile shares stay
+    // balanced.
+    {
+      const char* rc_ = getenv("SGP_RESERVE_CU");
+      c->reserve_cu = rc_ ? atoi(rc_) : 0;
+      const char* rn_ = getenv("SGP_RESERVE_MAX_N");
+      c->reserve_max_n = rn_ ? atol(rn_) : (1L << 40);
+      if (c->reserve_cu < -1 || c->reserve_cu > 8 || prop.multiProcessorCount != 256) c->reserve_cu = 0;
+      if (c->reserve_cu != 0) {   // -1: a masked stream with every CU enabled (A/B of the masked queue itself)
+        uint32_t mask[8];
+        for (int q = 0; q < 8; ++q) mask[q] = 0xFFFFFFFFu;
+        for (int b = 0; b < 8 * c->reserve_cu; ++b) mask[b / 32] &= ~(1u << (b % 32));
+        SGP_HIP(hipExtStreamCreateWithCUMask(&c->stream2m, 8, mask));
+      }
+    }
     SGP_HIP(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     SGP_HIP(hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming));
     const char* la = getenv("SGP_LOOKAHEAD");
     if (la) c->lookahead = atoi(la);
+    const char* lm = getenv("SGP_LA_MIN");
+    if (lm) c->la_min = atol(lm);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* rf = getenv("SGP_REFINE");
@@ -213,6 +233,7 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) hipStreamSynchronize(c->stream2);
+  if (c->stream2m) hipStreamSynchronize(c->stream2m);
   for (auto e : c->ev) hipEventDestroy(e);
   for (auto& b : c->pool) hipFree(b.p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -225,6 +246,7 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->ev_panel) hipEventDestroy(c->ev_panel);
   if (c->ev_rest) hipEventDestroy(c->ev_rest);
   if (c->stream2) hipStreamDestroy(c->stream2);
+  if (c->stream2m) hipStreamDestroy(c->stream2m);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -531,7 +553,7 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
     double* invd = d_invstore ? d_invstore + (j / TILE) * INVD_STRIDE : ctx->d_invd;
     if (ctx->inner_ll && j > 0)
       CHECK_RC(launch_gemm_nt(P + j, ld, P + j, ld, D, ld, m - j, TILE, j, -1.0, 1.0, 0, 0, 0, s));
-    CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s));
+    CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s, ctx->excl_now));
     long mrest = m - j - TILE;
     if (mrest > 0 && ctx->refine != 1) CHECK_RC(launch_trtri(D, ld, invd, ctx->d_w, s));  // A/B modes only
     if (mrest > 0) {
@@ -598,7 +620,13 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
                     : n_pad >= 32768 ? WOUT_LARGE
                                      : WOUT_SMALL;
   const bool la = ctx->lookahead && s == ctx->stream;
-  hipStream_t sB = la ? ctx->stream2 : s;
+  const bool reserve = la && ctx->stream2m && n_pad <= ctx->reserve_max_n;
+  hipStream_t sB = la ? (reserve ? ctx->stream2m : ctx->stream2) : s;
+  struct ExclScope {   // potrf_diag placement follows the update stream in use, on every exit path
+    sgp_ctx* c;
+    ExclScope(sgp_ctx* c_, int v) : c(c_) { c->excl_now = v; }
+    ~ExclScope() { c->excl_now = 0; }
+  } excl_scope(ctx, reserve && ctx->reserve_cu > 0 ? 1 : 0);
   bool rest_pending = false;
   if (la) {
     // the update stream must see everything enqueued on s so far (assembly)
@@ -614,7 +642,12 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
     if (c0 >= n_pad) break;
     long w1 = std::min(WOUT, n_pad - c0);   // width of the next panel
     long c1 = c0 + w1;
-    if (la) {
+    // The look-ahead only pays while the trailing update outlasts the panel chain it hides: sharing CUs with
+    // the update's MFMA waves makes the latency-bound panel kernels 2.5 - 5 x slower (potrf_diag: 35 -> 180 us
+    // resident beside one update workgroup, tools/gpu_potrf_contend.py), so once fewer than la_min columns
+    // remain the panel and its update run back to back on the panel stream with the chip to themselves.
+    const bool la_k = la && (n_pad - c0) > ctx->la_min;
+    if (la_k) {
       SGP_HIP(hipEventRecord(ctx->ev_panel, s));
       // look-ahead: next panel's columns on the panel stream (after the previous rest update)
       if (rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
@@ -627,6 +660,10 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
         rest_pending = true;
       }
     } else {
+      if (rest_pending) {
+        SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
+        rest_pending = false;
+      }
       CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_eff - c0, n_pad - c0, wj, s));
     }
   }
@@ -2284,6 +2321,38 @@ extern "C" int sgp_bench_hbm(sgp_ctx* ctx, int64_t bytes, int iters, double* wri
   return run_hbm_bench(ctx->stream, bytes, iters, write_gbs_out, copy_gbs_out);
 }
 
+// CU census under a CU mask: which (XCD, SE, SH, CU) the workgroups of a stream created with `mask` land on
+// (cnt[xcc << 8 | HW_ID[15:8]]); one workgroup per CU at a time (80 KB of LDS), each staying ~10 us.
+__global__ __launch_bounds__(256) void cu_census_kernel(unsigned* cnt, long long spin) {
+  extern __shared__ double census_lds[];
+  if (threadIdx.x == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg(63492);   // HW_ID
+    const unsigned xcc = __builtin_amdgcn_s_getreg(6164);   // XCC_ID 3:0
+    atomicAdd(&cnt[((xcc & 15) << 8) | ((hw >> 8) & 255)], 1u);
+    census_lds[0] = 0.0;
+  }
+  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+  while ((long long)__builtin_amdgcn_s_memtime() - t0 < spin) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int sgp_bench_cumask(sgp_ctx* ctx, const uint32_t* mask, int words, int nwg, unsigned* out /* [4096] */) {
+  CHECK_ARG(ctx && out && nwg > 0, "sgp_bench_cumask: NULL argument");
+  CtxScope scope(ctx);
+  hipStream_t st = nullptr;
+  if (mask && words > 0) SGP_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+  else SGP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  unsigned* d = nullptr;
+  if (hipMalloc(&d, 4096 * sizeof(unsigned)) != hipSuccess) { hipStreamDestroy(st); set_error("hipMalloc failed"); return -2; }
+  hipMemsetAsync(d, 0, 4096 * sizeof(unsigned), st);
+  SGP_LDS_ATTR_ONCE(cu_census_kernel, 81920);
+  hipLaunchKernelGGL(cu_census_kernel, dim3((unsigned)nwg), dim3(256), 81920, st, d, 20000LL);
+  hipError_t e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipMemcpy(out, d, 4096 * sizeof(unsigned), hipMemcpyDeviceToHost);
+  hipFree(d);
+  hipStreamDestroy(st);
+  SGP_HIP(e);
+  return 0;
+}
+
 __global__ void fill_rand_kernel(double* p, long n, unsigned long long seed) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -2333,12 +2402,72 @@ extern "C" int sgp_bench_potrf(sgp_ctx* ctx, int iters, double* us_out, long lon
   return 0;
 }
 
+// potrf_diag under the look-ahead's contention: `gemm_launches` trailing updates C(m^2 lower) -= P P' (depth k) are
+// queued on the update stream, then n potrf_diag launches go one by one down the panel stream: us_out[i] is launch
+// i's time by HIP events (it includes the wait for a free workgroup slot), ticks_out[i] its own s_memtime span of
+// wave 0 (the time it runs once resident).  busy_out[i] = 1 while the updates had not finished.
+extern "C" int sgp_bench_potrf_contended(sgp_ctx* ctx, int64_t m, int64_t k, int gemm_launches, int n,
+                                         double* us_out, long long* ticks_out, int* busy_out) {
+  CHECK_ARG(ctx && us_out && ticks_out && busy_out && n > 0, "sgp_bench_potrf_contended: NULL argument");
+  CHECK_ARG(m % TILE == 0 && k % 16 == 0 && m > 0, "sgp_bench_potrf_contended: bad sizes");
+  CtxScope scope(ctx);
+  hipStream_t s = ctx->stream, s2 = ctx->stream2m ? ctx->stream2m : ctx->stream2;
+  const int excl = ctx->stream2m && ctx->reserve_cu > 0 ? 1 : 0;
+  DevBuf P, Cm, A, A0;
+  CHECK_RC(P.alloc((size_t)m * k));
+  CHECK_RC(Cm.alloc((size_t)m * m));
+  CHECK_RC(A.alloc((size_t)TILE * TILE));
+  CHECK_RC(A0.alloc((size_t)TILE * TILE));
+  std::vector<double> h((size_t)TILE * TILE);
+  for (int c = 0; c < TILE; ++c)
+    for (int r = 0; r < TILE; ++r) h[r + (size_t)c * TILE] = (r == c ? 2.0 : 0.0) + std::exp(-0.02 * (r - c) * (r - c));
+  SGP_HIP(hipMemcpy(A0.p, h.data(), sizeof(double) * TILE * TILE, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(fill_rand_kernel, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, s2, P.p, m * k, 99ULL);
+  SGP_HIP(hipMemsetAsync(Cm.p, 0, sizeof(double) * m * m, s2));
+  long long* d_dbg = nullptr;
+  SGP_HIP(hipMalloc(&d_dbg, sizeof(long long) * 64));
+  SGP_HIP(hipMemset(d_dbg, 0, sizeof(long long) * 64));
+  hipEvent_t e0, e1, eg;
+  SGP_HIP(hipEventCreate(&e0));
+  SGP_HIP(hipEventCreate(&e1));
+  SGP_HIP(hipEventCreate(&eg));
+  SGP_HIP(hipStreamSynchronize(s2));
+  int rc = 0;
+  for (int i = 0; i < gemm_launches && rc == 0; ++i) rc = launch_gemm_nt_update(P.p, m, Cm.p, m, m, m, k, s2);
+  if (rc == 0 && hipEventRecord(eg, s2) != hipSuccess) rc = -2;
+  long long st[64];
+  for (int i = 0; i < n && rc == 0; ++i) {
+    hipMemcpyAsync(A.p, A0.p, sizeof(double) * TILE * TILE, hipMemcpyDeviceToDevice, s);
+    hipStreamSynchronize(s);
+    hipEventRecord(e0, s);
+    rc = launch_potrf_diag_dbg(A.p, TILE, ctx->d_invd, ctx->d_slots, ctx->d_info, d_dbg, s, excl);
+    hipEventRecord(e1, s);
+    hipEventSynchronize(e1);
+    busy_out[i] = hipEventQuery(eg) == hipErrorNotReady ? 1 : 0;
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    us_out[i] = ms * 1e3;
+    hipMemcpyAsync(st, d_dbg, sizeof(st), hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    long long last = 0;
+    for (int q = 0; q < 64; ++q)
+      if (st[q]) last = st[q];
+    ticks_out[i] = last - st[0];
+  }
+  hipStreamSynchronize(s2);
+  hipFree(d_dbg);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  hipEventDestroy(eg);
+  return rc;
+}
+
 extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only,
                               int iters, double* tflops_out, double* maxerr_out) {
   CHECK_ARG(ctx && tflops_out && maxerr_out, "sgp_bench_gemm: NULL argument");
   CHECK_ARG(m % TILE == 0 && n % TILE == 0 && k % 16 == 0 && m >= n, "sgp_bench_gemm: bad sizes");
   CtxScope scope(ctx);
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ctx->stream2m ? ctx->stream2m : ctx->stream;   // SGP_RESERVE_CU: the CU-masked update stream
   DevBuf A, C;
   CHECK_RC(A.alloc((size_t)m * k));
   CHECK_RC(C.alloc((size_t)m * n));

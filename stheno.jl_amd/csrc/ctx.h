@@ -28,8 +28,17 @@ struct sgp_ctx {
   sgp_multi* multi = nullptr;     // non-null: sgp_logpdf shards over several GPUs (sgp_ctx_create_multi)
   hipStream_t stream = nullptr;   // panel / critical-path stream (high priority)
   hipStream_t stream2 = nullptr;  // trailing-update stream (look-ahead overlap)
+  // CU reservation for the panel chain: stream2m is an update stream whose CU mask leaves `reserve_cu` CUs of
+  // every XCD out; while the trailing update runs there, potrf_diag asks for more LDS than a CU shared with an
+  // update workgroup has free and so lands on a reserved, otherwise empty CU (potrf.hip).  excl_now: set by the
+  // factorisation while its update stream is the masked one.
+  hipStream_t stream2m = nullptr;
+  int reserve_cu = 0;
+  long reserve_max_n = 0;
+  int excl_now = 0;
   hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
   int lookahead = 1;
+  long la_min = 0;   // look-ahead only while more than la_min columns of the trailing matrix remain (capi.hip)
   long wout = 0;  // 0 = automatic
   double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
   double* d_w = nullptr;       // 128 x 128 scratch inverse
@@ -84,6 +93,7 @@ struct CtxScope {
   ~CtxScope() {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream2);
+    if (ctx->stream2m) hipStreamSynchronize(ctx->stream2m);
     tl_ctx = prev;
   }
 };

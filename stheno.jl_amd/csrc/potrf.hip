@@ -47,6 +47,7 @@ constexpr int PD_THREADS = 512;
 // CU, so the high-priority panel stream gets onto the chip while the update of the previous panel
 // is still running (a 149 KB tile had to wait for an entirely idle CU, i.e. for the update's tail).
 constexpr size_t PD_LDS = (size_t)(36 * 256 + 256) * sizeof(double);
+constexpr size_t PD_LDS_EXCL = (size_t)90 * 1024;  // > 160 KB - one GEMM workgroup's 73.7 KB
 __device__ __forceinline__ int boff(int rb, int cb) { return (rb * (rb + 1) / 2 + cb) * 256; }
 
 // wave-uniform (rb, cb) of packed lower block `blk` (blk = rb (rb + 1) / 2 + cb)
@@ -336,18 +337,22 @@ __device__ __forceinline__ void potrf_diag_body(double* A, long ld, double* invd
 
 // bench / diagnosis: one launch with phase stamps (s_memtime ticks of wave 0) into dbg[64]
 int launch_potrf_diag_dbg(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long long* dbg,
-                          hipStream_t s) {
-  SGP_LDS_ATTR_ONCE(potrf_diag_dbg_kernel, PD_LDS);
-  hipLaunchKernelGGL(potrf_diag_dbg_kernel, dim3(1), dim3(PD_THREADS), PD_LDS, s, A, ld, d_invd, d_logdet_slot, d_info,
-                     0L, 0, dbg);
+                          hipStream_t s, int exclusive) {
+  SGP_LDS_ATTR_ONCE(potrf_diag_dbg_kernel, PD_LDS_EXCL);
+  hipLaunchKernelGGL(potrf_diag_dbg_kernel, dim3(1), dim3(PD_THREADS), exclusive ? PD_LDS_EXCL : PD_LDS, s, A, ld, d_invd,
+                     d_logdet_slot, d_info, 0L, panel_prio(), dbg);
   SGP_HIP(hipGetLastError());
   return 0;
 }
 
+// exclusive: ask for more LDS than a CU holding one trailing-update workgroup has left (160 - 73.7 KB), so the
+// block can only be placed on a CU WITHOUT update workgroups -- one of the CUs the update stream's CU mask leaves
+// out (ctx.h, reserve_cu).  Sharing a CU with 8 MFMA-saturating waves makes this latency-bound kernel 5 x slower
+// (profiles/r02_microbench.md).
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,
-                      long gcol0, hipStream_t s) {
-  SGP_LDS_ATTR_ONCE(potrf_diag_kernel, PD_LDS);
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PD_THREADS), PD_LDS, s, A, ld, d_invd,
+                      long gcol0, hipStream_t s, int exclusive) {
+  SGP_LDS_ATTR_ONCE(potrf_diag_kernel, PD_LDS_EXCL);
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PD_THREADS), exclusive ? PD_LDS_EXCL : PD_LDS, s, A, ld, d_invd,
                      d_logdet_slot, d_info, gcol0, panel_prio());
   SGP_HIP(hipGetLastError());
   return 0;
