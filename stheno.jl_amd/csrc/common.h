@@ -173,6 +173,11 @@ int launch_potrf_diag_dbg(double* A, long ld, double* d_invd, double* d_logdet_s
 int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
                        long inv_cstride, long inv_kstride, hipStream_t s);
 int launch_trtri(const double* L, long ld, const double* d_invd, double* d_w, hipStream_t s);
+// fp32 storage, fp64 arithmetic: the panel kernels of the fp32 instantiation (f32.hip)
+int launch_potrf_diag_f32(float* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
+                          hipStream_t s);
+int launch_panel_solve_f32(float* X, long ldx, long rows, const float* L, long ldl, const double* inv,
+                           long inv_cstride, long inv_kstride, hipStream_t s);
 
 // reduce.hip
 int launch_rowsumsq(const double* rows, long ld, long nc, long nrows, double* out, int accumulate,

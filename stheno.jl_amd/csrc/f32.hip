@@ -8,9 +8,10 @@
 //                           (inputs stay fp64 in HBM and are rounded once while staged into LDS)
 //   gemm_nt_f32_kernel      C -= A B' on v_mfma_f32_32x32x2_f32 (exact f32, 157 TFLOP/s peak): 128 x 128 tile,
 //                           4 waves x (2 x 2) MFMA tiles, K chunks of 16 through two LDS stages
-//   potrf_f32_kernel        128 x 128 diagonal block in LDS: 16-column sub-panels, wave-0 micro-Cholesky
-//                           (v_readlane broadcasts), row-per-thread sub-panel solve, VALU trailing update
-//   trsm_f32_kernel         X <- X inv(L11)' by substitution, one row per thread, L11 through scalar loads
+//   diagonal block + row solve: the fp64 path's potrf_diag / panel_solve kernels instantiated on fp32 storage
+//                           (potrf.hip: values converted while they are read and written, arithmetic in fp64) --
+//                           fp32 kernels of their own took 75 + 60 us per 128 columns against 33 + 17 us, and
+//                           made N <= 16384 slower than fp64 (profiles/r02_microbench.md)
 // Driver: two-level right-looking Cholesky (outer panels, 128-column steps inside) with the fp64 driver's
 // one-panel look-ahead on two streams.
 // Entry points: sgp_logpdf_f32, sgp_kernelmatrix_f32 (include/sthenomi.h).  Accuracy is fp32's: the
@@ -243,119 +244,6 @@ int launch_gemm_f32(const float* A, long lda, const float* B, long ldb, float* C
   return 0;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// 128 x 128 diagonal block Cholesky, fp32, one 256-thread workgroup, tile in LDS (column-major, ld 129).
-// Per 16-column sub-panel: wave 0 factors the 16 x 16 diagonal block in registers (lane i = row i, v_readlane
-// broadcasts); threads 0..127 solve their row of the sub-panel by substitution; all threads apply the
-// rank-16 update to the trailing block.  logdet partial in fp64.
-// ---------------------------------------------------------------------------------------------------------
-constexpr int LDP = TILE + 1;
-__global__ __launch_bounds__(256) void potrf_f32_kernel(float* A, long ld, float* Lt, double* logdet_slot, int* info,
-                                                        long gcol0) {
-  extern __shared__ __attribute__((aligned(16))) float sT[];  // 128 x 129
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  for (int idx = t; idx < TILE * TILE; idx += 256) {
-    const int r = idx & 127, c = idx >> 7;
-    sT[r + c * LDP] = (r >= c) ? A[r + (long)c * ld] : 0.0f;
-  }
-  __syncthreads();
-  int firstbad = 1 << 20;
-  for (int cb = 0; cb < 8; ++cb) {
-    const int c0 = cb * 16;
-    if (w == 0) {          // micro-Cholesky of the 16 x 16 diagonal block
-      const int i = lane & 15;
-      float row[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) row[c] = sT[(c0 + i) + (c0 + c) * LDP];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float djj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, row[j]), j));
-        firstbad = (djj > 0.0f) ? firstbad : min(firstbad, c0 + j);
-        const float r = rsqrtf(djj);
-        const float lij = (i == j) ? djj * r : row[j] * r;
-        row[j] = lij;
-#pragma unroll
-        for (int c2 = j + 1; c2 < 16; ++c2) {
-          const float lcj = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, lij), c2));
-          row[c2] = fmaf(-lij, lcj, row[c2]);
-        }
-      }
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c) sT[(c0 + i) + (c0 + c) * LDP] = (c <= i) ? row[c] : 0.0f;
-      }
-    }
-    __syncthreads();
-    // sub-panel solve: row r > c0 + 15: x_j = (x_j - sum_{k<j} x_k L[j][k]) / L[j][j]
-    if (t < TILE && t >= c0 + 16) {
-      float x[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) x[j] = sT[t + (c0 + j) * LDP];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float v = x[j];
-#pragma unroll
-        for (int k = 0; k < j; ++k) v = fmaf(-x[k], sT[(c0 + j) + (c0 + k) * LDP], v);
-        x[j] = v / sT[(c0 + j) + (c0 + j) * LDP];
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) sT[t + (c0 + j) * LDP] = x[j];
-    }
-    __syncthreads();
-    // trailing update: T[r][c] -= sum_k X[r][k] X[c][k] for c0 + 16 <= c <= r
-    const int n = TILE - c0 - 16;
-    for (int idx = t; idx < n * n; idx += 256) {
-      const int r = c0 + 16 + idx % n, c = c0 + 16 + idx / n;
-      if (r < c) continue;
-      float v = sT[r + c * LDP];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v = fmaf(-sT[r + (c0 + k) * LDP], sT[c + (c0 + k) * LDP], v);
-      sT[r + c * LDP] = v;
-    }
-    __syncthreads();
-  }
-  for (int idx = t; idx < TILE * TILE; idx += 256) {
-    const int r = idx & 127, c = idx >> 7;
-    A[r + (long)c * ld] = (r >= c) ? sT[r + c * LDP] : 0.0f;
-  }
-  for (int idx = t; idx < TILE * TILE; idx += 256) {   // row-major copy for the scalar loads of trsm_f32_kernel
-    const int k = idx & 127, j = idx >> 7;
-    Lt[j * TILE + k] = (k <= j) ? sT[j + k * LDP] : 0.0f;
-  }
-  // logdet partial (fp64 accumulation of the fp32 diagonal)
-  __shared__ double sh[4];
-  double lg = (t < TILE) ? log((double)sT[t + t * LDP]) : 0.0;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) lg += __shfl_xor(lg, off, 64);
-  if (lane == 0) sh[w] = lg;
-  __syncthreads();
-  if (t == 0) {
-    *logdet_slot = 2.0 * ((sh[0] + sh[1]) + (sh[2] + sh[3]));
-    if (firstbad < (1 << 20) && *info == 0) *info = (int)(gcol0 + firstbad + 1);
-  }
-}
-
-// X <- X inv(L)' for `rows` rows: substitution, one row per thread (its 128 values in registers).  The
-// factor comes as Lt = a contiguous row-major copy of L11 written by potrf_f32_kernel (Lt[j * 128 + k] =
-// L[j][k]): every L[j][k] is wave-uniform, so the fully unrolled loops read it with scalar loads straight
-// into the SGPR operand of the FMA -- one VALU instruction per multiply-add, no LDS traffic.
-__global__ __launch_bounds__(64) void trsm_f32_kernel(float* X, long ldx, long rows, const float* __restrict__ Lt) {
-  const long r = (long)blockIdx.x * 64 + threadIdx.x;
-  if (r >= rows) return;
-  float x[TILE];
-#pragma unroll
-  for (int j = 0; j < TILE; ++j) x[j] = X[r + (long)j * ldx];
-#pragma unroll
-  for (int j = 0; j < TILE; ++j) {
-    float v = x[j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) v = fmaf(-x[k], Lt[j * TILE + k], v);
-    x[j] = v / Lt[j * TILE + j];
-  }
-#pragma unroll
-  for (int j = 0; j < TILE; ++j) X[r + (long)j * ldx] = x[j];
-}
-
 __global__ void rowsumsq_f32_kernel(const float* row, long ld, long nc, double* out) {
   __shared__ double sh[4];
   double acc = 0.0;
@@ -419,20 +307,19 @@ int assemble_f32(const sgp_dspec* ds, float* K, long ld, int lower_only, int noi
 
 // factor one column panel in place (128-column steps: diagonal block, row solve, K = 128 update of the rest
 // of the panel)
-int panel_factor_f32(sgp_ctx* ctx, float* P, long ld, long m, long w, long g0, float* Lt, size_t pd_lds, hipStream_t s) {
+int panel_factor_f32(sgp_ctx* ctx, float* P, long ld, long m, long w, long g0, hipStream_t s) {
   for (long j = 0; j < w; j += TILE) {
     float* D = P + j + j * ld;
-    hipLaunchKernelGGL(potrf_f32_kernel, dim3(1), dim3(256), pd_lds, s, D, ld, Lt, ctx->d_slots + (g0 + j) / TILE,
-                       ctx->d_info, g0 + j);
+    // diagonal block and row solve in fp64 arithmetic on the fp32 storage (potrf.hip)
+    if (int rc = launch_potrf_diag_f32(D, ld, ctx->d_invd, ctx->d_slots + (g0 + j) / TILE, ctx->d_info, g0 + j, s)) return rc;
     const long mrest = m - j - TILE;
     if (mrest > 0) {
       float* A21 = P + (j + TILE) + j * ld;
-      hipLaunchKernelGGL(trsm_f32_kernel, dim3((unsigned)((mrest + 63) / 64)), dim3(64), 0, s, A21, ld, mrest, Lt);
+      if (int rc = launch_panel_solve_f32(A21, ld, mrest, D, ld, ctx->d_invd, 256, 16, s)) return rc;
       const long wrest = w - j - TILE;
       if (wrest > 0)
         if (int rc = launch_gemm_f32(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, 1, s)) return rc;
     }
-    SGP_HIP(hipGetLastError());
   }
   return 0;
 }
@@ -442,9 +329,6 @@ int panel_factor_f32(sgp_ctx* ctx, float* P, long ld, long m, long w, long g0, f
 // while the rest of the trailing matrix is updated with the current panel on the update stream
 int chol_f32(sgp_ctx* ctx, float* A, long ld, long n_pad, long m_tot, hipStream_t s) {
   const long W = n_pad <= 2048 ? n_pad : (n_pad <= 8192 ? 1024 : 512);
-  static const size_t PD = (size_t)TILE * LDP * sizeof(float);
-  SGP_LDS_ATTR_ONCE(potrf_f32_kernel, PD);
-  float* Lt = reinterpret_cast<float*>(ctx->d_w);   // 128 x 128 scratch (fp64-sized: twice what is needed)
   const bool la = ctx->lookahead && s == ctx->stream;
   hipStream_t sB = la ? ctx->stream2 : s;
   bool rest_pending = false;
@@ -454,7 +338,7 @@ int chol_f32(sgp_ctx* ctx, float* A, long ld, long n_pad, long m_tot, hipStream_
   }
   for (long J0 = 0; J0 < n_pad; J0 += W) {
     const long wj = std::min(W, n_pad - J0);
-    if (int rc = panel_factor_f32(ctx, A + J0 + J0 * ld, ld, m_tot - J0, wj, J0, Lt, PD, s)) return rc;
+    if (int rc = panel_factor_f32(ctx, A + J0 + J0 * ld, ld, m_tot - J0, wj, J0, s)) return rc;
     const long c0 = J0 + wj;
     if (c0 >= n_pad) break;
     const long w1 = std::min(W, n_pad - c0), c1 = c0 + w1;

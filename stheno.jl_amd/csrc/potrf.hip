@@ -169,24 +169,32 @@ __device__ __forceinline__ void micro_cholesky(double* Dcc, double* sInv, int cb
 //      waves 1..7: every other trailing block T[rb][cc] -= X_rb X_cc', cb < cc <= rb
 // Every MFMA chain on the critical path is 4 (update) or 12 (refined solve) instructions deep; the
 // left-looking form this replaces accumulated up to 28 dependent MFMAs per sub-panel (44 -> ~27 us).
-template <bool DBG>
-__device__ __forceinline__ void potrf_diag_body(double* A, long ld, double* invd, double* logdet_slot, int* info,
+// TS = storage type of the tile in global memory: double, or float for the fp32 instantiation (f32.hip), whose
+// diagonal blocks are factored HERE in fp64 -- converted on the way into and out of LDS -- so the serial chain
+// is this kernel's, not a second, slower fp32 one.
+template <bool DBG, typename TS>
+__device__ __forceinline__ void potrf_diag_body(TS* A, long ld, double* invd, double* logdet_slot, int* info,
                                                 long gcol0, int prio, long long* dbg);
 
 __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_kernel(double* A, long ld, double* invd,
                                                                    double* logdet_slot, int* info,
                                                                    long gcol0, int prio) {
-  potrf_diag_body<false>(A, ld, invd, logdet_slot, info, gcol0, prio, nullptr);
+  potrf_diag_body<false, double>(A, ld, invd, logdet_slot, info, gcol0, prio, nullptr);
+}
+__global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_f32_kernel(float* A, long ld, double* invd,
+                                                                       double* logdet_slot, int* info,
+                                                                       long gcol0, int prio) {
+  potrf_diag_body<false, float>(A, ld, invd, logdet_slot, info, gcol0, prio, nullptr);
 }
 // same code with s_memtime stamps of wave 0 at the phase boundaries (sgp_bench_potrf)
 __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_dbg_kernel(double* A, long ld, double* invd,
                                                                        double* logdet_slot, int* info,
                                                                        long gcol0, int prio, long long* dbg) {
-  potrf_diag_body<true>(A, ld, invd, logdet_slot, info, gcol0, prio, dbg);
+  potrf_diag_body<true, double>(A, ld, invd, logdet_slot, info, gcol0, prio, dbg);
 }
 
-template <bool DBG>
-__device__ __forceinline__ void potrf_diag_body(double* A, long ld, double* invd, double* logdet_slot, int* info,
+template <bool DBG, typename TS>
+__device__ __forceinline__ void potrf_diag_body(TS* A, long ld, double* invd, double* logdet_slot, int* info,
                                                 long gcol0, int prio, long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   set_wave_prio(prio);
@@ -215,7 +223,7 @@ __device__ __forceinline__ void potrf_diag_body(double* A, long ld, double* invd
       for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q, k = e >> 4, m = e & 15;
         const int r = rb * 16 + m, c = cb * 16 + k;
-        v[it][q] = (blk < 36 && r >= c) ? A[r + (long)c * ld] : 0.0;
+        v[it][q] = (blk < 36 && r >= c) ? (double)A[r + (long)c * ld] : 0.0;
       }
     }
 #pragma unroll
@@ -315,7 +323,7 @@ __device__ __forceinline__ void potrf_diag_body(double* A, long ld, double* invd
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int e = lane + 64 * q, k = e >> 4, m = e & 15;
-      A[(rb * 16 + m) + (long)(cbk * 16 + k) * ld] = v[q];
+      A[(rb * 16 + m) + (long)(cbk * 16 + k) * ld] = (TS)v[q];
     }
   }
   SGP_STAMP()
@@ -349,6 +357,15 @@ int launch_potrf_diag_dbg(double* A, long ld, double* d_invd, double* d_logdet_s
 // block can only be placed on a CU WITHOUT update workgroups -- one of the CUs the update stream's CU mask leaves
 // out (ctx.h, reserve_cu).  Sharing a CU with 8 MFMA-saturating waves makes this latency-bound kernel 5 x slower
 // (profiles/r02_microbench.md).
+int launch_potrf_diag_f32(float* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
+                          hipStream_t s) {
+  SGP_LDS_ATTR_ONCE(potrf_diag_f32_kernel, PD_LDS);
+  hipLaunchKernelGGL(potrf_diag_f32_kernel, dim3(1), dim3(PD_THREADS), PD_LDS, s, A, ld, d_invd, d_logdet_slot, d_info,
+                     gcol0, panel_prio());
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,
                       long gcol0, hipStream_t s, int exclusive) {
   SGP_LDS_ATTR_ONCE(potrf_diag_kernel, PD_LDS_EXCL);
@@ -373,9 +390,26 @@ int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot,
 constexpr int PS_ROWS = 64;  // rows per workgroup (4 waves)
 constexpr size_t PS_LDS = (size_t)36 * 256 * sizeof(double);  // == one GEMM workgroup's LDS
 
+template <typename TS>
+__device__ __forceinline__ void panel_solve_body(TS* X, long ldx, const TS* L, long ldl, const double* inv,
+                                                 long inv_cstride, long inv_kstride, int strips, long rows, int prio);
+
 __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx, const double* L, long ldl,
                                                           const double* inv, long inv_cstride,
                                                           long inv_kstride, int strips, long rows, int prio) {
+  panel_solve_body<double>(X, ldx, L, ldl, inv, inv_cstride, inv_kstride, strips, rows, prio);
+}
+// fp32 storage, fp64 arithmetic (f32.hip): the rows and L11 are converted as they are read, the solved rows as
+// they are written
+__global__ __launch_bounds__(256, 2) void panel_solve_f32_kernel(float* X, long ldx, const float* L, long ldl,
+                                                              const double* inv, long inv_cstride,
+                                                              long inv_kstride, int strips, long rows, int prio) {
+  panel_solve_body<float>(X, ldx, L, ldl, inv, inv_cstride, inv_kstride, strips, rows, prio);
+}
+
+template <typename TS>
+__device__ __forceinline__ void panel_solve_body(TS* X, long ldx, const TS* L, long ldl, const double* inv,
+                                                 long inv_cstride, long inv_kstride, int strips, long rows, int prio) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   set_wave_prio(prio);
   double* sL = smem;  // block (c, p), c >= p at (c (c + 1) / 2 + p) * 256, [k][m]
@@ -391,7 +425,7 @@ __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int e = lane + 64 * q, k = e >> 4, m = e & 15;
-        v[q] = L[(16 * c + m) + (long)(16 * p + k) * ldl];
+        v[q] = (double)L[(16 * c + m) + (long)(16 * p + k) * ldl];
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) sL[blk * 256 + lane + 64 * q] = v[q];
@@ -415,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx
 #pragma unroll
     for (int c = 0; c < 8; ++c)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) nb[c][r] = -(X + (long)(16 * c + 4 * r) * ldx)[loff];
+      for (int r = 0; r < 4; ++r) nb[c][r] = -(double)(X + (long)(16 * c + 4 * r) * ldx)[loff];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const double* Lcc = sL + (c * (c + 1) / 2 + c) * 256 + aoff;
@@ -433,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) x = mfma_f64(icc[ks], rr[ks], x);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) (X + (long)(16 * c + 4 * r) * ldx)[loff] = x[r];
+      for (int r = 0; r < 4; ++r) (X + (long)(16 * c + 4 * r) * ldx)[loff] = (TS)x[r];
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -441,6 +475,23 @@ __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx
           nb[c2] = mfma_f64(sL[(c2 * (c2 + 1) / 2 + c) * 256 + aoff + ks * 64], x[ks], nb[c2]);
     }
   }
+}
+
+int launch_panel_solve_f32(float* X, long ldx, long rows, const float* L, long ldl, const double* inv,
+                           long inv_cstride, long inv_kstride, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (rows % PS_ROWS) {
+    set_error("panel_solve_f32: rows must be a multiple of 64");
+    return -1;
+  }
+  SGP_LDS_ATTR_ONCE(panel_solve_f32_kernel, PS_LDS);
+  long nstrips = rows / PS_ROWS;
+  int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + 255) / 256));
+  long nwg = (nstrips + strips - 1) / strips;
+  hipLaunchKernelGGL(panel_solve_f32_kernel, dim3((unsigned)nwg), dim3(256), PS_LDS, s, X, ldx, L, ldl, inv,
+                     inv_cstride, inv_kstride, strips, rows, panel_prio());
+  SGP_HIP(hipGetLastError());
+  return 0;
 }
 
 int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
