@@ -310,6 +310,24 @@ int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp, int64_t p
 int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nc, int64_t nrows,
                      double* d_out, void* stream);
 
+/* ---- posterior on the sharded factor (AbstractGPs.posterior / mean / var / cov of the
+ * PosteriorGP [EXT], Appendix A.5; the reference's call sites: /root/reference/test/gp/util.jl) ------------
+ * The test points ride through the sharded factorisation as extra bordered rows: the caller sizes its
+ * panels for m_tot = n_pad + 128 + pad128(n*) rows, fills rows row0 = n_pad + 128 .. with K(x*, x)
+ * (sgp_dev_assemble_cross_rows, after sgp_dev_assemble_cols on the same columns), factors as usual, and
+ * reads V' = K(x*, x) L^-T off the same rows:  mean* - m* = V' z  and  sum_c V'^2  per test point
+ * (sgp_dev_rows_dot, z' = the observation row), V' V (sgp_dev_rows_gram): sums over columns, i.e. one
+ * all-reduce across ranks.  d_dst: as in sgp_dev_assemble_cols (address of global row 0 of column c0). */
+int sgp_dev_assemble_cross_rows(sgp_ctx* ctx, const sgp_dspec* cross, int64_t c0, int64_t nc,
+                                double* d_dst, int64_t ldd, int64_t row0, void* stream);
+/* d_sumsq[r] += sum_{c < nc} R[r,c]^2, d_dot[r] += sum_c R[r,c] z[c] for r < nrows; R = d_rows (ld),
+ * z[c] = d_zrow[c * ld] */
+int sgp_dev_rows_dot(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nrows, int64_t nc,
+                     const double* d_zrow, double* d_sumsq, double* d_dot, void* stream);
+/* d_G (nrows_pad x nrows_pad, ld ldg) += R R' over nc columns (nrows_pad multiple of 128, nc of 16) */
+int sgp_dev_rows_gram(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nrows_pad, int64_t nc,
+                      double* d_G, int64_t ldg, void* stream);
+
 /* ---- N-sharded ELBO (reference entry /root/reference/src/gp/sparse_finite_gp.jl:52-58) --
  * The bound is a sum over data points up to one M x M factorisation: every rank turns ITS slice of the
  * data (rows of xz, var_x, mean_x, noise_x, y: host pointers, as in sgp_elbo) into a "part" -- a

@@ -2259,7 +2259,8 @@ extern "C" int sgp_dev_assemble_cols(sgp_ctx* ctx, const sgp_dspec* ds, int64_t 
   sgp_geometry(N, ncols, &n_pad, &mt);
   // ldd >= m_tot - c0: a panel may be stored packed (rows c0 .. m_tot only); the caller then passes the
   // virtual address of global row 0 (first stored row minus c0), which is never dereferenced above row c0
-  CHECK_ARG(mt == m_tot && ldd >= m_tot - c0, "sgp_dev_assemble_cols: geometry mismatch");
+  // m_tot > mt: the caller appends more bordered rows below the observation rows (sgp_dev_assemble_cross_rows)
+  CHECK_ARG(mt <= m_tot && m_tot % TILE == 0 && ldd >= m_tot - c0, "sgp_dev_assemble_cols: geometry mismatch");
   double* Kv = d_dst - c0 * ldd;  // virtual base: global column index
   double s2 = noise_host ? noise_host[0] : 0.0;
   CHECK_RC(assemble(ds, Kv, ldd, c0 / TILE, n_pad / TILE, c0 / TILE, (c0 + nc) / TILE, 1, noise_kind,
@@ -2267,6 +2268,52 @@ extern "C" int sgp_dev_assemble_cols(sgp_ctx* ctx, const sgp_dspec* ds, int64_t 
   CHECK_RC(launch_fill_pad(d_dst, ldd, N, n_pad, c0, nc, m_tot, c0, s));
   CHECK_RC(launch_border_rows(d_dst, ldd, n_pad, N, c0, nc, d_Y, ldy, ncols, d_mean, s));
   return 0;
+}
+
+// Sharded posterior (AbstractGPs.posterior + mean / var / cov of the PosteriorGP [EXT], App. A.5):
+// K(x*, x) rides through the sharded factorisation as extra bordered rows and comes out as V' = K(x*, x) L^-T,
+// next to the observation row z' = (L^-1 (y - m))'; then  mean* = m* + V' z,  var* = k** - rowsumsq(V'),
+// cov* = K** - V' V  are sums over columns = over ranks: one all-reduce of 2 n* (+ n*^2) doubles.
+extern "C" int sgp_dev_assemble_cross_rows(sgp_ctx* ctx, const sgp_dspec* cross, int64_t c0, int64_t nc,
+                                           double* d_dst, int64_t ldd, int64_t row0, void* stream) {
+  CHECK_ARG(ctx && cross && d_dst, "sgp_dev_assemble_cross_rows: NULL argument");
+  CHECK_ARG(!cross->symmetric, "sgp_dev_assemble_cross_rows: needs a cross-covariance spec (rows x*, columns x)");
+  CHECK_ARG(c0 % TILE == 0 && nc % TILE == 0 && row0 % TILE == 0 && row0 >= c0 + nc,
+            "sgp_dev_assemble_cross_rows: c0, nc, row0 must be multiples of 128, rows below the square part");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  const long ns = cross->N, Nx = cross->M;
+  const long ns_pad = (ns + TILE - 1) / TILE * TILE;
+  CHECK_ARG(ldd >= row0 + ns_pad - c0, "sgp_dev_assemble_cross_rows: leading dimension too small");
+  const long nc_valid = std::max<long>(0, std::min<long>(nc, Nx - c0));   // columns >= Nx are identity padding
+  if (nc_valid > 0) {
+    double* Kv = d_dst + row0 - c0 * ldd;   // element (r, c) of K(x*, x) at Kv[r + c * ldd]
+    CHECK_RC(assemble(cross, Kv, ldd, 0, ns_pad / TILE, c0 / TILE, (c0 + nc) / TILE, 0, -1, 0.0, nullptr, s));
+    CHECK_RC(launch_zero_rows(d_dst, ldd, row0 + ns, row0 + ns_pad, nc_valid, s));
+  }
+  if (nc_valid < nc) CHECK_RC(launch_zero_rows(d_dst + nc_valid * ldd, ldd, row0, row0 + ns_pad, nc - nc_valid, s));
+  return 0;
+}
+
+extern "C" int sgp_dev_rows_dot(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nrows, int64_t nc,
+                                const double* d_zrow, double* d_sumsq, double* d_dot, void* stream) {
+  CHECK_ARG(ctx && d_rows && d_zrow && d_sumsq && d_dot, "sgp_dev_rows_dot: NULL argument");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return launch_rows_dot(d_rows, ld, nrows, nc, d_zrow, d_sumsq, d_dot, s);
+}
+
+// G (nrows_pad x nrows_pad, ld ldg, all tiles) += R R' over the nc columns of the bordered rows R
+extern "C" int sgp_dev_rows_gram(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nrows_pad, int64_t nc,
+                                 double* d_G, int64_t ldg, void* stream) {
+  CHECK_ARG(ctx && d_rows && d_G, "sgp_dev_rows_gram: NULL argument");
+  CHECK_ARG(nrows_pad % TILE == 0 && nc % 16 == 0 && ldg >= nrows_pad, "sgp_dev_rows_gram: bad sizes");
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  return launch_gemm_nt(d_rows, ld, d_rows, ld, d_G, ldg, nrows_pad, nrows_pad, nc, 1.0, 1.0, NOMASK, 0, 0, s);
 }
 
 extern "C" int sgp_dev_panel_factor(sgp_ctx* ctx, double* d_P, int64_t ld, int64_t m, int64_t w,

@@ -116,6 +116,9 @@ int launch_assemble_block(double* K, long ld, long r0, long nr, long c0, long nc
                           long tile_r_first, long tile_c_first, long tile_r_cnt, long tile_c_cnt,
                           hipStream_t s);
 int assemble_terms_per_launch(int dmax);  // how many terms one launch_assemble_block may carry (LDS)
+int launch_rows_dot(const double* rows, long ld, long nrows, long nc, const double* zrow, double* sumsq,
+                    double* dot, hipStream_t s);
+int launch_zero_rows(double* A, long ld, long r0, long r1, long nc, hipStream_t s);
 int launch_fill_pad(double* K, long ld, long N, long n_pad, long c0, long nc, long m_tot,
                     long row_lo, hipStream_t s);
 int launch_border_rows(double* A, long ld, long n_pad, long N, long c0, long nc, const double* dY,

@@ -40,6 +40,49 @@ int launch_rowsumsq(const double* rows, long ld, long nc, long nrows, double* ou
   return 0;
 }
 
+// Bordered rows after the factorisation: rows r < nrows of a local panel hold V' = K(x*, x) L^-T (columns =
+// this panel's nc columns), zrow the transformed observation row z' = (L^-1 (y - m))'.  One thread per row,
+// columns in order (coalesced across rows, deterministic):  sumsq[r] += sum_c V'[r,c]^2,
+// dot[r] += sum_c V'[r,c] z[c]  -- the posterior variance reduction and mean shift of test point r.
+__global__ void rows_dot_kernel(const double* rows, long ld, long nrows, long nc, const double* zrow,
+                                double* sumsq, double* dot) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= nrows) return;
+  double a = 0.0, b = 0.0;
+  for (long c = 0; c < nc; ++c) {
+    const double v = rows[r + c * ld];
+    a = fma(v, v, a);
+    b = fma(v, zrow[c * ld], b);
+  }
+  sumsq[r] += a;
+  dot[r] += b;
+}
+
+int launch_rows_dot(const double* rows, long ld, long nrows, long nc, const double* zrow, double* sumsq,
+                    double* dot, hipStream_t s) {
+  if (nrows <= 0 || nc <= 0) return 0;
+  hipLaunchKernelGGL(rows_dot_kernel, dim3((unsigned)((nrows + 127) / 128)), dim3(128), 0, s, rows, ld, nrows, nc,
+                     zrow, sumsq, dot);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+// rows [r0, r1) x nc columns of a column-major matrix = 0
+__global__ void zero_rows_kernel(double* A, long ld, long r0, long r1, long nc) {
+  const long h = r1 - r0;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= h * nc) return;
+  A[r0 + idx % h + (idx / h) * ld] = 0.0;
+}
+
+int launch_zero_rows(double* A, long ld, long r0, long r1, long nc, hipStream_t s) {
+  if (r1 <= r0 || nc <= 0) return 0;
+  const long tot = (r1 - r0) * nc;
+  hipLaunchKernelGGL(zero_rows_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, ld, r0, r1, nc);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 __global__ void sum_array_kernel(const double* in, long n, double* out) {
   __shared__ double sh[4];
   double acc = 0.0;

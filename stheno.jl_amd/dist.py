@@ -195,6 +195,24 @@ class HipOps:
                                        self.stream())
         _lib.check(rc, "sgp_dev_rowsumsq")
 
+    # -- posterior on the sharded factor -----------------------------------------------------
+    def assemble_cross_rows(self, dx, c0, nc, A, off, ld, row0):
+        rc = self.lib.sgp_dev_assemble_cross_rows(self.ctx.handle, dx, c0, nc, A.data_ptr() + 8 * (off - c0), ld, row0,
+                                                  self.stream())
+        _lib.check(rc, "sgp_dev_assemble_cross_rows")
+
+    def rows_dot(self, A, r_off, ld, nrows, nc, z_off, pv, ns_pad):
+        """pv[:ns_pad] += rowsumsq, pv[ns_pad:] += rows . z   (rows at A[r_off..], z row at A[z_off..])"""
+        rc = self.lib.sgp_dev_rows_dot(self.ctx.handle, A.data_ptr() + 8 * r_off, ld, nrows, nc,
+                                       A.data_ptr() + 8 * z_off, pv.data_ptr(), pv.data_ptr() + 8 * ns_pad,
+                                       self.stream())
+        _lib.check(rc, "sgp_dev_rows_dot")
+
+    def rows_gram(self, A, r_off, ld, nrows_pad, nc, G):
+        rc = self.lib.sgp_dev_rows_gram(self.ctx.handle, A.data_ptr() + 8 * r_off, ld, nrows_pad, nc, G.data_ptr(),
+                                        nrows_pad, self.stream())
+        _lib.check(rc, "sgp_dev_rows_gram")
+
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
 
@@ -202,6 +220,10 @@ class HipOps:
     def prior_var(self, f, x):
         from . import finite_gp as _fg
         return np.ascontiguousarray(_fg.prior_var(f, x)) if len(x) else np.zeros(0)
+
+    def prior_cov(self, f, x):
+        from . import finite_gp as _fg
+        return np.ascontiguousarray(_fg.prior_cov(f, x))
 
     def elbo_part(self, M):
         n = C.c_int64()
@@ -239,11 +261,74 @@ def dist_logpdf(ops, spec, y, mean, sigma2, world=1, rank=0, group=None, W=1024,
         ops.free_dspec(ds)
 
 
-def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, always_collective=False):
+def dist_posterior_predict(ops, spec, cross, y, mean, sigma2, prior_mean_s, prior_var_s, prior_cov_s=None,
+                           world=1, rank=0, group=None, W=1024, always_collective=False):
+    """Posterior marginals at test points x* from the SHARDED factorisation: what
+    `mean_and_var(posterior(f(x, s2), y)(x*))` (and `cov(...)` when prior_cov_s is given) returns on the
+    reference path (AbstractGPs.posterior / PosteriorGP mean, var, cov [EXT], App. A.5; reference call sites
+    /root/reference/test/gp/util.jl, /root/reference/src/gp/sparse_finite_gp.jl:60-62 for the dispatch).
+
+    K(x*, x) is appended to the bordered matrix as extra rows below the observation row; the column-panel
+    factorisation that computes logpdf turns them into V' = K(x*, x) L^-T on every rank's own columns, so
+        mean* = m* + V' z,   var* = k** - sum_c V'^2,   cov* = K** - V' V      (z = L^-1 (y - m))
+    are sums over columns: ONE all-reduce of 2 n* (+ n*^2) doubles, no distributed triangular solve.
+
+    spec  : lib.Spec (symmetric) of cov(f, x);  cross : lib.Spec of cov(f, x*, x) (rows x*, columns x)
+    prior_mean_s, prior_var_s (, prior_cov_s) : m(x*), diag K(x*, x*) (, K(x*, x*)) as host arrays
+    Returns (logpdf, mean*, var*, cov* or None), identical on every rank."""
+    ds = ops.make_dspec(spec)
+    dx = ops.make_dspec(cross)
+    try:
+        with ops.stream_context():
+            out = {}
+            lp = _dist_logpdf(ops, ds, spec.N, y, mean, sigma2, world, rank, group, W, None, None, always_collective,
+                              cross=(dx, cross.N, prior_cov_s is not None), post=out)
+    finally:
+        ops.free_dspec(ds)
+        ops.free_dspec(dx)
+    ns = cross.N
+    mean_s = np.asarray(prior_mean_s, dtype=np.float64).reshape(-1) + out["dot"][:ns]
+    var_s = np.asarray(prior_var_s, dtype=np.float64).reshape(-1) - out["sumsq"][:ns]
+    cov_s = None
+    if prior_cov_s is not None:
+        cov_s = np.asarray(prior_cov_s, dtype=np.float64) - out["gram"][:ns, :ns]
+    return lp, mean_s, var_s, cov_s
+
+
+def dist_posterior(ops, fx, y, xs, want_cov=False, world=1, rank=0, group=None, W=1024, always_collective=False):
+    """`mean_and_var(posterior(fx, y)(xs))` (and `cov` when want_cov) with the factorisation sharded over
+    `world` ranks: fx = f(x, s2) a FiniteGP of a prior process with isotropic noise, xs the test inputs (any
+    input collection of the host mirror).  Builds the two specs and the prior moments at xs and calls
+    dist_posterior_predict.  Returns (mean*, var*, cov* or None); every rank gets the same arrays."""
+    from .flatten import build_spec
+    from .gp import mean_vector
+    noise = np.asarray(fx.noise, dtype=np.float64)
+    if noise.ndim != 0:
+        raise ValueError("the sharded posterior takes isotropic observation noise")
+    spec, _, _ = build_spec(fx.f, fx.x)
+    cross, _, _ = build_spec(fx.f, xs, fx.f, fx.x)
+    mean_x = mean_vector(fx.f, fx.x)
+    mean_x = None if not np.any(mean_x) else np.ascontiguousarray(mean_x)
+    with ops.stream_context():
+        var_s = ops.prior_var(fx.f, xs)
+        cov_s = ops.prior_cov(fx.f, xs) if want_cov else None
+    _, m, v, c = dist_posterior_predict(ops, spec, cross, y, mean_x, float(noise), mean_vector(fx.f, xs), var_s, cov_s,
+                                        world=world, rank=rank, group=group, W=W, always_collective=always_collective)
+    return m, v, c
+
+
+def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, always_collective=False,
+                 cross=None, post=None):
     import torch
     import torch.distributed as dist
 
     n_pad, m_tot = geometry(N, 1)
+    ns = ns_pad = 0
+    if cross is not None:   # test points as extra bordered rows (dist_posterior_predict)
+        ns = cross[1]
+        ns_pad = (ns + TILE - 1) // TILE * TILE
+        row_s = m_tot
+        m_tot += ns_pad
     W = min(W, n_pad)
     lay = PanelLayout(n_pad, W, world, rank, m_tot)
     if A is None:
@@ -259,6 +344,8 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, a
     # 1. every rank assembles its own column panels (no communication)
     for J in lay.mine:
         ops.assemble_cols(ds, N, lay.col0(J), lay.width(J), A, lay.offset(J), lay.ld(J), m_tot, dmean, sigma2, dY, 1)
+        if ns:
+            ops.assemble_cross_rows(cross[0], lay.col0(J), lay.width(J), A, lay.offset(J), lay.ld(J), row_s)
 
     def panel(J):
         """(tensor, offset) of factored panel J on this rank: its own storage, or the receive buffer"""
@@ -338,6 +425,26 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, a
         nc = min(lay.width(J), max(0, N - lay.col0(J)))
         if nc > 0:
             ops.rowsumsq(A, lay.offset(J) + (n_pad - lay.col0(J)), lay.ld(J), nc, 1, sq)
+    if ns:
+        # posterior sums over this rank's columns: V' z, rowsumsq(V') (and V' V), then one all-reduce
+        pv = ops.zeros(2 * ns_pad)
+        G = ops.zeros(ns_pad * ns_pad) if cross[2] else None
+        for J in lay.mine:
+            nc = min(lay.width(J), max(0, N - lay.col0(J)))
+            if nc > 0:
+                r_off = lay.offset(J) + (row_s - lay.col0(J))
+                ops.rows_dot(A, r_off, lay.ld(J), ns, nc, lay.offset(J) + (n_pad - lay.col0(J)), pv, ns_pad)
+                if G is not None:
+                    ops.rows_gram(A, r_off, lay.ld(J), ns_pad, lay.width(J), G)
+        if world > 1 or always_collective:
+            ops.synchronize()
+            dist.all_reduce(pv, op=dist.ReduceOp.SUM, group=group)
+            if G is not None:
+                dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+        pv_h = ops.to_host(pv)
+        post["sumsq"], post["dot"] = pv_h[:ns_pad].copy(), pv_h[ns_pad:].copy()
+        if G is not None:
+            post["gram"] = ops.to_host(G).reshape(ns_pad, ns_pad).copy()   # symmetric: storage order irrelevant
     red = torch.stack([logdet.reshape(()), sq.reshape(())])
     inf = info.to(torch.float64)
     big = float(2 ** 52)

@@ -117,6 +117,9 @@ _SIGS = {
     "sgp_bench_mfma_f64": (C.c_int, [_P, C.c_int, _D, _D]),
     "sgp_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D]),
     "sgp_bench_potrf": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_longlong)]),
+    "sgp_dev_assemble_cross_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
+    "sgp_dev_rows_dot": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
+    "sgp_dev_rows_gram": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
     "sgp_bench_cumask": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_uint)]),
     "sgp_bench_potrf_contended": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int, C.c_int, _D, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "sgp_bench_gemm": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _D, _D]),

@@ -70,7 +70,7 @@ class NumpyOps:
     def assemble_cols(self, ds, N, c0, nc, A, off, ld, m_tot, mean, sigma2, Y, ncols):
         self.calls.append(("assemble", c0, nc))
         assert ld == m_tot - c0
-        n_pad = m_tot - 128 * ((ncols + 127) // 128)
+        n_pad = max(128, (N + 127) // 128 * 128)       # m_tot may hold more bordered rows (test points) below
         M = self._mat(A, off, ld, nc)
         K = ds["K"]
         for lc in range(nc):
@@ -115,6 +115,31 @@ class NumpyOps:
         rows = P[c0 - J0:, :]
         M[:, :] -= rows @ P[c0 - J0:c0 - J0 + nc, :].T
 
+    # -- posterior on the sharded factor (sgp_dev_assemble_cross_rows / rows_dot / rows_gram)
+    def assemble_cross_rows(self, dx, c0, nc, A, off, ld, row0):
+        self.calls.append(("cross", c0, nc))
+        Kx = dx["K"]                                     # n* x N
+        ns, Nx = Kx.shape
+        ns_pad = (ns + 127) // 128 * 128
+        M = self._mat(A, off, ld, nc)                    # rows c0..m_tot
+        blk = np.zeros((ns_pad, nc))
+        v = max(0, min(nc, Nx - c0))
+        blk[:ns, :v] = Kx[:, c0:c0 + v]
+        M[row0 - c0: row0 - c0 + ns_pad, :] = blk
+
+    def rows_dot(self, A, r_off, ld, nrows, nc, z_off, pv, ns_pad):
+        a = A.numpy()
+        for r in range(nrows):
+            row = a[r_off + r: r_off + r + ld * nc: ld]
+            z = a[z_off: z_off + ld * nc: ld]
+            pv[r] += float((row ** 2).sum())
+            pv[ns_pad + r] += float((row * z).sum())
+
+    def rows_gram(self, A, r_off, ld, nrows_pad, nc, G):
+        a = A.numpy()
+        R = np.stack([a[r_off + r: r_off + r + ld * nc: ld] for r in range(nrows_pad)])
+        G.numpy()[:] += (R @ R.T).reshape(-1)
+
     def rowsumsq(self, A, off, ld, nc, nrows, out):
         for s in range(nrows):
             out[s] += float((A.numpy()[off + s: off + s + ld * nc: ld] ** 2).sum())
@@ -126,6 +151,11 @@ class NumpyOps:
         if len(x) == 0:
             return np.zeros(0)
         return np.diag(np_terms.dense_from_spec(P.build_spec(f, x)[0])).copy()
+
+    def prior_cov(self, f, x):
+        import stheno_jl_amd as P
+        K = np_terms.dense_from_spec(P.build_spec(f, x)[0])
+        return np.tril(K) + np.tril(K, -1).T
 
     def elbo_part(self, M):
         return torch.zeros(M * M + M + 4, dtype=torch.float64)

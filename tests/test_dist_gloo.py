@@ -129,6 +129,88 @@ def test_posdef_failure_reaches_every_rank():
     assert len({r[2] for r in res}) == 1 and res[0][2] >= 1
 
 
+# ---- posterior on the sharded factor: test points ride along as bordered rows, one all-reduce ---------
+def _post_problem(N, ns):
+    import stheno_jl_amd as P
+    spec, xs, y, s2 = _problem(N)
+    rng = np.random.default_rng(97531)
+    Xs = np.asfortranarray(rng.standard_normal((2, ns)))
+    F = P.gppp_sum_model()
+    x = P.BlockData([P.GPPPInput(k, P.ColVecs(np.asfortranarray(v))) for k, v in zip(("f1", "f2", "f3"), xs)])
+    xq = P.GPPPInput("f3", P.ColVecs(Xs))
+    cross, _, _ = P.build_spec(F, xq, F, x)
+    kss, _, _ = P.build_spec(F, xq)
+    return spec, cross, kss, xs, y, s2, Xs
+
+
+def _post_worker(rank, world, port, N, ns, W, want_cov, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        import __graft_entry__ as entry
+        entry.load_package()
+        from stheno_jl_amd import dist as sdist
+        import np_ops
+        import np_terms
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        spec, cross, kss, xs, y, s2, Xs = _post_problem(N, ns)
+        Kss = np_terms.dense_from_spec(kss)
+        Kss = np.tril(Kss) + np.tril(Kss, -1).T
+        ops = np_ops.NumpyOps()
+        lp, m, v, c = sdist.dist_posterior_predict(ops, spec, cross, y, None, s2, np.zeros(ns), np.diag(Kss).copy(),
+                                                   Kss if want_cov else None, world=world, rank=rank, W=W)
+        # the FiniteGP-level wrapper builds the same specs and prior moments itself
+        import stheno_jl_amd as P
+        F = P.gppp_sum_model()
+        x = P.BlockData([P.GPPPInput(k, P.ColVecs(np.asfortranarray(u))) for k, u in zip(("f1", "f2", "f3"), xs)])
+        m2, v2, c2 = sdist.dist_posterior(ops, F(x, s2), y, P.GPPPInput("f3", P.ColVecs(Xs)), want_cov=want_cov,
+                                          world=world, rank=rank, W=W)
+        assert np.array_equal(m2, m) and np.array_equal(v2, v) and (c is None or np.array_equal(c2, c))
+        q.put((rank, "ok", (lp, m, v, c), {}, ops.calls))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc(), {}, []))
+
+
+@pytest.mark.parametrize("world,N,ns,W,want_cov", [(2, 700, 37, 128, True), (3, 900, 130, 256, False), (2, 300, 1, 128, True)])
+def test_sharded_posterior_matches_oracle(world, N, ns, W, want_cov):
+    import oracle.abstractgps as oagp
+    import oracle.kernelfunctions as okf
+    import oracle.stheno as ost
+    from oracle import reference_model as orm
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_post_worker, args=(r, world, port, N, ns, W, want_cov, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    spec, cross, kss, xs, y, s2, Xs = _post_problem(N, ns)
+    Fo = orm.gppp_sum()
+    post = oagp.posterior(Fo(orm._blockdata(xs), s2), y)
+    xq = ost.GPPPInput("f3", okf.ColVecs(Xs))
+    m_ref, v_ref = post.mean(xq), post.var(xq)
+    lp_ref = orm.gppp_sum_logpdf(xs, y, s2)
+    lp0, m0, v0, c0 = res[0][2]
+    for r in res[1:]:                                       # the all-reduce leaves the same numbers everywhere
+        assert r[2][0] == lp0 and np.array_equal(r[2][1], m0) and np.array_equal(r[2][2], v0)
+    assert abs(lp0 - lp_ref) <= 1e-10 * abs(lp_ref)
+    assert np.max(np.abs(m0 - m_ref)) <= 1e-9 and np.max(np.abs(v0 - v_ref)) <= 1e-9
+    if want_cov:
+        c_ref = post.cov(xq)
+        assert np.max(np.abs(c0 - c_ref)) <= 1e-9 and np.allclose(np.diag(c0), v0, atol=1e-12)
+    # every rank assembled the cross rows of exactly its own panels
+    for rank, _, _, _, calls in res:
+        assert [c[1] for c in calls if c[0] == "cross"] == [c[1] for c in calls if c[0] == "assemble"]
+
+
 # ---- sparse ELBO sharded over the data points (one all-reduce of the partial sums) --------------------
 def _elbo_problem(N, M, diag_noise):
     import stheno_jl_amd as P

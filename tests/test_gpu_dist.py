@@ -145,6 +145,89 @@ def test_rccl_backend_executes_the_sharded_drivers_collectives():
     assert abs(res[2] - ref) <= 1e-10 * abs(ref)
 
 
+# ---- posterior on the sharded factor (test points as bordered rows) -----------------------------------
+def _post_inputs(ns, D=4):
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(8642)
+    return P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((D, ns)))))
+
+
+def test_sharded_posterior_world1_matches_single_gpu_posterior_and_oracle():
+    import stheno_jl_amd as P
+    import oracle.abstractgps as oagp
+    import oracle.kernelfunctions as okf
+    import oracle.stheno as ost
+    from oracle import reference_model as orm
+    from stheno_jl_amd import dist as sdist
+    for N, ns, W in [(500, 1, 128), (3000, 200, 512), (4500, 129, 1024)]:
+        F, x, xs, y = _problem(N)
+        xq = _post_inputs(ns)
+        fx = F(x, 0.1)
+        m1, v1, c1 = sdist.dist_posterior(sdist.HipOps(), fx, y, xq, want_cov=True, world=1, rank=0, W=W)
+        post = P.posterior(fx, y)
+        m0, v0 = post.mean_and_var(xq)
+        c0 = post.cov(xq)
+        assert np.max(np.abs(m1 - m0)) <= 1e-10 and np.max(np.abs(v1 - v0)) <= 1e-10 and np.max(np.abs(c1 - c0)) <= 1e-10
+        if N <= 3000:
+            po = oagp.posterior(orm.gppp_sum()(orm._blockdata(xs), 0.1), y)
+            xo = ost.GPPPInput("f3", okf.ColVecs(xq.x.X))
+            assert np.max(np.abs(m1 - po.mean(xo))) <= 1e-9 and np.max(np.abs(v1 - po.var(xo))) <= 1e-9
+            assert np.max(np.abs(c1 - po.cov(xo))) <= 1e-9
+
+
+def _post_worker(rank, world, port, N, ns, W, backend, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, HERE)
+        import torch
+        import torch.distributed as dist
+        import __graft_entry__ as entry
+        P = entry.load_package()
+        from stheno_jl_amd import dist as sdist
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        torch.cuda.set_device(0)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        F, x, xs, y = _problem(N)
+        m, v, c = sdist.dist_posterior(sdist.HipOps(P.lib.Context(0)), F(x, 0.1), y, _post_inputs(ns), want_cov=True,
+                                       world=world, rank=rank, W=W, always_collective=True)
+        q.put((rank, "ok", (m, v, c)))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "error", traceback.format_exc()))
+
+
+@pytest.mark.parametrize("world,backend", [(2, "gloo"), (1, "nccl")])
+def test_sharded_posterior_two_ranks_on_one_gpu_and_rccl_world1(world, backend):
+    import torch.multiprocessing as mp
+    import stheno_jl_amd as P
+    N, ns, W = 2600, 150, 256
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_post_worker, args=(r, world, port, N, ns, W, backend, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    F, x, xs, y = _problem(N)
+    post = P.posterior(F(x, 0.1), y)
+    xq = _post_inputs(ns)
+    m0, v0 = post.mean_and_var(xq)
+    c0 = post.cov(xq)
+    for r in res:
+        m, v, c = r[2]
+        assert np.array_equal(m, res[0][2][0]) and np.array_equal(v, res[0][2][1])
+        assert np.max(np.abs(m - m0)) <= 1e-10 and np.max(np.abs(v - v0)) <= 1e-10 and np.max(np.abs(c - c0)) <= 1e-10
+
+
 # ---- sparse ELBO sharded over the data points ----------------------------------------------------------
 def _elbo_problem(N, M, D=3):
     import stheno_jl_amd as P
