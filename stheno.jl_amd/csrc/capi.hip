@@ -111,6 +111,7 @@ void pool_trim(sgp_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   hipStreamSynchronize(ctx->stream2);
   if (ctx->stream2m) hipStreamSynchronize(ctx->stream2m);
+  if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
   std::vector<sgp_pool_block> keep;
   for (auto& b : ctx->pool) {
     if (b.used) {
@@ -192,6 +193,11 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
         SGP_HIP(hipExtStreamCreateWithCUMask(&c->stream2m, 8, mask));
       }
     }
+    SGP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, p2));
+    SGP_HIP(hipEventCreateWithFlags(&c->ev_isolve, hipEventDisableTiming));
+    SGP_HIP(hipEventCreateWithFlags(&c->ev_irest, hipEventDisableTiming));
+    const char* ila_ = getenv("SGP_INNER_LA");
+    if (ila_) c->inner_la = atoi(ila_);
     SGP_HIP(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     SGP_HIP(hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming));
     const char* la = getenv("SGP_LOOKAHEAD");
@@ -234,6 +240,7 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) hipStreamSynchronize(c->stream2);
   if (c->stream2m) hipStreamSynchronize(c->stream2m);
+  if (c->stream3) hipStreamSynchronize(c->stream3);
   for (auto e : c->ev) hipEventDestroy(e);
   for (auto& b : c->pool) hipFree(b.p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -247,6 +254,9 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->ev_rest) hipEventDestroy(c->ev_rest);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream2m) hipStreamDestroy(c->stream2m);
+  if (c->stream3) hipStreamDestroy(c->stream3);
+  if (c->ev_isolve) hipEventDestroy(c->ev_isolve);
+  if (c->ev_irest) hipEventDestroy(c->ev_irest);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -548,6 +558,14 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
   // but every C tile of the panel is read and written once per block column instead of once per
   // (earlier block, block) pair and the products are deep enough for the MFMA kernel to be efficient:
   // the K = 128 updates ran at ~25 TFLOP/s and held ~10 % of an N = 65536 step's chip time.
+  // Inner look-ahead (SGP_INNER_LA=1, off by default): the next diagonal block only needs block column j + 1 updated, so that strip goes first
+  // on the panel stream and the update of everything to its right runs on stream3 while potrf_diag and the row
+  // solve of block column j + 1 are already under way -- the K = 128 product (15 - 80 us) leaves the serial chain.
+  //   ev_isolve: block column j is solved (stream3 may read it)
+  //   ev_irest : stream3's update with block column j is done (it also touched block column j + 2, which the
+  //              panel stream updates next)
+  const bool ila = ctx->inner_la && !ctx->inner_ll && s == ctx->stream && ctx->stream3;
+  bool irest_pending = false;
   for (long j = 0; j < w; j += TILE) {
     double* D = P + j + j * ld;
     double* invd = d_invstore ? d_invstore + (j / TILE) * INVD_STRIDE : ctx->d_invd;
@@ -560,11 +578,28 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
       double* A21 = P + (j + TILE) + j * ld;
       CHECK_RC(solve_rows(ctx, A21, ld, mrest, ctx->d_w, D, ld, invd, 256, 16, s));  // L21 = A21 * L11^-T
       long wrest = w - j - TILE;
-      if (wrest > 0 && !ctx->inner_ll)
-        CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest,
-                                TILE, -1.0, 1.0, 0, 0, 0, s));
+      if (wrest > 0 && !ctx->inner_ll) {
+        if (irest_pending) {
+          SGP_HIP(hipStreamWaitEvent(s, ctx->ev_irest, 0));
+          irest_pending = false;
+        }
+        if (ila && wrest > TILE) {
+          SGP_HIP(hipEventRecord(ctx->ev_isolve, s));
+          CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, TILE, TILE, -1.0, 1.0, 0,
+                                  0, 0, s));
+          SGP_HIP(hipStreamWaitEvent(ctx->stream3, ctx->ev_isolve, 0));
+          CHECK_RC(launch_gemm_nt(A21 + TILE, ld, A21 + TILE, ld, P + (j + 2 * TILE) + (j + 2 * TILE) * ld, ld,
+                                  mrest - TILE, wrest - TILE, TILE, -1.0, 1.0, 0, 0, 0, ctx->stream3));
+          SGP_HIP(hipEventRecord(ctx->ev_irest, ctx->stream3));
+          irest_pending = true;
+        } else {
+          CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, -1.0, 1.0,
+                                  0, 0, 0, s));
+        }
+      }
     }
   }
+  if (irest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_irest, 0));
   return 0;
 }
 

@@ -32,6 +32,11 @@ struct sgp_ctx {
   // every XCD out; while the trailing update runs there, potrf_diag asks for more LDS than a CU shared with an
   // update workgroup has free and so lands on a reserved, otherwise empty CU (potrf.hip).  excl_now: set by the
   // factorisation while its update stream is the masked one.
+  // Inner look-ahead (panel_factor): inside a panel the K = 128 update of everything right of the NEXT block
+  // column runs on stream3 while the panel stream already factors that next block column.
+  hipStream_t stream3 = nullptr;
+  hipEvent_t ev_isolve = nullptr, ev_irest = nullptr;
+  int inner_la = 0;   // measured slower (event hand-offs + potrf_diag sharing CUs with the update): r02_microbench.md
   hipStream_t stream2m = nullptr;
   int reserve_cu = 0;
   long reserve_max_n = 0;
@@ -94,6 +99,7 @@ struct CtxScope {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream2);
     if (ctx->stream2m) hipStreamSynchronize(ctx->stream2m);
+    if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
     tl_ctx = prev;
   }
 };
