@@ -172,11 +172,24 @@ int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, 
  * user's x is the host's job).  Stationary kernels only depend on x - x', so this is
  * sum_j 2 G_ij coef rs_i cs_j kappa'(d2_ij) 2 (x_i - x'_j) over every term that reads input k.
  * Input dimension <= 16.  Matern-1/2 is not differentiable at coincident points: those pairs
- * contribute 0.  Row / column scale vectors (function-scaled processes) are held fixed. */
+ * contribute 0.  Row / column scale vectors (function-scaled processes) are held fixed here: see
+ * sgp_logpdf_grad_xs. */
 int sgp_logpdf_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                       const double* noise, const double* y, double* logpdf_out, double* grad_y,
                       double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
                       double* const* grad_inputs);
+/* Same, plus the gradient w.r.t. the ROW SCALE vectors of function-scaled processes (sigma(x) * f,
+ * /root/reference/src/affine_transformations/product.jl:25-48; on the reference path Zygote differentiates
+ * through sigma.(x)): K_ij = coef rs_i k_ij cs_j, and grad_rowscale[t] (one entry per term, NULL to skip; ignored
+ * for terms without a row scale) receives, for the row_len[I] points of the term's row block,
+ *   2 sum_j G_ij coef k_ij cs_j.
+ * The column scale of a term is the row scale of its mirror term in block pair (J, I), so the gradient of ONE
+ * scale vector is the sum of the grad_rowscale arrays of every term that carries it as row scale (the host
+ * mirror does this by array identity).  grad_inputs may be NULL. */
+int sgp_logpdf_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                       const double* noise, const double* y, double* logpdf_out, double* grad_y,
+                       double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
+                       double* const* grad_inputs, double* const* grad_rowscale);
 
 /* ---- rand(rng, fx, S) (A3; App. A.4): out = mean .+ L * Z, Z = randn(rng, N, S) drawn by
  * the caller's RNG (column-major fill order), so the integer RNG stream stays the caller's. */

@@ -308,7 +308,8 @@ AbstractGPs.mean_and_var(p::MI355XSparsePosterior, xs::AbstractVector) = predict
 #   (∘, f, Stretch(l))   ∂l  = ⟨∂X_out, X_in⟩ (scalar l) ;  ∂X_in = l · ∂X_out
 #   leaf ScaledKernel σ² ∂σ² = Σ d_coef_t · coef_t / σ² ;  leaf ScaleTransform s: ∂s = ⟨∂X_out, X_in⟩
 #   AtomicGP inputs      ∂x  = what is left of ∂X at the leaf
-# Function-valued scales σ(x) and custom warps are treated as constants (as on the device).
+# Function-valued scales σ(x): the device returns d logpdf / d σ.(x) (logpdf_and_gradient_xs below); this rrule,
+# which has no RuleConfig to call back into the AD system, holds them and custom warps fixed.
 using ChainRulesCore
 function logpdf_and_gradient_x(fx::SthenoFGP, y::AbstractVector{<:Real})
     sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
@@ -321,6 +322,30 @@ function logpdf_and_gradient_x(fx::SthenoFGP, y::AbstractVector{<:Real})
          Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Float64}}),
         ctx(), sp.c, m, kind, nz, yd, lp, gy, gm, gn, gc, gs, px))
     return (logpdf = lp[1], y = gy, mean = gm, noise = gn, coef = gc, inscale = gs, inputs = gx, spec = sp)
+end
+
+# Same call with the gradient w.r.t. the row-scale vectors of function-scaled processes σ(x) * f
+# (src/affine_transformations/product.jl:25-48): rowscale[t] = d logpdf / d (r_t)_i for every term whose row
+# carries a scale vector r_t = Π σ_k.(x) (sgp_logpdf_grad_xs); terms sharing one vector add up, and
+# ∂σ_k.(x) = (Σ_t rowscale[t]) .* Π_{l≠k} σ_l.(x).  A pullback that wants ∂θ of σ(x; θ) hands that vector to
+# the AD system's own pullback of `x -> σ.(x)` (`rrule_via_ad(config, x -> σ.(x), x)` under a RuleConfig).
+function logpdf_and_gradient_xs(fx::SthenoFGP, y::AbstractVector{<:Real})
+    sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
+    @assert kind != 2 "dense observation noise has no device gradient"
+    yd = collect(Float64, y); n = length(yd); terms = sp.keep[5]; tptr = sp.keep[6]; nt = max(1, length(terms))
+    lp = zeros(1); gy = zeros(n); gm = zeros(n); gn = zeros(kind == 1 ? n : 1); gc = zeros(nt); gs = zeros(nt)
+    gx = [zeros(size(X)) for X in sp.keep[3]]; px = [pointer(g) for g in gx]
+    rl = [length(v) for (_, v) in blocks_of(fx.f, fx.x)]; nrb = length(rl)          # row_len per block
+    gr = Vector{Vector{Float64}}(undef, length(terms)); pr = fill(Ptr{Float64}(C_NULL), nt)
+    for I in 1:nrb, J in 1:nrb, t in (tptr[(I - 1) * nrb + J] + 1):tptr[(I - 1) * nrb + J + 1]
+        gr[t] = terms[t].row_scale == C_NULL ? Float64[] : zeros(rl[I])
+        isempty(gr[t]) || (pr[t] = pointer(gr[t]))
+    end
+    GC.@preserve sp m nz yd gx px gr pr check(ccall((:sgp_logpdf_grad_xs, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64},
+         Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}),
+        ctx(), sp.c, m, kind, nz, yd, lp, gy, gm, gn, gc, gs, px, pr))
+    return (logpdf = lp[1], y = gy, mean = gm, noise = gn, coef = gc, inscale = gs, inputs = gx, rowscale = gr, spec = sp)
 end
 
 # parameter bookkeeping of one path: the real-scale nodes it passed (with their σ) and the Stretch warps

@@ -1031,7 +1031,7 @@ static int contract_spec(const sgp_dspec* ds, const double* Gm, long ldg, const 
 static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                             const double* noise, const double* y, double* logpdf_out, double* grad_y,
                             double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
-                            double* const* grad_inputs) {
+                            double* const* grad_inputs, double* const* grad_rowscale = nullptr) {
   CHECK_ARG(ctx && spec && noise && y && logpdf_out, "sgp_logpdf_grad: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_logpdf_grad: spec must be symmetric");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
@@ -1089,9 +1089,13 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   // gradient w.r.t. the input points: row-side contraction over every block pair; the spec is
   // symmetric (block (J, I) mirrors (I, J)) and so is G, hence the column side equals the row side of
   // the mirror block and the total is twice the row-side sum
+  // The row-scale vectors of function-scaled processes (K_ij = coef rs_i k_ij cs_j) ride along: the same
+  // row-side sums with k in place of its derivative; the column scale of a term is the row scale of its mirror
+  // term, so "row side x 2" covers both roles as it does for the points.
   std::vector<DevBuf> dgx(grad_inputs ? spec->n_inputs : 0);
-  if (grad_inputs) {
-    for (int k = 0; k < spec->n_inputs; ++k) {
+  std::vector<DevBuf> dgr(grad_rowscale ? nterms_total : 0);
+  if (grad_inputs || grad_rowscale) {
+    for (int k = 0; grad_inputs && k < spec->n_inputs; ++k) {
       size_t cnt = (size_t)std::max<long>(1, (long)ds->in_dim[k] * ds->in_n[k]);
       CHECK_RC(dgx[k].alloc(cnt));
       SGP_HIP(hipMemsetAsync(dgx[k].p, 0, sizeof(double) * cnt, s));
@@ -1102,9 +1106,17 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
         int p = I * ds->ncb + J;
         for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t) {
           int a = ds->term_row_input[t];
+          double* gsv = nullptr;
+          if (grad_rowscale && grad_rowscale[t] && ds->h_terms[t].rs) {
+            CHECK_RC(dgr[t].alloc((size_t)ds->row_len[I]));
+            SGP_HIP(hipMemsetAsync(dgr[t].p, 0, sizeof(double) * ds->row_len[I], s));
+            gsv = dgr[t].p;
+          }
+          if (!grad_inputs && !gsv) continue;
           CHECK_ARG(ds->in_dim[a] <= 16, "input gradients: input dimension > 16 is not supported on device");
           CHECK_RC(launch_grad_inputs(dKinv.p, 1, n_pad, dalpha.p, ds->row_off[I], ds->row_len[I], ds->col_off[J],
-                                      ds->col_len[J], ds->h_terms[t], ds->pair_dmax[p], 2.0, dgx[a].p, s));
+                                      ds->col_len[J], ds->h_terms[t], ds->pair_dmax[p], 2.0,
+                                      grad_inputs ? dgx[a].p : nullptr, s, gsv));
         }
       }
     }
@@ -1136,7 +1148,22 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
       SGP_HIP(hipMemcpy(grad_inputs[k], dgx[k].p, sizeof(double) * in.dim * in.n, hipMemcpyDeviceToHost));
     }
   }
+  if (grad_rowscale) {
+    for (int I = 0; I < ds->nrb; ++I)
+      for (int J = 0; J < ds->ncb; ++J)
+        for (int t = ds->term_ptr[I * ds->ncb + J]; t < ds->term_ptr[I * ds->ncb + J + 1]; ++t)
+          if (dgr[t].p && ds->row_len[I] > 0)
+            SGP_HIP(hipMemcpy(grad_rowscale[t], dgr[t].p, sizeof(double) * ds->row_len[I], hipMemcpyDeviceToHost));
+  }
   return 0;
+}
+
+extern "C" int sgp_logpdf_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                                  const double* noise, const double* y, double* logpdf_out, double* grad_y,
+                                  double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
+                                  double* const* grad_inputs, double* const* grad_rowscale) {
+  return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
+                          grad_coef, grad_inscale, grad_inputs, grad_rowscale);
 }
 
 extern "C" int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,

@@ -161,7 +161,7 @@ int launch_vfe_rowstats(const double* R, long ld, const double* RZ, long ldrz, c
 int launch_vfe_gxz(double* E, long ld, const double* delta, const double* ut, const double* rsig, long nrows,
                    long m, hipStream_t s);
 int launch_grad_inputs(const double* Gm, long sr, long sc, const double* alpha, long r0, long nr, long c0, long nc,
-                       const DevTerm& T, int dmax, double scale, double* gx, hipStream_t s);
+                       const DevTerm& T, int dmax, double scale, double* gx, hipStream_t s, double* gsv = nullptr);
 int launch_diag_grad_inputs(const double* w, long n, const DevTerm& T, double* gxr, double* gxc, hipStream_t s);
 int launch_grad_border(double* A, long ld, long n_pad, long N, const double* y, const double* mean,
                        long nrows, hipStream_t s);

@@ -424,10 +424,21 @@ __device__ __forceinline__ double kern_dd2(int kind, double d2, double param) {
   }
 }
 
-template <int DMAX>
+// kappa(d^2) itself, for the row-scale gradient (the value next to kern_dd2's derivative)
+__device__ __forceinline__ double kern_val(int kind, double d2, double param) {
+  double k, dk;
+  kern_and_dscale(kind, d2, param, k, dk);
+  return k;
+}
+
+// WS: also accumulate the gradient w.r.t. the term's ROW SCALE vector (function-scaled processes,
+// /root/reference/src/affine_transformations/product.jl:25-48):  gsv[i] += scale * sum_j G_ij coef k_ij cs_j
+// (K_ij = coef rs_i k_ij cs_j) -- the per-row sums this kernel forms anyway.  gx may then be NULL.
+template <int DMAX, bool WS>
 __global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long sr, long sc, const double* alpha,
                                                           long r0, long nr, long c0, long nc, DevTerm T,
-                                                          double scale, double* gx /* T.dim x nr, packed */) {
+                                                          double scale, double* gx /* T.dim x nr, packed */,
+                                                          double* gsv /* nr */) {
   // G(i, j) of this launch's (row point i, column point j) lives at Gm[(r0 + i) * sr + (c0 + j) * sc]:
   // (sr, sc) = (1, ld) for the matrix as stored, (ld, 1) to contract its transpose (column-side
   // gradients of a rectangular block: the caller swaps the term's row / column data).
@@ -440,6 +451,7 @@ __global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long
   const bool live = lrow < nr;
   const long grow = r0 + lrow;
   double xr[DMAX], acc[DMAX];
+  double accs = 0.0;
 #pragma unroll
   for (int d = 0; d < DMAX; ++d) {
     xr[d] = (live && d < T.dim) ? T.xr[lrow * T.ldr + d] : 0.0;
@@ -475,6 +487,7 @@ __global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long
         const double w = 2.0 * g * wrow * scs[p] * kern_dd2(T.kind, d2, T.param);
 #pragma unroll
         for (int d = 0; d < DMAX; ++d) acc[d] = fma(w, df[d], acc[d]);
+        if (WS) accs = fma(g * T.coef * scs[p], kern_val(T.kind, d2, T.param), accs);
       }
     }
   }
@@ -483,20 +496,32 @@ __global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long
   if (th == 1) {
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) comb[trow * DMAX + d] = acc[d];
+    if (WS) scs[trow] = accs;   // the column scales are no longer needed
   }
   __syncthreads();
   if (th == 0 && live) {
+    if (gx) {
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d)
-      if (d < T.dim) gx[lrow * T.dim + d] += scale * (acc[d] + comb[trow * DMAX + d]);
+      for (int d = 0; d < DMAX; ++d)
+        if (d < T.dim) gx[lrow * T.dim + d] += scale * (acc[d] + comb[trow * DMAX + d]);
+    }
+    if (WS) gsv[lrow] += scale * (accs + scs[trow]);
   }
 }
 
 int launch_grad_inputs(const double* Gm, long sr, long sc, const double* alpha, long r0, long nr, long c0, long nc,
-                       const DevTerm& T, int dmax, double scale, double* gx, hipStream_t s) {
+                       const DevTerm& T, int dmax, double scale, double* gx, hipStream_t s, double* gsv) {
   if (nr <= 0 || nc <= 0) return 0;
   dim3 grid((unsigned)((nr + TILE - 1) / TILE)), block(256);
-#define SGP_GI(DM) hipLaunchKernelGGL(grad_inputs_kernel<DM>, grid, block, 0, s, Gm, sr, sc, alpha, r0, nr, c0, nc, T, scale, gx)
+#define SGP_GI(DM)                                                                                                    \
+  do {                                                                                                                \
+    if (gsv)                                                                                                          \
+      hipLaunchKernelGGL((grad_inputs_kernel<DM, true>), grid, block, 0, s, Gm, sr, sc, alpha, r0, nr, c0, nc, T, scale, \
+                         gx, gsv);                                                                                    \
+    else                                                                                                              \
+      hipLaunchKernelGGL((grad_inputs_kernel<DM, false>), grid, block, 0, s, Gm, sr, sc, alpha, r0, nr, c0, nc, T,      \
+                         scale, gx, gsv);                                                                             \
+  } while (0)
   if (dmax <= 1) SGP_GI(1);
   else if (dmax <= 2) SGP_GI(2);
   else if (dmax <= 4) SGP_GI(4);

@@ -229,8 +229,41 @@ def logpdf_f32(fx, y):
     return np.float32(out[0])
 
 
-def logpdf_and_gradient(fx, y, inputs=False):
+def _scale_records(spec, grs):
+    """Per-term row-scale gradients -> one record per function scale `sigma * f` and input collection it was
+    mapped over: {node, x, values (= sigma.(x)), d_values (= d logpdf / d values)}.  A path's scale vector is the
+    product of its factors' values; a vector carried by several terms gets the sum of their gradients."""
+    by_vec = {}
+    for t, g in enumerate(grs):
+        if g is None:
+            continue
+        r = spec.term_row_scale[t]
+        if id(r) in by_vec:
+            by_vec[id(r)][1] += g
+        else:
+            by_vec[id(r)] = [r, g.copy()]
+    out, index = [], {}
+    for r, g in by_vec.values():
+        fac = getattr(r, "factors", [])
+        for k, (node, x, vals) in enumerate(fac):
+            others = np.ones(len(vals))
+            for l, (_, _, v) in enumerate(fac):
+                if l != k:
+                    others = others * v
+            key = (id(node), id(x))
+            if key in index:
+                out[index[key]]["d_values"] += g * others
+            else:
+                index[key] = len(out)
+                out.append(dict(node=node, x=x, values=np.asarray(vals, dtype=np.float64).copy(), d_values=g * others))
+    return out
+
+
+def logpdf_and_gradient(fx, y, inputs=False, scales=False):
     """logpdf(fx, y) and its reverse-mode gradient (what Zygote derives on the reference path).
+    scales=True adds `scales`: one record per function-valued scale (`sigma * f`, product.jl:25-48) and input
+    collection it is mapped over, {node, x, values, d_values} with d_values[i] = d logpdf / d sigma(x_i); the
+    gradient of a parameter theta of sigma is sum_i d_values[i] * d sigma(x_i) / d theta.
     inputs=True adds `inputs`: one (dim, n) array per spec input (g["_spec"].inputs[k]) with
     d logpdf / d (the points the terms read -- after Stretch / Select / Periodic; for
     stretch(f, a) the gradient w.r.t. the user's x is a * that array).
@@ -255,7 +288,26 @@ def logpdf_and_gradient(fx, y, inputs=False):
     nt = max(1, spec.n_terms)
     gc, gs = np.zeros(nt), np.zeros(nt)
     gx = None
-    if inputs:
+    grs = None
+    if scales:
+        if inputs:
+            gx = [np.zeros(np.asarray(a).shape, order="F") for a in spec.inputs]
+            ptrs = (C.POINTER(C.c_double) * len(gx))(*[_lib.dptr(a) for a in gx])
+        else:
+            ptrs = None
+        rl = np.asarray(spec.row_len)
+        ncb = len(spec.col_len)
+        grs = [None] * nt
+        for p in range(len(rl) * ncb):
+            for t in range(spec._term_ptr[p], spec._term_ptr[p + 1]):
+                if spec.term_row_scale[t] is not None:
+                    grs[t] = np.zeros(int(rl[p // ncb]))
+        sptrs = (C.POINTER(C.c_double) * nt)(*[_lib.dptr(a) if a is not None else None for a in grs])
+        rc = _ctx().lib.sgp_logpdf_grad_xs(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf),
+                                           _lib.dptr(yv), _lib.dptr(lp), _lib.dptr(gy), _lib.dptr(gm), _lib.dptr(gn),
+                                           _lib.dptr(gc), _lib.dptr(gs), ptrs, sptrs)
+        _lib.check(rc, "sgp_logpdf_grad_xs")
+    elif inputs:
         gx = [np.zeros(np.asarray(a).shape, order="F") for a in spec.inputs]
         ptrs = (C.POINTER(C.c_double) * len(gx))(*[_lib.dptr(a) for a in gx])
         rc = _ctx().lib.sgp_logpdf_grad_x(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf),
@@ -273,7 +325,8 @@ def logpdf_and_gradient(fx, y, inputs=False):
     # the first of them)
     xb = chain_input_gradients(spec, gx)[0] if inputs else None
     return dict(logpdf=float(lp[0]), y=gy, mean=gm, noise=(gn if kind == _lib.NOISE_DIAG else float(gn[0])),
-                terms=terms, inputs=gx, x=xb, _raw=(gc, gs), _spec=spec)
+                terms=terms, inputs=gx, x=xb, scales=(_scale_records(spec, grs) if scales else None),
+                _raw=(gc, gs), _rowscale=grs, _spec=spec)
 
 
 def _draw(rng, n, s):

@@ -38,6 +38,20 @@ class _Path:
         self.key, self.atom, self.c, self.r, self.X, self.chain = key, atom, c, r, X, chain
 
 
+class _ScaleVector(np.ndarray):
+    """The row-scale vector r of a path (a product of sigma.(x) factors) that remembers its factors:
+    `factors` = [(node, x, values)] with node the `sigma * f` process, x the inputs sigma was mapped over and
+    values = sigma.(x) -- what the chain rule of the scale gradients needs (finite_gp.logpdf_and_gradient)."""
+
+    def __new__(cls, values, factors):
+        obj = np.asarray(values, dtype=np.float64).view(cls)
+        obj.factors = list(factors)
+        return obj
+
+    def __array_finalize__(self, obj):
+        self.factors = getattr(obj, "factors", [])
+
+
 class _MatCache:
     """as_matrix with identity caching so equal inputs are uploaded once."""
 
@@ -95,8 +109,9 @@ def _paths(f, x, c, r, key, mat, chain=()):
         s = f.args[1]
         if _gp._is_real(s):
             return _paths(f.args[2], x, c * float(s), r, key, mat, chain)
-        sx = _gp._map_points(s, x)
-        return _paths(f.args[2], x, c, sx if r is None else r * sx, key, mat, chain)
+        sx = np.asarray(_gp._map_points(s, x), dtype=np.float64)
+        fac = ([] if r is None else list(r.factors)) + [(f, x, sx)]
+        return _paths(f.args[2], x, c, _ScaleVector(sx if r is None else np.asarray(r) * sx, fac), key, mat, chain)
     if op == "o":
         return _paths(f.args[1], _gp.warp(f.args[2], x), c, r, key, mat, chain + ((f.args[2], x),))
     if op == "cross":

@@ -77,6 +77,8 @@ _SIGS = {
     "sgp_logpdf_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D]),
     "sgp_logpdf_grad_x": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D,
                                     C.POINTER(_D)]),
+    "sgp_logpdf_grad_xs": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D,
+                                     C.POINTER(_D), C.POINTER(_D)]),
     "sgp_rand": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64, C.c_int64,
                            _D, C.c_int64]),
     "sgp_posterior_create": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D,
@@ -284,6 +286,7 @@ class Spec:
         # with scales (rs, cs) is mirrored in pair (J, I) by the term with (cs, rs)
         self.term_scale_ids = [(None if rs is None else id(rs), None if cs is None else id(cs))
                                for (_, _, _, _, _, rs, cs) in terms]
+        self.term_row_scale = [rs for (_, _, _, _, _, rs, _) in terms]   # the flattener's own vectors (with factors)
         self._keep.extend(terms)
         for k, (kind, ri, ci, coef, param, rs, cs) in enumerate(terms):
             t = self._terms[k]

@@ -303,3 +303,29 @@ def test_float32_inputs_are_tagged_for_the_fp32_path():
     mixed = P.BlockData([P.GPPPInput("f1", P.ColVecs(X32)), P.GPPPInput("f2", P.ColVecs(X32.astype(np.float64)))])
     assert eltype(mixed) == np.float64
     assert eltype(P.BlockData([P.GPPPInput("f1", P.ColVecs(X32)), P.GPPPInput("f2", P.ColVecs(X32))])) == np.float32
+
+
+def test_function_scales_remember_their_factors():
+    """sigma(x) * f: the path's row-scale vector is the product of its factors and names them (node, inputs,
+    values) -- what the chain rule of the scale gradients walks (finite_gp._scale_records)."""
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(4)
+    x1, x2 = rng.standard_normal(11), rng.standard_normal(7)
+    gpc = P.GPC()
+    f1 = P.atomic(P.GP(P.SEKernel()), gpc)
+    s1 = lambda x: 1.0 + 0.5 * float(np.sum(np.sin(x)))
+    s2 = lambda x: float(np.exp(0.1 * np.sum(x)))
+    g1 = s1 * f1
+    h = s2 * g1
+    F = P.GPPP({"f1": f1, "g1": g1, "h": h}, gpc)
+    spec, _, _ = P.build_spec(F, P.BlockData([P.GPPPInput("h", x1), P.GPPPInput("g1", x2)]))
+    vecs = {id(r): r for r in spec.term_row_scale if r is not None}
+    assert len(vecs) == 2
+    for r in vecs.values():
+        prod = np.ones(len(r))
+        for node, x, vals in r.factors:
+            assert node in (g1, h)
+            prod = prod * vals
+        assert np.allclose(np.asarray(r), prod)
+    lens = sorted((len(r), len(r.factors)) for r in vecs.values())
+    assert lens == [(7, 1), (11, 2)]                 # g1 at x2: one factor; h at x1: s2 and the nested s1

@@ -536,6 +536,77 @@ def test_logpdf_gradient_records_with_scale_only_differences():
     assert abs(d_b - fd_b) <= 1e-6 * max(1.0, abs(fd_b)), (d_b, fd_b)
 
 
+def test_logpdf_gradient_wrt_function_scales():
+    """sigma(x) * f (product.jl:25-48): d logpdf / d sigma(x_i) per scale and input collection, (a) per term
+    against a NumPy contraction of the oracle's G, (b) end to end -- two parametrised scales, one of them nested
+    under the other and shared by two blocks -- against central differences of the GPU logpdf."""
+    import np_terms
+    rng = np.random.default_rng(33)
+    x1, x2 = rng.standard_normal(120), rng.standard_normal(75)
+    y = rng.standard_normal(195)
+
+    def fx(th, ph):
+        gpc = P.GPC()
+        f1 = P.atomic(P.GP(P.Matern32Kernel()), gpc)
+        f2 = P.atomic(P.GP(P.SEKernel()), gpc)
+        s1 = lambda x: 1.0 + th * float(np.sum(np.sin(x)))
+        s2 = lambda x: float(np.exp(ph * np.sum(x)))
+        g1 = s1 * f1
+        F = P.GPPP({"f1": f1, "g1": g1, "h": s2 * (g1 + f2)}, gpc)
+        return F(P.BlockData([P.GPPPInput("h", x1), P.GPPPInput("g1", x2)]), 0.3), s1, s2
+
+    th, ph = 0.4, 0.15
+    f, s1, s2 = fx(th, ph)
+    g = P.logpdf_and_gradient(f, y, scales=True)
+    spec, grs = g["_spec"], g["_rowscale"]
+    # (a) per term: 2 sum_j G_ij coef k_ij cs_j
+    from oracle import stheno as ost  # noqa: F401  (oracle side of the same model)
+    K = np_terms.dense_from_spec(spec)
+    K = np.tril(K) + np.tril(K, -1).T
+    C = K + 0.3 * np.eye(195)
+    Ci = np.linalg.inv(C)
+    al = Ci @ y
+    G = 0.5 * (np.outer(al, al) - Ci)
+    roff = np.concatenate([[0], np.cumsum(spec.row_len)])
+    n_scaled = 0
+    for t, (I, J, kind, ri, ci, coef, param, rs, cs) in enumerate(np_terms.spec_terms(spec)):
+        if rs is None:
+            assert grs[t] is None
+            continue
+        n_scaled += 1
+        X, Y = spec.inputs[ri], spec.inputs[ci]
+        d2 = ((X[:, :, None] - Y[:, None, :]) ** 2).sum(0)
+        k = np_terms._kern(kind, d2, param)
+        w = G[roff[I]:roff[I + 1], roff[J]:roff[J + 1]] * coef * k
+        if cs is not None:
+            w = w * cs[None, :]
+        exp = 2.0 * w.sum(1)
+        assert np.max(np.abs(grs[t] - exp)) <= 1e-9 * max(1.0, np.max(np.abs(exp))), t
+    assert n_scaled >= 4
+    # (b) chain rule onto the two parameters
+    d_th = d_ph = 0.0
+    seen = set()
+    for r in g["scales"]:
+        xs = np.asarray(r["x"].x if hasattr(r["x"], "x") else r["x"], dtype=np.float64)
+        vals = r["values"]
+        if np.allclose(vals, 1.0 + th * np.sin(xs)):            # s1 at this block's points
+            d_th += float(r["d_values"] @ np.sin(xs))
+            seen.add("s1")
+        else:                                                   # s2 = exp(ph x): d/dph = x * values
+            assert np.allclose(vals, np.exp(ph * xs))
+            d_ph += float(r["d_values"] @ (xs * vals))
+            seen.add("s2")
+    assert seen == {"s1", "s2"} and len(g["scales"]) == 3       # s1 at x1 and at x2, s2 at x1
+    h = 1e-5
+    fd_th = (P.logpdf(fx(th + h, ph)[0], y) - P.logpdf(fx(th - h, ph)[0], y)) / (2 * h)
+    fd_ph = (P.logpdf(fx(th, ph + h)[0], y) - P.logpdf(fx(th, ph - h)[0], y)) / (2 * h)
+    assert abs(d_th - fd_th) <= 1e-6 * max(1.0, abs(fd_th)), (d_th, fd_th)
+    assert abs(d_ph - fd_ph) <= 1e-6 * max(1.0, abs(fd_ph)), (d_ph, fd_ph)
+    # the plain entry points are unchanged by the request
+    g0 = P.logpdf_and_gradient(f, y)
+    assert g0["logpdf"] == g["logpdf"] and np.array_equal(g0["_raw"][0], g["_raw"][0]) and g0["scales"] is None
+
+
 def _kappa_prime(kind, d2):
     """d kappa / d (d^2) of the stationary kernels (independent restatement for the test)."""
     d = np.sqrt(d2)
