@@ -314,7 +314,7 @@ static int dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out) {
   std::vector<size_t> in_off(sp->n_inputs);
   for (int k = 0; k < sp->n_inputs; ++k) {
     const sgp_input& in = sp->inputs[k];
-    if (in.dim < 1 || in.dim > 64) return fail("spec: input dimension must be in [1, 64]");
+    if (in.dim < 1 || in.dim > (1 << 20)) return fail("spec: input dimension must be >= 1");
     if (in.n < 0 || in.ld < in.dim) return fail("spec: bad input n / ld");
     in_off[k] = place(sizeof(double) * (size_t)(in.dim * in.n));
     ds->in_dim.push_back((int)in.dim);

@@ -158,6 +158,82 @@ __global__ __launch_bounds__(256) void assemble_block_kernel(
 }
 
 // ---------------------------------------------------------------------------------------
+// Any input dimension (the templated kernels stop at 64): ONE term per launch, the squared distances of a
+// thread's row to its 64 columns accumulated in registers while the input dimension is walked in chunks of
+// 16 (column-point chunk in LDS, row-point chunk in registers).  Same direct sum_d (a_d - b_d)^2 as the
+// other kernels (exact zeros on coincident points), 2 fp64 VALU operations per entry and dimension: at D = 256
+// the assembly of an N x N block costs what ~0.4 N^3 / 3 MFMA flops do at N = 16 384 -- no GEMM trick needed
+// to stay below the factorisation.  (KernelFunctions' kernelmatrix [EXT] takes ColVecs of any dimension.)
+// ---------------------------------------------------------------------------------------
+constexpr int BIGD_CHUNK = 16;
+__global__ __launch_bounds__(256) void assemble_bigd_kernel(double* K, long ld, long r0, long nr, long c0, long nc,
+                                                            const DevTerm* terms, int lower_only, int accumulate,
+                                                            int noise_kind, double sigma2, const double* noise_diag,
+                                                            long tile_r_first, long tile_c_first) {
+  const long gtr = tile_r_first + blockIdx.x;
+  const long gtc = tile_c_first + blockIdx.y;
+  if (lower_only && gtr < gtc) return;
+  __shared__ __attribute__((aligned(16))) double sx[TILE * BIGD_CHUNK];
+  const int t = threadIdx.x;
+  const int trow = t & 127, th = t >> 7;
+  long cbeg = gtc * TILE, cend = cbeg + TILE;
+  if (cbeg < c0) cbeg = c0;
+  if (cend > c0 + nc) cend = c0 + nc;
+  long rbeg = gtr * TILE, rend = rbeg + TILE;
+  if (rbeg < r0) rbeg = r0;
+  if (rend > r0 + nr) rend = r0 + nr;
+  if (cbeg >= cend || rbeg >= rend) return;   // uniform over the workgroup
+  const DevTerm T = terms[0];
+  const int D = T.dim;
+  const long grow = gtr * TILE + trow;
+  const bool row_ok = grow >= rbeg && grow < rend;
+  const long lrow = grow - r0;
+  double acc[64];
+#pragma unroll
+  for (int q = 0; q < 64; ++q) acc[q] = 0.0;
+  for (int d0 = 0; d0 < D; d0 += BIGD_CHUNK) {
+    __syncthreads();
+    for (int idx = t; idx < TILE * BIGD_CHUNK; idx += 256) {
+      const int p = idx / BIGD_CHUNK, d = idx % BIGD_CHUNK;
+      const long gc = gtc * TILE + p;
+      sx[idx] = (d0 + d < D && gc >= cbeg && gc < cend) ? T.xc[(gc - c0) * T.ldc + d0 + d] : 0.0;
+    }
+    __syncthreads();
+    if (row_ok) {
+      double xi[BIGD_CHUNK];
+      const double* xr = T.xr + lrow * T.ldr + d0;
+#pragma unroll
+      for (int d = 0; d < BIGD_CHUNK; ++d) xi[d] = (d0 + d < D) ? xr[d] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 64; ++q) {
+        const double* sp = &sx[(th * 64 + q) * BIGD_CHUNK];
+        double s = 0.0;
+#pragma unroll
+        for (int d = 0; d < BIGD_CHUNK; ++d) {
+          const double df = xi[d] - sp[d];
+          s = fma(df, df, s);
+        }
+        acc[q] += s;
+      }
+    }
+  }
+  if (!row_ok) return;
+  const double rsv = T.coef * (T.rs ? T.rs[lrow] : 1.0);
+  double nval = 0.0;
+  if (noise_kind >= 0) nval = (noise_kind == 0) ? sigma2 : noise_diag[grow];
+#pragma unroll
+  for (int q = 0; q < 64; ++q) {
+    const long gc = gtc * TILE + th * 64 + q;
+    if (gc < cbeg || gc >= cend) continue;
+    double v = kern_eval(T.kind, acc[q], T.param) * rsv * (T.cs ? T.cs[gc - c0] : 1.0);
+    if (noise_kind >= 0 && gc == grow) v += nval;
+    double* p = K + grow + gc * ld;
+    if (accumulate) v += *p;
+    *p = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Two-rows-per-thread variant (input dimension <= 16): thread (lane, wave) owns rows 2 lane, 2 lane + 1
 // of the tile and the 32 columns of quarter `wave`, so
 //   * every store is 16 bytes per lane: one wave instruction writes 128 consecutive rows of a column
@@ -368,8 +444,15 @@ int launch_assemble_block(double* K, long ld, long r0, long nr, long c0, long nc
   if (dmax <= 32) SGP_ASM(32);
   if (dmax <= 64) SGP_ASM(64);
 #undef SGP_ASM
-  set_error("assemble: input dimension > 64 is not supported on device");
-  return -1;
+  if (nterms != 1) {
+    set_error("assemble: input dimension > 64 takes one term per launch");
+    return -1;
+  }
+  hipLaunchKernelGGL(assemble_bigd_kernel, dim3((unsigned)tile_r_cnt, (unsigned)tile_c_cnt), dim3(256), 0, s, K, ld, r0,
+                     nr, c0, nc, d_terms, lower_only, accumulate, noise_kind, sigma2, d_noise_diag, tile_r_first,
+                     tile_c_first);
+  SGP_HIP(hipGetLastError());
+  return 0;
 }
 
 // identity padding: rows/cols in [N, n_pad) of the square part get delta(r, c); everything in a

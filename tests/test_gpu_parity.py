@@ -89,6 +89,35 @@ def test_cov_colvecs(recipe, D):
     assert np.abs(Kp - Ko).max() < 2e-12 * max(1.0, np.abs(Ko).max())
 
 
+@pytest.mark.parametrize("D", [33, 64, 65, 100, 257])
+def test_cov_and_logpdf_high_dimensional_inputs(D):
+    """ColVecs of any dimension (KernelFunctions.kernelmatrix [EXT] has no limit): D <= 64 runs on the templated
+    one-row kernel, D > 64 on assemble_bigd_kernel (dimension walked in chunks of 16); several terms per block
+    pair accumulate launch by launch.  Inputs scaled by 1 / sqrt(D) so that distances stay O(1)."""
+    import np_terms
+    rng = np.random.default_rng(500 + D)
+    Fo, Fp, fo, fp = both(models.correlated_sums)
+    names = list(fo)[:3]
+    xs = [np.asfortranarray(rng.standard_normal((D, n)) / np.sqrt(D)) for n in (140, 1, 203)][:len(names)]
+    xo, xp = blockdata(names, xs, True)
+    Ko, Kp = Fo.cov(xo), P.prior_cov(Fp, xp)
+    assert np.abs(Kp - Ko).max() < 1e-11 * max(1.0, np.abs(Ko).max())
+    spec, _, _ = P.build_spec(Fp, xp)
+    Kd = np_terms.dense_from_spec(spec)                      # direct differences, like the device
+    Kd = np.tril(Kd) + np.tril(Kd, -1).T
+    assert np.abs(Kp - Kd).max() < 2e-13 * max(1.0, np.abs(Kd).max())
+    assert np.array_equal(P.prior_var(Fp, xp), np.diag(Kp))
+    N = sum(x.shape[1] for x in xs)
+    y = rng.standard_normal(N)
+    lo, lp = oagp.logpdf(Fo(xo, 0.2), y), P.logpdf(Fp(xp, 0.2), y)
+    assert abs(lp - lo) <= REL * abs(lo)
+    # cross-covariance and the posterior path use the same assembly
+    xq = [np.asfortranarray(rng.standard_normal((D, 37)) / np.sqrt(D))]
+    xqo, xqp = blockdata(names[:1], xq, True)
+    po, pp = oagp.posterior(Fo(xo, 0.2), y), P.posterior(Fp(xp, 0.2), y)
+    assert rel(pp.mean(xqp), po.mean(xqo)) < 1e-9 and np.max(np.abs(pp.var(xqp) - po.var(xqo))) < 1e-9
+
+
 @pytest.mark.parametrize("D", [12, 16])
 def test_cov_many_terms_per_block_pair_accumulate_path(D):
     """More terms per block pair than one assembly launch can stage in LDS (D = 16: one term per launch): the

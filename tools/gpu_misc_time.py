@@ -32,3 +32,9 @@ Xs = P.ColVecs(rng.standard_normal((D, Ns)) / np.sqrt(D))
 y = rng.standard_normal(N)
 post = timed(f"posterior(VFE) N={N} M={M}", lambda: P.posterior(P.VFE(f(Z, 1e-6)), f(X, 0.1), y))
 timed(f"sparse mean_and_var Ns={Ns}", lambda: P.mean_and_var(post(Xs, 0.0)))
+# input dimension beyond the templated kernels (assemble_bigd_kernel): logpdf at N = 16384 for D = 8 / 64 / 256 --
+# the difference to D = 8 is what the assembly costs
+for Dh in (8, 64, 256):
+    Xh = P.ColVecs(rng.standard_normal((Dh, 16384)) / np.sqrt(Dh))
+    yh = rng.standard_normal(16384)
+    timed(f"logpdf N=16384 D={Dh}", lambda: P.logpdf(f(Xh, 0.1), yh))
