@@ -26,7 +26,6 @@ using namespace sgp;
 namespace {
 
 typedef float f16v __attribute__((ext_vector_type(16)));
-constexpr int KBF = 16;          // K chunk of the fp32 GEMM
 constexpr int LDF = 128 + 4;     // LDS leading dimension (floats) of a 128-row operand chunk
 
 enum { K_SE = 0, K_M12 = 1, K_M32 = 2, K_M52 = 3, K_WHITE = 4, K_CONST = 5 };
@@ -142,8 +141,9 @@ __global__ void border_f32_kernel(float* A, long ld, long n_pad, long N, const d
 // computed TRANSPOSED (Aop = rows of B, Bop = rows of A), so j = l & 31 runs along the contiguous row index
 // of C: one store instruction writes 32 consecutive rows of two columns.
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* A, long lda, const float* B, long ldb, float* C,
-                                                          long ldc, long K, int lower, long n_tr, long n_tc) {
+template <int KBF, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_nt_f32_kernel(const float* A, long lda, const float* B, long ldb, float* C,
+                                                            long ldc, long K, int lower, long n_tr, long n_tc) {
   long tr, tc;
   if (lower) {   // 1-D grid over the live tiles only: the lower triangle of the n_tc x n_tc square, then full rows
     const long id = blockIdx.x, tri = n_tc * (n_tc + 1) / 2;
@@ -177,17 +177,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_f32_kernel(const float* A, lon
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  float4 ra[2], rb[2];
+  constexpr int NU = KBF / 8;   // staging units per thread and operand
+  float4 ra[NU], rb[NU];
   auto gload = [&](long k0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NU; ++i) {
       ra[i] = *reinterpret_cast<const float4*>(Ag + srow + (k0 + scol + 8 * i) * lda);
       rb[i] = *reinterpret_cast<const float4*>(Bg + srow + (k0 + scol + 8 * i) * ldb);
     }
   };
   auto sstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NU; ++i) {
       *reinterpret_cast<float4*>(&sA[buf][(scol + 8 * i) * LDF + srow]) = ra[i];
       *reinterpret_cast<float4*>(&sB[buf][(scol + 8 * i) * LDF + srow]) = rb[i];
     }
@@ -239,7 +240,9 @@ int launch_gemm_f32(const float* A, long lda, const float* B, long ldb, float* C
   const long n_tr = M / TILE, n_tc = Nc / TILE;
   dim3 grid((unsigned)n_tr, (unsigned)n_tc);
   if (lower) grid = dim3((unsigned)(n_tc * (n_tc + 1) / 2 + (n_tr - n_tc) * n_tc));   // (M >= Nc for every lower update)
-  hipLaunchKernelGGL(gemm_nt_f32_kernel, grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, lower, n_tr, n_tc);
+  // (KBF = 32 and launch bounds asking for 3 - 4 workgroups per CU measured no better: 1244 / 1068 / 1070 ms vs
+  // 1069 ms at N = 65536 -- gpurun_out/f32_gemm_ab.txt)
+  hipLaunchKernelGGL((gemm_nt_f32_kernel<16, 2>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, lower, n_tr, n_tc);
   SGP_HIP(hipGetLastError());
   return 0;
 }
