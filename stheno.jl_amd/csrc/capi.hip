@@ -202,6 +202,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     SGP_HIP(hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming));
     const char* la = getenv("SGP_LOOKAHEAD");
     if (la) c->lookahead = atoi(la);
+    const char* em = getenv("SGP_EXCL_MAX");
+    if (em) c->excl_max = atol(em);
     const char* lm = getenv("SGP_LA_MIN");
     if (lm) c->la_min = atol(lm);
     const char* wo = getenv("SGP_WOUT");
@@ -670,6 +672,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   }
   for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
     long wj = std::min(WOUT, n_pad - J0);
+    if (la && !reserve && ctx->excl_max > 0) ctx->excl_now = (n_pad - J0) <= ctx->excl_max ? 1 : 0;
     const long m_eff = grow > 0 ? std::min(m_tot, grow + J0 + wj) : m_tot;  // rows this panel touches
     CHECK_RC(panel_factor(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
                           ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s));

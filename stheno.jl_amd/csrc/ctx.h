@@ -41,6 +41,8 @@ struct sgp_ctx {
   int reserve_cu = 0;
   long reserve_max_n = 0;
   int excl_now = 0;
+  long excl_max = 0;   // SGP_EXCL_MAX: potrf_diag waits for a CU without update workgroups while <= this many
+                       // trailing columns remain (no CU mask: such CUs only appear in an update's tail)
   hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
   int lookahead = 1;
   long la_min = 0;   // look-ahead only while more than la_min columns of the trailing matrix remain (capi.hip)
