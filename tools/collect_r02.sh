@@ -38,7 +38,8 @@ timeout 200 python $R/tools/gpu_illcond.py > $OUT/illcond.log 2>&1
 timeout 400 python $R/tools/gpu_multi_time.py c2 c5 > $OUT/multi_time.log 2>&1
 timeout 100 python $R/tools/gpu_potrf_phases.py > $OUT/potrf_phases.log 2>&1
 timeout 100 python $R/tools/gpu_potrf_contend.py > $OUT/potrf_contend.log 2>&1
-timeout 300 python $R/tools/gpu_f32_time.py 4096 16384 32768 65536 > $OUT/f32_time.log 2>&1
+timeout 300 python $R/tools/gpu_f32_time.py 2048 4096 16384 32768 65536 > $OUT/f32_time.log 2>&1
+timeout 200 python $R/tools/gpu_bign.py 98304 2>&1 | grep "N=" > $OUT/bign.log
 timeout 300 python $R/bench.py --config c5 --dtype f32 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_f32.json 2> $OUT/bench_c5_f32.err
 rm -f $OUT/*/*/*kernel_trace.csv $OUT/*/*kernel_trace.csv
 head -c 300 $OUT/bench_c5.json; echo; tail -3 $OUT/multi_time.log

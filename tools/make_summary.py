@@ -206,6 +206,8 @@ def main():
               ("gemm_sizes.log", "Isolated trailing-update launches by size and depth (`tools/gpu_gemm_sizes.py`)"),
               ("multi_time.log", "In-process multi-rank context on the one GPU (`tools/gpu_multi_time.py`)"),
               ("potrf_phases.log", "`potrf_diag_kernel` phase by phase (s_memtime ticks of wave 0, `tools/gpu_potrf_phases.py`)"),
+              ("potrf_contend.log", "`potrf_diag_kernel` while trailing updates run on the other stream (`tools/gpu_potrf_contend.py`)"),
+              ("bign.log", "Beyond the BASELINE sizes (`tools/gpu_bign.py`)"),
               ("f32_time.log", "fp32 instantiation against the fp64 path (`tools/gpu_f32_time.py`; host API incl. uploads)"),
               ("grad_time.log", "Reverse-mode gradients (`tools/gpu_grad_time.py`; host API incl. uploads)"),
               ("predict_time.log", "Prediction side (`tools/gpu_predict_time.py`)"),
