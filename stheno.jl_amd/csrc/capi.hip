@@ -214,6 +214,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (wm) c->wmid = atol(wm) / TILE * TILE;
     const char* il = getenv("SGP_INNER_LL");
     if (il) c->inner_ll = atoi(il);
+    const char* fp = getenv("SGP_FUSE_POTRF");
+    if (fp) c->fuse_potrf = atoi(fp);
     const char* po = getenv("SGP_POOL");
     if (po) c->pool_enabled = atoi(po);
     SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
@@ -531,8 +533,10 @@ static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double
 // P: m x w, top w x w block is the diagonal block.  d_invstore: optional array that keeps the
 // eight 16x16 inverse diagonal blocks of every 128-block (INVD_STRIDE doubles per block, the
 // layout potrf_diag writes) for later solves against the factor; else ctx scratch.
+// first_done: the panel's first diagonal block is already factored -- the trailing update that produced it had
+// potrf_diag fused into the workgroup of that tile (ctx->fuse_potrf, gemm_nt.hip: gemm_nt_dma_potrf_kernel).
 static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_slots,
-                        int* d_info, double* d_invstore, hipStream_t s) {
+                        int* d_info, double* d_invstore, hipStream_t s, bool first_done = false) {
   // ctx->wmid (multiple of 128, < w): one more blocking level -- the panel is factored in sub-panels of
   // wmid columns (128-column steps inside), each followed by ONE K = wmid update of the rest of the
   // panel, so that only wmid / w of the in-panel flops run as shallow K = 128 products.
@@ -567,13 +571,19 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
   //   ev_irest : stream3's update with block column j is done (it also touched block column j + 2, which the
   //              panel stream updates next)
   const bool ila = ctx->inner_la && !ctx->inner_ll && s == ctx->stream && ctx->stream3;
+  // Fused inner updates (SGP_FUSE_POTRF bit 0): the K = 128 update with block column j also factors the diagonal
+  // block of block column j + 1 in the workgroup that updates it, so the 128-pivot chain runs under the rest of
+  // the update instead of after it and one launch per block column disappears.
+  const bool fuse = (ctx->fuse_potrf & 1) && ctx->refine == 1 && !ctx->inner_ll && !ila;
+  bool diag_done = first_done;
   bool irest_pending = false;
   for (long j = 0; j < w; j += TILE) {
     double* D = P + j + j * ld;
     double* invd = d_invstore ? d_invstore + (j / TILE) * INVD_STRIDE : ctx->d_invd;
     if (ctx->inner_ll && j > 0)
       CHECK_RC(launch_gemm_nt(P + j, ld, P + j, ld, D, ld, m - j, TILE, j, -1.0, 1.0, 0, 0, 0, s));
-    CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s, ctx->excl_now));
+    if (!diag_done) CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s, ctx->excl_now));
+    diag_done = false;
     long mrest = m - j - TILE;
     if (mrest > 0 && ctx->refine != 1) CHECK_RC(launch_trtri(D, ld, invd, ctx->d_w, s));  // A/B modes only
     if (mrest > 0) {
@@ -594,6 +604,14 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
                                   mrest - TILE, wrest - TILE, TILE, -1.0, 1.0, 0, 0, 0, ctx->stream3));
           SGP_HIP(hipEventRecord(ctx->ev_irest, ctx->stream3));
           irest_pending = true;
+        } else if (fuse) {
+          // the scratch inverse blocks (no d_invstore) are free again: the row solve that read block column j's
+          // ran before this launch on the same stream
+          double* invn = d_invstore ? d_invstore + (j / TILE + 1) * INVD_STRIDE : ctx->d_invd;
+          CHECK_RC(launch_gemm_nt_potrf(A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, 0,
+                                        (ctx->fuse_potrf & 8) ? 1 : 0, invn, d_slots + j / TILE + 1, d_info,
+                                        g0 + j + TILE, s));
+          diag_done = true;
         } else {
           CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, -1.0, 1.0,
                                   0, 0, 0, s));
@@ -613,8 +631,21 @@ static double update_flops(long m, long nc, long k) {
 }
 
 // timed (optional) trailing-update launch
+struct FusedDiag {   // the diagonal block a fused trailing update factors: tile (0, 0) of its C
+  double* invd;
+  double* slot;
+  int* info;
+  long gcol0;
+  int handoff;   // accumulators -> potrf_diag's LDS layout directly (SGP_FUSE_POTRF bit 3)
+};
+static int launch_update_kernel(const double* P, long ld, double* C, long M, long Nc, long K, hipStream_t s,
+                                const FusedDiag* fz) {
+  if (fz)
+    return launch_gemm_nt_potrf(P, ld, C, ld, M, Nc, K, 1, fz->handoff, fz->invd, fz->slot, fz->info, fz->gcol0, s);
+  return launch_gemm_nt_update(P, ld, C, ld, M, Nc, K, s);
+}
 static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long M, long Nc, long K,
-                         hipStream_t s) {
+                         hipStream_t s, const FusedDiag* fz = nullptr) {
   if (M <= 0 || Nc <= 0) return 0;
   if (ctx->time_updates) {
     // the context owns both events from the moment they exist (destroyed with the next timed call or the
@@ -631,11 +662,11 @@ static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long
     ctx->ev.push_back(e1);
     ctx->ev_flops.push_back(update_flops(M, Nc, K));
     SGP_HIP(hipEventRecord(e0, s));
-    CHECK_RC(launch_gemm_nt_update(P, ld, C, ld, M, Nc, K, s));
+    CHECK_RC(launch_update_kernel(P, ld, C, M, Nc, K, s, fz));
     SGP_HIP(hipEventRecord(e1, s));
     return 0;
   }
-  return launch_gemm_nt_update(P, ld, C, ld, M, Nc, K, s);
+  return launch_update_kernel(P, ld, C, M, Nc, K, s, fz);
 }
 
 // Two-level right-looking Cholesky of the bordered matrix with one-panel look-ahead:
@@ -664,6 +695,14 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
     ExclScope(sgp_ctx* c_, int v) : c(c_) { c->excl_now = v; }
     ~ExclScope() { c->excl_now = 0; }
   } excl_scope(ctx, reserve && ctx->reserve_cu > 0 ? 1 : 0);
+  // SGP_FUSE_POTRF bit 1: the trailing update that finishes the next panel's first diagonal block (the look-ahead
+  // column update, or the whole update when the look-ahead is off) factors that block in the same launch
+  // (bit 1: while n_pad < 32768, where the panel chain is the critical path; from there on the panel stream has slack
+  // and the trailing updates -- the launches bench.py's roofline line is about -- stay one kernel symbol; bit 2: at
+  // every size.)
+  const bool fuse_outer = (((ctx->fuse_potrf & 2) && n_pad < 32768) || (ctx->fuse_potrf & 4)) && ctx->refine == 1 &&
+                          !ctx->inner_ll && !(ctx->wmid >= TILE && ctx->wmid < WOUT);
+  bool first_done = false;
   bool rest_pending = false;
   if (la) {
     // the update stream must see everything enqueued on s so far (assembly)
@@ -675,9 +714,13 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
     if (la && !reserve && ctx->excl_max > 0) ctx->excl_now = (n_pad - J0) <= ctx->excl_max ? 1 : 0;
     const long m_eff = grow > 0 ? std::min(m_tot, grow + J0 + wj) : m_tot;  // rows this panel touches
     CHECK_RC(panel_factor(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
-                          ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s));
+                          ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done));
     long c0 = J0 + wj;
     if (c0 >= n_pad) break;
+    const FusedDiag fz_next = {d_wall ? d_wall + (c0 / TILE) * INVD_STRIDE : ctx->d_invd, ctx->d_slots + c0 / TILE,
+                               ctx->d_info, c0, (ctx->fuse_potrf & 8) ? 1 : 0};
+    const FusedDiag* fz = fuse_outer ? &fz_next : nullptr;
+    first_done = fuse_outer;
     long w1 = std::min(WOUT, n_pad - c0);   // width of the next panel
     long c1 = c0 + w1;
     // The look-ahead only pays while the trailing update outlasts the panel chain it hides: sharing CUs with
@@ -689,7 +732,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       SGP_HIP(hipEventRecord(ctx->ev_panel, s));
       // look-ahead: next panel's columns on the panel stream (after the previous rest update)
       if (rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
-      CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_eff - c0, w1, wj, s));
+      CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_eff - c0, w1, wj, s, fz));
       if (c1 < n_pad) {
         SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
         CHECK_RC(launch_update(ctx, A + c1 + J0 * ld, ld, A + c1 + c1 * ld, m_eff - c1, n_pad - c1,
@@ -702,7 +745,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
         SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
         rest_pending = false;
       }
-      CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_eff - c0, n_pad - c0, wj, s));
+      CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_eff - c0, n_pad - c0, wj, s, fz));
     }
   }
   if (la && rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));

@@ -135,6 +135,10 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
                    long M, long Nc, long K, double alpha, double beta, long mask_off,
                    int kcap_mode, long kcap_off, hipStream_t s);
 int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, hipStream_t s);
+// the same lower update with potrf_diag of tile (0, 0) -- the next diagonal block -- fused into its workgroup
+int launch_gemm_nt_potrf(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, int outer,
+                         int handoff, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
+                         hipStream_t s);
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,
                        double* C, long ldc, long M, long Nc, long K, double alpha, double beta,
                        hipStream_t s);

@@ -34,6 +34,7 @@
 // and at any position in the grid all 8 XCDs see (almost) the same mask.  Inside an XCD the order is 8 owned rows x 8 tile columns, row fastest: 64
 // consecutive workgroups form a patch sharing 8 A panels and 8 B panels in that XCD's L2.
 #include "common.h"
+#include "potrf_diag.h"
 
 namespace sgp {
 
@@ -118,15 +119,18 @@ __device__ __forceinline__ bool tile_of_block(long n_tr, long n_tc, long mask_of
 // TAG only changes the symbol: <1> = the outer trailing updates of the blocked Cholesky (the launches
 // bench.py times and the roofline line is about), <0> = every other use (inner K = 128 updates,
 // solves' updates, Gram / inverse / L Z products), so that rocprofv3 --stats lists them apart.
-template <int TAG>
-__global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, long lda,
-                                                             const double* B, long ldb, double* C,
-                                                             long ldc, long K, double alpha,
-                                                             double beta, long mask_off, long n_tr,
-                                                             long n_tc, long c_slice_stride,
-                                                             const double* Cin, long ldcin, int klo) {
+// The tile program itself (one workgroup = one 128 x 128 tile of C), shared by the plain kernel and the fused
+// update + next-diagonal-block kernel below.  smem: 2 stages x (A chunk + B chunk) = 73 728 bytes of LDS.
+// Returns false for a workgroup without a tile; tr / tc = the tile it computed.
+// HANDOFF: the workgroup of tile (0, 0) does not store its result but scatters it into LDS in potrf_diag_body's
+// packed-block layout (lower 16x16 blocks, strictly upper entries of the diagonal blocks zeroed -- exactly what
+// that routine's own load phase would have produced from the stored tile).
+template <bool HANDOFF>
+__device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, const double* B, long ldb, double* C,
+                                                 long ldc, long K, double alpha, double beta, long mask_off,
+                                                 long n_tr, long n_tc, long c_slice_stride, const double* Cin,
+                                                 long ldcin, int klo, double* smem, long& tr, long& tc) {
   constexpr int NJ = 8, WCOLS = 32;
-  long tr, tc;
   if (klo == 3) {
     // Gram product split over K by XCD: workgroup id % 8 is the XCD the hardware puts it on, and that is
     // the K slice it contracts, so each XCD's L2 only ever holds its own slice of the operands (all
@@ -137,12 +141,12 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
     while (tr * (tr + 1) / 2 > k) --tr;
     while ((tr + 1) * (tr + 2) / 2 <= k) ++tr;
     tc = k - tr * (tr + 1) / 2;
-    if (tr >= n_tr) return;
+    if (tr >= n_tr) return false;
     A += sl * K * lda;
     B += sl * K * ldb;
     C += sl * c_slice_stride;
   } else {
-    if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return;
+    if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return false;
     // split-K (blockIdx.y > 0 only in launch_gemm_nt_splitk): slice s contracts columns
     // [s K, (s + 1) K) of A and B into its own slab of C
     A += (long)blockIdx.y * K * lda;
@@ -150,7 +154,6 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
     C += (long)blockIdx.y * c_slice_stride;
   }
   // stage s: A chunk at smem + s*2*KB*LDS_LD, B chunk right after it
-  __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w = t >> 6;
@@ -300,10 +303,69 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  if (HANDOFF && tr == 0 && tc == 0) {
+    // the loop's closing barrier: every wave is done reading the operand stages this overwrites.
+    // acc[j][i] is C[row = 64 wr + 16 i + l15][col = 32 wc + 4 j + lq]: block row 4 wr + i, block column
+    // 2 wc + (j >> 2), element [m = l15][k = 4 (j & 3) + lq] at [k * 16 + m] -- 64 consecutive doubles per store
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rb = 4 * wr + i, cb = 2 * wc + (j >> 2);
+        const int k = 4 * (j & 3) + lq;
+        if (rb >= cb) smem[boff(rb, cb) + k * 16 + l15] = (rb > cb || l15 >= k) ? alpha * acc[j][i] : 0.0;
+      }
+    return true;
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = alpha * acc[j][i];
+  return true;
+}
+
+template <int TAG>
+__global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, long lda,
+                                                             const double* B, long ldb, double* C,
+                                                             long ldc, long K, double alpha,
+                                                             double beta, long mask_off, long n_tr,
+                                                             long n_tc, long c_slice_stride,
+                                                             const double* Cin, long ldcin, int klo) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
+  long tr, tc;
+  gemm_nt_dma_tile<false>(A, lda, B, ldb, C, ldc, K, alpha, beta, mask_off, n_tr, n_tc, c_slice_stride, Cin, ldcin,
+                          klo, smem, tr, tc);
+}
+
+// Fused lower update + Cholesky of the NEXT diagonal block (SGP_FUSE_POTRF, capi.hip: panel_factor /
+// chol_bordered): tile (0, 0) of every trailing update C[lower] -= P P' is the diagonal block the factorisation
+// needs next.  Its workgroup -- the first one dispatched -- goes straight from the store of the updated tile
+// into potrf_diag_body on it, while the other workgroups of the launch are still updating their tiles: the
+// 128-pivot chain of block column j + 1 runs under the update with block column j instead of after it, with no
+// extra launch, stream or event (the cross-stream version of this overlap, SGP_INNER_LA, lost more on its two
+// event hand-offs per block than it hid).  Dynamic LDS: PD_LDS bytes (>= the tile program's 73 728), so two
+// workgroups still fit a CU.
+// HANDOFF = false: the tile goes through global memory (stored by the tile program, re-read by potrf_diag_body's
+// own load phase); true: straight from the accumulators into potrf_diag_body's LDS layout (no store, no fence, no
+// reload: ~4 us less on the serial chain).
+template <int TAG, bool HANDOFF>
+__global__ __launch_bounds__(512, 4) void gemm_nt_dma_potrf_kernel(const double* A, long lda, const double* B,
+                                                                   long ldb, double* C, long ldc, long K,
+                                                                   long n_tr, long n_tc, double* invd,
+                                                                   double* logdet_slot, int* info, long gcol0,
+                                                                   int prio) {
+  extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+  long tr, tc;
+  const bool live = gemm_nt_dma_tile<HANDOFF>(A, lda, B, ldb, C, ldc, K, -1.0, 1.0, 0L, n_tr, n_tc, 0L, C, ldc, 0,
+                                              dyn_smem, tr, tc);
+  if (live && tr == 0 && tc == 0) {   // workgroup-uniform
+    if (!HANDOFF) {
+      // the tile was written by all eight waves: stores complete + visible to the workgroup before it is re-read
+      __threadfence_block();
+    }
+    __syncthreads();
+    potrf_diag_body<false, double, HANDOFF>(C, ldc, invd, logdet_slot, info, gcol0, prio, nullptr);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -446,6 +508,38 @@ int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M
                      -1.0, 1.0, 0L, n_tr, n_tc, 0L, (const double*)C, ldc, 0);
   SGP_HIP(hipGetLastError());
   return 0;
+}
+
+// C[lower] -= P P' (as launch_gemm_nt_update / the inner K = 128 updates) with the Cholesky of tile (0, 0) -- the
+// next diagonal block -- fused into the workgroup that updates it.  outer != 0: the <1> symbol (the launches
+// bench.py times as trailing updates), else <0>.
+template <int TAG, bool HANDOFF>
+static int launch_potrf_variant(unsigned grid, const double* P, long ldp, double* C, long ldc, long K, long n_tr,
+                                long n_tc, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
+                                hipStream_t s) {
+  SGP_LDS_ATTR_ONCE((gemm_nt_dma_potrf_kernel<TAG, HANDOFF>), PD_LDS);
+  hipLaunchKernelGGL((gemm_nt_dma_potrf_kernel<TAG, HANDOFF>), dim3(grid), dim3(512), PD_LDS, s, P, ldp, P, ldp, C, ldc,
+                     K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, panel_prio());
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_gemm_nt_potrf(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, int outer,
+                         int handoff, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
+                         hipStream_t s) {
+  if (M <= 0 || Nc <= 0) return 0;
+  if (M % TILE || Nc % TILE || K % KB) {
+    set_error("gemm_nt_potrf: M, Nc must be multiples of 128 and K of 16");
+    return -1;
+  }
+  long n_tr = M / TILE, n_tc = Nc / TILE;
+  long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc));
+  const unsigned grid = (unsigned)(per_xcd * 8);
+  if (outer)
+    return handoff ? launch_potrf_variant<1, true>(grid, P, ldp, C, ldc, K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, s)
+                   : launch_potrf_variant<1, false>(grid, P, ldp, C, ldc, K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, s);
+  return handoff ? launch_potrf_variant<0, true>(grid, P, ldp, C, ldc, K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, s)
+                 : launch_potrf_variant<0, false>(grid, P, ldp, C, ldc, K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, s);
 }
 
 // C_out = alpha A B' + beta C_in with C_in a different matrix than C_out (full rectangle).  C_out may
