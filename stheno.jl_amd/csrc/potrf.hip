@@ -194,9 +194,16 @@ int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl
     return -1;
   }
   SGP_LDS_ATTR_ONCE(panel_solve_kernel, PS_LDS);
-  // one strip per workgroup until the chip is full (256 CUs), then fatter workgroups
+  // one strip per workgroup until the chip is full (256 CUs), then fatter workgroups.  SGP_PS_DIV=<n> (A/B knob):
+  // aim at n workgroups instead of 256 -- under the look-ahead overlap the launch waits for one CU slot per
+  // workgroup, so fewer, fatter workgroups trade slot waits against serial strips.
+  static const long div = [] {
+    const char* e = getenv("SGP_PS_DIV");
+    long v = e ? atol(e) : 256;
+    return v >= 1 ? v : 256;
+  }();
   long nstrips = rows / PS_ROWS;
-  int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + 255) / 256));
+  int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + div - 1) / div));
   long nwg = (nstrips + strips - 1) / strips;
   hipLaunchKernelGGL(panel_solve_kernel, dim3((unsigned)nwg), dim3(256), PS_LDS, s, X, ldx, L, ldl, inv,
                      inv_cstride, inv_kstride, strips, rows, panel_prio());
