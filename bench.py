@@ -59,7 +59,7 @@ def update_bytes_avg(N):
     lower 128-tiles of its C block once and reads its panel rows once (the driver's panel rule: capi.hip)."""
     n_pad = (N + 127) // 128 * 128
     m_tot = n_pad + 128
-    W = n_pad if n_pad <= 2048 else (1024 if n_pad <= 8192 or n_pad >= 32768 else 512)
+    W = n_pad if n_pad <= 4096 else (1024 if n_pad <= 8192 or n_pad >= 32768 else 512)
     tot, cnt = 0.0, 0
     J0 = 0
     while J0 < n_pad:
@@ -260,15 +260,21 @@ def main():
         upd_ms, n_launch, upd_flops = timings[3], int(timings[4]), timings[5]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
         if n_launch == 0:
-            # N <= 2048 is factored as ONE outer panel (no outer trailing update): the step is the latency
-            # chain potrf_diag -> panel_solve -> K = 128 update per 128 columns; report the whole step
+            # N <= 4096 is factored as ONE outer panel (no outer trailing update): the step is the latency
+            # chain panel_solve -> K = 128 update with the next diagonal block's potrf_diag fused in, per 128
+            # columns; report the whole step
             achieved = whole_tflops
+        n_pad = (N + 127) // 128 * 128
+        fused = n_pad < 32768     # capi.hip: fuse_mode -- the look-ahead column updates carry the next diagonal block
         roofline = {
-            "kernel": "sgp::gemm_nt_dma_kernel<1> (fp64 MFMA trailing update of the blocked Cholesky, v_mfma_f64_4x4x4_4b_f64; <0> = the same code in its auxiliary uses)",
+            "kernel": "sgp::gemm_nt_dma_kernel<1> (fp64 MFMA trailing update of the blocked Cholesky, v_mfma_f64_4x4x4_4b_f64; <0> = the same code in its auxiliary uses)"
+                      + ("; below N = 32768 the look-ahead half of the launches is sgp::gemm_nt_dma_potrf_kernel<1, true>: the same "
+                         "tile program, whose tile (0, 0) workgroup goes on to factor the next diagonal block" if fused else ""),
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
-            "note": ("single outer panel: no trailing-update launches; achieved = whole-step N^3/3 rate, latency-bound on "
-                     "sgp::potrf_diag_kernel (39 us per 128 columns)") if n_launch == 0 else None,
+            "note": ("single outer panel: no trailing-update launches; achieved = whole-step N^3/3 rate, latency-bound on the "
+                     "chain sgp::panel_solve_kernel (14 us) -> sgp::gemm_nt_dma_potrf_kernel<0, true> (K = 128 tile update + "
+                     "potrf_diag of the next diagonal block, 50 us) per 128 columns") if n_launch == 0 else None,
             "launches": n_launch, "avg_launch_ms": upd_ms / max(1, n_launch),
             "algorithmic_flops_per_launch_avg": upd_flops / max(1, n_launch),
             # The look-ahead keeps update launches of two streams (and the panel kernels) on the chip at

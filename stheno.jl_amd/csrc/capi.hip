@@ -216,6 +216,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (il) c->inner_ll = atoi(il);
     const char* fp = getenv("SGP_FUSE_POTRF");
     if (fp) c->fuse_potrf = atoi(fp);
+    const char* fm = getenv("SGP_FUSE_MAX_N");
+    if (fm) c->fuse_max_n = atol(fm);
     const char* po = getenv("SGP_POOL");
     if (po) c->pool_enabled = atoi(po);
     SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
@@ -533,6 +535,19 @@ static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double
 // P: m x w, top w x w block is the diagonal block.  d_invstore: optional array that keeps the
 // eight 16x16 inverse diagonal blocks of every 128-block (INVD_STRIDE doubles per block, the
 // layout potrf_diag writes) for later solves against the factor; else ctx scratch.
+// Which fused update + potrf_diag launches a factorisation of `n` columns (or a panel of `n` rows) uses: the
+// context's SGP_FUSE_POTRF below SGP_FUSE_MAX_N, nothing from there on unless bit 2 asks for every size.
+static int fuse_mode(const sgp_ctx* ctx, long n) {
+  if (n < ctx->fuse_max_n) return ctx->fuse_potrf;
+  return (ctx->fuse_potrf & 4) ? (ctx->fuse_potrf | 3) : 0;
+}
+struct FuseScope {   // panel_factor reads ctx->fuse_now; restored on every exit path
+  sgp_ctx* c;
+  int saved;
+  FuseScope(sgp_ctx* c_, int v) : c(c_), saved(c_->fuse_now) { c->fuse_now = v; }
+  ~FuseScope() { c->fuse_now = saved; }
+};
+
 // first_done: the panel's first diagonal block is already factored -- the trailing update that produced it had
 // potrf_diag fused into the workgroup of that tile (ctx->fuse_potrf, gemm_nt.hip: gemm_nt_dma_potrf_kernel).
 static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_slots,
@@ -574,7 +589,7 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
   // Fused inner updates (SGP_FUSE_POTRF bit 0): the K = 128 update with block column j also factors the diagonal
   // block of block column j + 1 in the workgroup that updates it, so the 128-pivot chain runs under the rest of
   // the update instead of after it and one launch per block column disappears.
-  const bool fuse = (ctx->fuse_potrf & 1) && ctx->refine == 1 && !ctx->inner_ll && !ila;
+  const bool fuse = (ctx->fuse_now & 1) && ctx->refine == 1 && !ctx->inner_ll && !ila;
   bool diag_done = first_done;
   bool irest_pending = false;
   for (long j = 0; j < w; j += TILE) {
@@ -609,7 +624,7 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
           // ran before this launch on the same stream
           double* invn = d_invstore ? d_invstore + (j / TILE + 1) * INVD_STRIDE : ctx->d_invd;
           CHECK_RC(launch_gemm_nt_potrf(A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, 0,
-                                        (ctx->fuse_potrf & 8) ? 1 : 0, invn, d_slots + j / TILE + 1, d_info,
+                                        (ctx->fuse_now & 8) ? 1 : 0, invn, d_slots + j / TILE + 1, d_info,
                                         g0 + j + TILE, s));
           diag_done = true;
         } else {
@@ -678,12 +693,13 @@ static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long
 static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
                          hipStream_t s, long grow = 0) {
   CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
-  // outer panel width, measured (profiles/r02_summary.md): one panel for n_pad <= 2048 (the outer level only
-  // adds launches there: 1.52 -> 1.30 ms at N = 2048), 1024 up to 8192 (3.35 -> 3.16 ms at N = 4096), 512 in the
+  // outer panel width, measured (profiles/r02_summary.md): one panel for n_pad <= 4096 (the outer level only
+  // adds launches there: 1.52 -> 1.30 ms at N = 2048; with the fused diagonal blocks 2.73 -> 2.47 ms at N = 4096),
+  // 1024 up to 8192, 512 in the
   // mid range where the panel stream is the critical path (N = 16384: 34.8 vs 35.4 ms), 1024 from 32768 on
   // (halves the C-tile traffic per flop of the big trailing updates).
   const long WOUT = ctx->wout > 0 ? ctx->wout
-                    : n_pad <= 2048 ? n_pad
+                    : n_pad <= 4096 ? n_pad
                     : n_pad <= 8192 ? WOUT_LARGE
                     : n_pad >= 32768 ? WOUT_LARGE
                                      : WOUT_SMALL;
@@ -697,11 +713,12 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   } excl_scope(ctx, reserve && ctx->reserve_cu > 0 ? 1 : 0);
   // SGP_FUSE_POTRF bit 1: the trailing update that finishes the next panel's first diagonal block (the look-ahead
   // column update, or the whole update when the look-ahead is off) factors that block in the same launch
-  // (bit 1: while n_pad < 32768, where the panel chain is the critical path; from there on the panel stream has slack
-  // and the trailing updates -- the launches bench.py's roofline line is about -- stay one kernel symbol; bit 2: at
-  // every size.)
-  const bool fuse_outer = (((ctx->fuse_potrf & 2) && n_pad < 32768) || (ctx->fuse_potrf & 4)) && ctx->refine == 1 &&
-                          !ctx->inner_ll && !(ctx->wmid >= TILE && ctx->wmid < WOUT);
+  // Both apply while n_pad < SGP_FUSE_MAX_N (32768), where the panel chain is the critical path: N = 2048 1.17 ->
+  // 1.09 ms, 4096 2.93 -> 2.73 ms, 16384 33.8 -> 33.2 ms; from 32768 on the panel stream has slack and the fused
+  // launches measure the same or 1 % slower (profiles/r02_microbench.md).  Bit 2: at every size (A/B).
+  FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad));
+  const bool fuse_outer = (ctx->fuse_now & 2) && ctx->refine == 1 && !ctx->inner_ll &&
+                          !(ctx->wmid >= TILE && ctx->wmid < WOUT);
   bool first_done = false;
   bool rest_pending = false;
   if (la) {
@@ -718,7 +735,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
     long c0 = J0 + wj;
     if (c0 >= n_pad) break;
     const FusedDiag fz_next = {d_wall ? d_wall + (c0 / TILE) * INVD_STRIDE : ctx->d_invd, ctx->d_slots + c0 / TILE,
-                               ctx->d_info, c0, (ctx->fuse_potrf & 8) ? 1 : 0};
+                               ctx->d_info, c0, (ctx->fuse_now & 8) ? 1 : 0};
     const FusedDiag* fz = fuse_outer ? &fz_next : nullptr;
     first_done = fuse_outer;
     long w1 = std::min(WOUT, n_pad - c0);   // width of the next panel
@@ -2432,6 +2449,7 @@ extern "C" int sgp_dev_panel_factor(sgp_ctx* ctx, double* d_P, int64_t ld, int64
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   // per-block logdet slots live in ctx scratch; accumulate their sum into d_logdet[0]
+  FuseScope fuse_scope(ctx, fuse_mode(ctx, m));   // inner fused launches by the panel's height
   CHECK_RC(panel_factor(ctx, d_P, ld, m, w, g0, ctx->d_slots, d_info, nullptr, s));
   CHECK_RC(launch_sum_array(ctx->d_slots, w / TILE, ctx->d_scal + 8, s));
   hipLaunchKernelGGL(accum_kernel, dim3(1), dim3(1), 0, s, d_logdet, ctx->d_scal + 8);

@@ -53,9 +53,11 @@ struct sgp_ctx {
   long n_solve_rows = 0;
   long wmid = 0;               // SGP_WMID=<cols>: middle blocking level inside an outer panel (0 = none)
   int inner_ll = 0;            // SGP_INNER_LL=1: left-looking block columns inside an outer panel
-  int fuse_potrf = 0;          // SGP_FUSE_POTRF: bit 0 = inner K = 128 updates, bit 1 = outer trailing updates (n_pad < 32768),
-                               // bit 2 = outer trailing updates at every size also factor the next diagonal block (tile
-                               // (0, 0) of their C) in the workgroup that updates it
+  int fuse_potrf = 11;         // SGP_FUSE_POTRF: bit 0 = inner K = 128 updates, bit 1 = outer trailing updates also factor the next
+                               // diagonal block (tile (0, 0) of their C) in the workgroup that updates it, bit 3 = that tile goes
+                               // from the accumulators straight into the factorisation's LDS layout; bit 2 = at every size
+  long fuse_max_n = 32768;     // SGP_FUSE_MAX_N: fused launches only while n_pad is below this (bit 2 lifts the limit)
+  int fuse_now = 0;            // what the factorisation under way uses (set by chol_bordered / sgp_dev_panel_factor)
   int refine = 1;              // SGP_REFINE=0: plain explicit-inverse panel solve (A/B timing only)
   double* d_slots = nullptr;   // per-128-block logdet contributions
   long n_slots = 0;

@@ -19,7 +19,7 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {
 inline int panel_prio() {
   static const int v = [] {
     const char* e = getenv("SGP_PANEL_PRIO");
-    return e ? atoi(e) : 0;
+    return e ? atoi(e) : 3;   // measured with the fused launches: N = 16384 33.2 -> 32.7 ms, 4096 2.73 -> 2.71, 2048 1.093 -> 1.087
   }();
   return v;
 }
@@ -73,8 +73,16 @@ __device__ __forceinline__ void block_rc(int blk, int& rb, int& cb) {
 // issues in order, so the 2 (14 - J) independent FMAs of a rank-1 update would sit between one pivot's
 // dependency chain and the next; spread over the gaps of the NEXT pivot's chain (each of its ten steps waits
 // ~20 cycles for its operand) they cost nothing.  Only column J + 1 -- the next pivot -- is updated at once.
+#ifndef SGP_POTRF_NEWTON
+#define SGP_POTRF_NEWTON 2   /* Newton steps on 1 / sqrt(pivot) inside the dependency chain (A/B: -DSGP_POTRF_NEWTON=1) */
+#endif
+#if SGP_POTRF_NEWTON == 2
+#define SGP_NSLOT 7
+#else
+#define SGP_NSLOT 5
+#endif
 #define SGP_SLOT_N(J, K, N) \
-  if (J >= 1 && N >= J + 1 && (N % 7) == K) SGP_DPP_UPD1(lp, ip, N)
+  if (J >= 1 && N >= J + 1 && (N % SGP_NSLOT) == K) SGP_DPP_UPD1(lp, ip, N)
 #define SGP_SLOT(J, K)                                                                                   \
   SGP_SLOT_N(J, K, 1) SGP_SLOT_N(J, K, 2) SGP_SLOT_N(J, K, 3) SGP_SLOT_N(J, K, 4) SGP_SLOT_N(J, K, 5)   \
   SGP_SLOT_N(J, K, 6) SGP_SLOT_N(J, K, 7) SGP_SLOT_N(J, K, 8) SGP_SLOT_N(J, K, 9) SGP_SLOT_N(J, K, 10)  \
@@ -82,6 +90,21 @@ __device__ __forceinline__ void block_rc(int blk, int& rb, int& cb) {
 #define SGP_PIN(x) asm volatile("" : "+v"(x))   /* keeps x's computation between the neighbouring slots */
 #define SGP_NEXT_N(J, N) \
   if (N == J + 1) SGP_DPP_UPD1(lij, iij, N)
+#if SGP_POTRF_NEWTON == 2
+#define SGP_NEWTON2(J)                                                                   \
+    t = h * r;                                                                           \
+    SGP_PIN(t);                                                                          \
+    SGP_SLOT(J, 5)                                                                       \
+    t = fma(t, r, 1.5);                                                                  \
+    SGP_PIN(t);                                                                          \
+    SGP_SLOT(J, 6)                                                                       \
+    r = r * t; /* 1 / sqrt(djj) to rounding level */
+#else
+/* one Newton step: 1 / sqrt(djj) with a relative error of ~2^-51 (v_rsq_f64 seeds ~2^-26) scales the whole column --
+   a componentwise backward error of two units in the last place, inside the factorisation's own rounding; the
+   diagonal entry itself is still the corrected root */
+#define SGP_NEWTON2(J)
+#endif
 #define SGP_PIVOT(J)                                                                     \
   {                                                                                      \
     double djj;                                                                          \
@@ -101,13 +124,7 @@ __device__ __forceinline__ void block_rc(int blk, int& rb, int& cb) {
     r = r * t;                                                                           \
     SGP_PIN(r);                                                                          \
     SGP_SLOT(J, 4)                                                                       \
-    t = h * r;                                                                           \
-    SGP_PIN(t);                                                                          \
-    SGP_SLOT(J, 5)                                                                       \
-    t = fma(t, r, 1.5);                                                                  \
-    SGP_PIN(t);                                                                          \
-    SGP_SLOT(J, 6)                                                                       \
-    r = r * t; /* 1 / sqrt(djj) to rounding level */                                     \
+    SGP_NEWTON2(J)                                                                       \
     const double lij = Lr[J] * r, iij = Ir[J] * r;                                       \
     double d = djj * r;                                                                  \
     d = fma(0.5 * r, fma(-d, d, djj), d); /* sqrt(djj) */                                \
@@ -149,6 +166,7 @@ __device__ __forceinline__ void micro_cholesky(double* Dcc, double* sInv, int cb
 #undef SGP_SLOT_N
 #undef SGP_DPP_UPD1
 #undef SGP_PIVOT
+#undef SGP_NEWTON2
 #undef SGP_DPP_BCAST
 
 // Right-looking over the eight 16-column sub-panels, software-pipelined so that the serial pivot chain

@@ -70,9 +70,9 @@ def _operators(N):
     return out, (xs, y)
 
 
-@pytest.mark.parametrize("N", [130, 700, 2500])
+@pytest.mark.parametrize("N", [130, 700, 4500])
 def test_fused_potrf_is_bit_identical_to_separate_launches(monkeypatch, N):
-    # default panel widths: N = 130 / 700 are one panel (inner fusion only), 2500 has three outer panels
+    # default panel widths: N = 130 / 700 are one panel (inner fusion only), 4500 has five outer panels of 1024
     ref_ctx = _ctx(monkeypatch, 0)
     ref, (xs, y) = _with_ctx(ref_ctx, lambda: _operators(N))
     want = orm.gppp_sum_logpdf(xs, y, 0.1)

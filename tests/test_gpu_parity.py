@@ -446,14 +446,24 @@ def test_many_right_hand_sides(S):
 
 
 def test_input_dimension_limit_is_reported():
+    """Assembly (cov, logpdf, posterior, rand, elbo) takes ColVecs of any dimension; the reverse-mode kernels
+    stop at 64 (term gradients) and 16 (input gradients) and must say so instead of computing something else."""
     f = P.atomic(P.GP(P.SEKernel()), P.GPC())
-    X = P.ColVecs(np.zeros((65, 4)))
+    rng = np.random.default_rng(0)
+    for D in (64, 65):
+        X = P.ColVecs(rng.standard_normal((D, 40)) / np.sqrt(D))
+        K = P.prior_cov(f, X)
+        assert np.abs(K - okf.kernelmatrix(okf.SEKernel(), okf.ColVecs(X.X), faithful=False)).max() < 1e-13
+    y = rng.standard_normal(40)
+    X65 = P.ColVecs(rng.standard_normal((65, 40)) / np.sqrt(65))
     with pytest.raises(P.SthenoMIError) as ei:
-        P.prior_cov(f, X)
+        P.logpdf_and_gradient(f(X65, 0.1), y)
     assert "dimension" in str(ei.value)
-    X64 = P.ColVecs(np.random.default_rng(0).standard_normal((64, 40)))
-    K = P.prior_cov(f, X64)
-    assert np.abs(K - okf.kernelmatrix(okf.SEKernel(), okf.ColVecs(X64.X), faithful=False)).max() < 1e-13
+    X17 = P.ColVecs(rng.standard_normal((17, 40)) / np.sqrt(17))
+    assert np.isfinite(P.logpdf_and_gradient(f(X17, 0.1), y)["logpdf"])       # term gradients: fine up to 64
+    with pytest.raises(P.SthenoMIError) as ei:
+        P.logpdf_and_gradient(f(X17, 0.1), y, inputs=True)
+    assert "dimension" in str(ei.value)
 
 
 # ---- reverse-mode gradient of logpdf (SURVEY.md 8f item 1) -------------------------------------------
