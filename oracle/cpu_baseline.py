@@ -67,7 +67,11 @@ def sweep_threads(n=6144):
             t0 = time.perf_counter()
             cholesky_blocked_inplace(A)
             rates[c] = n ** 3 / 3 / (time.perf_counter() - t0) / 1e9
-    best = max(rates, key=rates.get)
+    # the smallest thread count within 10 % of the best rate: on the 256-core GPU hosts the sweep is flat within its
+    # noise (50 - 60 GFLOP/s at n = 6144 from 8 to 256 threads), and a many-thread pick then runs the small samples
+    # (N <= 8192) several times slower than 8 threads do -- the CPU gets its best ROBUST configuration
+    top = max(rates.values())
+    best = min(c for c in cands if rates[c] >= 0.9 * top)
     return best, rates
 
 

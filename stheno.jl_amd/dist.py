@@ -230,7 +230,16 @@ class HipOps:
         _lib.check(self.lib.sgp_elbo_part_len(M, C.byref(n)), "sgp_elbo_part_len")
         return self.torch.zeros(n.value, dtype=self.torch.float64, device=self.device)
 
+    # sgp_dev_elbo_partial / _finish take no stream argument: they run on the context's own stream, which is not
+    # ordered with torch's.  `part` is zero-filled (and, between the two calls, all-reduced) by work enqueued on the
+    # current torch stream, so that stream is drained before the library touches the buffer -- otherwise a zero-fill
+    # (or a still running all-reduce) that lands late overwrites / precedes what the library wrote / reads.  The
+    # library drains its own streams before it returns (CtxScope), so torch-side consumers need nothing more.
+    def _drain_current_stream(self):
+        self.torch.cuda.current_stream(self.device).synchronize()
+
     def elbo_partial(self, zz, xz, var_x, mean_x, nk, nbuf, zk, zbuf, y, part):
+        self._drain_current_stream()
         rc = self.lib.sgp_dev_elbo_partial(self.ctx.handle, zz.ref(), xz.ref(), _lib.dptr(var_x), _lib.dptr(mean_x), nk,
                                            _lib.dptr(nbuf), zk, _lib.dptr(zbuf), _lib.dptr(y), part.data_ptr(),
                                            part.numel())
@@ -238,6 +247,7 @@ class HipOps:
 
     def elbo_finish(self, M, N_total, part):
         out = np.zeros(1)
+        self._drain_current_stream()
         _lib.check(self.lib.sgp_dev_elbo_finish(self.ctx.handle, M, N_total, part.data_ptr(), _lib.dptr(out)),
                    "sgp_dev_elbo_finish")
         return float(out[0])
