@@ -68,7 +68,9 @@ def update_bytes_avg(N):
         if c0 >= n_pad:
             break
         w1 = min(W, n_pad - c0)
-        for (c, nc) in ((c0, w1), (c0 + w1, n_pad - c0 - w1)):
+        # below 65536 columns: look-ahead split (next panel's columns, then the rest); from there on one launch
+        split = ((c0, w1), (c0 + w1, n_pad - c0 - w1)) if n_pad < 65536 else ((c0, n_pad - c0),)
+        for (c, nc) in split:
             if nc <= 0:
                 continue
             m = m_tot - c
@@ -266,10 +268,18 @@ def main():
             achieved = whole_tflops
         n_pad = (N + 127) // 128 * 128
         fused = n_pad < 32768     # capi.hip: fuse_mode -- the look-ahead column updates carry the next diagonal block
+        serial = n_pad >= 65536   # capi.hip: chol_bordered -- no look-ahead from 65536 columns on, every update launch fused
+        if serial:
+            kname = ("sgp::gemm_nt_dma_potrf_kernel<1, true> (fp64 MFMA trailing update of the blocked Cholesky, "
+                     "v_mfma_f64_4x4x4_4b_f64: the tile program of sgp::gemm_nt_dma_kernel, whose tile (0, 0) workgroup goes on "
+                     "to factor the next diagonal block; one launch per outer panel, no look-ahead at this size)")
+        else:
+            kname = ("sgp::gemm_nt_dma_kernel<1> (fp64 MFMA trailing update of the blocked Cholesky, v_mfma_f64_4x4x4_4b_f64; "
+                     "<0> = the same code in its auxiliary uses)"
+                     + ("; below N = 32768 the look-ahead half of the launches is sgp::gemm_nt_dma_potrf_kernel<1, true>: the same "
+                        "tile program, whose tile (0, 0) workgroup goes on to factor the next diagonal block" if fused else ""))
         roofline = {
-            "kernel": "sgp::gemm_nt_dma_kernel<1> (fp64 MFMA trailing update of the blocked Cholesky, v_mfma_f64_4x4x4_4b_f64; <0> = the same code in its auxiliary uses)"
-                      + ("; below N = 32768 the look-ahead half of the launches is sgp::gemm_nt_dma_potrf_kernel<1, true>: the same "
-                         "tile program, whose tile (0, 0) workgroup goes on to factor the next diagonal block" if fused else ""),
+            "kernel": kname,
             "bound": "mfma", "achieved": achieved, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
             "note": ("single outer panel: no trailing-update launches; achieved = whole-step N^3/3 rate, latency-bound on the "

@@ -206,6 +206,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (em) c->excl_max = atol(em);
     const char* lm = getenv("SGP_LA_MIN");
     if (lm) c->la_min = atol(lm);
+    const char* lx = getenv("SGP_LA_MAX_N");
+    if (lx) c->la_max_n = atol(lx);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* rf = getenv("SGP_REFINE");
@@ -537,8 +539,11 @@ static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double
 // layout potrf_diag writes) for later solves against the factor; else ctx scratch.
 // Which fused update + potrf_diag launches a factorisation of `n` columns (or a panel of `n` rows) uses: the
 // context's SGP_FUSE_POTRF below SGP_FUSE_MAX_N, nothing from there on unless bit 2 asks for every size.
-static int fuse_mode(const sgp_ctx* ctx, long n) {
-  if (n < ctx->fuse_max_n) return ctx->fuse_potrf;
+// `serial`: the factorisation runs without the two-stream look-ahead (every kernel has the chip to itself) -- there
+// the fused launches pay at every size: the diagonal block's pivot chain runs under the other tiles of its own
+// launch (N = 65536: 1541 -> 1525 ms).
+static int fuse_mode(const sgp_ctx* ctx, long n, bool serial = false) {
+  if (n < ctx->fuse_max_n || serial) return ctx->fuse_potrf;
   return (ctx->fuse_potrf & 4) ? (ctx->fuse_potrf | 3) : 0;
 }
 struct FuseScope {   // panel_factor reads ctx->fuse_now; restored on every exit path
@@ -703,7 +708,12 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
                     : n_pad <= 8192 ? WOUT_LARGE
                     : n_pad >= 32768 ? WOUT_LARGE
                                      : WOUT_SMALL;
-  const bool la = ctx->lookahead && s == ctx->stream;
+  // Look-ahead below SGP_LA_MAX_N (65536) columns only.  At N = 65536 the overlap hides ~70 ms of panel chain but the
+  // sharing costs the trailing updates as much (per launch 0.72 of the fp64 MFMA peak beside the panel stream, 0.81
+  // alone); the serial schedule with fused diagonal blocks measures the same or better (1525 vs 1539 ms dense
+  // Matern-5/2, 1515 vs 1501 ms on the three-block model, same box) and leaves every kernel uncontended; at 32768 the
+  // look-ahead still wins (202 vs 207 ms).  SGP_LOOKAHEAD=2: look-ahead at every size.
+  const bool la = ctx->lookahead && s == ctx->stream && (n_pad < ctx->la_max_n || ctx->lookahead == 2);
   const bool reserve = la && ctx->stream2m && n_pad <= ctx->reserve_max_n;
   hipStream_t sB = la ? (reserve ? ctx->stream2m : ctx->stream2) : s;
   struct ExclScope {   // potrf_diag placement follows the update stream in use, on every exit path
@@ -716,7 +726,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // Both apply while n_pad < SGP_FUSE_MAX_N (32768), where the panel chain is the critical path: N = 2048 1.17 ->
   // 1.09 ms, 4096 2.93 -> 2.73 ms, 16384 33.8 -> 33.2 ms; from 32768 on the panel stream has slack and the fused
   // launches measure the same or 1 % slower (profiles/r02_microbench.md).  Bit 2: at every size (A/B).
-  FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad));
+  FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad, !la));
   const bool fuse_outer = (ctx->fuse_now & 2) && ctx->refine == 1 && !ctx->inner_ll &&
                           !(ctx->wmid >= TILE && ctx->wmid < WOUT);
   bool first_done = false;

@@ -46,6 +46,7 @@ struct sgp_ctx {
   hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
   int lookahead = 1;
   long la_min = 0;   // look-ahead only while more than la_min columns of the trailing matrix remain (capi.hip)
+  long la_max_n = 65536;   // SGP_LA_MAX_N: look-ahead only for factorisations of fewer columns (serial + fused from there on)
   long wout = 0;  // 0 = automatic
   double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
   double* d_w = nullptr;       // 128 x 128 scratch inverse
