@@ -301,7 +301,15 @@ def main():
         tr_file = os.path.join(ROOT, "profiles", "r02_update_traffic.json")
         if os.path.exists(tr_file):
             rec = json.load(open(tr_file)).get(args.config)
-            if rec:
+            if rec and serial and "look-ahead" in rec.get("schedule", ""):
+                # the committed passes profiled the look-ahead schedule (125 launches per step); the serial schedule
+                # runs the same tiles with the same depth in 63 launches, so the per-STEP traffic carries over but no
+                # per-launch figure was measured for it: `traffic` stays null, the passes are attached as they are
+                roofline["traffic_previous_schedule"] = rec
+                roofline["traffic_note"] = ("FETCH_SIZE / WRITE_SIZE passes exist for the look-ahead schedule only: %.2f TB per step "
+                                            "(2.94 x the algorithmic bytes); not re-collected for the one-launch-per-panel schedule"
+                                            % (rec.get("per_step_bytes", 0.0) / 1e12))
+            elif rec:
                 roofline["traffic"] = rec["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = rec
         roofline["algorithmic_bytes_per_launch_avg"] = update_bytes_avg(N)
