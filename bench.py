@@ -306,6 +306,10 @@ def main():
                 # runs the same tiles with the same depth in 63 launches, so the per-STEP traffic carries over but no
                 # per-launch figure was measured for it: `traffic` stays null, the passes are attached as they are
                 roofline["traffic_previous_schedule"] = rec
+                if n_launch > 0 and rec.get("per_step_bytes"):
+                    # same tiles, same depth, merged launches: the per-step sum spread over this schedule's launches
+                    # (a derived figure, labelled as such; `traffic` itself stays null until the passes are re-run)
+                    roofline["traffic_derived_from_previous_schedule"] = rec["per_step_bytes"] / n_launch
                 roofline["traffic_note"] = ("FETCH_SIZE / WRITE_SIZE passes exist for the look-ahead schedule only: %.2f TB per step "
                                             "(2.94 x the algorithmic bytes); not re-collected for the one-launch-per-panel schedule"
                                             % (rec.get("per_step_bytes", 0.0) / 1e12))
