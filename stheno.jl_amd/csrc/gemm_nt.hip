@@ -35,79 +35,15 @@
 // consecutive workgroups form a patch sharing 8 A panels and 8 B panels in that XCD's L2.
 #include "common.h"
 #include "potrf_diag.h"
+#include "tilemap.h"
 
 namespace sgp {
 
 constexpr int KB = 16;  // K chunk per LDS stage
 
-// Workgroup -> tile enumeration.  Rectangular launches enumerate (8 owned rows) x n_tc per group
-// of 8 owned rows.  Lower-triangular launches (mask_off == 0) enumerate ONLY live tiles wherever
-// that has a closed form: dead workgroups above the diagonal cost ~1 us of dispatcher time each
-// and a 128^2-tile lower update lost 20 % to them.  Per XCD, group G (tile rows 64G .. 64G+63)
-// has 512 G tiles strictly left of its diagonal 64-block plus exactly 260 live tiles inside it
-// (the boustrophedon row ownership makes that count independent of the XCD).
-struct TriShape {
-  long Gn, r_last, Ga, sA, sB, t_last, n_tc;
-};
-__host__ __device__ __forceinline__ TriShape tri_shape(long n_tr, long n_tc) {
-  TriShape t;
-  const long J = (n_tr + 7) / 8;  // owned rows per XCD
-  t.n_tc = n_tc;
-  t.Gn = J / 8;
-  t.r_last = J % 8;
-  const long g_full = n_tc / 64;
-  t.Ga = t.Gn < g_full ? t.Gn : g_full;              // groups enumerated exactly
-  t.sA = 256 * t.Ga * (t.Ga - 1) + 260 * t.Ga;
-  t.sB = (t.Gn - t.Ga) * 8 * n_tc;                   // groups enumerated as 8 x n_tc rectangles
-  t.t_last = (64 * (t.Gn + 1) < n_tc) ? 64 * (t.Gn + 1) : n_tc;
-  return t;
-}
-__host__ __device__ __forceinline__ long tri_ids_per_xcd(const TriShape& t) {
-  return t.sA + t.sB + t.r_last * t.t_last;
-}
-
+// Workgroup -> tile enumeration: tilemap.h (host-compilable; tests/tilemap_host.cpp checks it exhaustively).
 __device__ __forceinline__ bool tile_of_block(long n_tr, long n_tc, long mask_off, long& tr, long& tc) {
-  const long id = (long)blockIdx.x;
-  const long xcd = id & 7, k = id >> 3;
-  long j;
-  if (mask_off == 0) {
-    const TriShape t = tri_shape(n_tr, n_tc);
-    if (k < t.sA) {
-      // S(G) = 256 G (G - 1) + 260 G = 256 G^2 + 4 G
-      long G = (long)((sqrt(16.0 + 1024.0 * (double)k) - 4.0) / 512.0);
-      while (256 * G * G + 4 * G > k) --G;
-      while (256 * (G + 1) * (G + 1) + 4 * (G + 1) <= k) ++G;
-      const long within = k - (256 * G * G + 4 * G);
-      if (within < 512 * G) {
-        j = G * 8 + (within & 7);
-        tc = within >> 3;
-      } else {
-        long d = within - 512 * G, jj = 0, cum = 0;
-        for (; jj < 8; ++jj) {
-          const long cnt = 8 * jj + ((jj & 1) ? 7 - xcd : xcd) + 1;
-          if (d < cum + cnt) break;
-          cum += cnt;
-        }
-        j = G * 8 + jj;
-        tc = 64 * G + (d - cum);
-      }
-    } else if (k < t.sA + t.sB) {
-      const long kk = k - t.sA;
-      const long within = kk % (8 * n_tc);
-      j = (t.Ga + kk / (8 * n_tc)) * 8 + (within & 7);
-      tc = within >> 3;
-    } else {  // partial last group: r_last owned rows
-      const long within = k - t.sA - t.sB;
-      j = t.Gn * 8 + within % t.r_last;
-      tc = within / t.r_last;
-    }
-  } else {
-    const long gs = 8 * n_tc;
-    j = (k / gs) * 8 + ((k % gs) & 7);
-    tc = (k % gs) >> 3;
-  }
-  tr = 8 * j + ((j & 1) ? 7 - xcd : xcd);  // boustrophedon: equal live-tile counts per XCD
-  return tr < n_tr && tc < n_tc && tr >= tc + mask_off;
+  return tile_of_id((long)blockIdx.x, n_tr, n_tc, mask_off, tr, tc);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -480,7 +416,7 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
   }
   long n_tr = M / TILE, n_tc = Nc / TILE;
   long groups = ((n_tr + 7) / 8 + 7) / 8;  // groups of 8 owned rows per XCD
-  long per_xcd = (mask_off == 0) ? tri_ids_per_xcd(tri_shape(n_tr, n_tc)) : groups * 8 * n_tc;
+  long per_xcd = (mask_off == 0) ? tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1)) : groups * 8 * n_tc;
   dim3 grid((unsigned)(per_xcd * 8));
   if (kcap_mode)
     hipLaunchKernelGGL((gemm_nt_reg_kernel<true>), grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha,
@@ -503,7 +439,7 @@ int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M
     return -1;
   }
   long n_tr = M / TILE, n_tc = Nc / TILE;
-  long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc));
+  long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1));
   hipLaunchKernelGGL(gemm_nt_dma_kernel<1>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, P, ldp, C, ldc, K,
                      -1.0, 1.0, 0L, n_tr, n_tc, 0L, (const double*)C, ldc, 0);
   SGP_HIP(hipGetLastError());
@@ -533,7 +469,7 @@ int launch_gemm_nt_potrf(const double* P, long ldp, double* C, long ldc, long M,
     return -1;
   }
   long n_tr = M / TILE, n_tc = Nc / TILE;
-  long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc));
+  long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1));
   const unsigned grid = (unsigned)(per_xcd * 8);
   if (outer)
     return handoff ? launch_potrf_variant<1, true>(grid, P, ldp, C, ldc, K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, s)
@@ -571,7 +507,7 @@ int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, h
     return -1;
   }
   long n_t = n / TILE;
-  long per_xcd = tri_ids_per_xcd(tri_shape(n_t, n_t));
+  long per_xcd = tri_ids_per_xcd(tri_shape(n_t, n_t, -1));
   hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
                      1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 1);
   SGP_HIP(hipGetLastError());
@@ -617,7 +553,7 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
   }
   long groups = ((n_tr + 7) / 8 + 7) / 8;
   long mask_off = lower_only ? 0 : -(1L << 40);
-  long per_xcd = lower_only ? tri_ids_per_xcd(tri_shape(n_tr, n_tc)) : groups * 8 * n_tc;
+  long per_xcd = lower_only ? tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1)) : groups * 8 * n_tc;
   dim3 grid((unsigned)(per_xcd * 8), (unsigned)nsplit);
   hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, grid, dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc, K / nsplit, 1.0,
                      0.0, mask_off, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 0);
