@@ -78,11 +78,14 @@ int main() {
         worst_tr = n_tr, worst_tc = n_tc;
       }
     }
+  double worst_big = 0.0;
   for (long n : {512L, 513L, 520L, 768L, 1023L, 1024L, 1026L})   // N = 65536 .. 131328: the BASELINE sizes and beyond
     for (long n_tc : {8L, n, n - 8}) {
       long ids, live;
       check_shape(n, n_tc, 0, &ids, &live);
       ++shapes;
+      const double f = (double)(ids - live) / (double)live;
+      worst_big = f > worst_big ? f : worst_big;
     }
   // rectangular launches (row solves' updates, L Z, cin products)
   for (long n_tr = 1; n_tr <= 150; n_tr += (n_tr < 40 ? 1 : 5))
@@ -91,7 +94,7 @@ int main() {
       check_shape(n_tr, n_tc, NOMASK, &ids, &live);
       ++shapes;
     }
-  std::printf("shapes %ld failures %ld worst_dead_fraction %.4f at %ld x %ld\n", shapes, failures, (double)worst_num / (double)worst_den,
-              worst_tr, worst_tc);
+  std::printf("shapes %ld failures %ld worst_dead_fraction %.4f at %ld x %ld worst_dead_fraction_big %.4f\n", shapes, failures,
+              (double)worst_num / (double)worst_den, worst_tr, worst_tc, worst_big);
   return failures ? 1 : 0;
 }
