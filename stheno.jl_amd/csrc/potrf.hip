@@ -5,10 +5,11 @@
 // Together they replace LAPACK dpotf2/dtrsm inside dpotrf on the reference path
 // (LinearAlgebra.cholesky under AbstractGPs.logpdf/posterior/rand/elbo [EXT]).
 //
-// potrf_diag: left-looking over 16-column sub-panels.  The rank-k updates and the sub-panel
+// potrf_diag (potrf_diag.h: potrf_diag_body, shared with the fused update + diagonal block launches of
+// gemm_nt.hip): right-looking over 16-column sub-panels.  The rank-16 updates and the sub-panel
 // solves run on v_mfma_f64_16x16x4_f64 straight out of LDS (packed 16x16 blocks, k-major:
 // conflict-free operand reads); the 16x16 micro-Cholesky and its inverse run in the registers of one wave with
-// v_readlane broadcasts (no LDS round trips, no barriers) -- "wavefront shuffles for the
+// DPP row broadcasts inside the FMAs (no LDS round trips, no barriers) -- "wavefront shuffles for the
 // diagonal panel" in north-star terms.
 #include "common.h"
 #include "potrf_diag.h"   // potrf_diag_body: the diagonal-block factorisation itself
