@@ -53,11 +53,34 @@ class _ScaleVector(np.ndarray):
 
 
 class _MatCache:
-    """as_matrix with identity caching so equal inputs are uploaded once."""
+    """as_matrix with identity caching so equal inputs are uploaded once -- and the memo of the walk down the tree:
+    a shared sub-tree is reached along several paths (f5 = f3 + f4 with f4 = f1 + f3: the reference's recursion
+    re-evaluates it once per path, test/affine_transformations/addition.jl:7-9); the warped inputs of a compose node
+    and the scale vector of a `sigma * f` node are computed ONCE per (node, inputs[, incoming scale]) and the same
+    object is handed to every path, so that paths which read the same points with the same scales merge into one
+    kernel term (identity keys) instead of one term per path."""
 
     def __init__(self):
         self.m = {}
         self.keep = []
+        self.warped = {}
+        self.scaled = {}
+
+    def warp(self, f, g, x):
+        k = (id(f), id(x))
+        if k not in self.warped:
+            self.warped[k] = _gp.warp(g, x)
+            self.keep.append((f, x))
+        return self.warped[k]
+
+    def scale(self, f, s, x, r):
+        k = (id(f), id(x), id(r) if r is not None else None)
+        if k not in self.scaled:
+            sx = np.asarray(_gp._map_points(s, x), dtype=np.float64)
+            fac = ([] if r is None else list(r.factors)) + [(f, x, sx)]
+            self.scaled[k] = _ScaleVector(sx if r is None else np.asarray(r) * sx, fac)
+            self.keep.append((f, x, r))
+        return self.scaled[k]
 
     def __call__(self, x):
         k = id(x)
@@ -109,11 +132,9 @@ def _paths(f, x, c, r, key, mat, chain=()):
         s = f.args[1]
         if _gp._is_real(s):
             return _paths(f.args[2], x, c * float(s), r, key, mat, chain)
-        sx = np.asarray(_gp._map_points(s, x), dtype=np.float64)
-        fac = ([] if r is None else list(r.factors)) + [(f, x, sx)]
-        return _paths(f.args[2], x, c, _ScaleVector(sx if r is None else np.asarray(r) * sx, fac), key, mat, chain)
+        return _paths(f.args[2], x, c, mat.scale(f, s, x, r), key, mat, chain)
     if op == "o":
-        return _paths(f.args[1], _gp.warp(f.args[2], x), c, r, key, mat, chain + ((f.args[2], x),))
+        return _paths(f.args[1], mat.warp(f, f.args[2], x), c, r, key, mat, chain + ((f.args[2], x),))
     if op == "cross":
         raise ValueError("cross(...) can only appear at block level")
     raise ValueError(op)
@@ -129,7 +150,9 @@ def _merge_paths(ps):
             q = _Path(p.key, p.atom, p.c, p.r, p.X, p.chain)
             index[k] = q
             out.append(q)
-    return out
+    # paths that cancel exactly (f - f, 2 f - f - f, ...) leave no term: the block is an exact zero, as in the
+    # reference's recursion, which adds and subtracts identical matrices
+    return [q for q in out if q.c != 0.0]
 
 
 class _InputTable:
