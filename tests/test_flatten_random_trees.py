@@ -134,3 +134,43 @@ def test_random_programme_on_colvecs(seed):
     np.testing.assert_allclose(Kp, Ko, rtol=1e-11, atol=1e-12 * scale)
     np.testing.assert_allclose(P.mean_vector(Fp, xp), Fo.mean(xo), rtol=1e-12, atol=1e-12)
     assert np.all((Ko == 0.0) <= (Kp == 0.0))
+
+
+# ---- random kernel expressions (KernelFunctions composites: ScaledKernel, KernelSum, TransformedKernel) ------------
+def _random_kernel(api, rng, depth, periodic_ok):
+    """A random kernel expression; at most one PeriodicTransform on the way from the raw 1-D point to a leaf."""
+    leaves = [api.SEKernel, api.Matern12Kernel, api.Matern32Kernel, api.Matern52Kernel, api.WhiteKernel]
+    op = rng.integers(7) if depth > 0 else 6
+    if op == 0:
+        return api.ScaledKernel(_random_kernel(api, rng, depth - 1, periodic_ok), float(0.2 + 2 * rng.random()))
+    if op == 1:
+        n = 2 + rng.integers(2)
+        return api.KernelSum([_random_kernel(api, rng, depth - 1, periodic_ok) for _ in range(n)])
+    if op == 2:
+        return api.with_lengthscale(_random_kernel(api, rng, depth - 1, periodic_ok), float(0.4 + 2 * rng.random()))
+    if op == 3:
+        return api.TransformedKernel(_random_kernel(api, rng, depth - 1, periodic_ok), api.ScaleTransform(float(0.3 + rng.random())))
+    if op == 4 and periodic_ok:
+        # everything below reads the 2-D image of the point: no second PeriodicTransform there
+        return api.TransformedKernel(_random_kernel(api, rng, depth - 1, False), api.PeriodicTransform(float(0.3 + rng.random())))
+    if op == 5:
+        return api.ConstantKernel(float(0.1 + rng.random()))
+    return leaves[rng.integers(len(leaves))]()
+
+
+@pytest.mark.parametrize("seed", range(200, 260))
+def test_random_kernel_expression_expands_to_the_same_matrix(seed):
+    ko = _random_kernel(models.oracle_api(), np.random.default_rng(seed), 1 + seed % 4, True)
+    kp = _random_kernel(models.product_api(), np.random.default_rng(seed), 1 + seed % 4, True)
+    rng = np.random.default_rng(30_000 + seed)
+    x = rng.standard_normal(6)
+    x[4] = x[1]                                  # a repeated point: WhiteKernel's delta off the diagonal
+    z = np.concatenate([rng.standard_normal(3), x[:2]])
+    f = P.atomic(P.GP(kp), P.GPC())
+    Ko = okf.kernelmatrix(ko, x)
+    Kp = np_terms.dense_from_spec(P.build_spec(f, x)[0])
+    scale = max(1.0, float(np.abs(Ko).max()))
+    np.testing.assert_allclose(Kp, Ko, rtol=1e-11, atol=1e-12 * scale)
+    Kxo = okf.kernelmatrix(ko, x, z)
+    Kxp = np_terms.dense_from_spec(P.build_spec(f, x, f, z)[0])
+    np.testing.assert_allclose(Kxp, Kxo, rtol=1e-11, atol=1e-12 * scale)
