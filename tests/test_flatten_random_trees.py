@@ -174,3 +174,40 @@ def test_random_kernel_expression_expands_to_the_same_matrix(seed):
     Kxo = okf.kernelmatrix(ko, x, z)
     Kxp = np_terms.dense_from_spec(P.build_spec(f, x, f, z)[0])
     np.testing.assert_allclose(Kxp, Kxo, rtol=1e-11, atol=1e-12 * scale)
+
+
+# ---- the whole host mirror on random programmes (library = the NumPy double of its C-ABI, tests/np_capi.py) ---------
+@pytest.mark.parametrize("seed", range(300, 325))
+def test_random_programme_logpdf_posterior_and_gradient_through_the_host_mirror(seed, monkeypatch):
+    import np_capi
+    import oracle.abstractgps as oagp
+    np_capi.install(monkeypatch)
+    n_atoms, n_ops = 2 + seed % 3, 3 + seed % 6
+    fo, go = _build(models.oracle_api(), seed, n_atoms, n_ops)
+    fp, gp = _build(models.product_api(), seed, n_atoms, n_ops)
+    names = list(fo)
+    rng = np.random.default_rng(40_000 + seed)
+    xs = [rng.standard_normal(3 + (i + seed) % 4) for i in range(len(names))]
+    xo = ost.BlockData([ost.GPPPInput(k, x) for k, x in zip(names, xs)])
+    xp = P.BlockData([P.GPPPInput(k, x) for k, x in zip(names, xs)])
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    N = sum(len(x) for x in xs)
+    y = rng.standard_normal(N)
+    noise = 0.3 + rng.random(N)
+    lo, lp = oagp.logpdf(Fo(xo, noise), y), P.logpdf(Fp(xp, noise), y)
+    assert abs(lp - lo) <= 1e-9 * max(1.0, abs(lo))
+    k = names[-1]
+    t = rng.standard_normal(4)
+    po, pp = oagp.posterior(Fo(xo, noise), y), P.posterior(Fp(xp, noise), y)
+    mo, vo = po.mean_and_var(ost.GPPPInput(k, t))
+    mp, vp = pp.mean_and_var(P.GPPPInput(k, t))
+    np.testing.assert_allclose(mp, mo, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(vp, vo, rtol=1e-8, atol=1e-9)
+    # the gradient records: d logpdf / d (a common factor on every coefficient) = sum_t coef_t d_coef_t, against a
+    # finite difference of the product's own logpdf with the whole covariance scaled
+    g = P.logpdf_and_gradient(Fp(xp, noise), y)
+    lhs = sum(r["coef"] * r["d_coef"] for r in g["terms"])
+    _, alpha, Gm = oagp.logpdf_gradient_wrt_cov(Fo(xo, noise), y)
+    rhs = float((Gm * Fo.cov(xo)).sum())          # d logpdf / d s at s = 1 for C = s K + Sigma_y
+    assert abs(lhs - rhs) <= 1e-7 * max(1.0, abs(rhs)), (lhs, rhs)
+    np.testing.assert_allclose(g["y"], -alpha, rtol=1e-8, atol=1e-9)
