@@ -647,13 +647,21 @@ class ApproxPosteriorGP:
         return self._predict(xs, False, True, False)[1]
 
     def cov(self, xs, zs=None):
-        if zs is not None:
-            raise NotImplementedError
-        return self._predict(xs, False, False, True)[2]
+        if zs is None:
+            return self._predict(xs, False, False, True)[2]
+        # cov(post, x*, z*): the off-diagonal block of the joint covariance over [x*; z*] (as PosteriorGP.cov)
+        joint = self._predict(BlockData([xs, zs]) if not isinstance(xs, BlockData) else _concat(xs, zs),
+                              False, False, True)[2]
+        nx = len(xs)
+        return joint[:nx, nx:]
 
     def mean_and_var(self, xs):
         m, v, _ = self._predict(xs, True, True, False)
         return m, v
+
+    def mean_and_cov(self, xs):
+        m, _, c = self._predict(xs, True, False, True)
+        return m, c
 
 
 def posterior_vfe(vfe, fx, y):

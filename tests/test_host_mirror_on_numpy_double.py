@@ -50,3 +50,26 @@ def test_double_is_installed_and_the_product_has_no_cpu_path_of_its_own():
     f = P.atomic(P.GP(P.SEKernel()), P.GPC())
     K = P.prior_cov(f, x)
     assert np.allclose(K, np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2), rtol=0, atol=1e-15)
+
+
+def test_sparse_posterior_cross_covariance_and_mean_and_cov():
+    """cov(post, x*, z*) and mean_and_cov of the VFE posterior (AbstractGPs ApproxPosteriorGP [EXT]): the off-diagonal
+    block of the joint posterior covariance, against the oracle's joint."""
+    import oracle.abstractgps as oagp
+    import oracle.stheno as ost
+    import stheno_jl_amd as P
+    import models
+    rng = np.random.default_rng(77)
+    fo, go = models.gppp_docstring(models.oracle_api())
+    fp, gp = models.gppp_docstring(models.product_api())
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    x, z, y = rng.standard_normal(40), rng.standard_normal(9), rng.standard_normal(40)
+    a, b = rng.standard_normal(5), rng.standard_normal(4)
+    po = oagp.posterior_vfe(oagp.VFE(Fo(ost.GPPPInput("f3", z), 1e-6)), Fo(ost.GPPPInput("f3", x), 0.2), y)
+    pp = P.posterior(P.VFE(Fp(P.GPPPInput("f3", z), 1e-6)), Fp(P.GPPPInput("f3", x), 0.2), y)
+    joint = po.cov(ost.BlockData([ost.GPPPInput("f1", a), ost.GPPPInput("f3", b)]))
+    got = pp.cov(P.GPPPInput("f1", a), P.GPPPInput("f3", b))
+    np.testing.assert_allclose(got, joint[:5, 5:], rtol=1e-9, atol=1e-10)
+    m, c = pp.mean_and_cov(P.GPPPInput("f3", b))
+    np.testing.assert_allclose(m, po.mean(ost.GPPPInput("f3", b)), rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(c, po.cov(ost.GPPPInput("f3", b)), rtol=1e-9, atol=1e-10)
