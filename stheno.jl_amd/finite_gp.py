@@ -436,8 +436,11 @@ def posterior(fx, y, y_vfe=None):
         n1, n2 = len(p1.x), len(fx)
         a1, a2 = np.asarray(p1.noise, dtype=np.float64), np.asarray(fx.noise, dtype=np.float64)
         if a1.ndim > 1 or a2.ndim > 1:
-            raise NotImplementedError("sequential conditioning with dense observation noise")
-        if a1.ndim == 0 and a2.ndim == 0 and float(a1) == float(a2):
+            # a dense Sigma_y on either side: the stacked observation noise is block diagonal (dense noise kind)
+            noise = np.zeros((n1 + n2, n1 + n2))
+            noise[:n1, :n1] = _noise_dense(a1, n1)
+            noise[n1:, n1:] = _noise_dense(a2, n2)
+        elif a1.ndim == 0 and a2.ndim == 0 and float(a1) == float(a2):
             noise = float(a1)
         else:
             noise = np.concatenate([_noise_diag(a1, n1), _noise_diag(a2, n2)])

@@ -73,3 +73,23 @@ def test_sparse_posterior_cross_covariance_and_mean_and_cov():
     m, c = pp.mean_and_cov(P.GPPPInput("f3", b))
     np.testing.assert_allclose(m, po.mean(ost.GPPPInput("f3", b)), rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(c, po.cov(ost.GPPPInput("f3", b)), rtol=1e-9, atol=1e-10)
+
+
+def test_sequential_conditioning_with_dense_observation_noise():
+    """posterior(f_post(x2, Sigma2), y2) with matrix-valued Sigma_y (AbstractGPs FiniteGP noise kinds, A1): the product
+    conditions the prior once on the stacked data with the block-diagonal noise; the oracle conditions twice."""
+    import oracle.abstractgps as oagp
+    import oracle.kernelfunctions as okf
+    import oracle.stheno as ost
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(5150)
+    f_o, f_p = ost.atomic(oagp.GP(okf.Matern52Kernel()), ost.GPC()), P.atomic(P.GP(P.Matern52Kernel()), P.GPC())
+    a, b, c = rng.standard_normal(12), rng.standard_normal(8), rng.standard_normal(5)
+    ya, yb = rng.standard_normal(12), rng.standard_normal(8)
+    A1 = rng.standard_normal((12, 12))
+    S1 = A1 @ A1.T / 12 + 0.2 * np.eye(12)
+    for S2 in (0.3, 0.1 + rng.random(8)):
+        qo = oagp.posterior(oagp.posterior(f_o(a, S1), ya)(b, S2), yb)
+        qp = P.posterior(P.posterior(f_p(a, S1), ya)(b, S2), yb)
+        np.testing.assert_allclose(qp.mean(c), qo.mean(c), rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(qp.cov(c), qo.cov(c), rtol=1e-9, atol=1e-10)
