@@ -141,5 +141,19 @@ def mauna_loa(api):
     return {"trend": trend, "co2": co2, "T": temp, "per": per, "per2": per2}, gpc
 
 
+def sensor_fusion(api):
+    """examples/sensor_fusion/script.jl:33-45: a latent process seen through two sensors -- white noise with a known,
+    input-dependent mean (`GP + function`, addition.jl:73-86) and white noise with a constant bias."""
+    gpc = api.GPC()
+    f = api.atomic(api.GP(api.SEKernel()), gpc)
+    noise1 = np.sqrt(1e-2) * api.atomic(api.GP(api.WhiteKernel()), gpc) + (lambda x: float(np.sin(x) - 5.0 + np.sqrt(abs(x))))
+    noise2 = np.sqrt(1e-1) * api.atomic(api.GP(3.5, api.WhiteKernel()), gpc)
+    return {"f": f, "noise1": noise1, "noise2": noise2, "y1": f + noise1, "y2": f + noise2}, gpc
+
+
+# recipes that so far only the CPU suites use (flattening against the recursion, the host mirror on the NumPy double);
+# they join RECIPES_1D -- and with it the -m gpu covariance tests -- once they have run on the device
+RECIPES_1D_CPU_ONLY = [sensor_fusion]
+
 RECIPES_1D = [gppp_docstring, toy_gppp, correlated_sums, warped, composite_kernels, periodic_model, mauna_loa]
 RECIPES_ND = [gppp_docstring, correlated_sums, scaled, warped_colvecs, composite_kernels]

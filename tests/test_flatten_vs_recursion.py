@@ -31,7 +31,7 @@ def _mean_close(a, b):
     np.testing.assert_allclose(a, b, rtol=1e-13, atol=1e-13)
 
 
-@pytest.mark.parametrize("recipe", models.RECIPES_1D, ids=lambda r: r.__name__)
+@pytest.mark.parametrize("recipe", models.RECIPES_1D + models.RECIPES_1D_CPU_ONLY, ids=lambda r: r.__name__)
 def test_gppp_blockdata_1d(recipe):
     rng = np.random.default_rng(123456)
     fo, go, fp, gp = _pair(recipe)

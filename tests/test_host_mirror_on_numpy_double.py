@@ -118,3 +118,31 @@ def test_differentiation_example_known_answer():
         assert np.linalg.norm(m - dfn(x_pred)) <= 1e-5 * np.linalg.norm(dfn(x_pred))
         # the derivative process is (nearly) deterministic given f on a dense grid: tiny posterior variance
         assert np.max(post.var(P.GPPPInput("df", x_pred))) < 1e-3
+
+
+def test_sensor_fusion_example_posterior():
+    """examples/sensor_fusion/script.jl:33-66: observe y1 (3 points) and y2 (10 points), predict f, y1, y2 jointly --
+    posterior mean / var / joint cov over a BlockData of three processes and a sample from it, against the oracle."""
+    import models
+    import oracle.abstractgps as oagp
+    import oracle.stheno as ost
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(123456)
+    fo, go = models.sensor_fusion(models.oracle_api())
+    fp, gp = models.sensor_fusion(models.product_api())
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    x1, x2 = np.sort(rng.random(3) * 10), np.sort(rng.random(10) * 10)
+    xo = ost.BlockData([ost.GPPPInput("y1", x1), ost.GPPPInput("y2", x2)])
+    xp = P.BlockData([P.GPPPInput("y1", x1), P.GPPPInput("y2", x2)])
+    Z = rng.standard_normal(13)
+    y = P.rand(None, Fp(xp), Z=Z)                                     # a draw from the model (default noise 1e-18)
+    np.testing.assert_allclose(y, oagp.rand(Fo(xo), Z), rtol=1e-9, atol=1e-9)
+    po, pp = oagp.posterior(Fo(xo), y), P.posterior(Fp(xp), y)
+    t = np.linspace(-2.5, 12.5, 40)
+    tq_o = ost.BlockData([ost.GPPPInput(k, t) for k in ("f", "y1", "y2")])
+    tq_p = P.BlockData([P.GPPPInput(k, t) for k in ("f", "y1", "y2")])
+    np.testing.assert_allclose(pp.mean(tq_p), po.mean(tq_o), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(pp.var(tq_p), po.var(tq_o), rtol=1e-7, atol=1e-7)
+    np.testing.assert_allclose(pp.cov(tq_p), po.cov(tq_o), rtol=1e-7, atol=1e-7)
+    parts = P.split(tq_p, pp.mean(tq_p))
+    assert [len(a) for a in parts] == [40, 40, 40]
