@@ -151,9 +151,20 @@ def sensor_fusion(api):
     return {"f": f, "noise1": noise1, "noise2": noise2, "y1": f + noise1, "y2": f + noise2}, gpc
 
 
+def time_varying_blr(api):
+    """examples/time_varying_blr/script.jl:22-29: time-varying basis functions times slowly varying GP weights plus
+    rough temporally correlated noise (function-scaled processes, product.jl:25-48)."""
+    gpc = api.GPC()
+    w1 = api.stretch(api.atomic(api.GP(api.SEKernel()), gpc), 0.2)
+    w2 = api.stretch(api.atomic(api.GP(api.SEKernel()), gpc), 1.0)
+    f = (lambda x: float(np.sum(x)) / 4) * w1 + (lambda x: float(np.sum(np.cos(x)))) * w2
+    y = f + 0.3 * api.atomic(api.GP(api.Matern12Kernel()), gpc)
+    return {"w1": w1, "w2": w2, "f": f, "y": y}, gpc
+
+
 # recipes that so far only the CPU suites use (flattening against the recursion, the host mirror on the NumPy double);
 # they join RECIPES_1D -- and with it the -m gpu covariance tests -- once they have run on the device
-RECIPES_1D_CPU_ONLY = [sensor_fusion]
+RECIPES_1D_CPU_ONLY = [sensor_fusion, time_varying_blr]
 
 RECIPES_1D = [gppp_docstring, toy_gppp, correlated_sums, warped, composite_kernels, periodic_model, mauna_loa]
 RECIPES_ND = [gppp_docstring, correlated_sums, scaled, warped_colvecs, composite_kernels]

@@ -146,3 +146,30 @@ def test_sensor_fusion_example_posterior():
     np.testing.assert_allclose(pp.cov(tq_p), po.cov(tq_o), rtol=1e-7, atol=1e-7)
     parts = P.split(tq_p, pp.mean(tq_p))
     assert [len(a) for a in parts] == [40, 40, 40]
+
+
+def test_time_varying_blr_example_draw_condition_and_sample_the_posterior():
+    """examples/time_varying_blr/script.jl:31-41: draw y from the model, condition on it, sample w1, w2, y jointly from
+    the posterior FiniteGP f'(xp, 1e-9) (rand of a posterior: AbstractGPs rand(::FiniteGP{<:PosteriorGP}) [EXT])."""
+    import models
+    import oracle.abstractgps as oagp
+    import oracle.stheno as ost
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(0)
+    fo, go = models.time_varying_blr(models.oracle_api())
+    fp, gp = models.time_varying_blr(models.product_api())
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    x = np.sort(rng.random(60) * 10)
+    Z = rng.standard_normal(60)
+    y = P.rand(None, Fp(P.GPPPInput("y", x)), Z=Z)
+    np.testing.assert_allclose(y, oagp.rand(Fo(ost.GPPPInput("y", x)), Z), rtol=1e-8, atol=1e-8)
+    po, pp = oagp.posterior(Fo(ost.GPPPInput("y", x)), y), P.posterior(Fp(P.GPPPInput("y", x)), y)
+    t = np.linspace(-2.5, 12.5, 30)
+    tq_o = ost.BlockData([ost.GPPPInput(k, t) for k in ("w1", "w2", "y")])
+    tq_p = P.BlockData([P.GPPPInput(k, t) for k in ("w1", "w2", "y")])
+    Z2 = rng.standard_normal((90, 3))
+    s_p, s_o = P.rand(None, pp(tq_p, 1e-9), 3, Z=Z2), oagp.rand(po(tq_o, 1e-9), Z2)
+    assert s_p.shape == (90, 3)
+    np.testing.assert_allclose(s_p, s_o, rtol=1e-5, atol=1e-5)      # Cholesky of a posterior covariance with jitter 1e-9
+    w1s, w2s, ys = P.split(tq_p, s_p)
+    assert w1s.shape == w2s.shape == ys.shape == (30, 3)
