@@ -173,3 +173,33 @@ def test_time_varying_blr_example_draw_condition_and_sample_the_posterior():
     np.testing.assert_allclose(s_p, s_o, rtol=1e-5, atol=1e-5)      # Cholesky of a posterior covariance with jitter 1e-9
     w1s, w2s, ys = P.split(tq_p, s_p)
     assert w1s.shape == w2s.shape == ys.shape == (30, 3)
+
+
+def test_process_decomposition_example_marginals_of_the_posterior():
+    """examples/process_decomposition/script.jl:24-52: observe f1 and f3 = f1 + f2, then `marginals(f_post(xp, 1e-9))`
+    over a BlockData of all three processes, split back per process (mean.(ms), std.(ms))."""
+    import models
+    import oracle.abstractgps as oagp
+    import oracle.stheno as ost
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(123546)
+    fo, go = models.gppp_docstring(models.oracle_api())
+    fp, gp = models.gppp_docstring(models.product_api())
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    x1, x3 = np.sort(rng.random(10) * 10), np.sort(rng.random(11) * 10)
+    xo = ost.BlockData([ost.GPPPInput("f1", x1), ost.GPPPInput("f3", x3)])
+    xp = P.BlockData([P.GPPPInput("f1", x1), P.GPPPInput("f3", x3)])
+    y = oagp.rand(Fo(xo, 1e-6), rng.standard_normal(21))
+    y1, y3 = P.split(xp, y)
+    assert len(y1) == 10 and len(y3) == 11
+    po, pp = oagp.posterior(Fo(xo, 1e-6), y), P.posterior(Fp(xp, 1e-6), y)
+    t = np.linspace(-2.5, 12.5, 50)
+    tq_o = ost.BlockData([ost.GPPPInput(k, t) for k in ("f1", "f2", "f3")])
+    tq_p = P.BlockData([P.GPPPInput(k, t) for k in ("f1", "f2", "f3")])
+    ms = P.marginals(pp(tq_p, 1e-9))
+    mo, so = oagp.marginals(po(tq_o, 1e-9))
+    mean_p, std_p = np.array([d.mu for d in ms]), np.array([d.sigma for d in ms])       # mean.(ms), std.(ms)
+    np.testing.assert_allclose(mean_p, mo, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(std_p, so, rtol=1e-5, atol=1e-6)
+    m1, m2, m3 = P.split(tq_p, mean_p)
+    np.testing.assert_allclose(m1 + m2, m3, rtol=0, atol=1e-6)          # the decomposition: E[f3 | y] = E[f1 | y] + E[f2 | y]
