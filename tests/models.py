@@ -162,9 +162,17 @@ def time_varying_blr(api):
     return {"w1": w1, "w2": w2, "f": f, "y": y}, gpc
 
 
+def pseudo_points(api):
+    """examples/gppp_and_pseudo_points/script.jl:9-13: f1 = periodic(GP(SE), w), f2 = GP(0.1 * SE), f3 = f1 + f2."""
+    gpc = api.GPC()
+    f1 = api.periodic(api.atomic(api.GP(api.SEKernel()), gpc), 1.0)
+    f2 = api.atomic(api.GP(api.ScaledKernel(api.SEKernel(), 0.1)), gpc)
+    return {"f1": f1, "f2": f2, "f3": f1 + f2}, gpc
+
+
 # recipes that so far only the CPU suites use (flattening against the recursion, the host mirror on the NumPy double);
 # they join RECIPES_1D -- and with it the -m gpu covariance tests -- once they have run on the device
-RECIPES_1D_CPU_ONLY = [sensor_fusion, time_varying_blr]
+RECIPES_1D_CPU_ONLY = [sensor_fusion, time_varying_blr, pseudo_points]
 
 RECIPES_1D = [gppp_docstring, toy_gppp, correlated_sums, warped, composite_kernels, periodic_model, mauna_loa]
 RECIPES_ND = [gppp_docstring, correlated_sums, scaled, warped_colvecs, composite_kernels]

@@ -203,3 +203,40 @@ def test_process_decomposition_example_marginals_of_the_posterior():
     np.testing.assert_allclose(std_p, so, rtol=1e-5, atol=1e-6)
     m1, m2, m3 = P.split(tq_p, mean_p)
     np.testing.assert_allclose(m1 + m2, m3, rtol=0, atol=1e-6)          # the decomposition: E[f3 | y] = E[f1 | y] + E[f2 | y]
+
+
+def test_gppp_and_pseudo_points_example_inducing_points_in_the_marginal_and_in_the_latents():
+    """examples/gppp_and_pseudo_points/script.jl:44-77: pseudo-points placed in the observed process f3, and in the two
+    latent processes f1 and f2 (a BlockData of inducing inputs): elbo and the approximate posterior over all three
+    processes, against the oracle; the bound sits below the exact logpdf in both placements."""
+    import models
+    import oracle.abstractgps as oagp
+    import oracle.stheno as ost
+    import stheno_jl_amd as P
+    rng = np.random.default_rng(123456)
+    fo, go = models.pseudo_points(models.oracle_api())
+    fp, gp = models.pseudo_points(models.product_api())
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    T = 25.0
+    x = np.linspace(0.0, T, 120)
+    y = oagp.rand(Fo(ost.GPPPInput("f3", x), 1.0), rng.standard_normal(120))
+    fxo, fxp = Fo(ost.GPPPInput("f3", x), 1.0), Fp(P.GPPPInput("f3", x), 1.0)
+    lp = P.logpdf(fxp, y)
+    assert abs(lp - oagp.logpdf(fxo, y)) <= 1e-9 * abs(lp)
+    t = np.linspace(-2.5, T + 2.5, 35)
+    tq_o = ost.BlockData([ost.GPPPInput(k, t) for k in ("f1", "f2", "f3")])
+    tq_p = P.BlockData([P.GPPPInput(k, t) for k in ("f1", "f2", "f3")])
+    placements = [
+        (ost.GPPPInput("f3", np.linspace(0, T, 25)), P.GPPPInput("f3", np.linspace(0, T, 25))),
+        (ost.BlockData([ost.GPPPInput("f1", np.linspace(0, T, 15)), ost.GPPPInput("f2", np.linspace(0, T, 10))]),
+         P.BlockData([P.GPPPInput("f1", np.linspace(0, T, 15)), P.GPPPInput("f2", np.linspace(0, T, 10))])),
+    ]
+    for zo, zp in placements:
+        eo, ep = oagp.elbo(oagp.VFE(Fo(zo, 1e-9)), fxo, y), P.elbo(P.VFE(Fp(zp, 1e-9)), fxp, y)
+        assert abs(ep - eo) <= 1e-7 * abs(eo) and ep <= lp + 1e-9
+        qo = oagp.posterior_vfe(oagp.VFE(Fo(zo, 1e-9)), fxo, y)
+        qp = P.posterior(P.VFE(Fp(zp, 1e-9)), fxp, y)
+        mo, vo = qo.mean_and_var(tq_o)
+        mp, vp = qp.mean_and_var(tq_p)
+        np.testing.assert_allclose(mp, mo, rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(vp, vo, rtol=1e-6, atol=1e-6)
