@@ -1,4 +1,4 @@
-"""Chooses the SGP_FUSE_POTRF value for the rest of tools/r02_run6.sh from the A/B lines and the bit-identity
+"""Chooses the SGP_FUSE_POTRF value for the rest of tools/r02_pass10.sh from the A/B lines and the bit-identity
 test log: a fused variant is eligible only if tests/test_gpu_fused_potrf.py passed and every line of it holds
 parity (< 1e-10 against the CPU goldens); it wins if it is faster than the separate launches at N = 16 384 and not
 slower (1 %) at the small sizes.  Prints the reasoning, then the chosen value on the last line.

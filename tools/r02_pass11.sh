@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU pass 7 (one gpurun call, ~4 min): the new defaults (fused launches below 32768, one panel up to 4096, panel wave
+# GPU pass 11 (one gpurun call, ~4 min): the new defaults (fused launches below 32768, one panel up to 4096, panel wave
 # priority 3) through the whole -m gpu suite; A/B of the one-Newton-step pivot chain (libsthenomi_n1.so swapped in);
 # panel width at N = 8192; fused launches at c3; profiles of c1 / n4k / c2 with the new defaults.
 R=${GRAFT_REPO_ROOT:-/root/repo}

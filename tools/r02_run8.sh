@@ -1,26 +1,15 @@
 #!/bin/bash
-# GPU pass 8 (~3 min): at N >= 32768, is the serial schedule (no look-ahead: every kernel has the chip to itself) with
-# the fused update + potrf_diag launches as fast as the two-stream look-ahead?  Alternating repetitions (boxes drift).
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r02h
 mkdir -p $OUT
+cd $R
+timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "rc=$?" >> $OUT/pytest.log
+tail -6 $OUT/pytest.log
 cd /tmp && export TMPDIR=/tmp
-one() {  # env config steps
-  echo -n "$1 $2 "
-  env $1 timeout 120 python $R/bench.py --config $2 --steps $3 --warmup 1 --cpu-sample 0 --no-host-api 2>>$OUT/bench_err.log \
-    | python -c "import sys,json; d=json.loads(sys.stdin.read()); r=d.get('roofline') or {}; print(round(d['ms_per_step'],3), d['parity_rel'], r.get('frac'), r.get('achieved_while_busy'))" 2>/dev/null || echo "FAILED"
-}
-{
-for rep in 1 2; do
-  one "X=default" c5 3
-  one "SGP_LOOKAHEAD=0" c5 3
-  one "SGP_LOOKAHEAD=0 SGP_FUSE_POTRF=15" c5 3
-done
-one "X=default" c3 5
-one "SGP_LOOKAHEAD=0 SGP_FUSE_POTRF=15" c3 5
-one "SGP_LOOKAHEAD=0" c3 5
-one "X=default" target 3
-one "SGP_LOOKAHEAD=0 SGP_FUSE_POTRF=15" target 3
-one "SGP_LOOKAHEAD=0 SGP_FUSE_POTRF=15 SGP_WOUT=2048" c5 3
-one "SGP_LOOKAHEAD=0 SGP_FUSE_POTRF=15 SGP_WOUT=512" c5 3
-} | tee $OUT/serial.txt
+one() { echo -n "$1 $2 " ; env $1 timeout 300 python $R/bench.py --config $2 --steps $3 --warmup 3 --cpu-sample 0 --no-host-api 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],3), d['parity_rel'], round(d['roofline']['frac'],3))"; }
+for c in c1 n4k c2; do one X=1 $c 30; done | tee $OUT/dpp.txt
+one X=1 c5 3 | tee -a $OUT/dpp.txt
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c1 -o c1 -- python $R/bench.py --config c1 --steps 10 --warmup 2 --cpu-sample 0 --no-host-api > /dev/null 2>&1
+f=$(find $OUT/prof_c1 -name "*kernel_stats.csv" | head -1); head -5 $f
+timeout 200 python $R/tools/gpu_illcond.py 2>&1 | grep -v amdgpu | tail -12
+rm -f $OUT/*/*/*kernel_trace.csv $OUT/*/*kernel_trace.csv
