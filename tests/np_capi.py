@@ -172,6 +172,18 @@ class FakeLib:
         _vec(out, s.N)[:] = np.diag(s.dense())
         return 0
 
+    # -- fp32 instantiation (sthenomi.h:145-152): the double computes in fp64 and rounds the result, which is inside
+    #    every fp32 tolerance; what it serves is the host mirror's Float32 tagging / type stability ------------------
+    def sgp_kernelmatrix_f32(self, ctx, spec, K, ldk):
+        s = _Spec(spec)
+        flat = np.ctypeslib.as_array(K, shape=(int(ldk) * s.M,))
+        flat.reshape((s.M, int(ldk)))[:, : s.N].T[:, :] = s.dense().astype(np.float32)
+        return 0
+
+    def sgp_logpdf_f32(self, ctx, spec, mean, kind, noise, y, out):
+        s = _Spec(spec)
+        return self.sgp_logpdf(ctx, spec, mean, kind, noise, y, s.N, 1, out)
+
     # -- the observation model C = K + Sigma_y ---------------------------------------------------------
     def _observed(self, spec, mean, kind, noise):
         s = _Spec(spec)

@@ -42,6 +42,14 @@ for _name in _REUSED:
     globals()[_name] = getattr(G, _name)
 del _name
 
+# Float32 tagging and type stability of the host mirror (test/gp/util.jl:76-88): the bodies of tests/test_gpu_f32.py
+import test_gpu_f32 as F32  # noqa: E402
+
+for _name in ("test_logpdf_f32_single_gp", "test_logpdf_f32_gppp_blocks_diag_noise_and_means", "test_cov_and_mean_f32",
+              "test_posdef_failure_f32"):
+    globals()[_name] = getattr(F32, _name)
+del _name
+
 
 def test_double_is_installed_and_the_product_has_no_cpu_path_of_its_own():
     import stheno_jl_amd as P
