@@ -296,26 +296,19 @@ def main():
         }
         # HBM traffic cannot be read from inside the process (it needs rocprofv3 --pmc passes): `traffic` is the
         # committed per-launch average of exactly this command under the FETCH_SIZE / WRITE_SIZE passes
-        # (tools/collect_traffic.sh -> profiles/r02_update_traffic.json), null for configurations not profiled;
+        # (tools/collect_traffic.sh -> profiles/r03_update_traffic.json), null for configurations not profiled;
         # the PMC passes of one representative launch shape are attached as well.
-        tr_file = os.path.join(ROOT, "profiles", "r02_update_traffic.json")
-        if os.path.exists(tr_file):
-            rec = json.load(open(tr_file)).get(args.config)
-            if rec and serial and "look-ahead" in rec.get("schedule", ""):
-                # the committed passes profiled the look-ahead schedule (125 launches per step); the serial schedule
-                # runs the same tiles with the same depth in 63 launches, so the per-STEP traffic carries over but no
-                # per-launch figure was measured for it: `traffic` stays null, the passes are attached as they are
-                roofline["traffic_previous_schedule"] = rec
-                if n_launch > 0 and rec.get("per_step_bytes"):
-                    # same tiles, same depth, merged launches: the per-step sum spread over this schedule's launches
-                    # (a derived figure, labelled as such; `traffic` itself stays null until the passes are re-run)
-                    roofline["traffic_derived_from_previous_schedule"] = rec["per_step_bytes"] / n_launch
-                roofline["traffic_note"] = ("FETCH_SIZE / WRITE_SIZE passes exist for the look-ahead schedule only: %.2f TB per step "
-                                            "(2.94 x the algorithmic bytes); not re-collected for the one-launch-per-panel schedule"
-                                            % (rec.get("per_step_bytes", 0.0) / 1e12))
-            elif rec:
+        for tr_name in ("r03_update_traffic.json", "r02_update_traffic.json"):
+            tr_file = os.path.join(ROOT, "profiles", tr_name)
+            rec = json.load(open(tr_file)).get(args.config) if os.path.exists(tr_file) else None
+            if not rec:
+                continue
+            # a record only counts for the schedule it was collected under (serial = one launch per outer panel)
+            rec_serial = rec.get("schedule", "").startswith("serial")
+            if rec_serial == serial:
                 roofline["traffic"] = rec["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = rec
+                roofline["traffic_source"] = dict(rec, file="profiles/" + tr_name)
+                break
         roofline["algorithmic_bytes_per_launch_avg"] = update_bytes_avg(N)
         for pmc_name in ("r02_gemm_pmc.json", "r01_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)

@@ -53,6 +53,7 @@ struct Rccl {
   int (*GroupStart)() = nullptr;
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
+  int (*CommCount)(ncclComm_p, int*) = nullptr;
   bool load() {
     if (h) return true;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -67,6 +68,7 @@ struct Rccl {
     GroupStart = (decltype(GroupStart))dlsym(h, "ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
     GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
+    CommCount = (decltype(CommCount))dlsym(h, "ncclCommCount");
     return CommInitAll && CommDestroy && Broadcast && AllReduce && GroupStart && GroupEnd;
   }
 };
@@ -85,6 +87,9 @@ struct Rank {
   hipStream_t s_pool[NPOOL] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_pool[NPOOL] = {nullptr, nullptr, nullptr}, ev_fork = nullptr;
   hipEvent_t ev_upd = nullptr, ev_fact = nullptr, ev_recv[2] = {nullptr, nullptr}, ev_done = nullptr;
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // timing events: first / last trailing update of a call (sgp_ctx_multi_stats)
+  double upd_flops = 0.0, upd_span_ms = 0.0, recv_bytes = 0.0;
+  long n_factored = 0;
   bool factored_once = false;
   double* store = nullptr;       // owned panels, packed
   size_t store_cap = 0;
@@ -162,7 +167,7 @@ void sgp_multi_destroy(sgp_multi* m) {
     if (k.d_small) hipFree(k.d_small);
     if (k.d_info) hipFree(k.d_info);
     for (hipEvent_t e : {k.ev_upd, k.ev_fact, k.ev_recv[0], k.ev_recv[1], k.ev_done, k.ev_fork, k.ev_pool[0], k.ev_pool[1],
-                         k.ev_pool[2]})
+                         k.ev_pool[2], k.ev_t0, k.ev_t1})
       if (e) hipEventDestroy(e);
     for (auto st : k.s_pool)
       if (st) {
@@ -221,6 +226,7 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(-2);
     for (auto& st : k.s_pool)
       if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(-2);
+    if (hipEventCreate(&k.ev_t0) != hipSuccess || hipEventCreate(&k.ev_t1) != hipSuccess) return fail(-2);
     if (hipMalloc(&k.d_info, sizeof(int)) != hipSuccess) return fail(-2);
   }
   if (m->transport == TR_P2P || m->transport == TR_RCCL) {
