@@ -12,8 +12,13 @@ N ranks (stheno.jl_amd/dist.py) -- strong scaling.  --config picks the other BAS
 N = 65536, D = 8).
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus 8 --steps 3 --warmup 1          # ONE process, 8 GPUs: the in-library multi-GPU context
+                                                         # (sgp_ctx_create_multi: what the Julia `ccall` reaches)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
-         --master-port 29501 bench.py --gpus 8 --steps 3 --warmup 1
+         --master-port 29501 bench.py --gpus 8 --steps 3 --warmup 1     # one process per GPU (stheno.jl_amd/dist.py)
+
+--gpus N never runs on fewer than N GPUs: without WORLD_SIZE it builds the N-device context and exits non-zero when
+fewer devices are visible; under torch.distributed.run WORLD_SIZE must equal N.
 
 Prints ONE JSON line on rank 0 (contract in the round prompt) carrying, next to the contract's keys:
   parity_rel   |value - CPU golden| / |golden| for the configuration that ran (tests/golden/)
@@ -81,6 +86,31 @@ def update_bytes_avg(N):
     return tot / max(1, cnt)
 
 
+def resolve_devices(gpus, devices_arg, device_count, world):
+    """Which GPUs an in-process (WORLD_SIZE unset) run uses: `--devices a,b,..` verbatim (a device may repeat: several
+    ranks on one GPU, the 1-GPU test hook), else 0 .. gpus-1.  Raises SystemExit -- never falls back to fewer GPUs."""
+    if world > 1:
+        if devices_arg:
+            raise SystemExit("--devices is for the in-process multi-GPU context; under torch.distributed.run each rank "
+                             "takes LOCAL_RANK")
+        if gpus != world:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}")
+        return None
+    if devices_arg:
+        devs = [int(d) for d in devices_arg.split(",") if d.strip() != ""]
+        if len(devs) != gpus:
+            raise SystemExit(f"--gpus {gpus} but --devices lists {len(devs)} entries")
+    else:
+        devs = list(range(gpus))
+    if device_count <= 0:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    bad = [d for d in devs if d < 0 or d >= device_count]
+    if bad:
+        raise SystemExit(f"--gpus {gpus} needs devices {devs} but only {device_count} GPU(s) are visible: refusing to "
+                         f"run on fewer GPUs than asked for (launch on a node with {max(devs) + 1} GPUs)")
+    return devs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -91,6 +121,9 @@ def main():
                     help="N of the bounded CPU-baseline sample (0 = skip; ELBO: 2x this many data points)")
     ap.add_argument("--panel", type=int, default=1024, help="column-panel width of the multi-GPU path")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded (multi-GPU) driver even at 1 GPU")
+    ap.add_argument("--devices", default=os.environ.get("SGP_BENCH_DEVICES", ""),
+                    help="in-process multi-GPU context over exactly these devices, e.g. 0,1,2,3 (a repeated device = "
+                         "several ranks on one GPU: loopback test configuration)")
     ap.add_argument("--no-host-api", action="store_true", help="skip the host-buffer C-ABI leg")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"],
                     help="f32: the fp32 instantiation (sgp_logpdf_f32, host-buffer entry point; 1 GPU, dense configs)")
@@ -113,10 +146,15 @@ def main():
         local_rank = int(os.environ["SGP_FORCE_DEVICE"])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    devs = resolve_devices(args.gpus, args.devices, torch.cuda.device_count(), world)
+    inproc = devs is not None and (len(devs) > 1 or bool(args.devices))   # one process, sgp_ctx_create_multi
+    if inproc:
+        local_rank = devs[0]
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    if inproc and (use_dist or args.dtype != "f64"):
+        raise SystemExit("--gpus N > 1 without torch.distributed.run is the in-process fp64 context: not with "
+                         "--force-dist / --dtype f32")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -135,7 +173,13 @@ def main():
     is_elbo = kind == "elbo"
     if is_elbo and use_dist:
         raise SystemExit("config c4 (ELBO) is a single-GPU bench line")
-    ctx = L.default_context() if is_elbo else L.Context(local_rank)
+    if inproc:
+        ctx = L.Context(devices=devs)
+        if ctx.ndev != len(devs):
+            raise SystemExit(f"multi-GPU context reports {ctx.ndev} ranks, asked for {len(devs)}")
+        L.set_default_context(ctx)
+    else:
+        ctx = L.default_context() if is_elbo else L.Context(local_rank)
     lib = ctx.lib
     sigma2 = bc.SIGMA2
     spec = None if is_elbo else pkg.build_spec(w["f"], w["x"])[0]
@@ -143,6 +187,9 @@ def main():
     def sync():
         if use_dist:
             dist.barrier()
+        if inproc:
+            for d in sorted(set(devs)):
+                torch.cuda.synchronize(d)
         torch.cuda.synchronize()
 
     timings = np.zeros(8)
@@ -168,6 +215,16 @@ def main():
         def step(tm=None):
             L.check(lib.sgp_logpdf_f32(ctx.handle, spec.ref(), None, L.NOISE_SCALAR, L.dptr(nz), L.dptr(yh), L.dptr(out)),
                     "sgp_logpdf_f32")
+            return float(out[0])
+    elif inproc:
+        # the host-buffer entry point on the multi-GPU context: exactly the call the Julia shim makes
+        yh = np.ascontiguousarray(y)
+        out = np.zeros(1)
+        nz = np.array([sigma2])
+
+        def step(tm=None):
+            L.check(lib.sgp_logpdf(ctx.handle, spec.ref(), None, L.NOISE_SCALAR, L.dptr(nz), L.dptr(yh), N, 1, L.dptr(out)),
+                    "sgp_logpdf (multi-GPU context)")
             return float(out[0])
     elif not use_dist:
         ds = C.c_void_p()
@@ -257,7 +314,31 @@ def main():
                     "frac": whole_tflops / PEAK_F32, "traffic": None,
                     "note": "whole-step N^3/3 rate of the fp32 path (host-buffer entry point; panel chain in fp64 arithmetic "
                             "on fp32 storage, two-stream look-ahead)"}
-    if not use_dist and not is_elbo and args.dtype == "f64":
+    multi = None
+    if inproc:
+        st = np.zeros(8 + 4 * len(devs))
+        nst = C.c_int64()
+        L.check(lib.sgp_ctx_multi_stats(ctx.handle, L.dptr(st), len(st), C.byref(nst)), "sgp_ctx_multi_stats")
+        P_ = len(devs)
+        per_rank = [{"rank": i, "device": devs[i], "update_flops": st[8 + 4 * i], "update_span_ms": st[9 + 4 * i],
+                     "update_tflops": (st[8 + 4 * i] / (st[9 + 4 * i] * 1e-3) / 1e12) if st[9 + 4 * i] > 0 else None,
+                     "panels_factored": int(st[10 + 4 * i]), "bytes_received": st[11 + 4 * i]} for i in range(P_)]
+        multi = {"driver": "in-process: sgp_ctx_create_multi + sgp_logpdf / sgp_elbo (one host thread, one C-ABI call)",
+                 "devices": devs, "ranks": int(st[0]), "transport": ctx.transport,
+                 "rccl_ranks": int(st[3]) if st[3] >= 0 else None,
+                 "peer_copy_form": ("scatter + all-gather" if st[6] else "direct") if ctx.transport in ("p2p", "loopback") else None,
+                 "panel_width": int(st[4]), "panels": int(st[5]), "last_call_ms": st[1], "per_rank": per_rank}
+        if not is_elbo:
+            tf = [r["update_tflops"] for r in per_rank if r["update_tflops"]]
+            per_gpu = whole_tflops / len(set(devs))
+            roofline = {"kernel": "sgp::gemm_nt_dma_kernel<1> (per-panel trailing updates of the in-library column-panel driver)",
+                        "bound": "mfma", "achieved": per_gpu, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": per_gpu / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                        "per_rank_update_tflops": [r["update_tflops"] for r in per_rank],
+                        "note": "achieved = whole-step N^3/3 rate per physical GPU of the sharded run (panel factorisations "
+                                "and transport included); per_rank_update_tflops = each rank's trailing-update flops / the "
+                                "span from its first to its last update (HIP events)" + ("" if tf else " (no updates ran)")}
+    if not use_dist and not inproc and not is_elbo and args.dtype == "f64":
         step(timings)
         upd_ms, n_launch, upd_flops = timings[3], int(timings[4]), timings[5]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
@@ -319,7 +400,7 @@ def main():
         stages = {"assemble_ms": timings[0], "cholesky_ms": timings[1], "finalize_ms": timings[2],
                   "kernelmatrix_GBps": asm_bytes / (timings[0] * 1e-3) / 1e9,
                   "kernelmatrix_frac_of_hbm_peak": asm_bytes / (timings[0] * 1e-3) / 1e9 / PEAK_HBM_GBS}
-    if use_dist and not is_elbo:
+    if use_dist and not inproc and not is_elbo:
         # the per-launch HIP-event instrument lives in the 1-GPU driver; the sharded run reports its whole-step rate
         per_gpu = whole_tflops / world
         roofline = {"kernel": "sgp::gemm_nt_dma_kernel<1> (per-panel trailing updates of the column-panel driver)",
@@ -343,19 +424,24 @@ def main():
         gval = None if g is None else g.get("elbo" if is_elbo else "logpdf")
         parity = None if gval is None else abs(val - gval) / abs(gval)   # (fp32 lines: fp32 accuracy, ~1e-6)
         cpu = None
-        if args.cpu_sample > 0 and world == 1:
+        if args.cpu_sample > 0 and world == 1 and not inproc:
             cpu = cpu_baseline(args.config, args.cpu_sample * (2 if is_elbo else 1))
         line = {
             "metric": "elbo_per_sec" if is_elbo else "logpdf_per_sec",
-            "value": 1e3 / ms_per_step, "unit": "elbo/s" if is_elbo else "logpdf/s", "n_gpus": world,
+            "value": 1e3 / ms_per_step, "unit": "elbo/s" if is_elbo else "logpdf/s",
+            "n_gpus": len(devs) if inproc else world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": bc.describe(args.config) + (", host-buffer C-ABI" if is_elbo else ""),
                        "N": N, "D": D, "kernel": kind,
-                       "parallelism": f"column-panel x{world}" if use_dist else "1 GPU",
-                       "panel_width": args.panel if use_dist else None},
+                       "parallelism": (f"in-process multi-GPU context x{len(devs)} ({'data points' if is_elbo else 'column panels'} "
+                                       f"sharded inside libsthenomi, transport {ctx.transport})" if inproc
+                                       else f"column-panel x{world}" if use_dist else "1 GPU"),
+                       "panel_width": (multi or {}).get("panel_width") if inproc else (args.panel if use_dist else None)},
             "cholesky_tflops_whole_step": whole_tflops,  # (c4: ELBO flops of SURVEY 8d)
-            "cholesky_frac_of_fp64_matrix_peak": whole_tflops / (PEAK_FP64_MFMA_TFLOPS * world) if args.dtype == "f64" else None,
+            "cholesky_frac_of_fp64_matrix_peak": (whole_tflops / (PEAK_FP64_MFMA_TFLOPS * (len(set(devs)) if inproc else world))
+                                                  if args.dtype == "f64" else None),
+            "multi_gpu": multi,
             "logpdf": val, "golden": gval, "parity_rel": parity,
             "stages": stages, "roofline": roofline, "host_api": host_api, "cpu_baseline": cpu,
         }

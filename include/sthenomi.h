@@ -98,18 +98,37 @@ typedef struct sgp_sparse_post sgp_sparse_post;
 int sgp_abi_version(void);
 /* device: HIP ordinal.  Fails (<0) when no gfx950 device is present: there is no CPU path. */
 int sgp_ctx_create(int device, sgp_ctx** out);
-/* One context over several GPUs of the node (BASELINE.json north_star): sgp_logpdf on
- * such a context shards the N x N covariance in column panels, block-cyclic over devices[0..ndev),
- * right-looking blocked Cholesky with one-panel look-ahead; factored panels travel by RCCL
- * (ncclCommInitAll inside, one grouped ncclBroadcast per panel over xGMI) or peer copies
- * (SGP_MULTI_TRANSPORT=rccl|p2p|auto), logdet and |L^-1 (y - m)|^2 by ncclAllReduce.  One host thread, one
- * `ccall`: the Julia side is unchanged.  Every other entry point runs on devices[0].  A device listed
- * several times gives that many ranks on one GPU (test configuration).  SGP_MULTI_PANEL=<cols> sets the
- * panel width (default 1024).  sgp_ctx_ndev -> number of ranks (1 for an ordinary context);
- * sgp_ctx_transport -> "single" | "rccl" | "p2p" | "loopback". */
+/* One context over several GPUs of the node (BASELINE.json north_star).  On such a context
+ *   sgp_logpdf            shards the N x N covariance in column panels, block-cyclic over devices[0..ndev):
+ *                         right-looking blocked Cholesky with one-panel look-ahead; factored panels travel by RCCL
+ *                         (ncclCommInitAll inside, one grouped ncclBroadcast per panel over xGMI) or by peer copies as
+ *                         scatter + all-gather (every receiver's ndev - 1 ingress links carry a slab each;
+ *                         SGP_MULTI_TRANSPORT=rccl|p2p|auto, SGP_MULTI_BCAST=direct for one copy owner -> receiver);
+ *                         logdet and |L^-1 (Y - m)|^2 by ncclAllReduce (or summed on the host in rank order);
+ *   sgp_posterior_create  keeps that sharded factor, sgp_posterior_predict solves K(x*, x) L^-T against it (left-looking,
+ *                         one n* x W reduction per panel) -- any number of predictions per factor;
+ *   sgp_rand              multiplies every rank's own panels of L with Z, one reduction;
+ *   sgp_elbo              shards the DATA POINTS (sgp_dev_elbo_partial per rank, ONE reduction of M^2 + M + 2 doubles).
+ * One host thread, one `ccall`: the Julia side is unchanged.  Dense Sigma_y, the gradients, the sparse posterior and
+ * the covariance entry points run on devices[0].  A device listed several times gives that many ranks on one GPU
+ * (test configuration).  SGP_MULTI_PANEL=<cols> sets the panel width (default 1024).  sgp_ctx_ndev -> number of ranks
+ * (1 for an ordinary context); sgp_ctx_transport -> "single" | "rccl" | "p2p" | "p2p-staged" (peer access missing:
+ * refused unless SGP_MULTI_ALLOW_STAGED=1) | "loopback". */
 int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out);
 int sgp_ctx_ndev(sgp_ctx* ctx);
 const char* sgp_ctx_transport(sgp_ctx* ctx);
+/* Figures of the last sharded factorisation of a multi-GPU context: out[0] ranks, [1] wall ms (enqueue to
+ * completion), [2] transport (0 loopback, 1 peer copies, 2 RCCL), [3] ranks the RCCL communicator reports (-1: none),
+ * [4] panel width, [5] panels, [6] 1 = scatter + all-gather peer copies, [7] reserved; then per rank 4 doubles:
+ * algorithmic flops of its trailing updates, ms from the start of its first to the end of its last update, panels it
+ * factored, bytes it received.  cap >= 8 + 4 * ranks; *n_out = doubles written. */
+int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out);
+/* Profile mode (enable != 0): the following sharded factorisations run SERIALISED, every group of launches alone on
+ * the hardware and timed on the host -- per panel J {factor_ms, lookahead_update_ms, panel bytes, rest_update_ms of
+ * rank 0 .. P - 1} (3 + P doubles).  With all ranks on one GPU these are the times each GPU of a node would see for
+ * its own share (tools/multi_projection.py).  _get: out may be NULL to query *n_out. */
+int sgp_ctx_multi_profile(sgp_ctx* ctx, int enable);
+int sgp_ctx_multi_profile_get(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out);
 int sgp_ctx_destroy(sgp_ctx* ctx);
 /* A ctx keeps the device workspaces of finished calls (the m_tot x n_pad factor buffer of
  * sgp_logpdf etc.) in a grow-only cache so that repeated calls of one shape do not pay

@@ -1,6 +1,7 @@
 // libsthenomi.so host driver + C ABI (include/sthenomi.h).  gfx950 only; no CPU fallback:
 // every numerical result is produced by the HIP kernels in this directory.
 #include "ctx.h"
+#include "driver.h"
 
 #include <algorithm>
 #include <cmath>
@@ -1002,8 +1003,9 @@ extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
   CHECK_ARG(spec->symmetric, "sgp_logpdf: spec must be symmetric");
   CtxScope scope(ctx);
   // a multi-GPU context (sgp_ctx_create_multi) shards the covariance over its devices
-  if (ctx->multi && ncols == 1 && noise_kind != SGP_NOISE_DENSE && noise)
-    return sgp_multi_logpdf(ctx, spec, mean, noise_kind, noise, Y, out);
+  // (dense Sigma_y is an N x N host matrix: that case stays on devices[0])
+  if (ctx->multi && ncols >= 1 && noise_kind != SGP_NOISE_DENSE && noise)
+    return sgp_multi_logpdf(ctx, spec, mean, noise_kind, noise, Y, ldy, ncols, out);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
@@ -1034,6 +1036,8 @@ extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* me
   CHECK_ARG(ctx && spec && Z && out, "sgp_rand: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_rand: spec must be symmetric");
   CtxScope scope(ctx);
+  if (ctx->multi && noise && noise_kind != SGP_NOISE_DENSE)
+    return sgp_multi_rand(ctx, spec, mean, noise_kind, noise, Z, ldz, S, out, ldo);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
@@ -1264,6 +1268,7 @@ struct sgp_post {
   long N = 0, n_pad = 0, m_tot = 0;
   double* dA = nullptr;     // L (lower tiles) + row n_pad = (L^-1 (y - m))'
   double* d_wall = nullptr; // inverse 16x16 diagonal blocks (INVD_STRIDE per 128-block)
+  sgp_mpost* mp = nullptr;  // non-null: the factor is sharded over the ranks of a multi-GPU context (multi.hip)
 };
 
 // rows <- rows * L^-T for `nrows` (multiple of 128) rows stored at R (ld = ldr), against the factor L
@@ -1345,20 +1350,23 @@ __global__ __launch_bounds__(256) void backsolve_diag_kernel(const double* invd,
   if (t < TILE) alpha[k0 + t] = as[t];
 }
 
-static int back_substitute(const sgp_post* post, double* d_z /*n_pad, overwritten*/,
-                           double* d_alpha, hipStream_t s) {
-  for (long k0 = post->n_pad - TILE; k0 >= 0; k0 -= TILE) {
-    if (k0 + TILE < post->n_pad) {
-      hipLaunchKernelGGL(backsolve_gemvt_kernel, dim3(TILE), dim3(256), 0, s, post->dA, post->m_tot,
-                         k0, post->n_pad, d_alpha, d_z);
+static int back_substitute_range(const double* Lv, long ld, const double* wall_v, long k_first, long k_last,
+                                 long n_end, double* d_z, double* d_alpha, hipStream_t s) {
+  for (long k0 = k_first; k0 >= k_last; k0 -= TILE) {
+    if (k0 + TILE < n_end) {
+      hipLaunchKernelGGL(backsolve_gemvt_kernel, dim3(TILE), dim3(256), 0, s, Lv, ld, k0, n_end, d_alpha, d_z);
       SGP_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(backsolve_diag_kernel, dim3(1), dim3(256), 0, s,
-                       post->d_wall + (k0 / TILE) * INVD_STRIDE, post->dA + k0 + k0 * post->m_tot,
-                       post->m_tot, d_z, d_alpha, k0);
+    hipLaunchKernelGGL(backsolve_diag_kernel, dim3(1), dim3(256), 0, s, wall_v + (k0 / TILE) * INVD_STRIDE,
+                       Lv + k0 + k0 * ld, ld, d_z, d_alpha, k0);
     SGP_HIP(hipGetLastError());
   }
   return 0;
+}
+static int back_substitute(const sgp_post* post, double* d_z /*n_pad, overwritten*/,
+                           double* d_alpha, hipStream_t s) {
+  return back_substitute_range(post->dA, post->m_tot, post->d_wall, post->n_pad - TILE, 0, post->n_pad, d_z, d_alpha,
+                               s);
 }
 
 __global__ void copy_strided_kernel(const double* src, long lds, long n, double* dst) {
@@ -1368,6 +1376,7 @@ __global__ void copy_strided_kernel(const double* src, long lds, long n, double*
 
 extern "C" int sgp_posterior_destroy(sgp_post* p) {
   if (!p) return 0;
+  if (p->mp) sgp_multi_posterior_destroy(p->mp);
   if (p->dA) hipFree(p->dA);
   if (p->d_wall) hipFree(p->d_wall);
   delete p;
@@ -1380,6 +1389,15 @@ extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, cons
   CHECK_ARG(ctx && spec && y && out, "sgp_posterior_create: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_posterior_create: spec must be symmetric");
   CtxScope scope(ctx);
+  if (ctx->multi && noise && noise_kind != SGP_NOISE_DENSE) {
+    sgp_mpost* mp = nullptr;
+    CHECK_RC(sgp_multi_posterior_create(ctx, spec, mean, noise_kind, noise, y, alpha_out, &mp));
+    sgp_post* post = new sgp_post();
+    post->ctx = ctx;
+    post->mp = mp;
+    *out = post;
+    return 0;
+  }
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
@@ -1482,6 +1500,7 @@ extern "C" int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross,
   CHECK_ARG(post && cross, "sgp_posterior_predict: NULL argument");
   sgp_ctx* ctx = post->ctx;
   CtxScope scope(ctx);
+  if (post->mp) return sgp_multi_posterior_predict(post->mp, cross, prior_ss, mean_s, mean_out, var_out, cov_out, ldcov);
   SpecGuard gc, gp;
   CHECK_RC(dspec_create(ctx, cross, &gc.ds));
   if (prior_ss) CHECK_RC(dspec_create(ctx, prior_ss, &gp.ds));
@@ -1956,6 +1975,8 @@ extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
                         const double* y, double* out) {
   CHECK_ARG(ctx && zz && xz && var_x && noise_x && z_noise && y && out, "sgp_elbo: NULL argument");
   CtxScope scope(ctx);
+  if (ctx->multi && ctx->multi_nranks > 1)   // data points sharded over the ranks, one reduction of M^2 + M + 2 doubles
+    return sgp_multi_elbo(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, out);
   double h[6];
   CHECK_RC(vfe_pipeline(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, h,
                         nullptr));
@@ -2696,3 +2717,67 @@ extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int
   hipEventDestroy(e1);
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------
+// driver.h: the routines above for the multi-GPU driver (multi.hip)
+// ---------------------------------------------------------------------------------------
+__global__ void axpy_block_kernel(double* C, long ldc, const double* S, long lds, long nr, long nc, double a) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= nr * nc) return;
+  const long r = idx % nr, c = idx / nr;
+  C[r + c * ldc] += a * S[r + c * lds];
+}
+
+namespace sgp {
+int drv_assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long tile_r_hi, long tile_c_lo,
+                 long tile_c_hi, int lower_only, int noise_kind, double sigma2, const double* d_noise_diag,
+                 hipStream_t s) {
+  return assemble(ds, Kv, ld, tile_r_lo, tile_r_hi, tile_c_lo, tile_c_hi, lower_only, noise_kind, sigma2,
+                  d_noise_diag, s);
+}
+int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_logdet, int* d_info,
+                     double* d_invstore, hipStream_t s) {
+  CHECK_ARG(w % TILE == 0 && m % TILE == 0 && m >= w, "drv_panel_factor: bad sizes");
+  FuseScope fuse_scope(ctx, fuse_mode(ctx, m));
+  CHECK_RC(panel_factor(ctx, P, ld, m, w, g0, ctx->d_slots, d_info, d_invstore, s));
+  CHECK_RC(launch_sum_array(ctx->d_slots, w / TILE, ctx->d_scal + 8, s));
+  hipLaunchKernelGGL(accum_kernel, dim3(1), dim3(1), 0, s, d_logdet, ctx->d_scal + 8);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+int drv_row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl, const double* d_invall,
+                 long n, hipStream_t s) {
+  return row_trsm(ctx, R, ldr, nrows, L, ldl, d_invall, n, s);
+}
+int drv_back_substitute(const double* Lv, long ld, const double* wall_v, long k_first, long k_last, long n_end,
+                        double* d_z, double* d_alpha, hipStream_t s) {
+  return back_substitute_range(Lv, ld, wall_v, k_first, k_last, n_end, d_z, d_alpha, s);
+}
+int drv_diag_of_spec(sgp_ctx* ctx, const sgp_dspec* ds, double* d_out, hipStream_t s) {
+  return diag_of_spec(ctx, ds, d_out, s);
+}
+int drv_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out) { return dspec_create(ctx, sp, out); }
+void drv_dspec_free(sgp_dspec* ds) { dspec_free(ds); }
+long drv_invd_stride() { return INVD_STRIDE; }
+int drv_copy_strided(const double* src, long stride, long n, double* dst, hipStream_t s) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(copy_strided_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, src, stride, n, dst);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+int drv_axpy_block(double* C, long ldc, const double* S, long lds, long nr, long nc, double a, hipStream_t s) {
+  if (nr <= 0 || nc <= 0) return 0;
+  hipLaunchKernelGGL(axpy_block_kernel, dim3((unsigned)((nr * nc + 255) / 256)), dim3(256), 0, s, C, ldc, S, lds, nr, nc,
+                     a);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+int drv_fill_mean_cols(double* dst, long ld, long nrows, long ncols, long N, const double* mean, hipStream_t s) {
+  if (nrows <= 0 || ncols <= 0) return 0;
+  hipLaunchKernelGGL(fill_mean_cols_kernel, dim3((unsigned)((nrows * ncols + 255) / 256)), dim3(256), 0, s, dst, ld,
+                     nrows, ncols, N, mean);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+long drv_vfe_part_len(long m_pad) { return vfe_part_len(m_pad); }
+}  // namespace sgp

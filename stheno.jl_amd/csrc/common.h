@@ -144,6 +144,8 @@ int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, con
                        hipStream_t s);
 int launch_gemm_nt_lz(const double* L, long ldl, const double* Zt, long ldz, double* C, long ldc, long n,
                       long ns, double beta, hipStream_t s);
+int launch_gemm_nt_lz_k(const double* L, long ldl, const double* Zt, long ldz, double* C, long ldc, long n,
+                        long ns, long K, double beta, hipStream_t s);
 int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, hipStream_t s);
 int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
                           long M, long Nc, long K, int nsplit, long part_stride, int lower_only,

@@ -20,12 +20,26 @@ struct sgp_pool_block {
 
 struct sgp_multi;   // multi.hip: the ranks of a multi-GPU context
 void sgp_multi_destroy(sgp_multi* m);
+struct sgp_mpost;   // multi.hip: a kept sharded factor (posterior on a multi-GPU context)
+// the operators of a multi-GPU context (multi.hip), called from the C-ABI entry points with the primary context held
 int sgp_multi_logpdf(struct sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
-                     const double* noise, const double* y, double* out);
+                     const double* noise, const double* Y, int64_t ldy, int64_t ncols, double* out);
+int sgp_multi_rand(struct sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                   const double* noise, const double* Z, int64_t ldz, int64_t S, double* out, int64_t ldo);
+int sgp_multi_posterior_create(struct sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                               const double* noise, const double* y, double* alpha_out, sgp_mpost** out);
+int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const sgp_cov_spec* prior_ss,
+                                const double* mean_s, double* mean_out, double* var_out, double* cov_out,
+                                int64_t ldcov);
+void sgp_multi_posterior_destroy(sgp_mpost* mp);
+int sgp_multi_elbo(struct sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                   const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                   const double* z_noise, const double* y, double* out);
 
 struct sgp_ctx {
   int device = 0;
-  sgp_multi* multi = nullptr;     // non-null: sgp_logpdf shards over several GPUs (sgp_ctx_create_multi)
+  sgp_multi* multi = nullptr;     // non-null: the operators shard over several GPUs (sgp_ctx_create_multi)
+  int multi_nranks = 0;
   hipStream_t stream = nullptr;   // panel / critical-path stream (high priority)
   hipStream_t stream2 = nullptr;  // trailing-update stream (look-ahead overlap)
   // CU reservation for the panel chain: stream2m is an update stream whose CU mask leaves `reserve_cu` CUs of

@@ -1,0 +1,39 @@
+// Internal entry points of the single-GPU driver (capi.hip) used by the multi-GPU driver (multi.hip): the same
+// routines the C-ABI entry points are built from, without locking (the caller serialises: one host thread per
+// multi-GPU call) and on an explicit stream.  Not part of the ABI.
+#pragma once
+#include "ctx.h"
+
+namespace sgp {
+
+// K(rows, cols) of `ds` restricted to the global tile window, element (r, c) at Kv[r + c * ld]
+int drv_assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long tile_r_hi, long tile_c_lo,
+                 long tile_c_hi, int lower_only, int noise_kind, double sigma2, const double* d_noise_diag,
+                 hipStream_t s);
+// sgp_dev_panel_factor that also keeps the panel's inverse 16x16 diagonal blocks (INVD_STRIDE doubles per
+// 128-block) in d_invstore (may be NULL) -- what later solves against the factor need
+int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_logdet, int* d_info,
+                     double* d_invstore, hipStream_t s);
+// R <- R L^-T for nrows (multiple of 128) rows against an n x n lower factor with its kept inverse blocks
+int drv_row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl, const double* d_invall,
+                 long n, hipStream_t s);
+// back substitution over the 128-blocks k_first, k_first - 128, ..., k_last of alpha = L^-T z:
+// element (r, c) of the factor at Lv[r + c * ld] (virtual base), inverse blocks of 128-block b at
+// wall_v + b * INVD_STRIDE; d_z / d_alpha are indexed globally, rows up to n_end are read.
+int drv_back_substitute(const double* Lv, long ld, const double* wall_v, long k_first, long k_last, long n_end,
+                        double* d_z, double* d_alpha, hipStream_t s);
+int drv_diag_of_spec(sgp_ctx* ctx, const sgp_dspec* ds, double* d_out, hipStream_t s);
+int drv_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out);   // caller holds the context
+void drv_dspec_free(sgp_dspec* ds);
+long drv_invd_stride();
+// dst[i] = src[i * stride], i < n
+int drv_copy_strided(const double* src, long stride, long n, double* dst, hipStream_t s);
+// C[r + c * ldc] += a * S[r + c * lds], nr x nc
+int drv_axpy_block(double* C, long ldc, const double* S, long lds, long nr, long nc, double a, hipStream_t s);
+// dst[i + c * ld] = mean[i] (i < N) else 0
+int drv_fill_mean_cols(double* dst, long ld, long nrows, long ncols, long N, const double* mean, hipStream_t s);
+// sparse-ELBO partial sums of a slice of the data / the final factorisation (see sgp_dev_elbo_partial / _finish);
+// keep != 0: the M x M factors stay in the caller's buffers (sparse posterior)
+long drv_vfe_part_len(long m_pad);
+
+}  // namespace sgp

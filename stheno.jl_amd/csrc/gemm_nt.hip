@@ -518,19 +518,24 @@ int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, h
 // ld ldz): rand's m + L Z, with every tile row contracting only the columns left of its diagonal
 // tile's right edge.  Tile rows are spread over all XCDs (n / 128 of them) -- the transposed
 // arrangement (ns / 128 tile rows) would leave most of the chip idle for a few hundred samples.
-int launch_gemm_nt_lz(const double* L, long ldl, const double* Zt, long ldz, double* C, long ldc, long n,
-                      long ns, double beta, hipStream_t s) {
-  if (n <= 0 || ns <= 0) return 0;
-  if (n % TILE || ns % TILE) {
-    set_error("gemm_nt_lz: n, ns must be multiples of 128");
+// _k: L is an n x K column panel of the factor (K <= n, its top K x K block the triangle): the multi-GPU rand.
+int launch_gemm_nt_lz_k(const double* L, long ldl, const double* Zt, long ldz, double* C, long ldc, long n,
+                        long ns, long K, double beta, hipStream_t s) {
+  if (n <= 0 || ns <= 0 || K <= 0) return 0;
+  if (n % TILE || ns % TILE || K % TILE) {
+    set_error("gemm_nt_lz: n, ns, K must be multiples of 128");
     return -1;
   }
   long n_tr = n / TILE, n_tc = ns / TILE;
   long groups = ((n_tr + 7) / 8 + 7) / 8;
   hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(groups * 8 * n_tc * 8)), dim3(512), 0, s, L, ldl, Zt, ldz, C,
-                     ldc, n, 1.0, beta, -(1L << 40), n_tr, n_tc, 0L, (const double*)C, ldc, 2);
+                     ldc, K, 1.0, beta, -(1L << 40), n_tr, n_tc, 0L, (const double*)C, ldc, 2);
   SGP_HIP(hipGetLastError());
   return 0;
+}
+int launch_gemm_nt_lz(const double* L, long ldl, const double* Zt, long ldz, double* C, long ldc, long n,
+                      long ns, double beta, hipStream_t s) {
+  return launch_gemm_nt_lz_k(L, ldl, Zt, ldz, C, ldc, n, ns, n, beta, s);
 }
 
 // Cpart[s] = A[:, sK' : (s+1)K'] B[:, sK' : (s+1)K']'  for s < nsplit (K' = K / nsplit, a multiple of

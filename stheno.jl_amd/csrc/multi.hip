@@ -1,29 +1,45 @@
-// In-process multi-GPU logpdf behind the C-ABI: sgp_ctx_create_multi(devices, ndev, &ctx) returns an
-// ordinary sgp_ctx whose sgp_logpdf shards the N x N covariance over the listed GPUs,
-// so that ONE `ccall` from the Julia host reaches the whole node.  The reference has no distributed
-// code; the contract is BASELINE.json's north_star.
+// In-process multi-GPU operators behind the C-ABI: sgp_ctx_create_multi(devices, ndev, &ctx) returns an ordinary
+// sgp_ctx whose sgp_logpdf / sgp_posterior_create + _predict / sgp_rand / sgp_elbo shard their work over the
+// listed GPUs, so that ONE `ccall` from the Julia host reaches the whole node.  The reference
+// has no distributed code; the contract is BASELINE.json's north_star.
 //
-// Layout: outer column panels of W columns, block-cyclic over the ranks (= devices); every rank keeps
-// its panels PACKED (panel J holds rows J0 .. m_tot only, leading dimension m_tot - J0), so a factored
-// panel is one contiguous block that travels as is -- no packing copy.  Right-looking blocked Cholesky
-// with one-panel look-ahead, driven by one host thread that only enqueues (three streams per rank:
+// Dense operators (logpdf, posterior, rand) -- layout: outer column panels of W columns, block-cyclic over the
+// ranks (= devices); every rank keeps its panels PACKED (panel J holds rows J0 .. m_tot only, leading dimension
+// m_tot - J0), so a factored panel is one contiguous block that travels as is -- no packing copy.  Right-looking
+// blocked Cholesky with one-panel look-ahead, driven by one host thread that only enqueues (streams per rank:
 // trailing updates / panel factorisation at high priority / panel receive):
-//   step J:  every rank updates its panels > J + 1 with panel J (update stream) while the owner of
-//            panel J + 1 updates + factors it (panel stream) and the transport moves it to the others'
-//            receive buffers (double-buffered), overlapping the updates of step J.
-// Transport (SGP_MULTI_TRANSPORT=rccl|p2p|auto): RCCL ncclBroadcast in one group call per panel over
-// communicators from ncclCommInitAll (xGMI rings; librccl is dlopen'ed here, not linked), or plain
-// peer copies (hipMemcpyPeerAsync: xGMI point to point, one link per receiver).  A device listed more
-// than once gives several ranks on one GPU ("loopback": same-device copies) -- that is how the 1-GPU
-// test box exercises the multi-rank orchestration with the real kernels.
-// Scalars (logdet, |L^-1 (y - m)|^2) are all-reduced (ncclAllReduce) or summed on the host.
-#include "ctx.h"
+//   step J:  every rank updates its panels > J + 1 with panel J (update streams) while the owner of panel J + 1
+//            updates + factors it (panel stream) and the transport moves it to the others' receive buffers
+//            (double-buffered), overlapping the updates of step J.
+// Transport (SGP_MULTI_TRANSPORT=rccl|p2p|auto): RCCL ncclBroadcast in one group call per panel over communicators
+// from ncclCommInitAll (librccl is dlopen'ed here, not linked), or peer copies.  xGMI is point to point (one link
+// per GPU pair), so a plain owner -> receiver copy is bound by ONE link per receiver: the peer-copy transport moves
+// a panel as scatter + all-gather -- the owner sends each of the P - 1 peers a different 1 / (P - 1) slab, the
+// peers then exchange slabs among themselves -- so that all P - 1 ingress links of every receiver carry traffic
+// (SGP_MULTI_BCAST=direct restores the one-link form).  A device listed more than once gives several ranks on one
+// GPU ("loopback": same-device copies) -- that is how the 1-GPU test box exercises the multi-rank orchestration,
+// both broadcast forms included, with the real kernels.
+// Scalars (logdet, |L^-1 (y - m)|^2 per column) are all-reduced (ncclAllReduce) or summed on the host in rank order.
+//
+// posterior: the sharded factor is KEPT (with the inverse diagonal blocks of every panel) so that repeated
+// predictions run against it: K(x*, x) is assembled column-sharded like the factor, V' = K(x*, x) L^-T by a
+// left-looking sweep -- every rank forms the partial sums of its own panels, the owner of panel J collects them
+// (P - 1 messages of n* x W doubles), subtracts in rank order and solves against its diagonal block -- and
+// mean* - m* = V' z, var*, cov* are sums over columns, i.e. one small reduction over ranks.  alpha = L^-T z by a
+// panel-wise back substitution (one W-vector broadcast per panel).
+// rand: m + L Z = sum over panels of L[:, J] Z[J, :]: every rank multiplies its own panels, one reduction.
+// elbo: the data points are sharded (contiguous slices), every rank turns its slice into a "part" (see
+// sgp_dev_elbo_partial) on a host thread of its own, ONE reduction of M^2 + M + 2 doubles, rank 0 finishes.
+#include "driver.h"
 
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <thread>
 
 using namespace sgp;
 
@@ -87,19 +103,28 @@ struct Rank {
   hipStream_t s_pool[NPOOL] = {nullptr, nullptr, nullptr};
   hipEvent_t ev_pool[NPOOL] = {nullptr, nullptr, nullptr}, ev_fork = nullptr;
   hipEvent_t ev_upd = nullptr, ev_fact = nullptr, ev_recv[2] = {nullptr, nullptr}, ev_done = nullptr;
-  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // timing events: first / last trailing update of a call (sgp_ctx_multi_stats)
+  // scatter + all-gather panel transport: one incoming stream per source rank, one "piece landed" event per
+  // (receive buffer, source), one "buffer free" event per receive buffer
+  std::vector<hipStream_t> s_in;
+  std::vector<hipEvent_t> ev_in[2];
+  hipEvent_t ev_free[2] = {nullptr, nullptr};
+  hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // timing: first / last trailing update of a call (sgp_ctx_multi_stats)
+  bool t0_set = false;
   double upd_flops = 0.0, upd_span_ms = 0.0, recv_bytes = 0.0;
   long n_factored = 0;
   bool factored_once = false;
-  double* store = nullptr;       // owned panels, packed
+  double* store = nullptr;       // owned panels of a transient factorisation, packed (grow-only)
   size_t store_cap = 0;
   double* buf[2] = {nullptr, nullptr};
   size_t buf_cap = 0;
-  double* d_small = nullptr;     // y (N) | mean (N) | noise diag (N) | scal: logdet, sq
+  double* d_small = nullptr;     // Y | mean | noise diag | scalars
   size_t small_cap = 0;
+  double* d_work = nullptr;      // grow-only scratch of the operators on top of a factor (predict, rand, elbo)
+  size_t work_cap = 0;
+  double* d_work2 = nullptr;
+  size_t work2_cap = 0;
   int* d_info = nullptr;
   ncclComm_p comm = nullptr;
-  std::vector<size_t> off;       // offset of local panel i in store
 };
 
 }  // namespace
@@ -107,9 +132,15 @@ struct Rank {
 struct sgp_multi {
   std::vector<Rank> r;
   int transport = TR_LOOPBACK;
+  bool allgather = true;    // peer-copy transport: scatter + all-gather (false: one copy owner -> receiver)
+  bool peer_ok = true;      // every distinct device pair has peer access enabled (else copies stage through the host)
   long W = 1024;
   Rccl rccl;
   double last_ms = 0.0;
+  long last_npan = 0;
+  // profile mode (sgp_ctx_multi_profile): the factorisation runs serialised, every group of launches timed alone
+  int profile = 0;
+  std::vector<double> prof;   // per panel J: factor_ms, lookahead_update_ms, panel bytes, rest_update_ms[rank 0..P)
 };
 
 namespace {
@@ -138,13 +169,73 @@ int grow(double** p, size_t* cap, size_t need) {
   return 0;
 }
 
+inline long rup(long x, long m) { return (x + m - 1) / m * m; }
+
 struct Geometry {
-  long N, n_pad, m_tot, W, npan, P;
+  long N = 0, n_pad = 0, m_tot = 0, W = 0, npan = 0, P = 1, S = 0;
   long col0(long J) const { return J * W; }
   long width(long J) const { return std::min(W, n_pad - J * W); }
   long ldp(long J) const { return m_tot - J * W; }          // packed leading dimension of panel J
   int owner(long J) const { return (int)(J % P); }
+  long local(long J) const { return J / P; }
+  long ncols_owned(int i) const {
+    long t = 0;
+    for (long J = i; J < npan; J += P) t += width(J);
+    return t;
+  }
 };
+
+Geometry make_geometry(const sgp_multi* m, long N, long S) {
+  Geometry g;
+  int64_t n_pad, m_tot;
+  sgp_geometry(N, S, &n_pad, &m_tot);
+  g.N = N;
+  g.S = S;
+  g.n_pad = n_pad;
+  g.m_tot = m_tot;
+  g.W = std::min<long>(m->W, n_pad);
+  g.npan = (n_pad + g.W - 1) / g.W;
+  g.P = (long)m->r.size();
+  return g;
+}
+
+// one sharded factorisation: per rank the base of its packed panels, their offsets and (kept factors only) the
+// inverse diagonal blocks of every owned panel
+struct Fact {
+  Geometry g;
+  std::vector<double*> base;
+  std::vector<std::vector<size_t>> off;
+  std::vector<double*> inv;   // [P] or empty
+  long inv_per_panel = 0;
+  double* panel(int i, long J) const { return base[i] + off[i][g.local(J)]; }
+  double* invp(int i, long J) const { return inv.empty() ? nullptr : inv[i] + g.local(J) * inv_per_panel; }
+};
+
+size_t plan_offsets(const Geometry& g, int i, std::vector<size_t>& off) {
+  off.clear();
+  size_t tot = 0;
+  for (long J = i; J < g.npan; J += g.P) {
+    off.push_back(tot);
+    tot += (size_t)g.ldp(J) * g.width(J);
+  }
+  return tot;
+}
+
+double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int sync_all(sgp_multi* m) {
+  for (auto& k : m->r) {
+    M_HIP(hipSetDevice(k.dev));
+    M_HIP(hipDeviceSynchronize());
+  }
+  return 0;
+}
+
+double update_flops(long mrows, long nc, long k) {
+  return (double)k * (double)nc * (double)(nc + 1) + 2.0 * (double)k * (double)(mrows - nc) * (double)nc;
+}
 
 }  // namespace
 
@@ -165,11 +256,21 @@ void sgp_multi_destroy(sgp_multi* m) {
     for (auto b : k.buf)
       if (b) hipFree(b);
     if (k.d_small) hipFree(k.d_small);
+    if (k.d_work) hipFree(k.d_work);
+    if (k.d_work2) hipFree(k.d_work2);
     if (k.d_info) hipFree(k.d_info);
     for (hipEvent_t e : {k.ev_upd, k.ev_fact, k.ev_recv[0], k.ev_recv[1], k.ev_done, k.ev_fork, k.ev_pool[0], k.ev_pool[1],
-                         k.ev_pool[2], k.ev_t0, k.ev_t1})
+                         k.ev_pool[2], k.ev_t0, k.ev_t1, k.ev_free[0], k.ev_free[1]})
       if (e) hipEventDestroy(e);
+    for (auto& v : k.ev_in)
+      for (auto e : v)
+        if (e) hipEventDestroy(e);
     for (auto st : k.s_pool)
+      if (st) {
+        hipStreamSynchronize(st);
+        hipStreamDestroy(st);
+      }
+    for (auto st : k.s_in)
       if (st) {
         hipStreamSynchronize(st);
         hipStreamDestroy(st);
@@ -186,6 +287,7 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   M_RC(sgp_ctx_create(devices[0], &primary));
   sgp_multi* m = new sgp_multi();
   primary->multi = m;
+  primary->multi_nranks = ndev;
   auto fail = [&](int rc) {
     sgp_ctx_destroy(primary);   // destroys m as well
     return rc;
@@ -209,6 +311,8 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     } else
       m->transport = TR_P2P;
   }
+  const char* bc = getenv("SGP_MULTI_BCAST");
+  m->allgather = !(bc && !strcmp(bc, "direct"));
   const char* pw = getenv("SGP_MULTI_PANEL");
   if (pw && atol(pw) >= TILE) m->W = atol(pw) / TILE * TILE;
   m->r.resize(ndev);
@@ -222,10 +326,18 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     if (hipSetDevice(k.dev) != hipSuccess) return fail(-2);
     if (hipStreamCreateWithFlags(&k.s_comm, hipStreamNonBlocking) != hipSuccess) return fail(-2);
     for (hipEvent_t* e : {&k.ev_upd, &k.ev_fact, &k.ev_recv[0], &k.ev_recv[1], &k.ev_done, &k.ev_fork, &k.ev_pool[0],
-                          &k.ev_pool[1], &k.ev_pool[2]})
+                          &k.ev_pool[1], &k.ev_pool[2], &k.ev_free[0], &k.ev_free[1]})
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(-2);
     for (auto& st : k.s_pool)
       if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(-2);
+    k.s_in.assign(ndev, nullptr);
+    for (int b = 0; b < 2; ++b) k.ev_in[b].assign(ndev, nullptr);
+    for (int q = 0; q < ndev; ++q) {
+      if (q == i) continue;
+      if (hipStreamCreateWithFlags(&k.s_in[q], hipStreamNonBlocking) != hipSuccess) return fail(-2);
+      for (int b = 0; b < 2; ++b)
+        if (hipEventCreateWithFlags(&k.ev_in[b][q], hipEventDisableTiming) != hipSuccess) return fail(-2);
+    }
     if (hipEventCreate(&k.ev_t0) != hipSuccess || hipEventCreate(&k.ev_t1) != hipSuccess) return fail(-2);
     if (hipMalloc(&k.d_info, sizeof(int)) != hipSuccess) return fail(-2);
   }
@@ -234,13 +346,25 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
       for (int j = 0; j < ndev; ++j) {
         if (i == j) continue;
         int can = 0;
-        hipDeviceCanAccessPeer(&can, devices[i], devices[j]);
+        if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) != hipSuccess) can = 0;
         if (can) {
           hipSetDevice(devices[i]);
           hipError_t e = hipDeviceEnablePeerAccess(devices[j], 0);
-          if (e != hipSuccess) (void)hipGetLastError();   // already enabled is fine
+          if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) can = 0;
+          (void)hipGetLastError();
         }
+        if (!can) m->peer_ok = false;
       }
+    // a node without peer access between its GPUs would run every panel through host memory: say so
+    // instead of silently being an order of magnitude slower (SGP_MULTI_ALLOW_STAGED=1 accepts it)
+    if (!m->peer_ok && m->transport == TR_P2P) {
+      const char* ok = getenv("SGP_MULTI_ALLOW_STAGED");
+      if (!(ok && atoi(ok))) {
+        set_error("sgp_ctx_create_multi: peer access between the listed GPUs is not available and RCCL could not be "
+                  "loaded: panel copies would be staged through host memory (SGP_MULTI_ALLOW_STAGED=1 to accept)");
+        return fail(-3);
+      }
+    }
   }
   if (m->transport == TR_RCCL) {
     std::vector<ncclComm_p> comms(ndev, nullptr);
@@ -252,6 +376,8 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     }
     for (int i = 0; i < ndev; ++i) m->r[i].comm = comms[i];
   }
+  const char* pf = getenv("SGP_MULTI_PROFILE");
+  if (pf) m->profile = atoi(pf);
   hipSetDevice(devices[0]);
   *out = primary;
   return 0;
@@ -261,21 +387,82 @@ extern "C" const char* sgp_ctx_transport(sgp_ctx* ctx) {
   if (!ctx || !ctx->multi) return "single";
   switch (ctx->multi->transport) {
     case TR_RCCL: return "rccl";
-    case TR_P2P: return "p2p";
+    case TR_P2P: return ctx->multi->peer_ok ? "p2p" : "p2p-staged";
     default: return "loopback";
   }
 }
 
+// out[0] = ranks, [1] = wall ms of the last sharded factorisation (enqueue to completion), [2] = transport
+// (0 loopback, 1 peer copies, 2 RCCL), [3] = ranks the RCCL communicator reports (-1: none), [4] = panel width,
+// [5] = panels, [6] = 1 if the peer-copy transport runs scatter + all-gather, [7] = reserved; then per rank 4
+// doubles: algorithmic flops of its trailing updates, ms from its first update's start to its last update's end,
+// panels factored, bytes received.
+extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out) {
+  M_CHECK_ARG(ctx && out && n_out, "sgp_ctx_multi_stats: NULL argument");
+  M_CHECK_ARG(ctx->multi, "sgp_ctx_multi_stats: not a multi-GPU context");
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  M_CHECK_ARG(cap >= 8 + 4 * P, "sgp_ctx_multi_stats: buffer too small (8 + 4 * ranks doubles)");
+  out[0] = P;
+  out[1] = m->last_ms;
+  out[2] = m->transport;
+  out[3] = -1;
+  if (m->transport == TR_RCCL && m->rccl.CommCount && m->r[0].comm) {
+    int c = -1;
+    if (m->rccl.CommCount(m->r[0].comm, &c) == 0) out[3] = c;
+  }
+  out[4] = (double)m->W;
+  out[5] = (double)m->last_npan;
+  out[6] = m->allgather ? 1 : 0;
+  out[7] = 0;
+  for (int i = 0; i < P; ++i) {
+    out[8 + 4 * i] = m->r[i].upd_flops;
+    out[9 + 4 * i] = m->r[i].upd_span_ms;
+    out[10 + 4 * i] = (double)m->r[i].n_factored;
+    out[11 + 4 * i] = m->r[i].recv_bytes;
+  }
+  *n_out = 8 + 4 * P;
+  return 0;
+}
+
+// Profile mode: the next sharded factorisations run SERIALISED -- every group of launches (the look-ahead update
+// and factorisation of a panel on its owner; each rank's remaining trailing updates) alone on the hardware and
+// timed with the host clock around a device synchronisation.  With several ranks on one GPU (loopback) these are
+// the times each GPU of a real node would see for its own share; tools/multi_projection.py turns them into a
+// critical-path projection.  sgp_ctx_multi_profile_get: per panel J  {factor_ms, lookahead_update_ms, panel bytes,
+// rest_update_ms[0 .. P)}  (3 + P doubles).
+extern "C" int sgp_ctx_multi_profile(sgp_ctx* ctx, int enable) {
+  M_CHECK_ARG(ctx && ctx->multi, "sgp_ctx_multi_profile: not a multi-GPU context");
+  ctx->multi->profile = enable ? 1 : 0;
+  ctx->multi->prof.clear();
+  return 0;
+}
+extern "C" int sgp_ctx_multi_profile_get(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out) {
+  M_CHECK_ARG(ctx && ctx->multi && n_out, "sgp_ctx_multi_profile_get: bad argument");
+  const auto& v = ctx->multi->prof;
+  *n_out = (int64_t)v.size();
+  if (out) {
+    M_CHECK_ARG(cap >= (int64_t)v.size(), "sgp_ctx_multi_profile_get: buffer too small");
+    std::copy(v.begin(), v.end(), out);
+  }
+  return 0;
+}
+
 namespace {
 
+// ---- panel transport ----------------------------------------------------------------------------------
 // move factored panel J from its owner to every other rank's receive buffer (J % 2)
-int broadcast_panel(sgp_multi* m, const Geometry& g, long J) {
+int broadcast_panel(sgp_multi* m, const Fact& F, long J) {
+  const Geometry& g = F.g;
   const int o = g.owner(J);
   const size_t count = (size_t)g.ldp(J) * g.width(J);
   const int P = (int)m->r.size();
+  const int b = (int)(J % 2);
   if (P == 1 && m->transport != TR_RCCL) return 0;
   Rank& root = m->r[o];
-  double* src = root.store + root.off[J / g.P];
+  double* src = F.panel(o, J);
+  for (int i = 0; i < P; ++i)
+    if (i != o) m->r[i].recv_bytes += 8.0 * (double)count;
   if (m->transport == TR_RCCL) {
     for (int i = 0; i < P; ++i) {   // order the communicator streams behind the data / the buffer's readers
       Rank& k = m->r[i];
@@ -291,8 +478,8 @@ int broadcast_panel(sgp_multi* m, const Geometry& g, long J) {
     for (int i = 0; i < P && rc == 0; ++i) {
       Rank& k = m->r[i];
       hipSetDevice(k.dev);
-      void* recv = (i == o) ? (void*)src : (void*)k.buf[J % 2];
-      rc = m->rccl.Broadcast((i == o) ? (const void*)src : (const void*)k.buf[J % 2], recv, count, NCCL_DOUBLE, o,
+      void* recv = (i == o) ? (void*)src : (void*)k.buf[b];
+      rc = m->rccl.Broadcast((i == o) ? (const void*)src : (const void*)k.buf[b], recv, count, NCCL_DOUBLE, o,
                              k.comm, k.s_comm);
     }
     int rc2 = m->rccl.GroupEnd();
@@ -304,203 +491,404 @@ int broadcast_panel(sgp_multi* m, const Geometry& g, long J) {
     for (int i = 0; i < P; ++i) {
       Rank& k = m->r[i];
       M_HIP(hipSetDevice(k.dev));
-      M_HIP(hipEventRecord(k.ev_recv[J % 2], k.s_comm));
+      M_HIP(hipEventRecord(k.ev_recv[b], k.s_comm));
     }
     return 0;
   }
-  for (int i = 0; i < P; ++i) {
-    if (i == o) continue;
-    Rank& k = m->r[i];
-    M_HIP(hipSetDevice(k.dev));
-    M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_upd, 0));                         // readers of this buffer two panels ago
-    if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_fact, 0));   // ... on the panel stream as well
-    M_HIP(hipStreamWaitEvent(k.s_comm, root.ev_fact, 0));                     // the panel is factored
-    if (k.dev == root.dev)
-      M_HIP(hipMemcpyAsync(k.buf[J % 2], src, sizeof(double) * count, hipMemcpyDeviceToDevice, k.s_comm));
+  auto copy = [&](Rank& dst, double* d, Rank& from, const double* s, size_t n, hipStream_t st) -> int {
+    if (n == 0) return 0;
+    if (dst.dev == from.dev)
+      M_HIP(hipMemcpyAsync(d, s, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
     else
-      M_HIP(hipMemcpyPeerAsync(k.buf[J % 2], k.dev, src, root.dev, sizeof(double) * count, k.s_comm));
-    M_HIP(hipEventRecord(k.ev_recv[J % 2], k.s_comm));
+      M_HIP(hipMemcpyPeerAsync(d, dst.dev, s, from.dev, sizeof(double) * n, st));
+    return 0;
+  };
+  if (!m->allgather || P <= 2) {
+    // one copy owner -> receiver (one xGMI link per receiver)
+    for (int i = 0; i < P; ++i) {
+      if (i == o) continue;
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_upd, 0));                         // readers of this buffer two panels ago
+      if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_fact, 0));   // ... on the panel stream as well
+      M_HIP(hipStreamWaitEvent(k.s_comm, root.ev_fact, 0));                     // the panel is factored
+      M_RC(copy(k, k.buf[b], root, src, count, k.s_comm));
+      M_HIP(hipEventRecord(k.ev_recv[b], k.s_comm));
+    }
+    return 0;
+  }
+  // scatter + all-gather: peer q_c (c = 0 .. P - 2, the ranks != o in order) gets slab c from the owner, then every
+  // other peer copies slab c from q_c's receive buffer -- P - 1 concurrent incoming copies per receiver, one per link
+  std::vector<int> peers;
+  for (int i = 0; i < P; ++i)
+    if (i != o) peers.push_back(i);
+  const int np = (int)peers.size();
+  const size_t align = 512;   // 4 KB slab boundaries
+  const size_t per = ((count + np - 1) / np + align - 1) / align * align;
+  auto slab = [&](int c, size_t& beg, size_t& n) {
+    beg = std::min(count, (size_t)c * per);
+    n = std::min(count - beg, per);
+  };
+  // (1) the receive buffer of every peer is free: its readers of two panels ago are done -- this rank's own updates
+  //     and, since slabs are forwarded out of it, the incoming copies the other peers made FROM it
+  for (int c = 0; c < np; ++c) {
+    Rank& k = m->r[peers[c]];
+    M_HIP(hipSetDevice(k.dev));
+    M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_upd, 0));
+    if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_fact, 0));
+    if (J >= 2)
+      for (int d = 0; d < P; ++d) {
+        if (d == peers[c]) continue;
+        M_HIP(hipStreamWaitEvent(k.s_comm, m->r[d].ev_in[b][peers[c]], 0));   // (never recorded == complete)
+      }
+    M_HIP(hipEventRecord(k.ev_free[b], k.s_comm));
+  }
+  // (2) scatter: owner -> q_c, slab c
+  for (int c = 0; c < np; ++c) {
+    Rank& k = m->r[peers[c]];
+    size_t beg, n;
+    slab(c, beg, n);
+    M_HIP(hipSetDevice(k.dev));
+    hipStream_t st = k.s_in[o];
+    M_HIP(hipStreamWaitEvent(st, k.ev_free[b], 0));
+    M_HIP(hipStreamWaitEvent(st, root.ev_fact, 0));
+    M_RC(copy(k, k.buf[b] + beg, root, src + beg, n, st));
+    M_HIP(hipEventRecord(k.ev_in[b][o], st));
+  }
+  // (3) all-gather: q_d <- q_c, slab c
+  for (int d = 0; d < np; ++d) {
+    Rank& k = m->r[peers[d]];
+    M_HIP(hipSetDevice(k.dev));
+    for (int c = 0; c < np; ++c) {
+      if (c == d) continue;
+      Rank& from = m->r[peers[c]];
+      size_t beg, n;
+      slab(c, beg, n);
+      hipStream_t st = k.s_in[peers[c]];
+      M_HIP(hipStreamWaitEvent(st, k.ev_free[b], 0));
+      M_HIP(hipStreamWaitEvent(st, from.ev_in[b][o], 0));
+      M_RC(copy(k, k.buf[b] + beg, from, from.buf[b] + beg, n, st));
+      M_HIP(hipEventRecord(k.ev_in[b][peers[c]], st));
+    }
+    // (4) join: the whole panel has landed
+    for (int q = 0; q < P; ++q)
+      if (q != peers[d]) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_in[b][q], 0));
+    M_HIP(hipEventRecord(k.ev_recv[b], k.s_comm));
   }
   return 0;
 }
 
 // panel J as seen by rank i (pointer to its row J0, leading dimension ldp(J))
-const double* panel_on(sgp_multi* m, const Geometry& g, long J, int i) {
-  Rank& k = m->r[i];
-  return (g.owner(J) == i) ? k.store + k.off[J / g.P] : k.buf[J % 2];
+const double* panel_on(sgp_multi* m, const Fact& F, long J, int i) {
+  return (F.g.owner(J) == i) ? F.panel(i, J) : m->r[i].buf[J % 2];
 }
 
-int wait_panel(sgp_multi* m, const Geometry& g, long J, int i, hipStream_t s) {
+int wait_panel(sgp_multi* m, const Fact& F, long J, int i, hipStream_t s) {
   Rank& k = m->r[i];
-  if (g.owner(J) == i) return hipStreamWaitEvent(s, k.ev_fact, 0) == hipSuccess ? 0 : -2;
+  if (F.g.owner(J) == i) return hipStreamWaitEvent(s, k.ev_fact, 0) == hipSuccess ? 0 : -2;
   return hipStreamWaitEvent(s, k.ev_recv[J % 2], 0) == hipSuccess ? 0 : -2;
 }
 
-int update_panel(sgp_multi* m, const Geometry& g, long J, long Jp, int i, hipStream_t s) {
+int update_panel(sgp_multi* m, const Fact& F, long J, long Jp, int i, hipStream_t s) {
+  const Geometry& g = F.g;
   Rank& k = m->r[i];
-  const double* Pj = panel_on(m, g, J, i);
-  double* C = k.store + k.off[Jp / g.P];              // row Jp0 of panel Jp
+  const double* Pj = panel_on(m, F, J, i);
+  double* C = F.panel(i, Jp);              // row Jp0 of panel Jp
   const long c0 = g.col0(Jp);
+  k.upd_flops += update_flops(g.m_tot - c0, g.width(Jp), g.width(J));
   // sgp_dev_panel_update indexes C by global row: hand it the (virtual) address of global row 0
   return sgp_dev_panel_update(k.ctx, Pj, g.ldp(J), g.col0(J), g.width(J), C - c0, g.ldp(Jp), c0, g.width(Jp),
                               g.m_tot, (void*)s);
 }
 
-}  // namespace
+// ---- host-side inputs of one call, uploaded to every rank ----------------------------------------------
+struct SmallLayout {
+  long N, S;
+  size_t y, mean, noise, scal, total;
+  SmallLayout(long N_, long S_) : N(N_), S(S_) {
+    y = 0;
+    mean = y + (size_t)N * std::max<long>(S, 1);
+    noise = mean + N;
+    scal = noise + N;
+    total = scal + 16 + 2 * (size_t)std::max<long>(S, 1);
+  }
+};
 
-// logpdf(fx, y) over the ranks of ctx->multi (called from sgp_logpdf with the primary context held)
-int sgp_multi_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
-                     const double* noise, const double* y, double* out) {
-  sgp_multi* m = ctx->multi;
-  const int P = (int)m->r.size();
-  long N = 0;
-  for (int i = 0; i < spec->n_row_blocks; ++i) N += spec->row_len[i];
-  M_CHECK_ARG(N >= 1, "sgp_logpdf (multi): empty data");
-  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
-              "sgp_logpdf (multi): noise kind must be SCALAR or DIAG");
-  int64_t n_pad, m_tot;
-  sgp_geometry(N, 1, &n_pad, &m_tot);
-  Geometry g;
-  g.N = N;
-  g.n_pad = n_pad;
-  g.m_tot = m_tot;
-  g.W = std::min<long>(m->W, n_pad);
-  g.npan = (n_pad + g.W - 1) / g.W;
-  g.P = P;
+// Assemble every rank's owned panels of K + Sigma_y (+ the bordered rows (Y - m)') and run the sharded
+// factorisation.  d_small of rank i afterwards holds at `scal`: [0] logdet contribution, [1 .. 1 + S) the
+// |L^-1 (Y - m)|^2 contributions of its columns.
+int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mean, int noise_kind, const double* noise,
+              const double* Y, long ldy, std::vector<sgp_dspec*>& ds) {
+  const Geometry& g = F.g;
+  const int P = (int)g.P;
+  const long N = g.N, S = g.S;
   const double s2 = noise_kind == SGP_NOISE_SCALAR ? noise[0] : 0.0;
-  std::vector<sgp_dspec*> ds(P, nullptr);
-  auto cleanup = [&]() {
-    for (int i = 0; i < P; ++i) {
-      hipSetDevice(m->r[i].dev);
-      hipStreamSynchronize(m->r[i].s_upd);
-      hipStreamSynchronize(m->r[i].s_panel);
-      hipStreamSynchronize(m->r[i].s_comm);
-      for (auto st : m->r[i].s_pool) hipStreamSynchronize(st);
-      if (ds[i]) sgp_dspec_destroy(ds[i]);
-    }
-    hipSetDevice(ctx->device);
-  };
-  auto body = [&]() -> int {
-    // ---- per-rank storage and inputs
-    for (int i = 0; i < P; ++i) {
-      Rank& k = m->r[i];
-      M_HIP(hipSetDevice(k.dev));
-      k.off.clear();
-      size_t tot = 0;
-      for (long J = i; J < g.npan; J += P) {
-        k.off.push_back(tot);
-        tot += (size_t)g.ldp(J) * g.width(J);
-      }
-      M_RC(grow(&k.store, &k.store_cap, std::max<size_t>(tot, 1)));
-      if (P > 1 || m->transport == TR_RCCL) {
-        size_t bc = (size_t)m_tot * g.W;
-        if (bc > k.buf_cap) {
-          for (auto& b : k.buf) {
-            if (b) hipFree(b);
-            b = nullptr;
+  const SmallLayout L(N, S);
+  const bool prof = m->profile != 0;
+  if (prof) m->prof.assign((size_t)g.npan * (3 + P), 0.0);
+  const double t_begin = now_ms();
+  for (int i = 0; i < P; ++i) {
+    Rank& k = m->r[i];
+    M_HIP(hipSetDevice(k.dev));
+    if (P > 1 || m->transport == TR_RCCL) {
+      size_t bc = (size_t)g.m_tot * g.W;
+      if (bc > k.buf_cap) {
+        M_HIP(hipDeviceSynchronize());
+        for (auto& b : k.buf) {
+          if (b) hipFree(b);
+          b = nullptr;
+        }
+        k.buf_cap = 0;
+        for (auto& b : k.buf)
+          if (hipMalloc(&b, sizeof(double) * bc) != hipSuccess) {
+            (void)hipGetLastError();
+            set_error("multi: hipMalloc failed (panel receive buffer)");
+            return -2;
           }
-          k.buf_cap = 0;
-          for (auto& b : k.buf)
-            if (hipMalloc(&b, sizeof(double) * bc) != hipSuccess) {
-              (void)hipGetLastError();
-              set_error("multi: hipMalloc failed (panel receive buffer)");
-              return -2;
-            }
-          k.buf_cap = bc;
-        }
+        k.buf_cap = bc;
       }
-      M_RC(grow(&k.d_small, &k.small_cap, (size_t)3 * N + 8));
-      k.factored_once = false;
-      M_RC(sgp_dspec_create(k.ctx, spec, &ds[i]));
-      double* dY = k.d_small;
-      double* dM = k.d_small + N;
-      double* dNz = k.d_small + 2 * N;
-      double* dSc = k.d_small + 3 * N;
-      M_HIP(hipMemcpyAsync(dY, y, sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
-      if (mean) M_HIP(hipMemcpyAsync(dM, mean, sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
-      if (noise_kind == SGP_NOISE_DIAG)
-        M_HIP(hipMemcpyAsync(dNz, noise, sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
-      M_HIP(hipMemsetAsync(dSc, 0, sizeof(double) * 8, k.s_upd));
-      M_HIP(hipMemsetAsync(k.d_info, 0, sizeof(int), k.s_upd));
-      // ---- assembly of the owned panels: no communication
-      for (long J = i; J < g.npan; J += P) {
-        double* base = k.store + k.off[J / P];
-        M_RC(sgp_dev_assemble_cols(k.ctx, ds[i], N, g.col0(J), g.width(J), base - g.col0(J), g.ldp(J), m_tot,
-                                   mean ? dM : nullptr, noise_kind, &s2, noise_kind == SGP_NOISE_DIAG ? dNz : nullptr,
-                                   dY, N, 1, (void*)k.s_upd));
-      }
-      M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
     }
-    auto factor = [&](long J) -> int {
-      const int o = g.owner(J);
-      Rank& k = m->r[o];
+    M_RC(grow(&k.d_small, &k.small_cap, L.total));
+    k.factored_once = false;
+    k.t0_set = false;
+    k.upd_flops = k.upd_span_ms = k.recv_bytes = 0.0;
+    k.n_factored = 0;
+    M_RC(drv_dspec_create(k.ctx, spec, &ds[i]));
+    double* dY = k.d_small + L.y;
+    double* dM = k.d_small + L.mean;
+    double* dNz = k.d_small + L.noise;
+    double* dSc = k.d_small + L.scal;
+    if (S > 0) {
+      if (ldy == N)
+        M_HIP(hipMemcpyAsync(dY, Y, sizeof(double) * N * S, hipMemcpyHostToDevice, k.s_upd));
+      else
+        M_HIP(hipMemcpy2DAsync(dY, sizeof(double) * N, Y, sizeof(double) * ldy, sizeof(double) * N, (size_t)S,
+                               hipMemcpyHostToDevice, k.s_upd));
+    }
+    if (mean) M_HIP(hipMemcpyAsync(dM, mean, sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
+    if (noise_kind == SGP_NOISE_DIAG)
+      M_HIP(hipMemcpyAsync(dNz, noise, sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
+    M_HIP(hipMemsetAsync(dSc, 0, sizeof(double) * (16 + 2 * std::max<long>(S, 1)), k.s_upd));
+    M_HIP(hipMemsetAsync(k.d_info, 0, sizeof(int), k.s_upd));
+    // ---- assembly of the owned panels: no communication
+    for (long J = i; J < g.npan; J += P) {
+      double* base = F.panel(i, J);
+      M_RC(sgp_dev_assemble_cols(k.ctx, ds[i], N, g.col0(J), g.width(J), base - g.col0(J), g.ldp(J), g.m_tot,
+                                 mean ? dM : nullptr, noise_kind, &s2, noise_kind == SGP_NOISE_DIAG ? dNz : nullptr,
+                                 S > 0 ? dY : nullptr, N, S, (void*)k.s_upd));
+    }
+    M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
+  }
+  auto factor = [&](long J) -> int {
+    const int o = g.owner(J);
+    Rank& k = m->r[o];
+    M_HIP(hipSetDevice(k.dev));
+    M_RC(drv_panel_factor(k.ctx, F.panel(o, J), g.ldp(J), g.ldp(J), g.width(J), g.col0(J), k.d_small + L.scal,
+                          k.d_info, F.invp(o, J), k.s_panel));
+    M_HIP(hipEventRecord(k.ev_fact, k.s_panel));
+    k.factored_once = true;
+    k.n_factored += 1;
+    return 0;
+  };
+  // ---- panel 0
+  {
+    Rank& k = m->r[g.owner(0)];
+    M_HIP(hipSetDevice(k.dev));
+    M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_upd, 0));
+    double t0 = 0;
+    if (prof) {
+      M_RC(sync_all(m));
+      t0 = now_ms();
+    }
+    M_RC(factor(0));
+    if (prof) {
+      M_RC(sync_all(m));
+      m->prof[0] = now_ms() - t0;
+      m->prof[2] = 8.0 * (double)g.ldp(0) * (double)g.width(0);
+    }
+    M_RC(broadcast_panel(m, F, 0));
+  }
+  // ---- right-looking sweep with one-panel look-ahead
+  for (long J = 0; J < g.npan; ++J) {
+    const long nxt = J + 1;
+    for (int i = 0; i < P; ++i) {   // (a) update streams need panel J
+      M_HIP(hipSetDevice(m->r[i].dev));
+      M_RC(wait_panel(m, F, J, i, m->r[i].s_upd));
+    }
+    if (nxt < g.npan) {             // (b) look-ahead on the owner of the next panel
+      const int o1 = g.owner(nxt);
+      Rank& k = m->r[o1];
       M_HIP(hipSetDevice(k.dev));
-      double* base = k.store + k.off[J / P];
-      M_RC(sgp_dev_panel_factor(k.ctx, base, g.ldp(J), g.ldp(J), g.width(J), g.col0(J), k.d_small + 3 * N, k.d_info,
-                                (void*)k.s_panel));
-      M_HIP(hipEventRecord(k.ev_fact, k.s_panel));
-      k.factored_once = true;
-      return 0;
-    };
-    // ---- panel 0
-    {
-      Rank& k = m->r[g.owner(0)];
-      M_HIP(hipSetDevice(k.dev));
-      M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_upd, 0));
-      M_RC(factor(0));
-      M_RC(broadcast_panel(m, g, 0));
+      M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_upd, 0));      // step J - 1's updates of panel nxt
+      M_RC(wait_panel(m, F, J, o1, k.s_panel));
+      double t0 = 0, t1 = 0;
+      if (prof) {
+        M_RC(sync_all(m));
+        t0 = now_ms();
+      }
+      M_RC(update_panel(m, F, J, nxt, o1, k.s_panel));
+      if (prof) {
+        M_RC(sync_all(m));
+        t1 = now_ms();
+        m->prof[(size_t)nxt * (3 + P) + 1] = t1 - t0;
+      }
+      M_RC(factor(nxt));
+      if (prof) {
+        M_RC(sync_all(m));
+        m->prof[(size_t)nxt * (3 + P) + 0] = now_ms() - t1;
+        m->prof[(size_t)nxt * (3 + P) + 2] = 8.0 * (double)g.ldp(nxt) * (double)g.width(nxt);
+      }
+      M_RC(broadcast_panel(m, F, nxt));
+      if (prof) M_RC(sync_all(m));
     }
-    // ---- right-looking sweep with one-panel look-ahead
-    for (long J = 0; J < g.npan; ++J) {
-      const long nxt = J + 1;
-      for (int i = 0; i < P; ++i) {   // (a) update streams need panel J
-        M_HIP(hipSetDevice(m->r[i].dev));
-        M_RC(wait_panel(m, g, J, i, m->r[i].s_upd));
-      }
-      if (nxt < g.npan) {             // (b) look-ahead on the owner of the next panel
-        const int o1 = g.owner(nxt);
-        Rank& k = m->r[o1];
-        M_HIP(hipSetDevice(k.dev));
-        M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_upd, 0));      // step J - 1's updates of panel nxt
-        M_RC(wait_panel(m, g, J, o1, k.s_panel));
-        M_RC(update_panel(m, g, J, nxt, o1, k.s_panel));
-        M_RC(factor(nxt));
-        M_RC(broadcast_panel(m, g, nxt));
-      }
-      for (int i = 0; i < P; ++i) {   // (c) the rest of every rank's trailing panels, fanned over the stream pool
-        Rank& k = m->r[i];
-        M_HIP(hipSetDevice(k.dev));
-        M_HIP(hipEventRecord(k.ev_fork, k.s_upd));
-        for (auto st : k.s_pool) M_HIP(hipStreamWaitEvent(st, k.ev_fork, 0));
-        for (long Jp = i; Jp < g.npan; Jp += P)
-          if (Jp > nxt) M_RC(update_panel(m, g, J, Jp, i, k.s_pool[(Jp / P) % Rank::NPOOL]));
-        for (int q = 0; q < Rank::NPOOL; ++q) {
-          M_HIP(hipEventRecord(k.ev_pool[q], k.s_pool[q]));
-          M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_pool[q], 0));
-        }
-        M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
-      }
-    }
-    // ---- scalars: |L^-1 (y - m)|^2 from the bordered row of the owned panels, logdet
-    for (int i = 0; i < P; ++i) {
+    for (int i = 0; i < P; ++i) {   // (c) the rest of every rank's trailing panels, fanned over the stream pool
       Rank& k = m->r[i];
       M_HIP(hipSetDevice(k.dev));
-      if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_fact, 0));
+      bool any = false;
+      for (long Jp = i; Jp < g.npan; Jp += P)
+        if (Jp > nxt) any = true;
+      double t0 = 0;
+      if (prof) {
+        M_RC(sync_all(m));
+        t0 = now_ms();
+      }
+      if (any && !k.t0_set) {
+        M_HIP(hipEventRecord(k.ev_t0, k.s_upd));
+        k.t0_set = true;
+      }
+      M_HIP(hipEventRecord(k.ev_fork, k.s_upd));
+      for (auto st : k.s_pool) M_HIP(hipStreamWaitEvent(st, k.ev_fork, 0));
+      for (long Jp = i; Jp < g.npan; Jp += P)
+        if (Jp > nxt) M_RC(update_panel(m, F, J, Jp, i, k.s_pool[(Jp / P) % Rank::NPOOL]));
+      for (int q = 0; q < Rank::NPOOL; ++q) {
+        M_HIP(hipEventRecord(k.ev_pool[q], k.s_pool[q]));
+        M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_pool[q], 0));
+      }
+      if (any) M_HIP(hipEventRecord(k.ev_t1, k.s_upd));
+      M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
+      if (prof) {
+        M_RC(sync_all(m));
+        m->prof[(size_t)J * (3 + P) + 3 + i] = now_ms() - t0;
+      }
+    }
+  }
+  // ---- |L^-1 (Y - m)|^2 from the bordered rows of the owned panels
+  for (int i = 0; i < P; ++i) {
+    Rank& k = m->r[i];
+    M_HIP(hipSetDevice(k.dev));
+    if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_fact, 0));
+    if (S > 0)
       for (long J = i; J < g.npan; J += P) {
         long nc = std::min(g.width(J), std::max<long>(0, N - g.col0(J)));
         if (nc > 0)
-          M_RC(sgp_dev_rowsumsq(k.ctx, k.store + k.off[J / P] + (n_pad - g.col0(J)), g.ldp(J), nc, 1,
-                                k.d_small + 3 * N + 1, (void*)k.s_upd));
+          M_RC(sgp_dev_rowsumsq(k.ctx, F.panel(i, J) + (g.n_pad - g.col0(J)), g.ldp(J), nc, S,
+                                k.d_small + L.scal + 1, (void*)k.s_upd));
       }
+  }
+  // completion of the factorisation proper (statistics; the reductions follow in the caller)
+  for (int i = 0; i < P; ++i) {
+    Rank& k = m->r[i];
+    M_HIP(hipSetDevice(k.dev));
+    M_HIP(hipStreamSynchronize(k.s_upd));
+    M_HIP(hipStreamSynchronize(k.s_panel));
+    M_HIP(hipStreamSynchronize(k.s_comm));
+    for (auto st : k.s_in)
+      if (st) M_HIP(hipStreamSynchronize(st));
+    if (k.t0_set) {
+      float ms = 0;
+      if (hipEventElapsedTime(&ms, k.ev_t0, k.ev_t1) == hipSuccess) k.upd_span_ms = ms;
+      (void)hipGetLastError();
     }
-    double red[2] = {0.0, 0.0};
+  }
+  m->last_ms = now_ms() - t_begin;
+  m->last_npan = g.npan;
+  return 0;
+}
+
+// info of every rank -> LAPACK's (smallest failing leading minor); > 0 sets the error text
+int collect_info(sgp_multi* m) {
+  int info = 0;
+  for (auto& k : m->r) {
+    int inf = 0;
+    M_HIP(hipSetDevice(k.dev));
+    M_HIP(hipMemcpy(&inf, k.d_info, sizeof(int), hipMemcpyDeviceToHost));
+    if (inf > 0 && (info == 0 || inf < info)) info = inf;
+  }
+  if (info > 0)
+    set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
+              std::to_string(info));
+  return info;
+}
+
+void drain(sgp_multi* m, std::vector<sgp_dspec*>& ds, int restore_dev) {
+  for (size_t i = 0; i < m->r.size(); ++i) {
+    Rank& k = m->r[i];
+    hipSetDevice(k.dev);
+    hipStreamSynchronize(k.s_upd);
+    hipStreamSynchronize(k.s_panel);
+    hipStreamSynchronize(k.s_comm);
+    for (auto st : k.s_pool) hipStreamSynchronize(st);
+    for (auto st : k.s_in)
+      if (st) hipStreamSynchronize(st);
+    if (i < ds.size() && ds[i]) {
+      drv_dspec_free(ds[i]);
+      ds[i] = nullptr;
+    }
+  }
+  hipSetDevice(restore_dev);
+}
+
+long spec_rows(const sgp_cov_spec* spec) {
+  long N = 0;
+  for (int i = 0; i < spec->n_row_blocks; ++i) N += spec->row_len[i];
+  return N;
+}
+
+// transient factor in the ranks' grow-only stores
+int transient_fact(sgp_multi* m, Fact& F) {
+  const int P = (int)F.g.P;
+  F.base.assign(P, nullptr);
+  F.off.assign(P, {});
+  for (int i = 0; i < P; ++i) {
+    Rank& k = m->r[i];
+    M_HIP(hipSetDevice(k.dev));
+    size_t tot = plan_offsets(F.g, i, F.off[i]);
+    if (tot > k.store_cap) M_HIP(hipDeviceSynchronize());
+    M_RC(grow(&k.store, &k.store_cap, std::max<size_t>(tot, 1)));
+    F.base[i] = k.store;
+  }
+  return 0;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------
+// logpdf(fx, y) / logpdf(fx, Y) over the ranks of ctx->multi (called from sgp_logpdf with the primary context held)
+// ---------------------------------------------------------------------------------------------------------
+int sgp_multi_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                     const double* noise, const double* Y, int64_t ldy, int64_t ncols, double* out) {
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  const long N = spec_rows(spec);
+  M_CHECK_ARG(N >= 1 && ncols >= 1 && ldy >= N, "sgp_logpdf (multi): bad sizes");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+              "sgp_logpdf (multi): noise kind must be SCALAR or DIAG");
+  Fact F;
+  F.g = make_geometry(m, N, ncols);
+  const SmallLayout L(N, ncols);
+  std::vector<sgp_dspec*> ds(P, nullptr);
+  auto body = [&]() -> int {
+    M_RC(transient_fact(m, F));
+    M_RC(factorize(m, F, spec, mean, noise_kind, noise, Y, ldy, ds));
+    const long nred = 1 + ncols;
+    std::vector<double> red(nred, 0.0), tmp(nred);
     if (m->transport == TR_RCCL) {
       int rc = m->rccl.GroupStart();
       for (int i = 0; i < P && rc == 0; ++i) {
         Rank& k = m->r[i];
         hipSetDevice(k.dev);
-        double* sc = k.d_small + 3 * N;
-        rc = m->rccl.AllReduce(sc, sc + 4, 2, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
+        double* sc = k.d_small + L.scal;
+        rc = m->rccl.AllReduce(sc, sc, nred, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
       }
       int rc2 = m->rccl.GroupEnd();
       if (rc || rc2) {
@@ -509,34 +897,529 @@ int sgp_multi_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
       }
       Rank& k0 = m->r[0];
       M_HIP(hipSetDevice(k0.dev));
-      M_HIP(hipMemcpyAsync(red, k0.d_small + 3 * N + 4, sizeof(double) * 2, hipMemcpyDeviceToHost, k0.s_upd));
-    }
-    int info = 0;
-    for (int i = 0; i < P; ++i) {
-      Rank& k = m->r[i];
-      M_HIP(hipSetDevice(k.dev));
-      double sc[2];
-      int inf = 0;
-      M_HIP(hipMemcpyAsync(sc, k.d_small + 3 * N, sizeof(double) * 2, hipMemcpyDeviceToHost, k.s_upd));
-      M_HIP(hipMemcpyAsync(&inf, k.d_info, sizeof(int), hipMemcpyDeviceToHost, k.s_upd));
-      M_HIP(hipStreamSynchronize(k.s_upd));
-      M_HIP(hipStreamSynchronize(k.s_panel));
-      M_HIP(hipStreamSynchronize(k.s_comm));
-      if (m->transport != TR_RCCL) {   // fixed rank order: deterministic
-        red[0] += sc[0];
-        red[1] += sc[1];
+      M_HIP(hipMemcpyAsync(red.data(), k0.d_small + L.scal, sizeof(double) * nred, hipMemcpyDeviceToHost, k0.s_upd));
+      for (auto& k : m->r) {
+        M_HIP(hipSetDevice(k.dev));
+        M_HIP(hipStreamSynchronize(k.s_upd));
       }
-      if (inf > 0 && (info == 0 || inf < info)) info = inf;
+    } else {
+      for (int i = 0; i < P; ++i) {   // fixed rank order: deterministic
+        Rank& k = m->r[i];
+        M_HIP(hipSetDevice(k.dev));
+        M_HIP(hipMemcpy(tmp.data(), k.d_small + L.scal, sizeof(double) * nred, hipMemcpyDeviceToHost));
+        for (long q = 0; q < nred; ++q) red[q] += tmp[q];
+      }
     }
-    if (info > 0) {
-      set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
-                std::to_string(info));
-      return info;
-    }
-    out[0] = -0.5 * ((double)N * 1.8378770664093453 + red[0] + red[1]);
+    int info = collect_info(m);
+    if (info) return info;
+    for (long s = 0; s < ncols; ++s) out[s] = -0.5 * ((double)N * 1.8378770664093453 + red[0] + red[1 + s]);
     return 0;
   };
   int rc = body();
-  cleanup();
+  drain(m, ds, ctx->device);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rand(rng, fx, S): m + L Z with the factor sharded; every rank multiplies its own column panels
+// ---------------------------------------------------------------------------------------------------------
+int sgp_multi_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind, const double* noise,
+                   const double* Z, int64_t ldz, int64_t S, double* out, int64_t ldo) {
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  const long N = spec_rows(spec);
+  M_CHECK_ARG(N >= 1 && S >= 1 && ldz >= N && ldo >= N, "sgp_rand (multi): bad sizes");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+              "sgp_rand (multi): noise kind must be SCALAR or DIAG");
+  Fact F;
+  F.g = make_geometry(m, N, 0);
+  const Geometry& g = F.g;
+  const long s_pad = rup(S, TILE), n_pad = g.n_pad;
+  std::vector<sgp_dspec*> ds(P, nullptr);
+  auto body = [&]() -> int {
+    M_RC(transient_fact(m, F));
+    M_RC(factorize(m, F, spec, nullptr, noise_kind, noise, nullptr, N, ds));
+    int info = collect_info(m);
+    if (info) return info;
+    std::vector<double> acc((size_t)N * S), part((size_t)N * S);
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      // work: Z (N x S) | Zt (s_pad x n_pad) ; work2: Out (n_pad x s_pad)
+      M_RC(grow(&k.d_work, &k.work_cap, (size_t)N * S + (size_t)s_pad * n_pad));
+      M_RC(grow(&k.d_work2, &k.work2_cap, (size_t)n_pad * s_pad));
+      double* dZ = k.d_work;
+      double* dZt = k.d_work + (size_t)N * S;
+      double* dOut = k.d_work2;
+      hipStream_t s = k.s_upd;
+      M_HIP(hipMemcpy2DAsync(dZ, sizeof(double) * N, Z, sizeof(double) * ldz, sizeof(double) * N, (size_t)S,
+                             hipMemcpyHostToDevice, s));
+      M_HIP(hipMemsetAsync(dZt, 0, sizeof(double) * s_pad * n_pad, s));
+      M_HIP(hipMemsetAsync(dOut, 0, sizeof(double) * n_pad * s_pad, s));
+      M_RC(launch_transpose_add(dZ, N, N, S, dZt, s_pad, nullptr, s));
+      for (long J = i; J < g.npan; J += P) {
+        const long J0 = g.col0(J);
+        M_RC(launch_gemm_nt_lz_k(F.panel(i, J), g.ldp(J), dZt + J0 * s_pad, s_pad, dOut + J0, n_pad, n_pad - J0, s_pad,
+                                 g.width(J), 1.0, s));
+      }
+    }
+    for (int i = 0; i < P; ++i) {   // fixed rank order: deterministic
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      M_HIP(hipStreamSynchronize(k.s_upd));
+      M_HIP(hipMemcpy2D(part.data(), sizeof(double) * N, k.d_work2, sizeof(double) * n_pad, sizeof(double) * N,
+                        (size_t)S, hipMemcpyDeviceToHost));
+      if (i == 0)
+        acc = part;
+      else
+        for (size_t q = 0; q < acc.size(); ++q) acc[q] += part[q];
+    }
+    for (long s = 0; s < S; ++s)
+      for (long r = 0; r < N; ++r) out[r + s * ldo] = (mean ? mean[r] : 0.0) + acc[(size_t)r + (size_t)s * N];
+    return 0;
+  };
+  int rc = body();
+  drain(m, ds, ctx->device);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// posterior(fx, y): a KEPT sharded factor
+// ---------------------------------------------------------------------------------------------------------
+struct sgp_mpost {
+  sgp_ctx* ctx = nullptr;
+  std::vector<int> devs;        // device of every rank (the object may outlive its context: freed without it)
+  Fact F;
+  std::vector<double*> zloc;    // [P] z = L^-1 (y - m) of the rank's own columns, contiguous (panel order)
+  std::vector<double*> stage;   // [P] receive slots of the left-looking row solve: (P - 1) x ns_pad x W, grow-only
+  std::vector<size_t> stage_cap;
+};
+
+void sgp_multi_posterior_destroy(sgp_mpost* mp) {
+  if (!mp) return;
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (size_t i = 0; i < mp->F.base.size(); ++i) {
+    if (i < mp->devs.size()) hipSetDevice(mp->devs[i]);
+    if (mp->F.base[i]) hipFree(mp->F.base[i]);
+    if (i < mp->F.inv.size() && mp->F.inv[i]) hipFree(mp->F.inv[i]);
+    if (i < mp->zloc.size() && mp->zloc[i]) hipFree(mp->zloc[i]);
+    if (i < mp->stage.size() && mp->stage[i]) hipFree(mp->stage[i]);
+  }
+  hipSetDevice(cur);
+  delete mp;
+}
+
+int sgp_multi_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                               const double* noise, const double* y, double* alpha_out, sgp_mpost** out) {
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  const long N = spec_rows(spec);
+  M_CHECK_ARG(N >= 1, "sgp_posterior_create (multi): empty data");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+              "sgp_posterior_create (multi): noise kind must be SCALAR or DIAG");
+  sgp_mpost* mp = new sgp_mpost();
+  mp->ctx = ctx;
+  for (auto& k : m->r) mp->devs.push_back(k.dev);
+  Fact& F = mp->F;
+  F.g = make_geometry(m, N, 1);
+  const Geometry& g = F.g;
+  F.base.assign(P, nullptr);
+  F.inv.assign(P, nullptr);
+  F.off.assign(P, {});
+  F.inv_per_panel = (g.W / TILE) * drv_invd_stride();
+  mp->zloc.assign(P, nullptr);
+  mp->stage.assign(P, nullptr);
+  mp->stage_cap.assign(P, 0);
+  std::vector<sgp_dspec*> ds(P, nullptr);
+  auto body = [&]() -> int {
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      size_t tot = plan_offsets(g, i, F.off[i]);
+      size_t cap = 0;
+      M_RC(grow(&F.base[i], &cap, std::max<size_t>(tot, 1)));
+      cap = 0;
+      M_RC(grow(&F.inv[i], &cap, std::max<size_t>((size_t)F.off[i].size() * F.inv_per_panel, 1)));
+      cap = 0;
+      M_RC(grow(&mp->zloc[i], &cap, (size_t)std::max<long>(g.ncols_owned(i), 1)));
+    }
+    M_RC(factorize(m, F, spec, mean, noise_kind, noise, y, N, ds));
+    int info = collect_info(m);
+    if (info) return info;
+    // z of the owned columns, contiguous
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      long at = 0;
+      for (long J = i; J < g.npan; J += P) {
+        M_RC(drv_copy_strided(F.panel(i, J) + (g.n_pad - g.col0(J)), g.ldp(J), g.width(J), mp->zloc[i] + at, k.s_upd));
+        at += g.width(J);
+      }
+    }
+    if (alpha_out) {
+      // alpha = L^-T z, panel by panel from the last: the owner subtracts what the later panels contribute
+      // (its own columns of L times the alpha tail, which every rank holds) and solves its diagonal block;
+      // the W new entries go to every rank.  work: zg (n_pad, global index) | alpha (n_pad)
+      for (int i = 0; i < P; ++i) {
+        Rank& k = m->r[i];
+        M_HIP(hipSetDevice(k.dev));
+        M_RC(grow(&k.d_work, &k.work_cap, (size_t)2 * g.n_pad));
+        M_HIP(hipMemsetAsync(k.d_work, 0, sizeof(double) * 2 * g.n_pad, k.s_upd));
+        long at = 0;
+        for (long J = i; J < g.npan; J += P) {
+          M_HIP(hipMemcpyAsync(k.d_work + g.col0(J), mp->zloc[i] + at, sizeof(double) * g.width(J),
+                               hipMemcpyDeviceToDevice, k.s_upd));
+          at += g.width(J);
+        }
+        M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
+        M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_upd, 0));
+      }
+      for (long J = g.npan - 1; J >= 0; --J) {
+        const int o = g.owner(J);
+        Rank& k = m->r[o];
+        const long J0 = g.col0(J), w = g.width(J);
+        M_HIP(hipSetDevice(k.dev));
+        // virtual bases: factor element (r, c) at Lv[r + c * ldp], inverse blocks of global 128-block b at
+        // wall_v + b * stride
+        const double* Lv = F.panel(o, J) - J0 - J0 * g.ldp(J);
+        const double* wall_v = F.invp(o, J) - (J0 / TILE) * drv_invd_stride();
+        M_RC(drv_back_substitute(Lv, g.ldp(J), wall_v, J0 + w - TILE, J0, g.n_pad, k.d_work, k.d_work + g.n_pad,
+                                 k.s_panel));
+        M_HIP(hipEventRecord(k.ev_fact, k.s_panel));
+        for (int i = 0; i < P; ++i) {   // the W new entries of alpha -> every other rank (written once: nothing to order)
+          if (i == o) continue;
+          Rank& q = m->r[i];
+          M_HIP(hipSetDevice(q.dev));
+          M_HIP(hipStreamWaitEvent(q.s_panel, k.ev_fact, 0));
+          if (q.dev == k.dev)
+            M_HIP(hipMemcpyAsync(q.d_work + g.n_pad + J0, k.d_work + g.n_pad + J0, sizeof(double) * w,
+                                 hipMemcpyDeviceToDevice, q.s_panel));
+          else
+            M_HIP(hipMemcpyPeerAsync(q.d_work + g.n_pad + J0, q.dev, k.d_work + g.n_pad + J0, k.dev, sizeof(double) * w,
+                                     q.s_panel));
+        }
+      }
+      Rank& k0 = m->r[0];
+      M_HIP(hipSetDevice(k0.dev));
+      M_HIP(hipStreamSynchronize(k0.s_panel));
+      M_HIP(hipMemcpy(alpha_out, k0.d_work + g.n_pad, sizeof(double) * N, hipMemcpyDeviceToHost));
+    }
+    return 0;
+  };
+  int rc = body();
+  drain(m, ds, ctx->device);
+  if (rc) {
+    sgp_multi_posterior_destroy(mp);
+    return rc;
+  }
+  *out = mp;
+  return 0;
+}
+
+int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const sgp_cov_spec* prior_ss,
+                                const double* mean_s, double* mean_out, double* var_out, double* cov_out,
+                                int64_t ldcov) {
+  sgp_ctx* ctx = mp->ctx;
+  sgp_multi* m = ctx->multi;
+  const Fact& F = mp->F;
+  const Geometry& g = F.g;
+  const int P = (int)g.P;
+  const long Ns = spec_rows(cross);
+  long Mx = 0;
+  for (int j = 0; j < cross->n_col_blocks; ++j) Mx += cross->col_len[j];
+  M_CHECK_ARG(Mx == g.N, "sgp_posterior_predict: cross spec columns != training size");
+  M_CHECK_ARG(!prior_ss || spec_rows(prior_ss) == Ns, "sgp_posterior_predict: prior_ss size != number of x*");
+  M_CHECK_ARG(!cov_out || ldcov >= Ns, "sgp_posterior_predict: ldcov < Ns");
+  M_CHECK_ARG((!var_out && !cov_out) || prior_ss, "sgp_posterior_predict: prior_ss spec required for var / cov");
+  if (Ns == 0) return 0;
+  const long ns_pad = rup(Ns, TILE);
+  std::vector<sgp_dspec*> ds(P, nullptr);
+  sgp_dspec* dprior = nullptr;
+  auto body = [&]() -> int {
+    // ---- K(x*, x), column-sharded like the factor: rank i holds ns_pad x (its columns), panel after panel
+    std::vector<std::vector<long>> at(P);   // column offset of local panel l inside the rank's block
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      const long nco = g.ncols_owned(i);
+      // work: R / V' (ns_pad x nco) | partial sums S (ns_pad x W);  work2: results (dot, sumsq, zero, Gram)
+      M_RC(grow(&k.d_work, &k.work_cap, (size_t)ns_pad * std::max<long>(nco, 1) + (size_t)ns_pad * g.W));
+      M_RC(grow(&k.d_work2, &k.work2_cap, (size_t)3 * ns_pad + (cov_out ? (size_t)ns_pad * ns_pad : 0)));
+      if (P > 1) {
+        size_t need = (size_t)(P - 1) * ns_pad * g.W;
+        if (need > mp->stage_cap[i]) M_HIP(hipDeviceSynchronize());
+        M_RC(grow(&mp->stage[i], &mp->stage_cap[i], need));
+      }
+      M_RC(drv_dspec_create(k.ctx, cross, &ds[i]));
+      M_HIP(hipMemsetAsync(k.d_work, 0, sizeof(double) * ns_pad * std::max<long>(nco, 1), k.s_upd));
+      long a = 0;
+      for (long J = i; J < g.npan; J += P) {
+        at[i].push_back(a);
+        const long c0 = g.col0(J), w = g.width(J);
+        // element (r, c) of K(x*, x) at Kv[r + c * ns_pad] with Kv = block - c0 * ns_pad
+        double* blk = k.d_work + (size_t)a * ns_pad;
+        M_RC(drv_assemble(ds[i], blk - c0 * ns_pad, ns_pad, 0, ns_pad / TILE, c0 / TILE, (c0 + w) / TILE, 0, -1, 0.0,
+                          nullptr, k.s_upd));
+        a += w;
+      }
+    }
+    // ---- V' = K(x*, x) L^-T, left-looking over the panels
+    std::vector<char> stage_used(P, 0);
+    for (long J = 0; J < g.npan; ++J) {
+      const int o = g.owner(J);
+      const long J0 = g.col0(J), w = g.width(J);
+      Rank& ko = m->r[o];
+      double* Tj = ko.d_work + (size_t)at[o][g.local(J)] * ns_pad;   // R_J, becomes V_J
+      bool used_now = false;
+      for (int i = 0; i < P; ++i) {
+        Rank& k = m->r[i];
+        M_HIP(hipSetDevice(k.dev));
+        const long nco = g.ncols_owned(i);
+        double* Si = k.d_work + (size_t)ns_pad * std::max<long>(nco, 1);
+        bool first = true, any = false;
+        for (long kk = i; kk < J; kk += P) {
+          // V_kk (ns_pad x w_kk) times rows J0 .. J0 + w of panel kk
+          const double* Vk = k.d_work + (size_t)at[i][g.local(kk)] * ns_pad;
+          const double* Ljk = F.panel(i, kk) + (J0 - g.col0(kk));
+          if (i == o)
+            M_RC(launch_gemm_nt(Vk, ns_pad, Ljk, g.ldp(kk), Tj, ns_pad, ns_pad, w, g.width(kk), -1.0, 1.0, -(1L << 40), 0,
+                                0, k.s_upd));
+          else
+            M_RC(launch_gemm_nt(Vk, ns_pad, Ljk, g.ldp(kk), Si, ns_pad, ns_pad, w, g.width(kk), 1.0, first ? 0.0 : 1.0,
+                                -(1L << 40), 0, 0, k.s_upd));
+          first = false;
+          any = true;
+        }
+        if (i != o && any) {
+          double* slot = mp->stage[o] + (size_t)(i < o ? i : i - 1) * ns_pad * g.W;
+          if (stage_used[o]) M_HIP(hipStreamWaitEvent(k.s_upd, ko.ev_done, 0));   // the slot's last content was consumed
+          if (k.dev == ko.dev)
+            M_HIP(hipMemcpyAsync(slot, Si, sizeof(double) * ns_pad * w, hipMemcpyDeviceToDevice, k.s_upd));
+          else
+            M_HIP(hipMemcpyPeerAsync(slot, ko.dev, Si, k.dev, sizeof(double) * ns_pad * w, k.s_upd));
+          M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
+          M_HIP(hipSetDevice(ko.dev));
+          M_HIP(hipStreamWaitEvent(ko.s_upd, k.ev_upd, 0));
+          M_RC(drv_axpy_block(Tj, ns_pad, slot, ns_pad, ns_pad, w, -1.0, ko.s_upd));   // rank order: deterministic
+          used_now = true;
+        }
+      }
+      M_HIP(hipSetDevice(ko.dev));
+      if (used_now) {
+        M_HIP(hipEventRecord(ko.ev_done, ko.s_upd));
+        stage_used[o] = 1;
+      }
+      M_RC(drv_row_trsm(ko.ctx, Tj, ns_pad, ns_pad, F.panel(o, J), g.ldp(J), F.invp(o, J), w, ko.s_upd));
+    }
+    // ---- sums over columns = over ranks
+    std::vector<double> dot(Ns, 0.0), ssq(Ns, 0.0), tmp(Ns), prior(Ns, 0.0);
+    std::vector<double> G, Gt;
+    if (cov_out) {
+      G.assign((size_t)Ns * Ns, 0.0);
+      Gt.resize((size_t)Ns * Ns);
+    }
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      const long nco = g.ncols_owned(i);
+      if (nco == 0) continue;
+      double* r_dot = k.d_work2;
+      double* r_ssq = k.d_work2 + ns_pad;
+      double* r_zero = k.d_work2 + 2 * ns_pad;
+      double* r_G = k.d_work2 + 3 * ns_pad;
+      hipStream_t s = k.s_upd;
+      M_HIP(hipMemsetAsync(r_zero, 0, sizeof(double) * ns_pad, s));
+      if (mean_out) M_RC(launch_gemv_rows(k.d_work, ns_pad, Ns, nco, mp->zloc[i], 1, nullptr, r_dot, s));
+      if (var_out) M_RC(launch_colsumsq_sub(k.d_work, ns_pad, Ns, nco, r_zero, r_ssq, 1.0, s));
+      if (cov_out)
+        M_RC(launch_gemm_nt(k.d_work, ns_pad, k.d_work, ns_pad, r_G, ns_pad, ns_pad, ns_pad, nco, 1.0, 0.0, -(1L << 40), 0,
+                            0, s));
+    }
+    for (int i = 0; i < P; ++i) {   // fixed rank order: deterministic
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      M_HIP(hipStreamSynchronize(k.s_upd));
+      if (g.ncols_owned(i) == 0) continue;
+      if (mean_out) {
+        M_HIP(hipMemcpy(tmp.data(), k.d_work2, sizeof(double) * Ns, hipMemcpyDeviceToHost));
+        for (long q = 0; q < Ns; ++q) dot[q] += tmp[q];
+      }
+      if (var_out) {
+        M_HIP(hipMemcpy(tmp.data(), k.d_work2 + ns_pad, sizeof(double) * Ns, hipMemcpyDeviceToHost));
+        for (long q = 0; q < Ns; ++q) ssq[q] += tmp[q];
+      }
+      if (cov_out) {
+        M_HIP(hipMemcpy2D(Gt.data(), sizeof(double) * Ns, k.d_work2 + 3 * ns_pad, sizeof(double) * ns_pad,
+                          sizeof(double) * Ns, (size_t)Ns, hipMemcpyDeviceToHost));
+        for (size_t q = 0; q < G.size(); ++q) G[q] += Gt[q];
+      }
+    }
+    if (mean_out)
+      for (long q = 0; q < Ns; ++q) mean_out[q] = (mean_s ? mean_s[q] : 0.0) + dot[q];
+    if (var_out || cov_out) {   // the prior at x*: rank 0
+      Rank& k = m->r[0];
+      M_HIP(hipSetDevice(k.dev));
+      M_RC(drv_dspec_create(k.ctx, prior_ss, &dprior));
+      hipStream_t s = k.s_upd;
+      if (var_out) {
+        M_RC(drv_diag_of_spec(k.ctx, dprior, k.d_work2, s));
+        M_HIP(hipStreamSynchronize(s));
+        M_HIP(hipMemcpy(prior.data(), k.d_work2, sizeof(double) * Ns, hipMemcpyDeviceToHost));
+        for (long q = 0; q < Ns; ++q) var_out[q] = prior[q] - ssq[q];
+      }
+      if (cov_out) {
+        double* r_G = k.d_work2 + 3 * ns_pad;
+        M_HIP(hipMemsetAsync(r_G, 0, sizeof(double) * ns_pad * ns_pad, s));
+        M_RC(drv_assemble(dprior, r_G, ns_pad, 0, ns_pad / TILE, 0, ns_pad / TILE, 0, -1, 0.0, nullptr, s));
+        M_HIP(hipStreamSynchronize(s));
+        M_HIP(hipMemcpy2D(Gt.data(), sizeof(double) * Ns, r_G, sizeof(double) * ns_pad, sizeof(double) * Ns, (size_t)Ns,
+                          hipMemcpyDeviceToHost));
+        for (long c = 0; c < Ns; ++c)
+          for (long r = 0; r < Ns; ++r)
+            cov_out[r + c * ldcov] = Gt[(size_t)r + (size_t)c * Ns] - G[(size_t)r + (size_t)c * Ns];
+      }
+    }
+    return 0;
+  };
+  int rc = body();
+  if (dprior) {
+    hipSetDevice(m->r[0].dev);
+    hipStreamSynchronize(m->r[0].s_upd);
+    drv_dspec_free(dprior);
+  }
+  drain(m, ds, ctx->device);
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// elbo(VFE(fz), fx, y): data points sharded, one reduction (reference entry: src/gp/sparse_finite_gp.jl:52-58)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+// rows [lo, hi) of a cross spec (rows = data blocks): new row lengths, fresh input entries for the sliced row
+// inputs (an input may also serve as a column input somewhere: never edited in place), row scales offset
+struct SlicedSpec {
+  sgp_cov_spec c;
+  std::vector<int64_t> row_len;
+  std::vector<sgp_input> inputs;
+  std::vector<sgp_term> terms;
+  SlicedSpec(const sgp_cov_spec* sp, long lo, long hi) {
+    c = *sp;
+    const int nrb = sp->n_row_blocks, ncb = sp->n_col_blocks;
+    inputs.assign(sp->inputs, sp->inputs + sp->n_inputs);
+    terms.assign(sp->terms, sp->terms + sp->term_ptr[nrb * ncb]);
+    row_len.resize(nrb);
+    std::map<std::pair<int, int>, int> made;
+    long off = 0;
+    for (int I = 0; I < nrb; ++I) {
+      const long n = sp->row_len[I];
+      const long a = std::min(std::max(lo - off, 0L), n), e = std::min(std::max(hi - off, 0L), n);
+      row_len[I] = e - a;
+      for (int J = 0; J < ncb; ++J) {
+        const int p = I * ncb + J;
+        for (int t = sp->term_ptr[p]; t < sp->term_ptr[p + 1]; ++t) {
+          sgp_term& T = terms[t];
+          auto key = std::make_pair((int)T.row_input, I);
+          auto it = made.find(key);
+          if (it == made.end()) {
+            sgp_input in = sp->inputs[T.row_input];
+            in.x = in.x + a * in.ld;
+            in.n = e - a;
+            inputs.push_back(in);
+            it = made.emplace(key, (int)inputs.size() - 1).first;
+          }
+          T.row_input = it->second;
+          if (T.row_scale) T.row_scale = T.row_scale + a;
+        }
+      }
+      off += n;
+    }
+    c.row_len = row_len.data();
+    c.n_inputs = (int32_t)inputs.size();
+    c.inputs = inputs.data();
+    c.terms = terms.data();
+  }
+};
+
+}  // namespace
+
+int sgp_multi_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                   const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                   const double* z_noise, const double* y, double* out) {
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  const long N = spec_rows(xz), M = spec_rows(zz);
+  M_CHECK_ARG(N >= 1 && M >= 1, "sgp_elbo (multi): empty inputs");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+              "vfe: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
+  int64_t len = 0;
+  M_RC(sgp_elbo_part_len(M, &len));
+  for (int i = 0; i < P; ++i) {
+    Rank& k = m->r[i];
+    M_HIP(hipSetDevice(k.dev));
+    M_RC(grow(&k.d_work, &k.work_cap, (size_t)len));
+    if (i == 0 && P > 1 && m->transport != TR_RCCL) M_RC(grow(&k.d_work2, &k.work2_cap, (size_t)len));
+  }
+  // every rank's slice on a host thread of its own (the pipeline synchronises inside: Lz's info, chunk buffers)
+  std::vector<int> rcs(P, 0);
+  std::vector<std::string> errs(P);
+  std::vector<std::thread> th;
+  const double t0 = now_ms();
+  for (int i = 0; i < P; ++i) {
+    th.emplace_back([&, i]() {
+      const long lo = N * i / P, hi = N * (i + 1) / P;
+      SlicedSpec sl(xz, lo, hi);
+      Rank& k = m->r[i];
+      hipSetDevice(k.dev);
+      rcs[i] = sgp_dev_elbo_partial(k.ctx, zz, &sl.c, var_x + lo, mean_x ? mean_x + lo : nullptr, noise_kind,
+                                    noise_kind == SGP_NOISE_DIAG ? noise_x + lo : noise_x, z_noise_kind, z_noise,
+                                    y + lo, k.d_work, len);
+      if (rcs[i]) errs[i] = sgp_last_error();
+    });
+  }
+  for (auto& t : th) t.join();
+  for (int i = 0; i < P; ++i)
+    if (rcs[i]) {
+      set_error(errs[i]);
+      hipSetDevice(ctx->device);
+      return rcs[i];
+    }
+  // ---- ONE reduction of the parts
+  if (P > 1) {
+    if (m->transport == TR_RCCL) {
+      int rc = m->rccl.GroupStart();
+      for (int i = 0; i < P && rc == 0; ++i) {
+        Rank& k = m->r[i];
+        hipSetDevice(k.dev);
+        rc = m->rccl.AllReduce(k.d_work, k.d_work, (size_t)len, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
+      }
+      int rc2 = m->rccl.GroupEnd();
+      if (rc || rc2) {
+        set_error("ncclAllReduce failed (elbo parts)");
+        hipSetDevice(ctx->device);
+        return -4;
+      }
+      for (auto& k : m->r) {
+        M_HIP(hipSetDevice(k.dev));
+        M_HIP(hipStreamSynchronize(k.s_upd));
+      }
+    } else {
+      Rank& k0 = m->r[0];
+      for (int i = 1; i < P; ++i) {   // rank order: deterministic
+        Rank& k = m->r[i];
+        M_HIP(hipSetDevice(k0.dev));
+        if (k.dev == k0.dev)
+          M_HIP(hipMemcpyAsync(k0.d_work2, k.d_work, sizeof(double) * len, hipMemcpyDeviceToDevice, k0.s_upd));
+        else
+          M_HIP(hipMemcpyPeerAsync(k0.d_work2, k0.dev, k.d_work, k.dev, sizeof(double) * len, k0.s_upd));
+        M_RC(drv_axpy_block(k0.d_work, len, k0.d_work2, len, len, 1, 1.0, k0.s_upd));
+      }
+      M_HIP(hipStreamSynchronize(k0.s_upd));
+    }
+  }
+  int rc = sgp_dev_elbo_finish(m->r[0].ctx, M, N, m->r[0].d_work, out);
+  m->last_ms = now_ms() - t0;
+  hipSetDevice(ctx->device);
   return rc;
 }

@@ -63,6 +63,9 @@ _SIGS = {
     "sgp_ctx_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
     "sgp_ctx_ndev": (C.c_int, [_P]),
     "sgp_ctx_transport": (C.c_char_p, [_P]),
+    "sgp_ctx_multi_stats": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
+    "sgp_ctx_multi_profile": (C.c_int, [_P, C.c_int]),
+    "sgp_ctx_multi_profile_get": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_ctx_destroy": (C.c_int, [_P]),
     "sgp_ctx_trim": (C.c_int, [_P]),
     "sgp_ctx_stage_timing": (C.c_int, [_P, C.c_int]),

@@ -107,3 +107,133 @@ def test_p2p_transport_single_device_is_loopback_free(monkeypatch):
     v = _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
     assert abs(v - P.logpdf(F(x, 0.1), y)) <= 1e-12 * abs(v)
     ctx.close()
+
+
+# ---- round 3: every Cholesky-based operator behind the multi-GPU context ---------------------------------
+def _post_problem(N, ns, D=3, seed=7):
+    F, x, xs, y = _problem(N, D=D, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    xnew = P.BlockData([P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((D, ns))))),
+                        P.GPPPInput("f1", P.ColVecs(np.asfortranarray(rng.standard_normal((D, 17)))))])
+    return F, x, xs, y, xnew
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_posterior_on_kept_sharded_factor(panel128, nranks):
+    """posterior(fx, y) on a multi-GPU context keeps the sharded factor; mean / var / cov at x* and alpha against the
+    single-GPU driver (which the parity suite holds against the oracle), repeated predictions on one posterior."""
+    ctx = P.lib.Context(devices=[0] * nranks)
+    for N, ns in ((300, 40), (1411, 150)):
+        F, x, xs, y, xnew = _post_problem(N, ns)
+        noise = 0.05 + np.random.default_rng(N).random(N)
+        for nz in (0.1, noise):
+            p0 = P.posterior(F(x, nz), y)
+            m0, c0 = p0.mean_and_cov(xnew)
+            v0 = p0.var(xnew)
+            pm = _with_ctx(ctx, lambda: P.posterior(F(x, nz), y))
+            assert np.max(np.abs(pm.alpha - p0.alpha)) <= 1e-9 * np.max(np.abs(p0.alpha))
+            for _ in range(2):      # the factor stays resident: any number of predictions
+                m1, c1 = pm.mean_and_cov(xnew)
+                v1 = pm.var(xnew)
+                assert np.max(np.abs(m1 - m0)) <= 1e-10 * max(1.0, np.max(np.abs(m0)))
+                assert np.max(np.abs(v1 - v0)) <= 1e-10
+                assert np.max(np.abs(c1 - c0)) <= 1e-10
+            # a second, different query against the same factor
+            x2 = P.GPPPInput("f2", P.ColVecs(np.asfortranarray(np.random.default_rng(3).standard_normal((3, 33)))))
+            ma, va = pm.mean_and_var(x2)
+            mb, vb = p0.mean_and_var(x2)
+            assert np.max(np.abs(ma - mb)) <= 1e-10 * max(1.0, np.max(np.abs(mb))) and np.max(np.abs(va - vb)) <= 1e-10
+    ctx.close()
+
+
+def test_posterior_multi_against_oracle(panel128):
+    ctx = P.lib.Context(devices=[0, 0, 0])
+    rng = np.random.default_rng(11)
+    D, n = 4, 257
+    F = P.gppp_sum_model()
+    xs = [np.asfortranarray(rng.standard_normal((D, n + k))) for k in range(3)]
+    x = P.BlockData([P.GPPPInput(k, P.ColVecs(v)) for k, v in zip(("f1", "f2", "f3"), xs)])
+    y = rng.standard_normal(len(x))
+    xnew = P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((D, 33)))))
+    m, v = _with_ctx(ctx, lambda: P.mean_and_var(P.posterior(F(x, 0.1), y)(xnew)))
+    m_ref, v_ref = orm.gppp_sum_posterior(xs, y, 0.1, xnew.x.X)
+    assert np.max(np.abs(m - m_ref)) < 1e-8 * max(1.0, np.max(np.abs(m_ref)))
+    assert np.max(np.abs(v - (v_ref + 1e-18))) < 1e-8 * max(1.0, np.max(np.abs(v_ref)))
+    ctx.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_logpdf_matrix_rhs_and_rand_multi(panel128, nranks):
+    ctx = P.lib.Context(devices=[0] * nranks)
+    F, x, xs, y = _problem(900)
+    Y = np.asfortranarray(np.random.default_rng(5).standard_normal((900, 3)))
+    v0 = P.logpdf(F(x, 0.1), Y)
+    v1 = _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), Y))
+    assert v1.shape == (3,) and np.max(np.abs(v1 - v0)) <= 1e-11 * np.max(np.abs(v0))
+    Z = np.asfortranarray(np.random.default_rng(6).standard_normal((900, 5)))
+    r0 = P.rand(None, F(x, 0.1), 5, Z=Z)
+    r1 = _with_ctx(ctx, lambda: P.rand(None, F(x, 0.1), 5, Z=Z))
+    r2 = _with_ctx(ctx, lambda: P.rand(None, F(x, 0.1), 5, Z=Z))
+    assert np.max(np.abs(r1 - r0)) <= 1e-11 * np.max(np.abs(r0))
+    assert np.array_equal(r1, r2)          # deterministic: fixed-order reduction over the ranks
+    ctx.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_elbo_data_sharded_multi(nranks):
+    """elbo on a multi-GPU context: data points sharded over the ranks (one host thread each), one reduction."""
+    ctx = P.lib.Context(devices=[0] * nranks)
+    rng = np.random.default_rng(21)
+    D, N, M = 3, 1500, 96
+    f = P.stretch(P.atomic(P.GP(P.SEKernel()), P.GPC()), 0.7)
+    X = np.asfortranarray(rng.standard_normal((D, N)))
+    Z = np.asfortranarray(X[:, :M] + 0.01)
+    y = rng.standard_normal(N)
+    for nz in (0.1, 0.05 + rng.random(N)):
+        fx, fz = f(P.ColVecs(X), nz), f(P.ColVecs(Z), 1e-6)
+        e0 = P.elbo(P.VFE(fz), fx, y)
+        e1 = _with_ctx(ctx, lambda: P.elbo(P.VFE(fz), fx, y))
+        assert abs(e1 - e0) <= 1e-10 * abs(e0), (e0, e1)
+    # fewer data points than ranks would leave empty slices: still exact
+    Xs = np.asfortranarray(X[:, :nranks - 1])
+    fx, fz = f(P.ColVecs(Xs), 0.1), f(P.ColVecs(Z[:, :8]), 1e-6)
+    e0 = P.elbo(P.VFE(fz), fx, y[:nranks - 1])
+    e1 = _with_ctx(ctx, lambda: P.elbo(P.VFE(fz), fx, y[:nranks - 1]))
+    assert abs(e1 - e0) <= 1e-10 * abs(e0)
+    ctx.close()
+
+
+def test_broadcast_forms_agree_bit_for_bit(panel128, monkeypatch):
+    """scatter + all-gather (default for >= 3 ranks) vs one copy owner -> receiver: the same panels arrive."""
+    F, x, xs, y = _problem(1411)
+    vals = []
+    for form in ("allgather", "direct"):
+        monkeypatch.setenv("SGP_MULTI_BCAST", form)
+        ctx = P.lib.Context(devices=[0] * 5)
+        vals.append(_with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y)))
+        ctx.close()
+    assert vals[0] == vals[1]
+
+
+def test_multi_stats_and_profile(panel128):
+    import ctypes as C
+    ctx = P.lib.Context(devices=[0, 0, 0])
+    F, x, xs, y = _problem(1000)
+    _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
+    out = np.zeros(64)
+    n = C.c_int64()
+    P.lib.check(ctx.lib.sgp_ctx_multi_stats(ctx.handle, P.lib.dptr(out), 64, C.byref(n)))
+    assert n.value == 8 + 4 * 3 and out[0] == 3 and out[1] > 0 and out[5] == 8
+    assert all(out[8 + 4 * i] > 0 for i in range(3))              # every rank did trailing updates
+    assert sum(out[10 + 4 * i] for i in range(3)) == 8             # the 8 panels were factored exactly once
+    P.lib.check(ctx.lib.sgp_ctx_multi_profile(ctx.handle, 1))
+    v = _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
+    assert abs(v - P.logpdf(F(x, 0.1), y)) <= 1e-11 * abs(v)
+    P.lib.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, None, 0, C.byref(n)))
+    assert n.value == 8 * (3 + 3)
+    prof = np.zeros(n.value)
+    P.lib.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, P.lib.dptr(prof), n.value, C.byref(n)))
+    prof = prof.reshape(8, 6)
+    assert np.all(prof[:, 0] > 0) and np.all(prof[:, 2] > 0)
+    P.lib.check(ctx.lib.sgp_ctx_multi_profile(ctx.handle, 0))
+    ctx.close()
