@@ -30,8 +30,9 @@ end
 
 const CTX = Ref{Ptr{Cvoid}}(C_NULL)
 # One context per process.  ENV["STHENOMI_DEVICES"] = "0,1,2,3,4,5,6,7" makes it a multi-GPU context
-# (sgp_ctx_create_multi): `logpdf(fx, y)` is then sharded over the listed GPUs inside the library (RCCL
-# over xGMI), everything else runs on the first device -- the Julia side does not change.
+# (sgp_ctx_create_multi): `logpdf`, `posterior` (+ its predictions), `rand` and `elbo` are then sharded over the
+# listed GPUs inside the library (RCCL / peer copies over xGMI); covariances, gradients and the sparse posterior run
+# on the first device -- the Julia side does not change.
 function ctx()
     if CTX[] == C_NULL
         devs = get(ENV, "STHENOMI_DEVICES", "")
@@ -308,9 +309,29 @@ AbstractGPs.mean_and_var(p::MI355XSparsePosterior, xs::AbstractVector) = predict
 #   (∘, f, Stretch(l))   ∂l  = ⟨∂X_out, X_in⟩ (scalar l) ;  ∂X_in = l · ∂X_out
 #   leaf ScaledKernel σ² ∂σ² = Σ d_coef_t · coef_t / σ² ;  leaf ScaleTransform s: ∂s = ⟨∂X_out, X_in⟩
 #   AtomicGP inputs      ∂x  = what is left of ∂X at the leaf
-# Function-valued scales σ(x): the device returns d logpdf / d σ.(x) (logpdf_and_gradient_xs below); this rrule,
-# which has no RuleConfig to call back into the AD system, holds them and custom warps fixed.
+# Coverage: real `*` scales, scalar `Stretch`, the input points, Σy and y.  Everything else that carries a
+# differentiable parameter -- hyper-parameters INSIDE `GP(kernel)` (ScaledKernel σ², ScaleTransform s,
+# PeriodicTransform f, ConstantKernel c, kernel sums of those), function-valued scales σ(x) (the device returns
+# d logpdf / d σ.(x): logpdf_and_gradient_xs below, but this rule has no RuleConfig to call back into the AD system),
+# matrix / vector Stretch, Shift, Select, Periodic and custom warps -- is NOT differentiated by this rule, and the rule
+# REFUSES such a model (`uncovered` below, ArgumentError from the rrule) instead of handing the optimiser a silent zero:
+# before this rule existed Zygote failed loudly on those models, and a training loop must keep failing loudly.  Write
+# such parameters at the Stheno level (σ * stretch(GP(SEKernel()), 1 / l)), which is covered, or take the per-term
+# gradients of `logpdf_and_gradient_x` / `_xs` and chain them by hand.
 using ChainRulesCore
+const ParameterFreeKernel = Union{SEKernel,Matern12Kernel,Matern32Kernel,Matern52Kernel,WhiteKernel}
+uncovered(k::ParameterFreeKernel) = String[]
+uncovered(k::Kernel) = ["hyper-parameters of the leaf kernel $(nameof(typeof(k))) inside GP(kernel)"]
+uncovered(f::AtomicGP) = f.gp isa GP ? uncovered(f.gp.kernel) : uncovered(f.gp)
+uncovered(f::GPPP) = reduce(vcat, map(uncovered, collect(values(f.fs))); init = String[])
+uncovered(f::DerivedGP) = uncovered(f.args)
+uncovered((_, fa, fb)::Tuple{typeof(+),AbstractGP,AbstractGP}) = vcat(uncovered(fa), uncovered(fb))
+uncovered((_, b, f)::Tuple{typeof(+),Any,AbstractGP}) = uncovered(f)            # a known shift only moves the mean
+uncovered((_, s, f)::Tuple{typeof(*),Real,AbstractGP}) = uncovered(f)
+uncovered((_, s, f)::Tuple{typeof(*),Any,AbstractGP}) = vcat(["function-valued scale σ(x) * f"], uncovered(f))
+uncovered((_, f, g)::Tuple{typeof(∘),AbstractGP,Any}) =
+    g isa Stheno.Stretch{<:Real} ? uncovered(f) : vcat(["input transformation $(nameof(typeof(g)))"], uncovered(f))
+uncovered(args::Tuple) = ["GP node $(args[1]) without a gradient rule"]
 function logpdf_and_gradient_x(fx::SthenoFGP, y::AbstractVector{<:Real})
     sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
     @assert kind != 2 "dense observation noise has no device gradient"
@@ -361,6 +382,10 @@ trace((_, s, f)::Tuple{typeof(*),Any,AbstractGP}, node, x, sc, wp) = trace(f, x,
 trace((_, f, g)::Tuple{typeof(∘),AbstractGP,Any}, node, x, sc, wp) = trace(f, g.(x), sc, vcat(wp, Any[(node, g, x)]))
 
 function ChainRulesCore.rrule(::typeof(logpdf), fx::SthenoFGP, y::AbstractVector{<:Real})
+    missing_rules = unique(uncovered(fx.f))
+    isempty(missing_rules) || throw(ArgumentError("SthenoMI355X: the logpdf rrule does not differentiate " *
+        join(missing_rules, "; ") * " -- it would return a silent zero gradient for them.  Move the parameter to a " *
+        "Stheno-level scale / stretch, or use logpdf_and_gradient_x / logpdf_and_gradient_xs and chain by hand."))
     g = logpdf_and_gradient_x(fx, y)
     function logpdf_pullback(Δ̄)
         Δ = unthunk(Δ̄)
@@ -391,13 +416,13 @@ function ChainRulesCore.rrule(::typeof(logpdf), fx::SthenoFGP, y::AbstractVector
                         if w isa Stheno.Stretch{<:Real}
                             dl[node] = get(dl, node, 0.0) + sum(G .* mat(xin))
                             G = w.l .* G
-                        end                                            # other warps: held fixed
+                        end                                            # (other warps never get here: `uncovered`)
                     end
                     size(G) == size(dX[B]) && (dX[B] .+= G)
                 end
             end
         end
-        tangent(f::AtomicGP) = NoTangent()
+        tangent(f::AtomicGP) = NoTangent()      # parameter-free leaf kernels only (checked by `uncovered` above)
         tangent(f::GPPP) = Tangent{typeof(f)}(fs = map(tangent, f.fs))
         function tangent(f::DerivedGP)
             a = f.args

@@ -104,7 +104,12 @@ def prior_mean(f, x):
 def prior_cov(f, x, x2=None):
     if _is_prior(f):
         if _eltype(x) == np.float32 and (x2 is None or _eltype(x2) == np.float32):
-            return _kernelmatrix_f32(_prior_spec(f, x, x2))      # fp32 assembly on the device
+            spec = _prior_spec(f, x, x2)
+            if spec.f32_supported():
+                return _kernelmatrix_f32(spec)                   # fp32 assembly on the device
+            # beyond the fp32 kernels' limits (input dimension > 16, very many terms per block pair): the fp64
+            # kernels take any dimension and term count; the result is rounded to the model's type
+            return _kernelmatrix(spec).astype(np.float32)
         return _kernelmatrix(_prior_spec(f, x, x2))
     return f.cov(x, x2)
 
@@ -194,8 +199,12 @@ def logpdf(fx, y):
         if Y.ndim == 2:
             return np.array([elbo(VFE(fx.finducing), fx.fobs, Y[:, j]) for j in range(Y.shape[1])])
         return elbo(VFE(fx.finducing), fx.fobs, Y)
-    if _is_prior(fx.f) and _is_f32(fx, y) and np.ndim(y) == 1 and np.ndim(fx.noise) <= 1:
+    f32 = _is_prior(fx.f) and _is_f32(fx, y)
+    if f32 and np.ndim(y) == 1 and np.ndim(fx.noise) <= 1 and _prior_spec(fx.f, fx.x).f32_supported():
         return logpdf_f32(fx, y)
+    # Float32 models the fp32 kernels do not cover (matrix Y, dense Sigma_y, input dimension > 16, more than
+    # 64 / dimension terms per block pair) are computed in fp64 and returned in the model's type, so that
+    # `logpdf(fx, y) isa Float32` (test/gp/util.jl:76-88) holds whichever path ran
     Y = np.asarray(y, dtype=np.float64)
     vec = Y.ndim == 1
     Y = _f64(Y.reshape(len(fx), -1))
@@ -207,6 +216,8 @@ def logpdf(fx, y):
     rc = _ctx().lib.sgp_logpdf(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(Y),
                                Y.shape[0], Y.shape[1], _lib.dptr(out))
     _lib.check(rc, "sgp_logpdf")
+    if f32:
+        return np.float32(out[0]) if vec else out.astype(np.float32)
     return float(out[0]) if vec else out
 
 

@@ -318,6 +318,22 @@ class Spec:
     def ref(self):
         return C.byref(self.c)
 
+    def f32_supported(self):
+        """The fp32 device kernels (csrc/f32.hip: assemble_f32) take input dimension <= 16 and, per block pair,
+        (number of terms) x (dimension rounded up to a power of two) <= 64; anything else runs on the fp64 path."""
+        tp = self._term_ptr
+        for p in range(len(tp) - 1):
+            t0, t1 = int(tp[p]), int(tp[p + 1])
+            if t1 == t0:
+                continue
+            d = max(self.inputs[int(self._terms[t].row_input)].shape[0] for t in range(t0, t1))
+            dmax = 1
+            while dmax < d:
+                dmax *= 2
+            if dmax > 16 or (t1 - t0) * dmax > 64:
+                return False
+        return True
+
 
 def _noise_args(noise, N):
     """(kind, buffer) for a FiniteGP noise: scalar -> s2*I, vector -> Diagonal, matrix -> dense."""

@@ -174,14 +174,36 @@ class FakeLib:
 
     # -- fp32 instantiation (sthenomi.h:145-152): the double computes in fp64 and rounds the result, which is inside
     #    every fp32 tolerance; what it serves is the host mirror's Float32 tagging / type stability ------------------
+    def _f32_limits(self, s):
+        """csrc/f32.hip: assemble_f32 -- input dimension <= 16 and (terms per block pair) x (dimension rounded up to a
+        power of two) <= 64, else rc = -1 (the host mirror must not send such a model down the fp32 path)"""
+        per_pair = {}
+        for (I, J, _, ri, _, _, _, _, _) in s.terms:
+            d = s.inputs[ri].shape[0]
+            dmax = 1
+            while dmax < d:
+                dmax *= 2
+            n, dm = per_pair.get((I, J), (0, 1))
+            per_pair[(I, J)] = (n + 1, max(dm, dmax))
+        for (n, dm) in per_pair.values():
+            if dm > 16 or n * dm > 64:
+                return self._fail("fp32 path: input dimension <= 16 and (terms per block pair) x dimension <= 64")
+        return 0
+
     def sgp_kernelmatrix_f32(self, ctx, spec, K, ldk):
         s = _Spec(spec)
+        rc = self._f32_limits(s)
+        if rc:
+            return rc
         flat = np.ctypeslib.as_array(K, shape=(int(ldk) * s.M,))
         flat.reshape((s.M, int(ldk)))[:, : s.N].T[:, :] = s.dense().astype(np.float32)
         return 0
 
     def sgp_logpdf_f32(self, ctx, spec, mean, kind, noise, y, out):
         s = _Spec(spec)
+        rc = self._f32_limits(s)
+        if rc:
+            return rc
         return self.sgp_logpdf(ctx, spec, mean, kind, noise, y, s.N, 1, out)
 
     # -- the observation model C = K + Sigma_y ---------------------------------------------------------

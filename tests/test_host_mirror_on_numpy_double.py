@@ -60,191 +60,9 @@ def test_double_is_installed_and_the_product_has_no_cpu_path_of_its_own():
     assert np.allclose(K, np.exp(-0.5 * (x[:, None] - x[None, :]) ** 2), rtol=0, atol=1e-15)
 
 
-def test_sparse_posterior_cross_covariance_and_mean_and_cov():
-    """cov(post, x*, z*) and mean_and_cov of the VFE posterior (AbstractGPs ApproxPosteriorGP [EXT]): the off-diagonal
-    block of the joint posterior covariance, against the oracle's joint."""
-    import oracle.abstractgps as oagp
-    import oracle.stheno as ost
-    import stheno_jl_amd as P
-    import models
-    rng = np.random.default_rng(77)
-    fo, go = models.gppp_docstring(models.oracle_api())
-    fp, gp = models.gppp_docstring(models.product_api())
-    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
-    x, z, y = rng.standard_normal(40), rng.standard_normal(9), rng.standard_normal(40)
-    a, b = rng.standard_normal(5), rng.standard_normal(4)
-    po = oagp.posterior_vfe(oagp.VFE(Fo(ost.GPPPInput("f3", z), 1e-6)), Fo(ost.GPPPInput("f3", x), 0.2), y)
-    pp = P.posterior(P.VFE(Fp(P.GPPPInput("f3", z), 1e-6)), Fp(P.GPPPInput("f3", x), 0.2), y)
-    joint = po.cov(ost.BlockData([ost.GPPPInput("f1", a), ost.GPPPInput("f3", b)]))
-    got = pp.cov(P.GPPPInput("f1", a), P.GPPPInput("f3", b))
-    np.testing.assert_allclose(got, joint[:5, 5:], rtol=1e-9, atol=1e-10)
-    m, c = pp.mean_and_cov(P.GPPPInput("f3", b))
-    np.testing.assert_allclose(m, po.mean(ost.GPPPInput("f3", b)), rtol=1e-9, atol=1e-10)
-    np.testing.assert_allclose(c, po.cov(ost.GPPPInput("f3", b)), rtol=1e-9, atol=1e-10)
+# the example models / host features of round 2, whose bodies now live in the -m gpu suite (tests/test_gpu_examples.py)
+import test_gpu_examples as EX  # noqa: E402
 
-
-def test_sequential_conditioning_with_dense_observation_noise():
-    """posterior(f_post(x2, Sigma2), y2) with matrix-valued Sigma_y (AbstractGPs FiniteGP noise kinds, A1): the product
-    conditions the prior once on the stacked data with the block-diagonal noise; the oracle conditions twice."""
-    import oracle.abstractgps as oagp
-    import oracle.kernelfunctions as okf
-    import oracle.stheno as ost
-    import stheno_jl_amd as P
-    rng = np.random.default_rng(5150)
-    f_o, f_p = ost.atomic(oagp.GP(okf.Matern52Kernel()), ost.GPC()), P.atomic(P.GP(P.Matern52Kernel()), P.GPC())
-    a, b, c = rng.standard_normal(12), rng.standard_normal(8), rng.standard_normal(5)
-    ya, yb = rng.standard_normal(12), rng.standard_normal(8)
-    A1 = rng.standard_normal((12, 12))
-    S1 = A1 @ A1.T / 12 + 0.2 * np.eye(12)
-    for S2 in (0.3, 0.1 + rng.random(8)):
-        qo = oagp.posterior(oagp.posterior(f_o(a, S1), ya)(b, S2), yb)
-        qp = P.posterior(P.posterior(f_p(a, S1), ya)(b, S2), yb)
-        np.testing.assert_allclose(qp.mean(c), qo.mean(c), rtol=1e-9, atol=1e-10)
-        np.testing.assert_allclose(qp.cov(c), qo.cov(c), rtol=1e-9, atol=1e-10)
-
-
-def test_differentiation_example_known_answer():
-    """The one analytic known-answer check in the reference tree (examples/differentiation/script.jl:120-134): condition
-    f ~ GP(SE) on sin (cos) at 25 points with noise 1e-12 and the posterior mean of the derivative process reproduces
-    cos (-sin) to rtol 1e-5.  The example defines `derivative` as a user-written affine transformation with finite
-    differences of the kernel; here the derivative process is composed from the package's own primitives,
-    df = (shift(f, -h) - shift(f, h)) / 2h, so the check runs through flattening (four shifted views of one atom per
-    block pair), the posterior and the cross-covariance path.  (CPU double only for now: the conditioning is at
-    cond(C) ~ 1e13; it joins the -m gpu suite once it has been run on the device.)"""
-    import stheno_jl_amd as P
-
-    def build(GP):
-        f = GP(P.SEKernel())
-        h = 1e-3
-        return {"f": f, "df": (P.shift(f, -h) - P.shift(f, h)) * (1.0 / (2.0 * h))}
-
-    F = P.gppp(build)
-    x_obs, x_pred = np.linspace(-3.0, 3.0, 25), np.linspace(-2.5, 2.5, 25)
-    for fn, dfn in ((np.sin, np.cos), (np.cos, lambda t: -np.sin(t))):
-        post = P.posterior(F(P.GPPPInput("f", x_obs), 1e-12), fn(x_obs))
-        m = post.mean(P.GPPPInput("df", x_pred))
-        assert np.linalg.norm(m - dfn(x_pred)) <= 1e-5 * np.linalg.norm(dfn(x_pred))
-        # the derivative process is (nearly) deterministic given f on a dense grid: tiny posterior variance
-        assert np.max(post.var(P.GPPPInput("df", x_pred))) < 1e-3
-
-
-def test_sensor_fusion_example_posterior():
-    """examples/sensor_fusion/script.jl:33-66: observe y1 (3 points) and y2 (10 points), predict f, y1, y2 jointly --
-    posterior mean / var / joint cov over a BlockData of three processes and a sample from it, against the oracle."""
-    import models
-    import oracle.abstractgps as oagp
-    import oracle.stheno as ost
-    import stheno_jl_amd as P
-    rng = np.random.default_rng(123456)
-    fo, go = models.sensor_fusion(models.oracle_api())
-    fp, gp = models.sensor_fusion(models.product_api())
-    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
-    x1, x2 = np.sort(rng.random(3) * 10), np.sort(rng.random(10) * 10)
-    xo = ost.BlockData([ost.GPPPInput("y1", x1), ost.GPPPInput("y2", x2)])
-    xp = P.BlockData([P.GPPPInput("y1", x1), P.GPPPInput("y2", x2)])
-    Z = rng.standard_normal(13)
-    y = P.rand(None, Fp(xp), Z=Z)                                     # a draw from the model (default noise 1e-18)
-    np.testing.assert_allclose(y, oagp.rand(Fo(xo), Z), rtol=1e-9, atol=1e-9)
-    po, pp = oagp.posterior(Fo(xo), y), P.posterior(Fp(xp), y)
-    t = np.linspace(-2.5, 12.5, 40)
-    tq_o = ost.BlockData([ost.GPPPInput(k, t) for k in ("f", "y1", "y2")])
-    tq_p = P.BlockData([P.GPPPInput(k, t) for k in ("f", "y1", "y2")])
-    np.testing.assert_allclose(pp.mean(tq_p), po.mean(tq_o), rtol=1e-7, atol=1e-7)
-    np.testing.assert_allclose(pp.var(tq_p), po.var(tq_o), rtol=1e-7, atol=1e-7)
-    np.testing.assert_allclose(pp.cov(tq_p), po.cov(tq_o), rtol=1e-7, atol=1e-7)
-    parts = P.split(tq_p, pp.mean(tq_p))
-    assert [len(a) for a in parts] == [40, 40, 40]
-
-
-def test_time_varying_blr_example_draw_condition_and_sample_the_posterior():
-    """examples/time_varying_blr/script.jl:31-41: draw y from the model, condition on it, sample w1, w2, y jointly from
-    the posterior FiniteGP f'(xp, 1e-9) (rand of a posterior: AbstractGPs rand(::FiniteGP{<:PosteriorGP}) [EXT])."""
-    import models
-    import oracle.abstractgps as oagp
-    import oracle.stheno as ost
-    import stheno_jl_amd as P
-    rng = np.random.default_rng(0)
-    fo, go = models.time_varying_blr(models.oracle_api())
-    fp, gp = models.time_varying_blr(models.product_api())
-    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
-    x = np.sort(rng.random(60) * 10)
-    Z = rng.standard_normal(60)
-    y = P.rand(None, Fp(P.GPPPInput("y", x)), Z=Z)
-    np.testing.assert_allclose(y, oagp.rand(Fo(ost.GPPPInput("y", x)), Z), rtol=1e-8, atol=1e-8)
-    po, pp = oagp.posterior(Fo(ost.GPPPInput("y", x)), y), P.posterior(Fp(P.GPPPInput("y", x)), y)
-    t = np.linspace(-2.5, 12.5, 30)
-    tq_o = ost.BlockData([ost.GPPPInput(k, t) for k in ("w1", "w2", "y")])
-    tq_p = P.BlockData([P.GPPPInput(k, t) for k in ("w1", "w2", "y")])
-    Z2 = rng.standard_normal((90, 3))
-    s_p, s_o = P.rand(None, pp(tq_p, 1e-9), 3, Z=Z2), oagp.rand(po(tq_o, 1e-9), Z2)
-    assert s_p.shape == (90, 3)
-    np.testing.assert_allclose(s_p, s_o, rtol=1e-5, atol=1e-5)      # Cholesky of a posterior covariance with jitter 1e-9
-    w1s, w2s, ys = P.split(tq_p, s_p)
-    assert w1s.shape == w2s.shape == ys.shape == (30, 3)
-
-
-def test_process_decomposition_example_marginals_of_the_posterior():
-    """examples/process_decomposition/script.jl:24-52: observe f1 and f3 = f1 + f2, then `marginals(f_post(xp, 1e-9))`
-    over a BlockData of all three processes, split back per process (mean.(ms), std.(ms))."""
-    import models
-    import oracle.abstractgps as oagp
-    import oracle.stheno as ost
-    import stheno_jl_amd as P
-    rng = np.random.default_rng(123546)
-    fo, go = models.gppp_docstring(models.oracle_api())
-    fp, gp = models.gppp_docstring(models.product_api())
-    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
-    x1, x3 = np.sort(rng.random(10) * 10), np.sort(rng.random(11) * 10)
-    xo = ost.BlockData([ost.GPPPInput("f1", x1), ost.GPPPInput("f3", x3)])
-    xp = P.BlockData([P.GPPPInput("f1", x1), P.GPPPInput("f3", x3)])
-    y = oagp.rand(Fo(xo, 1e-6), rng.standard_normal(21))
-    y1, y3 = P.split(xp, y)
-    assert len(y1) == 10 and len(y3) == 11
-    po, pp = oagp.posterior(Fo(xo, 1e-6), y), P.posterior(Fp(xp, 1e-6), y)
-    t = np.linspace(-2.5, 12.5, 50)
-    tq_o = ost.BlockData([ost.GPPPInput(k, t) for k in ("f1", "f2", "f3")])
-    tq_p = P.BlockData([P.GPPPInput(k, t) for k in ("f1", "f2", "f3")])
-    ms = P.marginals(pp(tq_p, 1e-9))
-    mo, so = oagp.marginals(po(tq_o, 1e-9))
-    mean_p, std_p = np.array([d.mu for d in ms]), np.array([d.sigma for d in ms])       # mean.(ms), std.(ms)
-    np.testing.assert_allclose(mean_p, mo, rtol=1e-6, atol=1e-6)
-    np.testing.assert_allclose(std_p, so, rtol=1e-5, atol=1e-6)
-    m1, m2, m3 = P.split(tq_p, mean_p)
-    np.testing.assert_allclose(m1 + m2, m3, rtol=0, atol=1e-6)          # the decomposition: E[f3 | y] = E[f1 | y] + E[f2 | y]
-
-
-def test_gppp_and_pseudo_points_example_inducing_points_in_the_marginal_and_in_the_latents():
-    """examples/gppp_and_pseudo_points/script.jl:44-77: pseudo-points placed in the observed process f3, and in the two
-    latent processes f1 and f2 (a BlockData of inducing inputs): elbo and the approximate posterior over all three
-    processes, against the oracle; the bound sits below the exact logpdf in both placements."""
-    import models
-    import oracle.abstractgps as oagp
-    import oracle.stheno as ost
-    import stheno_jl_amd as P
-    rng = np.random.default_rng(123456)
-    fo, go = models.pseudo_points(models.oracle_api())
-    fp, gp = models.pseudo_points(models.product_api())
-    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
-    T = 25.0
-    x = np.linspace(0.0, T, 120)
-    y = oagp.rand(Fo(ost.GPPPInput("f3", x), 1.0), rng.standard_normal(120))
-    fxo, fxp = Fo(ost.GPPPInput("f3", x), 1.0), Fp(P.GPPPInput("f3", x), 1.0)
-    lp = P.logpdf(fxp, y)
-    assert abs(lp - oagp.logpdf(fxo, y)) <= 1e-9 * abs(lp)
-    t = np.linspace(-2.5, T + 2.5, 35)
-    tq_o = ost.BlockData([ost.GPPPInput(k, t) for k in ("f1", "f2", "f3")])
-    tq_p = P.BlockData([P.GPPPInput(k, t) for k in ("f1", "f2", "f3")])
-    placements = [
-        (ost.GPPPInput("f3", np.linspace(0, T, 25)), P.GPPPInput("f3", np.linspace(0, T, 25))),
-        (ost.BlockData([ost.GPPPInput("f1", np.linspace(0, T, 15)), ost.GPPPInput("f2", np.linspace(0, T, 10))]),
-         P.BlockData([P.GPPPInput("f1", np.linspace(0, T, 15)), P.GPPPInput("f2", np.linspace(0, T, 10))])),
-    ]
-    for zo, zp in placements:
-        eo, ep = oagp.elbo(oagp.VFE(Fo(zo, 1e-9)), fxo, y), P.elbo(P.VFE(Fp(zp, 1e-9)), fxp, y)
-        assert abs(ep - eo) <= 1e-7 * abs(eo) and ep <= lp + 1e-9
-        qo = oagp.posterior_vfe(oagp.VFE(Fo(zo, 1e-9)), fxo, y)
-        qp = P.posterior(P.VFE(Fp(zp, 1e-9)), fxp, y)
-        mo, vo = qo.mean_and_var(tq_o)
-        mp, vp = qp.mean_and_var(tq_p)
-        np.testing.assert_allclose(mp, mo, rtol=1e-6, atol=1e-6)
-        np.testing.assert_allclose(vp, vo, rtol=1e-6, atol=1e-6)
+for _name in [n for n in dir(EX) if n.startswith("test_")]:
+    globals()[_name] = getattr(EX, _name)
+del _name

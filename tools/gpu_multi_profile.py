@@ -1,0 +1,55 @@
+"""Serialised per-panel timings of the sharded factorisation with P loopback ranks on ONE GPU (sgp_ctx_multi_profile):
+what each GPU of a P-GPU node would spend on its own share -- input of tools/multi_projection.py.
+usage: python tools/gpu_multi_profile.py <config> <P> <out.json> [panel]"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry  # noqa: E402
+import bench_configs as bc  # noqa: E402
+
+cfg, P, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+if len(sys.argv) > 4:
+    os.environ["SGP_MULTI_PANEL"] = sys.argv[4]
+pkg = entry.load_package()
+L = pkg.lib
+kind, N, D = bc.CONFIGS[cfg]
+w = bc.build(pkg, cfg)
+spec = pkg.build_spec(w["f"], w["x"])[0]
+y = np.ascontiguousarray(w["y"])
+ctx = L.Context(devices=[0] * P)
+res = np.zeros(1)
+nz = np.array([bc.SIGMA2])
+
+
+def call():
+    t0 = time.perf_counter()
+    L.check(ctx.lib.sgp_logpdf(ctx.handle, spec.ref(), None, L.NOISE_SCALAR, L.dptr(nz), L.dptr(y), N, 1, L.dptr(res)))
+    return (time.perf_counter() - t0) * 1e3
+
+
+call()                       # warm-up (allocations)
+overlapped_ms = call()       # the normal (overlapped) schedule with P ranks sharing the one GPU
+st = np.zeros(8 + 4 * P)
+n = C.c_int64()
+L.check(ctx.lib.sgp_ctx_multi_stats(ctx.handle, L.dptr(st), len(st), C.byref(n)))
+L.check(ctx.lib.sgp_ctx_multi_profile(ctx.handle, 1))
+serial_ms = call()
+L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, None, 0, C.byref(n)))
+prof = np.zeros(n.value)
+L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, L.dptr(prof), n.value, C.byref(n)))
+prof = prof.reshape(-1, 3 + P)
+g = bc.golden(cfg)
+json.dump({"config": cfg, "N": N, "ranks": P, "panel_width": int(st[4]), "panels": int(st[5]),
+           "logpdf": float(res[0]), "parity_rel": None if g is None else abs(res[0] - g["logpdf"]) / abs(g["logpdf"]),
+           "one_gpu_overlapped_ms": overlapped_ms, "one_gpu_serialised_ms": serial_ms,
+           "columns": ["factor_ms", "lookahead_update_ms", "panel_bytes"] + [f"rest_update_ms_rank{i}" for i in range(P)],
+           "per_panel": prof.tolist()}, open(out, "w"))
+print(cfg, "P", P, "overlapped", round(overlapped_ms, 1), "serialised", round(serial_ms, 1), "factor sum", round(prof[:, 0].sum(), 1),
+      "la sum", round(prof[:, 1].sum(), 1), "rest sum per rank", np.round(prof[:, 3:].sum(axis=0), 1).tolist())
