@@ -28,6 +28,8 @@ CONFIGS = {
     "target": ("gppp3", 65536, 8),  # north-star run: c3's model, blocks 21846 / 21845 / 21845
     "n4k": ("matern52", 4096, 8),
     "n32k": ("matern52", 32768, 8),
+    # every input transformation of compose.jl in one programme (tests/golden/make_baseline_golden.py `w4k`)
+    "w4k": ("warp", 4096, 3),
 }
 GPPP_BLOCKS = {"c3": [10923, 10923, 10922], "target": [21846, 21845, 21845]}
 ELBO_M = 4096
@@ -48,7 +50,8 @@ def xs_points(D, ns=64):
 
 def describe(name):
     kind, N, D = CONFIGS[name]
-    body = {"gppp3": f"@gppp f3=f1+f2 (SE + Matern52) over 3 BlockData blocks {GPPP_BLOCKS.get(name)}, total N={N}, D={D}",
+    body = {"warp": f"@gppp h = g1 + 2 g2 - 0.5 g3 with select / stretch / periodic / shift views of two atoms, N={N}, D={D}",
+            "gppp3": f"@gppp f3=f1+f2 (SE + Matern52) over 3 BlockData blocks {GPPP_BLOCKS.get(name)}, total N={N}, D={D}",
             "elbo": f"sparse ELBO, SE, M={ELBO_M} inducing points, N={N}, D={D}"}.get(
                 kind, f"single GP, {kind}, N={N}, D={D}")
     return body + f", lengthscale sqrt(D), sigma2={SIGMA2} (BASELINE config '{name}')"
@@ -67,6 +70,17 @@ def build(pkg, name):
                             for i, k in enumerate(("f1", "f2", "f3"))])
         out.update(f=F, x=xb, fx=F(xb, SIGMA2),
                    xs_new=pkg.GPPPInput("f3", pkg.ColVecs(np.asfortranarray(xs_points(D) / ls))))
+    elif kind == "warp":
+        def prog(GP):
+            a, b = GP(pkg.SEKernel()), GP(pkg.Matern52Kernel())
+            g1 = pkg.select(pkg.stretch(a, 1.0 / math.sqrt(2.0)), [0, 1])
+            g2 = pkg.select(pkg.periodic(b, 0.3), 2)
+            g3 = pkg.shift(g1, np.array([0.4, -0.2, 0.1]))
+            return {"g1": g1, "g2": g2, "g3": g3, "h": g1 + 2.0 * g2 - 0.5 * g3}
+        F = pkg.gppp(prog)
+        xh = pkg.GPPPInput("h", pkg.ColVecs(X))
+        out.update(f=F, x=xh, fx=F(xh, SIGMA2),
+                   xs_new=pkg.GPPPInput("g1", pkg.ColVecs(np.asfortranarray(np.random.default_rng(987).standard_normal((D, 64))))))
     elif kind == "elbo":
         f = pkg.stretch(pkg.atomic(pkg.GP(pkg.SEKernel()), pkg.GPC()), 1.0 / ls)
         Z = np.asfortranarray(X[:, np.random.default_rng(7).permutation(N)[:ELBO_M]])

@@ -18,6 +18,8 @@ Reference files restated (all under /root/reference/src):
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 from . import abstractgps as agp
@@ -159,61 +161,66 @@ def var4(f, f2, x, x2):
     return var_args_right(f, f2.args, x, x2)
 
 
-# ---- input warps (compose.jl:36-127) ------------------------------------------------------------
+# ---- input warps (compose.jl:30-127) ------------------------------------------------------------
+# Stated here as the reference's POINT-WISE definitions -- `(s::Stretch)(x) = s.l * x` (compose.jl:38),
+# `(f::Select)(x) = x[f.idx]` (:71), `(p::Periodic)(t::Real) = [cos(2 pi f t), sin(2 pi f t)]` (:94),
+# `(f::Shift)(x) = x - f.a` (:113-115) -- and applied by ONE generic broadcast `g.(x)` (`_warp` below, what
+# compose.jl:16-28 writes), one point at a time.  The reference's `broadcasted` fast paths over ColVecs
+# (:40-42, 72-73, 95-97, 117) compute the same values in bulk; the product's host mirror (stheno.jl_amd/gp.py) uses
+# those bulk forms, so the two sides of the parity tests no longer share this code.
 class Stretch:
     def __init__(self, l):
         self.l = l
 
-    def __call__(self, x):
-        l = self.l
-        if isinstance(x, ColVecs):
-            if np.ndim(l) == 0:
-                return ColVecs(l * x.X)
-            return ColVecs(np.asarray(l) @ x.X)
-        return l * np.asarray(x, dtype=np.float64)
+    def __call__(self, pt):                      # one point: a real or a D-vector
+        if np.ndim(self.l) == 0:
+            return self.l * pt
+        return np.asarray(self.l, dtype=np.float64) @ np.asarray(pt, dtype=np.float64)
 
 
 class Select:
     def __init__(self, idx):
         self.idx = idx
 
-    def __call__(self, x):
+    def __call__(self, pt):
+        pt = np.asarray(pt, dtype=np.float64)
         if isinstance(self.idx, (int, np.integer)):
-            return x.X[self.idx, :].copy()       # compose.jl:77 -> plain vector of reals
-        return ColVecs(x.X[np.asarray(self.idx), :])
+            return float(pt[self.idx])           # x[idx] with an integer index: a real
+        return pt[np.asarray(self.idx)]
 
 
 class Periodic:
     def __init__(self, f):
         self.f = float(f)
 
-    def __call__(self, x):
-        t = (2.0 * np.pi * self.f) * np.asarray(x, dtype=np.float64)
-        return ColVecs(np.vstack([np.cos(t), np.sin(t)]))
+    def __call__(self, t):
+        w = 2.0 * np.pi * self.f
+        return np.array([math.cos(w * float(t)), math.sin(w * float(t))])
 
 
 class Shift:
     def __init__(self, a):
         self.a = a
 
-    def __call__(self, x):
-        if isinstance(x, ColVecs):
-            a = np.asarray(self.a, dtype=np.float64)
-            return ColVecs(x.X - (a[:, None] if a.ndim == 1 else a))
-        return np.asarray(x, dtype=np.float64) - self.a
+    def __call__(self, pt):
+        if np.ndim(pt) == 0:
+            return float(pt) - self.a
+        return np.asarray(pt, dtype=np.float64) - np.asarray(self.a, dtype=np.float64)
 
 
 def _warp(g, x):
-    """g.(x): the four structured warps broadcast over the collection, anything else maps."""
-    if isinstance(g, (Stretch, Select, Periodic, Shift)):
-        return g(x)
+    """g.(x): g applied to every point of the collection (a real per point of a vector, a column per point of
+    ColVecs); real results collect into a vector, vector results into ColVecs."""
     if isinstance(x, ColVecs):
         vals = [g(x.X[:, i]) for i in range(len(x))]
     else:
         vals = [g(float(v)) for v in np.asarray(x)]
+    if len(vals) == 0:
+        probe = g(np.zeros(x.X.shape[0])) if isinstance(x, ColVecs) else g(0.0)
+        return np.zeros(0) if np.ndim(probe) == 0 else ColVecs(np.zeros((len(probe), 0)))
     if np.ndim(vals[0]) == 0:
         return np.array(vals, dtype=np.float64)
-    return ColVecs(np.stack(vals, axis=1))
+    return ColVecs(np.stack([np.asarray(v, dtype=np.float64) for v in vals], axis=1))
 
 
 def compose(f, g):

@@ -111,8 +111,6 @@ void pool_free(sgp_ctx* ctx, void* p) {
 void pool_trim(sgp_ctx* ctx) {
   hipStreamSynchronize(ctx->stream);
   hipStreamSynchronize(ctx->stream2);
-  if (ctx->stream2m) hipStreamSynchronize(ctx->stream2m);
-  if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
   std::vector<sgp_pool_block> keep;
   for (auto& b : ctx->pool) {
     if (b.used) {
@@ -170,53 +168,19 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
   auto init = [&]() -> int {
     int lo = 0, hi = 0;
     SGP_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    // SGP_STREAM_PRIO=swap|equal: A/B knobs for the look-ahead's stream priorities (default: panel stream high)
-    const char* sp = getenv("SGP_STREAM_PRIO");
-    int p1 = hi, p2 = lo;
-    if (sp && !strcmp(sp, "swap")) { p1 = lo; p2 = hi; }
-    if (sp && !strcmp(sp, "equal")) { p1 = lo; p2 = lo; }
-    SGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, p1));
-    SGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, p2));
-    // SGP_RESERVE_CU = CUs per XCD kept free of trailing-update workgroups (0 = off), SGP_RESERVE_MAX_N = largest
-    // n_pad it is used for.  Mask bit i is CU i / 8 of XCD i % 8 (the driver deals the bits round-robin over the
-    // XCDs), so clearing the first 8 r bits takes r CUs from every XCD and the update's per-XCD tile shares stay
-    // balanced.
-    {
-      const char* rc_ = getenv("SGP_RESERVE_CU");
-      c->reserve_cu = rc_ ? atoi(rc_) : 0;
-      const char* rn_ = getenv("SGP_RESERVE_MAX_N");
-      c->reserve_max_n = rn_ ? atol(rn_) : (1L << 40);
-      if (c->reserve_cu < -1 || c->reserve_cu > 8 || prop.multiProcessorCount != 256) c->reserve_cu = 0;
-      if (c->reserve_cu != 0) {   // -1: a masked stream with every CU enabled (A/B of the masked queue itself)
-        uint32_t mask[8];
-        for (int q = 0; q < 8; ++q) mask[q] = 0xFFFFFFFFu;
-        for (int b = 0; b < 8 * c->reserve_cu; ++b) mask[b / 32] &= ~(1u << (b % 32));
-        SGP_HIP(hipExtStreamCreateWithCUMask(&c->stream2m, 8, mask));
-      }
-    }
-    SGP_HIP(hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, p2));
-    SGP_HIP(hipEventCreateWithFlags(&c->ev_isolve, hipEventDisableTiming));
-    SGP_HIP(hipEventCreateWithFlags(&c->ev_irest, hipEventDisableTiming));
-    const char* ila_ = getenv("SGP_INNER_LA");
-    if (ila_) c->inner_la = atoi(ila_);
+    // the panel (critical-path) stream at high priority, the trailing-update stream below it
+    SGP_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    SGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
     SGP_HIP(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     SGP_HIP(hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming));
     const char* la = getenv("SGP_LOOKAHEAD");
     if (la) c->lookahead = atoi(la);
-    const char* em = getenv("SGP_EXCL_MAX");
-    if (em) c->excl_max = atol(em);
-    const char* lm = getenv("SGP_LA_MIN");
-    if (lm) c->la_min = atol(lm);
     const char* lx = getenv("SGP_LA_MAX_N");
     if (lx) c->la_max_n = atol(lx);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* rf = getenv("SGP_REFINE");
     if (rf) c->refine = atoi(rf);
-    const char* wm = getenv("SGP_WMID");
-    if (wm) c->wmid = atol(wm) / TILE * TILE;
-    const char* il = getenv("SGP_INNER_LL");
-    if (il) c->inner_ll = atoi(il);
     const char* fp = getenv("SGP_FUSE_POTRF");
     if (fp) c->fuse_potrf = atoi(fp);
     const char* fm = getenv("SGP_FUSE_MAX_N");
@@ -248,8 +212,6 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   hipSetDevice(c->device);
   if (c->stream) hipStreamSynchronize(c->stream);
   if (c->stream2) hipStreamSynchronize(c->stream2);
-  if (c->stream2m) hipStreamSynchronize(c->stream2m);
-  if (c->stream3) hipStreamSynchronize(c->stream3);
   for (auto e : c->ev) hipEventDestroy(e);
   for (auto& b : c->pool) hipFree(b.p);
   if (c->h_stage) hipHostFree(c->h_stage);
@@ -262,10 +224,6 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->ev_panel) hipEventDestroy(c->ev_panel);
   if (c->ev_rest) hipEventDestroy(c->ev_rest);
   if (c->stream2) hipStreamDestroy(c->stream2);
-  if (c->stream2m) hipStreamDestroy(c->stream2m);
-  if (c->stream3) hipStreamDestroy(c->stream3);
-  if (c->ev_isolve) hipEventDestroy(c->ev_isolve);
-  if (c->ev_irest) hipEventDestroy(c->ev_irest);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return 0;
@@ -558,52 +516,15 @@ struct FuseScope {   // panel_factor reads ctx->fuse_now; restored on every exit
 // potrf_diag fused into the workgroup of that tile (ctx->fuse_potrf, gemm_nt.hip: gemm_nt_dma_potrf_kernel).
 static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_slots,
                         int* d_info, double* d_invstore, hipStream_t s, bool first_done = false) {
-  // ctx->wmid (multiple of 128, < w): one more blocking level -- the panel is factored in sub-panels of
-  // wmid columns (128-column steps inside), each followed by ONE K = wmid update of the rest of the
-  // panel, so that only wmid / w of the in-panel flops run as shallow K = 128 products.
-  if (ctx->wmid >= TILE && ctx->wmid < w) {
-    const long wm = ctx->wmid;
-    for (long j = 0; j < w; j += wm) {
-      const long wj = std::min(wm, w - j);
-      double* Pj = P + j + j * ld;
-      const long saved = ctx->wmid;
-      ctx->wmid = 0;
-      int rc = panel_factor(ctx, Pj, ld, m - j, wj, g0 + j, d_slots + j / TILE, d_info,
-                            d_invstore ? d_invstore + (j / TILE) * INVD_STRIDE : nullptr, s);
-      ctx->wmid = saved;
-      if (rc) return rc;
-      const long rest = w - j - wj;
-      if (rest > 0)   // rows below the sub-panel x remaining columns of the panel, lower tiles only
-        CHECK_RC(launch_gemm_nt(P + (j + wj) + j * ld, ld, P + (j + wj) + j * ld, ld, P + (j + wj) + (j + wj) * ld, ld,
-                                m - j - wj, rest, wj, -1.0, 1.0, 0, 0, 0, s));
-    }
-    return 0;
-  }
-  // ctx->inner_ll: LEFT-looking inside the panel -- block column j first receives the updates of all
-  // earlier block columns of the panel in ONE product of depth K = 128 j, then is factored and solved.
-  // Same flops as the right-looking sweep (one K = 128 update of every later block column per step),
-  // but every C tile of the panel is read and written once per block column instead of once per
-  // (earlier block, block) pair and the products are deep enough for the MFMA kernel to be efficient:
-  // the K = 128 updates ran at ~25 TFLOP/s and held ~10 % of an N = 65536 step's chip time.
-  // Inner look-ahead (SGP_INNER_LA=1, off by default): the next diagonal block only needs block column j + 1 updated, so that strip goes first
-  // on the panel stream and the update of everything to its right runs on stream3 while potrf_diag and the row
-  // solve of block column j + 1 are already under way -- the K = 128 product (15 - 80 us) leaves the serial chain.
-  //   ev_isolve: block column j is solved (stream3 may read it)
-  //   ev_irest : stream3's update with block column j is done (it also touched block column j + 2, which the
-  //              panel stream updates next)
-  const bool ila = ctx->inner_la && !ctx->inner_ll && s == ctx->stream && ctx->stream3;
   // Fused inner updates (SGP_FUSE_POTRF bit 0): the K = 128 update with block column j also factors the diagonal
   // block of block column j + 1 in the workgroup that updates it, so the 128-pivot chain runs under the rest of
   // the update instead of after it and one launch per block column disappears.
-  const bool fuse = (ctx->fuse_now & 1) && ctx->refine == 1 && !ctx->inner_ll && !ila;
+  const bool fuse = (ctx->fuse_now & 1) && ctx->refine == 1;
   bool diag_done = first_done;
-  bool irest_pending = false;
   for (long j = 0; j < w; j += TILE) {
     double* D = P + j + j * ld;
     double* invd = d_invstore ? d_invstore + (j / TILE) * INVD_STRIDE : ctx->d_invd;
-    if (ctx->inner_ll && j > 0)
-      CHECK_RC(launch_gemm_nt(P + j, ld, P + j, ld, D, ld, m - j, TILE, j, -1.0, 1.0, 0, 0, 0, s));
-    if (!diag_done) CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s, ctx->excl_now));
+    if (!diag_done) CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s));
     diag_done = false;
     long mrest = m - j - TILE;
     if (mrest > 0 && ctx->refine != 1) CHECK_RC(launch_trtri(D, ld, invd, ctx->d_w, s));  // A/B modes only
@@ -611,21 +532,8 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
       double* A21 = P + (j + TILE) + j * ld;
       CHECK_RC(solve_rows(ctx, A21, ld, mrest, ctx->d_w, D, ld, invd, 256, 16, s));  // L21 = A21 * L11^-T
       long wrest = w - j - TILE;
-      if (wrest > 0 && !ctx->inner_ll) {
-        if (irest_pending) {
-          SGP_HIP(hipStreamWaitEvent(s, ctx->ev_irest, 0));
-          irest_pending = false;
-        }
-        if (ila && wrest > TILE) {
-          SGP_HIP(hipEventRecord(ctx->ev_isolve, s));
-          CHECK_RC(launch_gemm_nt(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, TILE, TILE, -1.0, 1.0, 0,
-                                  0, 0, s));
-          SGP_HIP(hipStreamWaitEvent(ctx->stream3, ctx->ev_isolve, 0));
-          CHECK_RC(launch_gemm_nt(A21 + TILE, ld, A21 + TILE, ld, P + (j + 2 * TILE) + (j + 2 * TILE) * ld, ld,
-                                  mrest - TILE, wrest - TILE, TILE, -1.0, 1.0, 0, 0, 0, ctx->stream3));
-          SGP_HIP(hipEventRecord(ctx->ev_irest, ctx->stream3));
-          irest_pending = true;
-        } else if (fuse) {
+      if (wrest > 0) {
+        if (fuse) {
           // the scratch inverse blocks (no d_invstore) are free again: the row solve that read block column j's
           // ran before this launch on the same stream
           double* invn = d_invstore ? d_invstore + (j / TILE + 1) * INVD_STRIDE : ctx->d_invd;
@@ -640,7 +548,6 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
       }
     }
   }
-  if (irest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_irest, 0));
   return 0;
 }
 
@@ -715,21 +622,14 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // Matern-5/2, 1515 vs 1501 ms on the three-block model, same box) and leaves every kernel uncontended; at 32768 the
   // look-ahead still wins (202 vs 207 ms).  SGP_LOOKAHEAD=2: look-ahead at every size.
   const bool la = ctx->lookahead && s == ctx->stream && (n_pad < ctx->la_max_n || ctx->lookahead == 2);
-  const bool reserve = la && ctx->stream2m && n_pad <= ctx->reserve_max_n;
-  hipStream_t sB = la ? (reserve ? ctx->stream2m : ctx->stream2) : s;
-  struct ExclScope {   // potrf_diag placement follows the update stream in use, on every exit path
-    sgp_ctx* c;
-    ExclScope(sgp_ctx* c_, int v) : c(c_) { c->excl_now = v; }
-    ~ExclScope() { c->excl_now = 0; }
-  } excl_scope(ctx, reserve && ctx->reserve_cu > 0 ? 1 : 0);
+  hipStream_t sB = la ? ctx->stream2 : s;
   // SGP_FUSE_POTRF bit 1: the trailing update that finishes the next panel's first diagonal block (the look-ahead
   // column update, or the whole update when the look-ahead is off) factors that block in the same launch
   // Both apply while n_pad < SGP_FUSE_MAX_N (32768), where the panel chain is the critical path: N = 2048 1.17 ->
   // 1.09 ms, 4096 2.93 -> 2.73 ms, 16384 33.8 -> 33.2 ms; from 32768 on the panel stream has slack and the fused
   // launches measure the same or 1 % slower (profiles/r02_microbench.md).  Bit 2: at every size (A/B).
   FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad, !la));
-  const bool fuse_outer = (ctx->fuse_now & 2) && ctx->refine == 1 && !ctx->inner_ll &&
-                          !(ctx->wmid >= TILE && ctx->wmid < WOUT);
+  const bool fuse_outer = (ctx->fuse_now & 2) && ctx->refine == 1;
   bool first_done = false;
   bool rest_pending = false;
   if (la) {
@@ -739,7 +639,6 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   }
   for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
     long wj = std::min(WOUT, n_pad - J0);
-    if (la && !reserve && ctx->excl_max > 0) ctx->excl_now = (n_pad - J0) <= ctx->excl_max ? 1 : 0;
     const long m_eff = grow > 0 ? std::min(m_tot, grow + J0 + wj) : m_tot;  // rows this panel touches
     CHECK_RC(panel_factor(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
                           ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done));
@@ -751,11 +650,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
     first_done = fuse_outer;
     long w1 = std::min(WOUT, n_pad - c0);   // width of the next panel
     long c1 = c0 + w1;
-    // The look-ahead only pays while the trailing update outlasts the panel chain it hides: sharing CUs with
-    // the update's MFMA waves makes the latency-bound panel kernels 2.5 - 5 x slower (potrf_diag: 35 -> 180 us
-    // resident beside one update workgroup, tools/gpu_potrf_contend.py), so once fewer than la_min columns
-    // remain the panel and its update run back to back on the panel stream with the chip to themselves.
-    const bool la_k = la && (n_pad - c0) > ctx->la_min;
+    const bool la_k = la;
     if (la_k) {
       SGP_HIP(hipEventRecord(ctx->ev_panel, s));
       // look-ahead: next panel's columns on the panel stream (after the previous rest update)
@@ -2615,8 +2510,7 @@ extern "C" int sgp_bench_potrf_contended(sgp_ctx* ctx, int64_t m, int64_t k, int
   CHECK_ARG(ctx && us_out && ticks_out && busy_out && n > 0, "sgp_bench_potrf_contended: NULL argument");
   CHECK_ARG(m % TILE == 0 && k % 16 == 0 && m > 0, "sgp_bench_potrf_contended: bad sizes");
   CtxScope scope(ctx);
-  hipStream_t s = ctx->stream, s2 = ctx->stream2m ? ctx->stream2m : ctx->stream2;
-  const int excl = ctx->stream2m && ctx->reserve_cu > 0 ? 1 : 0;
+  hipStream_t s = ctx->stream, s2 = ctx->stream2;
   DevBuf P, Cm, A, A0;
   CHECK_RC(P.alloc((size_t)m * k));
   CHECK_RC(Cm.alloc((size_t)m * m));
@@ -2644,7 +2538,7 @@ extern "C" int sgp_bench_potrf_contended(sgp_ctx* ctx, int64_t m, int64_t k, int
     hipMemcpyAsync(A.p, A0.p, sizeof(double) * TILE * TILE, hipMemcpyDeviceToDevice, s);
     hipStreamSynchronize(s);
     hipEventRecord(e0, s);
-    rc = launch_potrf_diag_dbg(A.p, TILE, ctx->d_invd, ctx->d_slots, ctx->d_info, d_dbg, s, excl);
+    rc = launch_potrf_diag_dbg(A.p, TILE, ctx->d_invd, ctx->d_slots, ctx->d_info, d_dbg, s);
     hipEventRecord(e1, s);
     hipEventSynchronize(e1);
     busy_out[i] = hipEventQuery(eg) == hipErrorNotReady ? 1 : 0;
@@ -2671,7 +2565,7 @@ extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int
   CHECK_ARG(ctx && tflops_out && maxerr_out, "sgp_bench_gemm: NULL argument");
   CHECK_ARG(m % TILE == 0 && n % TILE == 0 && k % 16 == 0 && m >= n, "sgp_bench_gemm: bad sizes");
   CtxScope scope(ctx);
-  hipStream_t s = ctx->stream2m ? ctx->stream2m : ctx->stream;   // SGP_RESERVE_CU: the CU-masked update stream
+  hipStream_t s = ctx->stream;
   DevBuf A, C;
   CHECK_RC(A.alloc((size_t)m * k));
   CHECK_RC(C.alloc((size_t)m * n));

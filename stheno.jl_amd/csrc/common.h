@@ -176,9 +176,9 @@ int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N,
 
 // potrf.hip
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,
-                      long gcol0, hipStream_t s, int exclusive = 0);
+                      long gcol0, hipStream_t s);
 int launch_potrf_diag_dbg(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long long* dbg,
-                          hipStream_t s, int exclusive = 0);
+                          hipStream_t s);
 int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
                        long inv_cstride, long inv_kstride, hipStream_t s);
 int launch_trtri(const double* L, long ld, const double* d_invd, double* d_w, hipStream_t s);

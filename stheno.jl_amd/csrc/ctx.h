@@ -42,32 +42,14 @@ struct sgp_ctx {
   int multi_nranks = 0;
   hipStream_t stream = nullptr;   // panel / critical-path stream (high priority)
   hipStream_t stream2 = nullptr;  // trailing-update stream (look-ahead overlap)
-  // CU reservation for the panel chain: stream2m is an update stream whose CU mask leaves `reserve_cu` CUs of
-  // every XCD out; while the trailing update runs there, potrf_diag asks for more LDS than a CU shared with an
-  // update workgroup has free and so lands on a reserved, otherwise empty CU (potrf.hip).  excl_now: set by the
-  // factorisation while its update stream is the masked one.
-  // Inner look-ahead (panel_factor): inside a panel the K = 128 update of everything right of the NEXT block
-  // column runs on stream3 while the panel stream already factors that next block column.
-  hipStream_t stream3 = nullptr;
-  hipEvent_t ev_isolve = nullptr, ev_irest = nullptr;
-  int inner_la = 0;   // measured slower (event hand-offs + potrf_diag sharing CUs with the update): r02_microbench.md
-  hipStream_t stream2m = nullptr;
-  int reserve_cu = 0;
-  long reserve_max_n = 0;
-  int excl_now = 0;
-  long excl_max = 0;   // SGP_EXCL_MAX: potrf_diag waits for a CU without update workgroups while <= this many
-                       // trailing columns remain (no CU mask: such CUs only appear in an update's tail)
   hipEvent_t ev_panel = nullptr, ev_rest = nullptr;
   int lookahead = 1;
-  long la_min = 0;   // look-ahead only while more than la_min columns of the trailing matrix remain (capi.hip)
   long la_max_n = 65536;   // SGP_LA_MAX_N: look-ahead only for factorisations of fewer columns (serial + fused from there on)
   long wout = 0;  // 0 = automatic
   double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
   double* d_w = nullptr;       // 128 x 128 scratch inverse
   double* d_solve = nullptr;   // rows x 128 scratch of the refined panel solve (grown on demand)
   long n_solve_rows = 0;
-  long wmid = 0;               // SGP_WMID=<cols>: middle blocking level inside an outer panel (0 = none)
-  int inner_ll = 0;            // SGP_INNER_LL=1: left-looking block columns inside an outer panel
   int fuse_potrf = 11;         // SGP_FUSE_POTRF: bit 0 = inner K = 128 updates, bit 1 = outer trailing updates also factor the next
                                // diagonal block (tile (0, 0) of their C) in the workgroup that updates it, bit 3 = that tile goes
                                // from the accumulators straight into the factorisation's LDS layout; bit 2 = at every size
@@ -120,8 +102,6 @@ struct CtxScope {
   ~CtxScope() {
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream2);
-    if (ctx->stream2m) hipStreamSynchronize(ctx->stream2m);
-    if (ctx->stream3) hipStreamSynchronize(ctx->stream3);
     tl_ctx = prev;
   }
 };

@@ -38,18 +38,14 @@ __global__ __launch_bounds__(PD_THREADS, 4) void potrf_diag_dbg_kernel(double* A
 
 // bench / diagnosis: one launch with phase stamps (s_memtime ticks of wave 0) into dbg[64]
 int launch_potrf_diag_dbg(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long long* dbg,
-                          hipStream_t s, int exclusive) {
-  SGP_LDS_ATTR_ONCE(potrf_diag_dbg_kernel, PD_LDS_EXCL);
-  hipLaunchKernelGGL(potrf_diag_dbg_kernel, dim3(1), dim3(PD_THREADS), exclusive ? PD_LDS_EXCL : PD_LDS, s, A, ld, d_invd,
+                          hipStream_t s) {
+  SGP_LDS_ATTR_ONCE(potrf_diag_dbg_kernel, PD_LDS);
+  hipLaunchKernelGGL(potrf_diag_dbg_kernel, dim3(1), dim3(PD_THREADS), PD_LDS, s, A, ld, d_invd,
                      d_logdet_slot, d_info, 0L, panel_prio(), dbg);
   SGP_HIP(hipGetLastError());
   return 0;
 }
 
-// exclusive: ask for more LDS than a CU holding one trailing-update workgroup has left (160 - 73.7 KB), so the
-// block can only be placed on a CU WITHOUT update workgroups -- one of the CUs the update stream's CU mask leaves
-// out (ctx.h, reserve_cu).  Sharing a CU with 8 MFMA-saturating waves makes this latency-bound kernel 5 x slower
-// (profiles/r02_microbench.md).
 int launch_potrf_diag_f32(float* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
                           hipStream_t s) {
   SGP_LDS_ATTR_ONCE(potrf_diag_f32_kernel, PD_LDS);
@@ -60,9 +56,9 @@ int launch_potrf_diag_f32(float* A, long ld, double* d_invd, double* d_logdet_sl
 }
 
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,
-                      long gcol0, hipStream_t s, int exclusive) {
-  SGP_LDS_ATTR_ONCE(potrf_diag_kernel, PD_LDS_EXCL);
-  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PD_THREADS), exclusive ? PD_LDS_EXCL : PD_LDS, s, A, ld, d_invd,
+                      long gcol0, hipStream_t s) {
+  SGP_LDS_ATTR_ONCE(potrf_diag_kernel, PD_LDS);
+  hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(PD_THREADS), PD_LDS, s, A, ld, d_invd,
                      d_logdet_slot, d_info, gcol0, panel_prio());
   SGP_HIP(hipGetLastError());
   return 0;
@@ -195,14 +191,8 @@ int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl
     return -1;
   }
   SGP_LDS_ATTR_ONCE(panel_solve_kernel, PS_LDS);
-  // one strip per workgroup until the chip is full (256 CUs), then fatter workgroups.  SGP_PS_DIV=<n> (A/B knob):
-  // aim at n workgroups instead of 256 -- under the look-ahead overlap the launch waits for one CU slot per
-  // workgroup, so fewer, fatter workgroups trade slot waits against serial strips.
-  static const long div = [] {
-    const char* e = getenv("SGP_PS_DIV");
-    long v = e ? atol(e) : 256;
-    return v >= 1 ? v : 256;
-  }();
+  // one strip per workgroup until the chip is full (256 CUs), then fatter workgroups
+  const long div = 256;
   long nstrips = rows / PS_ROWS;
   int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + div - 1) / div));
   long nwg = (nstrips + strips - 1) / strips;

@@ -13,16 +13,11 @@ __device__ __forceinline__ double bcast_lane(double v, int srclane) {
   return __hiloint2double(hi, lo);
 }
 
-// SGP_PANEL_PRIO=<0..3> (read once): s_setprio level of the latency-critical panel kernels' waves.  Under
-// the look-ahead they share CUs with trailing-update GEMM waves issuing MFMAs back to back; a raised
-// wave priority wins the issue arbitration for the serial pivot / substitution chains.
-inline int panel_prio() {
-  static const int v = [] {
-    const char* e = getenv("SGP_PANEL_PRIO");
-    return e ? atoi(e) : 3;   // measured with the fused launches: N = 16384 33.2 -> 32.7 ms, 4096 2.73 -> 2.71, 2048 1.093 -> 1.087
-  }();
-  return v;
-}
+// s_setprio level of the latency-critical panel kernels' waves.  Under the look-ahead they share CUs with
+// trailing-update GEMM waves issuing MFMAs back to back; a raised wave priority wins the issue arbitration for the
+// serial pivot / substitution chains (measured with the fused launches, 0 vs 3: N = 16384 33.2 -> 32.7 ms,
+// 4096 2.73 -> 2.71, 2048 1.093 -> 1.087).
+inline int panel_prio() { return 3; }
 __device__ __forceinline__ void set_wave_prio(int p) {
   if (p == 1) __builtin_amdgcn_s_setprio(1);
   if (p == 2) __builtin_amdgcn_s_setprio(2);
@@ -37,7 +32,6 @@ constexpr int PD_THREADS = 512;
 // CU, so the high-priority panel stream gets onto the chip while the update of the previous panel
 // is still running (a 149 KB tile had to wait for an entirely idle CU, i.e. for the update's tail).
 constexpr size_t PD_LDS = (size_t)(36 * 256 + 256) * sizeof(double);
-constexpr size_t PD_LDS_EXCL = (size_t)90 * 1024;  // > 160 KB - one GEMM workgroup's 73.7 KB
 __device__ __forceinline__ int boff(int rb, int cb) { return (rb * (rb + 1) / 2 + cb) * 256; }
 
 // wave-uniform (rb, cb) of packed lower block `blk` (blk = rb (rb + 1) / 2 + cb)

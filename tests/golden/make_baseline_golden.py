@@ -16,6 +16,13 @@ the models of SURVEY.md 8d:
   c4     sparse ELBO (VFE), SE, M = 4096 inducing points, N = 262144, D = 8, Sigma_z = 1e-6 I
   c5     single GP, Matern-5/2, N = 65536,  D = 8
   target c3's model at N = 65536, D = 8, blocks 21846 / 21845 / 21845 (the north-star run)
+  w4k    every input transformation of /root/reference/src/affine_transformations/compose.jl in one programme
+         (round 3; the cases above only stretch and add), N = 4096, D = 3, a ~ GP(SE), b ~ GP(Matern-5/2):
+           g1 = select(stretch(a, 1 / l), [1, 2])        g1(x) = a(x[1:2] / l),  l = sqrt(2)
+           g2 = select(periodic(b, 0.3), 3)              g2(x) = b([cos(2 pi 0.3 x[3]), sin(2 pi 0.3 x[3])])
+           g3 = shift(g1, [0.4, -0.2, 0.1])              g3(x) = g1(x - s)
+           h  = g1 + 2 g2 - 0.5 g3
+         logpdf(h(X, 0.1), y) and the posterior of g1 at 64 points, stated point-wise below (WarpModel)
 
 Inputs (identical to bench.py `make_inputs`): rng = default_rng(123456);
 X = rng.standard_normal((D, N)); y = rng.standard_normal(N); lengthscale sqrt(D) (inputs divided
@@ -119,6 +126,40 @@ class Model:
 
     def prior_var(self, proc, ns):
         return np.full(ns, float(len(self.ATOMS[proc])))   # kappa(0) = 1 per atom
+
+
+class WarpModel:
+    """h = g1 + 2 g2 - 0.5 g3 of the `w4k` case (module docstring), covariances written out by bilinearity:
+      cov(h(x), h(x'))  = ka(u, u') + 4 kb(p, p') + 0.25 ka(us, us') - 0.5 (ka(u, us') + ka(us, u'))
+      cov(h(x), g1(x*)) = ka(u, u*) - 0.5 ka(us, u*)
+    u = x[0:2] / l, us = (x - s)[0:2] / l, p = [cos(2 pi f x[2]), sin(2 pi f x[2])]; ka = SE, kb = Matern-5/2."""
+    L, FREQ, SHIFT = math.sqrt(2.0), 0.3, np.array([0.4, -0.2, 0.1])
+
+    def __init__(self, X):
+        self.N = X.shape[1]
+        self.u, self.us, self.p = self.views(X)
+
+    def views(self, X):
+        u = X[0:2] / self.L
+        us = (X - self.SHIFT[:, None])[0:2] / self.L
+        w = 2.0 * math.pi * self.FREQ
+        p = np.vstack([np.cos(w * X[2]), np.sin(w * X[2])])
+        return u, us, p
+
+    def cov_rows_cols(self, r0, r1, c0, c1):
+        u, us, p = self.u, self.us, self.p
+        ka = lambda A, B: kappa("se", sqdist(A, B))
+        return (ka(u[:, r0:r1], u[:, c0:c1]) + 4.0 * kappa("m52", sqdist(p[:, r0:r1], p[:, c0:c1]))
+                + 0.25 * ka(us[:, r0:r1], us[:, c0:c1])
+                - 0.5 * (ka(u[:, r0:r1], us[:, c0:c1]) + ka(us[:, r0:r1], u[:, c0:c1])))
+
+    def cross(self, proc, Xs):
+        assert proc == "g1"
+        ustar = Xs[0:2] / self.L
+        return kappa("se", sqdist(self.u, ustar)) - 0.5 * kappa("se", sqdist(self.us, ustar))
+
+    def prior_var(self, proc, ns):
+        return np.ones(ns)
 
 
 def assemble_lower(model, s2, pool):
@@ -260,6 +301,11 @@ def xs_points(D):
     return np.random.default_rng(987).standard_normal((D, NS)) / math.sqrt(D)
 
 
+def warp4k():
+    X, y = inputs(4096, 3)
+    return WarpModel(X), y, "g1"
+
+
 CASES = {
     "c1": lambda: ("dense", single("se", 2048, 2), 2),
     "n4k": lambda: ("dense", single("m52", 4096, 8), 8),
@@ -268,6 +314,7 @@ CASES = {
     "c4": lambda: ("elbo", None, 8),
     "c5": lambda: ("dense", single("m52", 65536, 8), 8),
     "target": lambda: ("dense", gppp3(65536, 8, [21846, 21845, 21845]), 8),
+    "w4k": lambda: ("warp", warp4k(), 3),
 }
 
 
@@ -284,7 +331,9 @@ def main():
                 res["cases"][name] = elbo_case(name, X, y, 4096, 1e-6, pool)
             else:
                 model, y, proc = built
-                res["cases"][name] = dense_case(name, model, y, proc, xs_points(D), pool)
+                # (w4k: the prediction points are the raw standard normals -- the model applies its own transformations)
+                Xs = np.random.default_rng(987).standard_normal((D, NS)) if kind == "warp" else xs_points(D)
+                res["cases"][name] = dense_case(name, model, y, proc, Xs, pool)
             res["numpy"] = np.__version__
             res["scipy"] = __import__("scipy").__version__
             json.dump(res, open(OUT, "w"), indent=1)

@@ -43,3 +43,29 @@ def test_golden_file_holds_every_benchmarked_configuration():
     for k, v in judge.items():
         assert abs(bc.golden(k)["logpdf"] - v) <= 1e-13 * abs(v)
     assert abs(bc.golden("c4")["elbo"] - (-1248533.0159328678)) <= 1e-12 * 1248533.0
+
+
+def test_oracle_per_point_warps_match_standalone_warp_golden():
+    """`w4k`: select / stretch / periodic / shift views of two atoms in one programme.  Three statements agree here: the
+    standalone generator writes the covariance out by bilinearity (WarpModel), the oracle applies the reference's
+    point-wise warp definitions one point at a time (oracle/stheno.py `_warp`, compose.jl:16-28) through the
+    recursion of derived_gp.jl:31-60, and the -m gpu suite holds the product (bulk ColVecs forms + flattening + HIP)
+    against the same numbers."""
+    import oracle.stheno as st
+    g = bc.golden("w4k")
+    assert g is not None and g["N"] == 4096
+    kind, N, D = bc.CONFIGS["w4k"]
+    X, y = bc.make_inputs(N, D)
+    gpc = st.GPC()
+    a, b = st.atomic(agp.GP(kf.SEKernel()), gpc), st.atomic(agp.GP(kf.Matern52Kernel()), gpc)
+    g1 = st.select(st.stretch(a, 1.0 / math.sqrt(2.0)), [0, 1])
+    g2 = st.select(st.periodic(b, 0.3), 2)
+    g3 = st.shift(g1, np.array([0.4, -0.2, 0.1]))
+    F = st.GPPP({"g1": g1, "g2": g2, "g3": g3, "h": g1 + 2.0 * g2 - 0.5 * g3}, gpc)
+    fx = F(st.GPPPInput("h", kf.ColVecs(X)), bc.SIGMA2)
+    lp = agp.logpdf(fx, y)
+    assert abs(lp - g["logpdf"]) <= 1e-12 * abs(g["logpdf"])
+    Xs = np.random.default_rng(987).standard_normal((D, 64))
+    m, v = agp.posterior(fx, y).mean_and_var(st.GPPPInput("g1", kf.ColVecs(Xs)))
+    assert np.max(np.abs(m - np.array(g["post_mean"]))) <= 1e-10 * np.max(np.abs(g["post_mean"]))
+    assert np.max(np.abs(v - np.array(g["post_var"]))) <= 1e-10 * np.max(np.abs(g["post_var"]))
