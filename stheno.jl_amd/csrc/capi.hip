@@ -19,6 +19,11 @@ int run_mfma_bench(hipStream_t s, int iters, double* tflops_out, double* layout_
 int run_hbm_bench(hipStream_t s, long bytes, int iters, double* write_gbs, double* copy_gbs);
 
 static inline long rup(long x, long m) { return (x + m - 1) / m * m; }
+static inline long spec_rows_host(const sgp_cov_spec* sp) {
+  long n = 0;
+  for (int i = 0; i < sp->n_row_blocks; ++i) n += sp->row_len[i];
+  return n;
+}
 constexpr long NOMASK = -(1L << 40);
 constexpr long INVD_STRIDE = 8 * 256;  // eight 16x16 inverse diagonal blocks per 128-block
 constexpr long WOUT_SMALL = 512;   // outer panel width of the two-level blocked Cholesky
@@ -1689,10 +1694,12 @@ extern "C" int sgp_elbo_part_len(int64_t M, int64_t* len) {
   return 0;
 }
 
-extern "C" int sgp_dev_elbo_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
-                                    const double* var_x, const double* mean_x, int noise_kind,
-                                    const double* noise_x, int z_noise_kind, const double* z_noise,
-                                    const double* y, double* d_part, int64_t part_len) {
+// one rank's share: its slice of the data -> partial sums in d_part; the factor of K(z,z) + Sigma_z and its inverse
+// diagonal blocks go to dLz (m_pad x m_pad) / d_wz when given (a sparse posterior keeps them), else to scratch
+static int elbo_partial_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                             const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                             const double* z_noise, const double* y, double* dLz_keep, double* d_wz_keep,
+                             double* d_part, int64_t part_len) {
   CHECK_ARG(ctx && zz && xz && noise_x && z_noise && d_part, "sgp_dev_elbo_partial: NULL argument");
   CHECK_ARG(zz->symmetric, "vfe: zz spec must be symmetric");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
@@ -1703,25 +1710,38 @@ extern "C" int sgp_dev_elbo_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const 
   CHECK_RC(dspec_create(ctx, xz, &gx.ds));
   const long M = gz.ds->N, N = gx.ds->N;
   CHECK_ARG(gx.ds->M == M && M >= 1, "vfe: xz spec columns != number of inducing points");
-  CHECK_ARG(N == 0 || (var_x && y), "sgp_dev_elbo_partial: NULL data");
+  CHECK_ARG(N == 0 || y, "sgp_dev_elbo_partial: NULL data");
   const long m_pad = rup(M, TILE);
   CHECK_ARG(part_len >= vfe_part_len(m_pad), "sgp_dev_elbo_partial: part buffer too small (sgp_elbo_part_len)");
   DevBuf dLz, dwz;
-  CHECK_RC(dLz.alloc((size_t)m_pad * m_pad));
-  CHECK_RC(dwz.alloc((size_t)(m_pad / TILE) * INVD_STRIDE));
+  if (!dLz_keep) CHECK_RC(dLz.alloc((size_t)m_pad * m_pad));
+  if (!d_wz_keep) CHECK_RC(dwz.alloc((size_t)(m_pad / TILE) * INVD_STRIDE));
   StageTimer tm(ctx, ctx->stream);
-  CHECK_RC(vfe_rows_partial(ctx, gz.ds, gx.ds, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, dLz.p,
-                            dwz.p, d_part, tm));
+  CHECK_RC(vfe_rows_partial(ctx, gz.ds, gx.ds, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y,
+                            dLz_keep ? dLz_keep : dLz.p, d_wz_keep ? d_wz_keep : dwz.p, d_part, tm));
   tm.finish();
   return 0;
 }
 
+extern "C" int sgp_dev_elbo_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
+                                    const double* var_x, const double* mean_x, int noise_kind,
+                                    const double* noise_x, int z_noise_kind, const double* z_noise,
+                                    const double* y, double* d_part, int64_t part_len) {
+  CHECK_ARG(xz == nullptr || spec_rows_host(xz) == 0 || var_x, "sgp_dev_elbo_partial: NULL data");
+  return elbo_partial_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, nullptr, nullptr,
+                           d_part, part_len);
+}
+
+static int elbo_finish_core(sgp_ctx* ctx, int64_t M, double* d_part, double* d_wg, double* h) {
+  CtxScope scope(ctx);
+  StageTimer tm(ctx, ctx->stream);
+  return vfe_finish(ctx, d_part, rup(M, TILE), d_wg, h, tm);
+}
+
 extern "C" int sgp_dev_elbo_finish(sgp_ctx* ctx, int64_t M, int64_t N_total, double* d_part, double* out) {
   CHECK_ARG(ctx && d_part && out && M >= 1 && N_total >= 1, "sgp_dev_elbo_finish: bad argument");
-  CtxScope scope(ctx);
   double h[6];
-  StageTimer tm(ctx, ctx->stream);
-  CHECK_RC(vfe_finish(ctx, d_part, rup(M, TILE), nullptr, h, tm));
+  CHECK_RC(elbo_finish_core(ctx, M, d_part, nullptr, h));
   double tmp = h[0] + h[4] + h[1] - h[5];
   double dtc = -0.5 * ((double)N_total * 1.8378770664093453 + tmp);
   out[0] = dtc - 0.5 * (h[2] - h[3]);
@@ -1873,7 +1893,14 @@ extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   CHECK_ARG(ctx && zz && xz && var_x && noise_x && z_noise && y && out, "sgp_elbo: NULL argument");
   CtxScope scope(ctx);
   if (ctx->multi && ctx->multi_nranks > 1)   // data points sharded over the ranks, one reduction of M^2 + M + 2 doubles
-    return sgp_multi_elbo(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, out);
+  {
+    double hm[6];
+    CHECK_RC(sgp_multi_vfe(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, hm, nullptr, nullptr,
+                           nullptr, nullptr));
+    const long Nm = spec_rows_host(xz);
+    out[0] = -0.5 * ((double)Nm * 1.8378770664093453 + hm[0] + hm[4] + hm[1] - hm[5]) - 0.5 * (hm[2] - hm[3]);
+    return 0;
+  }
   double h[6];
   CHECK_RC(vfe_pipeline(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, h,
                         nullptr));
@@ -2244,6 +2271,32 @@ extern "C" int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz,
   CtxScope scope(ctx);
   sgp_sparse_post* p = new sgp_sparse_post();
   double h[6];
+  if (ctx->multi && ctx->multi_nranks > 1) {
+    // data points sharded over the ranks; the M x M factors of the posterior are kept on devices[0]
+    const long M = spec_rows_host(zz), m_pad = rup(M, TILE);
+    p->ctx = ctx;
+    p->M = M;
+    p->m_pad = m_pad;
+    p->ldg = m_pad + TILE;
+    int rc = 0;
+    if (hipMalloc(&p->dLz, sizeof(double) * m_pad * m_pad) != hipSuccess ||
+        hipMalloc(&p->d_wz, sizeof(double) * (m_pad / TILE) * INVD_STRIDE) != hipSuccess ||
+        hipMalloc(&p->dG, sizeof(double) * vfe_part_len(m_pad)) != hipSuccess ||
+        hipMalloc(&p->d_wg, sizeof(double) * (m_pad / TILE) * INVD_STRIDE) != hipSuccess) {
+      (void)hipGetLastError();
+      set_error("sgp_sparse_posterior_create: hipMalloc failed");
+      rc = -2;
+    }
+    if (!rc)
+      rc = sgp_multi_vfe(ctx, zz, xz, nullptr, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, h, p->dLz, p->d_wz,
+                         p->dG, p->d_wg);
+    if (rc) {
+      sgp_sparse_posterior_destroy(p);
+      return rc;
+    }
+    *out = p;
+    return 0;
+  }
   int rc = vfe_pipeline(ctx, zz, xz, nullptr, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y,
                         h, p);
   if (rc) {
@@ -2676,4 +2729,13 @@ int drv_fill_mean_cols(double* dst, long ld, long nrows, long ncols, long N, con
   return 0;
 }
 long drv_vfe_part_len(long m_pad) { return vfe_part_len(m_pad); }
+int drv_vfe_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                    const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind, const double* z_noise,
+                    const double* y, double* dLz, double* d_wz, double* d_part, long part_len) {
+  return elbo_partial_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, dLz, d_wz, d_part,
+                           part_len);
+}
+int drv_vfe_finish(sgp_ctx* ctx, long M, double* d_part, double* d_wg, double* h6) {
+  return elbo_finish_core(ctx, M, d_part, d_wg, h6);
+}
 }  // namespace sgp

@@ -32,9 +32,12 @@ int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const 
                                 const double* mean_s, double* mean_out, double* var_out, double* cov_out,
                                 int64_t ldcov);
 void sgp_multi_posterior_destroy(sgp_mpost* mp);
-int sgp_multi_elbo(struct sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
-                   const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
-                   const double* z_noise, const double* y, double* out);
+// h6: the six terms of the bound (capi.hip: vfe_pipeline).  dLz / d_wz / d_part0 / d_wg non-NULL (device 0
+// buffers): the M x M factors a sparse posterior keeps (d_part0 doubles as rank 0's part and ends up holding chol(A A' + I))
+int sgp_multi_vfe(struct sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                  const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                  const double* z_noise, const double* y, double* h6, double* dLz, double* d_wz, double* d_part0,
+                  double* d_wg);
 
 struct sgp_ctx {
   int device = 0;

@@ -35,5 +35,12 @@ int drv_fill_mean_cols(double* dst, long ld, long nrows, long ncols, long N, con
 // sparse-ELBO partial sums of a slice of the data / the final factorisation (see sgp_dev_elbo_partial / _finish);
 // keep != 0: the M x M factors stay in the caller's buffers (sparse posterior)
 long drv_vfe_part_len(long m_pad);
+// takes the context itself (CtxScope inside): d_part receives the partial sums of the slice; dLz / d_wz (optional) keep
+// the factor of K(z,z) + Sigma_z and its inverse diagonal blocks
+int drv_vfe_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                    const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind, const double* z_noise,
+                    const double* y, double* dLz, double* d_wz, double* d_part, long part_len);
+// h6: the six ELBO terms (see vfe_pipeline); d_wg (optional) keeps the inverse diagonal blocks of chol(A A' + I)
+int drv_vfe_finish(sgp_ctx* ctx, long M, double* d_part, double* d_wg, double* h6);
 
 }  // namespace sgp

@@ -1344,9 +1344,10 @@ struct SlicedSpec {
 
 }  // namespace
 
-int sgp_multi_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
-                   const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
-                   const double* z_noise, const double* y, double* out) {
+int sgp_multi_vfe(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                  const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                  const double* z_noise, const double* y, double* h6, double* dLz, double* d_wz, double* d_part0,
+                  double* d_wg) {
   sgp_multi* m = ctx->multi;
   const int P = (int)m->r.size();
   const long N = spec_rows(xz), M = spec_rows(zz);
@@ -1355,10 +1356,16 @@ int sgp_multi_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
               "vfe: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
   int64_t len = 0;
   M_RC(sgp_elbo_part_len(M, &len));
+  std::vector<double*> part(P, nullptr);
   for (int i = 0; i < P; ++i) {
     Rank& k = m->r[i];
     M_HIP(hipSetDevice(k.dev));
-    M_RC(grow(&k.d_work, &k.work_cap, (size_t)len));
+    if (i == 0 && d_part0) {
+      part[i] = d_part0;
+    } else {
+      M_RC(grow(&k.d_work, &k.work_cap, (size_t)len));
+      part[i] = k.d_work;
+    }
     if (i == 0 && P > 1 && m->transport != TR_RCCL) M_RC(grow(&k.d_work2, &k.work2_cap, (size_t)len));
   }
   // every rank's slice on a host thread of its own (the pipeline synchronises inside: Lz's info, chunk buffers)
@@ -1372,9 +1379,9 @@ int sgp_multi_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
       SlicedSpec sl(xz, lo, hi);
       Rank& k = m->r[i];
       hipSetDevice(k.dev);
-      rcs[i] = sgp_dev_elbo_partial(k.ctx, zz, &sl.c, var_x + lo, mean_x ? mean_x + lo : nullptr, noise_kind,
-                                    noise_kind == SGP_NOISE_DIAG ? noise_x + lo : noise_x, z_noise_kind, z_noise,
-                                    y + lo, k.d_work, len);
+      rcs[i] = drv_vfe_partial(k.ctx, zz, &sl.c, var_x ? var_x + lo : nullptr, mean_x ? mean_x + lo : nullptr, noise_kind,
+                               noise_kind == SGP_NOISE_DIAG ? noise_x + lo : noise_x, z_noise_kind, z_noise, y + lo,
+                               i == 0 ? dLz : nullptr, i == 0 ? d_wz : nullptr, part[i], len);
       if (rcs[i]) errs[i] = sgp_last_error();
     });
   }
@@ -1392,7 +1399,7 @@ int sgp_multi_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
       for (int i = 0; i < P && rc == 0; ++i) {
         Rank& k = m->r[i];
         hipSetDevice(k.dev);
-        rc = m->rccl.AllReduce(k.d_work, k.d_work, (size_t)len, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
+        rc = m->rccl.AllReduce(part[i], part[i], (size_t)len, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
       }
       int rc2 = m->rccl.GroupEnd();
       if (rc || rc2) {
@@ -1410,15 +1417,15 @@ int sgp_multi_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
         Rank& k = m->r[i];
         M_HIP(hipSetDevice(k0.dev));
         if (k.dev == k0.dev)
-          M_HIP(hipMemcpyAsync(k0.d_work2, k.d_work, sizeof(double) * len, hipMemcpyDeviceToDevice, k0.s_upd));
+          M_HIP(hipMemcpyAsync(k0.d_work2, part[i], sizeof(double) * len, hipMemcpyDeviceToDevice, k0.s_upd));
         else
-          M_HIP(hipMemcpyPeerAsync(k0.d_work2, k0.dev, k.d_work, k.dev, sizeof(double) * len, k0.s_upd));
-        M_RC(drv_axpy_block(k0.d_work, len, k0.d_work2, len, len, 1, 1.0, k0.s_upd));
+          M_HIP(hipMemcpyPeerAsync(k0.d_work2, k0.dev, part[i], k.dev, sizeof(double) * len, k0.s_upd));
+        M_RC(drv_axpy_block(part[0], len, k0.d_work2, len, len, 1, 1.0, k0.s_upd));
       }
       M_HIP(hipStreamSynchronize(k0.s_upd));
     }
   }
-  int rc = sgp_dev_elbo_finish(m->r[0].ctx, M, N, m->r[0].d_work, out);
+  int rc = drv_vfe_finish(m->r[0].ctx, M, part[0], d_wg, h6);
   m->last_ms = now_ms() - t0;
   hipSetDevice(ctx->device);
   return rc;

@@ -203,6 +203,29 @@ def test_elbo_data_sharded_multi(nranks):
     ctx.close()
 
 
+def test_sparse_posterior_data_sharded_multi():
+    """posterior(VFE(fz), fx, y) on a multi-GPU context: the N-sized work is sharded like the ELBO's, the M x M
+    factors are kept on devices[0] and answer predictions as on one GPU."""
+    ctx = P.lib.Context(devices=[0, 0, 0])
+    rng = np.random.default_rng(22)
+    D, N, M = 2, 1100, 64
+    f = P.stretch(P.atomic(P.GP(P.Matern52Kernel()), P.GPC()), 0.8)
+    X = np.asfortranarray(rng.standard_normal((D, N)))
+    Z = np.asfortranarray(rng.standard_normal((D, M)))
+    y = rng.standard_normal(N)
+    xs = P.ColVecs(np.asfortranarray(rng.standard_normal((D, 40))))
+    fx, fz = f(P.ColVecs(X), 0.2), f(P.ColVecs(Z), 1e-6)
+    q0 = P.posterior(P.VFE(fz), fx, y)
+    q1 = _with_ctx(ctx, lambda: P.posterior(P.VFE(fz), fx, y))
+    m0, c0 = q0.mean_and_cov(xs)
+    m1, c1 = q1.mean_and_cov(xs)
+    assert np.max(np.abs(m1 - m0)) <= 1e-9 * max(1.0, np.max(np.abs(m0)))
+    assert np.max(np.abs(c1 - c0)) <= 1e-9
+    assert np.max(np.abs(q1.var(xs) - q0.var(xs))) <= 1e-9
+    del q1
+    ctx.close()
+
+
 def test_broadcast_forms_agree_bit_for_bit(panel128, monkeypatch):
     """scatter + all-gather (default for >= 3 ranks) vs one copy owner -> receiver: the same panels arrive."""
     F, x, xs, y = _problem(1411)
