@@ -165,10 +165,23 @@ int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int n
  * /root/reference/test/gp/util.jl:76-88).  Same spec (the fp64 inputs are rounded to fp32 once on the
  * device), covariance assembly, blocked Cholesky (v_mfma_f32_32x32x2_f32 updates) and forward substitution
  * in single precision; the scalar result is returned as a double holding the fp32-accurate value.
- * y is one vector (N); noise SCALAR or DIAG.  sgp_kernelmatrix_f32: cov(f, x) / cov(f, x, x') as fp32. */
+ * y is one vector (N); noise SCALAR or DIAG.  sgp_kernelmatrix_f32: cov(f, x) / cov(f, x, x') as fp32.
+ * Limits of the fp32 kernels: input dimension <= 16 and (terms per block pair) x (dimension rounded up to a power of
+ * two) <= 64 (rc < 0 otherwise; the host mirror sends such models down the fp64 path and rounds the result). */
 int sgp_logpdf_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                    const double* noise, const double* y, double* out);
 int sgp_kernelmatrix_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, float* K, int64_t ldk);
+/* rand(rng, fx, S) on the fp32 factor: out (N x S floats) = mean .+ L Z, Z (N x S doubles) the caller's draw rounded
+ * to fp32 (AbstractGPs rand [EXT], App. A.4; `rand(rng, fx) isa Vector{Float32}`: test/gp/util.jl:76-88). */
+int sgp_rand_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                 const double* noise, const double* Z, int64_t ldz, int64_t S, float* out, int64_t ldo);
+/* posterior(fx, y) followed by mean_and_var at x* in single precision and ONE factorisation: K(x*, x) rides through
+ * the fp32 Cholesky as bordered rows below the observation row.  cross / prior_ss / mean_s as in
+ * sgp_posterior_predict; mean_out / var_out: Ns floats (either may be NULL). */
+int sgp_posterior_mean_var_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                               const double* noise, const double* y, const sgp_cov_spec* cross,
+                               const sgp_cov_spec* prior_ss, const double* mean_s, float* mean_out,
+                               float* var_out);
 
 /* ---- logpdf and its reverse-mode gradient -------------------------------
  * What Zygote derives through `logpdf(f(x, s2), y)` on the reference path for hyper-parameter

@@ -14,12 +14,13 @@
 //                           made N <= 16384 slower than fp64 (profiles/r02_microbench.md)
 // Driver: two-level right-looking Cholesky (outer panels, 128-column steps inside) with the fp64 driver's
 // one-panel look-ahead on two streams.
-// Entry points: sgp_logpdf_f32, sgp_kernelmatrix_f32 (include/sthenomi.h).  Accuracy is fp32's: the
+// Entry points: sgp_logpdf_f32, sgp_kernelmatrix_f32, sgp_rand_f32, sgp_posterior_mean_var_f32 (include/sthenomi.h).  Accuracy is fp32's: the
 // tests hold 1e-4 relative on logpdf against the fp64 oracle at N <= 3000.
-#include "ctx.h"
+#include "driver.h"
 
 #include <algorithm>
 #include <cmath>
+#include <vector>
 
 using namespace sgp;
 
@@ -464,5 +465,191 @@ extern "C" int sgp_kernelmatrix_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, floa
   SGP_HIP(hipGetLastError());
   SGP_HIP(hipStreamSynchronize(s));
   SGP_HIP(hipMemcpy2D(K, sizeof(float) * ldk, Od, sizeof(float) * N, sizeof(float) * N, (size_t)M, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// rand and posterior moments on the fp32 factor (round 3; the reference's type-stability test covers rand:
+// /root/reference/test/gp/util.jl:76-88)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+// per bordered row r < nrows:  dot[r] = sum_c R[r, c] z[c],  ssq[r] = sum_c R[r, c]^2  (fp32 storage, fp64 sums;
+// R and the z row live in the same bordered matrix: z[c] = zrow[c * ld]).  32 rows x 8 column lanes per workgroup:
+// every wave load is 32 consecutive rows of one column.
+__global__ __launch_bounds__(256) void rows_stats_f32_kernel(const float* R, long ld, long nrows, long nc, const float* zrow,
+                                                             double* dot, double* ssq) {
+  __shared__ double sh[2][8][33];
+  const int r = threadIdx.x & 31, kq = threadIdx.x >> 5;
+  const long j = (long)blockIdx.x * 32 + r;
+  double a = 0.0, b = 0.0;
+  if (j < nrows)
+    for (long c = kq; c < nc; c += 8) {
+      const double v = (double)R[j + c * ld];
+      a = fma(v, (double)zrow[c * ld], a);
+      b = fma(v, v, b);
+    }
+  sh[0][kq][r] = a;
+  sh[1][kq][r] = b;
+  __syncthreads();
+  if (kq == 0 && j < nrows) {
+    double ta = 0.0, tb = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      ta += sh[0][q][r];
+      tb += sh[1][q][r];
+    }
+    dot[j] = ta;
+    ssq[j] = tb;
+  }
+}
+
+struct SpecG {
+  sgp_dspec* d = nullptr;
+  ~SpecG() {
+    if (d) sgp_dspec_free_nolock(d);
+  }
+};
+
+// K + Sigma_y (fp32, lower tiles, identity padding) into the zero-initialised m_tot x n_pad matrix A
+int build_f32(sgp_ctx* ctx, const sgp_dspec* ds, float* A, long n_pad, long m_tot, int noise_kind, const double* noise,
+              const double* d_noise, hipStream_t s) {
+  const long N = ds->N;
+  SGP_HIP(hipMemsetAsync(A, 0, sizeof(float) * m_tot * n_pad, s));
+  if (int rc = assemble_f32(ds, A, m_tot, 1, noise_kind, noise_kind == SGP_NOISE_SCALAR ? (float)noise[0] : 0.0f, d_noise, s))
+    return rc;
+  const long h = n_pad - N;
+  if (h > 0) {
+    const long tot = h * m_tot;
+    hipLaunchKernelGGL(fill_pad_f32_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, A, m_tot, N, n_pad, m_tot);
+    SGP_HIP(hipGetLastError());
+  }
+  return 0;
+}
+
+int posdef_info(sgp_ctx* ctx, hipStream_t s) {
+  int info = 0;
+  SGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
+  SGP_HIP(hipStreamSynchronize(s));
+  if (info > 0)
+    set_error("matrix is not positive definite (fp32); Cholesky factorization failed at leading minor " +
+              std::to_string(info));
+  return info;
+}
+
+}  // namespace
+
+// rand(rng, fx, S) in single precision: out = mean .+ L Z with L the fp32 factor (AbstractGPs rand [EXT], App. A.4).
+// Z (N x S doubles, the caller's draw) is rounded to fp32.  The strictly upper 128-tiles of the factor buffer are zero
+// (never written) and potrf_diag zeroes the upper part of the diagonal tiles, so L Z is one plain fp32 MFMA product.
+extern "C" int sgp_rand_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind, const double* noise,
+                            const double* Z, int64_t ldz, int64_t S, float* out, int64_t ldo) {
+  F_CHECK_ARG(ctx && spec && noise && Z && out, "sgp_rand_f32: NULL argument");
+  F_CHECK_ARG(spec->symmetric, "sgp_rand_f32: spec must be symmetric");
+  F_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG, "sgp_rand_f32: noise kind must be SCALAR or DIAG");
+  CtxScope scope(ctx);
+  SpecG g;
+  if (int rc = sgp_dspec_create_nolock(ctx, spec, &g.d)) return rc;
+  const long N = g.d->N;
+  F_CHECK_ARG(N >= 1 && S >= 1 && ldz >= N && ldo >= N, "sgp_rand_f32: bad sizes");
+  int64_t n_pad, m_tot;
+  sgp_geometry(N, 0, &n_pad, &m_tot);
+  F_CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
+  const long s_pad = (S + TILE - 1) / TILE * TILE;
+  hipStream_t s = ctx->stream;
+  DevBuf dA, dn, dZt, dC;
+  if (int rc = dA.alloc((size_t)(m_tot * n_pad + 1) / 2 + 64)) return rc;
+  if (int rc = dZt.alloc((size_t)(s_pad * n_pad + 1) / 2 + 64)) return rc;
+  if (int rc = dC.alloc((size_t)(n_pad * s_pad + 1) / 2 + 64)) return rc;
+  if (noise_kind == SGP_NOISE_DIAG)
+    if (int rc = dn.upload(noise, N)) return rc;
+  float* A = reinterpret_cast<float*>(dA.p);
+  float* Zt = reinterpret_cast<float*>(dZt.p);
+  float* Cm = reinterpret_cast<float*>(dC.p);
+  // host staging: Zt[s + k * s_pad] = -Z[k, s] (the product kernel computes C -= A B'), C[i + s * n_pad] = mean[i]
+  std::vector<float> hz((size_t)s_pad * n_pad, 0.0f), hc((size_t)n_pad * s_pad, 0.0f);
+  for (long sc = 0; sc < S; ++sc)
+    for (long k = 0; k < N; ++k) {
+      hz[(size_t)sc + (size_t)k * s_pad] = -(float)Z[k + sc * ldz];
+      hc[(size_t)k + (size_t)sc * n_pad] = mean ? (float)mean[k] : 0.0f;
+    }
+  SGP_HIP(hipMemcpyAsync(Zt, hz.data(), sizeof(float) * hz.size(), hipMemcpyHostToDevice, s));
+  SGP_HIP(hipMemcpyAsync(Cm, hc.data(), sizeof(float) * hc.size(), hipMemcpyHostToDevice, s));
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  if (int rc = build_f32(ctx, g.d, A, n_pad, m_tot, noise_kind, noise, dn.p, s)) return rc;
+  if (int rc = chol_f32(ctx, A, m_tot, n_pad, m_tot, s)) return rc;
+  if (int rc = launch_gemm_f32(A, m_tot, Zt, s_pad, Cm, n_pad, n_pad, s_pad, n_pad, 0, s)) return rc;
+  if (int info = posdef_info(ctx, s)) return info;
+  SGP_HIP(hipMemcpy2D(out, sizeof(float) * ldo, Cm, sizeof(float) * n_pad, sizeof(float) * N, (size_t)S,
+                      hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// posterior(fx, y) followed by mean_and_var at x*, in single precision and ONE factorisation: the test points ride
+// through the fp32 Cholesky as bordered rows below the observation row (the trick the sharded fp64 posterior uses):
+//   rows n_pad            : (y - m)'          ->  z' = (L^-1 (y - m))'
+//   rows n_pad + 128 ...  : K(x*, x)          ->  V' = K(x*, x) L^-T
+// mean* = m* + V' z, var* = diag K** - rowsumsq(V')  (AbstractGPs posterior + mean_and_var [EXT], App. A.5).
+// cross: rows x*, columns x;  prior_ss: symmetric spec at x* (its diagonal is evaluated in fp64 and rounded).
+extern "C" int sgp_posterior_mean_var_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                                          const double* noise, const double* y, const sgp_cov_spec* cross,
+                                          const sgp_cov_spec* prior_ss, const double* mean_s, float* mean_out,
+                                          float* var_out) {
+  F_CHECK_ARG(ctx && spec && noise && y && cross, "sgp_posterior_mean_var_f32: NULL argument");
+  F_CHECK_ARG(spec->symmetric && !cross->symmetric, "sgp_posterior_mean_var_f32: spec symmetric, cross not");
+  F_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+              "sgp_posterior_mean_var_f32: noise kind must be SCALAR or DIAG");
+  F_CHECK_ARG(!var_out || prior_ss, "sgp_posterior_mean_var_f32: prior_ss spec required for var");
+  CtxScope scope(ctx);
+  SpecG g, gc, gp;
+  if (int rc = sgp_dspec_create_nolock(ctx, spec, &g.d)) return rc;
+  if (int rc = sgp_dspec_create_nolock(ctx, cross, &gc.d)) return rc;
+  if (prior_ss)
+    if (int rc = sgp_dspec_create_nolock(ctx, prior_ss, &gp.d)) return rc;
+  const long N = g.d->N, Ns = gc.d->N;
+  F_CHECK_ARG(N >= 1 && gc.d->M == N, "sgp_posterior_mean_var_f32: cross spec columns != training size");
+  F_CHECK_ARG(!gp.d || gp.d->N == Ns, "sgp_posterior_mean_var_f32: prior_ss size != number of x*");
+  if (Ns == 0) return 0;
+  int64_t n_pad, mt1;
+  sgp_geometry(N, 1, &n_pad, &mt1);
+  F_CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
+  const long ns_pad = (Ns + TILE - 1) / TILE * TILE;
+  const long m_tot = mt1 + ns_pad, row0 = mt1;
+  hipStream_t s = ctx->stream;
+  DevBuf dA, dy, dm, dn, dres;
+  if (int rc = dA.alloc((size_t)(m_tot * n_pad + 1) / 2 + 64)) return rc;
+  if (int rc = dy.upload(y, N)) return rc;
+  if (mean)
+    if (int rc = dm.upload(mean, N)) return rc;
+  if (noise_kind == SGP_NOISE_DIAG)
+    if (int rc = dn.upload(noise, N)) return rc;
+  if (int rc = dres.alloc((size_t)3 * ns_pad)) return rc;
+  float* A = reinterpret_cast<float*>(dA.p);
+  SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  if (int rc = build_f32(ctx, g.d, A, n_pad, m_tot, noise_kind, noise, dn.p, s)) return rc;
+  {
+    const long totb = (long)TILE * n_pad;
+    hipLaunchKernelGGL(border_f32_kernel, dim3((unsigned)((totb + 255) / 256)), dim3(256), 0, s, A, m_tot, (long)n_pad, N,
+                       dy.p, mean ? dm.p : nullptr);
+    SGP_HIP(hipGetLastError());
+  }
+  // K(x*, x): element (r, c) at A[row0 + r + c * m_tot]
+  if (int rc = assemble_f32(gc.d, A + row0, m_tot, 0, -1, 0.0f, nullptr, s)) return rc;
+  if (int rc = chol_f32(ctx, A, m_tot, n_pad, m_tot, s)) return rc;
+  double* d_dot = dres.p;
+  double* d_ssq = dres.p + ns_pad;
+  double* d_prior = dres.p + 2 * ns_pad;
+  hipLaunchKernelGGL(rows_stats_f32_kernel, dim3((unsigned)((Ns + 31) / 32)), dim3(256), 0, s, A + row0, m_tot, Ns, N,
+                     A + n_pad, d_dot, d_ssq);
+  SGP_HIP(hipGetLastError());
+  if (var_out)
+    if (int rc = drv_diag_of_spec(ctx, gp.d, d_prior, s)) return rc;
+  if (int info = posdef_info(ctx, s)) return info;
+  std::vector<double> h((size_t)3 * ns_pad);
+  SGP_HIP(hipMemcpy(h.data(), dres.p, sizeof(double) * 3 * ns_pad, hipMemcpyDeviceToHost));
+  for (long r = 0; r < Ns; ++r) {
+    if (mean_out) mean_out[r] = (float)((mean_s ? mean_s[r] : 0.0) + h[r]);
+    if (var_out) var_out[r] = (float)(h[2 * ns_pad + r] - h[ns_pad + r]);
+  }
   return 0;
 }

@@ -361,6 +361,13 @@ def rand(rng, fx, S=None, Z=None):
     Z = _f64(np.asarray(Z, dtype=np.float64).reshape(n, s))
     spec, m, kind, nbuf = _spec_mean_noise(fx)
     m = _f64(m)
+    if _is_prior(fx.f) and _eltype(fx.x) == np.float32 and kind != _lib.NOISE_DENSE and spec.f32_supported():
+        # Float32 model: the fp32 factor and an fp32 MFMA product L Z (sgp_rand_f32); `rand(rng, fx) isa Vector{Float32}`
+        out32 = np.zeros((n, s), dtype=np.float32, order="F")
+        rc = _ctx().lib.sgp_rand_f32(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(Z), n, s,
+                                     out32.ctypes.data_as(C.POINTER(C.c_float)), n)
+        _lib.check(rc, "sgp_rand_f32")
+        return out32[:, 0].copy() if S is None else out32
     out = np.zeros((n, s), order="F")
     rc = _ctx().lib.sgp_rand(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(Z), n, s,
                              _lib.dptr(out), n)
@@ -374,9 +381,30 @@ def rand(rng, fx, S=None, Z=None):
 class PosteriorGP:
     """posterior(fx, y): keeps L and L^-1 (y - m) in HBM (sgp_post); data = (alpha, x, delta)."""
 
-    def __init__(self, prior, x, handle, alpha, delta, noise=None, y=None):
-        self.prior, self.x, self._h, self.alpha, self.delta = prior, x, handle, alpha, delta
+    def __init__(self, prior, x, handle, alpha, delta, noise=None, y=None, mean_x=None):
+        self.prior, self.x, self._h, self._alpha, self.delta = prior, x, handle, alpha, delta
         self.noise, self.y = noise, y      # kept for sequential conditioning (posterior of a posterior)
+        self._mean_x = mean_x
+
+    def _ensure(self):
+        """The fp64 factor in HBM.  A Float32 model (handle None at construction) answers mean / var from the fp32
+        one-shot path (sgp_posterior_mean_var_f32) and only builds the fp64 factor when cov / alpha are asked for."""
+        if self._h is None:
+            n = len(self.y)
+            spec = _prior_spec(self.prior, self.x)
+            kind, nbuf = _lib._noise_args(self.noise, n)
+            alpha = np.zeros(n)
+            h = C.c_void_p()
+            rc = _ctx().lib.sgp_posterior_create(_ctx().handle, spec.ref(), _lib.dptr(self._mean_x), kind, _lib.dptr(nbuf),
+                                                 _lib.dptr(self.y), _lib.dptr(alpha), C.byref(h))
+            _lib.check(rc, "sgp_posterior_create")
+            self._h, self._alpha = h, alpha
+        return self._h
+
+    @property
+    def alpha(self):
+        self._ensure()
+        return self._alpha
 
     def __del__(self):  # pragma: no cover
         try:
@@ -394,6 +422,21 @@ class PosteriorGP:
         pss = _prior_spec(self.prior, xs) if (want_var or want_cov) else None
         ns = cross.N
         ms = _f64(mean_vector(self.prior, xs))
+        if self._h is None and not want_cov and ns > 0:
+            # Float32 model, moments only: one fp32 factorisation with x* riding along as bordered rows
+            spec = _prior_spec(self.prior, self.x)
+            kind, nbuf = _lib._noise_args(self.noise, len(self.y))
+            if (kind != _lib.NOISE_DENSE and spec.f32_supported() and cross.f32_supported()
+                    and _eltype(xs) == np.float32):
+                mo32 = np.zeros(ns, dtype=np.float32) if want_mean else None
+                vo32 = np.zeros(ns, dtype=np.float32) if want_var else None
+                fp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
+                rc = _ctx().lib.sgp_posterior_mean_var_f32(
+                    _ctx().handle, spec.ref(), _lib.dptr(self._mean_x), kind, _lib.dptr(nbuf), _lib.dptr(self.y),
+                    cross.ref(), pss.ref() if pss is not None else None, _lib.dptr(ms), fp(mo32), fp(vo32))
+                _lib.check(rc, "sgp_posterior_mean_var_f32")
+                return mo32, vo32, None
+        self._ensure()
         mo = np.zeros(ns) if want_mean else None
         vo = np.zeros(ns) if want_var else None
         co = np.zeros((ns, ns), order="F") if want_cov else None
@@ -465,15 +508,14 @@ def posterior(fx, y, y_vfe=None):
     n = len(fx)
     if y.shape[0] != n:
         raise ValueError("length(y) != length(fx)")
-    spec = _prior_spec(fx.f, fx.x)
     m = _f64(mean_vector(fx.f, fx.x))
-    kind, nbuf = _lib._noise_args(fx.noise, n)
-    alpha = np.zeros(n)
-    h = C.c_void_p()
-    rc = _ctx().lib.sgp_posterior_create(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(y),
-                                         _lib.dptr(alpha), C.byref(h))
-    _lib.check(rc, "sgp_posterior_create")
-    return PosteriorGP(fx.f, fx.x, h, alpha, y - m, fx.noise, y.copy())
+    post = PosteriorGP(fx.f, fx.x, None, None, y - m, fx.noise, y.copy(), mean_x=m)
+    if _eltype(fx.x) == np.float32 and np.ndim(fx.noise) <= 1 and _prior_spec(fx.f, fx.x).f32_supported():
+        # Float32 model: mean / var of the posterior come from the fp32 path; the fp64 factor is built on demand
+        # (cov, alpha).  A non-positive-definite covariance then surfaces at the first prediction.
+        return post
+    post._ensure()                 # fp64: factor now (PosDefException here, as `cholesky` throws in the reference)
+    return post
 
 
 # ---- VFE / sparse --------------------------------------------------------------------------------

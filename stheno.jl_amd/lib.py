@@ -77,6 +77,10 @@ _SIGS = {
                              C.c_int64, _D]),
     "sgp_logpdf_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D]),
     "sgp_kernelmatrix_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(C.c_float), C.c_int64]),
+    "sgp_rand_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64, C.c_int64,
+                               C.POINTER(C.c_float), C.c_int64]),
+    "sgp_posterior_mean_var_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.POINTER(sgp_cov_spec),
+                                             C.POINTER(sgp_cov_spec), _D, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "sgp_logpdf_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D]),
     "sgp_logpdf_grad_x": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D, _D, _D, _D, _D, _D,
                                     C.POINTER(_D)]),

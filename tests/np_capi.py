@@ -206,6 +206,37 @@ class FakeLib:
             return rc
         return self.sgp_logpdf(ctx, spec, mean, kind, noise, y, s.N, 1, out)
 
+    def sgp_rand_f32(self, ctx, spec, mean, kind, noise, Z, ldz, S, out, ldo):
+        s, m, Cm, rc = self._observed(spec, mean, kind, noise)
+        rc = rc or self._f32_limits(s)
+        if rc:
+            return rc
+        Lm, info = _chol(Cm)
+        if info:
+            return self._fail("matrix is not positive definite", info)
+        flat = np.ctypeslib.as_array(out, shape=(int(ldo) * int(S),))
+        flat.reshape((int(S), int(ldo)))[:, : s.N].T[:, :] = (m[:, None] + Lm @ _mat(Z, s.N, S, ldz)).astype(np.float32)
+        return 0
+
+    def sgp_posterior_mean_var_f32(self, ctx, spec, mean, kind, noise, y, cross, prior_ss, mean_s, mean_out, var_out):
+        s, m, Cm, rc = self._observed(spec, mean, kind, noise)
+        rc = rc or self._f32_limits(s) or self._f32_limits(_Spec(cross))
+        if rc:
+            return rc
+        Lm, info = _chol(Cm)
+        if info:
+            return self._fail("matrix is not positive definite", info)
+        Kx = _Spec(cross).dense()
+        ns = Kx.shape[0]
+        ms = np.zeros(ns) if not mean_s else _vec(mean_s, ns)
+        z = sla.solve_triangular(Lm, _vec(y, s.N) - m, lower=True, check_finite=False)
+        V = sla.solve_triangular(Lm, Kx.T, lower=True, check_finite=False)
+        if mean_out:
+            np.ctypeslib.as_array(mean_out, shape=(ns,))[:] = (ms + V.T @ z).astype(np.float32)
+        if var_out:
+            np.ctypeslib.as_array(var_out, shape=(ns,))[:] = (np.diag(_Spec(prior_ss).dense()) - (V * V).sum(0)).astype(np.float32)
+        return 0
+
     # -- the observation model C = K + Sigma_y ---------------------------------------------------------
     def _observed(self, spec, mean, kind, noise):
         s = _Spec(spec)

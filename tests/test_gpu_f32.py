@@ -79,3 +79,48 @@ def test_posdef_failure_f32():
     X = rng.standard_normal((2, 300)).astype(np.float32)
     with pytest.raises(P.PosDefException):
         P.logpdf(f(P.ColVecs(X), np.float32(-5.0)), rng.standard_normal(300).astype(np.float32))
+
+
+def test_rand_f32_type_stable_and_close_to_fp64():
+    """rand(rng, fx) / rand(rng, fx, S) of a Float32 model (test/gp/util.jl:76-88 checks `rand` type stability): the
+    fp32 factor times the caller's draw, against the oracle's m + L Z at fp32 tolerance."""
+    rng = np.random.default_rng(12)
+    Fo, Fp = _both(models.toy_gppp)
+    xs = [rng.standard_normal(n).astype(np.float32) for n in (150, 129, 200)]
+    names = ("f1", "f2", "f3")
+    xo = ost.BlockData([ost.GPPPInput(k, v.astype(np.float64)) for k, v in zip(names, xs)])
+    xp = P.BlockData([P.GPPPInput(k, v) for k, v in zip(names, xs)])
+    N = len(xp)
+    Z = rng.standard_normal((N, 3))
+    ref = oagp.rand(Fo(xo, 0.1), Z)
+    got = P.rand(None, Fp(xp, np.float32(0.1)), 3, Z=Z)
+    assert got.dtype == np.float32 and got.shape == (N, 3)
+    assert np.max(np.abs(got - ref)) <= 2e-4 * np.max(np.abs(ref))
+    one = P.rand(None, Fp(xp, np.float32(0.1)), Z=Z[:, :1])
+    assert one.dtype == np.float32 and one.shape == (N,) and np.array_equal(one, got[:, 0])
+
+
+def test_posterior_moments_f32_and_fp64_factor_on_demand():
+    """posterior(fx, y) of a Float32 model: mean / var at x* from ONE fp32 factorisation with x* riding along as bordered
+    rows (sgp_posterior_mean_var_f32); cov and alpha build the fp64 factor on demand."""
+    rng = np.random.default_rng(13)
+    Fo, Fp = _both(models.gppp_docstring)
+    x1, x3 = rng.standard_normal(300).astype(np.float32), rng.standard_normal(417).astype(np.float32)
+    xo = ost.BlockData([ost.GPPPInput("f1", x1.astype(np.float64)), ost.GPPPInput("f3", x3.astype(np.float64))])
+    xp = P.BlockData([P.GPPPInput("f1", x1), P.GPPPInput("f3", x3)])
+    y = rng.standard_normal(717).astype(np.float32)
+    t = np.linspace(-2, 2, 70).astype(np.float32)
+    s2 = float(np.float32(0.1))          # the Float32 noise value, exactly, on both sides
+    po = oagp.posterior(Fo(xo, s2), y.astype(np.float64))
+    pp = P.posterior(Fp(xp, np.float32(0.1)), y)
+    for proc in ("f2", "f3"):
+        mo, vo = po.mean_and_var(ost.GPPPInput(proc, t.astype(np.float64)))
+        mp, vp = pp.mean_and_var(P.GPPPInput(proc, t))
+        assert mp.dtype == np.float32 and vp.dtype == np.float32
+        assert np.max(np.abs(mp - mo)) <= 2e-4 * max(1.0, np.max(np.abs(mo)))
+        assert np.max(np.abs(vp - vo)) <= 2e-4
+    m, v = P.mean_and_var(pp(P.GPPPInput("f3", t), np.float32(0.01)))        # FiniteGP on top of the posterior
+    assert m.dtype == np.float32 and v.dtype == np.float32
+    c = pp.cov(P.GPPPInput("f3", t))                                          # needs the factor: fp64, built now
+    assert np.max(np.abs(c - po.cov(ost.GPPPInput("f3", t.astype(np.float64))))) <= 1e-8
+    assert np.max(np.abs(pp.alpha - po.alpha)) <= 1e-8 * np.max(np.abs(po.alpha))

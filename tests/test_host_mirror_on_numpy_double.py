@@ -46,7 +46,8 @@ del _name
 import test_gpu_f32 as F32  # noqa: E402
 
 for _name in ("test_logpdf_f32_single_gp", "test_logpdf_f32_gppp_blocks_diag_noise_and_means", "test_cov_and_mean_f32",
-              "test_posdef_failure_f32"):
+              "test_posdef_failure_f32", "test_rand_f32_type_stable_and_close_to_fp64",
+              "test_posterior_moments_f32_and_fp64_factor_on_demand"):
     globals()[_name] = getattr(F32, _name)
 del _name
 
