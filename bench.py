@@ -391,7 +391,7 @@ def main():
                 roofline["traffic_source"] = dict(rec, file="profiles/" + tr_name)
                 break
         roofline["algorithmic_bytes_per_launch_avg"] = update_bytes_avg(N)
-        for pmc_name in ("r02_gemm_pmc.json", "r01_gemm_pmc.json"):
+        for pmc_name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc):
                 roofline["traffic_profiled"] = json.load(open(pmc))

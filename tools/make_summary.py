@@ -1,5 +1,5 @@
-"""Builds profiles/r02_summary.md and copies the committed artefacts from gpurun_out/r02final
-(collected by tools/collect_r02.sh on the MI355X box).  usage: make_summary.py [tag] [srcdir]"""
+"""Builds profiles/<tag>_summary.md and copies the committed artefacts from gpurun_out/<tag>final
+(collected by tools/collect_<tag>.sh on the MI355X box).  usage: make_summary.py [tag=r03] [srcdir=<tag>final]"""
 import csv
 import collections
 import glob
@@ -9,8 +9,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
-SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else "r02final")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else TAG + "final")
 DST = os.path.join(ROOT, "profiles")
 CONFIGS = ("c1", "n4k", "c2", "c3", "c4", "c5", "target")
 
@@ -41,8 +41,8 @@ def pmc(prefix, tag, match):
 
 def main():
     os.makedirs(DST, exist_ok=True)
-    L = [f"# Round 2 — measurements on one MI355X (gfx950, ROCm 7.2, gpurun box: 256 host cores)", "",
-         "All numbers come from `tools/collect_r02.sh` (one gpurun call); raw files next to this one.  Inputs: "
+    L = [f"# Round {int(TAG[1:])} — measurements on one MI355X (gfx950, ROCm 7.2, gpurun box)", "",
+         f"All numbers come from `tools/collect_{TAG}.sh` (one gpurun call); raw files next to this one.  Inputs: "
          "bench_configs.py (seeded standard normals, lengthscale sqrt(D), sigma^2 = 0.1); `parity` = |value - CPU golden| / "
          "|golden| against tests/golden/baseline_configs.json.", ""]
     b = {c: jload(f"bench_{c}.json") for c in CONFIGS}
@@ -65,8 +65,27 @@ def main():
         L.append(f"| {c} | {j['config']['workload'][:78]} | {j['ms_per_step']:.3f} | {j['value']:.4g} {j['unit']} | "
                  f"{j['cholesky_tflops_whole_step']:.1f} | {j['cholesky_tflops_whole_step']/78.6:.2f} | {r.get('frac', float('nan')):.3f} | "
                  f"{(asm or float('nan')):.0f} | {ha.get('ms_per_call', float('nan')):.3f} | {j.get('parity_rel', float('nan')):.1e} |")
-    L += ["", "Round-1 values of the same lines (profiles/r01_summary.md): c1 1.89 ms, n4k 5.8 ms, c2 36.8 ms, c3 203.9 ms, "
-          "c4 177.4 ms, c5 1516 ms (boxes differ by +-3 % at N = 65536: the step is power / clock limited)."]
+    L += ["", "Earlier rounds, same lines: round 1 c1 1.89 ms, n4k 5.8, c2 36.8, c3 203.9, c4 177.4, c5 1516; round 2 c1 1.10, n4k 2.47, "
+          "c2 32.9, c3 200.2, c4 165.9, c5 1475 - 1525, target 1515 (boxes differ by +-3 % at N = 65536: the step is power / clock limited)."]
+    la = {c: jload(f"bench_{c}_lookahead.json") for c in ("c5", "target")}
+    if any(la.values()):
+        L += ["", "Schedule A/B at N = 65 536 on this box (default: serial, one fused trailing-update launch per panel; "
+              "`SGP_LOOKAHEAD=2`: two-stream look-ahead):", ""]
+        for c, j in la.items():
+            if j and b.get(c):
+                L.append(f"* {c}: serial {b[c]['ms_per_step']:.1f} ms (roofline.frac {b[c]['roofline']['frac']:.3f}), look-ahead "
+                         f"{j['ms_per_step']:.1f} ms (frac {j['roofline']['frac']:.3f}; while busy "
+                         f"{(j['roofline'].get('achieved_while_busy') or 0) / 78.6:.3f})")
+    for name, what in (("bench_c5_multi8_loopback.json", "`bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config c5` (the in-process "
+                        "multi-GPU context with eight loopback ranks on the ONE GPU: the code path `--gpus 8` takes on a node)"),
+                       ("bench_c4_multi2_loopback.json", "`bench.py --gpus 2 --devices 0,0 --config c4` (data-sharded ELBO, two loopback ranks)")):
+        j = jload(name)
+        if j:
+            json.dump(j, open(os.path.join(DST, f"{TAG}_{name}"), "w"), indent=1)
+            mg = j.get("multi_gpu") or {}
+            L += ["", f"* {what}: {j['ms_per_step']:.1f} ms, n_gpus {j['n_gpus']}, transport {mg.get('transport')} "
+                  f"({mg.get('peer_copy_form')}), parity {j['parity_rel']:.1e}; per-rank update TFLOP/s "
+                  f"{[round(r['update_tflops'], 1) if r.get('update_tflops') else None for r in mg.get('per_rank', [])]}"]
     for c in ("c5", "target", "c4"):
         j = b[c]
         if not j:
@@ -99,7 +118,7 @@ def main():
             sp.loader.exec_module(bm)
             alg = bm.update_bytes_avg(j["config"]["N"])
             L.append(f"* `roofline.traffic` (rocprofv3 `--pmc FETCH_SIZE` / `WRITE_SIZE`, separate passes over the same command, "
-                     f"{t['launches_profiled']} launches of `gemm_nt_dma_kernel<1>`; tools/collect_traffic.sh): FETCH_SIZE "
+                     f"{t['launches_profiled']} launches of `{t.get('kernel', 'gemm_nt_dma_kernel<1>')}`; tools/collect_traffic.sh): FETCH_SIZE "
                      f"{t['FETCH_SIZE_KiB_avg_per_launch']*1024/1e9:.2f} GB (x2 corrected), WRITE_SIZE {t['WRITE_SIZE_KiB_avg_per_launch']*1024/1e9:.2f} GB "
                      f"per launch -> **{t['hbm_bytes_per_launch']/1e9:.1f} GB per launch** against {alg/1e9:.2f} GB algorithmic "
                      f"(C block read + written once, panel rows once) = {t['hbm_bytes_per_launch']/alg:.2f}x: WRITE_SIZE is the algorithmic "
@@ -107,7 +126,7 @@ def main():
         if cpu:
             L.append(f"* cpu_baseline ({cpu['kind']}, {cpu['cores']} threads): {cpu['sample']} -> {cpu['value']:.3g} {cpu['unit']}; "
                      f"GPU / CPU = {j['value']/cpu['value']:.0f}x (reported baseline, not a target).  Thread sweep of the blocked "
-                     f"Cholesky at n = 6144 (GFLOP/s): {cpu.get('thread_sweep_cholesky_gflops')}.")
+                     f"Cholesky (GFLOP/s; host cores {cpu.get('host_cores')}, threads used {cpu.get('threads_used')}): {cpu.get('thread_sweep_cholesky_gflops')}.")
     # rocprof kernel stats
     for tag in ("c5", "target", "c2", "c1", "c4"):
         src = os.path.join(SRC, f"prof_{tag}", f"{tag}_kernel_stats.csv")
@@ -122,10 +141,11 @@ def main():
                      f"{float(rr['AverageNs'])/1e3:.1f} | {float(rr['Percentage']):.2f} |")
         jb = jload(f"prof_{tag}_bench.json")
         if jb and jb.get("roofline") and jb["roofline"].get("launches"):
-            upd = [rr for rr in rows if "gemm_nt_dma_kernel<1>" in rr["Name"]]
+            upd = [rr for rr in rows if "gemm_nt_dma_kernel<1>" in rr["Name"] or "gemm_nt_dma_potrf_kernel<1," in rr["Name"]]
+            upd.sort(key=lambda rr: -float(rr["TotalDurationNs"]))
             agree = ""
             if upd:
-                agree = (f"  rocprof's average for `gemm_nt_dma_kernel<1>` ({upd[0]['Calls']} calls over all steps of the run): "
+                agree = (f"  rocprof's average for `{upd[0]['Name'].split('(')[0].replace('void ', '')}` ({upd[0]['Calls']} calls over all steps of the run): "
                          f"{float(upd[0]['AverageNs'])/1e6:.3f} ms.")
             L += ["", f"Same run, bench's own HIP-event figure: {jb['roofline']['achieved']:.1f} TFLOP/s over "
                   f"{jb['roofline']['launches']} trailing updates (avg {jb['roofline']['avg_launch_ms']:.3f} ms)." + agree]
@@ -205,6 +225,9 @@ def main():
               ("timeline_c1.txt", "Same at N = 2048 (one outer panel, single stream)"),
               ("gemm_sizes.log", "Isolated trailing-update launches by size and depth (`tools/gpu_gemm_sizes.py`)"),
               ("multi_time.log", "In-process multi-rank context on the one GPU (`tools/gpu_multi_time.py`)"),
+              ("multi_ops_time.log", "Operators of the multi-GPU context on loopback ranks (`tools/gpu_multi_ops_time.py`)"),
+              ("multi_profile.log", "Serialised per-panel profile of the sharded factorisation (`tools/gpu_multi_profile.py`; "
+               "input of `tools/multi_projection.py`, see " + TAG + "_multi_projection.md)"),
               ("potrf_phases.log", "`potrf_diag_kernel` phase by phase (s_memtime ticks of wave 0, `tools/gpu_potrf_phases.py`)"),
               ("potrf_contend.log", "`potrf_diag_kernel` while trailing updates run on the other stream (`tools/gpu_potrf_contend.py`)"),
               ("bign.log", "Beyond the BASELINE sizes (`tools/gpu_bign.py`)"),
@@ -225,6 +248,28 @@ def main():
         L += ["", f"* `bench.py --config c5 --dtype f32` (fp32 instantiation, `sgp_logpdf_f32`): {j32['ms_per_step']:.1f} ms = "
               f"{j32['cholesky_tflops_whole_step']:.1f} TFLOP/s ({j32['roofline']['frac']:.2f} of the 157.3 TFLOP/s fp32 MFMA peak), "
               f"|value - fp64 golden| / |golden| = {j32['parity_rel']:.1e}."]
+    for pf in sorted(glob.glob(os.path.join(SRC, "multi_profile_*.json"))):
+        shutil.copy(pf, os.path.join(DST, f"{TAG}_" + os.path.basename(pf)))
+    trs = {}
+    for c in ("c5", "target"):
+        try:
+            f_, w_ = (json.load(open(os.path.join(SRC, f"{c}_{k}.json"))) for k in ("FETCH_SIZE", "WRITE_SIZE"))
+        except Exception:
+            continue
+        if b.get(c):
+            import importlib.util
+            sp = importlib.util.spec_from_file_location("benchmod2", os.path.join(ROOT, "bench.py"))
+            bm = importlib.util.module_from_spec(sp)
+            sp.loader.exec_module(bm)
+            alg = bm.update_bytes_avg(b[c]["config"]["N"])
+            hb = (2 * f_["avg_KiB_per_launch"] + w_["avg_KiB_per_launch"]) * 1024
+            trs[c] = {"FETCH_SIZE_KiB_avg_per_launch": f_["avg_KiB_per_launch"], "WRITE_SIZE_KiB_avg_per_launch": w_["avg_KiB_per_launch"],
+                      "launches_profiled": f_["launches"], "hbm_bytes_per_launch": hb, "algorithmic_bytes_per_launch": alg,
+                      "ratio_to_algorithmic": hb / alg}
+    if trs:
+        json.dump(trs, open(os.path.join(DST, f"{TAG}_update_traffic_final.json"), "w"), indent=1)
+        L += ["", f"* FETCH / WRITE passes of the trailing update re-collected in this call: " +
+              "; ".join(f"{c} {v['hbm_bytes_per_launch'] / 1e9:.1f} GB per launch = {v['ratio_to_algorithmic']:.2f} x algorithmic" for c, v in trs.items())]
     for c in ("c2_dist1", "c5_dist1"):
         j = jload(f"bench_{c}.json")
         if j:
