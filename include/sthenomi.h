@@ -282,6 +282,29 @@ int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz
                     double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
                     double* grad_inscale_xz, double* const* grad_inputs_zz, double* const* grad_inputs_xz);
 
+/* sgp_elbo_grad_x plus the gradient w.r.t. the scale vectors of function-scaled processes sigma(x) * f
+ * (/root/reference/src/affine_transformations/product.jl:25-48; see sgp_logpdf_grad_xs): one array per term, NULL to skip,
+ * ignored for terms without that scale.
+ *   grad_rowscale_zz[t] (row_len of the term's block, inducing points): 2 sum_j Gzz_ij coef k_ij cs_j -- K(z,z) is
+ *       symmetric, the column scale of a term is the row scale of its mirror term, "row side x 2" covers both roles;
+ *   grad_rowscale_xz[t] (data points): sum_j Gxz_ij coef k_ij cs_j;   grad_colscale_xz[t] (inducing points, col_len):
+ *       sum_i Gxz_ij coef rs_i k_ij.
+ * The dependence of var(f, x) on sigma(x) goes through grad_var_x and sgp_kernelmatrix_diag_grad_xs.  grad_inputs_* may
+ * be NULL here. */
+int sgp_elbo_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                     const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                     const double* z_noise, const double* y, double* elbo_out, double* grad_y,
+                     double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
+                     double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
+                     double* grad_inscale_xz, double* const* grad_inputs_zz, double* const* grad_inputs_xz,
+                     double* const* grad_rowscale_zz, double* const* grad_rowscale_xz,
+                     double* const* grad_colscale_xz);
+/* sgp_kernelmatrix_diag_grad_x plus, per diagonal term t, grad_rowscale[t][i] = w_i coef cs_i k_t(x_i, x'_i) and
+ * grad_colscale[t][i] = w_i coef rs_i k_t(x_i, x'_i) (var_i = sum_t coef rs_i cs_i k_t); grad_inputs may be NULL. */
+int sgp_kernelmatrix_diag_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
+                                  double* grad_inscale, double* const* grad_inputs,
+                                  double* const* grad_rowscale, double* const* grad_colscale);
+
 /* ---- elbo(VFE(fz), fx, y) (A5; App. A.6; src/gp/sparse_finite_gp.jl:52-58) -----------
  * zz: symmetric spec at the inducing inputs z (M);  xz: cross spec rows = x (N), cols = z;
  * var_x: prior var(f, x) (N) -- obtain with sgp_kernelmatrix_diag;  mean_x (N; NULL==0);

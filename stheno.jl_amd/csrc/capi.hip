@@ -1926,7 +1926,9 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
                           const double* z_noise, const double* y, double* elbo_out, double* grad_y,
                           double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
                           double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
-                          double* grad_inscale_xz, double* const* grad_inputs_zz, double* const* grad_inputs_xz) {
+                          double* grad_inscale_xz, double* const* grad_inputs_zz, double* const* grad_inputs_xz,
+                          double* const* grad_rowscale_zz = nullptr, double* const* grad_rowscale_xz = nullptr,
+                          double* const* grad_colscale_xz = nullptr) {
   CHECK_ARG(ctx && zz && xz && var_x && noise_x && z_noise && y && elbo_out, "sgp_elbo_grad: NULL argument");
   CHECK_ARG(zz->symmetric, "sgp_elbo_grad: zz spec must be symmetric");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
@@ -2085,21 +2087,39 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
     }
     return 0;
   };
-  if (grad_inputs_zz) {
-    CHECK_RC(zero_inputs(dgz, gz.ds));
+  // Function-valued scales sigma(x) * f (product.jl:25-48) ride along as in logpdf_grad_core: K_ij = coef rs_i k_ij cs_j,
+  // the row-scale sums come out of the same passes (zz symmetric: "row side x 2" covers the column role through the
+  // mirror term; xz: the row side gives d / d rs (scales at x), the transposed pass d / d cs (scales at z)).
+  const size_t ntz_s = gz.ds->h_terms.size(), ntx_s = gx.ds->h_terms.size();
+  std::vector<DevBuf> drz(grad_rowscale_zz ? ntz_s : 0), drx(grad_rowscale_xz ? ntx_s : 0), dcx(grad_colscale_xz ? ntx_s : 0);
+  auto scale_buf = [&](std::vector<DevBuf>& v, double* const* want, size_t t, const double* vec, long len, double** out) -> int {
+    *out = nullptr;
+    if (!want || !want[t] || !vec || len <= 0) return 0;
+    CHECK_RC(v[t].alloc((size_t)len));
+    SGP_HIP(hipMemsetAsync(v[t].p, 0, sizeof(double) * len, s));
+    *out = v[t].p;
+    return 0;
+  };
+  if (grad_inputs_zz || grad_rowscale_zz) {
+    if (grad_inputs_zz) CHECK_RC(zero_inputs(dgz, gz.ds));
     const sgp_dspec* ds = gz.ds;
     for (int I = 0; I < ds->nrb; ++I)
       for (int J = 0; J < ds->ncb; ++J) {
         if (ds->row_len[I] == 0 || ds->col_len[J] == 0) continue;
         int p = I * ds->ncb + J;
-        for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t)
+        for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t) {
+          double* gsv = nullptr;
+          CHECK_RC(scale_buf(drz, grad_rowscale_zz, t, ds->h_terms[t].rs, ds->row_len[I], &gsv));
+          if (!grad_inputs_zz && !gsv) continue;
+          CHECK_ARG(ds->in_dim[ds->term_row_input[t]] <= 16, "input gradients: input dimension > 16 is not supported on device");
           CHECK_RC(launch_grad_inputs(dGzz.p, 1, m_pad, nullptr, ds->row_off[I], ds->row_len[I], ds->col_off[J],
                                       ds->col_len[J], ds->h_terms[t], ds->pair_dmax[p], 2.0,
-                                      dgz[ds->term_row_input[t]].p, s));
+                                      grad_inputs_zz ? dgz[ds->term_row_input[t]].p : nullptr, s, gsv));
+        }
       }
   }
-  if (grad_inputs_xz) {
-    CHECK_RC(zero_inputs(dgxz, gx.ds));
+  if (grad_inputs_xz || grad_rowscale_xz || grad_colscale_xz) {
+    if (grad_inputs_xz) CHECK_RC(zero_inputs(dgxz, gx.ds));
     const sgp_dspec* ds = gx.ds;
     for (int I = 0; I < ds->nrb; ++I)
       for (int J = 0; J < ds->ncb; ++J) {
@@ -2107,17 +2127,27 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
         int p = I * ds->ncb + J;
         for (int t = ds->term_ptr[p]; t < ds->term_ptr[p + 1]; ++t) {
           const DevTerm& T = ds->h_terms[t];
-          CHECK_RC(launch_grad_inputs(dE.p, 1, n_rows, nullptr, ds->row_off[I], ds->row_len[I], ds->col_off[J],
-                                      ds->col_len[J], T, ds->pair_dmax[p], 1.0, dgxz[ds->term_row_input[t]].p, s));
-          DevTerm Tt = T;  // the same term seen from its column points
-          Tt.xr = T.xc;
-          Tt.ldr = T.ldc;
-          Tt.xc = T.xr;
-          Tt.ldc = T.ldr;
-          Tt.rs = T.cs;
-          Tt.cs = T.rs;
-          CHECK_RC(launch_grad_inputs(dE.p, n_rows, 1, nullptr, ds->col_off[J], ds->col_len[J], ds->row_off[I],
-                                      ds->row_len[I], Tt, ds->pair_dmax[p], 1.0, dgxz[ds->term_col_input[t]].p, s));
+          double *gsr = nullptr, *gsc = nullptr;
+          CHECK_RC(scale_buf(drx, grad_rowscale_xz, t, T.rs, ds->row_len[I], &gsr));
+          CHECK_RC(scale_buf(dcx, grad_colscale_xz, t, T.cs, ds->col_len[J], &gsc));
+          if (grad_inputs_xz || gsr || gsc)
+            CHECK_ARG(ds->in_dim[ds->term_row_input[t]] <= 16, "input gradients: input dimension > 16 is not supported on device");
+          if (grad_inputs_xz || gsr)
+            CHECK_RC(launch_grad_inputs(dE.p, 1, n_rows, nullptr, ds->row_off[I], ds->row_len[I], ds->col_off[J],
+                                        ds->col_len[J], T, ds->pair_dmax[p], 1.0,
+                                        grad_inputs_xz ? dgxz[ds->term_row_input[t]].p : nullptr, s, gsr));
+          if (grad_inputs_xz || gsc) {
+            DevTerm Tt = T;  // the same term seen from its column points
+            Tt.xr = T.xc;
+            Tt.ldr = T.ldc;
+            Tt.xc = T.xr;
+            Tt.ldc = T.ldr;
+            Tt.rs = T.cs;
+            Tt.cs = T.rs;
+            CHECK_RC(launch_grad_inputs(dE.p, n_rows, 1, nullptr, ds->col_off[J], ds->col_len[J], ds->row_off[I],
+                                        ds->row_len[I], Tt, ds->pair_dmax[p], 1.0,
+                                        grad_inputs_xz ? dgxz[ds->term_col_input[t]].p : nullptr, s, gsc));
+          }
         }
       }
   }
@@ -2171,6 +2201,19 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
     if (grad_inputs_xz[k] && xz->inputs[k].n > 0)
       SGP_HIP(hipMemcpy(grad_inputs_xz[k], dgxz[k].p, sizeof(double) * xz->inputs[k].dim * xz->inputs[k].n,
                         hipMemcpyDeviceToHost));
+  auto scale_out = [&](std::vector<DevBuf>& v, double* const* want, const sgp_dspec* ds, bool cols) -> int {
+    if (!want) return 0;
+    for (int I = 0; I < ds->nrb; ++I)
+      for (int J = 0; J < ds->ncb; ++J)
+        for (int t = ds->term_ptr[I * ds->ncb + J]; t < ds->term_ptr[I * ds->ncb + J + 1]; ++t)
+          if (want[t] && v[t].p)
+            SGP_HIP(hipMemcpy(want[t], v[t].p, sizeof(double) * (cols ? ds->col_len[J] : ds->row_len[I]),
+                              hipMemcpyDeviceToHost));
+    return 0;
+  };
+  CHECK_RC(scale_out(drz, grad_rowscale_zz, gz.ds, false));
+  CHECK_RC(scale_out(drx, grad_rowscale_xz, gx.ds, false));
+  CHECK_RC(scale_out(dcx, grad_colscale_xz, gx.ds, true));
   return 0;
 }
 
@@ -2198,9 +2241,24 @@ extern "C" int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_c
                         grad_inscale_xz, grad_inputs_zz, grad_inputs_xz);
 }
 
+extern "C" int sgp_elbo_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
+                                const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
+                                const double* z_noise, const double* y, double* elbo_out, double* grad_y,
+                                double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
+                                double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
+                                double* grad_inscale_xz, double* const* grad_inputs_zz,
+                                double* const* grad_inputs_xz, double* const* grad_rowscale_zz,
+                                double* const* grad_rowscale_xz, double* const* grad_colscale_xz) {
+  return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
+                        grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
+                        grad_inscale_xz, grad_inputs_zz, grad_inputs_xz, grad_rowscale_zz, grad_rowscale_xz,
+                        grad_colscale_xz);
+}
+
 // sum_i w[i] d var_i / d theta over the diagonal of `spec` (the blocks (I, I) kernelmatrix_diag reads)
 static int diag_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
-                          double* grad_inscale, double* const* grad_inputs) {
+                          double* grad_inscale, double* const* grad_inputs, double* const* grad_rowscale = nullptr,
+                          double* const* grad_colscale = nullptr) {
   CHECK_ARG(ctx && spec && w && grad_coef && grad_inscale, "sgp_kernelmatrix_diag_grad: NULL argument");
   CtxScope scope(ctx);
   SpecGuard g;
@@ -2240,9 +2298,38 @@ static int diag_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
                                          dgx[ds->term_row_input[t]].p, dgx[ds->term_col_input[t]].p, s));
     }
   }
+  std::vector<DevBuf> drs(grad_rowscale ? nt : 0), dcs(grad_colscale ? nt : 0);
+  if (grad_rowscale || grad_colscale)
+    for (int I = 0; I < ds->nrb; ++I) {
+      const long len = ds->row_len[I];
+      if (len == 0) continue;
+      for (int t = ds->term_ptr[I * ds->ncb + I]; t < ds->term_ptr[I * ds->ncb + I + 1]; ++t) {
+        const DevTerm& T = ds->h_terms[t];
+        double *o_r = nullptr, *o_c = nullptr;
+        if (grad_rowscale && grad_rowscale[t] && T.rs) {
+          CHECK_RC(drs[t].alloc((size_t)len));
+          SGP_HIP(hipMemsetAsync(drs[t].p, 0, sizeof(double) * len, s));
+          o_r = drs[t].p;
+        }
+        if (grad_colscale && grad_colscale[t] && T.cs) {
+          CHECK_RC(dcs[t].alloc((size_t)len));
+          SGP_HIP(hipMemsetAsync(dcs[t].p, 0, sizeof(double) * len, s));
+          o_c = dcs[t].p;
+        }
+        if (!o_r && !o_c) continue;
+        CHECK_RC(launch_diag_scale_grad(dw.p + ds->row_off[I], len, T, o_r, o_c, s));
+      }
+    }
   SGP_HIP(hipStreamSynchronize(s));
   SGP_HIP(hipMemcpy(grad_coef, dgc.p, sizeof(double) * nt, hipMemcpyDeviceToHost));
   SGP_HIP(hipMemcpy(grad_inscale, dgs.p, sizeof(double) * nt, hipMemcpyDeviceToHost));
+  for (int I = 0; I < ds->nrb && (grad_rowscale || grad_colscale); ++I)
+    for (int t = ds->term_ptr[I * ds->ncb + I]; t < ds->term_ptr[I * ds->ncb + I + 1]; ++t) {
+      if (grad_rowscale && grad_rowscale[t] && drs[t].p)
+        SGP_HIP(hipMemcpy(grad_rowscale[t], drs[t].p, sizeof(double) * ds->row_len[I], hipMemcpyDeviceToHost));
+      if (grad_colscale && grad_colscale[t] && dcs[t].p)
+        SGP_HIP(hipMemcpy(grad_colscale[t], dcs[t].p, sizeof(double) * ds->row_len[I], hipMemcpyDeviceToHost));
+    }
   for (size_t k = 0; k < dgx.size(); ++k)
     if (grad_inputs[k] && spec->inputs[k].n > 0)
       SGP_HIP(hipMemcpy(grad_inputs[k], dgx[k].p, sizeof(double) * spec->inputs[k].dim * spec->inputs[k].n,
@@ -2260,6 +2347,12 @@ extern "C" int sgp_kernelmatrix_diag_grad_x(sgp_ctx* ctx, const sgp_cov_spec* sp
                                             double* const* grad_inputs) {
   CHECK_ARG(grad_inputs != nullptr, "sgp_kernelmatrix_diag_grad_x: grad_inputs is NULL");
   return diag_grad_core(ctx, spec, w, grad_coef, grad_inscale, grad_inputs);
+}
+
+extern "C" int sgp_kernelmatrix_diag_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w,
+                                             double* grad_coef, double* grad_inscale, double* const* grad_inputs,
+                                             double* const* grad_rowscale, double* const* grad_colscale) {
+  return diag_grad_core(ctx, spec, w, grad_coef, grad_inscale, grad_inputs, grad_rowscale, grad_colscale);
 }
 
 extern "C" int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz,

@@ -159,6 +159,7 @@ int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0
                       double* partials, double* out_coef, double* out_scale, hipStream_t s);
 int launch_diag_grad(const double* w, long n, const DevTerm* d_terms, int nterms, double* out_coef,
                      double* out_scale, hipStream_t s);
+int launch_diag_scale_grad(const double* w, long n, const DevTerm& T, double* out_rs, double* out_cs, hipStream_t s);
 int launch_vfe_zs(const double* B, const double* Binv, const double* u, double* Z, double* S, long m,
                   hipStream_t s);
 int launch_vfe_rowstats(const double* R, long ld, const double* RZ, long ldrz, const double* u,

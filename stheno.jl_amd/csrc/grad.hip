@@ -322,6 +322,30 @@ __global__ __launch_bounds__(256) void diag_grad_kernel(const double* w, long n,
   }
 }
 
+// per point i of a diagonal term (function-valued scales, product.jl:25-48): out_rs[i] += w_i coef cs_i k(x_i, x'_i),
+// out_cs[i] += w_i coef rs_i k(x_i, x'_i)
+__global__ void diag_scale_grad_kernel(const double* w, long n, DevTerm T, double* out_rs, double* out_cs) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double d2 = 0.0;
+  for (int d = 0; d < T.dim; ++d) {
+    const double df = T.xr[i * T.ldr + d] - T.xc[i * T.ldc + d];
+    d2 = fma(df, df, d2);
+  }
+  double k, dk;
+  kern_and_dscale(T.kind, d2, T.param, k, dk);
+  k *= w[i] * T.coef;
+  if (out_rs) out_rs[i] += k * (T.cs ? T.cs[i] : 1.0);
+  if (out_cs) out_cs[i] += k * (T.rs ? T.rs[i] : 1.0);
+}
+
+int launch_diag_scale_grad(const double* w, long n, const DevTerm& T, double* out_rs, double* out_cs, hipStream_t s) {
+  if (n <= 0 || (!out_rs && !out_cs)) return 0;
+  hipLaunchKernelGGL(diag_scale_grad_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, w, n, T, out_rs, out_cs);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_diag_grad(const double* w, long n, const DevTerm* d_terms, int nterms, double* out_coef,
                      double* out_scale, hipStream_t s) {
   if (nterms <= 0) return 0;

@@ -240,19 +240,23 @@ def logpdf_f32(fx, y):
     return np.float32(out[0])
 
 
-def _scale_records(spec, grs):
+def _scale_records(spec, grs, more=()):
     """Per-term row-scale gradients -> one record per function scale `sigma * f` and input collection it was
     mapped over: {node, x, values (= sigma.(x)), d_values (= d logpdf / d values)}.  A path's scale vector is the
-    product of its factors' values; a vector carried by several terms gets the sum of their gradients."""
+    product of its factors' values; a vector carried by several terms gets the sum of their gradients.
+    `more`: further (spec, per-term gradients, "row" | "col") triples whose vectors join the same records (the ELBO
+    reads one scale vector through K(z,z), K(x,z) and diag K(x,x))."""
     by_vec = {}
-    for t, g in enumerate(grs):
-        if g is None:
-            continue
-        r = spec.term_row_scale[t]
-        if id(r) in by_vec:
-            by_vec[id(r)][1] += g
-        else:
-            by_vec[id(r)] = [r, g.copy()]
+    for sp, grads, side in ((spec, grs, "row"),) + tuple(more):
+        vecs = sp.term_row_scale if side == "row" else sp.term_col_scale
+        for t, g in enumerate(grads or []):
+            if g is None:
+                continue
+            r = vecs[t]
+            if id(r) in by_vec:
+                by_vec[id(r)][1] += g
+            else:
+                by_vec[id(r)] = [r, g.copy()]
     out, index = [], {}
     for r, g in by_vec.values():
         fac = getattr(r, "factors", [])
@@ -606,7 +610,19 @@ def _term_records(spec, gc, gs, symmetric):
     return out
 
 
-def elbo_and_gradient(vfe, fx, y=None, inputs=False):
+def _scale_arrays(spec, side):
+    """one zero array per term that carries a row ("row") / column ("col") scale vector, None elsewhere + the ctypes
+    pointer table"""
+    nt = max(1, spec.n_terms)
+    vecs = spec.term_row_scale if side == "row" else spec.term_col_scale
+    arrs = [None] * nt
+    for t in range(spec.n_terms):
+        if vecs[t] is not None:
+            arrs[t] = np.zeros(len(vecs[t]))
+    return arrs, (C.POINTER(C.c_double) * nt)(*[_lib.dptr(a) if a is not None else None for a in arrs])
+
+
+def elbo_and_gradient(vfe, fx, y=None, inputs=False, scales=False):
     """elbo(VFE(fz), fx, y) and its reverse-mode gradient (what Zygote derives through
     AbstractGPs.elbo on the reference path; sgp_elbo_grad).
 
@@ -614,9 +630,12 @@ def elbo_and_gradient(vfe, fx, y=None, inputs=False):
     zz_terms / xz_terms / xx_terms: per flattened covariance term of K(z,z), K(x,z) and diag K(x,x)
     {I, J, kind, coef, row_input, col_input, d_coef, d_inscale} (see logpdf_and_gradient).
     inputs=True adds zz_inputs / xz_inputs: d elbo / d (input points) per entry of
-    g["_specs"]["zz"].inputs and g["_specs"]["xz"].inputs (the inducing points appear in both)."""
+    g["_specs"]["zz"].inputs and g["_specs"]["xz"].inputs (the inducing points appear in both).
+    scales=True adds `scales`: one record per function-valued scale (`sigma * f`, product.jl:25-48) and input collection
+    it is mapped over -- {node, x, values, d_values} with d_values[i] = d elbo / d sigma(x_i), summed over the three
+    places the bound reads sigma: K(z,z), K(x,z) (row side at x, column side at z) and diag K(x,x)."""
     if isinstance(vfe, SparseFiniteGP):
-        return elbo_and_gradient(VFE(vfe.finducing), vfe.fobs, fx, inputs=inputs)
+        return elbo_and_gradient(VFE(vfe.finducing), vfe.fobs, fx, inputs=inputs, scales=scales)
     zz, xz, mean_x, nk, nbuf, zk, zbuf = _vfe_args(vfe, fx)
     if zk == _lib.NOISE_DENSE:
         raise NotImplementedError("elbo gradient with dense Sigma_z")
@@ -635,19 +654,34 @@ def elbo_and_gradient(vfe, fx, y=None, inputs=False):
     args = (_ctx().handle, zz.ref(), xz.ref(), _lib.dptr(var_x), _lib.dptr(mean_x), nk, _lib.dptr(nbuf), zk,
             _lib.dptr(zbuf), _lib.dptr(yv), _lib.dptr(out), _lib.dptr(gy), _lib.dptr(gm), _lib.dptr(gn), _lib.dptr(gv),
             _lib.dptr(gzn), _lib.dptr(gcz), _lib.dptr(gsz), _lib.dptr(gcx), _lib.dptr(gsx))
+    pz = px = None
     if inputs:
         gxz = [np.zeros(a.shape, order="F") for a in zz.inputs]
         gxx = [np.zeros(a.shape, order="F") for a in xz.inputs]
         pz = (C.POINTER(C.c_double) * max(1, len(gxz)))(*[_lib.dptr(a) for a in gxz])
         px = (C.POINTER(C.c_double) * max(1, len(gxx)))(*[_lib.dptr(a) for a in gxx])
+    srz = srx = scx = None
+    if scales:
+        srz, prz = _scale_arrays(zz, "row")
+        srx, prx = _scale_arrays(xz, "row")
+        scx, pcx = _scale_arrays(xz, "col")
+        _lib.check(lib.sgp_elbo_grad_xs(*args, pz, px, prz, prx, pcx), "sgp_elbo_grad_xs")
+    elif inputs:
         _lib.check(lib.sgp_elbo_grad_x(*args, pz, px), "sgp_elbo_grad_x")
     else:
         _lib.check(lib.sgp_elbo_grad(*args), "sgp_elbo_grad")
     gcd, gsd = np.zeros(max(1, xx.n_terms)), np.zeros(max(1, xx.n_terms))
-    gdx = None
+    gdx = pd = None
     if inputs:      # var(f, x) depends on x wherever a diagonal term reads two different views of x
         gdx = [np.zeros(a.shape, order="F") for a in xx.inputs]
         pd = (C.POINTER(C.c_double) * max(1, len(gdx)))(*[_lib.dptr(a) for a in gdx])
+    sdr = sdc = None
+    if scales:      # ... and on sigma(x): var_i = sum_t coef rs_i cs_i k_t
+        sdr, pdr = _scale_arrays(xx, "row")
+        sdc, pdc = _scale_arrays(xx, "col")
+        rc = lib.sgp_kernelmatrix_diag_grad_xs(_ctx().handle, xx.ref(), _lib.dptr(gv), _lib.dptr(gcd), _lib.dptr(gsd), pd,
+                                               pdr, pdc)
+    elif inputs:
         rc = lib.sgp_kernelmatrix_diag_grad_x(_ctx().handle, xx.ref(), _lib.dptr(gv), _lib.dptr(gcd), _lib.dptr(gsd), pd)
     else:
         rc = lib.sgp_kernelmatrix_diag_grad(_ctx().handle, xx.ref(), _lib.dptr(gv), _lib.dptr(gcd), _lib.dptr(gsd))
@@ -663,7 +697,10 @@ def elbo_and_gradient(vfe, fx, y=None, inputs=False):
     return dict(elbo=float(out[0]), y=gy, mean=gm, noise=(gn if nk == _lib.NOISE_DIAG else float(gn[0])), x=xb, z=zb,
                 z_noise=(gzn if zk == _lib.NOISE_DIAG else float(gzn[0])), var=gv,
                 zz_terms=_term_records(zz, gcz, gsz, True), xz_terms=_term_records(xz, gcx, gsx, False),
-                xx_terms=xx_terms, zz_inputs=gxz, xz_inputs=gxx, _raw=dict(zz=(gcz, gsz), xz=(gcx, gsx), xx=(gcd, gsd)),
+                xx_terms=xx_terms, zz_inputs=gxz, xz_inputs=gxx,
+                scales=(_scale_records(zz, srz, more=((xz, srx, "row"), (xz, scx, "col"), (xx, sdr, "row"), (xx, sdc, "col")))
+                        if scales else None),
+                _raw=dict(zz=(gcz, gsz), xz=(gcx, gsx), xx=(gcd, gsd)),
                 _specs=dict(zz=zz, xz=xz, xx=xx))
 
 

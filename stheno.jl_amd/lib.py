@@ -97,6 +97,11 @@ _SIGS = {
                                 _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D]),
     "sgp_elbo_grad_x": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D, C.c_int,
                                   _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, C.POINTER(_D), C.POINTER(_D)]),
+    "sgp_elbo_grad_xs": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D, C.c_int,
+                                   _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, C.POINTER(_D), C.POINTER(_D),
+                                   C.POINTER(_D), C.POINTER(_D), C.POINTER(_D)]),
+    "sgp_kernelmatrix_diag_grad_xs": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, _D, _D, C.POINTER(_D), C.POINTER(_D),
+                                                C.POINTER(_D)]),
     "sgp_kernelmatrix_diag_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, _D, _D]),
     "sgp_kernelmatrix_diag_grad_x": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, _D, _D, C.POINTER(_D)]),
     "sgp_elbo": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int,
@@ -294,6 +299,7 @@ class Spec:
         self.term_scale_ids = [(None if rs is None else id(rs), None if cs is None else id(cs))
                                for (_, _, _, _, _, rs, cs) in terms]
         self.term_row_scale = [rs for (_, _, _, _, _, rs, _) in terms]   # the flattener's own vectors (with factors)
+        self.term_col_scale = [cs for (_, _, _, _, _, _, cs) in terms]
         self._keep.extend(terms)
         for k, (kind, ri, ci, coef, param, rs, cs) in enumerate(terms):
             t = self._terms[k]

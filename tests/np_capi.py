@@ -365,7 +365,7 @@ class FakeLib:
         return 0
 
     # -- logpdf and its reverse-mode gradient (sthenomi.h:154-192) -------------------------------------------
-    def _term_grads(self, s, G, grad_coef, grad_inscale, grad_inputs, grad_rowscale):
+    def _term_grads(self, s, G, grad_coef, grad_inscale, grad_inputs, grad_rowscale, grad_colscale=None):
         gx = None
         if grad_inputs:
             gx = [np.zeros(X.shape) for X in s.inputs]
@@ -399,7 +399,13 @@ class FakeLib:
                 wc = G[r, c] * coef * k
                 if cs is not None:
                     wc = wc * cs[None, :]
-                _vec(grad_rowscale[t], s.row_len[I])[:] = 2.0 * wc.sum(1)
+                # symmetric spec: "row side x 2" (the mirror term covers the column role); cross spec: once
+                _vec(grad_rowscale[t], s.row_len[I])[:] = (2.0 if s.symmetric else 1.0) * wc.sum(1)
+            if grad_colscale and grad_colscale[t] and cs is not None:
+                wr = G[r, c] * coef * k
+                if rs is not None:
+                    wr = wr * rs[:, None]
+                _vec(grad_colscale[t], s.col_len[J])[:] = wr.sum(0)
         if gx is not None:
             for k_, g in enumerate(gx):
                 if grad_inputs[k_]:
@@ -449,6 +455,9 @@ class FakeLib:
 
     # -- gradient of var = sgp_kernelmatrix_diag(spec) (sthenomi.h: sgp_kernelmatrix_diag_grad[_x]) -----------
     def sgp_kernelmatrix_diag_grad_x(self, ctx, spec, w, gc, gs, grad_inputs):
+        return self.sgp_kernelmatrix_diag_grad_xs(ctx, spec, w, gc, gs, grad_inputs, None, None)
+
+    def sgp_kernelmatrix_diag_grad_xs(self, ctx, spec, w, gc, gs, grad_inputs, grad_rowscale, grad_colscale):
         s = _Spec(spec)
         nt = len(s.terms)
         wv = _vec(w, s.N)
@@ -477,6 +486,11 @@ class FakeLib:
                 core = coef * 2.0 * (ww * dk)[None, :] * (X - Y)
                 gx[ri] += core
                 gx[ci] -= core
+            base = wv[s.roff[I]:s.roff[I + 1]] * coef * k
+            if grad_rowscale and grad_rowscale[t] and rs is not None:
+                _vec(grad_rowscale[t], s.row_len[I])[:] = base * (cs if cs is not None else 1.0)
+            if grad_colscale and grad_colscale[t] and cs is not None:
+                _vec(grad_colscale[t], s.row_len[I])[:] = base * (rs if rs is not None else 1.0)
         if gx is not None:
             for k_, g in enumerate(gx):
                 if grad_inputs[k_]:
@@ -489,6 +503,11 @@ class FakeLib:
     # -- elbo and its reverse-mode gradient (sthenomi.h:216-250; cotangents: oracle/abstractgps.py derivation) -----
     def sgp_elbo_grad_x(self, ctx, zz, xz, var_x, mean_x, nk, noise_x, zk, z_noise, y, elbo_out, gy, gm, gn, gv, gzn,
                         gc_zz, gs_zz, gc_xz, gs_xz, gin_zz, gin_xz):
+        return self.sgp_elbo_grad_xs(ctx, zz, xz, var_x, mean_x, nk, noise_x, zk, z_noise, y, elbo_out, gy, gm, gn, gv, gzn,
+                                     gc_zz, gs_zz, gc_xz, gs_xz, gin_zz, gin_xz, None, None, None)
+
+    def sgp_elbo_grad_xs(self, ctx, zz, xz, var_x, mean_x, nk, noise_x, zk, z_noise, y, elbo_out, gy, gm, gn, gv, gzn,
+                         gc_zz, gs_zz, gc_xz, gs_xz, gin_zz, gin_xz, grs_zz, grs_xz, gcs_xz):
         if zk == L.NOISE_DENSE:
             return self._fail("elbo gradient: Sigma_z must be scalar or diagonal")
         parts, rc = self._vfe_parts(zz, xz, mean_x, nk, noise_x, zk, z_noise, y)
@@ -532,9 +551,9 @@ class FakeLib:
                 _vec(gzn, M)[:] = np.diag(dKzz)
         sz, sx = _Spec(zz), _Spec(xz)
         self._term_grads(sz, dKzz, _vec(gc_zz, len(sz.terms)) if gc_zz else None,
-                         _vec(gs_zz, len(sz.terms)) if gs_zz else None, gin_zz, None)
+                         _vec(gs_zz, len(sz.terms)) if gs_zz else None, gin_zz, grs_zz)
         self._term_grads(sx, dKxz, _vec(gc_xz, len(sx.terms)) if gc_xz else None,
-                         _vec(gs_xz, len(sx.terms)) if gs_xz else None, gin_xz, None)
+                         _vec(gs_xz, len(sx.terms)) if gs_xz else None, gin_xz, grs_xz, gcs_xz)
         return 0
 
     def sgp_elbo_grad(self, ctx, zz, xz, var_x, mean_x, nk, noise_x, zk, z_noise, y, elbo_out, gy, gm, gn, gv, gzn, gc_zz,

@@ -661,6 +661,49 @@ def _kappa_prime(kind, d2):
     return np.zeros_like(d2)
 
 
+def test_elbo_gradient_wrt_function_scales():
+    """sigma(x) * f under the ELBO (round 3; product.jl:25-48 + sparse_finite_gp.jl:52-58): d elbo / d sigma(.) summed
+    over K(z,z), K(x,z) (row side at x, column side at z) and diag K(x,x), against central differences of the elbo
+    w.r.t. the parameters of two scales -- one nested under the other; observations in the scaled process, inducing
+    points in two processes (one scaled, one not)."""
+    rng = np.random.default_rng(44)
+    x = rng.standard_normal(150)
+    z1, z2 = np.linspace(-2, 2, 9), np.linspace(-1.5, 1.5, 7)
+    y = rng.standard_normal(150)
+
+    def build(th, ph):
+        gpc = P.GPC()
+        f1 = P.atomic(P.GP(P.Matern32Kernel()), gpc)
+        f2 = P.atomic(P.GP(P.SEKernel()), gpc)
+        s1 = lambda t: 1.0 + th * float(np.sum(np.sin(t)))
+        s2 = lambda t: float(np.exp(ph * np.sum(t)))
+        g1 = s1 * f1
+        F = P.GPPP({"f1": f1, "f2": f2, "g1": g1, "h": s2 * (g1 + f2)}, gpc)
+        fx = F(P.GPPPInput("h", x), 0.3)
+        fz = F(P.BlockData([P.GPPPInput("g1", z1), P.GPPPInput("f2", z2)]), 1e-6)
+        return P.VFE(fz), fx
+
+    th, ph = 0.4, 0.15
+    vfe, fx = build(th, ph)
+    g = P.elbo_and_gradient(vfe, fx, y, scales=True)
+    assert abs(g["elbo"] - P.elbo(vfe, fx, y)) <= 1e-10 * abs(g["elbo"])
+    d_th = d_ph = 0.0
+    for r in g["scales"]:
+        xs = np.asarray(r["x"].x if hasattr(r["x"], "x") else r["x"], dtype=np.float64)
+        vals = r["values"]
+        if np.allclose(vals, 1.0 + th * np.sin(xs)):
+            d_th += float(r["d_values"] @ np.sin(xs))
+        else:
+            assert np.allclose(vals, np.exp(ph * xs))
+            d_ph += float(r["d_values"] @ (xs * vals))
+    assert len(g["scales"]) >= 3            # s1 at x and at z1, s2 at x
+    h = 1e-5
+    fd_th = (P.elbo(*build(th + h, ph), y) - P.elbo(*build(th - h, ph), y)) / (2 * h)
+    fd_ph = (P.elbo(*build(th, ph + h), y) - P.elbo(*build(th, ph - h), y)) / (2 * h)
+    assert abs(d_th - fd_th) <= 1e-5 * max(1.0, abs(fd_th)), (d_th, fd_th)
+    assert abs(d_ph - fd_ph) <= 1e-5 * max(1.0, abs(fd_ph)), (d_ph, fd_ph)
+
+
 @pytest.mark.parametrize("recipe", [models.gppp_docstring, models.composite_kernels], ids=lambda r: r.__name__)
 def test_logpdf_gradient_wrt_input_points(recipe):
     """sgp_logpdf_grad_x against a NumPy contraction of the oracle's G with the analytic kernel

@@ -30,6 +30,7 @@ _REUSED = [
     "test_many_right_hand_sides", "test_input_dimension_limit_is_reported", "test_logpdf_gradient_terms_noise_y_mean",
     "test_logpdf_gradient_matches_finite_differences_of_hyperparameters",
     "test_logpdf_gradient_records_with_scale_only_differences", "test_logpdf_gradient_wrt_function_scales",
+    "test_elbo_gradient_wrt_function_scales",
     "test_logpdf_gradient_wrt_input_points", "test_logpdf_input_gradient_matches_finite_differences",
     "test_input_gradients_chain_through_model_transformations", "test_elbo_gradient_against_oracle_cotangents",
     "test_elbo_gradient_matches_finite_differences_of_hyperparameters", "test_elbo_input_gradients_match_finite_differences",
