@@ -59,31 +59,51 @@ def cpu_baseline(name, n_sample):
                       elbo_m=bc.ELBO_M, elbo_znoise=bc.ELBO_ZNOISE)
 
 
-def update_bytes_avg(N):
-    """Algorithmic bytes of an average trailing-update launch of one logpdf: every launch reads and writes the
-    lower 128-tiles of its C block once and reads its panel rows once (the driver's panel rule: capi.hip)."""
+def update_launches(N):
+    """(rows m, columns nc, depth K) of every trailing-update launch of one logpdf, mirroring the driver's panel rule
+    (capi.hip: chol_bordered / panel_factor_mid): below 65536 columns outer panels of W with the look-ahead split (next
+    panel's columns, then the rest); from 65536 on the serial schedule with outer panels of 4096 columns factored by
+    recursive halving down to 1024 (one update of the right half per level)."""
     n_pad = (N + 127) // 128 * 128
     m_tot = n_pad + 128
-    W = n_pad if n_pad <= 4096 else (1024 if n_pad <= 8192 or n_pad >= 32768 else 512)
-    tot, cnt = 0.0, 0
+    out = []
+    deep = n_pad >= 65536
+    W = n_pad if n_pad <= 4096 else (1024 if n_pad <= 8192 else (4096 if deep else (1024 if n_pad >= 32768 else 512)))
+
+    def mid(c0, w):          # recursive halving inside the panel starting at global column c0
+        if not deep or w <= 1024:
+            return
+        wl = max(1024, (w // 2 + 1023) // 1024 * 1024)
+        mid(c0, wl)
+        if w - wl > 0:
+            out.append((m_tot - (c0 + wl), w - wl, wl))
+            mid(c0 + wl, w - wl)
+
     J0 = 0
     while J0 < n_pad:
         wj = min(W, n_pad - J0)
+        mid(J0, wj)
         c0 = J0 + wj
         if c0 >= n_pad:
             break
         w1 = min(W, n_pad - c0)
-        # below 65536 columns: look-ahead split (next panel's columns, then the rest); from there on one launch
-        split = ((c0, w1), (c0 + w1, n_pad - c0 - w1)) if n_pad < 65536 else ((c0, n_pad - c0),)
+        split = ((c0, n_pad - c0),) if deep else ((c0, w1), (c0 + w1, n_pad - c0 - w1))
         for (c, nc) in split:
-            if nc <= 0:
-                continue
-            m = m_tot - c
-            entries = nc * (nc + 128) / 2 + (m - nc) * nc          # lower tiles of the square part + rows below
-            tot += 2 * 8.0 * entries + 8.0 * m * wj
-            cnt += 1
+            if nc > 0:
+                out.append((m_tot - c, nc, wj))
         J0 += W
-    return tot / max(1, cnt)
+    return out
+
+
+def update_bytes_avg(N):
+    """Algorithmic bytes of an average trailing-update launch of one logpdf: every launch reads and writes the
+    lower 128-tiles of its C block once and reads its panel rows once."""
+    ls = update_launches(N)
+    tot = 0.0
+    for (m, nc, k) in ls:
+        entries = nc * (nc + 128) / 2 + (m - nc) * nc          # lower tiles of the square part + rows below
+        tot += 2 * 8.0 * entries + 8.0 * m * k
+    return tot / max(1, len(ls))
 
 
 def resolve_devices(gpus, devices_arg, device_count, world):
@@ -353,7 +373,8 @@ def main():
         if serial:
             kname = ("sgp::gemm_nt_dma_potrf_kernel<1, true> (fp64 MFMA trailing update of the blocked Cholesky, "
                      "v_mfma_f64_4x4x4_4b_f64: the tile program of sgp::gemm_nt_dma_kernel, whose tile (0, 0) workgroup goes on "
-                     "to factor the next diagonal block; one launch per outer panel, no look-ahead at this size)")
+                     "to factor the next diagonal block; serial schedule: outer panels of 4096 columns, one K = 4096 launch per "
+                     "panel + the K = 2048 / 1024 updates of the recursive halving inside a panel, no look-ahead at this size)")
         else:
             kname = ("sgp::gemm_nt_dma_kernel<1> (fp64 MFMA trailing update of the blocked Cholesky, v_mfma_f64_4x4x4_4b_f64; "
                      "<0> = the same code in its auxiliary uses)"

@@ -184,6 +184,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (lx) c->la_max_n = atol(lx);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
+    const char* wm = getenv("SGP_WMID");
+    if (wm) c->wmid = atol(wm) / TILE * TILE;
     const char* rf = getenv("SGP_REFINE");
     if (rf) c->refine = atoi(rf);
     const char* fp = getenv("SGP_FUSE_POTRF");
@@ -602,6 +604,25 @@ static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long
   return launch_update_kernel(P, ld, C, M, Nc, K, s, fz);
 }
 
+// Middle blocking level: an outer panel of w columns wider than `wmid` is factored as sub-panels of wmid columns, each
+// followed by ONE K = wmid update of the panel's remaining columns (lower trapezoid; the next sub-panel's first diagonal
+// block fused into it).  The outer trailing updates then run with K = w -- half the C-tile passes per flop of K = w / 2,
+// i.e. half the per-tile prologue / epilogue share -- while the shallow K = 128 work stays that of a wmid-wide panel.
+static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_slots, int* d_info,
+                            double* d_invstore, hipStream_t s, bool first_done, long wmid) {
+  if (wmid < TILE || wmid >= w) return panel_factor(ctx, P, ld, m, w, g0, d_slots, d_info, d_invstore, s, first_done);
+  // recursive halving down to wmid: the left half, ONE update of the right half with it (K = w / 2), the right half
+  const bool fuse_mid = (ctx->fuse_now & 2) && ctx->refine == 1;
+  const long wl = std::max(wmid, (w / 2 + wmid - 1) / wmid * wmid), c = wl, rest = w - wl;
+  CHECK_RC(panel_factor_mid(ctx, P, ld, m, wl, g0, d_slots, d_info, d_invstore, s, first_done, wmid));
+  if (rest <= 0) return 0;
+  const FusedDiag fz = {d_invstore ? d_invstore + (c / TILE) * INVD_STRIDE : ctx->d_invd, d_slots + c / TILE, d_info,
+                        g0 + c, (ctx->fuse_now & 8) ? 1 : 0};
+  CHECK_RC(launch_update(ctx, P + c, ld, P + c + c * ld, m - c, rest, wl, s, fuse_mid ? &fz : nullptr));
+  return panel_factor_mid(ctx, P + c + c * ld, ld, m - c, rest, g0 + c, d_slots + c / TILE, d_info,
+                          d_invstore ? d_invstore + (c / TILE) * INVD_STRIDE : nullptr, s, fuse_mid, wmid);
+}
+
 // Two-level right-looking Cholesky of the bordered matrix with one-panel look-ahead:
 // the outer panel J+1 is updated and factored on the (high-priority) panel stream while the
 // rest of the trailing matrix is still being updated with panel J on the update stream.
@@ -616,17 +637,25 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // 1024 up to 8192, 512 in the
   // mid range where the panel stream is the critical path (N = 16384: 34.8 vs 35.4 ms), 1024 from 32768 on
   // (halves the C-tile traffic per flop of the big trailing updates).
-  const long WOUT = ctx->wout > 0 ? ctx->wout
-                    : n_pad <= 4096 ? n_pad
-                    : n_pad <= 8192 ? WOUT_LARGE
-                    : n_pad >= 32768 ? WOUT_LARGE
-                                     : WOUT_SMALL;
   // Look-ahead below SGP_LA_MAX_N (65536) columns only.  At N = 65536 the overlap hides ~70 ms of panel chain but the
   // sharing costs the trailing updates as much (per launch 0.72 of the fp64 MFMA peak beside the panel stream, 0.81
   // alone); the serial schedule with fused diagonal blocks measures the same or better (1525 vs 1539 ms dense
   // Matern-5/2, 1515 vs 1501 ms on the three-block model, same box) and leaves every kernel uncontended; at 32768 the
   // look-ahead still wins (202 vs 207 ms).  SGP_LOOKAHEAD=2: look-ahead at every size.
   const bool la = ctx->lookahead && s == ctx->stream && (n_pad < ctx->la_max_n || ctx->lookahead == 2);
+  // Serial schedule at n_pad >= 65536 (round 3): outer panels of 4096 columns factored by recursive halving down to 1024
+  // (panel_factor_mid) -- the big trailing updates run with K = 4096, the mid updates with K = 2048 / 1024, the shallow
+  // K = 128 work stays that of 1024-wide panels: per-tile prologue / epilogue share and C-tile traffic per flop drop,
+  // same flops, bit-identical result.  N = 65536 on one box: W = 1024 1499 ms, 2048 / 1024 1469, 4096 / 1024 1458,
+  // 8192 / 1024 1463, 16384 / 1024 1469, 4096 / 512 1465; under the look-ahead (N = 16384, 32768) it loses.
+  const bool deep = !la && n_pad >= 65536;
+  const long WOUT = ctx->wout > 0 ? ctx->wout
+                    : n_pad <= 4096 ? n_pad
+                    : n_pad <= 8192 ? WOUT_LARGE
+                    : deep ? 4 * WOUT_LARGE
+                    : n_pad >= 32768 ? WOUT_LARGE
+                                     : WOUT_SMALL;
+  const long WMID = ctx->wmid > 0 ? ctx->wmid : (deep && ctx->wout <= 0 ? WOUT_LARGE : 0);
   hipStream_t sB = la ? ctx->stream2 : s;
   // SGP_FUSE_POTRF bit 1: the trailing update that finishes the next panel's first diagonal block (the look-ahead
   // column update, or the whole update when the look-ahead is off) factors that block in the same launch
@@ -645,8 +674,8 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
     long wj = std::min(WOUT, n_pad - J0);
     const long m_eff = grow > 0 ? std::min(m_tot, grow + J0 + wj) : m_tot;  // rows this panel touches
-    CHECK_RC(panel_factor(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
-                          ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done));
+    CHECK_RC(panel_factor_mid(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
+                              ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done, WMID));
     long c0 = J0 + wj;
     if (c0 >= n_pad) break;
     const FusedDiag fz_next = {d_wall ? d_wall + (c0 / TILE) * INVD_STRIDE : ctx->d_invd, ctx->d_slots + c0 / TILE,

@@ -49,6 +49,7 @@ struct sgp_ctx {
   int lookahead = 1;
   long la_max_n = 65536;   // SGP_LA_MAX_N: look-ahead only for factorisations of fewer columns (serial + fused from there on)
   long wout = 0;  // 0 = automatic
+  long wmid = 0;  // middle blocking level of an outer panel (capi.hip: panel_factor_mid); 0 = automatic
   double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
   double* d_w = nullptr;       // 128 x 128 scratch inverse
   double* d_solve = nullptr;   // rows x 128 scratch of the refined panel solve (grown on demand)

@@ -120,3 +120,27 @@ def test_fused_potrf_reports_the_failing_minor(monkeypatch):
             _with_ctx(ctx, lambda: P.logpdf(f(x, noise), y))
         assert e.value.info == 301, (fuse, e.value.info)
         ctx.close()
+
+
+@pytest.mark.parametrize("env", [dict(SGP_LOOKAHEAD=0, SGP_WOUT=1024, SGP_WMID=256), dict(SGP_LOOKAHEAD=0, SGP_WOUT=768, SGP_WMID=128),
+                                 dict(SGP_WOUT=512, SGP_WMID=256)])
+def test_middle_blocking_level_is_bit_identical(monkeypatch, env):
+    """Round 3: outer panels factored by recursive halving down to SGP_WMID columns (capi.hip: panel_factor_mid; the
+    default from 65536 columns on is 4096 / 1024).  A tile's updates are accumulated in the same ascending order of the
+    contraction index whatever the grouping into launches, so every operator is bit-identical to the plain two-level
+    driver of the same outer width, with the fusion on or off -- here at sizes with several outer panels, uneven halves
+    (768 = 384 + 384 -> 384 + 384 rounded to multiples of the mid width) and a ragged last panel."""
+    N = 1900
+    base = {k: v for k, v in env.items() if k != "SGP_WMID"}
+    ref_ctx = _ctx(monkeypatch, 0, **base)
+    monkeypatch.delenv("SGP_WMID", raising=False)
+    ref, (xs, y) = _with_ctx(ref_ctx, lambda: _operators(N))
+    want = orm.gppp_sum_logpdf(xs, y, 0.1)
+    assert abs(ref["logpdf"][0] - want) <= 1e-10 * abs(want)
+    for fuse in (0, 11):
+        ctx = _ctx(monkeypatch, fuse, **env)
+        got, _ = _with_ctx(ctx, lambda: _operators(N))
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (env, fuse, k, np.max(np.abs(ref[k] - got[k])))
+        ctx.close()
+    ref_ctx.close()
