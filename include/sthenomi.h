@@ -425,6 +425,10 @@ int sgp_bench_potrf(sgp_ctx* ctx, int iters, double* us_out, long long* stamps_o
 int sgp_bench_cumask(sgp_ctx* ctx, const uint32_t* mask, int words, int nwg, unsigned* out /* [4096] */);
 int sgp_bench_potrf_contended(sgp_ctx* ctx, int64_t m, int64_t k, int gemm_launches, int n, double* us_out /* [n] */,
                               long long* ticks_out /* [n] */, int* busy_out /* [n] */);
+/* one lower trailing update C(m x m) -= P P' (depth k) with per-workgroup phase stamps of the tile program (s_memtime
+ * ticks): out[8 id + {0 entry, 1 first operand chunk + old C tile landed, 2 contraction done, 3 stores drained,
+ * 4 XCC_ID << 16 | HW_ID, 5 tile row, 6 tile column}]; out == NULL: only *n_ids (workgroups of the launch). */
+int sgp_bench_gemm_stamps(sgp_ctx* ctx, int64_t m, int64_t k, long long* out, int64_t cap, int64_t* n_ids);
 /* raw GEMM-NT kernel timing: C(m x n) -= A(m x k) B(n x k)' on random data */
 int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only, int iters,
                    double* tflops_out, double* maxerr_out);

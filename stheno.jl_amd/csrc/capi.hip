@@ -2737,6 +2737,33 @@ extern "C" int sgp_bench_potrf_contended(sgp_ctx* ctx, int64_t m, int64_t k, int
   return rc;
 }
 
+// one lower update C(m x m) -= P P' (depth k) with per-workgroup phase stamps: out[8 * id + {0: entry, 1: first operand
+// chunk + old C tile landed, 2: contraction done, 3: stores drained, 4: XCC_ID << 16 | HW_ID, 5: tile row, 6: tile col}]
+// (s_memtime ticks; 0 rows = ids without a tile).  *n_ids = workgroups of the launch (call with out == NULL to size).
+extern "C" int sgp_bench_gemm_stamps(sgp_ctx* ctx, int64_t m, int64_t k, long long* out, int64_t cap, int64_t* n_ids) {
+  CHECK_ARG(ctx && n_ids && m % TILE == 0 && k % 16 == 0, "sgp_bench_gemm_stamps: bad argument");
+  CtxScope scope(ctx);
+  long ids = 0;
+  CHECK_RC(launch_gemm_nt_stamps(nullptr, m, nullptr, m, m, m, k, nullptr, &ids, ctx->stream));
+  *n_ids = ids;
+  if (!out) return 0;
+  CHECK_ARG(cap >= 8 * ids, "sgp_bench_gemm_stamps: buffer too small");
+  hipStream_t s = ctx->stream;
+  DevBuf A, C, D;
+  CHECK_RC(A.alloc((size_t)m * k));
+  CHECK_RC(C.alloc((size_t)m * m));
+  CHECK_RC(D.alloc((size_t)8 * ids));
+  hipLaunchKernelGGL(fill_rand_kernel, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, s, A.p, m * k, 1234ULL);
+  SGP_HIP(hipMemsetAsync(C.p, 0, sizeof(double) * m * m, s));
+  CHECK_RC(launch_gemm_nt_update(A.p, m, C.p, m, m, m, k, s));   // warm-up (clocks, caches)
+  SGP_HIP(hipMemsetAsync(D.p, 0, sizeof(double) * 8 * ids, s));
+  // SGP_STAMP_BETA0=1 (experiment): beta = 0, i.e. no old C tile to fetch -- isolates its share of the prologue
+  CHECK_RC(launch_gemm_nt_stamps(A.p, m, C.p, m, m, m, k, (long long*)D.p, &ids, s, getenv("SGP_STAMP_BETA0") ? 0.0 : 1.0));
+  SGP_HIP(hipStreamSynchronize(s));
+  SGP_HIP(hipMemcpy(out, D.p, sizeof(long long) * 8 * ids, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only,
                               int iters, double* tflops_out, double* maxerr_out) {
   CHECK_ARG(ctx && tflops_out && maxerr_out, "sgp_bench_gemm: NULL argument");

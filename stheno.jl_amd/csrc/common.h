@@ -139,6 +139,8 @@ int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M
 int launch_gemm_nt_potrf(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, int outer,
                          int handoff, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
                          hipStream_t s);
+int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
+                          long* n_ids, hipStream_t s, double beta = 1.0);   // bench: per-workgroup phase stamps of one lower update
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,
                        double* C, long ldc, long M, long Nc, long K, double alpha, double beta,
                        hipStream_t s);

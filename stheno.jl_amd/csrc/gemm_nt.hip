@@ -61,11 +61,15 @@ __device__ __forceinline__ bool tile_of_block(long n_tr, long n_tc, long mask_of
 // HANDOFF: the workgroup of tile (0, 0) does not store its result but scatters it into LDS in potrf_diag_body's
 // packed-block layout (lower 16x16 blocks, strictly upper entries of the diagonal blocks zeroed -- exactly what
 // that routine's own load phase would have produced from the stored tile).
-template <bool HANDOFF>
+template <bool HANDOFF, bool STAMP = false>
 __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, const double* B, long ldb, double* C,
                                                  long ldc, long K, double alpha, double beta, long mask_off,
                                                  long n_tr, long n_tc, long c_slice_stride, const double* Cin,
-                                                 long ldcin, int klo, double* smem, long& tr, long& tc) {
+                                                 long ldcin, int klo, double* smem, long& tr, long& tc,
+                                                 long long* dbg = nullptr) {
+  // STAMP (bench only, sgp_bench_gemm_stamps): s_memtime of thread 0 at the phase boundaries of the tile program
+  long long st0 = 0, st1 = 0, st2 = 0, stA = 0;
+  if (STAMP) st0 = (long long)__builtin_amdgcn_s_memtime();
   constexpr int NJ = 8, WCOLS = 32;
   if (klo == 3) {
     // Gram product split over K by XCD: workgroup id % 8 is the XCD the hardware puts it on, and that is
@@ -89,6 +93,7 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
     B += (long)blockIdx.y * K * ldb;
     C += (long)blockIdx.y * c_slice_stride;
   }
+  if (STAMP) stA = (long long)__builtin_amdgcn_s_memtime();   // the tile is known
   // stage s: A chunk at smem + s*2*KB*LDS_LD, B chunk right after it
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -145,6 +150,7 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  if (STAMP) st1 = (long long)__builtin_amdgcn_s_memtime();
   for (long c = cbeg; c < nchunks; ++c) {
     const int stage = (int)(c & 1);
     // the other stage was last read in iteration c-1, which every wave left through the barrier
@@ -239,6 +245,7 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
+  if (STAMP) st2 = (long long)__builtin_amdgcn_s_memtime();
   if (HANDOFF && tr == 0 && tc == 0) {
     // the loop's closing barrier: every wave is done reading the operand stages this overwrites.
     // acc[j][i] is C[row = 64 wr + 16 i + l15][col = 32 wc + 4 j + lq]: block row 4 wr + i, block column
@@ -257,7 +264,41 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = alpha * acc[j][i];
+  if (STAMP) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left: what the slot waits for before it is reused
+    if (threadIdx.x == 0) {
+      long long* d = dbg + (long)blockIdx.x * 8;
+      d[0] = st0;
+      d[1] = st1;
+      d[2] = st2;
+      d[3] = (long long)__builtin_amdgcn_s_memtime();
+      d[4] = (long long)((__builtin_amdgcn_s_getreg(6164) & 15) << 16 | (__builtin_amdgcn_s_getreg(63492) & 0xffff));   // XCC_ID, HW_ID
+      d[5] = tr;
+      d[6] = tc;
+      d[7] = stA;
+    }
+  }
   return true;
+}
+
+// bench only: the production tile program with phase stamps (own symbol: the production kernels' code is untouched)
+__global__ __launch_bounds__(512, 4) void gemm_nt_dma_stamp_kernel(const double* A, long lda, double* C, long ldc, long K,
+                                                                   long n_tr, long n_tc, long long* dbg, double beta) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
+  long tr, tc;
+  gemm_nt_dma_tile<false, true>(A, lda, A, lda, C, ldc, K, -1.0, beta, 0L, n_tr, n_tc, 0L, C, ldc, 0, smem, tr, tc, dbg);
+}
+
+int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
+                          long* n_ids, hipStream_t s, double beta) {
+  long n_tr = M / TILE, n_tc = Nc / TILE;
+  long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1));
+  *n_ids = per_xcd * 8;
+  if (!dbg) return 0;
+  hipLaunchKernelGGL(gemm_nt_dma_stamp_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, C, ldc, K, n_tr,
+                     n_tc, dbg, beta);
+  SGP_HIP(hipGetLastError());
+  return 0;
 }
 
 template <int TAG>

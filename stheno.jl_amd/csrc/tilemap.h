@@ -25,40 +25,45 @@ namespace sgp {
 //      sizes of the trailing updates are multiples of 4 or 8 tiles, not of 64: as a rectangle this group made a third
 //      of all ids of an N = 16384 factorisation dead.)
 //   B  groups below the last tile column (every tile live): rectangles of 8 (last: r_last) owned rows x n_tc.
+// (32-bit integers throughout: a launch has fewer than 2^31 workgroups, and 64-bit integer division -- which the
+// enumeration needs in a few places -- is a ~100-instruction software routine on the GPU: the id -> tile mapping cost
+// every workgroup ~4000 cycles of its prologue with `long` arithmetic, round 3 stamps)
+typedef int tm_int;
 struct TriShape {
-  long Ga, sA;            // A: number of groups, ids
-  long Rd, cd, sDl, sD;   // D: owned rows, columns of its diagonal block, ids left of the block, all ids (0: none)
-  long nB, sB, r_last;    // B: full groups, their ids, owned rows of the partial last group
-  long n_tc;
+  tm_int Ga, sA;            // A: number of groups, ids
+  tm_int Rd, cd, sDl, sD;   // D: owned rows, columns of its diagonal block, ids left of the block, all ids (0: none)
+  tm_int nB, sB, r_last;    // B: full groups, their ids, owned rows of the partial last group
+  tm_int n_tc;
 };
-__host__ __device__ __forceinline__ long tri_diag_row_count(long jj, long xcd, long c) {
-  const long cnt = 8 * jj + ((jj & 1) ? 7 - xcd : xcd) + 1;
+__host__ __device__ __forceinline__ tm_int tri_diag_row_count(tm_int jj, tm_int xcd, tm_int c) {
+  const tm_int cnt = 8 * jj + ((jj & 1) ? 7 - xcd : xcd) + 1;
   return cnt < c ? cnt : c;
 }
 // xcd in 0..7: the shape as that XCD walks it; xcd < 0: the largest over the XCDs (grid sizing on the host).
-__host__ __device__ __forceinline__ TriShape tri_shape(long n_tr, long n_tc, long xcd) {
+__host__ __device__ __forceinline__ TriShape tri_shape(long n_tr_, long n_tc_, long xcd_) {
   TriShape t;
-  const long J = (n_tr + 7) / 8;  // owned rows per XCD
-  const long Gn = J / 8, r_last = J % 8, g_full = n_tc / 64;
+  const tm_int n_tr = (tm_int)n_tr_, n_tc = (tm_int)n_tc_, xcd = (tm_int)xcd_;
+  const tm_int J = (n_tr + 7) / 8;  // owned rows per XCD
+  const tm_int Gn = J / 8, r_last = J % 8, g_full = n_tc / 64;
   t.n_tc = n_tc;
   t.Ga = Gn < g_full ? Gn : g_full;
   t.sA = 256 * t.Ga * (t.Ga - 1) + 260 * t.Ga;
   // the next group: complete rows (if any full group is left) or the partial last one
-  long g = t.Ga;
-  const long Rg = g < Gn ? 8 : r_last;
-  const long cg = n_tc - 64 * g < 64 ? n_tc - 64 * g : 64;
+  tm_int g = t.Ga;
+  const tm_int Rg = g < Gn ? 8 : r_last;
+  const tm_int cg = n_tc - 64 * g < 64 ? n_tc - 64 * g : 64;
   t.Rd = 0, t.cd = 0, t.sDl = 0, t.sD = 0;
   if (Rg > 0 && cg > 0) {
     t.Rd = Rg;
     t.cd = cg;
     t.sDl = Rg * 64 * g;
-    long tsum = 0;
+    tm_int tsum = 0;
     if (xcd >= 0) {
-      for (long jj = 0; jj < Rg; ++jj) tsum += tri_diag_row_count(jj, xcd, cg);
+      for (tm_int jj = 0; jj < Rg; ++jj) tsum += tri_diag_row_count(jj, xcd, cg);
     } else {
-      for (long x = 0; x < 8; ++x) {
-        long tx = 0;
-        for (long jj = 0; jj < Rg; ++jj) tx += tri_diag_row_count(jj, x, cg);
+      for (tm_int x = 0; x < 8; ++x) {
+        tm_int tx = 0;
+        for (tm_int jj = 0; jj < Rg; ++jj) tx += tri_diag_row_count(jj, x, cg);
         tsum = tx > tsum ? tx : tsum;
       }
     }
@@ -72,67 +77,73 @@ __host__ __device__ __forceinline__ TriShape tri_shape(long n_tr, long n_tc, lon
   return t;
 }
 __host__ __device__ __forceinline__ long tri_ids_per_xcd(const TriShape& t) {
-  return t.sA + t.sD + t.sB + t.r_last * t.n_tc;
+  return (long)t.sA + t.sD + t.sB + t.r_last * t.n_tc;
 }
 
-__host__ __device__ __forceinline__ bool tile_of_id(long id, long n_tr, long n_tc, long mask_off, long& tr, long& tc) {
-  const long xcd = id & 7, k = id >> 3;
-  long j;
+__host__ __device__ __forceinline__ bool tile_of_id(long id_, long n_tr_, long n_tc_, long mask_off, long& tr, long& tc) {
+  const tm_int id = (tm_int)id_, n_tr = (tm_int)n_tr_, n_tc = (tm_int)n_tc_;
+  const tm_int xcd = id & 7, k = id >> 3;
+  tm_int j, c;
   if (mask_off == 0) {
     const TriShape t = tri_shape(n_tr, n_tc, xcd);
     if (k < t.sA) {
       // S(G) = 256 G (G - 1) + 260 G = 256 G^2 + 4 G
-      long G = (long)((sqrt(16.0 + 1024.0 * (double)k) - 4.0) / 512.0);
+      tm_int G = (tm_int)((sqrtf(16.0f + 1024.0f * (float)k) - 4.0f) * (1.0f / 512.0f));
       while (256 * G * G + 4 * G > k) --G;
       while (256 * (G + 1) * (G + 1) + 4 * (G + 1) <= k) ++G;
-      const long within = k - (256 * G * G + 4 * G);
+      const tm_int within = k - (256 * G * G + 4 * G);
       if (within < 512 * G) {
         j = G * 8 + (within & 7);
-        tc = within >> 3;
+        c = within >> 3;
       } else {
-        long d = within - 512 * G, jj = 0, cum = 0;
+        tm_int d = within - 512 * G, jj = 0, cum = 0;
         for (; jj < 8; ++jj) {
-          const long cnt = 8 * jj + ((jj & 1) ? 7 - xcd : xcd) + 1;
+          const tm_int cnt = 8 * jj + ((jj & 1) ? 7 - xcd : xcd) + 1;
           if (d < cum + cnt) break;
           cum += cnt;
         }
         j = G * 8 + jj;
-        tc = 64 * G + (d - cum);
+        c = 64 * G + (d - cum);
       }
     } else if (k < t.sA + t.sD) {
-      const long kk = k - t.sA;
+      const tm_int kk = k - t.sA;
       if (kk < t.sDl) {
-        j = t.Ga * 8 + kk % t.Rd;
-        tc = kk / t.Rd;
+        const tm_int q = (tm_int)((unsigned)kk / (unsigned)t.Rd);
+        j = t.Ga * 8 + (kk - q * t.Rd);
+        c = q;
       } else {
-        long d = kk - t.sDl, jj = 0, cum = 0;
+        tm_int d = kk - t.sDl, jj = 0, cum = 0;
         for (; jj < t.Rd; ++jj) {
-          const long cnt = tri_diag_row_count(jj, xcd, t.cd);
+          const tm_int cnt = tri_diag_row_count(jj, xcd, t.cd);
           if (d < cum + cnt) break;
           cum += cnt;
         }
         if (jj == t.Rd) return false;   // this XCD's share of the block is smaller than the uniform grid's
         j = t.Ga * 8 + jj;
-        tc = 64 * t.Ga + (d - cum);
+        c = 64 * t.Ga + (d - cum);
       }
     } else if (k < t.sA + t.sD + t.sB) {
-      const long kk = k - t.sA - t.sD;
-      const long within = kk % (8 * n_tc);
-      j = (t.Ga + (t.sD > 0 ? 1 : 0) + kk / (8 * n_tc)) * 8 + (within & 7);
-      tc = within >> 3;
+      const tm_int kk = k - t.sA - t.sD;
+      const tm_int q = (tm_int)((unsigned)kk / (unsigned)(8 * n_tc)), within = kk - q * 8 * n_tc;
+      j = (t.Ga + (t.sD > 0 ? 1 : 0) + q) * 8 + (within & 7);
+      c = within >> 3;
     } else {  // partial last group: r_last owned rows, every tile column
       if (t.r_last == 0) return false;  // past this XCD's last tile (the launch is sized for the largest XCD)
-      const long within = k - t.sA - t.sD - t.sB;
-      j = (t.Ga + (t.sD > 0 ? 1 : 0) + t.nB) * 8 + within % t.r_last;
-      tc = within / t.r_last;
+      const tm_int within = k - t.sA - t.sD - t.sB;
+      const tm_int q = (tm_int)((unsigned)within / (unsigned)t.r_last);
+      j = (t.Ga + (t.sD > 0 ? 1 : 0) + t.nB) * 8 + (within - q * t.r_last);
+      c = q;
     }
   } else {
-    const long gs = 8 * n_tc;
-    j = (k / gs) * 8 + ((k % gs) & 7);
-    tc = (k % gs) >> 3;
+    const tm_int gs = 8 * n_tc;
+    const tm_int q = (tm_int)((unsigned)k / (unsigned)gs), r = k - q * gs;
+    j = q * 8 + (r & 7);
+    c = r >> 3;
   }
-  tr = 8 * j + ((j & 1) ? 7 - xcd : xcd);  // boustrophedon: equal live-tile counts per XCD
-  return tr < n_tr && tc < n_tc && tr >= tc + mask_off;
+  const tm_int row = 8 * j + ((j & 1) ? 7 - xcd : xcd);  // boustrophedon: equal live-tile counts per XCD
+  tr = row;
+  tc = c;
+  return row < n_tr && c < n_tc && (long)row >= (long)c + mask_off;
 }
 
 // ids per launch (what the launchers put into the grid)

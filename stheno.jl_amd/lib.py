@@ -136,6 +136,7 @@ _SIGS = {
     "sgp_dev_rows_gram": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
     "sgp_bench_cumask": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_uint)]),
     "sgp_bench_potrf_contended": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int, C.c_int, _D, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
+    "sgp_bench_gemm_stamps": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_longlong), C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_bench_gemm": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, _D, _D]),
 }
 
