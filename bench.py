@@ -405,8 +405,9 @@ def main():
             rec = json.load(open(tr_file)).get(args.config) if os.path.exists(tr_file) else None
             if not rec:
                 continue
-            # a record only counts for the schedule it was collected under (serial = one launch per outer panel)
-            rec_serial = rec.get("schedule", "").startswith("serial")
+            # a record only counts for the schedule it was collected under (serial-deep = today's default from 65536
+            # columns on: outer panels of 4096 columns, recursive halving inside)
+            rec_serial = rec.get("schedule", "").startswith("serial-deep")
             if rec_serial == serial:
                 roofline["traffic"] = rec["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = dict(rec, file="profiles/" + tr_name)

@@ -26,7 +26,7 @@ for c in c5 c2 c1 target; do
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c4 -o c4 -- \
     python $R/bench.py --config c4 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/prof_c4_bench.json 2> $OUT/prof_c4.err
-bash $R/tools/collect_traffic.sh c5 target > $OUT/traffic.log 2>&1; cp $R/gpurun_out/r02traffic/*_SIZE.json $OUT/ 2>/dev/null
+
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 120 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_gemm1_$c -o g -- python $R/tools/gpu_gemm_one.py > $OUT/pmc_gemm1_$c.log 2>&1
 done

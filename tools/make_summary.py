@@ -267,7 +267,7 @@ def main():
                       "launches_profiled": f_["launches"], "hbm_bytes_per_launch": hb, "algorithmic_bytes_per_launch": alg,
                       "ratio_to_algorithmic": hb / alg}
     if trs:
-        json.dump(trs, open(os.path.join(DST, f"{TAG}_update_traffic_final.json"), "w"), indent=1)
+        json.dump(trs, open(os.path.join(DST, f"{TAG}_update_traffic_recheck.json"), "w"), indent=1)
         L += ["", f"* FETCH / WRITE passes of the trailing update re-collected in this call: " +
               "; ".join(f"{c} {v['hbm_bytes_per_launch'] / 1e9:.1f} GB per launch = {v['ratio_to_algorithmic']:.2f} x algorithmic" for c, v in trs.items())]
     for c in ("c2_dist1", "c5_dist1"):
