@@ -193,6 +193,32 @@ def main():
     is_elbo = kind == "elbo"
     if is_elbo and use_dist:
         raise SystemExit("config c4 (ELBO) is a single-GPU bench line")
+    transport_probe = None
+    if (inproc and (len(set(devs)) > 2 or os.environ.get("SGP_BENCH_FORCE_PROBE")) and "SGP_MULTI_TRANSPORT" not in os.environ
+            and kind != "elbo"):       # (SGP_BENCH_FORCE_PROBE: test hook -- run the probe on loopback ranks too)
+        # Which panel transport this node runs faster is not knowable without the node (no multi-GPU hardware was
+        # available while this was written): peer copies as scatter + all-gather use every xGMI link of a receiver,
+        # RCCL's grouped broadcast is the conservative choice.  One UNTIMED logpdf per transport decides (part of the
+        # warm-up, reported in the line); a transport that fails to initialise or run is skipped.
+        transport_probe = {}
+        spec_p = pkg.build_spec(w["f"], w["x"])[0]
+        yp, op_, nzp = np.ascontiguousarray(y), np.zeros(1), np.array([bc.SIGMA2])
+        for tr_name in ("p2p", "rccl"):
+            os.environ["SGP_MULTI_TRANSPORT"] = tr_name
+            try:
+                c_ = L.Context(devices=devs)
+                for rep in range(2):        # first call allocates; the second is the probe
+                    t0p = time.perf_counter()
+                    L.check(c_.lib.sgp_logpdf(c_.handle, spec_p.ref(), None, L.NOISE_SCALAR, L.dptr(nzp), L.dptr(yp), N, 1,
+                                              L.dptr(op_)), "sgp_logpdf (transport probe)")
+                    transport_probe[tr_name] = (time.perf_counter() - t0p) * 1e3
+                c_.close()
+            except Exception as e:      # noqa: BLE001 -- e.g. peer access missing, librccl not loadable
+                transport_probe[tr_name + "_error"] = str(e)[:200]
+        ok = {k: v for k, v in transport_probe.items() if not k.endswith("_error")}
+        if not ok:
+            raise SystemExit(f"no multi-GPU transport works on this node: {transport_probe}")
+        os.environ["SGP_MULTI_TRANSPORT"] = min(ok, key=ok.get)
     if inproc:
         ctx = L.Context(devices=devs)
         if ctx.ndev != len(devs):
@@ -347,7 +373,8 @@ def main():
                  "devices": devs, "ranks": int(st[0]), "transport": ctx.transport,
                  "rccl_ranks": int(st[3]) if st[3] >= 0 else None,
                  "peer_copy_form": ("scatter + all-gather" if st[6] else "direct") if ctx.transport in ("p2p", "loopback") else None,
-                 "panel_width": int(st[4]), "panels": int(st[5]), "last_call_ms": st[1], "per_rank": per_rank}
+                 "panel_width": int(st[4]), "panels": int(st[5]), "last_call_ms": st[1], "per_rank": per_rank,
+                 "transport_probe_ms": transport_probe}
         if not is_elbo:
             tf = [r["update_tflops"] for r in per_rank if r["update_tflops"]]
             per_gpu = whole_tflops / len(set(devs))

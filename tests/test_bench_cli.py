@@ -58,6 +58,19 @@ def test_inprocess_multi_gpu_line_on_loopback_ranks():
 
 
 @pytest.mark.gpu
+def test_transport_probe_code_path_on_loopback_ranks():
+    """On a node with > 2 GPUs bench.py times one untimed logpdf per panel transport and keeps the faster one; the
+    probe's code path runs here with loopback ranks (both candidates resolve to same-device copies)."""
+    r = _bench("--gpus", "3", "--devices", "0,0,0", "--config", "c1", "--steps", "1", "--warmup", "1", "--cpu-sample", "0",
+               env={"SGP_BENCH_FORCE_PROBE": "1", "SGP_MULTI_PANEL": "512"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    probe = line["multi_gpu"]["transport_probe_ms"]
+    assert set(probe) == {"p2p", "rccl"} and all(v > 0 for v in probe.values())
+    assert line["n_gpus"] == 3 and line["parity_rel"] < 1e-10
+
+
+@pytest.mark.gpu
 def test_gpus_2_refuses_on_the_one_gpu_box():
     import torch
     if torch.cuda.device_count() >= 2:
