@@ -1119,7 +1119,6 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
             gsv = dgr[t].p;
           }
           if (!grad_inputs && !gsv) continue;
-          CHECK_ARG(ds->in_dim[a] <= 16, "input gradients: input dimension > 16 is not supported on device");
           CHECK_RC(launch_grad_inputs(dKinv.p, 1, n_pad, dalpha.p, ds->row_off[I], ds->row_len[I], ds->col_off[J],
                                       ds->col_len[J], ds->h_terms[t], ds->pair_dmax[p], 2.0,
                                       grad_inputs ? dgx[a].p : nullptr, s, gsv));
@@ -2109,7 +2108,6 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   std::vector<DevBuf> dgz(grad_inputs_zz ? zz->n_inputs : 0), dgxz(grad_inputs_xz ? xz->n_inputs : 0);
   auto zero_inputs = [&](std::vector<DevBuf>& v, const sgp_dspec* ds) -> int {
     for (size_t k = 0; k < v.size(); ++k) {
-      CHECK_ARG(ds->in_dim[k] <= 16, "input gradients: input dimension > 16 is not supported on device");
       size_t cnt = (size_t)std::max<long>(1, (long)ds->in_dim[k] * ds->in_n[k]);
       CHECK_RC(v[k].alloc(cnt));
       SGP_HIP(hipMemsetAsync(v[k].p, 0, sizeof(double) * cnt, s));
@@ -2140,7 +2138,6 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
           double* gsv = nullptr;
           CHECK_RC(scale_buf(drz, grad_rowscale_zz, t, ds->h_terms[t].rs, ds->row_len[I], &gsv));
           if (!grad_inputs_zz && !gsv) continue;
-          CHECK_ARG(ds->in_dim[ds->term_row_input[t]] <= 16, "input gradients: input dimension > 16 is not supported on device");
           CHECK_RC(launch_grad_inputs(dGzz.p, 1, m_pad, nullptr, ds->row_off[I], ds->row_len[I], ds->col_off[J],
                                       ds->col_len[J], ds->h_terms[t], ds->pair_dmax[p], 2.0,
                                       grad_inputs_zz ? dgz[ds->term_row_input[t]].p : nullptr, s, gsv));
@@ -2160,8 +2157,7 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
           CHECK_RC(scale_buf(drx, grad_rowscale_xz, t, T.rs, ds->row_len[I], &gsr));
           CHECK_RC(scale_buf(dcx, grad_colscale_xz, t, T.cs, ds->col_len[J], &gsc));
           if (grad_inputs_xz || gsr || gsc)
-            CHECK_ARG(ds->in_dim[ds->term_row_input[t]] <= 16, "input gradients: input dimension > 16 is not supported on device");
-          if (grad_inputs_xz || gsr)
+            if (grad_inputs_xz || gsr)
             CHECK_RC(launch_grad_inputs(dE.p, 1, n_rows, nullptr, ds->row_off[I], ds->row_len[I], ds->col_off[J],
                                         ds->col_len[J], T, ds->pair_dmax[p], 1.0,
                                         grad_inputs_xz ? dgxz[ds->term_row_input[t]].p : nullptr, s, gsr));

@@ -533,6 +533,123 @@ __global__ __launch_bounds__(256) void grad_inputs_kernel(const double* Gm, long
   }
 }
 
+// Any input dimension (> 16): the same sums with the dimension walked in chunks of 16, twice per column tile -- pass 1
+// forms the 64 squared distances of a thread's row (registers; column chunk in LDS, as assemble_bigd_kernel) and turns
+// them into the weights w_j = 2 G_ij coef rs_i cs_j kappa'(d2_ij); pass 2 forms sum_j w_j (x_i - x'_j)[d] chunk by
+// chunk and adds it into the gradient, which this workgroup owns for its 128 rows (no atomics, deterministic).
+constexpr int GBD_CHUNK = 16;
+template <bool WS>
+__global__ __launch_bounds__(256) void grad_inputs_bigd_kernel(const double* Gm, long sr, long sc, const double* alpha,
+                                                               long r0, long nr, long c0, long nc, DevTerm T,
+                                                               double scale, double* gx, double* gsv) {
+  __shared__ __attribute__((aligned(16))) double sx[TILE * GBD_CHUNK];
+  __shared__ double scs[TILE];
+  __shared__ double comb[TILE * GBD_CHUNK];
+  const int t = threadIdx.x;
+  const int trow = t & 127, th = t >> 7;
+  const long lrow = (long)blockIdx.x * TILE + trow;
+  const bool live = lrow < nr;
+  const long grow = r0 + lrow;
+  const int D = T.dim;
+  const double ai = (alpha && live) ? alpha[grow] : 0.0;
+  const double wrow = live ? T.coef * (T.rs ? T.rs[lrow] : 1.0) : 0.0;
+  double accs = 0.0;
+  for (long ct = 0; ct * TILE < nc; ++ct) {
+    double w[64];
+#pragma unroll
+    for (int q = 0; q < 64; ++q) w[q] = 0.0;
+    // ---- pass 1: squared distances
+    for (int d0 = 0; d0 < D; d0 += GBD_CHUNK) {
+      __syncthreads();
+      for (int idx = t; idx < TILE * GBD_CHUNK; idx += 256) {
+        const int p = idx / GBD_CHUNK, d = idx % GBD_CHUNK;
+        const long lc = ct * TILE + p;
+        sx[idx] = (lc < nc && d0 + d < D) ? T.xc[lc * T.ldc + d0 + d] : 0.0;
+      }
+      if (d0 == 0 && t < TILE) {
+        const long lc = ct * TILE + t;
+        scs[t] = (lc < nc) ? (T.cs ? T.cs[lc] : 1.0) : 0.0;   // 0 kills the padding columns
+      }
+      __syncthreads();
+      if (live) {
+        double xi[GBD_CHUNK];
+#pragma unroll
+        for (int d = 0; d < GBD_CHUNK; ++d) xi[d] = (d0 + d < D) ? T.xr[lrow * T.ldr + d0 + d] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+          const double* sp = &sx[(th * 64 + q) * GBD_CHUNK];
+          double s = 0.0;
+#pragma unroll
+          for (int d = 0; d < GBD_CHUNK; ++d) {
+            const double df = xi[d] - sp[d];
+            s = fma(df, df, s);
+          }
+          w[q] += s;
+        }
+      }
+    }
+    // ---- weights
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < 64; ++q) {
+        const int p = th * 64 + q;
+        const long lc = ct * TILE + p;
+        double wq = 0.0;
+        if (lc < nc) {
+          const long gc = c0 + lc;
+          const double gm = Gm[grow * sr + gc * sc];
+          const double g = alpha ? 0.5 * (ai * alpha[gc] - gm) : gm;
+          const double d2 = w[q];
+          wq = 2.0 * g * wrow * scs[p] * kern_dd2(T.kind, d2, T.param);
+          if (WS) accs = fma(g * T.coef * scs[p], kern_val(T.kind, d2, T.param), accs);
+        }
+        w[q] = wq;
+      }
+    }
+    // ---- pass 2: sum_j w_j (x_i - x'_j)[d]
+    if (gx)
+      for (int d0 = 0; d0 < D; d0 += GBD_CHUNK) {
+        __syncthreads();
+        for (int idx = t; idx < TILE * GBD_CHUNK; idx += 256) {
+          const int p = idx / GBD_CHUNK, d = idx % GBD_CHUNK;
+          const long lc = ct * TILE + p;
+          sx[idx] = (lc < nc && d0 + d < D) ? T.xc[lc * T.ldc + d0 + d] : 0.0;
+        }
+        __syncthreads();
+        double part[GBD_CHUNK];
+#pragma unroll
+        for (int d = 0; d < GBD_CHUNK; ++d) part[d] = 0.0;
+        if (live) {
+          double xi[GBD_CHUNK];
+#pragma unroll
+          for (int d = 0; d < GBD_CHUNK; ++d) xi[d] = (d0 + d < D) ? T.xr[lrow * T.ldr + d0 + d] : 0.0;
+#pragma unroll
+          for (int q = 0; q < 64; ++q) {
+            const double* sp = &sx[(th * 64 + q) * GBD_CHUNK];
+#pragma unroll
+            for (int d = 0; d < GBD_CHUNK; ++d) part[d] = fma(w[q], xi[d] - sp[d], part[d]);
+          }
+        }
+        if (th == 1) {
+#pragma unroll
+          for (int d = 0; d < GBD_CHUNK; ++d) comb[trow * GBD_CHUNK + d] = part[d];
+        }
+        __syncthreads();
+        if (th == 0 && live) {
+#pragma unroll
+          for (int d = 0; d < GBD_CHUNK; ++d)
+            if (d0 + d < D) gx[lrow * D + d0 + d] += scale * (part[d] + comb[trow * GBD_CHUNK + d]);
+        }
+      }
+  }
+  if (WS) {
+    __syncthreads();
+    if (th == 1) scs[trow] = accs;
+    __syncthreads();
+    if (th == 0 && live) gsv[lrow] += scale * (accs + scs[trow]);
+  }
+}
+
 int launch_grad_inputs(const double* Gm, long sr, long sc, const double* alpha, long r0, long nr, long c0, long nc,
                        const DevTerm& T, int dmax, double scale, double* gx, hipStream_t s, double* gsv) {
   if (nr <= 0 || nc <= 0) return 0;
@@ -551,10 +668,10 @@ int launch_grad_inputs(const double* Gm, long sr, long sc, const double* alpha, 
   else if (dmax <= 4) SGP_GI(4);
   else if (dmax <= 8) SGP_GI(8);
   else if (dmax <= 16) SGP_GI(16);
-  else {
-    set_error("input gradients: input dimension > 16 is not supported on device");
-    return -1;
-  }
+  else if (gsv)   // any dimension: chunked two-pass kernel
+    hipLaunchKernelGGL((grad_inputs_bigd_kernel<true>), grid, block, 0, s, Gm, sr, sc, alpha, r0, nr, c0, nc, T, scale, gx, gsv);
+  else
+    hipLaunchKernelGGL((grad_inputs_bigd_kernel<false>), grid, block, 0, s, Gm, sr, sc, alpha, r0, nr, c0, nc, T, scale, gx, gsv);
 #undef SGP_GI
   SGP_HIP(hipGetLastError());
   return 0;

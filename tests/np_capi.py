@@ -419,8 +419,6 @@ class FakeLib:
         s, m, Cm, rc = self._observed(spec, mean, kind, noise)
         if rc:
             return rc
-        if grad_inputs and any(X.shape[0] > 16 for X in s.inputs):
-            return self._fail("input gradients: input dimension > 16 is not supported on device")
         if any(X.shape[0] > 64 for X in s.inputs):
             return self._fail("grad: input dimension > 64 is not supported on device")
         Lm, info = _chol(Cm)

@@ -446,8 +446,10 @@ def test_many_right_hand_sides(S):
 
 
 def test_input_dimension_limit_is_reported():
-    """Assembly (cov, logpdf, posterior, rand, elbo) takes ColVecs of any dimension; the reverse-mode kernels
-    stop at 64 (term gradients) and 16 (input gradients) and must say so instead of computing something else."""
+    """Assembly (cov, logpdf, posterior, rand, elbo) takes ColVecs of any dimension; the term-gradient kernels stop at
+    64 and must say so instead of computing something else.  Input gradients take any dimension up to that (round 3:
+    grad_inputs_bigd_kernel walks the dimension in chunks of 16; they used to stop at 16): checked against central
+    differences of the logpdf at D = 17 and 40, incl. a function-valued scale (the row-scale sums of the same kernel)."""
     f = P.atomic(P.GP(P.SEKernel()), P.GPC())
     rng = np.random.default_rng(0)
     for D in (64, 65):
@@ -459,11 +461,36 @@ def test_input_dimension_limit_is_reported():
     with pytest.raises(P.SthenoMIError) as ei:
         P.logpdf_and_gradient(f(X65, 0.1), y)
     assert "dimension" in str(ei.value)
-    X17 = P.ColVecs(rng.standard_normal((17, 40)) / np.sqrt(17))
-    assert np.isfinite(P.logpdf_and_gradient(f(X17, 0.1), y)["logpdf"])       # term gradients: fine up to 64
-    with pytest.raises(P.SthenoMIError) as ei:
-        P.logpdf_and_gradient(f(X17, 0.1), y, inputs=True)
-    assert "dimension" in str(ei.value)
+    y60 = rng.standard_normal(60)
+    for D in (17, 40):
+        X = np.asfortranarray(rng.standard_normal((D, 60)) / np.sqrt(D))
+        sig = lambda pt: 1.0 + 0.3 * float(np.sin(np.sum(pt)))
+        for proc in (f, sig * f):
+            lp = lambda Xq: P.logpdf(proc(P.ColVecs(np.asfortranarray(Xq)), 0.1), y60)
+            g = P.logpdf_and_gradient(proc(P.ColVecs(X), 0.1), y60, inputs=True, scales=proc is not f)
+            assert abs(g["logpdf"] - lp(X)) <= 1e-12 * abs(g["logpdf"])
+            gx = g["inputs"][0]                 # d logpdf / d (the points the kernel reads), sigma(x) held fixed
+            assert gx.shape == (D, 60)
+            if proc is f:
+                for (d, i) in ((0, 0), (D - 1, 59), (D // 2, 17)):
+                    h = 1e-6
+                    Xp, Xm = X.copy(), X.copy()
+                    Xp[d, i] += h
+                    Xm[d, i] -= h
+                    fd = (lp(Xp) - lp(Xm)) / (2 * h)
+                    assert abs(gx[d, i] - fd) <= 1e-5 * max(1.0, abs(fd)), (D, d, i, gx[d, i], fd)
+            else:
+                # total derivative w.r.t. one coordinate = through the kernel's points + through sigma at that point
+                (rec,) = g["scales"]
+                for (d, i) in ((1, 3), (D - 2, 41)):
+                    h = 1e-6
+                    Xp, Xm = X.copy(), X.copy()
+                    Xp[d, i] += h
+                    Xm[d, i] -= h
+                    fd = (lp(Xp) - lp(Xm)) / (2 * h)
+                    dsig = 0.3 * float(np.cos(np.sum(X[:, i])))
+                    tot = gx[d, i] + rec["d_values"][i] * dsig
+                    assert abs(tot - fd) <= 1e-5 * max(1.0, abs(fd)), (D, d, i, tot, fd)
 
 
 # ---- reverse-mode gradient of logpdf -------------------------------------------
