@@ -71,27 +71,35 @@ function paths((_, s, f)::Tuple{typeof(*),Any,AbstractGP}, x, c, r, key)
 end
 paths((_, f, g)::Tuple{typeof(∘),AbstractGP,Any}, x, c, r, key) = paths(f, g.(x), c, r, key)
 
-# KernelFunctions kernel -> [(kind, coef, param, input_scale)]
-leaf(::SEKernel) = [(0, 1.0, 0.0, 1.0)]
-leaf(::Matern12Kernel) = [(1, 1.0, 0.0, 1.0)]       # == ExponentialKernel
-leaf(::Matern32Kernel) = [(2, 1.0, 0.0, 1.0)]
-leaf(::Matern52Kernel) = [(3, 1.0, 0.0, 1.0)]
-leaf(::WhiteKernel) = [(4, 1.0, 0.0, 1.0)]
-leaf(k::ConstantKernel) = [(5, 1.0, only(k.c), 1.0)]
-leaf(k::ScaledKernel) = [(a, c * only(k.σ²), p, s) for (a, c, p, s) in leaf(k.kernel)]
+# KernelFunctions kernel -> [(kind, coef, param, chain)]: `chain` is the ordered list of input-transform steps the
+# host applies to the points before upload -- (:scale, s) for ScaleTransform(s) / with_lengthscale, (:periodic, f) for
+# PeriodicTransform(f) (examples/extended_mauna_loa/script.jl:129: x -> [sin(2 pi f x); cos(2 pi f x)]) -- outermost
+# transform first, exactly as stheno.jl_amd/kernels.py (`_push` / `apply_chain`, which IS tested against the reference
+# semantics): (k o PeriodicTransform(f)) o ScaleTransform(a) and nested periodic transforms are ordinary chains.
+const Chain = Vector{Tuple{Symbol,Float64}}
+leaf(::SEKernel) = [(0, 1.0, 0.0, Chain())]
+leaf(::Matern12Kernel) = [(1, 1.0, 0.0, Chain())]       # == ExponentialKernel
+leaf(::Matern32Kernel) = [(2, 1.0, 0.0, Chain())]
+leaf(::Matern52Kernel) = [(3, 1.0, 0.0, Chain())]
+leaf(::WhiteKernel) = [(4, 1.0, 0.0, Chain())]
+leaf(k::ConstantKernel) = [(5, 1.0, only(k.c), Chain())]
+leaf(k::ScaledKernel) = [(a, c * only(k.σ²), p, ch) for (a, c, p, ch) in leaf(k.kernel)]
 leaf(k::KernelSum) = reduce(vcat, leaf.(k.kernels))
+# k o t evaluates k(t(x), t(y)): t is applied to the raw points first, the inner kernel's own chain after it
 leaf(k::TransformedKernel{<:Any,<:ScaleTransform}) =
-    [(a, c, p, s * only(k.transform.s)) for (a, c, p, s) in leaf(k.kernel)]
-# k ∘ PeriodicTransform(f) (examples/extended_mauna_loa/script.jl:129): the 1-D points are mapped to
-# [sin(2πfx); cos(2πfx)] on the host before upload; expressed as a negative "scale" tag carrying f so
-# that build_spec's input!(X, s) applies the map (stheno.jl_amd/kernels.py: apply_chain).
-struct PeriodicTag; f::Float64; s::Float64; end
+    [(a, c, p, vcat([(:scale, Float64(only(k.transform.s)))], ch)) for (a, c, p, ch) in leaf(k.kernel)]
 leaf(k::TransformedKernel{<:Any,<:PeriodicTransform}) =
-    [(a, c, p, PeriodicTag(only(k.transform.f), s)) for (a, c, p, s) in leaf(k.kernel)]
-apply_input(X, s::Real) = s == 1.0 ? X : s .* X
-function apply_input(X, t::PeriodicTag)
-    θ = (2π * t.f) .* X
-    return t.s .* vcat(sin.(θ), cos.(θ))
+    [(a, c, p, vcat([(:periodic, Float64(only(k.transform.f)))], ch)) for (a, c, p, ch) in leaf(k.kernel)]
+function apply_input(X, chain::Chain)
+    for (op, v) in chain
+        if op === :scale
+            X = v == 1.0 ? X : v .* X
+        else                                 # :periodic -- 1-D points only, as PeriodicTransform itself
+            θ = (2π * v) .* X
+            X = vcat(sin.(θ), cos.(θ))
+        end
+    end
+    return X
 end
 
 blocks_of(f::GPPP, x) = blocks_of(extract_components(f, x)...)
@@ -148,10 +156,30 @@ logpdf(fx::SthenoFGP, y::AbstractVector{<:Real}) = only(logpdf(fx, reshape(y, :,
 
 # Float32 models (test/gp/util.jl:76-88: `logpdf(fx, y) isa Float32`): fp32 assembly + fp32 Cholesky on the device
 # (sgp_logpdf_f32).  The spec is passed in Float64 (an exact conversion); the library rounds it to fp32 once.
-function logpdf(fx::FiniteGP{<:Union{GPPP,SthenoAbstractGP},<:AbstractVector{<:Union{Float32,AbstractVector{Float32}}}},
-                y::AbstractVector{Float32})
+# The element type of the POINTS, looking through GPPPInput / BlockData (whose own eltype is a Tuple / a Union): what decides
+# between the fp32 and the fp64 device path for GPPP models too.
+point_eltype(x::AbstractVector{<:Real}) = eltype(x)
+point_eltype(x::ColVecs) = eltype(x.X)
+point_eltype(x::GPPPInput) = point_eltype(x.x)
+point_eltype(x::BlockData) = promote_type(map(point_eltype, x.X)...)
+point_eltype(x) = Float64
+# limits of the fp32 kernels (include/sthenomi.h): input dimension <= 16, terms per block pair x dimension <= 64
+function f32_supported(sp::Spec)
+    tptr = sp.keep[6]; terms = sp.keep[5]; inputs = sp.keep[3]
+    for p in 1:(length(tptr) - 1)
+        t0, t1 = tptr[p] + 1, tptr[p + 1]
+        t1 < t0 && continue
+        d = maximum(size(inputs[terms[t].row_input + 1], 1) for t in t0:t1)
+        dmax = nextpow(2, max(d, 1))
+        (dmax > 16 || (t1 - t0 + 1) * dmax > 64) && return false
+    end
+    return true
+end
+function logpdf(fx::SthenoFGP, y::AbstractVector{Float32})
+    point_eltype(fx.x) === Float32 || return only(logpdf(fx, reshape(y, :, 1)))
     sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
-    kind == 2 && return Float32(invoke(logpdf, Tuple{SthenoFGP,AbstractVector{<:Real}}, fx, y))
+    # dense Sigma_y and models beyond the fp32 kernels' limits: fp64 arithmetic, Float32 result (type stability)
+    (kind == 2 || !f32_supported(sp)) && return Float32(only(logpdf(fx, reshape(y, :, 1))))
     yd = collect(Float64, y); out = zeros(1)
     GC.@preserve sp m nz yd out check(ccall((:sgp_logpdf_f32, LIB), Cint,
         (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
@@ -160,12 +188,28 @@ function logpdf(fx::FiniteGP{<:Union{GPPP,SthenoAbstractGP},<:AbstractVector{<:U
 end
 
 function rand(rng::AbstractRNG, fx::SthenoFGP, S::Int)
-    sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
+    point_eltype(fx.x) === Float32 && return rand_f32(rng, fx, S)
     Z = randn(rng, Float64, length(fx), S)      # the caller's integer RNG stream, column-major fill
+    return rand_with(fx, Z)
+end
+# `rand(rng, fx) isa Vector{Float32}` for Float32 models (test/gp/util.jl:76-88): the draw stays Float32 on the caller's
+# RNG stream (randn(rng, Float32, ...), as AbstractGPs does), the fp32 factor and product run on the device (sgp_rand_f32)
+function rand_f32(rng::AbstractRNG, fx::SthenoFGP, S::Int)
+    sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
+    Z32 = randn(rng, Float32, length(fx), S)
+    (kind == 2 || !f32_supported(sp)) && return Float32.(rand_with(fx, Float64.(Z32)))
+    Z = Float64.(Z32); out = zeros(Float32, size(Z))
+    GC.@preserve sp m nz Z out check(ccall((:sgp_rand_f32, LIB), Cint,
+        (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float32}, Int64),
+        ctx(), sp.c, m, kind, collect(Float64, nz), Z, size(Z, 1), S, out, size(out, 1)))
+    return out
+end
+function rand_with(fx::SthenoFGP, Z::Matrix{Float64})          # m .+ L Z for a given draw (fp64 device path)
+    sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x)); kind, nz = noise_args(fx.Σy)
     out = similar(Z)
     GC.@preserve sp m nz Z out check(ccall((:sgp_rand, LIB), Cint,
         (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}, Int64),
-        ctx(), sp.c, m, kind, nz, Z, size(Z, 1), S, out, size(out, 1)))
+        ctx(), sp.c, m, kind, nz, Z, size(Z, 1), size(Z, 2), out, size(out, 1)))
     return out
 end
 rand(rng::AbstractRNG, fx::SthenoFGP) = vec(rand(rng, fx, 1))
@@ -408,10 +452,10 @@ function ChainRulesCore.rrule(::typeof(logpdf), fx::SthenoFGP, y::AbstractVector
         k = 0
         for I in eachindex(rp), J in eachindex(rp), (ip, p) in enumerate(rp[I]), (iq, q) in enumerate(rp[J])
             p.key == q.key || continue
-            for (_, _, _, s) in leaf(p.atom.gp.kernel)
+            for _ in leaf(p.atom.gp.kernel)
                 for (B, ib) in ((I, ip), (J, iq))
                     k += 1
-                    G = (s isa Real ? s : 1.0) .* g.inputs[k]          # undo the kernel's ScaleTransform
+                    G = copy(g.inputs[k])          # (covered models have parameter-free leaf kernels: empty chains)
                     for (node, w, xin) in reverse(tr[B][ib].warps)
                         if w isa Stheno.Stretch{<:Real}
                             dl[node] = get(dl, node, 0.0) + sum(G .* mat(xin))
