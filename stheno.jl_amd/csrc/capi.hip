@@ -194,6 +194,21 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (fm) c->fuse_max_n = atol(fm);
     const char* po = getenv("SGP_POOL");
     if (po) c->pool_enabled = atoi(po);
+    const char* df = getenv("SGP_DATAFLOW");
+    if (df) c->dataflow = atoi(df);
+    const char* dfa = getenv("SGP_DF_MIN_N");
+    if (dfa) c->df_min_n = atol(dfa);
+    const char* dfb = getenv("SGP_DF_MAX_N");
+    if (dfb) c->df_max_n = atol(dfb);
+    const char* dft = getenv("SGP_DF_TIMEOUT_S");
+    if (dft) c->df_timeout_s = atof(dft);
+    {
+      hipDeviceProp_t prop;
+      SGP_HIP(hipGetDeviceProperties(&prop, device));
+      c->df_wgs = 2 * prop.multiProcessorCount;
+      const char* dfw = getenv("SGP_DF_WGS");
+      if (dfw && atoi(dfw) > 0) c->df_wgs = atoi(dfw);
+    }
     SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
     SGP_HIP(hipMalloc(&c->d_w, sizeof(double) * TILE * TILE));
     c->n_slots = 1 << 15;
@@ -228,6 +243,8 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->d_slots) hipFree(c->d_slots);
   if (c->d_scal) hipFree(c->d_scal);
   if (c->d_info) hipFree(c->d_info);
+  if (c->d_df_state) hipFree(c->d_df_state);
+  if (c->d_df_inv) hipFree(c->d_df_inv);
   if (c->ev_panel) hipEventDestroy(c->ev_panel);
   if (c->ev_rest) hipEventDestroy(c->ev_rest);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -632,6 +649,31 @@ static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, lo
 static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
                          hipStream_t s, long grow = 0) {
   CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
+  // Dataflow factorisation (chol_df.hip): one launch of persistent workgroups, tile-level dependencies instead of
+  // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
+  // upper-triangular border, `grow`: its tasks would have to skip the structurally zero tiles.)
+  const bool df_auto = n_pad >= ctx->df_min_n && n_pad < ctx->df_max_n;
+  if (grow == 0 && ctx->refine == 1 && (ctx->dataflow == 1 || (ctx->dataflow < 0 && df_auto))) {
+    const long need_state = 8 + m_tot / TILE, need_inv = (n_pad / TILE) * INVD_STRIDE;
+    if (need_state > ctx->n_df_state) {
+      SGP_HIP(hipStreamSynchronize(s));
+      if (ctx->d_df_state) hipFree(ctx->d_df_state);
+      ctx->d_df_state = nullptr;
+      ctx->n_df_state = 0;
+      SGP_HIP(hipMalloc(&ctx->d_df_state, sizeof(int) * need_state));
+      ctx->n_df_state = need_state;
+    }
+    if (!d_wall && need_inv > ctx->n_df_inv) {
+      SGP_HIP(hipStreamSynchronize(s));
+      if (ctx->d_df_inv) hipFree(ctx->d_df_inv);
+      ctx->d_df_inv = nullptr;
+      ctx->n_df_inv = 0;
+      SGP_HIP(hipMalloc(&ctx->d_df_inv, sizeof(double) * need_inv));
+      ctx->n_df_inv = need_inv;
+    }
+    return launch_chol_dataflow(A, ld, n_pad, m_tot, ctx->d_df_state, d_wall ? d_wall : ctx->d_df_inv, ctx->d_slots,
+                                ctx->d_info, ctx->df_wgs, ctx->df_timeout_s, s);
+  }
   // outer panel width, measured (profiles/r02_summary.md): one panel for n_pad <= 4096 (the outer level only
   // adds launches there: 1.52 -> 1.30 ms at N = 2048; with the fused diagonal blocks 2.73 -> 2.47 ms at N = 4096),
   // 1024 up to 8192, 512 in the
@@ -727,6 +769,8 @@ static int fetch_info(sgp_ctx* ctx, hipStream_t s) {
   int info = 0;
   SGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   SGP_HIP(hipStreamSynchronize(s));
+  if (info == SGP_DF_TIMEOUT)
+    set_error("dataflow factorisation: a dependency wait inside the kernel ran into its bound (SGP_DF_TIMEOUT_S)");
   return info;
 }
 
@@ -820,6 +864,7 @@ static int dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, const 
       timings[7] = 0.0;
     }
   }
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
               std::to_string(info));
@@ -996,6 +1041,7 @@ extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* me
   SGP_HIP(hipGetLastError());
   CHECK_RC(launch_gemm_nt_lz(dA.p, m_tot, dZt.p, s_pad, dOut.p, n_pad, n_pad, s_pad, 1.0, s));
   int info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
               std::to_string(info));
@@ -1127,6 +1173,7 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
     }
   }
   int info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
               std::to_string(info));
@@ -1374,6 +1421,7 @@ extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, cons
     SGP_HIP(hipMemcpy(alpha_out, dal.p, sizeof(double) * N, hipMemcpyDeviceToHost));
   }
   int info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " +
               std::to_string(info));
@@ -1616,6 +1664,7 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
   CHECK_RC(launch_fill_pad(dLz, m_pad, M, m_pad, 0, m_pad, m_pad, 0, s));
   CHECK_RC(chol_bordered(ctx, dLz, m_pad, m_pad, m_pad, d_wz, s));
   int info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("vfe: Kzz + Sigma_z is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
@@ -1672,6 +1721,7 @@ static int vfe_finish(sgp_ctx* ctx, double* d_part, long m_pad, double* d_wg, do
   SGP_HIP(hipMemcpyAsync(h, d_sc, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
   tm.finish();
   int info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("vfe: A A' + I is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
@@ -1843,6 +1893,7 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   // thrashes the TLB (N = 262 144, M = 4096: 225 -> 700 ms).
   CHECK_RC(chol_bordered(ctx, dA.p, ld, m_pad, ld, d_wz, s));
   int info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("vfe: Kzz + Sigma_z is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
@@ -1896,6 +1947,7 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   CHECK_RC(launch_rowsumsq(dG + m_pad, ldg, m_pad, 1, ctx->d_scal + 6, 0, s));
   SGP_HIP(hipMemcpyAsync(h, ctx->d_scal + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
   info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("vfe: A A' + I is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
@@ -2029,6 +2081,7 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   SGP_HIP(hipGetLastError());
   CHECK_RC(chol_bordered(ctx, dA.p, ld, m_pad, ld, nullptr, s, m_pad + n_rows));
   int info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("vfe: Kzz + Sigma_z is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
@@ -2072,6 +2125,7 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   double h[6];
   SGP_HIP(hipMemcpyAsync(h, ctx->d_scal + 1, sizeof(double) * 6, hipMemcpyDeviceToHost, s));
   info = fetch_info(ctx, s);
+  if (info < 0) return -3;
   if (info > 0) {
     set_error("vfe: A A' + I is not positive definite (leading minor " + std::to_string(info) + ")");
     return info;
@@ -2754,7 +2808,27 @@ extern "C" int sgp_bench_gemm_stamps(sgp_ctx* ctx, int64_t m, int64_t k, long lo
   CHECK_RC(launch_gemm_nt_update(A.p, m, C.p, m, m, m, k, s));   // warm-up (clocks, caches)
   SGP_HIP(hipMemsetAsync(D.p, 0, sizeof(double) * 8 * ids, s));
   // SGP_STAMP_BETA0=1 (experiment): beta = 0, i.e. no old C tile to fetch -- isolates its share of the prologue
-  CHECK_RC(launch_gemm_nt_stamps(A.p, m, C.p, m, m, m, k, (long long*)D.p, &ids, s, getenv("SGP_STAMP_BETA0") ? 0.0 : 1.0));
+  // SGP_STAMP_SCRAMBLE=<multiplier> (experiment): tiles dealt to the workgroup ids through id -> id * multiplier mod n_ids
+  // (made coprime here), i.e. no operand panel shared between neighbouring workgroups
+  long scr = getenv("SGP_STAMP_SCRAMBLE") ? atol(getenv("SGP_STAMP_SCRAMBLE")) : 0;
+  auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
+  // SGP_STAMP_ROTATE=1 on top: every workgroup also starts at its own k offset (desynchronised panel reads)
+  while (scr > 1 && gcd(scr, ids) != 1) ++scr;
+  if (scr > 1 && getenv("SGP_STAMP_ROTATE")) scr = -scr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  SGP_HIP(hipEventCreate(&e0));
+  SGP_HIP(hipEventCreate(&e1));
+  SGP_HIP(hipEventRecord(e0, s));
+  int rc_st = launch_gemm_nt_stamps(A.p, m, C.p, m, m, m, k, (long long*)D.p, &ids, s, getenv("SGP_STAMP_BETA0") ? 0.0 : 1.0,
+                                    (scr > 1 || scr < -1) ? scr : 0);
+  hipEventRecord(e1, s);
+  hipStreamSynchronize(s);
+  float ms_st = 0;
+  hipEventElapsedTime(&ms_st, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc_st) return rc_st;
+  if (getenv("SGP_STAMP_VERBOSE")) fprintf(stderr, "sgp_bench_gemm_stamps: launch %.3f ms (HIP events)\n", ms_st);
   SGP_HIP(hipStreamSynchronize(s));
   SGP_HIP(hipMemcpy(out, D.p, sizeof(long long) * 8 * ids, hipMemcpyDeviceToHost));
   return 0;

@@ -1,0 +1,301 @@
+// Dataflow blocked Cholesky: the whole bordered factorisation in ONE launch (replaces LAPACK dpotrf under
+// LinearAlgebra.cholesky on the reference path -- SURVEY.md section 8a A2-A5 -- for the sizes where the launch-per-step
+// schedules of capi.hip: chol_bordered are bound by their serial chain of ~3 launches per 128 columns).
+//
+// Left-looking by 128 x 128 tile.  Task (i, j), i >= j: tile row i, tile column j of the m_tot x n_pad factor matrix
+//   acc  = -A_ij + sum_{k < j} L_ik L_jk'          the production GEMM tile program (gemm_nt.hip), K = 128 j
+//   i == j : L_jj = chol(-acc)                     potrf_diag_body, straight from the accumulators (LDS hand-off)
+//   i >  j : L_ij = (-acc) inv(L_jj)'              panel_solve_strip, eight waves x 16 rows
+// Workgroups are persistent: each takes the next task id from a device counter (column-major task order = a topological
+// order of the dependency graph, so whoever holds the earliest unfinished task can always finish it: no residency
+// requirement, no deadlock) and walks its contraction as far as the two operand tile rows are final.  Progress is one
+// counter per tile row (row i's tiles become final in increasing column order): prog[i] = number of final tiles of row
+// i.  A workgroup that runs ahead of the diagonal chain simply accumulates the k blocks that exist and polls for the
+// next: the look-ahead of the launch-based schedules falls out of the data dependencies, at tile granularity and with
+// no kernel boundary, stream or event on the chain -- and the trailing work never waits for a whole panel.
+//
+// Arithmetic: every entry sees exactly the operations of the launch-based path in the same order (k ascending in steps
+// of 4 through v_mfma_f64_4x4x4_4b; a stored and re-read fp64 accumulator is the same number), the same diagonal-block
+// routine and the same refined substitution: the factor is BIT-IDENTICAL to chol_bordered's (tests/test_gpu_dataflow.py).
+//
+// Inter-workgroup visibility (per-XCD L2s are not coherent, a CU's L1 is never refreshed by other CUs' stores): the
+// producer's waves drain their stores (s_waitcnt vmcnt(0)), barrier, one lane issues an agent-scope release fence
+// (buffer_wbl2 sc1) + a second drain, then the relaxed agent-scope store of prog[]; a consumer polls prog[] with
+// relaxed agent-scope loads from one lane, issues ONE agent-scope acquire (buffer_inv sc1) after the match, barrier,
+// plain loads.  No tile is read by another workgroup before it is final, so no cache can hold a stale copy of it.
+// Every wait is bounded: a poll that exceeds the limit raises the abort word (all workgroups leave) and reports through
+// *info = SGP_DF_TIMEOUT, which the host turns into an error.
+#include "common.h"
+#include "potrf_diag.h"
+#include "panel_solve.h"
+
+namespace sgp {
+
+constexpr int DF_KB = 16;                       // K chunk per LDS stage (as gemm_nt.hip)
+constexpr int DF_STAGE = 2 * DF_KB * LDS_LD;    // doubles per stage: A chunk + B chunk
+
+struct DfArgs {
+  double* A;        // m_tot x n_pad, column-major, lower tiles + bordered rows
+  long ld;
+  int T_r, T_c;     // tile rows (m_tot / 128), tile columns (n_pad / 128)
+  int* state;       // [0] next task id, [1] abort, [8 + i] prog[i]; zeroed before every launch
+  double* invall;   // T_c x INVD (2048 doubles): inverse 16x16 diagonal blocks of every 128-block
+  double* slots;    // T_c logdet contributions
+  int* info;
+  long long spin_ticks;   // wall_clock64 ticks (100 MHz) a single wait may last
+  long ntasks;
+  int prio;
+};
+
+template <int KS>
+__device__ __forceinline__ void df_kstep(double (&acc)[8][4], unsigned a_addr, unsigned b_addr) {
+  double a_r[4], b_c[8];
+  constexpr int O = KS * 4 * LDS_LD * 8;   // byte offset of k-step KS inside a stage
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[0]) : "v"(a_addr), "i"(O + 0));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[1]) : "v"(a_addr), "i"(O + 128));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[2]) : "v"(a_addr), "i"(O + 256));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[3]) : "v"(a_addr), "i"(O + 384));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[0]) : "v"(b_addr), "i"(O + 0));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[1]) : "v"(b_addr), "i"(O + 32));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[2]) : "v"(b_addr), "i"(O + 64));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[3]) : "v"(b_addr), "i"(O + 96));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[4]) : "v"(b_addr), "i"(O + 128));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[5]) : "v"(b_addr), "i"(O + 160));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[6]) : "v"(b_addr), "i"(O + 192));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[7]) : "v"(b_addr), "i"(O + 224));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (asm is opaque to hipcc)
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
+}
+
+// acc += A_panel[:, 16 c0 .. 16 c1) B_panel[:, 16 c0 .. 16 c1)' for one 128 x 128 tile; the chunk pipeline of
+// gemm_nt_dma_tile (global -> LDS DMA one chunk ahead, two stages, raw barriers)
+__device__ __forceinline__ void df_contract(const double* Ag, const double* Bg, long ld, long c0, long c1,
+                                            double (&acc)[8][4], double* smem, int wu, int lane, unsigned a_off,
+                                            unsigned b_off) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double*)smem;
+  auto dma = [&](long k0, int stage) {
+    double* sa = smem + stage * DF_STAGE;
+    double* sb = sa + DF_KB * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < DF_KB / 8; ++i) {  // wave w moves columns w and w + 8 of both operands
+      const int col = wu + 8 * i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ag + 2 * lane + (k0 + col) * ld), (lptr_t)(sa + col * LDS_LD), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bg + 2 * lane + (k0 + col) * ld), (lptr_t)(sb + col * LDS_LD), 16, 0, 0);
+    }
+  };
+  dma(c0 * DF_KB, (int)(c0 & 1));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (long c = c0; c < c1; ++c) {
+    const int stage = (int)(c & 1);
+    if (c + 1 < c1) dma((c + 1) * DF_KB, stage ^ 1);
+    const unsigned a_addr = lds_base + (unsigned)(stage * DF_STAGE * 8) + a_off;
+    const unsigned b_addr = lds_base + (unsigned)(stage * DF_STAGE * 8) + b_off;
+    df_kstep<0>(acc, a_addr, b_addr);
+    df_kstep<1>(acc, a_addr, b_addr);
+    df_kstep<2>(acc, a_addr, b_addr);
+    df_kstep<3>(acc, a_addr, b_addr);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+#define DF_RLX_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// thread 0: wait until min(prog[i], prog[j]) > have (returns min(.., cap)), or -1 on abort / timeout
+__device__ __forceinline__ int df_wait(const DfArgs& a, int i, int j, int have, int cap) {
+  int* prog = a.state + 8;
+  const long long t0 = wall_clock64();
+  int avail;
+  for (unsigned spins = 0;; ++spins) {
+    const int pi = DF_RLX_LOAD(prog + i);
+    const int pj = (i == j) ? pi : DF_RLX_LOAD(prog + j);
+    avail = min(min(pi, pj), cap);
+    if (avail > have) break;
+    if (DF_RLX_LOAD(a.state + 1) != 0) return -1;
+    __builtin_amdgcn_s_sleep(4);
+    if ((spins & 63) == 63 && wall_clock64() - t0 > a.spin_ticks) {
+      __hip_atomic_store(a.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicCAS(a.info, 0, SGP_DF_TIMEOUT);
+      return -1;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return avail;
+}
+
+// lane 0, after every wave has drained its stores and met at a barrier: release fence, drain, progress counter
+__device__ __forceinline__ void df_release_store(int* word, int value) {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (ROCm 7.2 may drop the wait after buffer_wbl2: restate it)
+  __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// lane 0: the next task id (or -1: none left / abort raised)
+__device__ __forceinline__ int df_dequeue(const DfArgs& a) {
+  int q = -1;
+  if (DF_RLX_LOAD(a.state + 1) == 0) q = atomicAdd(a.state, 1);
+  return (q >= 0 && (long)q < a.ntasks) ? q : -1;
+}
+
+// The three phases of a task are separate (non-inlined) functions: each gets its own register allocation -- inlined
+// into one loop body the diagonal-block routine (128 VGPRs), the substitution (wants > 200) and the contraction's 64
+// accumulators + LDS pipeline spilled into each other (265 VGPR / 220 SGPR spills); nothing but (i, j) crosses a phase
+// boundary: the accumulators leave through LDS (diagonal tile) or through the tile's own memory (off-diagonal).
+
+// Phase 1: acc = -A_ij + sum_k L_ik L_jk' as the operand rows become final.  Diagonal tile: the result goes into
+// potrf_diag_body's packed LDS layout; off-diagonal: T = -acc is stored in place.  Returns false on abort.
+__device__ __attribute__((noinline)) bool df_accumulate(const DfArgs& a, int i, int j, double* smem, int* s_word) {
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w = t >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int wr = w >> 2, wc = w & 3;
+  const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
+  const unsigned a_off = (unsigned)((lq * LDS_LD + wr * 64 + l15) * 8);
+  const unsigned b_off = (unsigned)((DF_KB * LDS_LD + lq * LDS_LD + wc * 32 + l3) * 8);
+  const long ld = a.ld;
+  const double* Ag = a.A + (long)i * TILE;
+  const double* Bg = a.A + (long)j * TILE;
+  double* Cg = a.A + ((long)i * TILE + wr * 64 + l15) + ((long)j * TILE + wc * 32 + lq) * ld;
+  // acc[jj][ii] = -A[row 64 wr + 16 ii + l15][col 32 wc + 4 jj + lq]: the seed of C_new = -(acc + P P')
+  double acc[8][4];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) acc[jj][ii] = Cg[ii * 16 + (long)(jj * 4) * ld];
+#pragma unroll
+  for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) acc[jj][ii] *= -1.0;
+  int kdone = 0;
+  while (kdone < j) {
+    if (t == 0) s_word[1] = df_wait(a, i, j, kdone, j);
+    __syncthreads();
+    const int avail = __builtin_amdgcn_readfirstlane(s_word[1]);   // wave-uniform for the compiler too
+    if (avail < 0) return false;
+    df_contract(Ag, Bg, ld, (long)kdone * (TILE / DF_KB), (long)avail * (TILE / DF_KB), acc, smem, wu, lane, a_off, b_off);
+    kdone = avail;
+  }
+  if (i == j) {
+    // accumulators -> potrf_diag_body's packed LDS layout (as gemm_nt_dma_tile<HANDOFF>)
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) {
+        const int rb = 4 * wr + ii, cb = 2 * wc + (jj >> 2);
+        const int k = 4 * (jj & 3) + lq;
+        if (rb >= cb) smem[boff(rb, cb) + k * 16 + l15] = (rb > cb || l15 >= k) ? -acc[jj][ii] : 0.0;
+      }
+  } else {
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj)
+#pragma unroll
+      for (int ii = 0; ii < 4; ++ii) Cg[ii * 16 + (long)(jj * 4) * ld] = -acc[jj][ii];
+  }
+  return true;
+}
+
+// Phase 2a: Cholesky of the diagonal tile sitting in LDS
+__device__ __attribute__((noinline)) void df_diag(const DfArgs& a, int j) {
+  potrf_diag_body<false, double, true>(a.A + (long)j * TILE + (long)j * TILE * a.ld, a.ld, a.invall + (long)j * 2048,
+                                       a.slots + j, a.info, (long)j * TILE, a.prio, nullptr);
+}
+
+// Phase 2b: L_ij = T inv(L_jj)' for the tile's 128 rows, eight waves x 16 rows
+__device__ __attribute__((noinline)) void df_solve(const DfArgs& a, int i, int j, double* smem) {
+  const int t = threadIdx.x;
+  const int lane = t & 63, w = t >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const long ld = a.ld;
+  const double* Ljj = a.A + (long)j * TILE + (long)j * TILE * ld;
+  panel_solve_fill<double, 8>(smem, Ljj, ld, __builtin_amdgcn_readfirstlane(w), lane);
+  __syncthreads();
+  double* X = a.A + (long)i * TILE + (long)j * TILE * ld;
+  const int loff = (int)(w * 16 + l15 + lq * ld);
+  panel_solve_strip<double>(X, ld, loff, smem, a.invall + (long)j * 2048, 256, 16, lane);
+}
+
+__global__ __launch_bounds__(512, 4) void chol_dataflow_kernel(DfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
+  __shared__ int s_word[4];   // [0] task id, [1] available k blocks / abort
+  const int t = threadIdx.x;
+  int* prog = a.state + 8;
+  if (t == 0) s_word[0] = df_dequeue(a);
+  // One lane-0 section per iteration (publish the finished tile AND take the next task), followed by the barrier at the
+  // top: with a separate lane-0 `dequeue` at the top and lane-0 `publish` at the bottom the compiler threaded lane 0
+  // from one straight into the other across the back edge, and the structurizer then ran lanes 1..63 of wave 0 into
+  // the next iteration's barrier BEFORE lane 0's publish -- a deadlock.  Every value that steers control flow is read
+  // through readfirstlane, so the task loop is scalar control flow for the compiler.
+  for (;;) {
+    __syncthreads();   // s_word[0] is set; the previous task's LDS phases are over for every wave
+    const int q = __builtin_amdgcn_readfirstlane(s_word[0]);
+    if (q < 0) break;
+    // column-major task order: column j holds the T_r - j tasks (j, j), (j + 1, j), ..., (T_r - 1, j)
+    int j, i;
+    {
+      const double b = 2.0 * a.T_r + 1.0;
+      j = (int)((b - sqrt(b * b - 8.0 * (double)q)) * 0.5);
+      if (j < 0) j = 0;
+      if (j >= a.T_c) j = a.T_c - 1;
+      while (j > 0 && (long)j * a.T_r - (long)j * (j - 1) / 2 > q) --j;
+      while (j + 1 < a.T_c && (long)(j + 1) * a.T_r - (long)(j + 1) * j / 2 <= q) ++j;
+      i = j + (int)(q - ((long)j * a.T_r - (long)j * (j - 1) / 2));
+    }
+    if (!__builtin_amdgcn_readfirstlane((int)df_accumulate(a, i, j, dyn_smem, s_word))) break;
+    if (i == j) {
+      __syncthreads();
+      df_diag(a, j);
+    } else {
+      if (t == 0) s_word[1] = df_wait(a, j, j, j, j + 1);   // prog[j] == j + 1: the diagonal tile of column j is final
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(s_word[1]) < 0) break;
+      df_solve(a, i, j, dyn_smem);
+    }
+    // the tile is final: every wave drains its stores, then lane 0 publishes row i's progress and takes the next task
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+      df_release_store(prog + i, j + 1);
+      s_word[0] = df_dequeue(a);
+    }
+  }
+}
+
+int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
+                         int* d_info, int n_wg, double timeout_s, hipStream_t s) {
+  if (n_pad % TILE || m_tot % TILE || n_pad <= 0 || m_tot < n_pad) {
+    set_error("chol_dataflow: sizes must be multiples of 128");
+    return -1;
+  }
+  if ((long)16 * ld + m_tot >= (1L << 31)) {   // panel_solve_strip's 32-bit lane offset
+    set_error("chol_dataflow: leading dimension too large");
+    return -1;
+  }
+  SGP_LDS_ATTR_ONCE(chol_dataflow_kernel, PD_LDS);
+  DfArgs a;
+  a.A = A;
+  a.ld = ld;
+  a.T_r = (int)(m_tot / TILE);
+  a.T_c = (int)(n_pad / TILE);
+  a.state = d_state;
+  a.invall = d_invall;
+  a.slots = d_slots;
+  a.info = d_info;
+  a.spin_ticks = (long long)(timeout_s * 1e8);
+  a.ntasks = (long)a.T_c * a.T_r - (long)a.T_c * (a.T_c - 1) / 2;
+  a.prio = 0;
+  SGP_HIP(hipMemsetAsync(d_state, 0, sizeof(int) * (8 + (size_t)a.T_r), s));
+  const long grid = std::min<long>(a.ntasks, n_wg);
+  hipLaunchKernelGGL(chol_dataflow_kernel, dim3((unsigned)grid), dim3(512), PD_LDS, s, a);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sgp

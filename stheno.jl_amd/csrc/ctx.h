@@ -65,6 +65,15 @@ struct sgp_ctx {
   double* d_scal = nullptr;    // [0] logdet, [1] misc, [16 ..] per-rhs sums
   long n_scal = 0;
   int* d_info = nullptr;
+  // dataflow (single-launch) factorisation, chol_df.hip: SGP_DATAFLOW = 0 never, 1 whenever it applies, unset: by size
+  int dataflow = -1;
+  long df_min_n = 0, df_max_n = 0;   // automatic mode: n_pad range it is used for (SGP_DF_MIN_N / SGP_DF_MAX_N)
+  int df_wgs = 0;                   // persistent workgroups (2 per CU)
+  double df_timeout_s = 10.0;       // bound of a single dependency wait inside the kernel
+  int* d_df_state = nullptr;        // task counter, abort word, per-tile-row progress (grown on demand)
+  long n_df_state = 0;
+  double* d_df_inv = nullptr;       // inverse diagonal blocks of every 128-block when the caller keeps none
+  long n_df_inv = 0;
   std::mutex mu;
   // optional per-launch timing of the trailing updates (roofline evidence for bench.py)
   bool time_updates = false;

@@ -66,7 +66,7 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
                                                  long ldc, long K, double alpha, double beta, long mask_off,
                                                  long n_tr, long n_tc, long c_slice_stride, const double* Cin,
                                                  long ldcin, int klo, double* smem, long& tr, long& tc,
-                                                 long long* dbg = nullptr) {
+                                                 long long* dbg = nullptr, long scr_mul = 0, long scr_mod = 0) {
   // STAMP (bench only, sgp_bench_gemm_stamps): s_memtime of thread 0 at the phase boundaries of the tile program
   long long st0 = 0, st1 = 0, st2 = 0, stA = 0;
   if (STAMP) st0 = (long long)__builtin_amdgcn_s_memtime();
@@ -86,7 +86,11 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
     B += sl * K * ldb;
     C += sl * c_slice_stride;
   } else {
-    if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return false;
+    // (STAMP only, experiment: ids dealt to the tiles through a multiplicative permutation -- neighbouring workgroups
+    // no longer share operand panels, which prices the L2 locality of the production order)
+    if (STAMP && scr_mod > 0) {
+      if (!tile_of_id(((long)blockIdx.x * (scr_mul < 0 ? -scr_mul : scr_mul)) % scr_mod, n_tr, n_tc, mask_off, tr, tc)) return false;
+    } else if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return false;
     // split-K (blockIdx.y > 0 only in launch_gemm_nt_splitk): slice s contracts columns
     // [s K, (s + 1) K) of A and B into its own slab of C
     A += (long)blockIdx.y * K * lda;
@@ -131,7 +135,11 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
   if (klo == 2 && (tr + 1) * (TILE / KB) < nchunks) nchunks = (tr + 1) * (TILE / KB);
   // prologue: the first operand chunk and the old C tile are requested together, so their
   // latencies overlap (one wait for both)
-  if (cbeg < nchunks) dma(cbeg * KB, 0);
+  // (STAMP + scramble: every workgroup starts its contraction at its own k offset and wraps around -- the workgroups of
+  // a launch no longer read the same k slice of the panels at the same time, the access pattern of desynchronised tiles)
+  const long rot = (STAMP && scr_mod > 0 && scr_mul < 0) ? (((long)blockIdx.x * 40503L) % nchunks) : 0;
+  auto kof = [&](long c) { return STAMP ? ((c + rot) % nchunks) * KB : c * KB; };
+  if (cbeg < nchunks) dma(kof(cbeg), 0);
   if (beta != 0.0) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -154,7 +162,7 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
   for (long c = cbeg; c < nchunks; ++c) {
     const int stage = (int)(c & 1);
     // the other stage was last read in iteration c-1, which every wave left through the barrier
-    if (c + 1 < nchunks) dma((c + 1) * KB, stage ^ 1);
+    if (c + 1 < nchunks) dma(kof(c + 1), stage ^ 1);
     const unsigned a_addr = lds_base + (unsigned)((stage * (2 * KB * LDS_LD) + lq * LDS_LD + wr * 64 + l15) * 8);
     const unsigned b_addr = lds_base + (unsigned)((stage * (2 * KB * LDS_LD) + KB * LDS_LD + lq * LDS_LD + wc * WCOLS + l3) * 8);
     {
@@ -283,20 +291,22 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
 
 // bench only: the production tile program with phase stamps (own symbol: the production kernels' code is untouched)
 __global__ __launch_bounds__(512, 4) void gemm_nt_dma_stamp_kernel(const double* A, long lda, double* C, long ldc, long K,
-                                                                   long n_tr, long n_tc, long long* dbg, double beta) {
+                                                                   long n_tr, long n_tc, long long* dbg, double beta,
+                                                                   long scr_mul, long scr_mod) {
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   long tr, tc;
-  gemm_nt_dma_tile<false, true>(A, lda, A, lda, C, ldc, K, -1.0, beta, 0L, n_tr, n_tc, 0L, C, ldc, 0, smem, tr, tc, dbg);
+  gemm_nt_dma_tile<false, true>(A, lda, A, lda, C, ldc, K, -1.0, beta, 0L, n_tr, n_tc, 0L, C, ldc, 0, smem, tr, tc, dbg,
+                                scr_mul, scr_mod);
 }
 
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
-                          long* n_ids, hipStream_t s, double beta) {
+                          long* n_ids, hipStream_t s, double beta, long scr_mul) {
   long n_tr = M / TILE, n_tc = Nc / TILE;
   long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1));
   *n_ids = per_xcd * 8;
   if (!dbg) return 0;
   hipLaunchKernelGGL(gemm_nt_dma_stamp_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, C, ldc, K, n_tr,
-                     n_tc, dbg, beta);
+                     n_tc, dbg, beta, scr_mul, scr_mul != 0 ? per_xcd * 8 : 0L);
   SGP_HIP(hipGetLastError());
   return 0;
 }

@@ -13,6 +13,7 @@
 // diagonal panel" in north-star terms.
 #include "common.h"
 #include "potrf_diag.h"   // potrf_diag_body: the diagonal-block factorisation itself
+#include "panel_solve.h"  // panel_solve_fill / panel_solve_strip: the 16-row blocked substitution (shared with chol_df.hip)
 #include <algorithm>
 #include <cstdlib>
 
@@ -105,24 +106,8 @@ __device__ __forceinline__ void panel_solve_body(TS* X, long ldx, const TS* L, l
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
-  {  // one wave per packed block of L11, four elements per lane: every load of a wave is independent
-    const int wu = __builtin_amdgcn_readfirstlane(w);
-    for (int blk = wu; blk < 36; blk += 4) {
-      int c, p;
-      block_rc(blk, c, p);
-      double v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int e = lane + 64 * q, k = e >> 4, m = e & 15;
-        v[q] = (double)L[(16 * c + m) + (long)(16 * p + k) * ldl];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sL[blk * 256 + lane + 64 * q] = v[q];
-    }
-  }
+  panel_solve_fill<TS, 4>(sL, L, ldl, __builtin_amdgcn_readfirstlane(w), lane);
   __syncthreads();
-  const int aoff = lq * 16 + l15;  // A operand of k-step ks: [k = 4 ks + lq][m = l15]
-  const int ioff = (int)(lq * inv_kstride + l15);
   // `strips` 64-row strips per workgroup: under the look-ahead overlap CU slots are the scarce
   // resource (they free up at the rate trailing-update workgroups retire), so a slot once taken
   // amortises its operand fill over several strips
@@ -134,35 +119,7 @@ __device__ __forceinline__ void panel_solve_body(TS* X, long ldx, const TS* L, l
     // uniform column base (scalar registers) + one 32-bit lane offset: keeps the 32 column
     // addresses out of the vector registers
     const int loff = (int)(row0 + w * 16 + l15 + lq * ldx);
-    d4 nb[8];  // nb[c][r] = -(B - sum X_p L_cp')[row l15][col 16 c + lq + 4 r]
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) nb[c][r] = -(double)(X + (long)(16 * c + 4 * r) * ldx)[loff];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const double* Lcc = sL + (c * (c + 1) / 2 + c) * 256 + aoff;
-      // inverse diagonal block: operand registers straight from global (16 KB in all, L1/L2-resident)
-      double icc[4];  // inv_c[m = l15][k = 4 ks + lq]
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) icc[ks] = (inv + c * inv_cstride + ks * 4 * inv_kstride)[ioff];
-      d4 nx1 = (d4){0.0, 0.0, 0.0, 0.0};  // -(T inv(L_cc)')
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) nx1 = mfma_f64(icc[ks], nb[c][ks], nx1);
-      d4 rr = -nb[c];  // T - X1 L_cc'
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) rr = mfma_f64(Lcc[ks * 64], nx1[ks], rr);
-      d4 x = -nx1;  // X1 + R inv(L_cc)'
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) x = mfma_f64(icc[ks], rr[ks], x);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) (X + (long)(16 * c + 4 * r) * ldx)[loff] = (TS)x[r];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-        for (int c2 = c + 1; c2 < 8; ++c2)
-          nb[c2] = mfma_f64(sL[(c2 * (c2 + 1) / 2 + c) * 256 + aoff + ks * 64], x[ks], nb[c2]);
-    }
+    panel_solve_strip<TS>(X, ldx, loff, sL, inv, inv_cstride, inv_kstride, lane);
   }
 }
 

@@ -24,9 +24,11 @@ d = buf.reshape(-1, 8)
 d = d[d[:, 0] > 0]
 t0 = d[:, 0].min()
 ent, land, done, drained = (d[:, i] - t0 for i in range(4))
-span = drained.max() - ent.min()
 # s_memtime rate: calibrate against the known MFMA time of the contraction is circular; report ticks and ratios
 pro, body, epi = land - ent, done - land, drained - done
+mode = ("  [tiles dealt at random" + (", k offset per workgroup" if os.environ.get("SGP_STAMP_ROTATE") else "") + "]") \
+    if os.environ.get("SGP_STAMP_SCRAMBLE") else ""
+print(f"launch span (first entry -> last store drained): {int(d[:, 3].max() - d[:, 0].min())} ticks{mode}")
 tmap = d[:, 7] - d[:, 0]
 print(f"  id -> tile mapping (tile_of_id)                      mean {tmap.mean():9.0f}  p50 {np.percentile(tmap, 50):9.0f}  p90 {np.percentile(tmap, 90):9.0f}")
 print(f"lower {m}^2 K={k}: {len(d)} tiles (s_memtime ticks = shader-clock cycles)")
