@@ -389,7 +389,14 @@ def main():
         step(timings)
         upd_ms, n_launch, upd_flops = timings[3], int(timings[4]), timings[5]
         achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
-        if n_launch == 0:
+        schedule = ctx.factor_schedule(N)
+        dataflow = schedule.startswith("dataflow")
+        if dataflow:
+            # one launch of persistent workgroups does the whole factorisation (chol_df.hip): the dominant kernel IS the
+            # Cholesky stage; its algorithmic flops are the factorisation's N^3 / 3 (+ the bordered row)
+            upd_ms, n_launch, upd_flops = timings[1], 1, N ** 3 / 3.0 + 1.0 * N * N
+            achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
+        elif n_launch == 0:
             # N <= 4096 is factored as ONE outer panel (no outer trailing update): the step is the latency
             # chain panel_solve -> K = 128 update with the next diagonal block's potrf_diag fused in, per 128
             # columns; report the whole step
@@ -397,7 +404,14 @@ def main():
         n_pad = (N + 127) // 128 * 128
         fused = n_pad < 32768     # capi.hip: fuse_mode -- the look-ahead column updates carry the next diagonal block
         serial = n_pad >= 65536   # capi.hip: chol_bordered -- no look-ahead from 65536 columns on, every update launch fused
-        if serial:
+        if dataflow:
+            kname = ("sgp::chol_dataflow_fat_kernel" if schedule == "dataflow-fat" else "sgp::chol_dataflow_kernel") + (
+                " (the whole blocked Cholesky in one launch of persistent workgroups: 128 x 128 tile tasks in topological "
+                "order, contraction = the v_mfma_f64_4x4x4_4b tile program of sgp::gemm_nt_dma_kernel, diagonal tiles through "
+                "potrf_diag_body, off-diagonal tiles through the refined 16-row substitution; tile-row progress counters with "
+                "agent-scope release / acquire instead of kernel boundaries" +
+                ("; one workgroup per CU, 256 VGPRs)" if schedule == "dataflow-fat" else "; two workgroups per CU)"))
+        elif serial:
             kname = ("sgp::gemm_nt_dma_potrf_kernel<1, true> (fp64 MFMA trailing update of the blocked Cholesky, "
                      "v_mfma_f64_4x4x4_4b_f64: the tile program of sgp::gemm_nt_dma_kernel, whose tile (0, 0) workgroup goes on "
                      "to factor the next diagonal block; serial schedule: outer panels of 4096 columns, one K = 4096 launch per "
@@ -413,7 +427,10 @@ def main():
             "frac": achieved / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
             "note": ("single outer panel: no trailing-update launches; achieved = whole-step N^3/3 rate, latency-bound on the "
                      "chain sgp::panel_solve_kernel (14 us) -> sgp::gemm_nt_dma_potrf_kernel<0, true> (K = 128 tile update + "
-                     "potrf_diag of the next diagonal block, 50 us) per 128 columns") if n_launch == 0 else None,
+                     "potrf_diag of the next diagonal block, 50 us) per 128 columns") if n_launch == 0 else
+                    ("achieved = (N^3 / 3 + N^2) flops / the Cholesky stage (HIP events around the one launch); SGP_DF_STATS=1 "
+                     "prints the per-workgroup time split and the per-column chain (profiles/r03_dataflow.md)") if dataflow else None,
+            "schedule": schedule,
             "launches": n_launch, "avg_launch_ms": upd_ms / max(1, n_launch),
             "algorithmic_flops_per_launch_avg": upd_flops / max(1, n_launch),
             # The look-ahead keeps update launches of two streams (and the panel kernels) on the chip at
@@ -435,11 +452,12 @@ def main():
             # a record only counts for the schedule it was collected under (serial-deep = today's default from 65536
             # columns on: outer panels of 4096 columns, recursive halving inside)
             rec_serial = rec.get("schedule", "").startswith("serial-deep")
-            if rec_serial == serial:
+            if rec_serial == serial and not dataflow:
                 roofline["traffic"] = rec["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = dict(rec, file="profiles/" + tr_name)
                 break
-        roofline["algorithmic_bytes_per_launch_avg"] = update_bytes_avg(N)
+        roofline["algorithmic_bytes_per_launch_avg"] = (8.0 * N * (N + 1) if dataflow else update_bytes_avg(N))   # dataflow: the
+        # lower triangle read once and written once
         for pmc_name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
             if os.path.exists(pmc):

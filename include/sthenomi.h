@@ -117,6 +117,10 @@ int sgp_ctx_create(int device, sgp_ctx** out);
 int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out);
 int sgp_ctx_ndev(sgp_ctx* ctx);
 const char* sgp_ctx_transport(sgp_ctx* ctx);
+/* Which schedule the blocked Cholesky of an N-point covariance runs on this context (bench / diagnosis): "dataflow-fat" |
+ * "dataflow" (one launch of persistent workgroups, chol_df.hip) | "launches-one-panel" | "launches-lookahead" |
+ * "launches-serial" | "launches-serial-deep" (capi.hip: chol_bordered).  Every schedule gives the same bits. */
+const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N);
 /* Figures of the last sharded factorisation of a multi-GPU context: out[0] ranks, [1] wall ms (enqueue to
  * completion), [2] transport (0 loopback, 1 peer copies, 2 RCCL), [3] ranks the RCCL communicator reports (-1: none),
  * [4] panel width, [5] panels, [6] 1 = scatter + all-gather peer copies, [7] reserved; then per rank 4 doubles:

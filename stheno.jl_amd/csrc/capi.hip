@@ -200,6 +200,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (dfa) c->df_min_n = atol(dfa);
     const char* dfb = getenv("SGP_DF_MAX_N");
     if (dfb) c->df_max_n = atol(dfb);
+    const char* dff = getenv("SGP_DF_FAT_MAX_N");
+    if (dff) c->df_fat_max_n = atol(dff);
     const char* dft = getenv("SGP_DF_TIMEOUT_S");
     if (dft) c->df_timeout_s = atof(dft);
     {
@@ -245,6 +247,7 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->d_info) hipFree(c->d_info);
   if (c->d_df_state) hipFree(c->d_df_state);
   if (c->d_df_inv) hipFree(c->d_df_inv);
+  if (c->d_df_stats) hipFree(c->d_df_stats);
   if (c->ev_panel) hipEventDestroy(c->ev_panel);
   if (c->ev_rest) hipEventDestroy(c->ev_rest);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -640,6 +643,29 @@ static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, lo
                           d_invstore ? d_invstore + (c / TILE) * INVD_STRIDE : nullptr, s, fuse_mid, wmid);
 }
 
+// Which schedule factors n_pad columns (measured on MI355X, profiles/r03_dataflow.md; Matern-5/2, D = 8, whole logpdf):
+//   n_pad <  3072            launches (one outer panel; the dataflow chain of 68 us per 128 columns loses to the fused
+//                            launches' 62: N = 2048 1.18 vs 1.25 ms)
+//   3072 <= n_pad < 24576    dataflow, one workgroup per CU (256 VGPRs: no spills in the chain tasks, and a chain task never
+//                            shares its CU with a contraction): N = 4096 2.51 -> 2.41 ms, 8192 7.7 -> 5.1, 16384 32.7 -> 27.8
+//   24576 <= n_pad < 65536   dataflow, two workgroups per CU (the contractions are the work): 32768 218.7 -> 204.8 ms
+//   n_pad >= 65536           launches, serial schedule with deep outer blocking: the lock-step trailing updates share
+//                            every operand k slice through L2, the desynchronised contractions of the dataflow kernel
+//                            stream theirs from HBM and the clock pays for it (-11 %, profiles/r03_experiments/)
+// SGP_DATAFLOW = 0 / 1 forces never / always; SGP_DF_MIN_N, SGP_DF_MAX_N, SGP_DF_FAT_MAX_N move the limits.
+static bool use_dataflow(const sgp_ctx* ctx, long n_pad) {
+  if (ctx->refine != 1 || ctx->dataflow == 0) return false;
+  return ctx->dataflow == 1 || (n_pad >= ctx->df_min_n && n_pad < ctx->df_max_n);
+}
+extern "C" const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N) {
+  if (!ctx || N < 1) return "";
+  const long n_pad = rup(N, TILE);
+  if (use_dataflow(ctx, n_pad)) return n_pad < ctx->df_fat_max_n ? "dataflow-fat" : "dataflow";
+  const bool la = ctx->lookahead && (n_pad < ctx->la_max_n || ctx->lookahead == 2);
+  if (la) return n_pad <= 4096 && ctx->wout <= 0 ? "launches-one-panel" : "launches-lookahead";
+  return n_pad >= 65536 ? "launches-serial-deep" : "launches-serial";
+}
+
 // Two-level right-looking Cholesky of the bordered matrix with one-panel look-ahead:
 // the outer panel J+1 is updated and factored on the (high-priority) panel stream while the
 // rest of the trailing matrix is still being updated with panel J on the update stream.
@@ -652,9 +678,8 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // Dataflow factorisation (chol_df.hip): one launch of persistent workgroups, tile-level dependencies instead of
   // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
   // upper-triangular border, `grow`: its tasks would have to skip the structurally zero tiles.)
-  const bool df_auto = n_pad >= ctx->df_min_n && n_pad < ctx->df_max_n;
-  if (grow == 0 && ctx->refine == 1 && (ctx->dataflow == 1 || (ctx->dataflow < 0 && df_auto))) {
-    const long need_state = 8 + m_tot / TILE, need_inv = (n_pad / TILE) * INVD_STRIDE;
+  if (grow == 0 && use_dataflow(ctx, n_pad)) {
+    const long need_state = SGP_DF_STATE_WORDS + m_tot / TILE, need_inv = (n_pad / TILE) * INVD_STRIDE;
     if (need_state > ctx->n_df_state) {
       SGP_HIP(hipStreamSynchronize(s));
       if (ctx->d_df_state) hipFree(ctx->d_df_state);
@@ -671,8 +696,73 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       SGP_HIP(hipMalloc(&ctx->d_df_inv, sizeof(double) * need_inv));
       ctx->n_df_inv = need_inv;
     }
-    return launch_chol_dataflow(A, ld, n_pad, m_tot, ctx->d_df_state, d_wall ? d_wall : ctx->d_df_inv, ctx->d_slots,
-                                ctx->d_info, ctx->df_wgs, ctx->df_timeout_s, s);
+    const int fat = n_pad < ctx->df_fat_max_n ? 1 : 0;
+    if (getenv("SGP_DF_STATS") && !ctx->d_df_stats)   // + 8 stamps for each of up to 4096 tile columns
+      SGP_HIP(hipMalloc(&ctx->d_df_stats, sizeof(long long) * 8 * ((size_t)ctx->df_wgs + 4096)));
+    long long* d_cols = ctx->d_df_stats && n_pad / TILE <= 4096 ? ctx->d_df_stats + 8 * (size_t)ctx->df_wgs : nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->d_df_stats) {
+      SGP_HIP(hipEventCreate(&e0));
+      SGP_HIP(hipEventCreate(&e1));
+      SGP_HIP(hipEventRecord(e0, s));
+    }
+    CHECK_RC(launch_chol_dataflow(A, ld, n_pad, m_tot, ctx->d_df_state, d_wall ? d_wall : ctx->d_df_inv, ctx->d_slots,
+                                  ctx->d_info, ctx->df_wgs, ctx->df_timeout_s, s, ctx->d_df_stats, d_cols, fat));
+    if (ctx->d_df_stats) {   // diagnosis only: drains the stream
+      hipEventRecord(e1, s);
+      hipStreamSynchronize(s);
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      hipEventDestroy(e0);
+      hipEventDestroy(e1);
+      std::vector<long long> h((size_t)8 * ctx->df_wgs);
+      SGP_HIP(hipMemcpy(h.data(), ctx->d_df_stats, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+      double sum[8] = {0};
+      long nw = 0;
+      for (int w = 0; w < ctx->df_wgs; ++w) {
+        if (h[(size_t)8 * w + 1] == 0) continue;
+        ++nw;
+        for (int q = 0; q < 8; ++q) sum[q] += (double)h[(size_t)8 * w + q];
+      }
+      const double us = 0.01 / (double)std::max<long>(nw, 1);   // ticks (100 MHz) -> us, averaged over the workgroups
+      fprintf(stderr,
+              "dataflow n_pad=%ld m_tot=%ld: %.3f ms, %ld workgroups, %.0f tasks; per workgroup (us): in kernel %.1f | "
+              "contraction %.1f (of which waiting %.1f) | wait diag %.1f | potrf %.1f | solve %.1f | publish+dequeue %.1f\n",
+              n_pad, m_tot, ms, nw, sum[0], sum[1] * us, sum[2] * us, sum[7] * us, sum[3] * us, sum[4] * us, sum[5] * us,
+              sum[6] * us);
+      if (d_cols && n_pad / TILE >= 3) {
+        const long T = n_pad / TILE;
+        std::vector<long long> c((size_t)8 * T);
+        SGP_HIP(hipMemcpy(c.data(), d_cols, sizeof(long long) * c.size(), hipMemcpyDeviceToHost));
+        // the chain, column j -> j + 1 (averages over the columns, us): diagonal tile published [4] -> the task below
+        // sees it [5] -> solved [6] -> published [7] -> next diagonal task sees it [1'] -> last k block done [2'] ->
+        // factored [3'] -> published [4']
+        double seg[7] = {0};
+        long cnt = 0;
+        for (long j = 1; j + 2 < T; ++j) {
+          const long long* a0 = &c[(size_t)8 * j];
+          const long long* a1 = &c[(size_t)8 * (j + 1)];
+          if (!a0[4] || !a0[5] || !a0[6] || !a0[7] || !a1[1] || !a1[2] || !a1[3] || !a1[4]) continue;
+          seg[0] += (double)(a0[5] - a0[4]);
+          seg[1] += (double)(a0[6] - a0[5]);
+          seg[2] += (double)(a0[7] - a0[6]);
+          seg[3] += (double)(a1[1] - a0[7]);
+          seg[4] += (double)(a1[2] - a1[1]);
+          seg[5] += (double)(a1[3] - a1[2]);
+          seg[6] += (double)(a1[4] - a1[3]);
+          ++cnt;
+        }
+        if (cnt) {
+          const double u = 0.01 / (double)cnt;
+          fprintf(stderr,
+                  "  chain per column (us, %ld columns): diag published -> seen below %.1f | solve %.1f | publish %.1f | -> "
+                  "seen by next diag %.1f | last k block %.1f | potrf %.1f | publish %.1f | sum %.1f\n",
+                  cnt, seg[0] * u, seg[1] * u, seg[2] * u, seg[3] * u, seg[4] * u, seg[5] * u, seg[6] * u,
+                  (seg[0] + seg[1] + seg[2] + seg[3] + seg[4] + seg[5] + seg[6]) * u);
+        }
+      }
+    }
+    return 0;
   }
   // outer panel width, measured (profiles/r02_summary.md): one panel for n_pad <= 4096 (the outer level only
   // adds launches there: 1.52 -> 1.30 ms at N = 2048; with the fused diagonal blocks 2.73 -> 2.47 ms at N = 4096),

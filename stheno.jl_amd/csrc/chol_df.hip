@@ -28,24 +28,30 @@
 #include "common.h"
 #include "potrf_diag.h"
 #include "panel_solve.h"
+#include <vector>
 
 namespace sgp {
 
 constexpr int DF_KB = 16;                       // K chunk per LDS stage (as gemm_nt.hip)
 constexpr int DF_STAGE = 2 * DF_KB * LDS_LD;    // doubles per stage: A chunk + B chunk
+constexpr int DF_PROG = 8;                      // offset of the tile-row progress counters in the state words
 
 struct DfArgs {
   double* A;        // m_tot x n_pad, column-major, lower tiles + bordered rows
   long ld;
   int T_r, T_c;     // tile rows (m_tot / 128), tile columns (n_pad / 128)
-  int* state;       // [0] next task id, [1] abort, [8 + i] prog[i]; zeroed before every launch
+  int* state;       // [0] next task id, [1] abort, [DF_PROG + i] prog[i]; zeroed before every launch
   double* invall;   // T_c x INVD (2048 doubles): inverse 16x16 diagonal blocks of every 128-block
   double* slots;    // T_c logdet contributions
   int* info;
   long long spin_ticks;   // wall_clock64 ticks (100 MHz) a single wait may last
   long ntasks;
   int prio;
+  long long* stats;   // optional (SGP_DF_STATS): 8 tick counters per workgroup, see launch_chol_dataflow
+  long long* cols;    // optional: 8 wall-clock stamps per tile column (the chain: diagonal task + the task below it)
 };
+
+#define DF_RLX_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 template <int KS>
 __device__ __forceinline__ void df_kstep(double (&acc)[8][4], unsigned a_addr, unsigned b_addr) {
@@ -106,11 +112,10 @@ __device__ __forceinline__ void df_contract(const double* Ag, const double* Bg, 
   }
 }
 
-#define DF_RLX_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
 // thread 0: wait until min(prog[i], prog[j]) > have (returns min(.., cap)), or -1 on abort / timeout
 __device__ __forceinline__ int df_wait(const DfArgs& a, int i, int j, int have, int cap) {
-  int* prog = a.state + 8;
+  int* prog = a.state + DF_PROG;
   const long long t0 = wall_clock64();
   int avail;
   for (unsigned spins = 0;; ++spins) {
@@ -150,7 +155,7 @@ __device__ __forceinline__ int df_dequeue(const DfArgs& a) {
 
 // Phase 1: acc = -A_ij + sum_k L_ik L_jk' as the operand rows become final.  Diagonal tile: the result goes into
 // potrf_diag_body's packed LDS layout; off-diagonal: T = -acc is stored in place.  Returns false on abort.
-__device__ __attribute__((noinline)) bool df_accumulate(const DfArgs& a, int i, int j, double* smem, int* s_word) {
+__device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j, double* smem, int* s_word) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w = t >> 6;
@@ -175,13 +180,23 @@ __device__ __attribute__((noinline)) bool df_accumulate(const DfArgs& a, int i, 
     for (int ii = 0; ii < 4; ++ii) acc[jj][ii] *= -1.0;
   int kdone = 0;
   while (kdone < j) {
-    if (t == 0) s_word[1] = df_wait(a, i, j, kdone, j);
+    if (t == 0) {
+      const long long w0 = a.stats ? wall_clock64() : 0;
+      s_word[1] = df_wait(a, i, j, kdone, j);
+      if (a.stats) {
+        const long long tot = ((long long)(unsigned)s_word[2] | ((long long)s_word[3] << 32)) + (wall_clock64() - w0);
+        s_word[2] = (int)(unsigned)tot;
+        s_word[3] = (int)(tot >> 32);
+      }
+    }
     __syncthreads();
     const int avail = __builtin_amdgcn_readfirstlane(s_word[1]);   // wave-uniform for the compiler too
     if (avail < 0) return false;
+    if (a.cols && t == 0 && i == j && avail == j) a.cols[(long)j * 8 + 1] = wall_clock64();
     df_contract(Ag, Bg, ld, (long)kdone * (TILE / DF_KB), (long)avail * (TILE / DF_KB), acc, smem, wu, lane, a_off, b_off);
     kdone = avail;
   }
+  if (a.cols && t == 0 && i == j) a.cols[(long)j * 8 + 2] = wall_clock64();
   if (i == j) {
     // accumulators -> potrf_diag_body's packed LDS layout (as gemm_nt_dma_tile<HANDOFF>)
 #pragma unroll
@@ -202,13 +217,13 @@ __device__ __attribute__((noinline)) bool df_accumulate(const DfArgs& a, int i, 
 }
 
 // Phase 2a: Cholesky of the diagonal tile sitting in LDS
-__device__ __attribute__((noinline)) void df_diag(const DfArgs& a, int j) {
+__device__ __forceinline__ void df_diag_body(const DfArgs& a, int j) {
   potrf_diag_body<false, double, true>(a.A + (long)j * TILE + (long)j * TILE * a.ld, a.ld, a.invall + (long)j * 2048,
-                                       a.slots + j, a.info, (long)j * TILE, a.prio, nullptr);
+                                       a.slots + j, a.info, (long)j * TILE, 0, nullptr);
 }
 
 // Phase 2b: L_ij = T inv(L_jj)' for the tile's 128 rows, eight waves x 16 rows
-__device__ __attribute__((noinline)) void df_solve(const DfArgs& a, int i, int j, double* smem) {
+__device__ __forceinline__ void df_solve_body(const DfArgs& a, int i, int j, double* smem) {
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -221,12 +236,53 @@ __device__ __attribute__((noinline)) void df_solve(const DfArgs& a, int i, int j
   panel_solve_strip<double>(X, ld, loff, smem, a.invall + (long)j * 2048, 256, 16, lane);
 }
 
-__global__ __launch_bounds__(512, 4) void chol_dataflow_kernel(DfArgs a) {
+// LEAN (two workgroups per CU, 128 VGPRs -- the sizes where the trailing contractions are the work): the phases are
+// separate functions.  FAT (one workgroup per CU, 256 VGPRs -- the sizes where the diagonal chain is the critical path and
+// occupancy buys nothing): everything inline, no spills in the substitution (228 VGPRs) or the diagonal-block routine.
+__device__ __attribute__((noinline)) bool df_accumulate_lean(const DfArgs& a, int i, int j, double* smem, int* s_word) {
+  return df_accumulate_body(a, i, j, smem, s_word);
+}
+__device__ __attribute__((noinline)) void df_diag_lean(const DfArgs& a, int j) { df_diag_body(a, j); }
+__device__ __attribute__((noinline)) void df_solve_lean(const DfArgs& a, int i, int j, double* smem) {
+  df_solve_body(a, i, j, smem);
+}
+#define DF_FAT_FN __device__ __attribute__((noinline))
+DF_FAT_FN bool df_accumulate_fat(const DfArgs& a, int i, int j, double* smem, int* s_word) {
+  return df_accumulate_body(a, i, j, smem, s_word);
+}
+DF_FAT_FN void df_diag_fat(const DfArgs& a, int j) { df_diag_body(a, j); }
+DF_FAT_FN void df_solve_fat(const DfArgs& a, int i, int j, double* smem) { df_solve_body(a, i, j, smem); }
+template <bool FAT>
+__device__ __forceinline__ bool df_accumulate(const DfArgs& a, int i, int j, double* smem, int* s_word) {
+  if (FAT) return df_accumulate_fat(a, i, j, smem, s_word);
+  return df_accumulate_lean(a, i, j, smem, s_word);
+}
+template <bool FAT>
+__device__ __forceinline__ void df_diag(const DfArgs& a, int j) {
+  if (FAT) df_diag_fat(a, j);
+  else df_diag_lean(a, j);
+}
+template <bool FAT>
+__device__ __forceinline__ void df_solve(const DfArgs& a, int i, int j, double* smem) {
+  if (FAT) df_solve_fat(a, i, j, smem);
+  else df_solve_lean(a, i, j, smem);
+}
+
+template <bool FAT>
+__device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
-  __shared__ int s_word[4];   // [0] task id, [1] available k blocks / abort
+  __shared__ int s_word[4];   // [0] task id, [1] available k blocks / abort, [2..3] wait ticks (statistics)
   const int t = threadIdx.x;
-  int* prog = a.state + 8;
-  if (t == 0) s_word[0] = df_dequeue(a);
+  int* prog = a.state + DF_PROG;
+  // optional per-workgroup time accounting (lane 0, 100 MHz wall clock): [0] tasks [1] kernel [2] contraction incl. its
+  // waits [3] wait for the diagonal tile [4] potrf [5] solve [6] publish + dequeue [7] of [2]: waiting
+  long long tk0 = 0, tk = 0, acc_c = 0, acc_w = 0, acc_p = 0, acc_s = 0, acc_q = 0, ntask = 0;
+  const bool st = a.stats != nullptr && t == 0;
+  if (st) tk0 = wall_clock64();
+  if (t == 0) {
+    s_word[0] = df_dequeue(a);
+    s_word[2] = s_word[3] = 0;
+  }
   // One lane-0 section per iteration (publish the finished tile AND take the next task), followed by the barrier at the
   // top: with a separate lane-0 `dequeue` at the top and lane-0 `publish` at the bottom the compiler threaded lane 0
   // from one straight into the other across the back edge, and the structurizer then ran lanes 1..63 of wave 0 into
@@ -236,9 +292,9 @@ __global__ __launch_bounds__(512, 4) void chol_dataflow_kernel(DfArgs a) {
     __syncthreads();   // s_word[0] is set; the previous task's LDS phases are over for every wave
     const int q = __builtin_amdgcn_readfirstlane(s_word[0]);
     if (q < 0) break;
-    // column-major task order: column j holds the T_r - j tasks (j, j), (j + 1, j), ..., (T_r - 1, j)
     int j, i;
     {
+      // column-major task order: column j holds the T_r - j tasks (j, j), (j + 1, j), ..., (T_r - 1, j)
       const double b = 2.0 * a.T_r + 1.0;
       j = (int)((b - sqrt(b * b - 8.0 * (double)q)) * 0.5);
       if (j < 0) j = 0;
@@ -247,16 +303,47 @@ __global__ __launch_bounds__(512, 4) void chol_dataflow_kernel(DfArgs a) {
       while (j + 1 < a.T_c && (long)(j + 1) * a.T_r - (long)(j + 1) * j / 2 <= q) ++j;
       i = j + (int)(q - ((long)j * a.T_r - (long)j * (j - 1) / 2));
     }
-    if (!__builtin_amdgcn_readfirstlane((int)df_accumulate(a, i, j, dyn_smem, s_word))) break;
+    // the chain tasks run at raised wave priority: beside a contraction's back-to-back MFMAs the pivot chain of the
+    // diagonal block and the substitution otherwise wait for issue slots (potrf 35 -> 100 us at N = 16384)
+    const bool chain = (i == j || i == j + 1);
+    if (chain) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(0);
+    if (st) tk = wall_clock64();
+    if (st && a.cols && i == j) a.cols[(long)j * 8 + 0] = tk;
+    if (!__builtin_amdgcn_readfirstlane((int)df_accumulate<FAT>(a, i, j, dyn_smem, s_word))) break;
+    if (st) {
+      const long long n = wall_clock64();
+      acc_c += n - tk;
+      tk = n;
+      ++ntask;
+    }
     if (i == j) {
       __syncthreads();
-      df_diag(a, j);
+      df_diag<FAT>(a, j);
+      if (st) {
+        const long long n = wall_clock64();
+        acc_p += n - tk;
+        tk = n;
+        if (a.cols) a.cols[(long)j * 8 + 3] = n;
+      }
     } else {
       if (t == 0) s_word[1] = df_wait(a, j, j, j, j + 1);   // prog[j] == j + 1: the diagonal tile of column j is final
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (__builtin_amdgcn_readfirstlane(s_word[1]) < 0) break;
-      df_solve(a, i, j, dyn_smem);
+      if (st) {
+        const long long n = wall_clock64();
+        acc_w += n - tk;
+        tk = n;
+        if (a.cols && i == j + 1) a.cols[(long)j * 8 + 5] = n;
+      }
+      df_solve<FAT>(a, i, j, dyn_smem);
+      if (st) {
+        const long long n = wall_clock64();
+        acc_s += n - tk;
+        tk = n;
+        if (a.cols && i == j + 1) a.cols[(long)j * 8 + 6] = n;
+      }
     }
     // the tile is final: every wave drains its stores, then lane 0 publishes row i's progress and takes the next task
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -265,11 +352,32 @@ __global__ __launch_bounds__(512, 4) void chol_dataflow_kernel(DfArgs a) {
       df_release_store(prog + i, j + 1);
       s_word[0] = df_dequeue(a);
     }
+    if (st) {
+      const long long n = wall_clock64();
+      acc_q += n - tk;
+      if (a.cols && i == j) a.cols[(long)j * 8 + 4] = n;
+      if (a.cols && i == j + 1) a.cols[(long)j * 8 + 7] = n;
+    }
+  }
+  if (st) {
+    long long* d = a.stats + (long)blockIdx.x * 8;
+    d[0] = ntask;
+    d[1] = wall_clock64() - tk0;
+    d[2] = acc_c;
+    d[3] = acc_w;
+    d[4] = acc_p;
+    d[5] = acc_s;
+    d[6] = acc_q;
+    d[7] = (long long)(unsigned)s_word[2] | ((long long)s_word[3] << 32);   // ticks spent polling inside the contraction
   }
 }
 
+__global__ __launch_bounds__(512, 4) void chol_dataflow_kernel(DfArgs a) { chol_dataflow_body<false>(a); }
+__global__ __launch_bounds__(512, 2) void chol_dataflow_fat_kernel(DfArgs a) { chol_dataflow_body<true>(a); }
+
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
-                         int* d_info, int n_wg, double timeout_s, hipStream_t s) {
+                         int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats, long long* d_cols,
+                         int fat) {
   if (n_pad % TILE || m_tot % TILE || n_pad <= 0 || m_tot < n_pad) {
     set_error("chol_dataflow: sizes must be multiples of 128");
     return -1;
@@ -279,6 +387,7 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
     return -1;
   }
   SGP_LDS_ATTR_ONCE(chol_dataflow_kernel, PD_LDS);
+  SGP_LDS_ATTR_ONCE(chol_dataflow_fat_kernel, PD_LDS);
   DfArgs a;
   a.A = A;
   a.ld = ld;
@@ -291,9 +400,14 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
   a.spin_ticks = (long long)(timeout_s * 1e8);
   a.ntasks = (long)a.T_c * a.T_r - (long)a.T_c * (a.T_c - 1) / 2;
   a.prio = 0;
-  SGP_HIP(hipMemsetAsync(d_state, 0, sizeof(int) * (8 + (size_t)a.T_r), s));
+  a.stats = d_stats;
+  a.cols = d_stats ? d_cols : nullptr;
+  SGP_HIP(hipMemsetAsync(d_state, 0, sizeof(int) * (DF_PROG + (size_t)a.T_r), s));
   const long grid = std::min<long>(a.ntasks, n_wg);
-  hipLaunchKernelGGL(chol_dataflow_kernel, dim3((unsigned)grid), dim3(512), PD_LDS, s, a);
+  if (fat)
+    hipLaunchKernelGGL(chol_dataflow_fat_kernel, dim3((unsigned)grid), dim3(512), PD_LDS, s, a);
+  else
+    hipLaunchKernelGGL(chol_dataflow_kernel, dim3((unsigned)grid), dim3(512), PD_LDS, s, a);
   SGP_HIP(hipGetLastError());
   return 0;
 }

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <atomic>
 #include <string>
+#include <vector>
 
 namespace sgp {
 
@@ -140,10 +141,12 @@ int launch_gemm_nt_potrf(const double* P, long ldp, double* C, long ldc, long M,
                          int handoff, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
                          hipStream_t s);
 // chol_df.hip: the whole bordered factorisation (lower tiles of the n_pad columns + rows n_pad .. m_tot) in one launch of
-// persistent workgroups; d_state: 8 + m_tot / 128 ints, d_invall: n_pad / 128 x 2048 doubles
+// persistent workgroups; d_state: SGP_DF_STATE_WORDS + m_tot / 128 ints, d_invall: n_pad / 128 x 2048 doubles
 constexpr int SGP_DF_TIMEOUT = -77;   // *info when a dependency wait inside the kernel ran into its bound
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
-                         int* d_info, int n_wg, double timeout_s, hipStream_t s);
+                         int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats = nullptr,
+                         long long* d_cols = nullptr, int fat = 0);
+constexpr long SGP_DF_STATE_WORDS = 8;   // state words ahead of the per-tile-row progress counters
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
                           long* n_ids, hipStream_t s, double beta = 1.0, long scr_mul = 0);   // bench: per-workgroup phase stamps of one lower update
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,

@@ -67,11 +67,13 @@ struct sgp_ctx {
   int* d_info = nullptr;
   // dataflow (single-launch) factorisation, chol_df.hip: SGP_DATAFLOW = 0 never, 1 whenever it applies, unset: by size
   int dataflow = -1;
-  long df_min_n = 0, df_max_n = 0;   // automatic mode: n_pad range it is used for (SGP_DF_MIN_N / SGP_DF_MAX_N)
+  long df_min_n = 3072, df_max_n = 65536;   // automatic mode: n_pad range it is used for (SGP_DF_MIN_N / SGP_DF_MAX_N)
   int df_wgs = 0;                   // persistent workgroups (2 per CU)
   double df_timeout_s = 10.0;       // bound of a single dependency wait inside the kernel
   int* d_df_state = nullptr;        // task counter, abort word, per-tile-row progress (grown on demand)
   long n_df_state = 0;
+  long df_fat_max_n = 24576;        // SGP_DF_FAT_MAX_N: below this the one-workgroup-per-CU (256 VGPR) instantiation
+  long long* d_df_stats = nullptr;  // SGP_DF_STATS=1: per-workgroup tick counters, summarised on stderr after every launch
   double* d_df_inv = nullptr;       // inverse diagonal blocks of every 128-block when the caller keeps none
   long n_df_inv = 0;
   std::mutex mu;

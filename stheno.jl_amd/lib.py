@@ -63,6 +63,7 @@ _SIGS = {
     "sgp_ctx_create_multi": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(_P)]),
     "sgp_ctx_ndev": (C.c_int, [_P]),
     "sgp_ctx_transport": (C.c_char_p, [_P]),
+    "sgp_ctx_factor_schedule": (C.c_char_p, [_P, C.c_int64]),
     "sgp_ctx_multi_stats": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_ctx_multi_profile": (C.c_int, [_P, C.c_int]),
     "sgp_ctx_multi_profile_get": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
@@ -214,6 +215,10 @@ class Context:
     @property
     def transport(self):
         return self.lib.sgp_ctx_transport(self.handle).decode()
+
+    def factor_schedule(self, N):
+        """Which schedule the blocked Cholesky of an N-point covariance runs on this context."""
+        return self.lib.sgp_ctx_factor_schedule(self.handle, int(N)).decode()
 
     def close(self):
         if getattr(self, "handle", None):

@@ -16,13 +16,16 @@ from test_gpu_fused_potrf import _ctx, _operators, _with_ctx
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("fat", [0, 1])
 @pytest.mark.parametrize("N", [130, 700, 4500])
-def test_dataflow_is_bit_identical_to_the_launch_based_factorisation(monkeypatch, N):
+def test_dataflow_is_bit_identical_to_the_launch_based_factorisation(monkeypatch, N, fat):
+    # fat = 1: the one-workgroup-per-CU instantiation (256 VGPRs, chol_dataflow_fat_kernel), 0: two per CU
     ref_ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0)
     ref, (xs, y) = _with_ctx(ref_ctx, lambda: _operators(N))
     want = orm.gppp_sum_logpdf(xs, y, 0.1)
     assert abs(ref["logpdf"][0] - want) <= 1e-10 * abs(want)
-    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=1)
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_FAT_MAX_N=(1 << 30) if fat else 0)
+    assert ctx.factor_schedule(N) == ("dataflow-fat" if fat else "dataflow")
     for rep in range(2):   # second pass: every cache warm with the first pass's data at the same addresses
         got, _ = _with_ctx(ctx, lambda: _operators(N))
         for k in ref:
@@ -31,14 +34,15 @@ def test_dataflow_is_bit_identical_to_the_launch_based_factorisation(monkeypatch
     ref_ctx.close()
 
 
+@pytest.mark.parametrize("fat", [0, 1])
 @pytest.mark.parametrize("wgs", [1, 3, 64, 2048])
-def test_any_number_of_persistent_workgroups(monkeypatch, wgs):
+def test_any_number_of_persistent_workgroups(monkeypatch, wgs, fat):
     # 1 workgroup = the tasks strictly in their topological order; 2048 = far more than fit the chip (the surplus finds
     # the task counter exhausted): progress must not depend on residency
     N = 1500
     ref_ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0)
     ref, _ = _with_ctx(ref_ctx, lambda: _operators(N))
-    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_WGS=wgs)
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_WGS=wgs, SGP_DF_FAT_MAX_N=(1 << 30) if fat else 0)
     got, _ = _with_ctx(ctx, lambda: _operators(N))
     for k in ref:
         assert np.array_equal(ref[k], got[k]), (wgs, k)
@@ -59,3 +63,37 @@ def test_not_positive_definite_is_reported_with_the_same_minor(monkeypatch):
         msgs.append(str(e.value))
         ctx.close()
     assert "not positive definite" in msgs[0] and msgs[0] == msgs[1]
+
+
+def test_schedule_by_size_and_the_baseline_goldens_under_it():
+    """The default context picks the schedule by the number of columns (capi.hip: use_dataflow); the committed CPU goldens
+    of the BASELINE sizes that fall into the dataflow range hold under it (tests/test_gpu_baseline_golden.py runs every
+    size on the default context as well -- this one pins WHICH code produced the number)."""
+    import bench_configs as bc
+    ctx = P.lib.default_context()
+    assert ctx.factor_schedule(2048) == "launches-one-panel"
+    assert ctx.factor_schedule(4096) == "dataflow-fat"
+    assert ctx.factor_schedule(16384) == "dataflow-fat"
+    assert ctx.factor_schedule(32768) == "dataflow"
+    assert ctx.factor_schedule(65536) == "launches-serial-deep"
+    for name in ("n4k", "c2"):
+        w = bc.build(P, name)
+        got = P.logpdf(w["fx"], w["y"])
+        want = bc.golden(name)["logpdf"]
+        assert abs(got - want) <= 1e-10 * abs(want), (name, got, want)
+
+
+def test_many_right_hand_sides_and_posterior_rows_ride_through(monkeypatch):
+    # bordered rows: 300 data columns (3 border tile rows) and a posterior's alpha row at N = 3500 -- tile rows below the
+    # square part are tasks like any other
+    rng = np.random.default_rng(11)
+    N = 3500
+    x = P.ColVecs(np.asfortranarray(rng.standard_normal((3, N))))
+    f = P.atomic(P.GP(P.Matern32Kernel()), P.GPC())
+    Y = np.asfortranarray(rng.standard_normal((N, 300)))
+    outs = []
+    for df in (0, 1):
+        ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=df)
+        outs.append(_with_ctx(ctx, lambda: (np.asarray(P.logpdf(f(x, 0.2), Y)), np.asarray(P.posterior(f(x, 0.2), Y[:, 0]).alpha))))
+        ctx.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])

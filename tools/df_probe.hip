@@ -24,7 +24,7 @@ int main(int argc, char** argv) {
   hipMalloc(&dA, sizeof(double) * h.size());
   hipMalloc(&dinv, sizeof(double) * (n_pad / 128) * 2048);
   hipMalloc(&dslots, sizeof(double) * (n_pad / 128));
-  hipMalloc(&dstate, sizeof(int) * (8 + m_tot / 128));
+  hipMalloc(&dstate, sizeof(int) * (sgp::SGP_DF_STATE_WORDS + m_tot / 128));
   hipMalloc(&dinfo, sizeof(int));
   hipMemcpy(dA, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
   hipMemset(dinfo, 0, sizeof(int));
@@ -37,7 +37,7 @@ int main(int argc, char** argv) {
   int rc = sgp::launch_chol_dataflow(dA, ld, n_pad, m_tot, dstate, dinv, dslots, dinfo, wgs, 5.0, s);
   printf("launch rc=%d (%s)\n", rc, rc ? sgp_last_error() : "ok");
   hipEventRecord(done, s);
-  int nst = 8 + (int)(m_tot / 128);
+  int nst = (int)sgp::SGP_DF_STATE_WORDS + (int)(m_tot / 128);
   std::vector<int> st(nst);
   for (int it = 0; it < 200; ++it) {
     bool fin = hipEventQuery(done) == hipSuccess;
@@ -45,7 +45,7 @@ int main(int argc, char** argv) {
     hipStreamSynchronize(s2);
     double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     printf("%8.1f ms head=%d abort=%d dbg=%d,%d prog=", ms, st[0], st[1], st[2], st[3]);
-    for (int i = 8; i < nst && i < 8 + 24; ++i) printf("%d ", st[i]);
+    for (int i = (int)sgp::SGP_DF_STATE_WORDS; i < nst && i < (int)sgp::SGP_DF_STATE_WORDS + 24; ++i) printf("%d ", st[i]);
     printf("%s\n", fin ? " [done]" : "");
     fflush(stdout);
     if (fin) break;
