@@ -456,11 +456,17 @@ def main():
                 roofline["traffic"] = rec["hbm_bytes_per_launch"]
                 roofline["traffic_source"] = dict(rec, file="profiles/" + tr_name)
                 break
+        if dataflow:
+            df_file = os.path.join(ROOT, "profiles", "r03_dataflow_pmc.json")
+            rec = json.load(open(df_file)).get(args.config) if os.path.exists(df_file) else None
+            if rec and rec.get("schedule") == schedule:
+                roofline["traffic"] = rec["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = dict(rec, file="profiles/r03_dataflow_pmc.json")
         roofline["algorithmic_bytes_per_launch_avg"] = (8.0 * N * (N + 1) if dataflow else update_bytes_avg(N))   # dataflow: the
         # lower triangle read once and written once
         for pmc_name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", pmc_name)
-            if os.path.exists(pmc):
+            if os.path.exists(pmc) and not dataflow:
                 roofline["traffic_profiled"] = json.load(open(pmc))
                 break
         asm_bytes = 8.0 * N * (N + 1) / 2 + 8.0 * D * N

@@ -14,12 +14,12 @@ P = g.load_package()
 sizes = [int(a) for a in sys.argv[1:]] or [1024, 2048, 4096, 6144, 8192, 12288, 16384, 24576]
 VARIANTS = [
     ("launches", {"SGP_DATAFLOW": "0"}),
-    ("df lean+park", {"SGP_DATAFLOW": "1", "SGP_DF_FAT_MAX_N": "0", "SGP_DF_LOOKAHEAD": "0"}),
-    ("df lean", {"SGP_DATAFLOW": "1", "SGP_DF_FAT_MAX_N": "0", "SGP_DF_LOOKAHEAD": "0", "SGP_DF_PARK": "0"}),
-    ("df fat", {"SGP_DATAFLOW": "1", "SGP_DF_FAT_MAX_N": "1000000", "SGP_DF_LOOKAHEAD": "0"}),
+    ("dataflow 2 WG/CU", {"SGP_DATAFLOW": "1", "SGP_DF_FAT_MAX_N": "0"}),
+    ("dataflow 1 WG/CU", {"SGP_DATAFLOW": "1", "SGP_DF_FAT_MAX_N": "1000000"}),
+    ("default", {}),
 ]
 KEYS = sorted({k for _, e in VARIANTS for k in e})
-print(f"{'N':>7s} " + " ".join(f"{n:>14s}" for n, _ in VARIANTS) + "   (ms, best of 5; logpdf identical across variants: checked)")
+print(f"{'N':>7s} " + " ".join(f"{n:>17s}" for n, _ in VARIANTS) + "   (ms, best of 5; logpdf identical across variants: checked)")
 for N in sizes:
     rng = np.random.default_rng(N)
     x = P.ColVecs(np.asfortranarray(rng.standard_normal((8, N))))
@@ -47,4 +47,4 @@ for N in sizes:
             P.lib.set_default_context(prev)
             ctx.close()
     assert all(v == vals[0] for v in vals), vals
-    print(f"{N:7d} " + " ".join(f"{b:14.3f}" for b in row), flush=True)
+    print(f"{N:7d} " + " ".join(f"{b:17.3f}" for b in row), flush=True)
