@@ -210,7 +210,8 @@ int launch_colsumsq_sub(const double* V, long ld, long nrows, long ncols, const 
 int launch_gemv_rows(const double* rows, long ld, long nrows, long nc, const double* z, long ldz,
                      const double* add, double* out, hipStream_t s, int upper_tri = 0);
 int launch_transpose_add(const double* src, long lds, long nr, long nc, double* dst, long ldd,
-                         const double* add_vec, hipStream_t s);
+                         const double* add_vec, hipStream_t s,
+                         const double* row_scale = nullptr);   // row_scale: src row r is multiplied by row_scale[r]
 int launch_scale_rows(double* rows, long ld, long nrows, long nc, const double* scale,
                       hipStream_t s);
 
