@@ -28,6 +28,7 @@
 #include "common.h"
 #include "potrf_diag.h"
 #include "panel_solve.h"
+#include "df_order.h"
 #include <vector>
 
 namespace sgp {
@@ -292,17 +293,9 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
     __syncthreads();   // s_word[0] is set; the previous task's LDS phases are over for every wave
     const int q = __builtin_amdgcn_readfirstlane(s_word[0]);
     if (q < 0) break;
+    // column-major task order (df_order.h): column j holds the T_r - j tasks (j, j), (j + 1, j), ..., (T_r - 1, j)
     int j, i;
-    {
-      // column-major task order: column j holds the T_r - j tasks (j, j), (j + 1, j), ..., (T_r - 1, j)
-      const double b = 2.0 * a.T_r + 1.0;
-      j = (int)((b - sqrt(b * b - 8.0 * (double)q)) * 0.5);
-      if (j < 0) j = 0;
-      if (j >= a.T_c) j = a.T_c - 1;
-      while (j > 0 && (long)j * a.T_r - (long)j * (j - 1) / 2 > q) --j;
-      while (j + 1 < a.T_c && (long)(j + 1) * a.T_r - (long)(j + 1) * j / 2 <= q) ++j;
-      i = j + (int)(q - ((long)j * a.T_r - (long)j * (j - 1) / 2));
-    }
+    df_task_tile((long)q, a.T_r, a.T_c, i, j);
     // the chain tasks run at raised wave priority: beside a contraction's back-to-back MFMAs the pivot chain of the
     // diagonal block and the substitution otherwise wait for issue slots (potrf 35 -> 100 us at N = 16384)
     const bool chain = (i == j || i == j + 1);
@@ -398,7 +391,7 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
   a.slots = d_slots;
   a.info = d_info;
   a.spin_ticks = (long long)(timeout_s * 1e8);
-  a.ntasks = (long)a.T_c * a.T_r - (long)a.T_c * (a.T_c - 1) / 2;
+  a.ntasks = df_ntasks(a.T_r, a.T_c);
   a.prio = 0;
   a.stats = d_stats;
   a.cols = d_stats ? d_cols : nullptr;

@@ -97,3 +97,22 @@ def test_many_right_hand_sides_and_posterior_rows_ride_through(monkeypatch):
         outs.append(_with_ctx(ctx, lambda: (np.asarray(P.logpdf(f(x, 0.2), Y)), np.asarray(P.posterior(f(x, 0.2), Y[:, 0]).alpha))))
         ctx.close()
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_a_dependency_wait_that_runs_out_is_an_error_not_a_hang(monkeypatch):
+    # every wait inside the kernel is bounded (SGP_DF_TIMEOUT_S); with a bound of 0.1 us the first tile that has to wait for
+    # the diagonal block's 30 us factorisation gives up, raises the abort word (all workgroups leave) and the entry point
+    # reports it; the context stays usable
+    rng = np.random.default_rng(3)
+    x = P.ColVecs(np.asfortranarray(rng.standard_normal((2, 1500))))
+    f = P.atomic(P.GP(P.SEKernel()), P.GPC())
+    y = rng.standard_normal(1500)
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_TIMEOUT_S="1e-7")
+    with pytest.raises(P.lib.SthenoMIError, match="dependency wait"):
+        _with_ctx(ctx, lambda: P.logpdf(f(x, 0.1), y))
+    ctx.close()
+    ok = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_TIMEOUT_S="10")
+    ref = _ctx(monkeypatch, 11, SGP_DATAFLOW=0)
+    assert _with_ctx(ok, lambda: P.logpdf(f(x, 0.1), y)) == _with_ctx(ref, lambda: P.logpdf(f(x, 0.1), y))
+    ok.close()
+    ref.close()
