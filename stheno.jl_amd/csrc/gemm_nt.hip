@@ -305,7 +305,11 @@ int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M
   long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1));
   *n_ids = per_xcd * 8;
   if (!dbg) return 0;
-  hipLaunchKernelGGL(gemm_nt_dma_stamp_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, C, ldc, K, n_tr,
+  // SGP_STAMP_LDS_PAD=<bytes> (experiment): unused dynamic LDS on top of the tile program's 73.7 KB -- from 12.6 KB on only
+  // ONE workgroup fits a CU (8 waves, two per SIMD): what the tile program delivers at the occupancy a 256 x 128 tile
+  // (128 accumulator registers per wave) would have to live with
+  const size_t pad = getenv("SGP_STAMP_LDS_PAD") ? (size_t)atol(getenv("SGP_STAMP_LDS_PAD")) : 0;
+  hipLaunchKernelGGL(gemm_nt_dma_stamp_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), pad, s, P, ldp, C, ldc, K, n_tr,
                      n_tc, dbg, beta, scr_mul, scr_mul != 0 ? per_xcd * 8 : 0L);
   SGP_HIP(hipGetLastError());
   return 0;
