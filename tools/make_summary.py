@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", sys.argv[2] if len(sys.argv) > 2 else TAG + "final")
 DST = os.path.join(ROOT, "profiles")
-CONFIGS = ("c1", "n4k", "c2", "c3", "c4", "c5", "target")
+CONFIGS = ("c1", "n4k", "c2", "c3", "n32k", "c4", "c5", "target")
 
 
 def jload(name):
@@ -50,8 +50,8 @@ def main():
         if j:
             json.dump(j, open(os.path.join(DST, f"{TAG}_bench_{c}.json"), "w"), indent=1)
     L += ["## bench.py lines (fp64, inputs resident in HBM; `python bench.py --config <c>`)", "",
-          "| config | workload | ms / step | value | whole-step TFLOP/s | frac of 78.6 | roofline.frac (dominant kernel) | assembly GB/s (alg.) | host API ms (sgp_logpdf) | parity |",
-          "|---|---|---|---|---|---|---|---|---|---|"]
+          "| config | workload | Cholesky schedule | ms / step | value | whole-step TFLOP/s | frac of 78.6 | roofline.frac (dominant kernel) | assembly GB/s (alg.) | host API ms (sgp_logpdf) | parity |",
+          "|---|---|---|---|---|---|---|---|---|---|---|"]
     for c in CONFIGS:
         j = b[c]
         if not j:
@@ -62,11 +62,25 @@ def main():
         asm = st.get("kernelmatrix_GBps")
         if asm is None and r.get("hbm_stage"):
             asm = r["hbm_stage"]["achieved"]
-        L.append(f"| {c} | {j['config']['workload'][:78]} | {j['ms_per_step']:.3f} | {j['value']:.4g} {j['unit']} | "
+        L.append(f"| {c} | {j['config']['workload'][:78]} | {r.get('schedule', '-')} | {j['ms_per_step']:.3f} | {j['value']:.4g} {j['unit']} | "
                  f"{j['cholesky_tflops_whole_step']:.1f} | {j['cholesky_tflops_whole_step']/78.6:.2f} | {r.get('frac', float('nan')):.3f} | "
-                 f"{(asm or float('nan')):.0f} | {ha.get('ms_per_call', float('nan')):.3f} | {j.get('parity_rel', float('nan')):.1e} |")
+                 f"{(asm or float('nan')):.0f} | {ha.get('ms_per_call', float('nan')):.3f} | {(j.get('parity_rel') if j.get('parity_rel') is not None else float('nan')):.1e} |")
     L += ["", "Earlier rounds, same lines: round 1 c1 1.89 ms, n4k 5.8, c2 36.8, c3 203.9, c4 177.4, c5 1516; round 2 c1 1.10, n4k 2.47, "
           "c2 32.9, c3 200.2, c4 165.9, c5 1475 - 1525, target 1515 (boxes differ by +-3 % at N = 65536: the step is power / clock limited)."]
+    ln_ = {c: jload(f"bench_{c}_launches.json") for c in ("n4k", "c2", "c3")}
+    if any(ln_.values()):
+        L += ["", "The dataflow factorisation (chol_df.hip: one launch of persistent workgroups, DESIGN 3.3b; default from 3072 to 65 536 "
+              "columns) against the launch-based schedules (`SGP_DATAFLOW=0`) on this box -- same bits, same goldens "
+              "(more in `r03_dataflow.md`):", ""]
+        for c, j in ln_.items():
+            if j and b.get(c):
+                json.dump(j, open(os.path.join(DST, f"{TAG}_bench_{c}_launches.json"), "w"), indent=1)
+                L.append(f"* {c}: {j['roofline'].get('schedule')} {j['ms_per_step']:.2f} ms -> {b[c]['roofline'].get('schedule')} "
+                         f"**{b[c]['ms_per_step']:.2f} ms**; whole step {j['cholesky_tflops_whole_step']/78.6:.3f} -> "
+                         f"{b[c]['cholesky_tflops_whole_step']/78.6:.3f} of the fp64 matrix peak")
+    dfs = os.path.join(SRC, "df_stats.txt")
+    if os.path.exists(dfs):
+        shutil.copy(dfs, os.path.join(DST, f"{TAG}_dataflow_stats.txt"))
     la = {c: jload(f"bench_{c}_lookahead.json") for c in ("c5", "target")}
     if any(la.values()):
         L += ["", "Schedule A/B at N = 65 536 on this box (default: serial, one fused trailing-update launch per panel; "
@@ -128,7 +142,7 @@ def main():
                      f"GPU / CPU = {j['value']/cpu['value']:.0f}x (reported baseline, not a target).  Thread sweep of the blocked "
                      f"Cholesky (GFLOP/s; host cores {cpu.get('host_cores')}, threads used {cpu.get('threads_used')}): {cpu.get('thread_sweep_cholesky_gflops')}.")
     # rocprof kernel stats
-    for tag in ("c5", "target", "c2", "c1", "c4"):
+    for tag in ("c5", "target", "c3", "c2", "n4k", "c1", "c4"):
         src = os.path.join(SRC, f"prof_{tag}", f"{tag}_kernel_stats.csv")
         if not os.path.exists(src):
             continue
@@ -140,7 +154,13 @@ def main():
             L.append(f"| `{rr['Name'].split('(')[0].replace('void ', '')}` | {rr['Calls']} | {float(rr['TotalDurationNs'])/1e6:.1f} | "
                      f"{float(rr['AverageNs'])/1e3:.1f} | {float(rr['Percentage']):.2f} |")
         jb = jload(f"prof_{tag}_bench.json")
-        if jb and jb.get("roofline") and jb["roofline"].get("launches"):
+        if jb and jb.get("roofline") and str(jb["roofline"].get("schedule", "")).startswith("dataflow"):
+            dfk = [rr for rr in rows if "chol_dataflow" in rr["Name"]]
+            if dfk:
+                L += ["", f"Same run, bench's own HIP-event figure for the one launch: {jb['roofline']['avg_launch_ms']:.3f} ms "
+                      f"({jb['roofline']['achieved']:.1f} TFLOP/s = {jb['roofline']['frac']:.3f}); rocprof's average for "
+                      f"`{dfk[0]['Name'].split('(')[0]}` ({dfk[0]['Calls']} calls): {float(dfk[0]['AverageNs'])/1e6:.3f} ms."]
+        elif jb and jb.get("roofline") and jb["roofline"].get("launches"):
             upd = [rr for rr in rows if "gemm_nt_dma_kernel<1>" in rr["Name"] or "gemm_nt_dma_potrf_kernel<1," in rr["Name"]]
             upd.sort(key=lambda rr: -float(rr["TotalDurationNs"]))
             agree = ""
