@@ -42,7 +42,9 @@ def pmc(prefix, tag, match):
 def main():
     os.makedirs(DST, exist_ok=True)
     L = [f"# Round {int(TAG[1:])} — measurements on one MI355X (gfx950, ROCm 7.2, gpurun box)", "",
-         f"All numbers come from `tools/collect_{TAG}.sh` (one gpurun call); raw files next to this one.  Inputs: "
+         f"The lines, kernel stats and the GPU test run below come from `tools/collect_{TAG}_final.sh` (one gpurun call, one box); the PMC "
+         f"passes, multi-GPU profiles and the prediction / gradient / fp32 timings from `tools/collect_{TAG}.sh` earlier in the round (code "
+         "unchanged since); raw files next to this one.  Inputs: "
          "bench_configs.py (seeded standard normals, lengthscale sqrt(D), sigma^2 = 0.1); `parity` = |value - CPU golden| / "
          "|golden| against tests/golden/baseline_configs.json.", ""]
     b = {c: jload(f"bench_{c}.json") for c in CONFIGS}
