@@ -101,6 +101,18 @@ def prior_mean(f, x):
     return f.mean(x)
 
 
+def _model_type(out, *inputs):
+    """ONE output-type rule for the whole operator surface: results come back in the element type of the inputs they were
+    asked at -- Float32 when every input is Float32 (test/gp/util.jl:76-88 checks `rand` / `logpdf` of Float32 models for
+    exactly that), Float64 otherwise -- whichever arithmetic produced them (the fp32 device paths cover logpdf, cov, rand
+    and posterior moments; everything else is computed in fp64 and rounded here).  None / tuples pass through."""
+    if out is None or not all(_eltype(x) == np.float32 for x in inputs):
+        return out
+    if isinstance(out, tuple):
+        return tuple(_model_type(o, *inputs) for o in out)
+    return np.float32(out) if np.ndim(out) == 0 else np.asarray(out).astype(np.float32, copy=False)
+
+
 def prior_cov(f, x, x2=None):
     if _is_prior(f):
         if _eltype(x) == np.float32 and (x2 is None or _eltype(x2) == np.float32):
@@ -111,12 +123,12 @@ def prior_cov(f, x, x2=None):
             # kernels take any dimension and term count; the result is rounded to the model's type
             return _kernelmatrix(spec).astype(np.float32)
         return _kernelmatrix(_prior_spec(f, x, x2))
-    return f.cov(x, x2)
+    return f.cov(x, x2)          # (posteriors round to the model's type themselves)
 
 
 def prior_var(f, x):
     if _is_prior(f):
-        return _kernelmatrix_diag(_prior_spec(f, x))
+        return _model_type(_kernelmatrix_diag(_prior_spec(f, x)), x)
     return f.var(x)
 
 
@@ -136,14 +148,14 @@ def cov(fx, gx=None):
     # src/gp/util.jl:12-14: cov(fx, gx) = cov(fx.f, gx.f, fx.x, gx.x) -- no noise
     if _is_prior(fx.f) and _is_prior(gx.f):
         spec, _, _ = build_spec(fx.f, fx.x, gx.f, gx.x)
-        return _kernelmatrix(spec)
+        return _model_type(_kernelmatrix(spec), fx.x, gx.x)
     raise TypeError("cov(fx, gx) needs two FiniteGPs of one Stheno model")
 
 
 def var(fx):
     if isinstance(fx, SparseFiniteGP):
         return var(fx.fobs)
-    return prior_var(fx.f, fx.x) + _noise_diag(fx.noise, len(fx))
+    return _model_type(prior_var(fx.f, fx.x) + _noise_diag(fx.noise, len(fx)), fx.x)
 
 
 def mean_and_cov(fx):
@@ -421,6 +433,9 @@ class PosteriorGP:
     def __call__(self, xs, noise=1e-18):
         return FiniteGP(self, xs, noise)
 
+    def _train_inputs(self):
+        return (self.x,)
+
     def _predict(self, xs, want_mean, want_var, want_cov):
         cross, _, _ = build_spec(self.prior, xs, self.prior, self.x)
         pss = _prior_spec(self.prior, xs) if (want_var or want_cov) else None
@@ -450,27 +465,27 @@ class PosteriorGP:
         return mo, vo, co
 
     def mean(self, xs):
-        return self._predict(xs, True, False, False)[0]
+        return _model_type(self._predict(xs, True, False, False)[0], xs, *self._train_inputs())
 
     def var(self, xs):
-        return self._predict(xs, False, True, False)[1]
+        return _model_type(self._predict(xs, False, True, False)[1], xs, *self._train_inputs())
 
     def cov(self, xs, zs=None):
         if zs is None:
-            return self._predict(xs, False, False, True)[2]
+            return _model_type(self._predict(xs, False, False, True)[2], xs, *self._train_inputs())
         # cov(post, x*, z*) = K(x*, z*) - V_x*' V_z*: the off-diagonal block of the joint covariance
         joint = self._predict(BlockData([xs, zs]) if not isinstance(xs, BlockData) else _concat(xs, zs),
                               False, False, True)[2]
         nx = len(xs)
-        return joint[:nx, nx:]
+        return _model_type(joint[:nx, nx:], xs, zs, *self._train_inputs())
 
     def mean_and_var(self, xs):
         m, v, _ = self._predict(xs, True, True, False)
-        return m, v
+        return _model_type((m, v), xs, *self._train_inputs())
 
     def mean_and_cov(self, xs):
         m, _, c = self._predict(xs, True, False, True)
-        return m, c
+        return _model_type((m, c), xs, *self._train_inputs())
 
 
 def _concat(xs, zs):
@@ -719,6 +734,9 @@ class ApproxPosteriorGP:
     def __call__(self, xs, noise=1e-18):
         return FiniteGP(self, xs, noise)
 
+    def _train_inputs(self):
+        return (self.z,)
+
     def _predict(self, xs, want_mean, want_var, want_cov):
         cross, _, _ = build_spec(self.prior, xs, self.prior, self.z)
         pss = _prior_spec(self.prior, xs) if (want_var or want_cov) else None
@@ -734,27 +752,27 @@ class ApproxPosteriorGP:
         return mo, vo, co
 
     def mean(self, xs):
-        return self._predict(xs, True, False, False)[0]
+        return _model_type(self._predict(xs, True, False, False)[0], xs, *self._train_inputs())
 
     def var(self, xs):
-        return self._predict(xs, False, True, False)[1]
+        return _model_type(self._predict(xs, False, True, False)[1], xs, *self._train_inputs())
 
     def cov(self, xs, zs=None):
         if zs is None:
-            return self._predict(xs, False, False, True)[2]
+            return _model_type(self._predict(xs, False, False, True)[2], xs, *self._train_inputs())
         # cov(post, x*, z*): the off-diagonal block of the joint covariance over [x*; z*] (as PosteriorGP.cov)
         joint = self._predict(BlockData([xs, zs]) if not isinstance(xs, BlockData) else _concat(xs, zs),
                               False, False, True)[2]
         nx = len(xs)
-        return joint[:nx, nx:]
+        return _model_type(joint[:nx, nx:], xs, zs, *self._train_inputs())
 
     def mean_and_var(self, xs):
         m, v, _ = self._predict(xs, True, True, False)
-        return m, v
+        return _model_type((m, v), xs, *self._train_inputs())
 
     def mean_and_cov(self, xs):
         m, _, c = self._predict(xs, True, False, True)
-        return m, c
+        return _model_type((m, c), xs, *self._train_inputs())
 
 
 def posterior_vfe(vfe, fx, y):

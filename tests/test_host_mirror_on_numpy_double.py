@@ -48,7 +48,7 @@ import test_gpu_f32 as F32  # noqa: E402
 
 for _name in ("test_logpdf_f32_single_gp", "test_logpdf_f32_gppp_blocks_diag_noise_and_means", "test_cov_and_mean_f32",
               "test_posdef_failure_f32", "test_rand_f32_type_stable_and_close_to_fp64",
-              "test_posterior_moments_f32_and_fp64_factor_on_demand"):
+              "test_posterior_moments_f32_and_fp64_factor_on_demand", "test_one_output_type_rule_across_the_operator_surface"):
     globals()[_name] = getattr(F32, _name)
 del _name
 
