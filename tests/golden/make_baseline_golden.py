@@ -15,6 +15,7 @@ the models of SURVEY.md 8d:
          (f1, 10923), (f2, 10923), (f3, 10922), total N = 32768, D = 4
   c4     sparse ELBO (VFE), SE, M = 4096 inducing points, N = 262144, D = 8, Sigma_z = 1e-6 I
   c5     single GP, Matern-5/2, N = 65536,  D = 8
+  n32k   single GP, Matern-5/2, N = 32768,  D = 8   (round 3: the largest size the dataflow factorisation serves)
   target c3's model at N = 65536, D = 8, blocks 21846 / 21845 / 21845 (the north-star run)
   w4k    every input transformation of /root/reference/src/affine_transformations/compose.jl in one programme
          (round 3; the cases above only stretch and add), N = 4096, D = 3, a ~ GP(SE), b ~ GP(Matern-5/2):
@@ -313,6 +314,7 @@ CASES = {
     "c3": lambda: ("dense", gppp3(32768, 4, [10923, 10923, 10922]), 4),
     "c4": lambda: ("elbo", None, 8),
     "c5": lambda: ("dense", single("m52", 65536, 8), 8),
+    "n32k": lambda: ("dense", single("m52", 32768, 8), 8),
     "target": lambda: ("dense", gppp3(65536, 8, [21846, 21845, 21845]), 8),
     "w4k": lambda: ("warp", warp4k(), 3),
 }

@@ -24,7 +24,7 @@ import bench_configs as bc  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 REL = 1e-10
-DENSE = ["c1", "n4k", "c2", "c3", "c5", "target", "w4k"]
+DENSE = ["c1", "n4k", "c2", "c3", "n32k", "c5", "target", "w4k"]
 
 
 def _rel(a, b):

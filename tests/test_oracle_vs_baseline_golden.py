@@ -34,7 +34,7 @@ def test_oracle_matches_standalone_golden(name):
 
 
 def test_golden_file_holds_every_benchmarked_configuration():
-    for name in ("c1", "n4k", "c2", "c3", "c4", "c5", "target"):
+    for name in ("c1", "n4k", "c2", "c3", "n32k", "c4", "c5", "target"):
         g = bc.golden(name)
         assert g is not None and g["N"] == bc.CONFIGS[name][1]
         assert math.isfinite(g.get("logpdf", g.get("elbo")))
