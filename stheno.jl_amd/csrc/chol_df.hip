@@ -47,7 +47,6 @@ struct DfArgs {
   int* info;
   long long spin_ticks;   // wall_clock64 ticks (100 MHz) a single wait may last
   long ntasks;
-  int prio;
   long long* stats;   // optional (SGP_DF_STATS): 8 tick counters per workgroup, see launch_chol_dataflow
   long long* cols;    // optional: 8 wall-clock stamps per tile column (the chain: diagonal task + the task below it)
 };
@@ -392,7 +391,6 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
   a.info = d_info;
   a.spin_ticks = (long long)(timeout_s * 1e8);
   a.ntasks = df_ntasks(a.T_r, a.T_c);
-  a.prio = 0;
   a.stats = d_stats;
   a.cols = d_stats ? d_cols : nullptr;
   SGP_HIP(hipMemsetAsync(d_state, 0, sizeof(int) * (DF_PROG + (size_t)a.T_r), s));
