@@ -116,3 +116,20 @@ def test_a_dependency_wait_that_runs_out_is_an_error_not_a_hang(monkeypatch):
     assert _with_ctx(ok, lambda: P.logpdf(f(x, 0.1), y)) == _with_ctx(ref, lambda: P.logpdf(f(x, 0.1), y))
     ok.close()
     ref.close()
+
+
+def test_schedule_limits_move_with_their_environment_variables(monkeypatch):
+    # SGP_DATAFLOW unset / -1 = by size; SGP_DF_MIN_N, SGP_DF_MAX_N, SGP_DF_FAT_MAX_N move the limits
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=-1, SGP_DF_MIN_N=1024, SGP_DF_MAX_N=8192, SGP_DF_FAT_MAX_N=4096)
+    assert ctx.factor_schedule(896) == "launches-one-panel"
+    assert ctx.factor_schedule(1000) == "dataflow-fat"              # the limits apply to the padded column count (1024)
+    assert ctx.factor_schedule(4096) == "dataflow"
+    assert ctx.factor_schedule(8192) == "launches-lookahead"
+    ctx.close()
+    never = _ctx(monkeypatch, 11, SGP_DATAFLOW=0)
+    always = _ctx(monkeypatch, 11, SGP_DATAFLOW=1)
+    for N in (130, 5000, 70000):
+        assert not never.factor_schedule(N).startswith("dataflow")
+        assert always.factor_schedule(N).startswith("dataflow")
+    never.close()
+    always.close()
