@@ -2,6 +2,7 @@
 // every numerical result is produced by the HIP kernels in this directory.
 #include "ctx.h"
 #include "driver.h"
+#include "df_order.h"
 
 #include <algorithm>
 #include <cmath>
@@ -204,6 +205,14 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (dff) c->df_fat_max_n = atol(dff);
     const char* dft = getenv("SGP_DF_TIMEOUT_S");
     if (dft) c->df_timeout_s = atof(dft);
+    const char* dfo = getenv("SGP_DF_ORDER");
+    if (dfo) c->df_order = atoi(dfo);
+    const char* dfpr = getenv("SGP_DF_PR");
+    if (dfpr) c->df_pr = atoi(dfpr);
+    const char* dfpc = getenv("SGP_DF_PC");
+    if (dfpc) c->df_pc = atoi(dfpc);
+    const char* dfg = getenv("SGP_DF_GANG_US");
+    if (dfg) c->df_gang_us = atof(dfg);
     {
       hipDeviceProp_t prop;
       SGP_HIP(hipGetDeviceProperties(&prop, device));
@@ -248,6 +257,7 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->d_df_state) hipFree(c->d_df_state);
   if (c->d_df_inv) hipFree(c->d_df_inv);
   if (c->d_df_stats) hipFree(c->d_df_stats);
+  if (c->d_df_tasks) hipFree(c->d_df_tasks);
   if (c->ev_panel) hipEventDestroy(c->ev_panel);
   if (c->ev_rest) hipEventDestroy(c->ev_rest);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -653,6 +663,22 @@ static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, lo
 //                            every operand k slice through L2, the desynchronised contractions of the dataflow kernel
 //                            stream theirs from HBM and the clock pays for it (-11 %, profiles/r03_experiments/)
 // SGP_DATAFLOW = 0 / 1 forces never / always; SGP_DF_MIN_N, SGP_DF_MAX_N, SGP_DF_FAT_MAX_N move the limits.
+// Task order of the dataflow kernel: XCD-affine queues (1) or column-major ids (0); the patch a queue deals out.
+// Default: column-major.  Round 4 measured the queues (profiles/r04_experiments/dataflow_xcd_queues.md): handing a queue's
+// patches to the free workgroups of its XCD does NOT make them share operand panels -- they start their tiles whenever they
+// become free, not together (L2 hit 0.11 -> 0.15, step +3.6 % at 32768 columns, +2 .. 5 % at 65536); a soft gang start
+// (SGP_DF_GANG_US) does create the sharing (L2 hit 0.43, contraction time per workgroup -10 %) but the waiting it costs is
+// larger (+15 .. 25 %).  Kept as SGP_DF_ORDER=1 for the record and for whoever finds a cheaper way to keep a patch in step.
+static bool df_order_of(const sgp_ctx* ctx, int fat) {
+  (void)fat;
+  return ctx->df_order > 0;
+}
+static void df_patch_of(const sgp_ctx* ctx, int fat, int& pr, int& pc) {
+  pc = ctx->df_pc;
+  if (pc != 1 && pc != 2 && pc != 4 && pc != 8) pc = fat ? 2 : 4;   // (the order's progress argument wants pc | 8)
+  const int slots = std::max(1, ctx->df_wgs / DF_NQ);                 // workgroups that serve one queue
+  pr = ctx->df_pr > 0 ? ctx->df_pr : std::max(1, slots / pc);
+}
 static bool use_dataflow(const sgp_ctx* ctx, long n_pad) {
   if (ctx->refine != 1 || ctx->dataflow == 0) return false;
   return ctx->dataflow == 1 || (n_pad >= ctx->df_min_n && n_pad < ctx->df_max_n);
@@ -697,6 +723,31 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       ctx->n_df_inv = need_inv;
     }
     const int fat = n_pad < ctx->df_fat_max_n ? 1 : 0;
+    // XCD-affine task queues (df_order.h): built on the host once per shape, kept on the device
+    const uint32_t* d_tasks = nullptr;
+    if (df_order_of(ctx, fat)) {
+      int pr, pc;
+      df_patch_of(ctx, fat, pr, pc);
+      const long key[4] = {m_tot / TILE, n_pad / TILE, pr, pc};
+      if (std::memcmp(key, ctx->df_tasks_key, sizeof(key)) != 0) {
+        std::vector<uint32_t> tasks, pend;
+        df_build_queues((int)key[0], (int)key[1], pr, pc, tasks, ctx->df_qstart, &pend);
+        tasks.insert(tasks.end(), pend.begin(), pend.end());
+        SGP_HIP(hipStreamSynchronize(s));   // (an earlier launch may still read the old queues)
+        tasks.insert(tasks.begin(), ctx->df_qstart, ctx->df_qstart + DF_NQ + 1);   // device layout: qstart[9], then the queues
+        if ((long)tasks.size() > ctx->n_df_tasks) {
+          if (ctx->d_df_tasks) hipFree(ctx->d_df_tasks);
+          ctx->d_df_tasks = nullptr;
+          ctx->n_df_tasks = 0;
+          SGP_HIP(hipMalloc(&ctx->d_df_tasks, sizeof(uint32_t) * tasks.size()));
+          ctx->n_df_tasks = (long)tasks.size();
+        }
+        ctx->df_tasks_key[0] = 0;
+        SGP_HIP(hipMemcpy(ctx->d_df_tasks, tasks.data(), sizeof(uint32_t) * tasks.size(), hipMemcpyHostToDevice));
+        std::memcpy(ctx->df_tasks_key, key, sizeof(key));
+      }
+      d_tasks = ctx->d_df_tasks;
+    }
     if (getenv("SGP_DF_STATS") && !ctx->d_df_stats)   // + 8 stamps for each of up to 4096 tile columns
       SGP_HIP(hipMalloc(&ctx->d_df_stats, sizeof(long long) * 8 * ((size_t)ctx->df_wgs + 4096)));
     long long* d_cols = ctx->d_df_stats && n_pad / TILE <= 4096 ? ctx->d_df_stats + 8 * (size_t)ctx->df_wgs : nullptr;
@@ -707,7 +758,8 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       SGP_HIP(hipEventRecord(e0, s));
     }
     CHECK_RC(launch_chol_dataflow(A, ld, n_pad, m_tot, ctx->d_df_state, d_wall ? d_wall : ctx->d_df_inv, ctx->d_slots,
-                                  ctx->d_info, ctx->df_wgs, ctx->df_timeout_s, s, ctx->d_df_stats, d_cols, fat));
+                                  ctx->d_info, ctx->df_wgs, ctx->df_timeout_s, s, ctx->d_df_stats, d_cols, fat, d_tasks,
+                                  ctx->df_qstart, ctx->df_gang_us));
     if (ctx->d_df_stats) {   // diagnosis only: drains the stream
       hipEventRecord(e1, s);
       hipStreamSynchronize(s);
@@ -719,11 +771,16 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       SGP_HIP(hipMemcpy(h.data(), ctx->d_df_stats, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
       double sum[8] = {0};
       long nw = 0;
+      long off_xcd = 0;
       for (int w = 0; w < ctx->df_wgs; ++w) {
         if (h[(size_t)8 * w + 1] == 0) continue;
         ++nw;
+        if ((int)((h[(size_t)8 * w] >> 40) & 15) != (w & 7)) ++off_xcd;   // not on XCD (id % 8)
+        h[(size_t)8 * w] &= (1LL << 40) - 1;
         for (int q = 0; q < 8; ++q) sum[q] += (double)h[(size_t)8 * w + q];
       }
+      fprintf(stderr, "dataflow order %s, %ld of %ld workgroups NOT on XCD (id %% 8)\n",
+              d_tasks ? "queues" : "column-major", off_xcd, nw);
       const double us = 0.01 / (double)std::max<long>(nw, 1);   // ticks (100 MHz) -> us, averaged over the workgroups
       fprintf(stderr,
               "dataflow n_pad=%ld m_tot=%ld: %.3f ms, %ld workgroups, %.0f tasks; per workgroup (us): in kernel %.1f | "

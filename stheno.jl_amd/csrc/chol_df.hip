@@ -35,18 +35,24 @@ namespace sgp {
 
 constexpr int DF_KB = 16;                       // K chunk per LDS stage (as gemm_nt.hip)
 constexpr int DF_STAGE = 2 * DF_KB * LDS_LD;    // doubles per stage: A chunk + B chunk
-constexpr int DF_PROG = 8;                      // offset of the tile-row progress counters in the state words
+constexpr int DF_PROG = (int)SGP_DF_STATE_WORDS; // offset of the tile-row progress counters in the state words
+constexpr int DF_HEAD = 2;                      // state[DF_HEAD + x]: head of queue x (XCD-affine order, df_order.h)
+static_assert(DF_HEAD + DF_NQ <= DF_PROG, "state words");
 
 struct DfArgs {
   double* A;        // m_tot x n_pad, column-major, lower tiles + bordered rows
   long ld;
   int T_r, T_c;     // tile rows (m_tot / 128), tile columns (n_pad / 128)
-  int* state;       // [0] next task id, [1] abort, [DF_PROG + i] prog[i]; zeroed before every launch
+  int* state;       // [0] next task id, [1] abort, [DF_HEAD + x] head of queue x, [DF_PROG + i] prog[i]; zeroed before every launch
+  const uint32_t* tasks;   // XCD-affine order: qstart[0 .. DF_NQ], then the eight queues back to back (df_build_queues,
+                           // offsets relative to tasks + DF_NQ + 1); nullptr = column-major ids
   double* invall;   // T_c x INVD (2048 doubles): inverse 16x16 diagonal blocks of every 128-block
   double* slots;    // T_c logdet contributions
   int* info;
   long long spin_ticks;   // wall_clock64 ticks (100 MHz) a single wait may last
   long ntasks;
+  long long gang_ticks;   // experiment (SGP_DF_GANG_US): soft gang start -- a workgroup that took a tile of a patch waits (at
+                          // most this long) until every tile of the patch has been taken; pend[] follows the tasks
   long long* stats;   // optional (SGP_DF_STATS): 8 tick counters per workgroup, see launch_chol_dataflow
   long long* cols;    // optional: 8 wall-clock stamps per tile column (the chain: diagonal task + the task below it)
 };
@@ -141,11 +147,40 @@ __device__ __forceinline__ void df_release_store(int* word, int value) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (ROCm 7.2 may drop the wait after buffer_wbl2: restate it)
   __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// lane 0: the next task id (or -1: none left / abort raised)
-__device__ __forceinline__ int df_dequeue(const DfArgs& a) {
-  int q = -1;
-  if (DF_RLX_LOAD(a.state + 1) == 0) q = atomicAdd(a.state, 1);
-  return (q >= 0 && (long)q < a.ntasks) ? q : -1;
+// lane 0: the next task -- tile (i << 16 | j) -- or -1: none left / abort raised.  Column-major order: one counter.
+// XCD-affine order: the workgroup serves queue `cur` (starts at workgroup id % 8 = the XCD the hardware dispatched it
+// to) and moves on to the next queue once that one is exhausted; every queue is handed out in order.
+__device__ __forceinline__ int df_dequeue(const DfArgs& a, int* curleft) {
+  if (DF_RLX_LOAD(a.state + 1) != 0) return -1;
+  if (!a.tasks) {
+    const int q = atomicAdd(a.state, 1);
+    if ((long)q >= a.ntasks) return -1;
+    int i, j;
+    df_task_tile((long)q, a.T_r, a.T_c, i, j);
+    return (int)df_pack(i, j);
+  }
+  int cur = curleft[0], left = curleft[1];
+  int r = -1;
+  while (left > 0) {
+    const int q0 = (int)a.tasks[cur], len = (int)a.tasks[cur + 1] - q0;
+    if (len > 0 && DF_RLX_LOAD(a.state + DF_HEAD + cur) < len) {
+      const int q = atomicAdd(a.state + DF_HEAD + cur, 1);
+      if (q < len) {
+        r = (int)a.tasks[DF_NQ + 1 + q0 + q];
+        if (a.gang_ticks > 0) {
+          const int pe = (int)a.tasks[DF_NQ + 1 + a.ntasks + q0 + q];
+          const long long t0 = wall_clock64();
+          while (DF_RLX_LOAD(a.state + DF_HEAD + cur) < pe && wall_clock64() - t0 < a.gang_ticks) __builtin_amdgcn_s_sleep(2);
+        }
+        break;
+      }
+    }
+    cur = (cur + 1) & (DF_NQ - 1);
+    --left;
+  }
+  curleft[0] = cur;
+  curleft[1] = left;
+  return r;
 }
 
 // The three phases of a task are separate (non-inlined) functions: each gets its own register allocation -- inlined
@@ -271,7 +306,8 @@ __device__ __forceinline__ void df_solve(const DfArgs& a, int i, int j, double* 
 template <bool FAT>
 __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
-  __shared__ int s_word[4];   // [0] task id, [1] available k blocks / abort, [2..3] wait ticks (statistics)
+  __shared__ int s_word[8];   // [0] task, [1] available k blocks / abort, [2..3] wait ticks (statistics), [4..5] lane 0's
+                              // queue cursor: the queue it serves, queues left to try (XCD-affine order)
   const int t = threadIdx.x;
   int* prog = a.state + DF_PROG;
   // optional per-workgroup time accounting (lane 0, 100 MHz wall clock): [0] tasks [1] kernel [2] contraction incl. its
@@ -280,7 +316,9 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
   const bool st = a.stats != nullptr && t == 0;
   if (st) tk0 = wall_clock64();
   if (t == 0) {
-    s_word[0] = df_dequeue(a);
+    s_word[4] = (int)(blockIdx.x & (DF_NQ - 1));
+    s_word[5] = DF_NQ;
+    s_word[0] = df_dequeue(a, s_word + 4);
     s_word[2] = s_word[3] = 0;
   }
   // One lane-0 section per iteration (publish the finished tile AND take the next task), followed by the barrier at the
@@ -292,9 +330,8 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
     __syncthreads();   // s_word[0] is set; the previous task's LDS phases are over for every wave
     const int q = __builtin_amdgcn_readfirstlane(s_word[0]);
     if (q < 0) break;
-    // column-major task order (df_order.h): column j holds the T_r - j tasks (j, j), (j + 1, j), ..., (T_r - 1, j)
     int j, i;
-    df_task_tile((long)q, a.T_r, a.T_c, i, j);
+    df_unpack((uint32_t)q, i, j);
     // the chain tasks run at raised wave priority: beside a contraction's back-to-back MFMAs the pivot chain of the
     // diagonal block and the substitution otherwise wait for issue slots (potrf 35 -> 100 us at N = 16384)
     const bool chain = (i == j || i == j + 1);
@@ -342,7 +379,7 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
     __syncthreads();
     if (t == 0) {
       df_release_store(prog + i, j + 1);
-      s_word[0] = df_dequeue(a);
+      s_word[0] = df_dequeue(a, s_word + 4);
     }
     if (st) {
       const long long n = wall_clock64();
@@ -353,7 +390,8 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
   }
   if (st) {
     long long* d = a.stats + (long)blockIdx.x * 8;
-    d[0] = ntask;
+    // (bits 40..43: the XCD this workgroup ran on, XCC_ID -- the queues assume workgroup id % 8)
+    d[0] = ntask | ((long long)(__builtin_amdgcn_s_getreg(6164) & 15) << 40);
     d[1] = wall_clock64() - tk0;
     d[2] = acc_c;
     d[3] = acc_w;
@@ -369,9 +407,13 @@ __global__ __launch_bounds__(512, 2) void chol_dataflow_fat_kernel(DfArgs a) { c
 
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
                          int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats, long long* d_cols,
-                         int fat) {
+                         int fat, const uint32_t* d_tasks, const int* qstart, double gang_us) {
   if (n_pad % TILE || m_tot % TILE || n_pad <= 0 || m_tot < n_pad) {
     set_error("chol_dataflow: sizes must be multiples of 128");
+    return -1;
+  }
+  if (m_tot / TILE >= 32768) {   // a task is (row << 16 | column) in a non-negative int
+    set_error("chol_dataflow: more than 32767 tile rows");
     return -1;
   }
   if ((long)16 * ld + m_tot >= (1L << 31)) {   // panel_solve_strip's 32-bit lane offset
@@ -391,6 +433,14 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
   a.info = d_info;
   a.spin_ticks = (long long)(timeout_s * 1e8);
   a.ntasks = df_ntasks(a.T_r, a.T_c);
+  // the queues need a workgroup each (a queue nobody serves would only be drained by workgroups whose own queue is
+  // exhausted -- and those may hold tasks that wait for it): fewer than DF_NQ workgroups run the column-major order
+  a.tasks = (d_tasks && qstart && std::min<long>(a.ntasks, n_wg) >= DF_NQ) ? d_tasks : nullptr;
+  if (a.tasks && (long)qstart[DF_NQ] != a.ntasks) {
+    set_error("chol_dataflow: task queues do not match the tile grid");
+    return -1;
+  }
+  a.gang_ticks = a.tasks ? (long long)(gang_us * 100.0) : 0;
   a.stats = d_stats;
   a.cols = d_stats ? d_cols : nullptr;
   SGP_HIP(hipMemsetAsync(d_state, 0, sizeof(int) * (DF_PROG + (size_t)a.T_r), s));

@@ -145,8 +145,10 @@ int launch_gemm_nt_potrf(const double* P, long ldp, double* C, long ldc, long M,
 constexpr int SGP_DF_TIMEOUT = -77;   // *info when a dependency wait inside the kernel ran into its bound
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
                          int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats = nullptr,
-                         long long* d_cols = nullptr, int fat = 0);
-constexpr long SGP_DF_STATE_WORDS = 8;   // state words ahead of the per-tile-row progress counters
+                         long long* d_cols = nullptr, int fat = 0, const uint32_t* d_tasks = nullptr,
+                         const int* qstart = nullptr, double gang_us = 0.0);
+// d_tasks = qstart[9], the queues, pend[] (df_order.h: df_build_queues); qstart: host copy
+constexpr long SGP_DF_STATE_WORDS = 16;   // state words ahead of the per-tile-row progress counters
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
                           long* n_ids, hipStream_t s, double beta = 1.0, long scr_mul = 0);   // bench: per-workgroup phase stamps of one lower update
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,

@@ -39,6 +39,65 @@ static bool replay(int T_r, int T_c, int W) {
   return true;
 }
 
+// XCD-affine order (df_build_queues): every tile exactly once, and a replay in which workgroup w serves queue w % 8 IN
+// ORDER and moves on to the next queue only when its own is exhausted -- as the kernel does -- must finish for any number
+// of workgroups >= DF_NQ.  Odd rounds retire ONE held task only (rotating start), so that the replay also visits schedules
+// in which a single late workgroup is the one able to move.
+static bool replay_queues(int T_r, int T_c, int pr, int pc, int W) {
+  std::vector<uint32_t> tasks;
+  int qs[DF_NQ + 1];
+  df_build_queues(T_r, T_c, pr, pc, tasks, qs);
+  const long nt = df_ntasks(T_r, T_c);
+  if ((long)tasks.size() != nt || qs[DF_NQ] != (int)nt) return false;
+  std::vector<char> seen((size_t)T_r * T_c, 0);
+  for (int x = 0; x < DF_NQ; ++x)
+    for (int q = qs[x]; q < qs[x + 1]; ++q) {
+      int i, j;
+      df_unpack(tasks[q], i, j);
+      if (i < j || i >= T_r || j >= T_c || seen[(size_t)i * T_c + j]) return false;
+      if (df_row_queue(i) != x) return false;   // a tile row lives in ONE queue
+      seen[(size_t)i * T_c + j] = 1;
+    }
+  std::vector<int> prog(T_r, 0), head(DF_NQ, 0), cur(W), left(W, DF_NQ);
+  std::vector<long> held(W, -1);
+  for (int w = 0; w < W; ++w) cur[w] = w % DF_NQ;
+  long done = 0, round = 0;
+  while (done < nt) {
+    for (int w = 0; w < W; ++w) {
+      if (held[w] >= 0) continue;
+      while (left[w] > 0) {
+        const int len = qs[cur[w] + 1] - qs[cur[w]];
+        if (head[cur[w]] < len) {
+          held[w] = tasks[qs[cur[w]] + head[cur[w]]++];
+          break;
+        }
+        cur[w] = (cur[w] + 1) % DF_NQ;
+        --left[w];
+      }
+    }
+    bool any = false;
+    for (int k = 0; k < W; ++k) {
+      const int w = (int)((k + round) % W);
+      if (held[w] < 0) continue;
+      int i, j;
+      df_unpack((uint32_t)held[w], i, j);
+      const bool ready = prog[i] >= j && prog[j] >= j && (i == j || prog[j] >= j + 1);
+      if (!ready) continue;
+      if (prog[i] != j) return false;
+      prog[i] = j + 1;
+      held[w] = -1;
+      ++done;
+      any = true;
+      if (round & 1) break;
+    }
+    if (!any) return false;
+    ++round;
+  }
+  for (int i = 0; i < T_r; ++i)
+    if (prog[i] != std::min(i + 1, T_c)) return false;
+  return true;
+}
+
 int main() {
   long shapes = 0, bad = 0;
   // exhaustive: every id of every shape up to 160 tile columns with 0 .. 3 bordered tile rows
@@ -94,6 +153,27 @@ int main() {
           printf("BAD replay T_r=%d T_c=%d W=%d\n", T_c + border, T_c, W);
         }
       }
-  printf("shapes %ld replays %ld bad %ld\n", shapes, replays, bad);
+  long qreplays = 0;
+  for (int T_c : {1, 2, 7, 8, 9, 16, 33, 70})
+    for (int border : {0, 1, 3, 40})
+      for (int pc : {1, 2, 4, 8})
+        for (int pr : {1, 3, 8, 16, 64})
+          for (int W : {8, 9, 16, 64, 512, 5000}) {
+            ++qreplays;
+            if (!replay_queues(T_c + border, T_c, pr, pc, W)) {
+              ++bad;
+              printf("BAD queue replay T_r=%d T_c=%d pr=%d pc=%d W=%d\n", T_c + border, T_c, pr, pc, W);
+            }
+          }
+  // the production shapes: N = 32768 / 65536 with one bordered tile row, the automatic patches
+  for (int T_c : {256, 512})
+    for (int pc : {2, 4, 8}) {
+      ++qreplays;
+      if (!replay_queues(T_c + 1, T_c, 64 / pc, pc, 512)) {
+        ++bad;
+        printf("BAD queue replay (large) T_c=%d pc=%d\n", T_c, pc);
+      }
+    }
+  printf("shapes %ld replays %ld queue replays %ld bad %ld\n", shapes, replays, qreplays, bad);
   return bad ? 1 : 0;
 }

@@ -2,7 +2,9 @@
 work that must be exact, and the kernel's freedom from deadlock rests on one property of it: every input of a task belongs
 to a task with a smaller id.  Compiled for the host with g++ (tests/df_order_host.cpp): the decode exhaustively for every
 shape up to 160 tile columns and at the column boundaries of large ones, and a replay of the schedule with 1 ... 5000
-simulated workgroups, which must always run to completion with the tiles of every row becoming final in column order."""
+simulated workgroups, which must always run to completion with the tiles of every row becoming final in column order.
+Round 4: the same replay for the XCD-affine order (eight in-order queues of tile patches, df_build_queues) over patch shapes,
+bordered rows and 8 ... 5000 workgroups, plus "every tile exactly once" and "a tile row lives in one queue"."""
 import os
 import subprocess
 import tempfile
@@ -17,4 +19,7 @@ def test_task_order_is_exact_and_always_makes_progress():
         r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     last = r.stdout.strip().splitlines()[-1].split()
-    assert last[0] == "shapes" and int(last[1]) > 600 and int(last[3]) > 100 and int(last[5]) == 0, r.stdout[-500:]
+    # "shapes S replays R queue replays Q bad B": Q = replays of the XCD-affine queues (df_build_queues), workgroup w serving
+    # queue w % 8 in order and the others only once its own is exhausted
+    assert last[0] == "shapes" and int(last[1]) > 600 and int(last[3]) > 100 and int(last[6]) > 3000 and int(last[8]) == 0, \
+        r.stdout[-500:]

@@ -68,3 +68,10 @@ import test_gpu_examples as EX  # noqa: E402
 for _name in [n for n in dir(EX) if n.startswith("test_")]:
     globals()[_name] = getattr(EX, _name)
 del _name
+
+# round 4: the dense Titsias statements (oracle/titsias_dense.py) against the host mirror's VFE dispatch on the double
+import test_gpu_dense_titsias as TD  # noqa: E402
+
+for _name in [n for n in dir(TD) if n.startswith("test_")]:
+    globals()[_name] = getattr(TD, _name)
+del _name
