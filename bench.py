@@ -362,7 +362,7 @@ def main():
                             "on fp32 storage, two-stream look-ahead)"}
     multi = None
     if inproc:
-        st = np.zeros(8 + 4 * len(devs))
+        st = np.zeros(9 + 4 * len(devs))
         nst = C.c_int64()
         L.check(lib.sgp_ctx_multi_stats(ctx.handle, L.dptr(st), len(st), C.byref(nst)), "sgp_ctx_multi_stats")
         P_ = len(devs)
@@ -373,12 +373,14 @@ def main():
                  "devices": devs, "ranks": int(st[0]), "transport": ctx.transport,
                  "rccl_ranks": int(st[3]) if st[3] >= 0 else None,
                  "peer_copy_form": ("scatter + all-gather" if st[6] else "direct") if ctx.transport in ("p2p", "loopback") else None,
-                 "panel_width": int(st[4]), "panels": int(st[5]), "last_call_ms": st[1], "per_rank": per_rank,
+                 "panel_width": int(st[4]), "panels": int(st[5]), "panels_per_update_group": int(st[7]),
+                 "last_call_ms": st[1], "host_enqueue_ms": st[8 + 4 * P_], "per_rank": per_rank,
                  "transport_probe_ms": transport_probe}
         if not is_elbo:
             tf = [r["update_tflops"] for r in per_rank if r["update_tflops"]]
             per_gpu = whole_tflops / len(set(devs))
-            roofline = {"kernel": "sgp::gemm_nt_dma_kernel<1> (per-panel trailing updates of the in-library column-panel driver)",
+            roofline = {"kernel": "sgp::gemm_nt_seg_kernel (batched trailing updates of the in-library column-panel driver: one launch "
+                                  "per rank, step and class, far panels with K = a whole group of received panels)",
                         "bound": "mfma", "achieved": per_gpu, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": per_gpu / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
                         "per_rank_update_tflops": [r["update_tflops"] for r in per_rank],
@@ -502,7 +504,10 @@ def main():
         line = {
             "metric": "elbo_per_sec" if is_elbo else "logpdf_per_sec",
             "value": 1e3 / ms_per_step, "unit": "elbo/s" if is_elbo else "logpdf/s",
-            "n_gpus": len(devs) if inproc else world,
+            # physical GPUs (advisor, round 3: several loopback ranks on one GPU are ranks, not GPUs)
+            "n_gpus": len(set(devs)) if inproc else world,
+            "ranks": len(devs) if inproc else world,
+            "loopback": bool(inproc and len(set(devs)) < len(devs)),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": bc.describe(args.config) + (", host-buffer C-ABI" if is_elbo else ""),

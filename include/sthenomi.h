@@ -123,14 +123,18 @@ const char* sgp_ctx_transport(sgp_ctx* ctx);
 const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N);
 /* Figures of the last sharded factorisation of a multi-GPU context: out[0] ranks, [1] wall ms (enqueue to
  * completion), [2] transport (0 loopback, 1 peer copies, 2 RCCL), [3] ranks the RCCL communicator reports (-1: none),
- * [4] panel width, [5] panels, [6] 1 = scatter + all-gather peer copies, [7] reserved; then per rank 4 doubles:
+ * [4] panel width (of the first part; the tail may be narrower), [5] panels, [6] 1 = scatter + all-gather peer copies,
+ * [7] panels per update group; then per rank 4 doubles:
  * algorithmic flops of its trailing updates, ms from the start of its first to the end of its last update, panels it
- * factored, bytes it received.  cap >= 8 + 4 * ranks; *n_out = doubles written. */
+ * factored, bytes it received.  cap >= 8 + 4 * ranks; with cap >= 9 + 4 * ranks one more: the host time (ms) the enqueue
+ * thread spent issuing that factorisation (everything is asynchronous: it must stay below the wall time).  *n_out =
+ * doubles written. */
 int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out);
 /* Profile mode (enable != 0): the following sharded factorisations run SERIALISED, every group of launches alone on
- * the hardware and timed on the host -- per panel J {factor_ms, lookahead_update_ms, panel bytes, rest_update_ms of
- * rank 0 .. P - 1} (3 + P doubles).  With all ranks on one GPU these are the times each GPU of a node would see for
- * its own share (tools/multi_projection.py).  _get: out may be NULL to query *n_out. */
+ * the hardware and timed on the host -- per panel J {factor_ms, lookahead_update_ms, panel bytes, then for rank
+ * 0 .. P - 1 the three update classes of step J: near_a_ms, near_b_ms, far_ms} (3 + 3 P doubles; csrc/multi.hip explains
+ * the classes).  With all ranks on one GPU these are the times each GPU of a node would see for its own share
+ * (tools/multi_projection.py).  _get: out may be NULL to query *n_out. */
 int sgp_ctx_multi_profile(sgp_ctx* ctx, int enable);
 int sgp_ctx_multi_profile_get(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out);
 int sgp_ctx_destroy(sgp_ctx* ctx);
@@ -377,6 +381,24 @@ int sgp_dev_panel_factor(sgp_ctx* ctx, double* d_P, int64_t ld, int64_t m, int64
 int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp, int64_t p_row0, int64_t w,
                          double* d_C, int64_t ldc, int64_t c0, int64_t nc, int64_t m_tot,
                          void* stream);
+/* Batched form of sgp_dev_panel_update (round 4): ONE launch updates `ndst` owned packed panels, destination d with the
+ * source panels srcs[src_first .. src_first + src_count) applied in that order (a tile's contraction runs over the sources
+ * back to back, accumulators in registers: bit-identical to src_count calls of sgp_dev_panel_update, at the arithmetic
+ * intensity of one K = sum of the widths update).  A source is a factored panel, packed: element (global row r, local
+ * column k) at base[(r - row0) + k * ld]; a destination is an owned panel, packed: element (global row r, global column c)
+ * at base[(r - c0) + (c - c0) * ld], rows c0 .. m_tot.  Widths, c0 multiples of 128; row0 <= c0; nsrc <= 8, ndst any
+ * (split into launches of 16 destinations). */
+typedef struct sgp_panel_src {
+  const double* base;
+  int64_t ld, row0, w;
+} sgp_panel_src;
+typedef struct sgp_panel_dst {
+  double* base;
+  int64_t ld, c0, w;
+  int32_t src_first, src_count;
+} sgp_panel_dst;
+int sgp_dev_panel_update_batch(sgp_ctx* ctx, const sgp_panel_src* srcs, int nsrc, const sgp_panel_dst* dsts, int ndst,
+                               int64_t m_tot, void* stream);
 /* sum of squares of bordered row s over columns [0, nc) of a local panel set, accumulated
  * into d_out[s] (atomic-free: one block per s). */
 int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nc, int64_t nrows,

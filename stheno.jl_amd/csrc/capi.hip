@@ -2762,6 +2762,36 @@ extern "C" int sgp_dev_panel_factor(sgp_ctx* ctx, double* d_P, int64_t ld, int64
   return 0;
 }
 
+extern "C" int sgp_dev_panel_update_batch(sgp_ctx* ctx, const sgp_panel_src* srcs, int nsrc, const sgp_panel_dst* dsts,
+                                          int ndst, int64_t m_tot, void* stream) {
+  CHECK_ARG(ctx && (srcs || nsrc == 0) && (dsts || ndst == 0), "sgp_dev_panel_update_batch: NULL argument");
+  CHECK_ARG(nsrc >= 0 && nsrc <= SEG_MAX_SRC && ndst >= 0, "sgp_dev_panel_update_batch: at most 8 source panels");
+  if (ndst == 0 || nsrc == 0) return 0;
+  std::lock_guard<std::mutex> lk(ctx->mu);
+  SGP_HIP(hipSetDevice(ctx->device));
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  SegBatch b;
+  b.m_tot = m_tot;
+  for (int q = 0; q < nsrc; ++q) {
+    CHECK_ARG(srcs[q].base && srcs[q].w > 0 && srcs[q].w % 16 == 0 && srcs[q].w < (1 << 30),
+              "sgp_dev_panel_update_batch: bad source panel");
+    b.src[q] = SegSrc{srcs[q].base, (long)srcs[q].ld, (long)srcs[q].row0, (int)srcs[q].w};
+  }
+  for (int q = nsrc; q < SEG_MAX_SRC; ++q) b.src[q] = SegSrc{nullptr, 0, 0, 0};
+  for (int d0 = 0; d0 < ndst; d0 += SEG_MAX_DST) {
+    b.n_dst = 0;
+    for (int d = d0; d < std::min(ndst, d0 + SEG_MAX_DST); ++d) {
+      const sgp_panel_dst& D = dsts[d];
+      CHECK_ARG(D.base && D.src_first >= 0 && D.src_count >= 0 && D.src_first + D.src_count <= nsrc && D.w < (1 << 30),
+                "sgp_dev_panel_update_batch: bad destination panel");
+      if (D.src_count == 0) continue;
+      b.dst[b.n_dst++] = SegDst{D.base, (long)D.ld, (long)D.c0, (int)D.w, D.src_first, D.src_count, 0u};
+    }
+    CHECK_RC(launch_gemm_nt_seg(b, s));
+  }
+  return 0;
+}
+
 extern "C" int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp, int64_t p_row0,
                                     int64_t w, double* d_C, int64_t ldc, int64_t c0, int64_t nc,
                                     int64_t m_tot, void* stream) {

@@ -29,6 +29,7 @@
 #include "potrf_diag.h"
 #include "panel_solve.h"
 #include "df_order.h"
+#include "kstep.h"
 #include <vector>
 
 namespace sgp {
@@ -59,30 +60,6 @@ struct DfArgs {
 
 #define DF_RLX_LOAD(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-template <int KS>
-__device__ __forceinline__ void df_kstep(double (&acc)[8][4], unsigned a_addr, unsigned b_addr) {
-  double a_r[4], b_c[8];
-  constexpr int O = KS * 4 * LDS_LD * 8;   // byte offset of k-step KS inside a stage
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[0]) : "v"(a_addr), "i"(O + 0));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[1]) : "v"(a_addr), "i"(O + 128));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[2]) : "v"(a_addr), "i"(O + 256));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[3]) : "v"(a_addr), "i"(O + 384));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[0]) : "v"(b_addr), "i"(O + 0));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[1]) : "v"(b_addr), "i"(O + 32));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[2]) : "v"(b_addr), "i"(O + 64));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[3]) : "v"(b_addr), "i"(O + 96));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[4]) : "v"(b_addr), "i"(O + 128));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[5]) : "v"(b_addr), "i"(O + 160));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[6]) : "v"(b_addr), "i"(O + 192));
-  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[7]) : "v"(b_addr), "i"(O + 224));
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (asm is opaque to hipcc)
-#pragma unroll
-  for (int j = 0; j < 8; ++j)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
-}
-
 // acc += A_panel[:, 16 c0 .. 16 c1) B_panel[:, 16 c0 .. 16 c1)' for one 128 x 128 tile; the chunk pipeline of
 // gemm_nt_dma_tile (global -> LDS DMA one chunk ahead, two stages, raw barriers)
 __device__ __forceinline__ void df_contract(const double* Ag, const double* Bg, long ld, long c0, long c1,
@@ -109,10 +86,10 @@ __device__ __forceinline__ void df_contract(const double* Ag, const double* Bg, 
     if (c + 1 < c1) dma((c + 1) * DF_KB, stage ^ 1);
     const unsigned a_addr = lds_base + (unsigned)(stage * DF_STAGE * 8) + a_off;
     const unsigned b_addr = lds_base + (unsigned)(stage * DF_STAGE * 8) + b_off;
-    df_kstep<0>(acc, a_addr, b_addr);
-    df_kstep<1>(acc, a_addr, b_addr);
-    df_kstep<2>(acc, a_addr, b_addr);
-    df_kstep<3>(acc, a_addr, b_addr);
+    tile_kstep<0>(acc, a_addr, b_addr);
+    tile_kstep<1>(acc, a_addr, b_addr);
+    tile_kstep<2>(acc, a_addr, b_addr);
+    tile_kstep<3>(acc, a_addr, b_addr);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }

@@ -151,6 +151,26 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
 constexpr long SGP_DF_STATE_WORDS = 16;   // state words ahead of the per-tile-row progress counters
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
                           long* n_ids, hipStream_t s, double beta = 1.0, long scr_mul = 0);   // bench: per-workgroup phase stamps of one lower update
+// batched, segmented trailing update (gemm_nt.hip: gemm_nt_seg_kernel): destination panels, each with a range of source panels
+constexpr int SEG_MAX_SRC = 8, SEG_MAX_DST = 16;
+struct SegSrc {      // a factored column panel, packed: element (global row r, local column k) at base[(r - row0) + k * ld]
+  const double* base;
+  long ld, row0;
+  int w;
+};
+struct SegDst {      // an owned column panel, packed: element (global row r, global column c) at C[(r - c0) + (c - c0) * ldc]
+  double* C;
+  long ldc, c0;
+  int w, s_first, s_count;
+  unsigned id0;      // (filled in by the launcher)
+};
+struct SegBatch {
+  SegSrc src[SEG_MAX_SRC];
+  SegDst dst[SEG_MAX_DST];
+  int n_dst;
+  long m_tot;
+};
+int launch_gemm_nt_seg(SegBatch& b, hipStream_t s, long* n_ids = nullptr);
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,
                        double* C, long ldc, long M, long Nc, long K, double alpha, double beta,
                        hipStream_t s);

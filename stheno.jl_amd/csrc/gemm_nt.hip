@@ -36,6 +36,7 @@
 #include "common.h"
 #include "potrf_diag.h"
 #include "tilemap.h"
+#include "kstep.h"
 
 namespace sgp {
 
@@ -357,6 +358,142 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_potrf_kernel(const double*
     __syncthreads();
     potrf_diag_body<false, double, HANDOFF>(C, ldc, invd, logdet_slot, info, gcol0, prio, nullptr);
   }
+}
+
+// ---------------------------------------------------------------------------------------
+// Batched, segmented trailing update (round 4; the multi-GPU drivers: csrc/multi.hip, stheno.jl_amd/dist.py).
+// A rank of the sharded factorisation owns several PACKED column panels (each its own matrix with its own leading
+// dimension) and receives the factored panels one by one, each again a matrix of its own.  One launch per (source panel,
+// destination panel) pair made 8 small launches per rank and step at K = one panel width -- 62 TFLOP/s against the 67
+// the single-GPU schedule reaches with its K = 4096 launches, and a launch rate one host thread had to keep up for eight
+// GPUs.  This kernel takes a LIST of destination panels, each with a RANGE of source panels, in ONE launch:
+//   C_d[lower trapezoid] -= sum_{s in range(d)} P_s[rows of C_d] P_s[rows of C_d's diagonal block]'
+// contracted source after source in ascending order with the accumulators kept in registers (a tile sees k ascending
+// over the whole range: bit-identical to applying the panels one launch at a time) and the LDS-DMA pipeline running
+// across the segment boundaries (the next chunk's address simply comes from the next source).  So the owner of far-away
+// panels can apply G received panels at once (K = G x 1024: the C tiles travel once instead of G times, the per-tile
+// prologue is paid once) and all destinations of a step share a launch.
+// The tile program is gemm_nt_dma_tile's: 128 x 128 tile, 8 waves as 2 x 4, chunks of 16 through two LDS stages.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 4) void gemm_nt_seg_kernel(SegBatch b) {
+  __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
+  // destination of this workgroup: ids are dealt destination after destination (id0 ascending, multiples of 8 so that
+  // id % 8 -- the XCD -- keeps its meaning inside every destination)
+  const unsigned id = blockIdx.x;
+  int d = 0;
+  for (int q = 1; q < b.n_dst; ++q)
+    if (id >= b.dst[q].id0) d = q;
+  d = __builtin_amdgcn_readfirstlane(d);
+  const long c0 = b.dst[d].c0;
+  const long n_tr = (b.m_tot - c0) / TILE, n_tc = b.dst[d].w / TILE;
+  long tr, tc;
+  if (!tile_of_id((long)(id - b.dst[d].id0), n_tr, n_tc, 0L, tr, tc)) return;
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int w = t >> 6;
+  const int wu = __builtin_amdgcn_readfirstlane(w);
+  const int wr = w >> 2, wc = w & 3;
+  const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
+  const long ldc = b.dst[d].ldc;
+  double* Cg = b.dst[d].C + (tr * TILE + wr * 64 + l15) + (tc * TILE + wc * 32 + lq) * ldc;
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double*)smem;
+  // source cursor: the NEXT chunk to request
+  int s = b.dst[d].s_first;
+  const int s_end = s + b.dst[d].s_count;
+  long total = 0;
+  for (int q = s; q < s_end; ++q) total += b.src[q].w / KB;
+  const double *pa = nullptr, *pb = nullptr;
+  long ld = 0;
+  int left = 0;
+  auto open = [&](int q) {
+    const long r0 = c0 - b.src[q].row0;   // first stored row of the source is its own column offset
+    ld = b.src[q].ld;
+    pa = b.src[q].base + r0 + tr * TILE;
+    pb = b.src[q].base + r0 + tc * TILE;
+    left = b.src[q].w / KB;
+  };
+  auto request = [&](int stage) {
+    double* sa = smem + stage * (2 * KB * LDS_LD);
+    double* sb = sa + KB * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < KB / 8; ++i) {  // wave w moves columns w and w + 8 of both operands
+      const int col = wu + 8 * i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(pa + 2 * lane + col * ld), (lptr_t)(sa + col * LDS_LD), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(pb + 2 * lane + col * ld), (lptr_t)(sb + col * LDS_LD), 16, 0, 0);
+    }
+    pa += KB * ld;
+    pb += KB * ld;
+    if (--left == 0 && ++s < s_end) open(s);
+  };
+  double acc[8][4];
+  if (total > 0) {
+    open(s);
+    request(0);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = Cg[i * 16 + (long)(j * 4) * ldc];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] *= -1.0;   // C_new = -(-C + P P')
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  const unsigned a_off = (unsigned)((lq * LDS_LD + wr * 64 + l15) * 8);
+  const unsigned b_off = (unsigned)((KB * LDS_LD + lq * LDS_LD + wc * 32 + l3) * 8);
+  for (long c = 0; c < total; ++c) {
+    const int stage = (int)(c & 1);
+    if (c + 1 < total) request(stage ^ 1);
+    const unsigned a_addr = lds_base + (unsigned)(stage * (2 * KB * LDS_LD) * 8) + a_off;
+    const unsigned b_addr = lds_base + (unsigned)(stage * (2 * KB * LDS_LD) * 8) + b_off;
+    tile_kstep<0>(acc, a_addr, b_addr);
+    tile_kstep<1>(acc, a_addr, b_addr);
+    tile_kstep<2>(acc, a_addr, b_addr);
+    tile_kstep<3>(acc, a_addr, b_addr);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = -acc[j][i];
+}
+
+// dsts[i].id0 is filled in here.  Every width a multiple of 128, every c0 a multiple of 128 and >= the row0 of its
+// sources.  Returns the number of workgroups launched through *n_ids (may be NULL).
+int launch_gemm_nt_seg(SegBatch& b, hipStream_t s, long* n_ids) {
+  if (b.n_dst <= 0) return 0;
+  if (b.n_dst > SEG_MAX_DST || b.m_tot % TILE) {
+    set_error("gemm_nt_seg: bad batch");
+    return -1;
+  }
+  long ids = 0;
+  for (int d = 0; d < b.n_dst; ++d) {
+    const SegDst& D = b.dst[d];
+    if (D.c0 % TILE || D.w % TILE || D.w <= 0 || D.c0 + D.w > b.m_tot || D.s_first < 0 || D.s_count < 0 ||
+        D.s_first + D.s_count > SEG_MAX_SRC) {
+      set_error("gemm_nt_seg: bad destination panel");
+      return -1;
+    }
+    for (int q = D.s_first; q < D.s_first + D.s_count; ++q)
+      if (b.src[q].w % KB || b.src[q].w <= 0 || b.src[q].row0 > D.c0) {
+        set_error("gemm_nt_seg: bad source panel");
+        return -1;
+      }
+    b.dst[d].id0 = (unsigned)ids;
+    ids += tile_ids((b.m_tot - D.c0) / TILE, D.w / TILE, 0);
+  }
+  if (ids >= (1L << 31)) {
+    set_error("gemm_nt_seg: too many tiles for one launch");
+    return -1;
+  }
+  if (n_ids) *n_ids = ids;
+  hipLaunchKernelGGL(gemm_nt_seg_kernel, dim3((unsigned)ids), dim3(512), 0, s, b);
+  SGP_HIP(hipGetLastError());
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------

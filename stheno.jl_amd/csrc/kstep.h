@@ -1,0 +1,35 @@
+// One k-step (K = 4) of the 128 x 128 tile program: 12 explicit ds_read_b64 operand fetches (256 B/clk; hipcc fuses plain
+// loads into ds_read2_b64 at half that rate) and the 32 v_mfma_f64_4x4x4_4b of a wave's 64 x 32 share (gemm_nt.hip explains
+// the lane maps).  Shared by the dataflow factorisation (chol_df.hip) and the batched panel update (gemm_nt.hip:
+// gemm_nt_seg_kernel); gemm_nt_dma_tile keeps its own unrolled copy (its ISA is pinned by the bench).
+#pragma once
+#include "common.h"
+
+namespace sgp {
+
+template <int KS>
+__device__ __forceinline__ void tile_kstep(double (&acc)[8][4], unsigned a_addr, unsigned b_addr) {
+  double a_r[4], b_c[8];
+  constexpr int O = KS * 4 * LDS_LD * 8;   // byte offset of k-step KS inside a stage
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[0]) : "v"(a_addr), "i"(O + 0));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[1]) : "v"(a_addr), "i"(O + 128));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[2]) : "v"(a_addr), "i"(O + 256));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[3]) : "v"(a_addr), "i"(O + 384));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[0]) : "v"(b_addr), "i"(O + 0));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[1]) : "v"(b_addr), "i"(O + 32));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[2]) : "v"(b_addr), "i"(O + 64));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[3]) : "v"(b_addr), "i"(O + 96));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[4]) : "v"(b_addr), "i"(O + 128));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[5]) : "v"(b_addr), "i"(O + 160));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[6]) : "v"(b_addr), "i"(O + 192));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[7]) : "v"(b_addr), "i"(O + 224));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);  // keep the MFMAs below the wait (asm is opaque to hipcc)
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
+}
+
+
+}  // namespace sgp

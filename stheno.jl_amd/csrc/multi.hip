@@ -5,12 +5,30 @@
 //
 // Dense operators (logpdf, posterior, rand) -- layout: outer column panels of W columns, block-cyclic over the
 // ranks (= devices); every rank keeps its panels PACKED (panel J holds rows J0 .. m_tot only, leading dimension
-// m_tot - J0), so a factored panel is one contiguous block that travels as is -- no packing copy.  Right-looking
-// blocked Cholesky with one-panel look-ahead, driven by one host thread that only enqueues (streams per rank:
-// trailing updates / panel factorisation at high priority / panel receive):
-//   step J:  every rank updates its panels > J + 1 with panel J (update streams) while the owner of panel J + 1
-//            updates + factors it (panel stream) and the transport moves it to the others' receive buffers
-//            (double-buffered), overlapping the updates of step J.
+// m_tot - J0), so a factored panel is one contiguous block that travels as is -- no packing copy.
+// Right-looking blocked Cholesky, driven by one host thread that only enqueues.  Round 4 rebuilt the schedule around what
+// the round-3 profile showed -- at 8 ranks the CHAIN (panel factorisation -> transport -> look-ahead update of the next
+// panel -> its factorisation ...: 74 + 65 + 74 ms at N = 65536) is as long as a rank's whole share of the trailing updates
+// (182 ms), and those ran as 8 small launches per rank and step:
+//  * ONE update launch per rank and step (gemm_nt.hip: gemm_nt_seg_kernel -- a list of destination panels, each contracted
+//    over a range of source panels): 8 loopback ranks on one GPU 1893 -> 1635 ms, per-rank updates at the single-GPU
+//    kernel's rate;
+//  * the chain is PIPELINED in sub-panels (SGP_MULTI_SUBPANEL, 512 columns): a panel is factored sub-panel by sub-panel
+//    (each followed by one update of the panel's remaining columns), every finished sub-panel is sent while the next is
+//    being factored, and the owner of the next panel applies them as they land -- only the LAST sub-panel's transport
+//    and update sit between the end of one factorisation and the start of the next (projected 8-GPU step 234 -> 216 ms);
+//  * optional (both measured, neither pays at N = 65536, off by default): panel GROUPS (SGP_MULTI_GROUP = G > 1) -- with
+//    g the group of the newest factored panel J a rank's panels fall into
+//      current group g  ("near A", stream s_near)  updated with panel J as soon as it arrives          K = one panel
+//      next group g + 1 ("near B", stream s_upd)   the same, behind whatever s_upd still has queued    K = one panel
+//      groups >= g + 2  ("far",    stream s_upd)   updated ONCE per group with the whole group          K = G panels
+//    (the single-GPU schedule's deep blocking; the far launches reach the same 64 - 66 TFLOP/s as the batched K = one
+//    panel launches, and the near classes cost what the far class saves) -- and MIXED panel widths (SGP_MULTI_PANEL_TAIL
+//    < SGP_MULTI_PANEL for the last 1 - SGP_MULTI_TAIL_FRAC of the columns: the panel work is dominated by the tall
+//    early panels, so a narrow tail does not shorten it).  With G = 1 every trailing panel is "far" and every step ends a
+//    group: one launch per rank and step.  A tile sees k ascending through the same tile program whatever the grouping:
+//    for one panel layout the results are bit-identical for every G.
+// Receive buffers: a ring of 2 G + 2 per rank.
 // Transport (SGP_MULTI_TRANSPORT=rccl|p2p|auto): RCCL ncclBroadcast in one group call per panel over communicators
 // from ncclCommInitAll (librccl is dlopen'ed here, not linked), or peer copies.  xGMI is point to point (one link
 // per GPU pair), so a plain owner -> receiver copy is bound by ONE link per receiver: the peer-copy transport moves
@@ -96,18 +114,21 @@ struct Rank {
   int dev = 0;
   sgp_ctx* ctx = nullptr;        // child context (kernels + scratch of this rank)
   hipStream_t s_upd = nullptr, s_panel = nullptr, s_comm = nullptr;
-  // A rank's trailing panels are separate (packed) matrices, one update launch each; issued round-robin
-  // on a small pool of streams the tail of one launch overlaps the head of the next (a panel always uses
-  // the same pool stream, so its successive updates stay ordered).
-  static constexpr int NPOOL = 3;
-  hipStream_t s_pool[NPOOL] = {nullptr, nullptr, nullptr};
-  hipEvent_t ev_pool[NPOOL] = {nullptr, nullptr, nullptr}, ev_fork = nullptr;
-  hipEvent_t ev_upd = nullptr, ev_fact = nullptr, ev_recv[2] = {nullptr, nullptr}, ev_done = nullptr;
+  hipStream_t s_near = nullptr;   // updates of the current group's panels (the ones the chain needs next)
+  hipEvent_t ev_upd = nullptr, ev_fact = nullptr, ev_done = nullptr;
+  hipEvent_t ev_A = nullptr;      // s_near: this step's "near A" updates are done
+  hipEvent_t ev_B = nullptr;      // s_upd: this step's "near B" updates are done (recorded BEFORE a far update)
+  static constexpr int NGEV = 8;
+  hipEvent_t ev_far[NGEV] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // s_upd: the far update with group g (slot g % NGEV)
+  std::vector<hipEvent_t> ev_recv;   // [ring slot] the panel in this receive buffer has landed (all of it)
+  static constexpr int NSUB = 8;     // a panel is factored and sent in up to NSUB sub-panels (sgp_multi::sub columns each)
+  hipEvent_t ev_sub[NSUB] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // s_panel: sub-panel q of the panel being factored is final
+  std::vector<std::vector<hipEvent_t>> ev_recv_sub;   // [ring slot][q] sub-panel q has landed
   // scatter + all-gather panel transport: one incoming stream per source rank, one "piece landed" event per
   // (receive buffer, source), one "buffer free" event per receive buffer
   std::vector<hipStream_t> s_in;
-  std::vector<hipEvent_t> ev_in[2];
-  hipEvent_t ev_free[2] = {nullptr, nullptr};
+  std::vector<std::vector<hipEvent_t>> ev_in;   // [ring slot][source rank]
+  std::vector<hipEvent_t> ev_free;              // [ring slot]
   hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;   // timing: first / last trailing update of a call (sgp_ctx_multi_stats)
   bool t0_set = false;
   double upd_flops = 0.0, upd_span_ms = 0.0, recv_bytes = 0.0;
@@ -115,7 +136,7 @@ struct Rank {
   bool factored_once = false;
   double* store = nullptr;       // owned panels of a transient factorisation, packed (grow-only)
   size_t store_cap = 0;
-  double* buf[2] = {nullptr, nullptr};
+  std::vector<double*> buf;      // ring of receive buffers (sgp_multi::ring of them), m_tot x widest panel each
   size_t buf_cap = 0;
   double* d_small = nullptr;     // Y | mean | noise diag | scalars
   size_t small_cap = 0;
@@ -134,9 +155,15 @@ struct sgp_multi {
   int transport = TR_LOOPBACK;
   bool allgather = true;    // peer-copy transport: scatter + all-gather (false: one copy owner -> receiver)
   bool peer_ok = true;      // every distinct device pair has peer access enabled (else copies stage through the host)
-  long W = 1024;
+  long W = 1024;            // panel width of the first part of the columns
+  long W_tail = 0;          // ... of the last part (SGP_MULTI_PANEL_TAIL); 0 / >= W: one width (the default: measured, round 4)
+  double tail_frac = 2.0 / 3.0;   // the first tail_frac of the columns get W
+  int group = 1;            // panels per group (see the head of this file); 1 = every update at K = one panel
+  long sub = 512;           // sub-panel width of the factorisation / transport / look-ahead pipeline (0: whole panels)
+  int ring = 10;            // receive buffers per rank: 2 * group + 2
   Rccl rccl;
   double last_ms = 0.0;
+  double last_enqueue_ms = 0.0;   // host time the one enqueue thread spent issuing the last sharded factorisation
   long last_npan = 0;
   // profile mode (sgp_ctx_multi_profile): the factorisation runs serialised, every group of launches timed alone
   int profile = 0;
@@ -172,10 +199,11 @@ int grow(double** p, size_t* cap, size_t need) {
 inline long rup(long x, long m) { return (x + m - 1) / m * m; }
 
 struct Geometry {
-  long N = 0, n_pad = 0, m_tot = 0, W = 0, npan = 0, P = 1, S = 0;
-  long col0(long J) const { return J * W; }
-  long width(long J) const { return std::min(W, n_pad - J * W); }
-  long ldp(long J) const { return m_tot - J * W; }          // packed leading dimension of panel J
+  long N = 0, n_pad = 0, m_tot = 0, W = 0, npan = 0, P = 1, S = 0;   // W: the widest panel
+  std::vector<long> c0s;   // first column of every panel, and n_pad
+  long col0(long J) const { return c0s[J]; }
+  long width(long J) const { return c0s[J + 1] - c0s[J]; }
+  long ldp(long J) const { return m_tot - c0s[J]; }          // packed leading dimension of panel J
   int owner(long J) const { return (int)(J % P); }
   long local(long J) const { return J / P; }
   long ncols_owned(int i) const {
@@ -194,7 +222,15 @@ Geometry make_geometry(const sgp_multi* m, long N, long S) {
   g.n_pad = n_pad;
   g.m_tot = m_tot;
   g.W = std::min<long>(m->W, n_pad);
-  g.npan = (n_pad + g.W - 1) / g.W;
+  // wide panels up to the first panel boundary at or beyond tail_frac of the columns, narrow ones from there on
+  const long wt = (m->W_tail >= TILE && m->W_tail < g.W) ? m->W_tail : g.W;
+  const long switch_col = (long)(m->tail_frac * (double)n_pad);
+  for (long c = 0; c < n_pad;) {
+    g.c0s.push_back(c);
+    c += std::min((c < switch_col ? g.W : wt), n_pad - c);
+  }
+  g.npan = (long)g.c0s.size();
+  g.c0s.push_back(n_pad);
   g.P = (long)m->r.size();
   return g;
 }
@@ -259,17 +295,25 @@ void sgp_multi_destroy(sgp_multi* m) {
     if (k.d_work) hipFree(k.d_work);
     if (k.d_work2) hipFree(k.d_work2);
     if (k.d_info) hipFree(k.d_info);
-    for (hipEvent_t e : {k.ev_upd, k.ev_fact, k.ev_recv[0], k.ev_recv[1], k.ev_done, k.ev_fork, k.ev_pool[0], k.ev_pool[1],
-                         k.ev_pool[2], k.ev_t0, k.ev_t1, k.ev_free[0], k.ev_free[1]})
+    for (hipEvent_t e : {k.ev_upd, k.ev_fact, k.ev_done, k.ev_A, k.ev_B, k.ev_far[0], k.ev_far[1], k.ev_far[2], k.ev_far[3],
+                         k.ev_far[4], k.ev_far[5], k.ev_far[6], k.ev_far[7], k.ev_t0, k.ev_t1})
+      if (e) hipEventDestroy(e);
+    for (auto e : k.ev_recv)
+      if (e) hipEventDestroy(e);
+    for (auto e : k.ev_sub)
+      if (e) hipEventDestroy(e);
+    for (auto& v : k.ev_recv_sub)
+      for (auto e : v)
+        if (e) hipEventDestroy(e);
+    for (auto e : k.ev_free)
       if (e) hipEventDestroy(e);
     for (auto& v : k.ev_in)
       for (auto e : v)
         if (e) hipEventDestroy(e);
-    for (auto st : k.s_pool)
-      if (st) {
-        hipStreamSynchronize(st);
-        hipStreamDestroy(st);
-      }
+    if (k.s_near) {
+      hipStreamSynchronize(k.s_near);
+      hipStreamDestroy(k.s_near);
+    }
     for (auto st : k.s_in)
       if (st) {
         hipStreamSynchronize(st);
@@ -315,6 +359,15 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   m->allgather = !(bc && !strcmp(bc, "direct"));
   const char* pw = getenv("SGP_MULTI_PANEL");
   if (pw && atol(pw) >= TILE) m->W = atol(pw) / TILE * TILE;
+  const char* pt = getenv("SGP_MULTI_PANEL_TAIL");
+  if (pt) m->W_tail = atol(pt) / TILE * TILE;
+  const char* tf = getenv("SGP_MULTI_TAIL_FRAC");
+  if (tf && atof(tf) >= 0.0 && atof(tf) <= 1.0) m->tail_frac = atof(tf);
+  const char* gr = getenv("SGP_MULTI_GROUP");
+  if (gr && atoi(gr) >= 1 && atoi(gr) <= SEG_MAX_SRC) m->group = atoi(gr);
+  m->ring = 2 * m->group + 2;
+  const char* sp = getenv("SGP_MULTI_SUBPANEL");
+  if (sp) m->sub = atol(sp) / TILE * TILE;
   m->r.resize(ndev);
   for (int i = 0; i < ndev; ++i) {
     Rank& k = m->r[i];
@@ -325,17 +378,35 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     k.s_upd = k.ctx->stream2;
     if (hipSetDevice(k.dev) != hipSuccess) return fail(-2);
     if (hipStreamCreateWithFlags(&k.s_comm, hipStreamNonBlocking) != hipSuccess) return fail(-2);
-    for (hipEvent_t* e : {&k.ev_upd, &k.ev_fact, &k.ev_recv[0], &k.ev_recv[1], &k.ev_done, &k.ev_fork, &k.ev_pool[0],
-                          &k.ev_pool[1], &k.ev_pool[2], &k.ev_free[0], &k.ev_free[1]})
+    {
+      // the near stream between the panel stream (highest) and the update stream (lowest)
+      int lo = 0, hi = 0;
+      if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) return fail(-2);
+      if (hipStreamCreateWithPriority(&k.s_near, hipStreamNonBlocking, hi < lo ? hi + 1 : hi) != hipSuccess) return fail(-2);
+    }
+    for (hipEvent_t* e : {&k.ev_upd, &k.ev_fact, &k.ev_done, &k.ev_A, &k.ev_B, &k.ev_far[0], &k.ev_far[1], &k.ev_far[2],
+                          &k.ev_far[3], &k.ev_far[4], &k.ev_far[5], &k.ev_far[6], &k.ev_far[7]})
       if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return fail(-2);
-    for (auto& st : k.s_pool)
-      if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return fail(-2);
+    const int R = m->ring;
+    for (auto& e : k.ev_sub)
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(-2);
+    k.ev_recv_sub.assign(R, std::vector<hipEvent_t>(Rank::NSUB, nullptr));
+    for (int b = 0; b < R; ++b)
+      for (auto& e : k.ev_recv_sub[b])
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return fail(-2);
+    k.buf.assign(R, nullptr);
+    k.ev_recv.assign(R, nullptr);
+    k.ev_free.assign(R, nullptr);
+    k.ev_in.assign(R, std::vector<hipEvent_t>(ndev, nullptr));
+    for (int b = 0; b < R; ++b) {
+      if (hipEventCreateWithFlags(&k.ev_recv[b], hipEventDisableTiming) != hipSuccess) return fail(-2);
+      if (hipEventCreateWithFlags(&k.ev_free[b], hipEventDisableTiming) != hipSuccess) return fail(-2);
+    }
     k.s_in.assign(ndev, nullptr);
-    for (int b = 0; b < 2; ++b) k.ev_in[b].assign(ndev, nullptr);
     for (int q = 0; q < ndev; ++q) {
       if (q == i) continue;
       if (hipStreamCreateWithFlags(&k.s_in[q], hipStreamNonBlocking) != hipSuccess) return fail(-2);
-      for (int b = 0; b < 2; ++b)
+      for (int b = 0; b < R; ++b)
         if (hipEventCreateWithFlags(&k.ev_in[b][q], hipEventDisableTiming) != hipSuccess) return fail(-2);
     }
     if (hipEventCreate(&k.ev_t0) != hipSuccess || hipEventCreate(&k.ev_t1) != hipSuccess) return fail(-2);
@@ -394,7 +465,7 @@ extern "C" const char* sgp_ctx_transport(sgp_ctx* ctx) {
 
 // out[0] = ranks, [1] = wall ms of the last sharded factorisation (enqueue to completion), [2] = transport
 // (0 loopback, 1 peer copies, 2 RCCL), [3] = ranks the RCCL communicator reports (-1: none), [4] = panel width,
-// [5] = panels, [6] = 1 if the peer-copy transport runs scatter + all-gather, [7] = reserved; then per rank 4
+// [5] = panels, [6] = 1 if the peer-copy transport runs scatter + all-gather, [7] = panels per update group; then per rank 4
 // doubles: algorithmic flops of its trailing updates, ms from its first update's start to its last update's end,
 // panels factored, bytes received.
 extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out) {
@@ -414,7 +485,7 @@ extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64
   out[4] = (double)m->W;
   out[5] = (double)m->last_npan;
   out[6] = m->allgather ? 1 : 0;
-  out[7] = 0;
+  out[7] = (double)m->group;
   for (int i = 0; i < P; ++i) {
     out[8 + 4 * i] = m->r[i].upd_flops;
     out[9 + 4 * i] = m->r[i].upd_span_ms;
@@ -422,6 +493,10 @@ extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64
     out[11 + 4 * i] = m->r[i].recv_bytes;
   }
   *n_out = 8 + 4 * P;
+  if (cap >= 9 + 4 * P) {   // one more figure for callers that leave room: the host-side enqueue time of that call
+    out[8 + 4 * P] = m->last_enqueue_ms;
+    *n_out = 9 + 4 * P;
+  }
   return 0;
 }
 
@@ -429,8 +504,8 @@ extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64
 // and factorisation of a panel on its owner; each rank's remaining trailing updates) alone on the hardware and
 // timed with the host clock around a device synchronisation.  With several ranks on one GPU (loopback) these are
 // the times each GPU of a real node would see for its own share; tools/multi_projection.py turns them into a
-// critical-path projection.  sgp_ctx_multi_profile_get: per panel J  {factor_ms, lookahead_update_ms, panel bytes,
-// rest_update_ms[0 .. P)}  (3 + P doubles).
+// critical-path projection.  sgp_ctx_multi_profile_get: per panel J  {factor_ms, lookahead_update_ms, panel bytes, then per
+// rank the three update classes of step J: near_a_ms, near_b_ms, far_ms}  (3 + 3 P doubles).
 extern "C" int sgp_ctx_multi_profile(sgp_ctx* ctx, int enable) {
   M_CHECK_ARG(ctx && ctx->multi, "sgp_ctx_multi_profile: not a multi-GPU context");
   ctx->multi->profile = enable ? 1 : 0;
@@ -451,36 +526,55 @@ extern "C" int sgp_ctx_multi_profile_get(sgp_ctx* ctx, double* out, int64_t cap,
 namespace {
 
 // ---- panel transport ----------------------------------------------------------------------------------
-// move factored panel J from its owner to every other rank's receive buffer (J % 2)
-int broadcast_panel(sgp_multi* m, const Fact& F, long J) {
+// `st` of rank k waits until ring slot J % ring may be overwritten with panel J: every launch that read the slot's previous
+// panel (J - ring) is done -- its near updates (s_near: the latest ev_A is at least that late), the far update with its
+// group (s_upd: ev_far of that group, which also orders everything s_upd did before it, the near-B update included), the
+// look-ahead that used it (s_panel: ev_fact)
+int wait_slot_free(sgp_multi* m, Rank& k, long J, hipStream_t st) {
+  M_HIP(hipStreamWaitEvent(st, k.ev_A, 0));
+  M_HIP(hipStreamWaitEvent(st, k.ev_upd, 0));   // (the assembly, before the first panel)
+  if (J >= m->ring) M_HIP(hipStreamWaitEvent(st, k.ev_far[((J - m->ring) / m->group) % Rank::NGEV], 0));
+  if (k.factored_once) M_HIP(hipStreamWaitEvent(st, k.ev_fact, 0));
+  return 0;
+}
+
+// Move sub-panel q -- columns [c, c + wq) -- of factored panel J from its owner to every other rank's receive buffer (ring
+// slot J % ring), as soon as the owner's panel stream has recorded ev_sub[q].  A panel travels sub-panel by sub-panel while
+// the owner is still factoring its later columns; `last`: the whole panel has then landed (ev_recv).
+int broadcast_panel(sgp_multi* m, const Fact& F, long J, int q, long c, long wq, bool last) {
   const Geometry& g = F.g;
   const int o = g.owner(J);
-  const size_t count = (size_t)g.ldp(J) * g.width(J);
+  const size_t off = (size_t)c * g.ldp(J);
+  const size_t count = (size_t)g.ldp(J) * wq;
   const int P = (int)m->r.size();
-  const int b = (int)(J % 2);
+  const int b = (int)(J % m->ring);
   if (P == 1 && m->transport != TR_RCCL) return 0;
   Rank& root = m->r[o];
-  double* src = F.panel(o, J);
+  double* src = F.panel(o, J) + off;
+  hipEvent_t ev_final = root.ev_sub[q];
   for (int i = 0; i < P; ++i)
     if (i != o) m->r[i].recv_bytes += 8.0 * (double)count;
+  auto landed = [&](Rank& k) -> int {   // on k.s_comm, after its copies of this sub-panel
+    M_HIP(hipEventRecord(k.ev_recv_sub[b][q], k.s_comm));
+    if (last) M_HIP(hipEventRecord(k.ev_recv[b], k.s_comm));
+    return 0;
+  };
   if (m->transport == TR_RCCL) {
     for (int i = 0; i < P; ++i) {   // order the communicator streams behind the data / the buffer's readers
       Rank& k = m->r[i];
       M_HIP(hipSetDevice(k.dev));
       if (i == o) {
-        M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_fact, 0));
-      } else {
-        M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_upd, 0));
-        if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_fact, 0));
+        M_HIP(hipStreamWaitEvent(k.s_comm, ev_final, 0));
+      } else if (q == 0) {
+        M_RC(wait_slot_free(m, k, J, k.s_comm));
       }
     }
     int rc = m->rccl.GroupStart();
     for (int i = 0; i < P && rc == 0; ++i) {
       Rank& k = m->r[i];
       hipSetDevice(k.dev);
-      void* recv = (i == o) ? (void*)src : (void*)k.buf[b];
-      rc = m->rccl.Broadcast((i == o) ? (const void*)src : (const void*)k.buf[b], recv, count, NCCL_DOUBLE, o,
-                             k.comm, k.s_comm);
+      void* buf = (i == o) ? (void*)src : (void*)(k.buf[b] + off);
+      rc = m->rccl.Broadcast(buf, buf, count, NCCL_DOUBLE, o, k.comm, k.s_comm);
     }
     int rc2 = m->rccl.GroupEnd();
     if (rc || rc2) {
@@ -491,16 +585,16 @@ int broadcast_panel(sgp_multi* m, const Fact& F, long J) {
     for (int i = 0; i < P; ++i) {
       Rank& k = m->r[i];
       M_HIP(hipSetDevice(k.dev));
-      M_HIP(hipEventRecord(k.ev_recv[b], k.s_comm));
+      M_RC(landed(k));
     }
     return 0;
   }
-  auto copy = [&](Rank& dst, double* d, Rank& from, const double* s, size_t n, hipStream_t st) -> int {
+  auto copy = [&](Rank& dst, double* d, Rank& from, const double* sp, size_t n, hipStream_t st) -> int {
     if (n == 0) return 0;
     if (dst.dev == from.dev)
-      M_HIP(hipMemcpyAsync(d, s, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
+      M_HIP(hipMemcpyAsync(d, sp, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
     else
-      M_HIP(hipMemcpyPeerAsync(d, dst.dev, s, from.dev, sizeof(double) * n, st));
+      M_HIP(hipMemcpyPeerAsync(d, dst.dev, sp, from.dev, sizeof(double) * n, st));
     return 0;
   };
   if (!m->allgather || P <= 2) {
@@ -509,11 +603,10 @@ int broadcast_panel(sgp_multi* m, const Fact& F, long J) {
       if (i == o) continue;
       Rank& k = m->r[i];
       M_HIP(hipSetDevice(k.dev));
-      M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_upd, 0));                         // readers of this buffer two panels ago
-      if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_fact, 0));   // ... on the panel stream as well
-      M_HIP(hipStreamWaitEvent(k.s_comm, root.ev_fact, 0));                     // the panel is factored
-      M_RC(copy(k, k.buf[b], root, src, count, k.s_comm));
-      M_HIP(hipEventRecord(k.ev_recv[b], k.s_comm));
+      if (q == 0) M_RC(wait_slot_free(m, k, J, k.s_comm));      // readers of the panel this slot held a ring ago
+      M_HIP(hipStreamWaitEvent(k.s_comm, ev_final, 0));         // the sub-panel is final
+      M_RC(copy(k, k.buf[b] + off, root, src, count, k.s_comm));
+      M_RC(landed(k));
     }
     return 0;
   }
@@ -525,80 +618,104 @@ int broadcast_panel(sgp_multi* m, const Fact& F, long J) {
   const int np = (int)peers.size();
   const size_t align = 512;   // 4 KB slab boundaries
   const size_t per = ((count + np - 1) / np + align - 1) / align * align;
-  auto slab = [&](int c, size_t& beg, size_t& n) {
-    beg = std::min(count, (size_t)c * per);
+  auto slab = [&](int cc, size_t& beg, size_t& n) {
+    beg = std::min(count, (size_t)cc * per);
     n = std::min(count - beg, per);
   };
-  // (1) the receive buffer of every peer is free: its readers of two panels ago are done -- this rank's own updates
-  //     and, since slabs are forwarded out of it, the incoming copies the other peers made FROM it
-  for (int c = 0; c < np; ++c) {
-    Rank& k = m->r[peers[c]];
-    M_HIP(hipSetDevice(k.dev));
-    M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_upd, 0));
-    if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_fact, 0));
-    if (J >= 2)
-      for (int d = 0; d < P; ++d) {
-        if (d == peers[c]) continue;
-        M_HIP(hipStreamWaitEvent(k.s_comm, m->r[d].ev_in[b][peers[c]], 0));   // (never recorded == complete)
-      }
-    M_HIP(hipEventRecord(k.ev_free[b], k.s_comm));
-  }
+  // (1) the receive buffer of every peer is free: the readers of the panel it held a ring ago are done -- this rank's own
+  //     updates and, since slabs are forwarded out of it, the incoming copies the other peers made FROM it.  Once per
+  //     panel: the later sub-panels follow the first on the same in-order streams.
+  if (q == 0)
+    for (int cc = 0; cc < np; ++cc) {
+      Rank& k = m->r[peers[cc]];
+      M_HIP(hipSetDevice(k.dev));
+      M_RC(wait_slot_free(m, k, J, k.s_comm));
+      if (J >= m->ring)
+        for (int d = 0; d < P; ++d) {
+          if (d == peers[cc]) continue;
+          M_HIP(hipStreamWaitEvent(k.s_comm, m->r[d].ev_in[b][peers[cc]], 0));   // (never recorded == complete)
+        }
+      M_HIP(hipEventRecord(k.ev_free[b], k.s_comm));
+    }
   // (2) scatter: owner -> q_c, slab c
-  for (int c = 0; c < np; ++c) {
-    Rank& k = m->r[peers[c]];
+  for (int cc = 0; cc < np; ++cc) {
+    Rank& k = m->r[peers[cc]];
     size_t beg, n;
-    slab(c, beg, n);
+    slab(cc, beg, n);
     M_HIP(hipSetDevice(k.dev));
     hipStream_t st = k.s_in[o];
     M_HIP(hipStreamWaitEvent(st, k.ev_free[b], 0));
-    M_HIP(hipStreamWaitEvent(st, root.ev_fact, 0));
-    M_RC(copy(k, k.buf[b] + beg, root, src + beg, n, st));
+    M_HIP(hipStreamWaitEvent(st, ev_final, 0));
+    M_RC(copy(k, k.buf[b] + off + beg, root, src + beg, n, st));
     M_HIP(hipEventRecord(k.ev_in[b][o], st));
   }
   // (3) all-gather: q_d <- q_c, slab c
   for (int d = 0; d < np; ++d) {
     Rank& k = m->r[peers[d]];
     M_HIP(hipSetDevice(k.dev));
-    for (int c = 0; c < np; ++c) {
-      if (c == d) continue;
-      Rank& from = m->r[peers[c]];
+    for (int cc = 0; cc < np; ++cc) {
+      if (cc == d) continue;
+      Rank& from = m->r[peers[cc]];
       size_t beg, n;
-      slab(c, beg, n);
-      hipStream_t st = k.s_in[peers[c]];
+      slab(cc, beg, n);
+      hipStream_t st = k.s_in[peers[cc]];
       M_HIP(hipStreamWaitEvent(st, k.ev_free[b], 0));
       M_HIP(hipStreamWaitEvent(st, from.ev_in[b][o], 0));
-      M_RC(copy(k, k.buf[b] + beg, from, from.buf[b] + beg, n, st));
-      M_HIP(hipEventRecord(k.ev_in[b][peers[c]], st));
+      M_RC(copy(k, k.buf[b] + off + beg, from, from.buf[b] + off + beg, n, st));
+      M_HIP(hipEventRecord(k.ev_in[b][peers[cc]], st));
     }
-    // (4) join: the whole panel has landed
-    for (int q = 0; q < P; ++q)
-      if (q != peers[d]) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_in[b][q], 0));
-    M_HIP(hipEventRecord(k.ev_recv[b], k.s_comm));
+    // (4) join: the whole sub-panel has landed
+    for (int qq = 0; qq < P; ++qq)
+      if (qq != peers[d]) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_in[b][qq], 0));
+    M_RC(landed(k));
   }
   return 0;
 }
 
 // panel J as seen by rank i (pointer to its row J0, leading dimension ldp(J))
 const double* panel_on(sgp_multi* m, const Fact& F, long J, int i) {
-  return (F.g.owner(J) == i) ? F.panel(i, J) : m->r[i].buf[J % 2];
+  return (F.g.owner(J) == i) ? F.panel(i, J) : m->r[i].buf[J % m->ring];
 }
 
 int wait_panel(sgp_multi* m, const Fact& F, long J, int i, hipStream_t s) {
   Rank& k = m->r[i];
   if (F.g.owner(J) == i) return hipStreamWaitEvent(s, k.ev_fact, 0) == hipSuccess ? 0 : -2;
-  return hipStreamWaitEvent(s, k.ev_recv[J % 2], 0) == hipSuccess ? 0 : -2;
+  return hipStreamWaitEvent(s, k.ev_recv[J % m->ring], 0) == hipSuccess ? 0 : -2;
 }
 
-int update_panel(sgp_multi* m, const Fact& F, long J, long Jp, int i, hipStream_t s) {
+// One launch: every panel of `dsts` (owned by rank i) -= its rows of the factored panels J_first .. J_last times their
+// rows of the panel's diagonal block, in that order (gemm_nt.hip: gemm_nt_seg_kernel).  Returns the flops through *fl.
+// sub_c >= 0: ONE source, the sub_w columns from sub_c on of panel J_first (== J_last).
+int update_panels(sgp_multi* m, const Fact& F, long J_first, long J_last, const std::vector<long>& dsts, int i,
+                  hipStream_t s, double* fl, long sub_c = -1, long sub_w = 0) {
   const Geometry& g = F.g;
-  Rank& k = m->r[i];
-  const double* Pj = panel_on(m, F, J, i);
-  double* C = F.panel(i, Jp);              // row Jp0 of panel Jp
-  const long c0 = g.col0(Jp);
-  k.upd_flops += update_flops(g.m_tot - c0, g.width(Jp), g.width(J));
-  // sgp_dev_panel_update indexes C by global row: hand it the (virtual) address of global row 0
-  return sgp_dev_panel_update(k.ctx, Pj, g.ldp(J), g.col0(J), g.width(J), C - c0, g.ldp(Jp), c0, g.width(Jp),
-                              g.m_tot, (void*)s);
+  if (dsts.empty() || J_last < J_first) return 0;
+  if (J_last - J_first + 1 > SEG_MAX_SRC) {
+    set_error("multi: more source panels than one update launch takes");
+    return -1;
+  }
+  SegBatch b;
+  b.m_tot = g.m_tot;
+  long ksum = 0;
+  for (int q = 0; q < SEG_MAX_SRC; ++q) b.src[q] = SegSrc{nullptr, 0, 0, 0};
+  for (long J = J_first; J <= J_last; ++J) {
+    b.src[J - J_first] = SegSrc{panel_on(m, F, J, i), g.ldp(J), g.col0(J), (int)g.width(J)};
+    if (sub_c >= 0) {   // columns [sub_c, sub_c + sub_w) of the packed panel: same first stored row, same leading dimension
+      b.src[0].base += (size_t)sub_c * g.ldp(J);
+      b.src[0].w = (int)sub_w;
+    }
+    ksum += b.src[J - J_first].w;
+  }
+  for (size_t d0 = 0; d0 < dsts.size(); d0 += SEG_MAX_DST) {
+    b.n_dst = 0;
+    for (size_t d = d0; d < std::min(dsts.size(), d0 + (size_t)SEG_MAX_DST); ++d) {
+      const long Jp = dsts[d];
+      b.dst[b.n_dst++] = SegDst{F.panel(i, Jp), g.ldp(Jp), g.col0(Jp), (int)g.width(Jp), 0, (int)(J_last - J_first + 1), 0u};
+      if (fl) *fl += update_flops(g.m_tot - g.col0(Jp), g.width(Jp), ksum);
+    }
+    M_RC(launch_gemm_nt_seg(b, s));
+  }
+  return 0;
 }
 
 // ---- host-side inputs of one call, uploaded to every rank ----------------------------------------------
@@ -625,14 +742,14 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   const double s2 = noise_kind == SGP_NOISE_SCALAR ? noise[0] : 0.0;
   const SmallLayout L(N, S);
   const bool prof = m->profile != 0;
-  if (prof) m->prof.assign((size_t)g.npan * (3 + P), 0.0);
+  if (prof) m->prof.assign((size_t)g.npan * (3 + 3 * P), 0.0);
   const double t_begin = now_ms();
   for (int i = 0; i < P; ++i) {
     Rank& k = m->r[i];
     M_HIP(hipSetDevice(k.dev));
     if (P > 1 || m->transport == TR_RCCL) {
       size_t bc = (size_t)g.m_tot * g.W;
-      if (bc > k.buf_cap) {
+      if (bc > k.buf_cap || k.buf.empty() || !k.buf[0]) {
         M_HIP(hipDeviceSynchronize());
         for (auto& b : k.buf) {
           if (b) hipFree(b);
@@ -679,18 +796,63 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     }
     M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
   }
+  // Factor panel J on its owner's panel stream in sub-panels of `sub` columns, each sent on its way as soon as it is final
+  // (broadcast_panel) while the later columns are still being factored: sub-panel q = its own factorisation (128-column
+  // steps inside: drv_panel_factor) + ONE update of the panel's remaining columns with it (K = sub; the same ascending-k
+  // accumulation per tile as the 128-column steps of an unsplit panel: bit-identical).
+  const long SUB = (m->sub >= TILE) ? m->sub : (1L << 40);
+  auto n_sub = [&](long J) { return (int)std::min<long>(Rank::NSUB, (g.width(J) + SUB - 1) / SUB); };
+  auto sub_range = [&](long J, int q, long& c, long& wq) {
+    const int ns = n_sub(J);
+    c = (long)q * SUB;
+    wq = (q == ns - 1) ? g.width(J) - c : SUB;   // (more than NSUB sub-panels: the last takes the rest)
+  };
+  std::vector<long> self(1);
   auto factor = [&](long J) -> int {
     const int o = g.owner(J);
     Rank& k = m->r[o];
     M_HIP(hipSetDevice(k.dev));
-    M_RC(drv_panel_factor(k.ctx, F.panel(o, J), g.ldp(J), g.ldp(J), g.width(J), g.col0(J), k.d_small + L.scal,
-                          k.d_info, F.invp(o, J), k.s_panel));
-    M_HIP(hipEventRecord(k.ev_fact, k.s_panel));
+    double* Pj = F.panel(o, J);
+    const long ldp = g.ldp(J), w = g.width(J), J0 = g.col0(J);
+    const int ns = n_sub(J);
+    for (int q = 0; q < ns; ++q) {
+      long c, wq;
+      sub_range(J, q, c, wq);
+      M_HIP(hipSetDevice(k.dev));   // (broadcast_panel leaves another rank's device current)
+      M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, k.d_small + L.scal, k.d_info,
+                            F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr, k.s_panel));
+      M_HIP(hipEventRecord(k.ev_sub[q], k.s_panel));
+      if (q == ns - 1) M_HIP(hipEventRecord(k.ev_fact, k.s_panel));
+      if (!prof) M_RC(broadcast_panel(m, F, J, q, c, wq, q == ns - 1));
+      M_HIP(hipSetDevice(k.dev));
+      if (c + wq < w) {   // the rest of the panel -= (its rows of sub-panel q) (sub-panel q's rows of the rest)'
+        SegBatch b;
+        b.m_tot = g.m_tot;
+        for (int t = 0; t < SEG_MAX_SRC; ++t) b.src[t] = SegSrc{nullptr, 0, 0, 0};
+        b.src[0] = SegSrc{Pj + (size_t)c * ldp, ldp, J0, (int)wq};
+        const long r = c + wq;
+        b.n_dst = 1;
+        b.dst[0] = SegDst{Pj + r + (size_t)r * ldp, ldp, J0 + r, (int)(w - r), 0, 1, 0u};
+        M_RC(launch_gemm_nt_seg(b, k.s_panel));
+      }
+    }
     k.factored_once = true;
     k.n_factored += 1;
     return 0;
   };
+  // (profile mode times the factorisation alone: the sub-panels are sent afterwards)
+  auto broadcast_all = [&](long J) -> int {
+    const int ns = n_sub(J);
+    for (int q = 0; q < ns; ++q) {
+      long c, wq;
+      sub_range(J, q, c, wq);
+      M_RC(broadcast_panel(m, F, J, q, c, wq, q == ns - 1));
+    }
+    return 0;
+  };
   // ---- panel 0
+  const long G = m->group;
+  auto group_of = [&](long J) { return J / G; };
   {
     Rank& k = m->r[g.owner(0)];
     M_HIP(hipSetDevice(k.dev));
@@ -705,71 +867,121 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
       M_RC(sync_all(m));
       m->prof[0] = now_ms() - t0;
       m->prof[2] = 8.0 * (double)g.ldp(0) * (double)g.width(0);
+      M_RC(broadcast_all(0));
     }
-    M_RC(broadcast_panel(m, F, 0));
   }
-  // ---- right-looking sweep with one-panel look-ahead
+  for (int i = 0; i < P; ++i) {   // the near stream starts behind the assembly
+    Rank& k = m->r[i];
+    M_HIP(hipSetDevice(k.dev));
+    M_HIP(hipStreamWaitEvent(k.s_near, k.ev_upd, 0));
+    M_HIP(hipEventRecord(k.ev_A, k.s_near));
+    M_HIP(hipEventRecord(k.ev_B, k.s_upd));
+  }
+  // ---- right-looking sweep (the schedule at the head of this file)
+  std::vector<long> near_a, near_b, far, la(1);
   for (long J = 0; J < g.npan; ++J) {
-    const long nxt = J + 1;
-    for (int i = 0; i < P; ++i) {   // (a) update streams need panel J
-      M_HIP(hipSetDevice(m->r[i].dev));
-      M_RC(wait_panel(m, F, J, i, m->r[i].s_upd));
-    }
-    if (nxt < g.npan) {             // (b) look-ahead on the owner of the next panel
+    const long nxt = J + 1, gj = group_of(J);
+    const bool group_ends = (J % G == G - 1) || J == g.npan - 1;
+    if (nxt < g.npan) {             // (a) look-ahead on the owner of the next panel
       const int o1 = g.owner(nxt);
       Rank& k = m->r[o1];
       M_HIP(hipSetDevice(k.dev));
-      M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_upd, 0));      // step J - 1's updates of panel nxt
-      M_RC(wait_panel(m, F, J, o1, k.s_panel));
+      // what updated panel nxt in the previous steps: near-A launches (s_near) while it was in the current group beyond
+      // the look-ahead, near-B launches (s_upd) before that -- the last of them at the previous step if nxt is the first
+      // or second panel of its group (ev_B is recorded BEFORE a far update: this never waits for one)
+      M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_A, 0));
+      if (nxt % G == 0 || J % G == 0) M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_B, 0));
+      // ... and, before those, the far update with the group two before its own (long done unless G = 1, where that is
+      // the previous step's launch)
+      if (group_of(nxt) >= 2) M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_far[(group_of(nxt) - 2) % Rank::NGEV], 0));
       double t0 = 0, t1 = 0;
       if (prof) {
         M_RC(sync_all(m));
         t0 = now_ms();
       }
-      M_RC(update_panel(m, F, J, nxt, o1, k.s_panel));
+      // the look-ahead update follows panel J sub-panel by sub-panel as they land (K = sub each): only the last one sits
+      // between the end of J's factorisation and the start of nxt's
+      la[0] = nxt;
+      {
+        const int ns = n_sub(J);
+        const int bj = (int)(J % m->ring);
+        for (int q = 0; q < ns; ++q) {
+          long c, wq;
+          sub_range(J, q, c, wq);
+          if (g.owner(J) == o1)
+            M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_sub[q], 0));   // (one rank: its own panel)
+          else
+            M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_recv_sub[bj][q], 0));
+          M_RC(update_panels(m, F, J, J, la, o1, k.s_panel, &k.upd_flops, c, wq));
+        }
+      }
       if (prof) {
         M_RC(sync_all(m));
         t1 = now_ms();
-        m->prof[(size_t)nxt * (3 + P) + 1] = t1 - t0;
+        m->prof[(size_t)nxt * (3 + 3 * P) + 1] = t1 - t0;
       }
       M_RC(factor(nxt));
       if (prof) {
         M_RC(sync_all(m));
-        m->prof[(size_t)nxt * (3 + P) + 0] = now_ms() - t1;
-        m->prof[(size_t)nxt * (3 + P) + 2] = 8.0 * (double)g.ldp(nxt) * (double)g.width(nxt);
+        m->prof[(size_t)nxt * (3 + 3 * P) + 0] = now_ms() - t1;
+        m->prof[(size_t)nxt * (3 + 3 * P) + 2] = 8.0 * (double)g.ldp(nxt) * (double)g.width(nxt);
+        M_RC(broadcast_all(nxt));
+        M_RC(sync_all(m));
       }
-      M_RC(broadcast_panel(m, F, nxt));
-      if (prof) M_RC(sync_all(m));
     }
-    for (int i = 0; i < P; ++i) {   // (c) the rest of every rank's trailing panels, fanned over the stream pool
+    for (int i = 0; i < P; ++i) {   // (b) every rank's trailing panels: near A, near B, and -- at the end of a group -- far
       Rank& k = m->r[i];
       M_HIP(hipSetDevice(k.dev));
-      bool any = false;
-      for (long Jp = i; Jp < g.npan; Jp += P)
-        if (Jp > nxt) any = true;
+      near_a.clear();
+      near_b.clear();
+      far.clear();
+      for (long Jp = i; Jp < g.npan; Jp += P) {
+        if (Jp <= nxt) continue;
+        const long gp = group_of(Jp);
+        if (gp == gj) near_a.push_back(Jp);
+        else if (gp == gj + 1) near_b.push_back(Jp);
+        else if (group_ends) far.push_back(Jp);
+      }
       double t0 = 0;
+      auto lap = [&](int slot) -> int {   // profile mode: the class just enqueued, alone on the hardware
+        if (!prof) return 0;
+        M_RC(sync_all(m));
+        const double t = now_ms();
+        m->prof[(size_t)J * (3 + 3 * P) + 3 + 3 * i + slot] = t - t0;
+        t0 = t;
+        return 0;
+      };
       if (prof) {
         M_RC(sync_all(m));
         t0 = now_ms();
       }
-      if (any && !k.t0_set) {
+      if ((!near_a.empty() || !near_b.empty() || !far.empty()) && !k.t0_set) {
         M_HIP(hipEventRecord(k.ev_t0, k.s_upd));
         k.t0_set = true;
       }
-      M_HIP(hipEventRecord(k.ev_fork, k.s_upd));
-      for (auto st : k.s_pool) M_HIP(hipStreamWaitEvent(st, k.ev_fork, 0));
-      for (long Jp = i; Jp < g.npan; Jp += P)
-        if (Jp > nxt) M_RC(update_panel(m, F, J, Jp, i, k.s_pool[(Jp / P) % Rank::NPOOL]));
-      for (int q = 0; q < Rank::NPOOL; ++q) {
-        M_HIP(hipEventRecord(k.ev_pool[q], k.s_pool[q]));
-        M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_pool[q], 0));
+      // near A: on the near stream.  A panel enters the current group out of the next one: its last near-B update (s_upd,
+      // previous step) must be done -- ev_B is recorded BEFORE a far update, so this never waits for one.
+      if (!near_a.empty()) {
+        M_RC(wait_panel(m, F, J, i, k.s_near));
+        if (J % G == 0) {
+          M_HIP(hipStreamWaitEvent(k.s_near, k.ev_B, 0));
+          if (gj >= 2) M_HIP(hipStreamWaitEvent(k.s_near, k.ev_far[(gj - 2) % Rank::NGEV], 0));
+        }
+        M_RC(update_panels(m, F, J, J, near_a, i, k.s_near, &k.upd_flops));
       }
-      if (any) M_HIP(hipEventRecord(k.ev_t1, k.s_upd));
-      M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
-      if (prof) {
-        M_RC(sync_all(m));
-        m->prof[(size_t)J * (3 + P) + 3 + i] = now_ms() - t0;
+      M_HIP(hipEventRecord(k.ev_A, k.s_near));
+      M_RC(lap(0));
+      // near B, then far: on the update stream, in order
+      M_RC(wait_panel(m, F, J, i, k.s_upd));
+      if (!near_b.empty()) M_RC(update_panels(m, F, J, J, near_b, i, k.s_upd, &k.upd_flops));
+      M_HIP(hipEventRecord(k.ev_B, k.s_upd));
+      M_RC(lap(1));
+      if (group_ends) {
+        if (!far.empty()) M_RC(update_panels(m, F, gj * G, J, far, i, k.s_upd, &k.upd_flops));
+        M_HIP(hipEventRecord(k.ev_far[gj % Rank::NGEV], k.s_upd));
       }
+      if (!near_a.empty() || !near_b.empty() || !far.empty()) M_HIP(hipEventRecord(k.ev_t1, k.s_upd));
+      M_RC(lap(2));
     }
   }
   // ---- |L^-1 (Y - m)|^2 from the bordered rows of the owned panels
@@ -777,6 +989,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     Rank& k = m->r[i];
     M_HIP(hipSetDevice(k.dev));
     if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_fact, 0));
+    M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_A, 0));
     if (S > 0)
       for (long J = i; J < g.npan; J += P) {
         long nc = std::min(g.width(J), std::max<long>(0, N - g.col0(J)));
@@ -785,10 +998,12 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
                                 k.d_small + L.scal + 1, (void*)k.s_upd));
       }
   }
+  m->last_enqueue_ms = now_ms() - t_begin;
   // completion of the factorisation proper (statistics; the reductions follow in the caller)
   for (int i = 0; i < P; ++i) {
     Rank& k = m->r[i];
     M_HIP(hipSetDevice(k.dev));
+    M_HIP(hipStreamSynchronize(k.s_near));
     M_HIP(hipStreamSynchronize(k.s_upd));
     M_HIP(hipStreamSynchronize(k.s_panel));
     M_HIP(hipStreamSynchronize(k.s_comm));
@@ -827,7 +1042,7 @@ void drain(sgp_multi* m, std::vector<sgp_dspec*>& ds, int restore_dev) {
     hipStreamSynchronize(k.s_upd);
     hipStreamSynchronize(k.s_panel);
     hipStreamSynchronize(k.s_comm);
-    for (auto st : k.s_pool) hipStreamSynchronize(st);
+    hipStreamSynchronize(k.s_near);
     for (auto st : k.s_in)
       if (st) hipStreamSynchronize(st);
     if (i < ds.size() && ds[i]) {

@@ -52,6 +52,17 @@ class sgp_cov_spec(C.Structure):
                 ("symmetric", C.c_int32), ("reserved", C.c_int32)]
 
 
+class sgp_panel_src(C.Structure):
+    """a factored column panel, packed (sgp_dev_panel_update_batch)"""
+    _fields_ = [("base", C.c_void_p), ("ld", C.c_int64), ("row0", C.c_int64), ("w", C.c_int64)]
+
+
+class sgp_panel_dst(C.Structure):
+    """an owned column panel, packed, and the range of sources applied to it"""
+    _fields_ = [("base", C.c_void_p), ("ld", C.c_int64), ("c0", C.c_int64), ("w", C.c_int64),
+                ("src_first", C.c_int32), ("src_count", C.c_int32)]
+
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -124,6 +135,7 @@ _SIGS = {
                                        _P]),
     "sgp_dev_panel_update": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64,
                                        C.c_int64, C.c_int64, C.c_int64, _P]),
+    "sgp_dev_panel_update_batch": (C.c_int, [_P, _P, C.c_int, _P, C.c_int, C.c_int64, _P]),
     "sgp_dev_rowsumsq": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P]),
     "sgp_elbo_part_len": (C.c_int, [C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_dev_elbo_partial": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D,

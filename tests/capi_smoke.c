@@ -20,7 +20,7 @@ static const struct { const char* name; size_t fnptr_size; } table[] = {
   E(sgp_elbo), E(sgp_elbo_grad), E(sgp_elbo_grad_x), E(sgp_elbo_grad_xs), E(sgp_kernelmatrix_diag_grad_xs), E(sgp_kernelmatrix_diag_grad),
   E(sgp_kernelmatrix_diag_grad_x), E(sgp_sparse_posterior_create), E(sgp_sparse_posterior_predict),
   E(sgp_sparse_posterior_destroy), E(sgp_dspec_create), E(sgp_dspec_destroy), E(sgp_geometry),
-  E(sgp_dev_logpdf), E(sgp_dev_assemble_cols), E(sgp_dev_panel_factor), E(sgp_dev_panel_update),
+  E(sgp_dev_logpdf), E(sgp_dev_assemble_cols), E(sgp_dev_panel_factor), E(sgp_dev_panel_update), E(sgp_dev_panel_update_batch),
   E(sgp_dev_rowsumsq), E(sgp_dev_assemble_cross_rows), E(sgp_dev_rows_dot), E(sgp_dev_rows_gram), E(sgp_elbo_part_len), E(sgp_dev_elbo_partial), E(sgp_dev_elbo_finish), E(sgp_bench_mfma_f64), E(sgp_bench_hbm), E(sgp_bench_potrf), E(sgp_bench_potrf_contended), E(sgp_bench_cumask), E(sgp_bench_gemm_stamps), E(sgp_bench_gemm),
 #undef E
 };
@@ -38,6 +38,11 @@ int main(int argc, char** argv) {
   OFF(sgp_cov_spec, col_len); OFF(sgp_cov_spec, n_inputs); OFF(sgp_cov_spec, inputs);
   OFF(sgp_cov_spec, term_ptr); OFF(sgp_cov_spec, terms); OFF(sgp_cov_spec, symmetric);
   OFF(sgp_cov_spec, reserved);
+  printf("sizeof sgp_panel_src %zu\n", sizeof(sgp_panel_src));
+  OFF(sgp_panel_src, base); OFF(sgp_panel_src, ld); OFF(sgp_panel_src, row0); OFF(sgp_panel_src, w);
+  printf("sizeof sgp_panel_dst %zu\n", sizeof(sgp_panel_dst));
+  OFF(sgp_panel_dst, base); OFF(sgp_panel_dst, ld); OFF(sgp_panel_dst, c0); OFF(sgp_panel_dst, w);
+  OFF(sgp_panel_dst, src_first); OFF(sgp_panel_dst, src_count);
   printf("enum SGP_SE %d SGP_CONST %d SGP_NOISE_DENSE %d\n", SGP_SE, SGP_CONST, SGP_NOISE_DENSE);
   if (argc > 1) {
     void* h = dlopen(argv[1], RTLD_NOW | RTLD_LOCAL);

@@ -49,7 +49,9 @@ def test_inprocess_multi_gpu_line_on_loopback_ranks():
     r = _bench("--gpus", "2", "--devices", "0,0", "--config", "c1", "--steps", "2", "--warmup", "1", "--cpu-sample", "0")
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["metric"] == "logpdf_per_sec" and line["scaling"] == "strong"
+    # two loopback ranks on ONE physical GPU: n_gpus counts GPUs, `ranks` the ranks, and the line says it is a loopback run
+    assert line["n_gpus"] == 1 and line["ranks"] == 2 and line["loopback"] is True
+    assert line["metric"] == "logpdf_per_sec" and line["scaling"] == "strong"
     mg = line["multi_gpu"]
     assert mg["ranks"] == 2 and mg["devices"] == [0, 0] and mg["transport"] == "loopback"
     assert len(mg["per_rank"]) == 2 and sum(p["panels_factored"] for p in mg["per_rank"]) == mg["panels"]
@@ -67,7 +69,7 @@ def test_transport_probe_code_path_on_loopback_ranks():
     line = json.loads(r.stdout.strip().splitlines()[-1])
     probe = line["multi_gpu"]["transport_probe_ms"]
     assert set(probe) == {"p2p", "rccl"} and all(v > 0 for v in probe.values())
-    assert line["n_gpus"] == 3 and line["parity_rel"] < 1e-10
+    assert line["n_gpus"] == 1 and line["ranks"] == 3 and line["parity_rel"] < 1e-10
 
 
 @pytest.mark.gpu

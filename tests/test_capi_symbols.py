@@ -66,7 +66,8 @@ def test_header_is_plain_c_and_struct_offsets_match_ctypes(tmp_path):
     src = os.path.join(ROOT, "tests", "capi_smoke.c")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-o", exe, src, "-ldl"])
     out = subprocess.check_output([exe, P.lib.LIB_PATH], text=True)
-    mirror = {"sgp_input": P.lib.sgp_input, "sgp_term": P.lib.sgp_term, "sgp_cov_spec": P.lib.sgp_cov_spec}
+    mirror = {"sgp_input": P.lib.sgp_input, "sgp_term": P.lib.sgp_term, "sgp_cov_spec": P.lib.sgp_cov_spec,
+              "sgp_panel_src": P.lib.sgp_panel_src, "sgp_panel_dst": P.lib.sgp_panel_dst}
     seen = 0
     for ln in out.splitlines():
         w = ln.split()

@@ -246,17 +246,130 @@ def test_multi_stats_and_profile(panel128):
     out = np.zeros(64)
     n = C.c_int64()
     P.lib.check(ctx.lib.sgp_ctx_multi_stats(ctx.handle, P.lib.dptr(out), 64, C.byref(n)))
-    assert n.value == 8 + 4 * 3 and out[0] == 3 and out[1] > 0 and out[5] == 8
+    assert n.value == 9 + 4 * 3 and out[0] == 3 and out[1] > 0 and out[5] == 8
+    assert 0 < out[8 + 4 * 3] <= out[1]                            # host enqueue time of that call <= its wall time
     assert all(out[8 + 4 * i] > 0 for i in range(3))              # every rank did trailing updates
     assert sum(out[10 + 4 * i] for i in range(3)) == 8             # the 8 panels were factored exactly once
     P.lib.check(ctx.lib.sgp_ctx_multi_profile(ctx.handle, 1))
     v = _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
     assert abs(v - P.logpdf(F(x, 0.1), y)) <= 1e-11 * abs(v)
     P.lib.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, None, 0, C.byref(n)))
-    assert n.value == 8 * (3 + 3)
+    assert n.value == 8 * (3 + 3 * 3)     # per panel: factor, look-ahead update, bytes, then near A / near B / far per rank
     prof = np.zeros(n.value)
     P.lib.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, P.lib.dptr(prof), n.value, C.byref(n)))
-    prof = prof.reshape(8, 6)
+    prof = prof.reshape(8, 12)
     assert np.all(prof[:, 0] > 0) and np.all(prof[:, 2] > 0)
+    assert out[7] == 1                    # panels per update group (SGP_MULTI_GROUP, default 1)
     P.lib.check(ctx.lib.sgp_ctx_multi_profile(ctx.handle, 0))
     ctx.close()
+
+
+# ---- round 4: grouped (deep-K) far updates, mixed panel widths, the batched update entry point -------------------------
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_update_groups_give_the_same_bits_and_panel_width_mixtures_the_same_value(monkeypatch, nranks):
+    """SGP_MULTI_GROUP (panels applied per far update: K = G panels) only regroups the trailing updates: every tile still
+    sees k ascending through the same tile program, so for ONE panel layout logpdf comes out bit for bit the same whatever
+    G.  SGP_MULTI_PANEL / _TAIL / _TAIL_FRAC (mixed panel widths) change which columns a panel's log det and |z|^2 partial
+    sums cover (their order of summation), so across layouts the value agrees to rounding -- and with the single-GPU driver
+    and the oracle to 1e-10."""
+    F, x, xs, y = _problem(2900, D=3)
+    ref = orm.gppp_sum_logpdf(xs, y, 0.1)
+    single = P.logpdf(F(x, 0.1), y)
+    layouts = [{"SGP_MULTI_PANEL": "128"},
+               {"SGP_MULTI_PANEL": "256", "SGP_MULTI_PANEL_TAIL": "128"},
+               {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PANEL_TAIL": "128", "SGP_MULTI_TAIL_FRAC": "0.4"},
+               {"SGP_MULTI_PANEL": "384", "SGP_MULTI_PANEL_TAIL": "256", "SGP_MULTI_TAIL_FRAC": "0.0"}]
+    for lay in layouts:
+        vals = []
+        for G in ("1", "2", "3", "4", "8"):
+            for k in ("SGP_MULTI_PANEL", "SGP_MULTI_PANEL_TAIL", "SGP_MULTI_TAIL_FRAC", "SGP_MULTI_GROUP"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in lay.items():
+                monkeypatch.setenv(k, v)
+            monkeypatch.setenv("SGP_MULTI_GROUP", G)
+            ctx = P.lib.Context(devices=[0] * nranks)
+            for rep in range(2):     # second call: ring buffers and stores reused
+                vals.append(_with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y)))
+            Ym = np.column_stack([y, 2.0 * y - 1.0, np.cos(y)])
+            vm = _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), Ym))
+            assert vm[0] == vals[-1]
+            ctx.close()
+        assert all(v == vals[0] for v in vals), (lay, vals)
+        assert abs(vals[0] - ref) <= 1e-10 * abs(ref)
+        assert abs(vals[0] - single) <= 1e-12 * abs(ref)
+
+
+def test_posterior_and_rand_on_mixed_width_grouped_factor(monkeypatch):
+    monkeypatch.setenv("SGP_MULTI_PANEL", "256")
+    monkeypatch.setenv("SGP_MULTI_PANEL_TAIL", "128")
+    monkeypatch.setenv("SGP_MULTI_GROUP", "4")
+    F, x, xs, y, xnew = _post_problem(1700, 40)
+    p0 = P.posterior(F(x, 0.1), y)
+    m0, v0 = P.mean_and_var(p0(xnew))
+    ctx = P.lib.Context(devices=[0] * 3)
+    pm = _with_ctx(ctx, lambda: P.posterior(F(x, 0.1), y))
+    m1, v1 = _with_ctx(ctx, lambda: P.mean_and_var(pm(xnew)))
+    assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
+    assert np.abs(v1 - v0).max() <= 1e-9 * max(1.0, np.abs(v0).max())
+    Z = np.random.default_rng(3).standard_normal((len(x), 4))
+    r0 = P.rand(None, F(x, 0.1), 4, Z=Z)
+    r1 = _with_ctx(ctx, lambda: P.rand(None, F(x, 0.1), 4, Z=Z))
+    assert np.abs(r1 - r0).max() <= 1e-9 * np.abs(r0).max()
+    del pm
+    ctx.close()
+
+
+def test_batched_panel_update_entry_point_is_bit_identical_to_single_updates():
+    """sgp_dev_panel_update_batch (one launch: several packed destination panels, each contracted over a range of packed
+    source panels) against the same updates issued one sgp_dev_panel_update at a time."""
+    import ctypes as C
+    import torch
+    lib = P.lib.load()
+    ctx = P.lib.default_context()
+    rng = np.random.default_rng(11)
+    m_tot = 128 * 13
+    srcs = [(0, 256), (256, 128), (384, 384)]                 # (first column = first stored row, width) of three factored panels
+    dsts = [(768, 256, 0, 3), (1024, 128, 1, 2), (1152, 384, 0, 1), (1536, 128, 2, 1)]   # (c0, w, src_first, src_count)
+    dev = torch.device("cuda", ctx.device)
+    # packed column-major panels as flat buffers: element (r, k) at (r - row0) + k * ld
+    sbuf = [torch.from_numpy(np.asfortranarray(rng.standard_normal((m_tot - r0, w))).ravel(order="F").copy()).to(dev)
+            for r0, w in srcs]
+    dbuf0 = [torch.from_numpy(np.asfortranarray(rng.standard_normal((m_tot - c0, w))).ravel(order="F").copy()).to(dev)
+             for c0, w, _, _ in dsts]
+    one = [t.clone() for t in dbuf0]
+    bat = [t.clone() for t in dbuf0]
+    stream = torch.cuda.Stream(dev)
+    with torch.cuda.stream(stream):
+        h = stream.cuda_stream
+        for d, (c0, w, s0, sn) in enumerate(dsts):
+            for q in range(s0, s0 + sn):
+                r0, sw = srcs[q]
+                P.lib.check(lib.sgp_dev_panel_update(ctx.handle, sbuf[q].data_ptr(), m_tot - r0, r0, sw,
+                                                     one[d].data_ptr() - 8 * c0, m_tot - c0, c0, w, m_tot, h))
+        src_arr = (P.lib.sgp_panel_src * len(srcs))()
+        for q, (r0, sw) in enumerate(srcs):
+            src_arr[q] = P.lib.sgp_panel_src(sbuf[q].data_ptr(), m_tot - r0, r0, sw)
+        dst_arr = (P.lib.sgp_panel_dst * len(dsts))()
+        for d, (c0, w, s0, sn) in enumerate(dsts):
+            dst_arr[d] = P.lib.sgp_panel_dst(bat[d].data_ptr(), m_tot - c0, c0, w, s0, sn)
+        P.lib.check(lib.sgp_dev_panel_update_batch(ctx.handle, src_arr, len(srcs), dst_arr, len(dsts), m_tot, h))
+    stream.synchronize()
+    for d, (c0, w, _, _) in enumerate(dsts):
+        a = one[d].cpu().numpy().reshape((m_tot - c0, w), order="F")
+        b = bat[d].cpu().numpy().reshape((m_tot - c0, w), order="F")
+        orig = dbuf0[d].cpu().numpy().reshape((m_tot - c0, w), order="F")
+        # lower trapezoid (tile rows >= tile columns) updated, identical bits; the strictly upper tiles untouched
+        low = (np.arange(m_tot - c0)[:, None] // 128) >= (np.arange(w)[None, :] // 128)
+        assert np.array_equal(a[low], b[low])
+        assert np.array_equal(b[~low], orig[~low])
+        assert not np.array_equal(b[low], orig[low])
+    # and against NumPy for one destination
+    c0, w, s0, sn = dsts[0]
+    want = dbuf0[0].cpu().numpy().reshape((m_tot - c0, w), order="F").copy()
+    for q in range(s0, s0 + sn):
+        r0, sw = srcs[q]
+        Pq = sbuf[q].cpu().numpy().reshape((m_tot - r0, sw), order="F")
+        want -= Pq[c0 - r0:, :] @ Pq[c0 - r0:c0 - r0 + w, :].T
+    got = bat[0].cpu().numpy().reshape((m_tot - c0, w), order="F")
+    low = (np.arange(m_tot - c0)[:, None] // 128) >= (np.arange(w)[None, :] // 128)
+    assert np.abs(got[low] - want[low]).max() <= 1e-11 * np.abs(want).max()

@@ -1,6 +1,7 @@
 """Serialised per-panel timings of the sharded factorisation with P loopback ranks on ONE GPU (sgp_ctx_multi_profile):
 what each GPU of a P-GPU node would spend on its own share -- input of tools/multi_projection.py.
-usage: python tools/gpu_multi_profile.py <config> <P> <out.json> [panel]"""
+usage: python tools/gpu_multi_profile.py <config> <P> <out.json> [panel]   (SGP_MULTI_GROUP / _PANEL_TAIL / _TAIL_FRAC from the
+environment)"""
 import ctypes as C
 import json
 import os
@@ -36,7 +37,7 @@ def call():
 
 call()                       # warm-up (allocations)
 overlapped_ms = call()       # the normal (overlapped) schedule with P ranks sharing the one GPU
-st = np.zeros(8 + 4 * P)
+st = np.zeros(9 + 4 * P)
 n = C.c_int64()
 L.check(ctx.lib.sgp_ctx_multi_stats(ctx.handle, L.dptr(st), len(st), C.byref(n)))
 L.check(ctx.lib.sgp_ctx_multi_profile(ctx.handle, 1))
@@ -44,12 +45,25 @@ serial_ms = call()
 L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, None, 0, C.byref(n)))
 prof = np.zeros(n.value)
 L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, L.dptr(prof), n.value, C.byref(n)))
-prof = prof.reshape(-1, 3 + P)
+prof = prof.reshape(-1, 3 + 3 * P)
 g = bc.golden(cfg)
-json.dump({"config": cfg, "N": N, "ranks": P, "panel_width": int(st[4]), "panels": int(st[5]),
+n_pad = (N + 127) // 128 * 128
+m_tot = n_pad + 128
+sub = int(os.environ.get("SGP_MULTI_SUBPANEL", "256")) // 128 * 128
+widths, c0 = [], 0
+for b in prof[:, 2]:                       # panel bytes = 8 * (m_tot - col0) * width
+    w = int(round(b / 8.0 / (m_tot - c0)))
+    widths.append(w)
+    c0 += w
+nsub = [min(8, -(-w // sub)) if sub >= 128 else 1 for w in widths]
+json.dump({"config": cfg, "N": N, "ranks": P, "panel_width": int(st[4]), "panels": int(st[5]), "group": int(st[7]),
+           "subpanel": sub, "widths": widths, "nsub": nsub,
+           "layout": "per panel: factor_ms, lookahead_update_ms, panel_bytes, then per rank near_a_ms, near_b_ms, far_ms",
            "logpdf": float(res[0]), "parity_rel": None if g is None else abs(res[0] - g["logpdf"]) / abs(g["logpdf"]),
-           "one_gpu_overlapped_ms": overlapped_ms, "one_gpu_serialised_ms": serial_ms,
-           "columns": ["factor_ms", "lookahead_update_ms", "panel_bytes"] + [f"rest_update_ms_rank{i}" for i in range(P)],
+           "one_gpu_overlapped_ms": overlapped_ms, "one_gpu_serialised_ms": serial_ms, "host_enqueue_ms": float(st[8 + 4 * P]),
+           "columns": ["factor_ms", "lookahead_update_ms", "panel_bytes"] +
+                      [f"{c}_ms_rank{i}" for i in range(P) for c in ("near_a", "near_b", "far")],
            "per_panel": prof.tolist()}, open(out, "w"))
-print(cfg, "P", P, "overlapped", round(overlapped_ms, 1), "serialised", round(serial_ms, 1), "factor sum", round(prof[:, 0].sum(), 1),
-      "la sum", round(prof[:, 1].sum(), 1), "rest sum per rank", np.round(prof[:, 3:].sum(axis=0), 1).tolist())
+print(cfg, "P", P, "host enqueue", round(float(st[8 + 4 * P]), 1), "overlapped", round(overlapped_ms, 1), "serialised", round(serial_ms, 1), "factor sum", round(prof[:, 0].sum(), 1),
+      "la sum", round(prof[:, 1].sum(), 1), "update sum per rank (near a + near b + far)",
+      np.round(prof[:, 3:].reshape(len(prof), P, 3).sum(axis=(0, 2)), 1).tolist())

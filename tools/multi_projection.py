@@ -1,27 +1,39 @@
 """8-GPU critical-path projection of the sharded factorisation from per-panel timings measured with P loopback ranks on
-one GPU (tools/gpu_multi_profile.py -> JSON).  Model (one-panel look-ahead, as csrc/multi.hip schedules it):
+one GPU (tools/gpu_multi_profile.py -> JSON; round-4 layout: per panel factor_ms, lookahead_update_ms, panel_bytes, then
+per rank near_a_ms, near_b_ms, far_ms -- csrc/multi.hip explains the three update classes).
 
-  fact_done[J+1] = max(recv[J] at owner(J+1), upd_done[J-1] at owner(J+1)) + lookahead_update[J+1] + factor[J+1]
-  recv[J+1][i]   = fact_done[J+1] + transport(bytes[J+1])                (i != owner; the owner has it at once)
-  upd_done[J][i] = max(recv[J][i], upd_done[J-1][i], [owner(J+1): its panel stream shares the GPU]) + rest_update[J][i]
+Every GPU is ONE server: its launches run one at a time, in the order the streams allow, the panel stream (look-ahead
+update + factorisation) first, then the near stream, then the update stream -- a launch of a higher stream that becomes
+ready while a lower one runs pushes the lower one's completion back by its own duration (dispatch priority; `contend`
+additionally stretches the look-ahead work while the GPU has other work, 1.3 = what the single-GPU look-ahead measured).
+This is more conservative than the round-3 model, which let the look-ahead overlap the owner's updates for free.
+Dependencies as csrc/multi.hip enqueues them (G = panels per group, g = J // G):
 
-transport(bytes): scatter + all-gather over point-to-point xGMI links of `link` GB/s per direction -- two phases of
-bytes / (P - 1) each over disjoint links: 2 * bytes / ((P - 1) * link); direct copy: bytes / link (every receiver
-pulls the whole panel over its one link to the owner, the owner's P - 1 egress links run in parallel).
-On the owner of the next panel the look-ahead update + factorisation share the GPU with its rest updates; `contend`
-multiplies both while they overlap (1.0 = perfect overlap, the measured single-GPU figure is ~1.3 for the updates).
+  panel J is factored, sent and applied to panel J+1 in nsub[J] sub-panels (the pipeline of csrc/multi.hip: factor): sub-panel
+  q is final at start + (q + 1) fac / nsub, lands transport / nsub later (the pieces queue on the links), and the look-ahead
+  update with it (la / nsub) starts when it has landed and the previous one is done -- only the last piece's transport and
+  update sit between the end of J's factorisation and the start of J+1's
+  look-ahead(J+1) on owner(J+1): needs near_a(J-1) there (and near_b(J-1) for the first two panels of a group)
+  recv[J+1][i] = the last sub-panel of J+1 has landed          (i != owner)
+  near_a(J)[i]: needs recv[J][i] (+ near_b(J-1)[i] at the first step of a group)       -- the current group's panels
+  near_b(J)[i]: needs recv[J][i], after everything earlier on the update stream          -- the next group's panels
+  far(g)[i]   : at the last step of group g, after near_b of that step                   -- groups >= g + 2, K = G panels
+
+transport(bytes): scatter + all-gather over point-to-point xGMI links of `link` GB/s per direction: 2 * bytes / ((P - 1) *
+link); direct copy: bytes / link.
 usage: python tools/multi_projection.py profile.json [link_GBps=77] [contend=1.0]"""
 import json
 import sys
 
 
-def project(prof, P, link_gbps, form, contend):
+def project(prof, P, link_gbps, form, contend, free_overlap=False):
     rows = prof["per_panel"]
+    G = int(prof.get("group", 1))
     npan = len(rows)
     fac = [r[0] for r in rows]
     la = [r[1] for r in rows]
     byt = [r[2] for r in rows]
-    rest = [r[3:3 + P] for r in rows]
+    cls = [[r[3 + 3 * i: 6 + 3 * i] for i in range(P)] for r in rows]   # [J][i] = (near_a, near_b, far)
 
     def transport(b):
         if P == 1:
@@ -31,30 +43,89 @@ def project(prof, P, link_gbps, form, contend):
         return b / (link_gbps * 1e9) * 1e3
 
     owner = lambda J: J % P
-    upd_done = [0.0] * P                  # end of each rank's update stream
-    fact_done = fac[0]
-    recv = [fact_done + (0.0 if i == owner(0) else transport(byt[0])) for i in range(P)]
-    exposed_transport = 0.0
-    panel_busy = [0.0] * P
+    t_upd = [0.0] * P      # the update stream of rank i is free
+    t_near = [0.0] * P     # the near stream
+    t_pan = [0.0] * P      # the panel stream
+    ev_a = [0.0] * P       # completion of the latest near-A launch
+    ev_b = [0.0] * P       # ... near-B
+    busy = [0.0] * P
+
+    def run(i, stream, ready, dur):
+        """a launch of `dur` ms on `stream` of GPU i that may start at `ready`: returns its end; lower streams that are busy
+        at that time are pushed back by `dur` (dispatch priority), idle ones cannot start before it ends"""
+        nonlocal t_upd, t_near, t_pan
+        busy[i] += dur
+        if stream == "panel":
+            start = max(ready, t_pan[i])
+            end = start + dur
+            t_pan[i] = end
+            if free_overlap:      # the round-3 model: the look-ahead work costs the owner's other streams nothing
+                return end
+            for t in (t_near, t_upd):
+                t[i] = t[i] + dur if t[i] > start else max(t[i], end)
+            return end
+        if stream == "near":
+            start = max(ready, t_near[i], 0.0 if free_overlap else t_pan[i])
+            end = start + dur
+            t_near[i] = end
+            t_upd[i] = t_upd[i] + dur if t_upd[i] > start else max(t_upd[i], end)
+            return end
+        start = max(ready, t_upd[i], t_near[i], 0.0 if free_overlap else t_pan[i])
+        end = start + dur
+        t_upd[i] = end
+        return end
+
+    nsub = prof.get("nsub") or [1] * npan
+
+    def factor_and_send(J, start_ready, scale):
+        """factor panel J on its owner from `start_ready` on; returns (end of the factorisation, arrival time of every
+        sub-panel at the other ranks)"""
+        o = owner(J)
+        ns = nsub[J]
+        piece = fac[J] * scale / ns
+        arr, t, link_free = [], start_ready, 0.0
+        for q in range(ns):
+            t = run(o, "panel", t, piece)
+            link_free = max(t, link_free) + transport(byt[J]) / ns
+            arr.append(link_free)
+        return t, arr
+
+    fact_done, arr = factor_and_send(0, 0.0, 1.0)
+    recv = [fact_done if i == owner(0) else arr[-1] for i in range(P)]
+    waited = 0.0
     for J in range(npan):
         nxt = J + 1
+        new_recv = None
         if nxt < npan:
             o = owner(nxt)
-            start = max(recv[o], upd_done[o] if J > 0 else 0.0)
-            fd = start + (la[nxt] + fac[nxt]) * contend
-            panel_busy[o] += (la[nxt] + fac[nxt]) * contend
-            new_recv = [fd + (0.0 if i == o else transport(byt[nxt])) for i in range(P)]
+            ready = max(ev_a[o], ev_b[o] if (nxt % G == 0 or J % G == 0) else 0.0)
+            loaded = t_upd[o] > recv[o] or t_near[o] > recv[o]
+            c = contend if loaded else 1.0
+            t = ready
+            for q in range(nsub[J]):       # the look-ahead update follows the sub-panels of J as they land
+                landed = arr[q] if o != owner(J) else fact_done
+                t = run(o, "panel", max(t, landed), la[nxt] * c / nsub[J])
+            fd, new_arr = factor_and_send(nxt, t, c)
+            new_recv = [fd if i == o else new_arr[-1] for i in range(P)]
         for i in range(P):
-            s = max(recv[i], upd_done[i])
-            c = contend if (nxt < npan and i == owner(nxt)) else 1.0
-            upd_done[i] = s + rest[J][i] * c
-        if nxt < npan:
-            # how long the slowest rank waited for the panel beyond the end of its own work
-            exposed_transport += max(0.0, max(new_recv[i] - upd_done[i] for i in range(P)))
+            a, b, f = cls[J][i]
+            if a > 0:
+                ev_a[i] = run(i, "near", max(recv[i], ev_b[i] if J % G == 0 else 0.0), a)
+            idle_until = max(t_upd[i], t_near[i], t_pan[i])
+            if b > 0 or f > 0:
+                waited += max(0.0, recv[i] - idle_until)
+            if b > 0:
+                ev_b[i] = run(i, "upd", recv[i], b)
+            else:
+                ev_b[i] = max(ev_b[i], min(t_upd[i], recv[i]))
+            if f > 0:
+                run(i, "upd", recv[i], f)
+        if new_recv is not None:
             recv = new_recv
             fact_done = fd
-    total = max(max(upd_done), fact_done)
-    return total, exposed_transport
+            arr = new_arr
+    total = max(max(t_upd), max(t_near), max(t_pan), fact_done)
+    return total, waited, max(busy)
 
 
 def main():
@@ -63,18 +134,25 @@ def main():
     contend = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
     P = prof["ranks"]
     rows = prof["per_panel"]
-    one_gpu = sum(r[0] + r[1] + sum(r[3:3 + P]) for r in rows)
-    print(f"config {prof['config']}  N {prof['N']}  ranks {P}  panels {prof['panels']} x {prof['panel_width']}")
+    if len(rows[0]) != 3 + 3 * P:
+        raise SystemExit("this is a round-3 profile (3 + P columns): use the tool of that round (git show 14a0e1b:tools/multi_projection.py)")
+    one_gpu = sum(r[0] + r[1] + sum(r[3:]) for r in rows)
+    per_rank = [[sum(r[3 + 3 * i + c] for r in rows) for c in range(3)] for i in range(P)]
+    print(f"config {prof['config']}  N {prof['N']}  ranks {P}  panels {prof['panels']} (first width {prof['panel_width']}), "
+          f"{prof.get('group', 1)} panels per update group")
     print(f"sum of all serialised kernel groups (= one GPU doing everything, no overlap): {one_gpu:.1f} ms")
     print(f"panel factorisations {sum(r[0] for r in rows):.1f} ms, look-ahead updates {sum(r[1] for r in rows):.1f} ms, "
-          f"rest updates per rank {[round(sum(r[3 + i] for r in rows), 1) for i in range(P)]} ms, "
           f"bytes per receiver {sum(r[2] for r in rows) / 1e9:.2f} GB")
+    print("updates per rank, ms (near a / near b / far): " + "  ".join("%.1f/%.1f/%.1f" % tuple(v) for v in per_rank))
     for form in ("allgather", "direct"):
         for c in sorted({contend, 1.0, 1.3}):
-            t, ex = project(prof, P, link, form, c)
-            print(f"  {form:9s} link {link:.0f} GB/s contend {c:.2f}: projected {t:8.1f} ms  (waiting for panels: {ex:6.1f} ms)")
-    t_inf, _ = project(prof, P, 1e9, "direct", 1.0)
-    print(f"  infinite link bandwidth: {t_inf:.1f} ms  -> compute/critical-path bound of this schedule")
+            t, w, b = project(prof, P, link, form, c)
+            t3, _, _ = project(prof, P, link, form, c, free_overlap=True)
+            print(f"  {form:9s} link {link:.0f} GB/s contend {c:.2f}: projected {t:8.1f} ms  (busiest GPU {b:6.1f} ms of work; "
+                  f"update streams idle waiting for panels: {w:6.1f} ms summed over ranks)   "
+                  f"[round-3 model, look-ahead overlaps the owner's updates for free: {t3:.1f} ms]")
+    t_inf, _, _ = project(prof, P, 1e9, "direct", 1.0)
+    print(f"  infinite link bandwidth: {t_inf:.1f} ms  -> compute / critical-path bound of this schedule")
 
 
 if __name__ == "__main__":
