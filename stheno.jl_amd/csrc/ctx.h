@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "../../include/sthenomi.h"
+#include "../../include/sthenomi_bench.h"
 
 #include <mutex>
 #include <vector>

@@ -4,6 +4,11 @@ panels travel between ranks with torch.distributed broadcast (backend "nccl" == 
 on the MI355X node; "gloo" in the CPU tests), scalars (logdet, |L^-1 (y - m)|^2, info) with one
 all-reduce at the end.  SURVEY.md 8e / DESIGN.md section 6.
 
+Round 4 (the schedule of csrc/multi.hip, same building blocks): a rank's trailing panels are updated by ONE launch
+per step (sgp_dev_panel_update_batch), and the chain factorisation -> broadcast -> look-ahead update is pipelined in
+sub-panels of `SUBPANEL` columns: a panel is factored sub-panel by sub-panel, each broadcast as soon as it is final
+while the next is being factored, and the owner of the next panel applies them as they land.
+
 The reference has no distributed path at all: this is the MI355X-side
 scaling of `logpdf(f(X, s2), y)` (AbstractGPs.logpdf [EXT], Appendix A.3).
 
@@ -23,6 +28,7 @@ from . import lib as _lib
 
 LOG2PI = math.log(2.0 * math.pi)
 TILE = 128
+SUBPANEL = 512   # sub-panel width of the factor / broadcast / look-ahead pipeline (multiple of 128; >= W: whole panels)
 
 
 def geometry(N, ncols):
@@ -189,6 +195,21 @@ class HipOps:
         rc = self.lib.sgp_dev_panel_update(self.ctx.handle, Pt.data_ptr() + 8 * p_off, ldp, J0, w,
                                            A.data_ptr() + 8 * (off - c0), ld, c0, nc, m_tot, self.stream())
         _lib.check(rc, "sgp_dev_panel_update")
+
+    def panel_update_batch(self, srcs, dsts, m_tot):
+        """ONE launch: every destination (tensor, offset, ld, c0, w, src_first, src_count) -= its rows of the sources
+        (tensor, offset, ld, row0, w) of its range, applied in order, times their rows of its diagonal block (the lower
+        trapezoid: tile rows >= tile columns).  Offsets address the first STORED element of a packed panel."""
+        if not srcs or not dsts:
+            return
+        sa = (_lib.sgp_panel_src * len(srcs))()
+        for q, (t, off, ld, row0, w) in enumerate(srcs):
+            sa[q] = _lib.sgp_panel_src(t.data_ptr() + 8 * off, ld, row0, w)
+        da = (_lib.sgp_panel_dst * len(dsts))()
+        for d, (t, off, ld, c0, w, s0, sn) in enumerate(dsts):
+            da[d] = _lib.sgp_panel_dst(t.data_ptr() + 8 * off, ld, c0, w, s0, sn)
+        rc = self.lib.sgp_dev_panel_update_batch(self.ctx.handle, sa, len(srcs), da, len(dsts), m_tot, self.stream())
+        _lib.check(rc, "sgp_dev_panel_update_batch")
 
     def rowsumsq(self, A, off, ld, nc, nrows, out):
         rc = self.lib.sgp_dev_rowsumsq(self.ctx.handle, A.data_ptr() + 8 * off, ld, nc, nrows, out.data_ptr(),
@@ -363,23 +384,53 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, a
             return A, lay.offset(J)
         return bufs[J % 2], 0
 
-    def bcast(J):
+    sub_w = max(TILE, SUBPANEL // TILE * TILE)
+
+    def subs(J):
+        """sub-panels (first column inside the panel, width) of panel J"""
+        w = lay.width(J)
+        return [(c, min(sub_w, w - c)) for c in range(0, w, sub_w)]
+
+    def bcast_sub(J, c, wq):
+        """columns [c, c + wq) of panel J: a contiguous slice of the packed panel (all its stored rows)"""
         if not need_bufs:
             return None
+        lo, hi = c * lay.ld(J), (c + wq) * lay.ld(J)
         if lay.owner(J) == rank:     # straight out of the packed storage: no packing copy
-            t = A[lay.offset(J): lay.offset(J) + lay.count(J)]
+            t = A[lay.offset(J) + lo: lay.offset(J) + hi]
         else:
-            t = bufs[J % 2][: lay.count(J)]
+            t = bufs[J % 2][lo:hi]
         return dist.broadcast(t, src=_global_rank(group, lay.owner(J)), group=group, async_op=True)
 
-    def factor(J):
-        ops.panel_factor(A, lay.offset(J), lay.ld(J), lay.ld(J), lay.col0(J), lay.width(J), logdet, info)
+    def receive(J):
+        return [bcast_sub(J, c, wq) for c, wq in subs(J)]
 
-    def update(J, Jp):
-        """local panel Jp (> J) -= P_J[rows] P_J[cols Jp]'"""
+    def factor_and_send(J):
+        """(owner, panel stream) factor panel J sub-panel by sub-panel; every finished sub-panel is broadcast at once and
+        the panel's remaining columns are updated with it (K = the sub-panel's width; a tile sees k ascending exactly as
+        in the 128-column steps of an unsplit panel)"""
+        works = []
+        ld, w, J0, off = lay.ld(J), lay.width(J), lay.col0(J), lay.offset(J)
+        for c, wq in subs(J):
+            ops.panel_factor(A, off + c + c * ld, ld, ld - c, J0 + c, wq, logdet, info)
+            works.append(bcast_sub(J, c, wq))
+            r = c + wq
+            if r < w:
+                ops.panel_update_batch([(A, off + c * ld, ld, J0, wq)],
+                                       [(A, off + r + r * ld, ld, J0 + r, w - r, 0, 1)], m_tot)
+        return works
+
+    def source(J, c=0, wq=None):
         Pt, p_off = panel(J)
-        ops.panel_update(Pt, p_off, lay.ld(J), lay.col0(J), lay.width(J), A, lay.offset(Jp), lay.ld(Jp),
-                         lay.col0(Jp), lay.width(Jp), m_tot)
+        return (Pt, p_off + c * lay.ld(J), lay.ld(J), lay.col0(J), lay.width(J) if wq is None else wq)
+
+    def dest(Jp):
+        return (A, lay.offset(Jp), lay.ld(Jp), lay.col0(Jp), lay.width(Jp), 0, 1)
+
+    def wait_all(works):
+        for wk in works:
+            if wk is not None:
+                wk.wait()
 
     # 2. right-looking factorisation with one-panel look-ahead.  Two streams per rank: the owner of
     # the next panel updates + factors + broadcasts it on the panel stream while its other
@@ -387,45 +438,41 @@ def _dist_logpdf(ops, ds, N, y, mean, sigma2, world, rank, group, W, A, stats, a
     #   "upd"   : update-stream work of the previous step (and the assembly) is complete
     #   "panel" : the panel this rank just factored is final in its (packed) storage
     ops.record("upd")
-    work = None
     if lay.owner(0) == rank:
         with ops.panel_context():
             ops.wait("upd")
-            factor(0)
+            works = factor_and_send(0)
             ops.record("panel")
-            work = bcast(0)
     else:
-        work = bcast(0)
+        works = receive(0)
     for J in range(lay.n_panels):
         nxt = J + 1
-        # (a) the update stream needs panel J (own storage on its owner, bufs[J % 2] elsewhere)
-        if work is not None:
-            work.wait()
-        if lay.owner(J) == rank:
-            ops.wait("panel")
-        # (b) look-ahead on the owner of the next panel
-        work_next = None
+        # (a) look-ahead on the owner of the next panel: the update follows panel J sub-panel by sub-panel
+        works_next = None
         if nxt < lay.n_panels:
             if lay.owner(nxt) == rank:
                 with ops.panel_context():
                     ops.wait("upd")            # step J-1's updates of panel nxt are done
-                    if work is not None:
-                        work.wait()            # panel J has landed (also for this stream)
-                    update(J, nxt)
-                    factor(nxt)
+                    if lay.owner(J) == rank:
+                        ops.wait("panel")
+                    for (c, wq), wk in zip(subs(J), works):
+                        if wk is not None:
+                            wk.wait()          # this sub-panel has landed
+                        ops.panel_update_batch([source(J, c, wq)], [dest(nxt)], m_tot)
+                    works_next = factor_and_send(nxt)
                     ops.record("panel")
-                    work_next = bcast(nxt)     # ordered after the factorisation on the panel stream
             else:
-                work_next = bcast(nxt)         # receive: ordered after step J-1's readers of that buffer
-        # (c) the rest of this rank's trailing panels
-        ops.fork_updates()
-        for Jp in lay.mine:
-            if Jp > nxt:
-                with ops.pool_context(lay.local_index(Jp)):
-                    update(J, Jp)
-        ops.join_updates()
+                works_next = receive(nxt)      # ordered after step J-1's readers of that buffer
+        # (b) the update stream needs all of panel J (own storage on its owner, bufs[J % 2] elsewhere); the rest of this
+        # rank's trailing panels in ONE launch
+        wait_all(works)
+        if lay.owner(J) == rank:
+            ops.wait("panel")
+        rest = [dest(Jp) for Jp in lay.mine if Jp > nxt]
+        if rest:
+            ops.panel_update_batch([source(J)], rest, m_tot)
         ops.record("upd")
-        work = work_next
+        works = works_next
     with ops.panel_context():
         pass
     ops.wait("panel")   # join: everything the panel stream did is visible to the update stream

@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include "../include/sthenomi.h"
+#include "../include/sthenomi_bench.h"   /* the bench hooks: their own header, resolved in the same library */
 
 #define OFF(T, f) printf("offset " #T "." #f " %zu\n", offsetof(T, f))
 

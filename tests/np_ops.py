@@ -87,8 +87,8 @@ class NumpyOps:
 
     def panel_factor(self, A, off, ld, m, J0, w, logdet, info):
         self.calls.append(("factor", J0, w))
-        assert m == ld
-        P = self._mat(A, off, ld, w)
+        assert m <= ld          # (m < ld: a sub-panel of a packed panel -- only its first m rows are the panel's)
+        P = self._strided(A, off, ld, m, w)
         D = np.tril(P[:w, :w]) + np.tril(P[:w, :w], -1).T
         try:
             L = np.linalg.cholesky(D)
@@ -106,6 +106,26 @@ class NumpyOps:
         P[:w, :w] = L
         P[w:, :] = np.linalg.solve(L, P[w:, :].T).T
         logdet[0] += 2.0 * np.log(np.diag(L)).sum()
+
+    @staticmethod
+    def _strided(A, off, ld, nrows, ncols):
+        """writable (nrows, ncols) view: element (r, k) at A[off + r + k * ld]"""
+        a = A.numpy()
+        return np.lib.stride_tricks.as_strided(a[off:], shape=(nrows, ncols), strides=(a.itemsize, a.itemsize * ld))
+
+    def panel_update_batch(self, srcs, dsts, m_tot):
+        """sgp_dev_panel_update_batch: destination (tensor, off, ld, c0, w, s_first, s_count) -= sum over its sources
+        (tensor, off, ld, row0, w) of P[rows >= c0] P[rows c0 .. c0 + w]'  (lower trapezoid by 128-tile)"""
+        self.calls.append(("update_batch", len(srcs), len(dsts)))
+        for (A, off, ld, c0, w, s0, sn) in dsts:
+            M = self._strided(A, off, ld, m_tot - c0, w)
+            low = (np.arange(m_tot - c0)[:, None] // 128) >= (np.arange(w)[None, :] // 128)
+            for (Pt, p_off, ldp, row0, sw) in srcs[s0:s0 + sn]:
+                self.calls.append(("update", row0, c0))      # (source panel's first column, destination's first column)
+                Pm = self._strided(Pt, p_off, ldp, m_tot - row0, sw)
+                rows = Pm[c0 - row0:, :]
+                upd = rows @ Pm[c0 - row0:c0 - row0 + w, :].T
+                M[low] -= upd[low]
 
     def panel_update(self, Pt, p_off, ldp, J0, w, A, off, ld, c0, nc, m_tot):
         self.calls.append(("update", J0, c0))

@@ -11,10 +11,23 @@ import stheno_jl_amd as P
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_symbols():
-    txt = open(os.path.join(ROOT, "include", "sthenomi.h")).read()
+def _symbols_of(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(sgp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def header_symbols():
+    """every entry point of the library: the product header + the bench / diagnosis header"""
+    return sorted(set(_symbols_of("sthenomi.h")) | set(_symbols_of("sthenomi_bench.h")))
+
+
+def test_product_header_carries_no_bench_hooks():
+    """round-3 verdict: sgp_bench_* lived in the public header.  They are declared in include/sthenomi_bench.h now; the
+    header a host binds (sthenomi.h) declares operators only."""
+    prod, bench = _symbols_of("sthenomi.h"), _symbols_of("sthenomi_bench.h")
+    assert not [s for s in prod if s.startswith("sgp_bench_")]
+    assert bench and all(s.startswith("sgp_bench_") for s in bench)
 
 
 def test_library_exports_every_declared_symbol():
@@ -84,3 +97,25 @@ def test_header_is_plain_c_and_struct_offsets_match_ctypes(tmp_path):
     src_txt = open(src).read()
     for s in header_symbols():
         assert f"E({s})" in src_txt, f"{s} missing from tests/capi_smoke.c"
+
+
+def test_c_consumer_compiles_against_the_product_header_and_fails_loudly_without_a_gpu(tmp_path):
+    """tests/capi_logpdf.c (the -m gpu suite runs it on the device: tests/test_gpu_capi_consumer.py) builds as plain C99
+    against include/sthenomi.h alone; on a box without a gfx950 device its first call, sgp_ctx_create, must fail with the
+    library's message -- the C path has no CPU fallback either."""
+    import struct
+    import subprocess
+    import torch
+    exe = str(tmp_path / "capi_logpdf")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-o", exe,
+                           os.path.join(ROOT, "tests", "capi_logpdf.c"), "-ldl", "-lm"])
+    assert "sthenomi_bench.h" not in open(os.path.join(ROOT, "tests", "capi_logpdf.c")).read().split("*/", 1)[1]
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the program runs in the -m gpu suite")
+    case = tmp_path / "tiny.bin"
+    with open(case, "wb") as fh:
+        fh.write(struct.pack("<qqq", 4, 1, 2))
+        fh.write(struct.pack("<dd", 0.1, -1.0))
+        fh.write(struct.pack("<" + "d" * (4 + 4 + 2 + 2 + 2), *([0.0] * 14)))
+    r = subprocess.run([exe, P.lib.LIB_PATH, str(case)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "sgp_ctx_create rc=" in r.stdout and ("no HIP device" in r.stdout or "no CPU path" in r.stdout)

@@ -37,7 +37,7 @@ def _problem(N, bad=False):
     return spec, xs, y, (-5.0 if bad else 0.1)
 
 
-def _worker(rank, world, port, N, W, bad, q):
+def _worker(rank, world, port, N, W, bad, q, subpanel=None):
     try:
         sys.path.insert(0, ROOT)
         sys.path.insert(0, HERE)
@@ -52,6 +52,8 @@ def _worker(rank, world, port, N, W, bad, q):
         spec, xs, y, s2 = _problem(N, bad)
         ops = np_ops.NumpyOps()
         stats = {}
+        if subpanel:
+            sdist.SUBPANEL = subpanel
         try:
             val = sdist.dist_logpdf(ops, spec, y, None, s2, world=world, rank=rank, W=W, stats=stats)
             q.put((rank, "ok", val, stats, ops.calls))
@@ -63,11 +65,11 @@ def _worker(rank, world, port, N, W, bad, q):
         q.put((rank, "error", traceback.format_exc(), {}, []))
 
 
-def _run(world, N, W, bad=False):
+def _run(world, N, W, bad=False, subpanel=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, N, W, bad, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, N, W, bad, q, subpanel)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=240) for _ in range(world)]
@@ -104,6 +106,35 @@ def test_sharded_logpdf_matches_oracle(world, N, W):
                 prev = [o for o in order[:i] if o[0] == "update" and o[2] == J0]
                 assert len(prev) == J0 // stats["W"]       # one update from every earlier panel
     assert sorted(factored) == list(range(n_panels))
+
+
+@pytest.mark.parametrize("world,N,W,sub", [(2, 1500, 512, 128), (3, 1300, 384, 256)])
+def test_sub_panel_pipeline_matches_oracle(world, N, W, sub):
+    """Round 4: a panel wider than SUBPANEL is factored, broadcast and applied to the next panel sub-panel by sub-panel
+    (dist.py: factor_and_send) -- same value as the oracle, every sub-panel factored once, in order, by the panel's owner,
+    each followed by the update of the panel's remaining columns, and the owner of the next panel applies them one by one."""
+    from oracle import reference_model as orm
+    res = _run(world, N, W, subpanel=sub)
+    for r in res:
+        assert r[1] == "ok", r[2]
+    spec, xs, y, s2 = _problem(N)
+    ref = orm.gppp_sum_logpdf(xs, y, s2)
+    vals = [r[2] for r in res]
+    assert all(v == vals[0] for v in vals)
+    assert abs(vals[0] - ref) <= 1e-10 * abs(ref)
+    n_pad = (N + 127) // 128 * 128
+    starts = []
+    for rank, _, _, stats, calls in res:
+        assert stats["W"] == W
+        for i, c in enumerate(calls):
+            if c[0] == "factor":
+                J0, w = c[1], c[2]
+                assert (J0 // W) % world == rank and w <= sub
+                starts.append(J0)
+                if (J0 % W) + w < min(W, n_pad - J0 // W * W):     # not the panel's last sub-panel: the rest of the panel follows
+                    nxt = [o for o in calls[i + 1:] if o[0] == "update"][0]
+                    assert nxt[1] == J0 // W * W and nxt[2] == J0 + w
+    assert sorted(starts) == [c for J in range(0, n_pad, W) for c in range(J, min(J + W, n_pad), sub)]
 
 
 def test_single_rank_path_and_layout():
