@@ -34,6 +34,10 @@ int sgp_bench_gemm_stamps(sgp_ctx* ctx, int64_t m, int64_t k, long long* out, in
 int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only, int iters,
                    double* tflops_out, double* maxerr_out);
 
+/* how many operators of this context were rerun on the launch-based schedule because the dataflow factorisation ran into
+ * its wait bound (SGP_DF_TIMEOUT_S; capi.hip: with_df_fallback) */
+int sgp_bench_df_fallbacks(sgp_ctx* ctx, int64_t* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <mutex>
+#include <set>
 #include <vector>
 
 namespace sgp {
@@ -152,6 +153,16 @@ extern "C" int sgp_ctx_stage_ms(sgp_ctx* ctx, double* out16) {
   return 0;
 }
 
+// Live contexts.  A posterior handle (sgp_post / sgp_sparse_post) may outlive the context it was created on -- it is freed
+// without it -- but predicting against it needs the context's streams, scratch and (multi-GPU) ranks: the predict entry
+// points look the context up here and fail cleanly when it is gone (advisor, round 3: that was a use-after-free).
+static std::mutex g_live_mu;
+static std::set<const sgp_ctx*> g_live_ctx;
+static bool ctx_is_live(const sgp_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  return g_live_ctx.count(c) != 0;
+}
+
 extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
   CHECK_ARG(out != nullptr, "sgp_ctx_create: out is NULL");
   int ndev = 0;
@@ -211,6 +222,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (dfpr) c->df_pr = atoi(dfpr);
     const char* dfpc = getenv("SGP_DF_PC");
     if (dfpc) c->df_pc = atoi(dfpc);
+    const char* dfb2 = getenv("SGP_DF_FALLBACK");
+    if (dfb2) c->df_fallback = atoi(dfb2);
     const char* dfg = getenv("SGP_DF_GANG_US");
     if (dfg) c->df_gang_us = atof(dfg);
     {
@@ -234,12 +247,20 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     sgp_ctx_destroy(c);
     return rc;
   }
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_ctx.insert(c);
+  }
   *out = c;
   return 0;
 }
 
 extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (!c) return 0;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_ctx.erase(c);
+  }
   if (c->multi) sgp_multi_destroy(c->multi);
   c->multi = nullptr;
   hipSetDevice(c->device);
@@ -916,8 +937,10 @@ static int fetch_info(sgp_ctx* ctx, hipStream_t s) {
   int info = 0;
   SGP_HIP(hipMemcpyAsync(&info, ctx->d_info, sizeof(int), hipMemcpyDeviceToHost, s));
   SGP_HIP(hipStreamSynchronize(s));
-  if (info == SGP_DF_TIMEOUT)
+  if (info == SGP_DF_TIMEOUT) {
+    ctx->df_timed_out = true;   // the entry point reruns the operator on the launch-based schedule (with_df_fallback)
     set_error("dataflow factorisation: a dependency wait inside the kernel ran into its bound (SGP_DF_TIMEOUT_S)");
+  }
   return info;
 }
 
@@ -1020,7 +1043,32 @@ static int dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, const 
   return 0;
 }
 
-extern "C" int sgp_dev_logpdf(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, const double* d_mean,
+// The dataflow kernel bounds every inter-workgroup wait by WALL-CLOCK time (SGP_DF_TIMEOUT_S): if the queue is preempted or
+// time-sliced (another process on the GPU, a profiler serialising kernels) producers can be descheduled while the clock
+// runs, and the kernel aborts although nothing is wrong (advisor, round 3).  An operator that comes back with that
+// timeout is therefore run again, once, on the launch-based schedule -- every operator rebuilds its matrix from the spec,
+// and every schedule gives the same bits, so the caller sees the result it would have seen, only later.
+extern "C" int sgp_bench_df_fallbacks(sgp_ctx* ctx, int64_t* out) {
+  CHECK_ARG(ctx && out, "sgp_bench_df_fallbacks: NULL argument");
+  *out = ctx->df_fallbacks;
+  return 0;
+}
+template <class F>
+static int with_df_fallback(sgp_ctx* ctx, F&& run) {
+  if (ctx) ctx->df_timed_out = false;
+  int rc = run();
+  if (ctx && rc == -3 && ctx->df_timed_out && ctx->df_fallback) {
+    const int keep = ctx->dataflow;
+    ctx->dataflow = 0;
+    ctx->df_timed_out = false;
+    ctx->df_fallbacks += 1;
+    rc = run();
+    ctx->dataflow = keep;
+  }
+  return rc;
+}
+
+static int sgp_dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, const double* d_mean,
                               int noise_kind, const double* noise_host, const double* d_noise,
                               const double* d_Y, int64_t ldy, int64_t ncols, double* out_host,
                               double* timings) {
@@ -1031,6 +1079,12 @@ extern "C" int sgp_dev_logpdf(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, co
   double s2 = noise_host ? noise_host[0] : 0.0;
   return dev_logpdf_impl(ctx, ds, d_A, d_mean, noise_kind, s2, d_noise, nullptr, 0, d_Y, ldy, ncols,
                          out_host, timings);
+}
+extern "C" int sgp_dev_logpdf(sgp_ctx* ctx, const sgp_dspec* ds, double* d_A, const double* d_mean,
+                              int noise_kind, const double* noise_host, const double* d_noise,
+                              const double* d_Y, int64_t ldy, int64_t ncols, double* out_host,
+                              double* timings) {
+  return with_df_fallback(ctx, [&]() { return sgp_dev_logpdf_impl(ctx, ds, d_A, d_mean, noise_kind, noise_host, d_noise, d_Y, ldy, ncols, out_host, timings); });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1117,7 +1171,7 @@ extern "C" int sgp_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, dou
   return 0;
 }
 
-extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+static int sgp_logpdf_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                           const double* noise, const double* Y, int64_t ldy, int64_t ncols,
                           double* out) {
   CHECK_ARG(ctx && spec && Y && out, "sgp_logpdf: NULL argument");
@@ -1142,6 +1196,11 @@ extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
   return dev_logpdf_impl(ctx, g.ds, dA.p, mean ? dmean.p : nullptr, nd.kind, nd.sigma2, nd.diag.p,
                          nd.dense.p, nd.ld_dense, dY.p, N, ncols, out, nullptr);
 }
+extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                          const double* noise, const double* Y, int64_t ldy, int64_t ncols,
+                          double* out) {
+  return with_df_fallback(ctx, [&]() { return sgp_logpdf_impl(ctx, spec, mean, noise_kind, noise, Y, ldy, ncols, out); });
+}
 
 // dst[i + c * ld] = mean[i] (i < N) else 0, for an nrows x ncols block
 __global__ void fill_mean_cols_kernel(double* dst, long ld, long nrows, long ncols, long N, const double* mean) {
@@ -1151,7 +1210,7 @@ __global__ void fill_mean_cols_kernel(double* dst, long ld, long nrows, long nco
   dst[i + c * ld] = (mean && i < N) ? mean[i] : 0.0;
 }
 
-extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+static int sgp_rand_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                         const double* noise, const double* Z, int64_t ldz, int64_t S, double* out,
                         int64_t ldo) {
   CHECK_ARG(ctx && spec && Z && out, "sgp_rand: NULL argument");
@@ -1197,6 +1256,11 @@ extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* me
   SGP_HIP(hipMemcpy2D(out, sizeof(double) * ldo, dOut.p, sizeof(double) * n_pad, sizeof(double) * N,
                       (size_t)S, hipMemcpyDeviceToHost));
   return 0;
+}
+extern "C" int sgp_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                        const double* noise, const double* Z, int64_t ldz, int64_t S, double* out,
+                        int64_t ldo) {
+  return with_df_fallback(ctx, [&]() { return sgp_rand_impl(ctx, spec, mean, noise_kind, noise, Z, ldz, S, out, ldo); });
 }
 
 // sum_ij G_ij dC_ij / d theta per flattened term of every block pair of `ds` (grad.hip):
@@ -1507,7 +1571,7 @@ extern "C" int sgp_posterior_destroy(sgp_post* p) {
   return 0;
 }
 
-extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
+static int sgp_posterior_create_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
                                     int noise_kind, const double* noise, const double* y,
                                     double* alpha_out, sgp_post** out) {
   CHECK_ARG(ctx && spec && y && out, "sgp_posterior_create: NULL argument");
@@ -1578,6 +1642,11 @@ extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, cons
   *out = post;
   return 0;
 }
+extern "C" int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
+                                    int noise_kind, const double* noise, const double* y,
+                                    double* alpha_out, sgp_post** out) {
+  return with_df_fallback(ctx, [&]() { return sgp_posterior_create_impl(ctx, spec, mean, noise_kind, noise, y, alpha_out, out); });
+}
 
 // shared by dense and sparse prediction: V rows (x* bordered rows, ns_pad x n_pad)
 static int predict_common(sgp_ctx* ctx, const sgp_dspec* cross, const sgp_dspec* prior,
@@ -1624,6 +1693,7 @@ extern "C" int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross,
                                      int64_t ldcov) {
   CHECK_ARG(post && cross, "sgp_posterior_predict: NULL argument");
   sgp_ctx* ctx = post->ctx;
+  CHECK_ARG(ctx_is_live(ctx), "sgp_posterior_predict: the context this posterior was created on has been destroyed");
   CtxScope scope(ctx);
   if (post->mp) return sgp_multi_posterior_predict(post->mp, cross, prior_ss, mean_s, mean_out, var_out, cov_out, ldcov);
   SpecGuard gc, gp;
@@ -2118,7 +2188,7 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   return 0;
 }
 
-extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
+static int sgp_elbo_impl(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
                         const double* var_x, const double* mean_x, int noise_kind,
                         const double* noise_x, int z_noise_kind, const double* z_noise,
                         const double* y, double* out) {
@@ -2143,6 +2213,12 @@ extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   double dtc = -0.5 * ((double)N * 1.8378770664093453 + tmp);
   out[0] = dtc - 0.5 * (h[2] - h[3]);
   return 0;
+}
+extern "C" int sgp_elbo(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz,
+                        const double* var_x, const double* mean_x, int noise_kind,
+                        const double* noise_x, int z_noise_kind, const double* z_noise,
+                        const double* y, double* out) {
+  return with_df_fallback(ctx, [&]() { return sgp_elbo_impl(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, out); });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2586,7 +2662,7 @@ extern "C" int sgp_kernelmatrix_diag_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* s
   return diag_grad_core(ctx, spec, w, grad_coef, grad_inscale, grad_inputs, grad_rowscale, grad_colscale);
 }
 
-extern "C" int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz,
+static int sgp_sparse_posterior_create_impl(sgp_ctx* ctx, const sgp_cov_spec* zz,
                                            const sgp_cov_spec* xz, const double* mean_x,
                                            int noise_kind, const double* noise_x, int z_noise_kind,
                                            const double* z_noise, const double* y,
@@ -2630,6 +2706,13 @@ extern "C" int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz,
   *out = p;
   return 0;
 }
+extern "C" int sgp_sparse_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* zz,
+                                           const sgp_cov_spec* xz, const double* mean_x,
+                                           int noise_kind, const double* noise_x, int z_noise_kind,
+                                           const double* z_noise, const double* y,
+                                           sgp_sparse_post** out) {
+  return with_df_fallback(ctx, [&]() { return sgp_sparse_posterior_create_impl(ctx, zz, xz, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, out); });
+}
 
 extern "C" int sgp_sparse_posterior_predict(sgp_sparse_post* post, const sgp_cov_spec* cross,
                                             const sgp_cov_spec* prior_ss, const double* mean_s,
@@ -2637,6 +2720,7 @@ extern "C" int sgp_sparse_posterior_predict(sgp_sparse_post* post, const sgp_cov
                                             int64_t ldcov) {
   CHECK_ARG(post && cross, "sgp_sparse_posterior_predict: NULL argument");
   sgp_ctx* ctx = post->ctx;
+  CHECK_ARG(ctx_is_live(ctx), "sgp_sparse_posterior_predict: the context this posterior was created on has been destroyed");
   CtxScope scope(ctx);
   SpecGuard gc, gp;
   CHECK_RC(dspec_create(ctx, cross, &gc.ds));

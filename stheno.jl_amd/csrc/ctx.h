@@ -86,6 +86,9 @@ struct sgp_ctx {
   long n_df_tasks = 0;
   long df_tasks_key[4] = {0, 0, 0, 0};   // T_r, T_c, pr, pc of what d_df_tasks holds
   int df_qstart[9] = {0};
+  bool df_timed_out = false;   // the last dataflow launch ran into its wait bound (fetch_info)
+  int df_fallback = 1;         // SGP_DF_FALLBACK=0: report the timeout instead (the kernel's own error path, tests)
+  long df_fallbacks = 0;       // operators rerun on the launch-based schedule because of that (capi.hip: with_df_fallback)
   std::mutex mu;
   // optional per-launch timing of the trailing updates (roofline evidence for bench.py)
   bool time_updates = false;

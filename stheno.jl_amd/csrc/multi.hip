@@ -1363,7 +1363,7 @@ int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const 
       M_RC(grow(&k.d_work2, &k.work2_cap, (size_t)3 * ns_pad + (cov_out ? (size_t)ns_pad * ns_pad : 0)));
       if (P > 1) {
         size_t need = (size_t)(P - 1) * ns_pad * g.W;
-        if (need > mp->stage_cap[i]) M_HIP(hipDeviceSynchronize());
+        if (need > mp->stage_cap[i]) M_RC(sync_all(m));   // peers copy into this buffer: all ranks idle before it is freed
         M_RC(grow(&mp->stage[i], &mp->stage_cap[i], need));
       }
       M_RC(drv_dspec_create(k.ctx, cross, &ds[i]));

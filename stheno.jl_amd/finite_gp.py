@@ -441,20 +441,6 @@ class PosteriorGP:
         pss = _prior_spec(self.prior, xs) if (want_var or want_cov) else None
         ns = cross.N
         ms = _f64(mean_vector(self.prior, xs))
-        if self._h is None and not want_cov and ns > 0:
-            # Float32 model, moments only: one fp32 factorisation with x* riding along as bordered rows
-            spec = _prior_spec(self.prior, self.x)
-            kind, nbuf = _lib._noise_args(self.noise, len(self.y))
-            if (kind != _lib.NOISE_DENSE and spec.f32_supported() and cross.f32_supported()
-                    and _eltype(xs) == np.float32):
-                mo32 = np.zeros(ns, dtype=np.float32) if want_mean else None
-                vo32 = np.zeros(ns, dtype=np.float32) if want_var else None
-                fp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_float))
-                rc = _ctx().lib.sgp_posterior_mean_var_f32(
-                    _ctx().handle, spec.ref(), _lib.dptr(self._mean_x), kind, _lib.dptr(nbuf), _lib.dptr(self.y),
-                    cross.ref(), pss.ref() if pss is not None else None, _lib.dptr(ms), fp(mo32), fp(vo32))
-                _lib.check(rc, "sgp_posterior_mean_var_f32")
-                return mo32, vo32, None
         self._ensure()
         mo = np.zeros(ns) if want_mean else None
         vo = np.zeros(ns) if want_var else None
@@ -529,12 +515,37 @@ def posterior(fx, y, y_vfe=None):
         raise ValueError("length(y) != length(fx)")
     m = _f64(mean_vector(fx.f, fx.x))
     post = PosteriorGP(fx.f, fx.x, None, None, y - m, fx.noise, y.copy(), mean_x=m)
-    if _eltype(fx.x) == np.float32 and np.ndim(fx.noise) <= 1 and _prior_spec(fx.f, fx.x).f32_supported():
-        # Float32 model: mean / var of the posterior come from the fp32 path; the fp64 factor is built on demand
-        # (cov, alpha).  A non-positive-definite covariance then surfaces at the first prediction.
-        return post
-    post._ensure()                 # fp64: factor now (PosDefException here, as `cholesky` throws in the reference)
+    # Factor ONCE, here, and keep the handle -- for Float32 models as well (advisor, round 3: a Float32 posterior used to
+    # re-assemble and re-factorise the whole covariance in fp32 on EVERY mean / var call, reported a covariance that is not
+    # positive definite only at the first prediction, and switched to fp64-rounded values once `cov` / `alpha` had built
+    # the fp64 factor, so a result depended on the call history).  Every prediction now runs against this one fp64
+    # factor; Float32 models get their results rounded by the one output-type rule (_model_type).  The one-shot fp32
+    # path (one fp32 factorisation with x* riding along as bordered rows) is the explicit posterior_mean_and_var_f32.
+    post._ensure()                 # PosDefException here, as `cholesky` throws in the reference's posterior
     return post
+
+
+def posterior_mean_and_var_f32(fx, y, xs):
+    """mean_and_var(posterior(fx, y)(xs)) of a Float32 model in ONE fp32 factorisation (sgp_posterior_mean_var_f32: K(x*, x)
+    rides through the fp32 Cholesky as bordered rows) -- the explicit fast path for "condition once, predict once"; nothing
+    is kept.  fx: FiniteGP of a prior process with scalar / diagonal noise within the fp32 kernels' limits."""
+    if not _is_prior(fx.f):
+        raise NotImplementedError("the fp32 one-shot posterior takes a prior process")
+    y = _f64(np.asarray(y, dtype=np.float64).ravel())
+    spec = _prior_spec(fx.f, fx.x)
+    cross, _, _ = build_spec(fx.f, xs, fx.f, fx.x)
+    pss = _prior_spec(fx.f, xs)
+    kind, nbuf = _lib._noise_args(fx.noise, len(y))
+    if kind == _lib.NOISE_DENSE or not spec.f32_supported() or not cross.f32_supported():
+        raise NotImplementedError("beyond the fp32 kernels' limits (dense noise, input dimension > 16, too many terms)")
+    ns = cross.N
+    m, ms = _f64(mean_vector(fx.f, fx.x)), _f64(mean_vector(fx.f, xs))
+    mo32, vo32 = np.zeros(ns, dtype=np.float32), np.zeros(ns, dtype=np.float32)
+    fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+    rc = _ctx().lib.sgp_posterior_mean_var_f32(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(y),
+                                               cross.ref(), pss.ref(), _lib.dptr(ms), fp(mo32), fp(vo32))
+    _lib.check(rc, "sgp_posterior_mean_var_f32")
+    return mo32, vo32
 
 
 # ---- VFE / sparse --------------------------------------------------------------------------------

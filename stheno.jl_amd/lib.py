@@ -141,6 +141,7 @@ _SIGS = {
     "sgp_dev_elbo_partial": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D,
                                        C.c_int, _D, _D, _P, C.c_int64]),
     "sgp_dev_elbo_finish": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _D]),
+    "sgp_bench_df_fallbacks": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sgp_bench_mfma_f64": (C.c_int, [_P, C.c_int, _D, _D]),
     "sgp_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D]),
     "sgp_bench_potrf": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_longlong)]),

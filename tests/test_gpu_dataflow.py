@@ -102,15 +102,17 @@ def test_many_right_hand_sides_and_posterior_rows_ride_through(monkeypatch):
 def test_a_dependency_wait_that_runs_out_is_an_error_not_a_hang(monkeypatch):
     # every wait inside the kernel is bounded (SGP_DF_TIMEOUT_S); with a bound of 0.1 us the first tile that has to wait for
     # the diagonal block's 30 us factorisation gives up, raises the abort word (all workgroups leave) and the entry point
-    # reports it; the context stays usable
+    # reports it (SGP_DF_FALLBACK=0: without the rerun on the launch-based schedule, tested further down); the context stays
+    # usable
     rng = np.random.default_rng(3)
     x = P.ColVecs(np.asfortranarray(rng.standard_normal((2, 1500))))
     f = P.atomic(P.GP(P.SEKernel()), P.GPC())
     y = rng.standard_normal(1500)
-    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_TIMEOUT_S="1e-7")
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_TIMEOUT_S="1e-7", SGP_DF_FALLBACK=0)
     with pytest.raises(P.lib.SthenoMIError, match="dependency wait"):
         _with_ctx(ctx, lambda: P.logpdf(f(x, 0.1), y))
     ctx.close()
+    monkeypatch.delenv("SGP_DF_FALLBACK")
     ok = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_TIMEOUT_S="10")
     ref = _ctx(monkeypatch, 11, SGP_DATAFLOW=0)
     assert _with_ctx(ok, lambda: P.logpdf(f(x, 0.1), y)) == _with_ctx(ref, lambda: P.logpdf(f(x, 0.1), y))
@@ -133,3 +135,50 @@ def test_schedule_limits_move_with_their_environment_variables(monkeypatch):
         assert always.factor_schedule(N).startswith("dataflow")
     never.close()
     always.close()
+
+
+def test_a_dataflow_timeout_falls_back_to_the_launches_with_the_same_bits(monkeypatch):
+    """Advisor, round 3: the dataflow kernel bounds its inter-workgroup waits by wall-clock time and used to fail the
+    operator (rc -3) when a wait ran out -- under preemption / profiler serialisation nothing is wrong, the launch-based
+    schedule would simply have run slower.  With a bound of a nanosecond every dependency wait "times out"; the entry
+    points rerun the operator on the launch-based schedule (capi.hip: with_df_fallback): same bits, no error."""
+    import ctypes as C
+    N = 4500
+    ref_ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0)
+    ref, _ = _with_ctx(ref_ctx, lambda: _operators(N))
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=1, SGP_DF_TIMEOUT_S="1e-9")
+    got, _ = _with_ctx(ctx, lambda: _operators(N))
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k
+    n = C.c_int64()
+    P.lib.check(ctx.lib.sgp_bench_df_fallbacks(ctx.handle, C.byref(n)))
+    assert n.value >= 1, "no wait ran into the 1 ns bound?"
+    ctx.close()
+    ref_ctx.close()
+
+
+def test_tall_bordered_vfe_shape_is_bit_identical_under_both_schedules(monkeypatch):
+    """Advisor, round 3: the VFE pipeline sends K(z,z) with ALL data rows as bordered rows through chol_bordered when it is
+    not chunked -- M >= 3072 inducing points selects the dataflow kernel with hundreds of bordered tile rows (T_r >> T_c),
+    a shape no other test reaches.  ELBO and the sparse posterior must come out bit-identical with SGP_DATAFLOW = 0 / 1."""
+    rng = np.random.default_rng(17)
+    N, M, D = 20000, 3200, 3
+    X = np.asfortranarray(rng.standard_normal((D, N)))
+    Z = np.asfortranarray(X[:, rng.permutation(N)[:M]] + 0.01 * rng.standard_normal((D, M)))
+    y = rng.standard_normal(N)
+    xs = P.ColVecs(np.asfortranarray(rng.standard_normal((D, 50))))
+    f = P.stretch(P.atomic(P.GP(P.Matern52Kernel()), P.GPC()), 0.7)
+    out = []
+    for df in (0, 1):
+        ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=df, SGP_VFE_CHUNK=0)
+        assert ctx.factor_schedule(M) == ("launches-one-panel" if df == 0 else "dataflow-fat")
+
+        def run():
+            vfe = P.VFE(f(P.ColVecs(Z), 1e-6))
+            e = P.elbo(vfe, f(P.ColVecs(X), 0.1), y)
+            m, v = P.posterior(vfe, f(P.ColVecs(X), 0.1), y).mean_and_var(xs)
+            return e, m, v
+        out.append(_with_ctx(ctx, run))
+        ctx.close()
+    assert out[0][0] == out[1][0]
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])

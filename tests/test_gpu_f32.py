@@ -101,8 +101,10 @@ def test_rand_f32_type_stable_and_close_to_fp64():
 
 
 def test_posterior_moments_f32_and_fp64_factor_on_demand():
-    """posterior(fx, y) of a Float32 model: mean / var at x* from ONE fp32 factorisation with x* riding along as bordered
-    rows (sgp_posterior_mean_var_f32); cov and alpha build the fp64 factor on demand."""
+    """posterior(fx, y) of a Float32 model factors ONCE, at construction (the fp64 factor; advisor, round 3), and every
+    accessor -- mean, var, cov, alpha, repeated, in any order -- runs against it with Float32 results; the one-shot fp32
+    path (ONE fp32 factorisation with x* riding along as bordered rows, sgp_posterior_mean_var_f32) is the explicit
+    posterior_mean_and_var_f32."""
     rng = np.random.default_rng(13)
     Fo, Fp = _both(models.gppp_docstring)
     x1, x3 = rng.standard_normal(300).astype(np.float32), rng.standard_normal(417).astype(np.float32)
@@ -113,20 +115,32 @@ def test_posterior_moments_f32_and_fp64_factor_on_demand():
     s2 = float(np.float32(0.1))          # the Float32 noise value, exactly, on both sides
     po = oagp.posterior(Fo(xo, s2), y.astype(np.float64))
     pp = P.posterior(Fp(xp, np.float32(0.1)), y)
+    assert pp._h is not None             # factored at construction
     for proc in ("f2", "f3"):
         mo, vo = po.mean_and_var(ost.GPPPInput(proc, t.astype(np.float64)))
         mp, vp = pp.mean_and_var(P.GPPPInput(proc, t))
         assert mp.dtype == np.float32 and vp.dtype == np.float32
-        assert np.max(np.abs(mp - mo)) <= 2e-4 * max(1.0, np.max(np.abs(mo)))
-        assert np.max(np.abs(vp - vo)) <= 2e-4
+        assert np.max(np.abs(mp - mo)) <= 1e-6 * max(1.0, np.max(np.abs(mo)))     # fp64 arithmetic, rounded once
+        assert np.max(np.abs(vp - vo)) <= 1e-6
+        # the explicit one-shot fp32 path: fp32 accuracy
+        m1, v1 = P.posterior_mean_and_var_f32(Fp(xp, np.float32(0.1)), y, P.GPPPInput(proc, t))
+        assert m1.dtype == np.float32 and v1.dtype == np.float32
+        assert np.max(np.abs(m1 - mo)) <= 2e-4 * max(1.0, np.max(np.abs(mo)))
+        assert np.max(np.abs(v1 - vo)) <= 2e-4
+    before = pp.mean_and_var(P.GPPPInput("f3", t))
     m, v = P.mean_and_var(pp(P.GPPPInput("f3", t), np.float32(0.01)))        # FiniteGP on top of the posterior
     assert m.dtype == np.float32 and v.dtype == np.float32
-    c = pp.cov(P.GPPPInput("f3", t))                # needs the factor: fp64 arithmetic, built now; Float32 result
+    c = pp.cov(P.GPPPInput("f3", t))                # the same factor; Float32 result
     assert c.dtype == np.float32
     assert np.max(np.abs(c - po.cov(ost.GPPPInput("f3", t.astype(np.float64))))) <= 1e-6
     c64 = pp.cov(P.GPPPInput("f3", t.astype(np.float64)))                     # asked at Float64 points: Float64 result
     assert c64.dtype == np.float64 and np.max(np.abs(c64 - po.cov(ost.GPPPInput("f3", t.astype(np.float64))))) <= 1e-8
     assert np.max(np.abs(pp.alpha - po.alpha)) <= 1e-8 * np.max(np.abs(po.alpha))
+    after = pp.mean_and_var(P.GPPPInput("f3", t))   # a result does not depend on which accessors ran before
+    assert np.array_equal(before[0], after[0]) and np.array_equal(before[1], after[1])
+    # a covariance that is not positive definite is reported by posterior() itself, as `cholesky` throws in the reference
+    with pytest.raises(P.PosDefException):
+        P.posterior(Fp(xp, np.float32(-5.0)), y)
 
 
 def test_one_output_type_rule_across_the_operator_surface():

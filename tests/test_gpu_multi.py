@@ -373,3 +373,20 @@ def test_batched_panel_update_entry_point_is_bit_identical_to_single_updates():
     got = bat[0].cpu().numpy().reshape((m_tot - c0, w), order="F")
     low = (np.arange(m_tot - c0)[:, None] // 128) >= (np.arange(w)[None, :] // 128)
     assert np.abs(got[low] - want[low]).max() <= 1e-11 * np.abs(want).max()
+
+
+def test_predicting_on_a_posterior_whose_context_is_gone_fails_cleanly(panel128):
+    """Advisor, round 3: a posterior handle may outlive its context (it is freed without it), but predicting needs the
+    context's ranks, streams and scratch -- that was a use-after-free; now an error, for the single-GPU and the sharded
+    posterior alike."""
+    F, x, xs, y, xnew = _post_problem(700, 20)
+    for devices in ([0], [0, 0, 0]):
+        ctx = P.lib.Context(devices=devices) if len(devices) > 1 else P.lib.Context(0)
+        post = _with_ctx(ctx, lambda: P.posterior(F(x, 0.1), y))
+        m0 = _with_ctx(ctx, lambda: post.mean(xnew))
+        assert np.all(np.isfinite(m0))
+        ctx.close()
+        with pytest.raises(P.SthenoMIError) as e:
+            post.mean(xnew)
+        assert "destroyed" in str(e.value)
+        del post
