@@ -1892,12 +1892,40 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
   const int nsplit = 8;  // one K slice per XCD (gemm_nt.hip, klo == 3)
   const long stride = ldg * m_pad;
   CHECK_RC(dR.alloc((size_t)CH * m_pad));
+  // Two chunks in flight (round 4, SGP_VFE_OVERLAP=1; OFF by default): the Gram product of chunk c (split-K MFMA GEMM + its
+  // fixed-order reduction into G, on the context's second stream) runs while chunk c + 1 is assembled, solved against Lz
+  // and transposed on the first; the transposed chunk A' is double-buffered; G is still accumulated in chunk order.
+  // Measured on the N = 262144, M = 4096 bound (profiles/r04_experiments/elbo_c4.txt): 159.7 -> 161.5 ms -- two MFMA-bound
+  // streams sharing the chip lose more to each other than the solve's latency-bound substitutions leave idle, the same
+  // finding as the factorisation's look-ahead at N = 65536.
+  const bool overlap = n_rows > CH && getenv("SGP_VFE_OVERLAP") && atoi(getenv("SGP_VFE_OVERLAP")) != 0 &&
+                       !ctx->stage_timing;
+  DevBuf dAt2;
   CHECK_RC(dAt.alloc((size_t)m_pad * CH));
-  CHECK_RC(dPart.alloc((size_t)nsplit * stride));
+  if (overlap) CHECK_RC(dAt2.alloc((size_t)m_pad * CH));
+  CHECK_RC(dPart.alloc((size_t)splitk_slabs(m_pad, CH, nsplit) * stride));   // (the largest chunk has the most slabs)
+  hipStream_t sg = overlap ? ctx->stream2 : s;
+  struct ChunkEvents {   // destroyed on every exit path
+    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    ~ChunkEvents() {
+      for (auto e : ready)
+        if (e) hipEventDestroy(e);
+      for (auto e : done)
+        if (e) hipEventDestroy(e);
+    }
+  } cev;
+  if (overlap)
+    for (int b = 0; b < 2; ++b) {
+      SGP_HIP(hipEventCreateWithFlags(&cev.ready[b], hipEventDisableTiming));
+      SGP_HIP(hipEventCreateWithFlags(&cev.done[b], hipEventDisableTiming));
+    }
   // ---- row chunks
-  for (long r0 = 0; r0 < n_rows; r0 += CH) {
+  long chunk = 0;
+  for (long r0 = 0; r0 < n_rows; r0 += CH, ++chunk) {
     const long ch = std::min(CH, n_rows - r0);            // rows of this chunk (multiple of 128)
     const long nv = std::max<long>(0, std::min(N - r0, ch));  // of which real data points
+    const int b = overlap ? (int)(chunk & 1) : 0;
+    double* At = b ? dAt2.p : dAt.p;
     tm.mark(1);
     // (a full chunk of an unpadded M is written entry for entry by the assembly: nothing to clear)
     if (nv < ch || M < m_pad) SGP_HIP(hipMemsetAsync(dR.p, 0, sizeof(double) * ch * m_pad, s));
@@ -1912,11 +1940,21 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
     hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, dR.p, ch, ch, ddelta.p + r0, d_dots, sq.p,
                        r0 > 0 ? 1 : 0, drsig.p + r0);
     SGP_HIP(hipGetLastError());
-    CHECK_RC(launch_transpose_add(dR.p, ch, ch, m_pad, dAt.p, m_pad, nullptr, s, drsig.p + r0));
+    if (overlap && chunk >= 2) SGP_HIP(hipStreamWaitEvent(s, cev.done[b], 0));   // the Gram product that read this buffer
+    CHECK_RC(launch_transpose_add(dR.p, ch, ch, m_pad, At, m_pad, nullptr, s, drsig.p + r0));
     tm.mark(4);
+    if (overlap) {
+      SGP_HIP(hipEventRecord(cev.ready[b], s));
+      SGP_HIP(hipStreamWaitEvent(sg, cev.ready[b], 0));
+    }
     // (the split-K slices need ch to be a multiple of 16 * nsplit = 128: it is)
-    CHECK_RC(launch_gemm_nt_splitk(dAt.p, m_pad, dAt.p, m_pad, dPart.p, ldg, m_pad, m_pad, ch, nsplit, stride, 1, s));
-    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, r0 > 0 ? 1.0 : 0.0, 1, s));
+    CHECK_RC(launch_gemm_nt_splitk(At, m_pad, At, m_pad, dPart.p, ldg, m_pad, m_pad, ch, nsplit, stride, 1, sg));
+    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, r0 > 0 ? 1.0 : 0.0, 1, sg, ch));
+    if (overlap) SGP_HIP(hipEventRecord(cev.done[b], sg));
+  }
+  if (overlap) {   // join: everything the Gram stream did is visible to the first stream
+    SGP_HIP(hipEventRecord(cev.done[0], sg));
+    SGP_HIP(hipStreamWaitEvent(s, cev.done[0], 0));
   }
   tm.mark(5);
   CHECK_RC(launch_sum_array(sq.p, m_pad, d_sc + 3, s));
@@ -2152,10 +2190,10 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
            n_rows / (nsplit * 2) >= 2048)
       nsplit *= 2;
     long stride = ldg * m_pad;
-    CHECK_RC(dPart.alloc((size_t)nsplit * stride));
+    CHECK_RC(dPart.alloc((size_t)splitk_slabs(m_pad, n_rows, nsplit) * stride));
     CHECK_RC(launch_gemm_nt_splitk(dAt.p, m_pad, dAt.p, m_pad, dPart.p, ldg, m_pad, m_pad, n_rows, nsplit,
                                    stride, 1, s));
-    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, 0.0, 1, s));
+    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, 0.0, 1, s, n_rows));
     SGP_HIP(hipStreamSynchronize(s));  // dAt / dPart are freed at scope exit
   }
   hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG,
@@ -2330,10 +2368,10 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
            n_rows / (nsplit * 2) >= 2048)
       nsplit *= 2;
     long stride = ldg * m_pad;
-    CHECK_RC(dPart.alloc((size_t)nsplit * stride));
+    CHECK_RC(dPart.alloc((size_t)splitk_slabs(m_pad, n_rows, nsplit) * stride));
     CHECK_RC(launch_gemm_nt_splitk(dAt.p, m_pad, dAt.p, m_pad, dPart.p, ldg, m_pad, m_pad, n_rows, nsplit, stride, 1,
                                    s));
-    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG.p, ldg, m_pad, m_pad, 1.0, 0.0, 1, s));
+    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG.p, ldg, m_pad, m_pad, 1.0, 0.0, 1, s, n_rows));
     SGP_HIP(hipStreamSynchronize(s));
   }
   hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG.p, ldg, m_pad);

@@ -183,7 +183,9 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
                           long M, long Nc, long K, int nsplit, long part_stride, int lower_only,
                           hipStream_t s);
 int launch_splitk_reduce(const double* part, long part_stride, int nsplit, double* C, long ldc, long M,
-                         long Nc, double alpha, double beta, int lower_only, hipStream_t s);
+                         long Nc, double alpha, double beta, int lower_only, hipStream_t s, long K = 0);
+long splitk_sub(long M, long K);                 // further k split of the Gram product's leftover tiles (gemm_nt.hip)
+long splitk_slabs(long M, long K, int nsplit);   // slabs launch_gemm_nt_splitk writes for this shape
 
 // grad.hip
 int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0, long nc,

@@ -77,15 +77,30 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
     // the K slice it contracts, so each XCD's L2 only ever holds its own slice of the operands (all
     // slices on all XCDs made the per-chunk working set 8 x 512 KB = the whole 4 MiB L2).  id / 8
     // enumerates the lower tiles linearly.
-    const long sl = (long)blockIdx.x & 7, k = (long)blockIdx.x >> 3;
+    // Round 4 -- whole rounds: an XCD has 64 workgroup slots and T (T + 1) / 2 tiles (528 at M = 4096: 8.25 rounds, the
+    // last one a quarter full, ~8 % of the product's time).  The tiles beyond the last multiple of 64 ("leftover": 16) are
+    // therefore split `sub` = 64 / leftover = 4 ways further over k, each piece into a slab of its own: 512 tiles x K and
+    // 64 pieces x K / 4 = exactly 8.25 rounds of work on 8.25 rounds of slots.  mask_off carries `sub` (>= 1); slab of
+    // (slice sl, piece q) = sl * sub + q, whole tiles use piece 0's slab; splitk_reduce_kernel sums them in that order.
+    const long sub = mask_off > 1 ? mask_off : 1;
+    const long tiles = n_tr * (n_tr + 1) / 2, full = sub > 1 ? tiles / 64 * 64 : tiles;
+    const long sl = (long)blockIdx.x & 7;
+    long k = (long)blockIdx.x >> 3, q = 0, kk = K;
+    if (k >= full) {
+      const long e = k - full;
+      k = full + e / sub;
+      q = e % sub;
+      kk = K / sub;
+    }
     tr = (long)((sqrt(8.0 * (double)k + 1.0) - 1.0) * 0.5);
     while (tr * (tr + 1) / 2 > k) --tr;
     while ((tr + 1) * (tr + 2) / 2 <= k) ++tr;
     tc = k - tr * (tr + 1) / 2;
     if (tr >= n_tr) return false;
-    A += sl * K * lda;
-    B += sl * K * ldb;
-    C += sl * c_slice_stride;
+    A += (sl * K + q * kk) * lda;
+    B += (sl * K + q * kk) * ldb;
+    C += (sl * sub + q) * c_slice_stride;
+    K = kk;
   } else {
     // (STAMP only, experiment: ids dealt to the tiles through a multiplicative permutation -- neighbouring workgroups
     // no longer share operand panels, which prices the L2 locality of the production order)
@@ -733,6 +748,19 @@ int launch_gemm_nt_lz(const double* L, long ldl, const double* Zt, long ldz, dou
 // Cpart[s] = A[:, sK' : (s+1)K'] B[:, sK' : (s+1)K']'  for s < nsplit (K' = K / nsplit, a multiple of
 // 16), slabs `part_stride` doubles apart: one launch, nsplit x the tiles -- for Gram matrices
 // with a huge contraction dimension and few output tiles (VFE: A A', M = 4096, K = 262144).
+// Further k split of the leftover tiles of the one-slice-per-XCD Gram product (see the kernel, klo == 3): 64 / leftover when
+// that is a whole number > 1 and the pieces stay multiples of the 16-column chunk; 1 = none.  The slab buffer then holds
+// 8 * sub slabs (launch_gemm_nt_splitk / launch_splitk_reduce callers size it with splitk_slabs).
+long splitk_sub(long M, long K) {
+  static const bool off = getenv("SGP_SPLITK_SUB") && atoi(getenv("SGP_SPLITK_SUB")) == 0;
+  const long n_t = M / TILE, tiles = n_t * (n_t + 1) / 2, left = tiles % 64;
+  if (off || left == 0 || tiles < 64 || 64 % left) return 1;
+  const long sub = 64 / left;
+  if (sub < 2 || sub > 8 || K % (8 * sub * KB)) return 1;
+  return sub;
+}
+long splitk_slabs(long M, long K, int nsplit) { return nsplit == 8 ? 8 * splitk_sub(M, K) : nsplit; }
+
 int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
                           long M, long Nc, long K, int nsplit, long part_stride, int lower_only,
                           hipStream_t s) {
@@ -742,9 +770,12 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
   }
   long n_tr = M / TILE, n_tc = Nc / TILE;
   if (lower_only && nsplit == 8 && M == Nc) {  // one K slice per XCD (see the kernel, klo == 3)
-    long tiles = n_tr * (n_tr + 1) / 2;
-    hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(tiles * 8)), dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc,
-                       K / nsplit, 1.0, 0.0, 0L, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 3);
+    const long tiles = n_tr * (n_tr + 1) / 2;
+    const long sub = splitk_sub(M, K);
+    const long full = sub > 1 ? tiles / 64 * 64 : tiles;
+    const long ids = full + (tiles - full) * sub;
+    hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(ids * 8)), dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc,
+                       K / nsplit, 1.0, 0.0, sub, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 3);
     SGP_HIP(hipGetLastError());
     return 0;
   }
@@ -758,30 +789,37 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
   return 0;
 }
 
-// C = beta C + alpha sum_s part[s]   (fixed order: deterministic)
-int launch_splitk_reduce(const double* part, long part_stride, int nsplit, double* C, long ldc, long M,
-                         long Nc, double alpha, double beta, int lower_only, hipStream_t s);
-
-// fixed-order reduction of split-K slabs (deterministic)
+// C = beta C + alpha sum_s part[s]   (fixed order: deterministic).  sub > 1 (the XCD-sliced Gram product with its leftover
+// tiles split further): whole tiles sum slabs 0, sub, 2 sub, ..., leftover tiles all 8 * sub slabs -- ascending k either way.
 __global__ void splitk_reduce_kernel(const double* part, long part_stride, int nsplit, double* C,
                                      long ldc, long M, long Nc, double alpha, double beta,
-                                     int lower_only) {
+                                     int lower_only, int sub, long full) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * Nc) return;
   long r = idx % M, c = idx / M;
-  if (lower_only && (r / TILE) < (c / TILE)) return;
+  const long tr = r / TILE, tc = c / TILE;
+  if (lower_only && tr < tc) return;
   double s = 0.0;
-  for (int k = 0; k < nsplit; ++k) s += part[k * part_stride + r + c * ldc];
+  if (sub > 1) {
+    const bool whole = tr * (tr + 1) / 2 + tc < full;
+    const int step = whole ? sub : 1;
+    for (int k = 0; k < nsplit * sub; k += step) s += part[k * part_stride + r + c * ldc];
+  } else {
+    for (int k = 0; k < nsplit; ++k) s += part[k * part_stride + r + c * ldc];
+  }
   double* p = C + r + c * ldc;
   double old = (beta == 0.0) ? 0.0 : beta * (*p);
   *p = old + alpha * s;
 }
 
+// K: the contraction length the slabs came from (launch_gemm_nt_splitk's K; 0 = plain nsplit slabs)
 int launch_splitk_reduce(const double* part, long part_stride, int nsplit, double* C, long ldc, long M,
-                         long Nc, double alpha, double beta, int lower_only, hipStream_t s) {
+                         long Nc, double alpha, double beta, int lower_only, hipStream_t s, long K) {
   long tot = M * Nc;
+  const long sub = (K > 0 && lower_only && nsplit == 8 && M == Nc) ? splitk_sub(M, K) : 1;
+  const long n_t = M / TILE, tiles = n_t * (n_t + 1) / 2;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, part,
-                     part_stride, nsplit, C, ldc, M, Nc, alpha, beta, lower_only);
+                     part_stride, nsplit, C, ldc, M, Nc, alpha, beta, lower_only, (int)sub, tiles / 64 * 64);
   SGP_HIP(hipGetLastError());
   return 0;
 }
