@@ -196,7 +196,7 @@ int sgp_posterior_mean_var_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
  * learning (examples/getting_started/script.jl:154-213; AD glue: SURVEY.md section 2 #11).
  * With alpha = C^-1 (y - m) and G = (alpha alpha' - C^-1)/2 = d logpdf / d C:
  *   grad_y[N]    = -alpha          grad_mean[N] = +alpha
- *   grad_noise   = tr G (SCALAR, 1 value)  or  diag G (DIAG, N values)
+ *   grad_noise   = tr G (SCALAR, 1 value), diag G (DIAG, N values) or G itself (DENSE: N x N, column-major, ld = N)
  *   grad_coef[t]    = sum_{i,j in block pair of term t} G_ij rs_i k_t(x_i, x_j) cs_j      = d/d coef_t
  *   grad_inscale[t] = sum G_ij coef_t rs_i cs_j d k_t(g x_i, g x_j)/dg at g = 1  (both inputs of the
  *                     term scaled by g: the derivative w.r.t. an inverse lengthscale / stretch)

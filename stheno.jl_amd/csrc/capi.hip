@@ -156,11 +156,13 @@ extern "C" int sgp_ctx_stage_ms(sgp_ctx* ctx, double* out16) {
 // Live contexts.  A posterior handle (sgp_post / sgp_sparse_post) may outlive the context it was created on -- it is freed
 // without it -- but predicting against it needs the context's streams, scratch and (multi-GPU) ranks: the predict entry
 // points look the context up here and fail cleanly when it is gone (advisor, round 3: that was a use-after-free).
+// (a destroyed context's address may be handed out again by the allocator: handles remember the context's SERIAL, too)
 static std::mutex g_live_mu;
 static std::set<const sgp_ctx*> g_live_ctx;
-static bool ctx_is_live(const sgp_ctx* c) {
+static long g_ctx_serial = 0;
+static bool ctx_is_live(const sgp_ctx* c, long serial) {
   std::lock_guard<std::mutex> lk(g_live_mu);
-  return g_live_ctx.count(c) != 0;
+  return g_live_ctx.count(c) != 0 && c->serial == serial;
 }
 
 extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
@@ -249,6 +251,7 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
   }
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
+    c->serial = ++g_ctx_serial;
     g_live_ctx.insert(c);
   }
   *out = c;
@@ -1179,7 +1182,7 @@ static int sgp_logpdf_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, const double*
   CtxScope scope(ctx);
   // a multi-GPU context (sgp_ctx_create_multi) shards the covariance over its devices
   // (dense Sigma_y is an N x N host matrix: that case stays on devices[0])
-  if (ctx->multi && ncols >= 1 && noise_kind != SGP_NOISE_DENSE && noise)
+  if (ctx->multi && ncols >= 1 && noise)
     return sgp_multi_logpdf(ctx, spec, mean, noise_kind, noise, Y, ldy, ncols, out);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
@@ -1216,7 +1219,7 @@ static int sgp_rand_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* m
   CHECK_ARG(ctx && spec && Z && out, "sgp_rand: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_rand: spec must be symmetric");
   CtxScope scope(ctx);
-  if (ctx->multi && noise && noise_kind != SGP_NOISE_DENSE)
+  if (ctx->multi && noise)
     return sgp_multi_rand(ctx, spec, mean, noise_kind, noise, Z, ldz, S, out, ldo);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
@@ -1297,14 +1300,14 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
                             double* const* grad_inputs, double* const* grad_rowscale = nullptr) {
   CHECK_ARG(ctx && spec && noise && y && logpdf_out, "sgp_logpdf_grad: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_logpdf_grad: spec must be symmetric");
-  CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
-            "sgp_logpdf_grad: noise kind must be SCALAR or DIAG");
+  CHECK_ARG(noise_kind >= SGP_NOISE_SCALAR && noise_kind <= SGP_NOISE_DENSE, "sgp_logpdf_grad: bad noise kind");
   CtxScope scope(ctx);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   const sgp_dspec* ds = g.ds;
   long N = ds->N;
   CHECK_ARG(N >= 1, "sgp_logpdf_grad: empty data");
+  const bool dense_noise = noise_kind == SGP_NOISE_DENSE;   // grad_noise is then N x N (ld = N): the cotangent G itself
   long n_pad = rup(N, TILE);
   long nrows = TILE + n_pad;            // the (y - m)' row (+ zero padding), then the identity rows
   long m_tot = n_pad + nrows;
@@ -1320,7 +1323,7 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   size_t nterms_total = ds->h_terms.size();
   CHECK_RC(dgc.alloc(std::max<size_t>(1, nterms_total)));
   CHECK_RC(dgs.alloc(std::max<size_t>(1, nterms_total)));
-  CHECK_RC(dgn.alloc(n_pad));
+  CHECK_RC(dgn.alloc(dense_noise && grad_noise ? (size_t)N * N : (size_t)n_pad));
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
   SGP_HIP(hipMemsetAsync(dalpha.p, 0, sizeof(double) * n_pad, s));
   SGP_HIP(hipMemsetAsync(dgc.p, 0, sizeof(double) * std::max<size_t>(1, nterms_total), s));
@@ -1328,7 +1331,9 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   // K + Sigma_y, identity padding, bordered rows [(y - m)' ; I].  The identity rows come last so
   // that the rows a panel touches (K rows below it, the y row, identity rows above its last
   // column) are contiguous: the factorisation + inv(L) cost 2/3 N^3 instead of 4/3 N^3.
-  CHECK_RC(assemble(ds, dA.p, m_tot, 0, n_pad / TILE, 0, n_pad / TILE, 1, nd.kind, nd.sigma2, nd.diag.p, s));
+  CHECK_RC(assemble(ds, dA.p, m_tot, 0, n_pad / TILE, 0, n_pad / TILE, 1, dense_noise ? -1 : nd.kind, nd.sigma2,
+                    nd.diag.p, s));
+  if (dense_noise) CHECK_RC(launch_add_dense(dA.p, m_tot, nd.dense.p, nd.ld_dense, N, 1, s));
   CHECK_RC(launch_fill_pad(dA.p, m_tot, N, n_pad, 0, n_pad, m_tot, 0, s));
   CHECK_RC(launch_grad_border(dA.p, m_tot, n_pad, N, dy.p, mean ? dmean.p : nullptr, nrows, s));
   CHECK_RC(chol_bordered(ctx, dA.p, m_tot, n_pad, m_tot, nullptr, s, n_pad + TILE));
@@ -1346,7 +1351,8 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   // C^-1 = inv(L)' inv(L): lower tiles on the MFMA GEMM, then mirrored
   CHECK_RC(launch_gemm_nt_uut(Rinv, m_tot, dKinv.p, n_pad, n_pad, s));
   CHECK_RC(launch_mirror_lower(dKinv.p, n_pad, n_pad, s));
-  if (grad_noise) CHECK_RC(launch_grad_noise(dKinv.p, n_pad, dalpha.p, N, nd.kind == SGP_NOISE_DIAG, dgn.p, s));
+  if (grad_noise && dense_noise) CHECK_RC(launch_grad_noise_dense(dKinv.p, n_pad, dalpha.p, N, dgn.p, s));
+  else if (grad_noise) CHECK_RC(launch_grad_noise(dKinv.p, n_pad, dalpha.p, N, nd.kind == SGP_NOISE_DIAG, dgn.p, s));
   if (grad_coef || grad_inscale)
     CHECK_RC(contract_spec(ds, dKinv.p, n_pad, dalpha.p, n_pad / TILE, n_pad / TILE, dpart, dgc.p, dgs.p, s));
   // gradient w.r.t. the input points: row-side contraction over every block pair; the spec is
@@ -1398,7 +1404,8 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   if (grad_mean)
     for (long i = 0; i < N; ++i) grad_mean[i] = ha[i];
   if (grad_noise)
-    SGP_HIP(hipMemcpy(grad_noise, dgn.p, sizeof(double) * (nd.kind == SGP_NOISE_DIAG ? N : 1),
+    SGP_HIP(hipMemcpy(grad_noise, dgn.p,
+                      sizeof(double) * (dense_noise ? (size_t)N * N : (nd.kind == SGP_NOISE_DIAG ? (size_t)N : (size_t)1)),
                       hipMemcpyDeviceToHost));
   if (grad_coef && nterms_total)
     SGP_HIP(hipMemcpy(grad_coef, dgc.p, sizeof(double) * nterms_total, hipMemcpyDeviceToHost));
@@ -1451,6 +1458,7 @@ extern "C" int sgp_logpdf_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const d
 // ---------------------------------------------------------------------------------------
 struct sgp_post {
   sgp_ctx* ctx = nullptr;
+  long ctx_serial = 0;
   long N = 0, n_pad = 0, m_tot = 0;
   double* dA = nullptr;     // L (lower tiles) + row n_pad = (L^-1 (y - m))'
   double* d_wall = nullptr; // inverse 16x16 diagonal blocks (INVD_STRIDE per 128-block)
@@ -1577,11 +1585,12 @@ static int sgp_posterior_create_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, con
   CHECK_ARG(ctx && spec && y && out, "sgp_posterior_create: NULL argument");
   CHECK_ARG(spec->symmetric, "sgp_posterior_create: spec must be symmetric");
   CtxScope scope(ctx);
-  if (ctx->multi && noise && noise_kind != SGP_NOISE_DENSE) {
+  if (ctx->multi && noise) {
     sgp_mpost* mp = nullptr;
     CHECK_RC(sgp_multi_posterior_create(ctx, spec, mean, noise_kind, noise, y, alpha_out, &mp));
     sgp_post* post = new sgp_post();
     post->ctx = ctx;
+    post->ctx_serial = ctx->serial;
     post->mp = mp;
     *out = post;
     return 0;
@@ -1600,6 +1609,7 @@ static int sgp_posterior_create_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, con
   CHECK_RC(dY.upload(y, N));
   sgp_post* post = new sgp_post();
   post->ctx = ctx;
+  post->ctx_serial = ctx->serial;
   post->N = N;
   post->n_pad = n_pad;
   post->m_tot = m_tot;
@@ -1693,7 +1703,8 @@ extern "C" int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross,
                                      int64_t ldcov) {
   CHECK_ARG(post && cross, "sgp_posterior_predict: NULL argument");
   sgp_ctx* ctx = post->ctx;
-  CHECK_ARG(ctx_is_live(ctx), "sgp_posterior_predict: the context this posterior was created on has been destroyed");
+  CHECK_ARG(ctx_is_live(ctx, post->ctx_serial),
+            "sgp_posterior_predict: the context this posterior was created on has been destroyed");
   CtxScope scope(ctx);
   if (post->mp) return sgp_multi_posterior_predict(post->mp, cross, prior_ss, mean_s, mean_out, var_out, cov_out, ldcov);
   SpecGuard gc, gp;
@@ -1796,6 +1807,7 @@ __global__ void set_row_kernel(double* G, long ld, long row, const double* v, lo
 
 struct sgp_sparse_post {
   sgp_ctx* ctx = nullptr;
+  long ctx_serial = 0;
   long M = 0, m_pad = 0;
   double* dLz = nullptr;   // m_pad x m_pad factor of Kzz + Sigma_z (ld = m_pad)
   double* d_wz = nullptr;  // inverse diagonal blocks of Lz
@@ -2018,6 +2030,7 @@ static int vfe_pipeline_chunked(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dsp
   CHECK_RC(vfe_finish(ctx, d_part, m_pad, keep ? keep->d_wg : nullptr, h, tm));
   if (keep) {
     keep->ctx = ctx;
+    keep->ctx_serial = ctx->serial;
     keep->M = M;
     keep->m_pad = m_pad;
     keep->ldg = m_pad + TILE;
@@ -2214,6 +2227,7 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   }
   if (keep) {
     keep->ctx = ctx;
+    keep->ctx_serial = ctx->serial;
     keep->M = M;
     keep->m_pad = m_pad;
     keep->ldg = ldg;
@@ -2713,6 +2727,7 @@ static int sgp_sparse_posterior_create_impl(sgp_ctx* ctx, const sgp_cov_spec* zz
     // data points sharded over the ranks; the M x M factors of the posterior are kept on devices[0]
     const long M = spec_rows_host(zz), m_pad = rup(M, TILE);
     p->ctx = ctx;
+    p->ctx_serial = ctx->serial;
     p->M = M;
     p->m_pad = m_pad;
     p->ldg = m_pad + TILE;
@@ -2758,7 +2773,8 @@ extern "C" int sgp_sparse_posterior_predict(sgp_sparse_post* post, const sgp_cov
                                             int64_t ldcov) {
   CHECK_ARG(post && cross, "sgp_sparse_posterior_predict: NULL argument");
   sgp_ctx* ctx = post->ctx;
-  CHECK_ARG(ctx_is_live(ctx), "sgp_sparse_posterior_predict: the context this posterior was created on has been destroyed");
+  CHECK_ARG(ctx_is_live(ctx, post->ctx_serial),
+            "sgp_sparse_posterior_predict: the context this posterior was created on has been destroyed");
   CtxScope scope(ctx);
   SpecGuard gc, gp;
   CHECK_RC(dspec_create(ctx, cross, &gc.ds));

@@ -127,6 +127,7 @@ int launch_border_rows(double* A, long ld, long n_pad, long N, long c0, long nc,
 int launch_diag_terms(double* out, long n, const DevTerm* d_terms, int nterms, hipStream_t s);
 int launch_add_dense(double* K, long ld, const double* S, long lds, long N, int lower_only,
                      hipStream_t s);
+int launch_add_dense_cols(double* P, long ldp, const double* S, long lds, long c0, long w, long N, hipStream_t s);
 int launch_mirror_lower(double* K, long ld, long N, hipStream_t s);
 
 // gemm_nt.hip : C = beta*C + alpha * A B'   (A: M x K, B: Nc x K, all column-major)
@@ -208,6 +209,7 @@ int launch_grad_border(double* A, long ld, long n_pad, long N, const double* y, 
                        long nrows, hipStream_t s);
 int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N, int diag, double* out,
                       hipStream_t s);
+int launch_grad_noise_dense(const double* Kinv, long ldk, const double* alpha, long N, double* out, hipStream_t s);
 
 // potrf.hip
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,

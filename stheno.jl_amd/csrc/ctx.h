@@ -42,6 +42,7 @@ int sgp_multi_vfe(struct sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spe
 
 struct sgp_ctx {
   int device = 0;
+  long serial = 0;                // unique per created context (capi.hip: ctx_is_live)
   sgp_multi* multi = nullptr;     // non-null: the operators shard over several GPUs (sgp_ctx_create_multi)
   int multi_nranks = 0;
   hipStream_t stream = nullptr;   // panel / critical-path stream (high priority)

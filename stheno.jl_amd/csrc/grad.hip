@@ -280,6 +280,21 @@ __global__ void grad_noise_kernel(const double* Kinv, long ldk, const double* al
   if (threadIdx.x == 0 && !diag) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// dense Sigma_y: out[r + c * N] = (alpha_r alpha_c - Kinv[r, c]) / 2 = d logpdf / d Sigma_y[r, c] (the cotangent G itself)
+__global__ void grad_noise_dense_kernel(const double* Kinv, long ldk, const double* alpha, long N, double* out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * N) return;
+  const long r = idx % N, c = idx / N;
+  out[idx] = 0.5 * (alpha[r] * alpha[c] - Kinv[r + c * ldk]);
+}
+int launch_grad_noise_dense(const double* Kinv, long ldk, const double* alpha, long N, double* out, hipStream_t s) {
+  const long tot = N * N;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(grad_noise_dense_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Kinv, ldk, alpha, N, out);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N, int diag, double* out,
                       hipStream_t s) {
   hipLaunchKernelGGL(grad_noise_kernel, dim3(1), dim3(256), 0, s, Kinv, ldk, alpha, N, diag, out);

@@ -572,6 +572,25 @@ int launch_add_dense(double* K, long ld, const double* S, long lds, long N, int 
   return 0;
 }
 
+// dense Sigma_y onto ONE packed column panel of a sharded factorisation (multi.hip): columns c0 .. c0 + w, rows c0 .. N;
+// P[(r - c0) + lc * ldp] += S[(r - c0) + lc * lds] on the tiles the factorisation reads (tile row >= tile column)
+__global__ void add_dense_cols_kernel(double* P, long ldp, const double* S, long lds, long c0, long w, long N) {
+  const long rows = N - c0;
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * w) return;
+  const long rr = idx % rows, lc = idx / rows;
+  if (c0 + lc >= N) return;
+  if ((rr / TILE) < (lc / TILE)) return;   // (c0 is a multiple of 128: tile indices relative to the panel)
+  P[rr + lc * ldp] += S[rr + lc * lds];
+}
+int launch_add_dense_cols(double* P, long ldp, const double* S, long lds, long c0, long w, long N, hipStream_t s) {
+  const long tot = (N - c0) * w;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(add_dense_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, P, ldp, S, lds, c0, w, N);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 // K[r, c] = K[c, r] for r < c: makes a symmetric covariance bit-exactly symmetric (multi-term
 // blocks sum their cross terms in a different order above and below the diagonal).
 __global__ void mirror_lower_kernel(double* K, long ld, long N) {

@@ -740,6 +740,8 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   const int P = (int)g.P;
   const long N = g.N, S = g.S;
   const double s2 = noise_kind == SGP_NOISE_SCALAR ? noise[0] : 0.0;
+  const bool dense_noise = noise_kind == SGP_NOISE_DENSE;   // noise: host N x N, column-major, ld = N
+  const int asm_kind = dense_noise ? SGP_NOISE_SCALAR : noise_kind;   // (dense: assembled with s2 = 0, the slabs added below)
   const SmallLayout L(N, S);
   const bool prof = m->profile != 0;
   if (prof) m->prof.assign((size_t)g.npan * (3 + 3 * P), 0.0);
@@ -787,12 +789,23 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
       M_HIP(hipMemcpyAsync(dNz, noise, sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
     M_HIP(hipMemsetAsync(dSc, 0, sizeof(double) * (16 + 2 * std::max<long>(S, 1)), k.s_upd));
     M_HIP(hipMemsetAsync(k.d_info, 0, sizeof(int), k.s_upd));
-    // ---- assembly of the owned panels: no communication
+    // ---- assembly of the owned panels: no communication.  A dense Sigma_y (round 4) is added slab by slab: the owner of
+    // panel J stages rows J0 .. N of ITS columns of the host matrix (one strided copy) and adds them on the tiles the
+    // factorisation reads -- every rank touches 1 / P of the matrix, nothing travels between ranks.
+    if (dense_noise) M_RC(grow(&k.d_work, &k.work_cap, (size_t)N * std::min<long>(g.W, N)));
     for (long J = i; J < g.npan; J += P) {
       double* base = F.panel(i, J);
       M_RC(sgp_dev_assemble_cols(k.ctx, ds[i], N, g.col0(J), g.width(J), base - g.col0(J), g.ldp(J), g.m_tot,
-                                 mean ? dM : nullptr, noise_kind, &s2, noise_kind == SGP_NOISE_DIAG ? dNz : nullptr,
+                                 mean ? dM : nullptr, asm_kind, &s2, noise_kind == SGP_NOISE_DIAG ? dNz : nullptr,
                                  S > 0 ? dY : nullptr, N, S, (void*)k.s_upd));
+      const long c0 = g.col0(J), wv = std::min(g.width(J), N - c0);
+      if (dense_noise && wv > 0) {
+        const long rows = N - c0;
+        M_HIP(hipSetDevice(k.dev));
+        M_HIP(hipMemcpy2DAsync(k.d_work, sizeof(double) * rows, noise + c0 + c0 * N, sizeof(double) * N, sizeof(double) * rows,
+                               (size_t)wv, hipMemcpyHostToDevice, k.s_upd));
+        M_RC(launch_add_dense_cols(base, g.ldp(J), k.d_work, rows, c0, wv, N, k.s_upd));
+      }
     }
     M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
   }
@@ -1086,8 +1099,8 @@ int sgp_multi_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
   const int P = (int)m->r.size();
   const long N = spec_rows(spec);
   M_CHECK_ARG(N >= 1 && ncols >= 1 && ldy >= N, "sgp_logpdf (multi): bad sizes");
-  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
-              "sgp_logpdf (multi): noise kind must be SCALAR or DIAG");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG || noise_kind == SGP_NOISE_DENSE,
+              "sgp_logpdf (multi): bad noise kind");
   Fact F;
   F.g = make_geometry(m, N, ncols);
   const SmallLayout L(N, ncols);
@@ -1144,8 +1157,8 @@ int sgp_multi_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, i
   const int P = (int)m->r.size();
   const long N = spec_rows(spec);
   M_CHECK_ARG(N >= 1 && S >= 1 && ldz >= N && ldo >= N, "sgp_rand (multi): bad sizes");
-  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
-              "sgp_rand (multi): noise kind must be SCALAR or DIAG");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG || noise_kind == SGP_NOISE_DENSE,
+              "sgp_rand (multi): bad noise kind");
   Fact F;
   F.g = make_geometry(m, N, 0);
   const Geometry& g = F.g;
@@ -1231,8 +1244,8 @@ int sgp_multi_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
   const int P = (int)m->r.size();
   const long N = spec_rows(spec);
   M_CHECK_ARG(N >= 1, "sgp_posterior_create (multi): empty data");
-  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
-              "sgp_posterior_create (multi): noise kind must be SCALAR or DIAG");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG || noise_kind == SGP_NOISE_DENSE,
+              "sgp_posterior_create (multi): bad noise kind");
   sgp_mpost* mp = new sgp_mpost();
   mp->ctx = ctx;
   for (auto& k : m->r) mp->devs.push_back(k.dev);

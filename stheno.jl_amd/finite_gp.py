@@ -307,11 +307,10 @@ def logpdf_and_gradient(fx, y, inputs=False, scales=False):
     spec = _prior_spec(fx.f, fx.x)
     m = _f64(mean_vector(fx.f, fx.x))
     kind, nbuf = _lib._noise_args(fx.noise, n)
-    if kind == _lib.NOISE_DENSE:
-        raise NotImplementedError("gradient with dense observation noise")
     lp = np.zeros(1)
     gy, gm = np.zeros(n), np.zeros(n)
-    gn = np.zeros(n if kind == _lib.NOISE_DIAG else 1)
+    # dense Sigma_y (round 4): the gradient w.r.t. the matrix is the cotangent G = (alpha alpha' - C^-1) / 2 itself, N x N
+    gn = np.zeros((n, n), order="F") if kind == _lib.NOISE_DENSE else np.zeros(n if kind == _lib.NOISE_DIAG else 1)
     nt = max(1, spec.n_terms)
     gc, gs = np.zeros(nt), np.zeros(nt)
     gx = None
@@ -351,7 +350,7 @@ def logpdf_and_gradient(fx, y, inputs=False, scales=False):
     # fx.x (one (D, n) array per block; blocks sharing one input object get their joint gradient in
     # the first of them)
     xb = chain_input_gradients(spec, gx)[0] if inputs else None
-    return dict(logpdf=float(lp[0]), y=gy, mean=gm, noise=(gn if kind == _lib.NOISE_DIAG else float(gn[0])),
+    return dict(logpdf=float(lp[0]), y=gy, mean=gm, noise=(gn if kind != _lib.NOISE_SCALAR else float(gn[0])),
                 terms=terms, inputs=gx, x=xb, scales=(_scale_records(spec, grs) if scales else None),
                 _raw=(gc, gs), _rowscale=grs, _spec=spec)
 

@@ -414,8 +414,6 @@ class FakeLib:
         return 0
 
     def sgp_logpdf_grad_xs(self, ctx, spec, mean, kind, noise, y, lp_out, gy, gm, gn, gc, gs, grad_inputs, grad_rowscale):
-        if kind == L.NOISE_DENSE:
-            return self._fail("gradient: noise kind must be SCALAR or DIAG")
         s, m, Cm, rc = self._observed(spec, mean, kind, noise)
         if rc:
             return rc
@@ -438,6 +436,8 @@ class FakeLib:
         if gn:
             if kind == L.NOISE_SCALAR:
                 gn[0] = np.trace(G)
+            elif kind == L.NOISE_DENSE:
+                _mat(gn, s.N, s.N, s.N)[:, :] = G
             else:
                 _vec(gn, s.N)[:] = np.diag(G)
         nt = len(s.terms)

@@ -390,3 +390,40 @@ def test_predicting_on_a_posterior_whose_context_is_gone_fails_cleanly(panel128)
             post.mean(xnew)
         assert "destroyed" in str(e.value)
         del post
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_dense_observation_noise_on_the_multi_gpu_context(panel128, nranks):
+    """Round 4: f(x, S::Matrix) -- a dense Sigma_y (/root/reference/test/affine_transformations/test_util.jl:114-120 treats
+    dense, diagonal and isotropic noise alike) -- no longer falls back to devices[0]: the owner of a panel adds its column
+    slab of Sigma_y at assembly, nothing travels.  logpdf, posterior and rand against the single-GPU driver and the oracle."""
+    import oracle.abstractgps as oagp
+    import oracle.kernelfunctions as okf
+    import oracle.stheno as ost
+    import models
+    N = 1111
+    F, x, xs, y, xnew = _post_problem(N, 25)
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((N, 7))
+    S = 0.05 * np.eye(N) + 0.01 * B @ B.T                      # dense, positive definite
+    v0 = P.logpdf(F(x, S), y)
+    fo, go = models.gppp_docstring(models.oracle_api())
+    Fo = ost.GPPP(fo, go)
+    xo = ost.BlockData([ost.GPPPInput(k, okf.ColVecs(v)) for k, v in zip(("f1", "f2", "f3"), xs)])
+    ref = oagp.logpdf(Fo(xo, S), y)
+    assert abs(v0 - ref) <= 1e-10 * abs(ref)
+    ctx = P.lib.Context(devices=[0] * nranks)
+    v = _with_ctx(ctx, lambda: P.logpdf(F(x, S), y))
+    assert abs(v - ref) <= 1e-10 * abs(ref) and abs(v - v0) <= 1e-12 * abs(ref)
+    p0 = P.posterior(F(x, S), y)
+    pm = _with_ctx(ctx, lambda: P.posterior(F(x, S), y))
+    m0, c0 = P.mean_and_cov(p0(xnew))
+    m1, c1 = _with_ctx(ctx, lambda: P.mean_and_cov(pm(xnew)))
+    assert np.abs(m1 - m0).max() <= 1e-9 * max(1.0, np.abs(m0).max())
+    assert np.abs(c1 - c0).max() <= 1e-9 * max(1.0, np.abs(c0).max())
+    Z = np.random.default_rng(9).standard_normal((N, 3))
+    r0 = P.rand(None, F(x, S), 3, Z=Z)
+    r1 = _with_ctx(ctx, lambda: P.rand(None, F(x, S), 3, Z=Z))
+    assert np.abs(r1 - r0).max() <= 1e-9 * np.abs(r0).max()
+    del pm
+    ctx.close()

@@ -526,13 +526,17 @@ def test_logpdf_gradient_terms_noise_y_mean(recipe):
     xo, xp = blockdata(names, xs, True)
     N = sum(x.shape[1] for x in xs)
     y = rng.standard_normal(N)
-    for noise in (0.3, 0.1 + rng.random(N)):
+    Bd = rng.standard_normal((N, 5))
+    dense = 0.2 * np.eye(N) + 0.02 * Bd @ Bd.T          # f(x, S::Matrix): round 4, the gradient w.r.t. S is G itself
+    for noise in (0.3, 0.1 + rng.random(N), dense):
         lp_o, alpha, G = oagp.logpdf_gradient_wrt_cov(Fo(xo, noise), y)
         g = P.logpdf_and_gradient(Fp(xp, noise), y)
         assert abs(g["logpdf"] - lp_o) <= REL * abs(lp_o)
         assert rel(g["y"], -alpha) < 1e-9 and rel(g["mean"], alpha) < 1e-9
         if np.ndim(noise) == 0:
             assert abs(g["noise"] - np.trace(G)) <= 1e-9 * max(1.0, abs(np.trace(G)))
+        elif np.ndim(noise) == 2:
+            assert g["noise"].shape == (N, N) and rel(g["noise"], G) < 1e-9
         else:
             assert rel(g["noise"], np.diag(G)) < 1e-9
         gc, gs = g["_raw"]
