@@ -100,7 +100,8 @@ int sgp_abi_version(void);
 int sgp_ctx_create(int device, sgp_ctx** out);
 /* One context over several GPUs of the node (BASELINE.json north_star).  On such a context
  *   sgp_logpdf            shards the N x N covariance in column panels, block-cyclic over devices[0..ndev):
- *                         right-looking blocked Cholesky with one-panel look-ahead; factored panels travel by RCCL
+ *                         right-looking blocked Cholesky, the chain factorisation -> transport -> look-ahead update
+ *                         pipelined in sub-panels, ONE batched update launch per rank and step; panels travel by RCCL
  *                         (ncclCommInitAll inside, one grouped ncclBroadcast per panel over xGMI) or by peer copies as
  *                         scatter + all-gather (every receiver's ndev - 1 ingress links carry a slab each;
  *                         SGP_MULTI_TRANSPORT=rccl|p2p|auto, SGP_MULTI_BCAST=direct for one copy owner -> receiver);
@@ -109,8 +110,13 @@ int sgp_ctx_create(int device, sgp_ctx** out);
  *                         one n* x W reduction per panel) -- any number of predictions per factor;
  *   sgp_rand              multiplies every rank's own panels of L with Z, one reduction;
  *   sgp_elbo              shards the DATA POINTS (sgp_dev_elbo_partial per rank, ONE reduction of M^2 + M + 2 doubles).
- * One host thread, one `ccall`: the Julia side is unchanged.  Dense Sigma_y, the gradients, the sparse posterior and
- * the covariance entry points run on devices[0].  A device listed several times gives that many ranks on one GPU
+ *   sgp_logpdf_grad       (round 4) the kept sharded factor, L^-T through the posterior's row sweep, C^-1 as a sum over
+ *                         ranks with a reduce-scatter by column slabs, every rank contracting its slabs with the kernel
+ *                         derivatives: gradients w.r.t. the kernel terms, scalar / diagonal noise, y and the mean.
+ * Dense Sigma_y shards as well (round 4: the owner of a panel adds its column slab at assembly).
+ * One host thread, one `ccall`: the Julia side is unchanged.  The input-point / function-scale gradients
+ * (sgp_logpdf_grad_x / _xs), a gradient with dense Sigma_y, the ELBO gradients, the M x M factors of a sparse posterior
+ * and the covariance entry points run on devices[0].  A device listed several times gives that many ranks on one GPU
  * (test configuration).  SGP_MULTI_PANEL=<cols> sets the panel width (default 1024).  sgp_ctx_ndev -> number of ranks
  * (1 for an ordinary context); sgp_ctx_transport -> "single" | "rccl" | "p2p" | "p2p-staged" (peer access missing:
  * refused unless SGP_MULTI_ALLOW_STAGED=1) | "loopback". */

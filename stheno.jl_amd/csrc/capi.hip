@@ -1302,6 +1302,11 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   CHECK_ARG(spec->symmetric, "sgp_logpdf_grad: spec must be symmetric");
   CHECK_ARG(noise_kind >= SGP_NOISE_SCALAR && noise_kind <= SGP_NOISE_DENSE, "sgp_logpdf_grad: bad noise kind");
   CtxScope scope(ctx);
+  // a multi-GPU context shards the gradient w.r.t. the kernel terms, the noise, y and the mean (multi.hip); the
+  // input-point / function-scale gradients and a dense Sigma_y run on devices[0]
+  if (ctx->multi && !grad_inputs && !grad_rowscale && noise_kind != SGP_NOISE_DENSE)
+    return sgp_multi_logpdf_grad(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise, grad_coef,
+                                 grad_inscale);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   const sgp_dspec* ds = g.ds;

@@ -191,7 +191,8 @@ long splitk_slabs(long M, long K, int nsplit);   // slabs launch_gemm_nt_splitk 
 // grad.hip
 int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0, long nc,
                       const DevTerm* d_terms, int nterms, int dmax, long trf, long tcf, long trc, long tcc,
-                      double* partials, double* out_coef, double* out_scale, hipStream_t s);
+                      double* partials, double* out_coef, double* out_scale, hipStream_t s, int accumulate = 0,
+                      long clo = -(1L << 60), long chi = (1L << 60));   // accumulate into out_*; column window [clo, chi)
 int launch_diag_grad(const double* w, long n, const DevTerm* d_terms, int nterms, double* out_coef,
                      double* out_scale, hipStream_t s);
 int launch_diag_scale_grad(const double* w, long n, const DevTerm& T, double* out_rs, double* out_cs, hipStream_t s);

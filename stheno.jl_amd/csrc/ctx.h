@@ -33,6 +33,9 @@ int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const 
                                 const double* mean_s, double* mean_out, double* var_out, double* cov_out,
                                 int64_t ldcov);
 void sgp_multi_posterior_destroy(sgp_mpost* mp);
+int sgp_multi_logpdf_grad(struct sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
+                          const double* noise, const double* y, double* logpdf_out, double* grad_y, double* grad_mean,
+                          double* grad_noise, double* grad_coef, double* grad_inscale);
 // h6: the six terms of the bound (capi.hip: vfe_pipeline).  dLz / d_wz / d_part0 / d_wg non-NULL (device 0
 // buffers): the M x M factors a sparse posterior keeps (d_part0 doubles as rank 0's part and ends up holding chol(A A' + I))
 int sgp_multi_vfe(struct sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,

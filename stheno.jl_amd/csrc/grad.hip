@@ -60,7 +60,8 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
                                                          long r0, long nr, long c0, long nc,
                                                          const DevTerm* terms, int nterms,
                                                          long tile_r_first, long tile_c_first,
-                                                         double* partials /*[blocks][GRAD_MAXT][2]*/) {
+                                                         double* partials /*[blocks][GRAD_MAXT][2]*/,
+                                                         long clo, long chi) {   // column window inside the block (absolute)
   // terms per launch: nterms * DMAX <= 64 (the launcher groups them so), at most GRAD_MAXT
   constexpr int TMAX = (64 / DMAX < GRAD_MAXT) ? 64 / DMAX : GRAD_MAXT;
   const long gtr = tile_r_first + blockIdx.x;
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
   long cbeg = gtc * TILE, cend = cbeg + TILE;
   if (cbeg < c0) cbeg = c0;
   if (cend > c0 + nc) cend = c0 + nc;
+  if (cbeg < clo) cbeg = clo;   // (a rank of the sharded gradient contracts the columns of ITS panels only: multi.hip)
+  if (cend > chi) cend = chi;
   long rbeg = gtr * TILE, rend = rbeg + TILE;
   if (rbeg < r0) rbeg = r0;
   if (rend > r0 + nr) rend = r0 + nr;
@@ -174,7 +177,7 @@ __global__ __launch_bounds__(256) void grad_block_kernel(const double* Kinv, lon
 // out[t*2 + c] = sum_b partials[b][t][c]: one workgroup per output, 256 strided partial sums
 // combined by a fixed tree (deterministic)
 __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partials, long nblocks, int nterms,
-                                                          double* out_coef, double* out_scale) {
+                                                          double* out_coef, double* out_scale, int accumulate) {
   __shared__ double sh[256];
   const int idx = blockIdx.x;  // term * 2 + component
   double s = 0.0;
@@ -186,17 +189,15 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partials
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (idx & 1)
-      out_scale[idx >> 1] = sh[0];
-    else
-      out_coef[idx >> 1] = sh[0];
+    double* dst = (idx & 1) ? out_scale + (idx >> 1) : out_coef + (idx >> 1);
+    *dst = accumulate ? *dst + sh[0] : sh[0];
   }
 }
 
 template <int DMAX>
 static int launch_grad_t(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0,
                          long nc, const DevTerm* d_terms, int nterms, long trf, long tcf, long trc, long tcc,
-                         double* partials, hipStream_t s) {
+                         double* partials, hipStream_t s, long clo, long chi) {
   constexpr int TMAX = (64 / DMAX < GRAD_MAXT) ? 64 / DMAX : GRAD_MAXT;
   if (nterms > TMAX) {
     set_error("grad: too many terms in one launch for this input dimension");
@@ -206,21 +207,22 @@ static int launch_grad_t(const double* Kinv, long ldk, const double* alpha, long
   dim3 grid((unsigned)trc, (unsigned)tcc), block(256);
   SGP_LDS_ATTR_ONCE(grad_block_kernel<DMAX>, lds);
   hipLaunchKernelGGL(grad_block_kernel<DMAX>, grid, block, lds, s, Kinv, ldk, alpha, r0, nr, c0, nc, d_terms,
-                     nterms, trf, tcf, partials);
+                     nterms, trf, tcf, partials, clo, chi);
   SGP_HIP(hipGetLastError());
   return 0;
 }
 
 int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0, long nc,
                       const DevTerm* d_terms, int nterms, int dmax, long trf, long tcf, long trc, long tcc,
-                      double* partials, double* out_coef, double* out_scale, hipStream_t s) {
+                      double* partials, double* out_coef, double* out_scale, hipStream_t s, int accumulate, long clo,
+                      long chi) {
   if (nterms <= 0 || trc <= 0 || tcc <= 0) return 0;
   if (nterms > GRAD_MAXT) {
     set_error("grad: too many terms in one launch");
     return -1;
   }
   int rc = -1;
-#define SGP_GR(DM) rc = launch_grad_t<DM>(Kinv, ldk, alpha, r0, nr, c0, nc, d_terms, nterms, trf, tcf, trc, tcc, partials, s)
+#define SGP_GR(DM) rc = launch_grad_t<DM>(Kinv, ldk, alpha, r0, nr, c0, nc, d_terms, nterms, trf, tcf, trc, tcc, partials, s, clo, chi)
   if (dmax <= 1) SGP_GR(1);
   else if (dmax <= 2) SGP_GR(2);
   else if (dmax <= 4) SGP_GR(4);
@@ -235,7 +237,7 @@ int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0
 #undef SGP_GR
   if (rc) return rc;
   hipLaunchKernelGGL(grad_reduce_kernel, dim3((unsigned)(nterms * 2)), dim3(256), 0, s, partials, trc * tcc, nterms, out_coef,
-                     out_scale);
+                     out_scale, accumulate);
   SGP_HIP(hipGetLastError());
   return 0;
 }

@@ -1345,6 +1345,64 @@ int sgp_multi_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
   return 0;
 }
 
+// R <- R L^-T for ns_pad rows held column-sharded like the factor (rank i: ns_pad x its columns in d_work, panel after panel,
+// at[i][l] = column offset of its l-th panel; the partial-sum scratch S behind them; mp->stage sized by the caller): the
+// left-looking sweep over the panels of the kept factor -- every rank forms the partial sums of its own earlier panels, the
+// owner collects them in rank order and solves against its diagonal block.
+static int sweep_rows(sgp_multi* m, sgp_mpost* mp, long ns_pad, const std::vector<std::vector<long>>& at) {
+  const Fact& F = mp->F;
+  const Geometry& g = F.g;
+  const int P = (int)g.P;
+  std::vector<char> stage_used(P, 0);
+  for (long J = 0; J < g.npan; ++J) {
+    const int o = g.owner(J);
+    const long J0 = g.col0(J), w = g.width(J);
+    Rank& ko = m->r[o];
+    double* Tj = ko.d_work + (size_t)at[o][g.local(J)] * ns_pad;   // R_J, becomes V_J
+    bool used_now = false;
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      const long nco = g.ncols_owned(i);
+      double* Si = k.d_work + (size_t)ns_pad * std::max<long>(nco, 1);
+      bool first = true, any = false;
+      for (long kk = i; kk < J; kk += P) {
+        // V_kk (ns_pad x w_kk) times rows J0 .. J0 + w of panel kk
+        const double* Vk = k.d_work + (size_t)at[i][g.local(kk)] * ns_pad;
+        const double* Ljk = F.panel(i, kk) + (J0 - g.col0(kk));
+        if (i == o)
+          M_RC(launch_gemm_nt(Vk, ns_pad, Ljk, g.ldp(kk), Tj, ns_pad, ns_pad, w, g.width(kk), -1.0, 1.0, -(1L << 40), 0,
+                              0, k.s_upd));
+        else
+          M_RC(launch_gemm_nt(Vk, ns_pad, Ljk, g.ldp(kk), Si, ns_pad, ns_pad, w, g.width(kk), 1.0, first ? 0.0 : 1.0,
+                              -(1L << 40), 0, 0, k.s_upd));
+        first = false;
+        any = true;
+      }
+      if (i != o && any) {
+        double* slot = mp->stage[o] + (size_t)(i < o ? i : i - 1) * ns_pad * g.W;
+        if (stage_used[o]) M_HIP(hipStreamWaitEvent(k.s_upd, ko.ev_done, 0));   // the slot's last content was consumed
+        if (k.dev == ko.dev)
+          M_HIP(hipMemcpyAsync(slot, Si, sizeof(double) * ns_pad * w, hipMemcpyDeviceToDevice, k.s_upd));
+        else
+          M_HIP(hipMemcpyPeerAsync(slot, ko.dev, Si, k.dev, sizeof(double) * ns_pad * w, k.s_upd));
+        M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
+        M_HIP(hipSetDevice(ko.dev));
+        M_HIP(hipStreamWaitEvent(ko.s_upd, k.ev_upd, 0));
+        M_RC(drv_axpy_block(Tj, ns_pad, slot, ns_pad, ns_pad, w, -1.0, ko.s_upd));   // rank order: deterministic
+        used_now = true;
+      }
+    }
+    M_HIP(hipSetDevice(ko.dev));
+    if (used_now) {
+      M_HIP(hipEventRecord(ko.ev_done, ko.s_upd));
+      stage_used[o] = 1;
+    }
+    M_RC(drv_row_trsm(ko.ctx, Tj, ns_pad, ns_pad, F.panel(o, J), g.ldp(J), F.invp(o, J), w, ko.s_upd));
+  }
+  return 0;
+}
+
 int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const sgp_cov_spec* prior_ss,
                                 const double* mean_s, double* mean_out, double* var_out, double* cov_out,
                                 int64_t ldcov) {
@@ -1392,54 +1450,7 @@ int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const 
         a += w;
       }
     }
-    // ---- V' = K(x*, x) L^-T, left-looking over the panels
-    std::vector<char> stage_used(P, 0);
-    for (long J = 0; J < g.npan; ++J) {
-      const int o = g.owner(J);
-      const long J0 = g.col0(J), w = g.width(J);
-      Rank& ko = m->r[o];
-      double* Tj = ko.d_work + (size_t)at[o][g.local(J)] * ns_pad;   // R_J, becomes V_J
-      bool used_now = false;
-      for (int i = 0; i < P; ++i) {
-        Rank& k = m->r[i];
-        M_HIP(hipSetDevice(k.dev));
-        const long nco = g.ncols_owned(i);
-        double* Si = k.d_work + (size_t)ns_pad * std::max<long>(nco, 1);
-        bool first = true, any = false;
-        for (long kk = i; kk < J; kk += P) {
-          // V_kk (ns_pad x w_kk) times rows J0 .. J0 + w of panel kk
-          const double* Vk = k.d_work + (size_t)at[i][g.local(kk)] * ns_pad;
-          const double* Ljk = F.panel(i, kk) + (J0 - g.col0(kk));
-          if (i == o)
-            M_RC(launch_gemm_nt(Vk, ns_pad, Ljk, g.ldp(kk), Tj, ns_pad, ns_pad, w, g.width(kk), -1.0, 1.0, -(1L << 40), 0,
-                                0, k.s_upd));
-          else
-            M_RC(launch_gemm_nt(Vk, ns_pad, Ljk, g.ldp(kk), Si, ns_pad, ns_pad, w, g.width(kk), 1.0, first ? 0.0 : 1.0,
-                                -(1L << 40), 0, 0, k.s_upd));
-          first = false;
-          any = true;
-        }
-        if (i != o && any) {
-          double* slot = mp->stage[o] + (size_t)(i < o ? i : i - 1) * ns_pad * g.W;
-          if (stage_used[o]) M_HIP(hipStreamWaitEvent(k.s_upd, ko.ev_done, 0));   // the slot's last content was consumed
-          if (k.dev == ko.dev)
-            M_HIP(hipMemcpyAsync(slot, Si, sizeof(double) * ns_pad * w, hipMemcpyDeviceToDevice, k.s_upd));
-          else
-            M_HIP(hipMemcpyPeerAsync(slot, ko.dev, Si, k.dev, sizeof(double) * ns_pad * w, k.s_upd));
-          M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
-          M_HIP(hipSetDevice(ko.dev));
-          M_HIP(hipStreamWaitEvent(ko.s_upd, k.ev_upd, 0));
-          M_RC(drv_axpy_block(Tj, ns_pad, slot, ns_pad, ns_pad, w, -1.0, ko.s_upd));   // rank order: deterministic
-          used_now = true;
-        }
-      }
-      M_HIP(hipSetDevice(ko.dev));
-      if (used_now) {
-        M_HIP(hipEventRecord(ko.ev_done, ko.s_upd));
-        stage_used[o] = 1;
-      }
-      M_RC(drv_row_trsm(ko.ctx, Tj, ns_pad, ns_pad, F.panel(o, J), g.ldp(J), F.invp(o, J), w, ko.s_upd));
-    }
+    M_RC(sweep_rows(m, mp, ns_pad, at));
     // ---- sums over columns = over ranks
     std::vector<double> dot(Ns, 0.0), ssq(Ns, 0.0), tmp(Ns), prior(Ns, 0.0);
     std::vector<double> G, Gt;
@@ -1518,6 +1529,207 @@ int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const 
   }
   drain(m, ds, ctx->device);
   return rc;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// logpdf and its reverse-mode gradient over the ranks (round 4; single-GPU: capi.hip: logpdf_grad_core) -- what Zygote
+// derives through logpdf(f(x, s2), y) for hyper-parameter learning (examples/getting_started/script.jl:154-213) at sizes
+// that need the node.  With alpha = C^-1 (y - m), G = (alpha alpha' - C^-1) / 2:
+//   1. the sharded factorisation, kept (sgp_multi_posterior_create: packed panels + inverse diagonal blocks, z, alpha);
+//   2. X = L^-T, column-sharded like the factor: the identity rides through the left-looking row sweep of the posterior
+//      (sweep_rows) -- rank i ends up with the columns of L^-T that belong to its panels;
+//   3. C^-1 = X X' = sum over ranks of X_i X_i': every rank forms its partial N x N product (one MFMA GEMM, K = its columns),
+//      then a reduce-scatter by column slabs with peer copies -- rank j adds, in rank order, the slabs of ITS columns;
+//   4. every rank contracts its column slabs of G with the kernel derivatives of every term (grad.hip: the single-GPU
+//      contraction kernel on a column window); the per-term sums are added over ranks in rank order on the host;
+//   5. d / d noise from diag C^-1 (each rank reports the diagonal entries of its columns), d / d y = -alpha, d / d m = alpha.
+// Per rank ~ (1/3 + 1/3 + 1) N^3 / P flops and (P - 1) / P N^2 doubles received; N^2 doubles of scratch per rank.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void set_identity_cols_kernel(double* blk, long ld, long c0, long w, long N) {
+  const long lc = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (lc < w && c0 + lc < N) blk[(c0 + lc) + lc * ld] = 1.0;
+}
+}  // namespace
+
+int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind, const double* noise,
+                          const double* y, double* logpdf_out, double* grad_y, double* grad_mean, double* grad_noise,
+                          double* grad_coef, double* grad_inscale) {
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  const long N = spec_rows(spec);
+  M_CHECK_ARG(N >= 1, "sgp_logpdf_grad (multi): empty data");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
+              "sgp_logpdf_grad (multi): noise kind must be SCALAR or DIAG");
+  M_CHECK_ARG(m->W <= 4096, "sgp_logpdf_grad (multi): panels wider than 4096 columns");
+  std::vector<double> alpha(N);
+  sgp_mpost* mp = nullptr;
+  M_RC(sgp_multi_posterior_create(ctx, spec, mean, noise_kind, noise, y, alpha.data(), &mp));
+  const Fact& F = mp->F;
+  const Geometry& g = F.g;
+  const long n_pad = g.n_pad;
+  const SmallLayout L(N, 1);
+  std::vector<sgp_dspec*> ds(P, nullptr);
+  size_t nterms = 0;
+  std::vector<double> gc_sum, gs_sum, kdiag(N, 0.0);
+  auto body = [&]() -> int {
+    // ---- logpdf from the scalars the factorisation left on every rank (rank order: deterministic)
+    double red[2] = {0.0, 0.0}, tmp[2];
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      M_HIP(hipMemcpy(tmp, k.d_small + L.scal, sizeof(double) * 2, hipMemcpyDeviceToHost));
+      red[0] += tmp[0];
+      red[1] += tmp[1];
+    }
+    *logpdf_out = -0.5 * ((double)N * 1.8378770664093453 + red[0] + red[1]);
+    // ---- X = L^-T: identity rows through the row sweep
+    std::vector<std::vector<long>> at(P);
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      const long nco = g.ncols_owned(i);
+      M_RC(grow(&k.d_work, &k.work_cap, (size_t)n_pad * std::max<long>(nco, 1) + (size_t)n_pad * g.W));
+      M_RC(grow(&k.d_work2, &k.work2_cap, (size_t)n_pad * n_pad + (size_t)n_pad + 4 * 4096));
+      if (P > 1) {
+        size_t need = (size_t)(P - 1) * n_pad * g.W;
+        if (need > mp->stage_cap[i]) M_RC(sync_all(m));
+        M_RC(grow(&mp->stage[i], &mp->stage_cap[i], need));
+      }
+      M_RC(drv_dspec_create(k.ctx, spec, &ds[i]));
+      M_HIP(hipMemsetAsync(k.d_work, 0, sizeof(double) * n_pad * std::max<long>(nco, 1), k.s_upd));
+      long a = 0;
+      for (long J = i; J < g.npan; J += P) {
+        at[i].push_back(a);
+        const long w = g.width(J);
+        hipLaunchKernelGGL(set_identity_cols_kernel, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, k.s_upd,
+                           k.d_work + (size_t)a * n_pad, n_pad, g.col0(J), w, N);
+        M_HIP(hipGetLastError());
+        a += w;
+      }
+    }
+    M_RC(sweep_rows(m, mp, n_pad, at));
+    // ---- partial C^-1 of every rank, then the reduce-scatter by column slabs
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      const long nco = g.ncols_owned(i);
+      if (nco > 0)
+        M_RC(launch_gemm_nt(k.d_work, n_pad, k.d_work, n_pad, k.d_work2, n_pad, n_pad, n_pad, nco, 1.0, 0.0, -(1L << 40), 0, 0,
+                            k.s_upd));
+      else
+        M_HIP(hipMemsetAsync(k.d_work2, 0, sizeof(double) * n_pad * n_pad, k.s_upd));
+      M_HIP(hipEventRecord(k.ev_done, k.s_upd));
+    }
+    for (int j = 0; j < P; ++j) {
+      Rank& kj = m->r[j];
+      M_HIP(hipSetDevice(kj.dev));
+      for (int i = 0; i < P; ++i)
+        if (i != j) M_HIP(hipStreamWaitEvent(kj.s_upd, m->r[i].ev_done, 0));
+      for (long J = j; J < g.npan; J += P) {
+        const long c0 = g.col0(J), w = g.width(J);
+        double* dst = kj.d_work2 + (size_t)c0 * n_pad;
+        for (int i = 0; i < P; ++i) {
+          if (i == j) continue;
+          Rank& ki = m->r[i];
+          double* slot = mp->stage[j] + (size_t)(i < j ? i : i - 1) * n_pad * g.W;
+          const double* src = ki.d_work2 + (size_t)c0 * n_pad;
+          if (ki.dev == kj.dev)
+            M_HIP(hipMemcpyAsync(slot, src, sizeof(double) * n_pad * w, hipMemcpyDeviceToDevice, kj.s_upd));
+          else
+            M_HIP(hipMemcpyPeerAsync(slot, kj.dev, src, ki.dev, sizeof(double) * n_pad * w, kj.s_upd));
+          M_RC(drv_axpy_block(dst, n_pad, slot, n_pad, n_pad, w, 1.0, kj.s_upd));   // rank order: deterministic
+        }
+      }
+    }
+    // (a rank's partial product is read by the others until their slabs are complete: nobody frees / reuses it before)
+    // ---- contraction of every rank's column slabs with the kernel derivatives, diag C^-1 of its columns
+    nterms = ds[0]->h_terms.size();
+    gc_sum.assign(std::max<size_t>(1, nterms), 0.0);
+    gs_sum.assign(std::max<size_t>(1, nterms), 0.0);
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      const sgp_dspec* d = ds[i];
+      double* d_alpha = k.d_work2 + (size_t)n_pad * n_pad;
+      double* d_gc = d_alpha + n_pad;          // nterms <= 4096 each (checked below)
+      double* d_gs = d_gc + 4096;
+      double* d_diag = d_gs + 4096;             // (4096 doubles: one panel's diagonal at a time)
+      M_CHECK_ARG(nterms <= 4096, "sgp_logpdf_grad (multi): more than 4096 terms");
+      M_HIP(hipMemsetAsync(d_alpha, 0, sizeof(double) * n_pad, k.s_upd));
+      M_HIP(hipMemcpyAsync(d_alpha, alpha.data(), sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
+      M_HIP(hipMemsetAsync(d_gc, 0, sizeof(double) * 2 * 4096, k.s_upd));
+      // partial-sum scratch of the contraction kernel: 16 doubles per tile of the largest window
+      double* d_part = k.d_work;   // (X is no longer needed)
+      M_CHECK_ARG((size_t)(n_pad / TILE) * (g.W / TILE) * 16 <= k.work_cap, "sgp_logpdf_grad (multi): scratch too small");
+      for (long J = i; J < g.npan; J += P) {
+        const long pc0 = g.col0(J), pw = std::min(g.width(J), N - pc0);
+        if (pw <= 0) continue;
+        if (grad_coef || grad_inscale)
+          for (int I = 0; I < d->nrb; ++I) {
+            if (d->row_len[I] == 0) continue;
+            for (int Jb = 0; Jb < d->ncb; ++Jb) {
+              if (d->col_len[Jb] == 0) continue;
+              // columns of block Jb inside this panel
+              const long bc0 = d->col_off[Jb], bc1 = bc0 + d->col_len[Jb];
+              const long lo = std::max(bc0, pc0), hi = std::min(bc1, pc0 + pw);
+              if (lo >= hi) continue;
+              const long r0 = d->row_off[I], nr = d->row_len[I];
+              const long trf = r0 / TILE, trl = (r0 + nr - 1) / TILE + 1, tcf = lo / TILE, tcl = (hi - 1) / TILE + 1;
+              const int p = I * d->ncb + Jb;
+              const int t0 = d->term_ptr[p], t1 = d->term_ptr[p + 1];
+              const int dmax = d->pair_dmax[p];
+              const int per = std::min(8, std::max(1, 64 / dmax));
+              for (int t = t0; t < t1; t += per) {
+                const int cnt = std::min(per, t1 - t);
+                // (the kernel masks entries outside rows r0 .. r0 + nr and columns lo .. hi of the block pair; the term's
+                // column points are addressed relative to the block's first column: the window starts at lo)
+                M_RC(launch_grad_block(k.d_work2, n_pad, d_alpha, r0, nr, bc0, bc1 - bc0, d->d_terms + t, cnt, dmax, trf, tcf,
+                                       trl - trf, tcl - tcf, d_part, d_gc + t, d_gs + t, k.s_upd, 1, lo, hi));
+              }
+            }
+          }
+        M_RC(drv_copy_strided(k.d_work2 + pc0 + (size_t)pc0 * n_pad, n_pad + 1, pw, d_diag, k.s_upd));
+        M_HIP(hipMemcpyAsync(kdiag.data() + pc0, d_diag, sizeof(double) * pw, hipMemcpyDeviceToHost, k.s_upd));
+        M_HIP(hipStreamSynchronize(k.s_upd));   // (d_diag is reused by the next panel; kdiag is pageable)
+      }
+    }
+    std::vector<double> tmpv(std::max<size_t>(1, nterms));
+    for (int i = 0; i < P; ++i) {   // rank order: deterministic
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      M_HIP(hipStreamSynchronize(k.s_upd));
+      if (nterms == 0) continue;
+      double* d_gc = k.d_work2 + (size_t)n_pad * n_pad + n_pad;
+      M_HIP(hipMemcpy(tmpv.data(), d_gc, sizeof(double) * nterms, hipMemcpyDeviceToHost));
+      for (size_t t = 0; t < nterms; ++t) gc_sum[t] += tmpv[t];
+      M_HIP(hipMemcpy(tmpv.data(), d_gc + 4096, sizeof(double) * nterms, hipMemcpyDeviceToHost));
+      for (size_t t = 0; t < nterms; ++t) gs_sum[t] += tmpv[t];
+    }
+    return 0;
+  };
+  int rc = body();
+  drain(m, ds, ctx->device);
+  sgp_multi_posterior_destroy(mp);
+  if (rc) return rc;
+  if (grad_y)
+    for (long i = 0; i < N; ++i) grad_y[i] = -alpha[i];
+  if (grad_mean)
+    for (long i = 0; i < N; ++i) grad_mean[i] = alpha[i];
+  if (grad_noise) {
+    if (noise_kind == SGP_NOISE_DIAG) {
+      for (long i = 0; i < N; ++i) grad_noise[i] = 0.5 * (alpha[i] * alpha[i] - kdiag[i]);
+    } else {
+      double acc = 0.0;
+      for (long i = 0; i < N; ++i) acc += 0.5 * (alpha[i] * alpha[i] - kdiag[i]);
+      grad_noise[0] = acc;
+    }
+  }
+  if (grad_coef)
+    for (size_t t = 0; t < nterms; ++t) grad_coef[t] = gc_sum[t];
+  if (grad_inscale)
+    for (size_t t = 0; t < nterms; ++t) grad_inscale[t] = gs_sum[t];
+  return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------------

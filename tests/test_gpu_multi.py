@@ -427,3 +427,31 @@ def test_dense_observation_noise_on_the_multi_gpu_context(panel128, nranks):
     assert np.abs(r1 - r0).max() <= 1e-9 * np.abs(r0).max()
     del pm
     ctx.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_logpdf_gradient_sharded_over_the_ranks(panel128, nranks):
+    """Round 4: sgp_logpdf_grad on a multi-GPU context -- the kept sharded factor, L^-T through the posterior's row sweep,
+    C^-1 = sum over ranks of X_i X_i' with a reduce-scatter by column slabs, every rank contracting its slabs with the
+    kernel derivatives -- against the single-GPU gradient (scalar and diagonal noise, a prior mean, several blocks and
+    terms; what Zygote derives for examples/getting_started/script.jl:154-213)."""
+    F, x, xs, y = _problem(1411, D=3)
+    ctx = P.lib.Context(devices=[0] * nranks)
+    for noise in (0.1, 0.05 + np.random.default_rng(3).random(len(y))):
+        g0 = P.logpdf_and_gradient(F(x, noise), y)
+        g1 = _with_ctx(ctx, lambda: P.logpdf_and_gradient(F(x, noise), y))
+        assert abs(g1["logpdf"] - g0["logpdf"]) <= 1e-11 * abs(g0["logpdf"])
+        assert np.abs(g1["y"] - g0["y"]).max() <= 1e-9 * np.abs(g0["y"]).max()
+        assert np.abs(g1["mean"] - g0["mean"]).max() <= 1e-9 * np.abs(g0["mean"]).max()
+        assert np.abs(np.asarray(g1["noise"]) - np.asarray(g0["noise"])).max() <= 1e-8 * max(1.0, np.abs(np.asarray(g0["noise"])).max())
+        assert len(g1["terms"]) == len(g0["terms"]) > 1
+        for t0, t1 in zip(g0["terms"], g1["terms"]):
+            assert (t0["I"], t0["J"], t0["kind"]) == (t1["I"], t1["J"], t1["kind"])
+            assert abs(t1["d_coef"] - t0["d_coef"]) <= 1e-8 * max(1.0, abs(t0["d_coef"]))
+            assert abs(t1["d_inscale"] - t0["d_inscale"]) <= 1e-8 * max(1.0, abs(t0["d_inscale"]))
+    # and against central differences of the sharded logpdf itself, for the noise
+    h = 1e-5
+    fd = (_with_ctx(ctx, lambda: P.logpdf(F(x, 0.1 + h), y)) - _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1 - h), y))) / (2 * h)
+    g = _with_ctx(ctx, lambda: P.logpdf_and_gradient(F(x, 0.1), y))
+    assert abs(g["noise"] - fd) <= 1e-5 * max(1.0, abs(fd))
+    ctx.close()
