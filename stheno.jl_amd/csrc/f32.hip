@@ -17,6 +17,7 @@
 // Entry points: sgp_logpdf_f32, sgp_kernelmatrix_f32, sgp_rand_f32, sgp_posterior_mean_var_f32 (include/sthenomi.h).  Accuracy is fp32's: the
 // tests hold 1e-4 relative on logpdf against the fp64 oracle at N <= 3000.
 #include "driver.h"
+#include "tilemap.h"
 
 #include <algorithm>
 #include <cmath>
@@ -146,17 +147,9 @@ template <int KBF, int OCC>
 __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_kernel(const float* A, long lda, const float* B, long ldb, float* C,
                                                             long ldc, long K, int lower, long n_tr, long n_tc) {
   long tr, tc;
-  if (lower) {   // 1-D grid over the live tiles only: the lower triangle of the n_tc x n_tc square, then full rows
-    const long id = blockIdx.x, tri = n_tc * (n_tc + 1) / 2;
-    if (id < tri) {
-      tr = (long)((sqrt(8.0 * (double)id + 1.0) - 1.0) * 0.5);
-      while (tr * (tr + 1) / 2 > id) --tr;
-      while ((tr + 1) * (tr + 2) / 2 <= id) ++tr;
-      tc = id - tr * (tr + 1) / 2;
-    } else {
-      tr = n_tc + (id - tri) / n_tc;
-      tc = (id - tri) % n_tc;
-    }
+  if (lower) {   // 1-D grid over the live tiles only, XCD-aware (tilemap.h: the fp64 update's enumeration -- every A row
+                 // panel goes through one XCD's L2, 64 consecutive workgroups of an XCD share 8 + 8 operand panels)
+    if (!tile_of_id((long)blockIdx.x, n_tr, n_tc, 0L, tr, tc)) return;
   } else {
     tr = blockIdx.x;
     tc = blockIdx.y;
@@ -164,13 +157,16 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_kernel(const float* A, l
   if (tr >= n_tr || tc >= n_tc) return;
   __shared__ __attribute__((aligned(16))) float sA[2][KBF * LDF];
   __shared__ __attribute__((aligned(16))) float sB[2][KBF * LDF];
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);   // (wave-uniform for the compiler too)
   const int wr = w >> 1, wc = w & 1;       // wave tile: rows wr * 64 .., cols wc * 64 ..
   const int l31 = lane & 31, lh = lane >> 5;
   const float* Ag = A + tr * TILE;
   const float* Bg = B + tc * TILE;
   // staging: thread t moves rows 4 (t & 31) .. +3 of columns (t >> 5) and (t >> 5) + 8 of both operands
   const int srow = 4 * (t & 31), scol = t >> 5;
+  // (seeding the accumulators with the old C tile in the prologue, as the fp64 kernel does, was tried in round 4: the 32
+  // column addresses then stay live across the main loop -- 118 -> 176 .. 238 VGPRs, half the occupancy, 1057 -> 1266 ms at
+  // N = 65536 -- so the tile is read-modified-written in the epilogue)
   f16v acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -240,9 +236,10 @@ int launch_gemm_f32(const float* A, long lda, const float* B, long ldb, float* C
   if (M <= 0 || Nc <= 0 || K <= 0) return 0;
   const long n_tr = M / TILE, n_tc = Nc / TILE;
   dim3 grid((unsigned)n_tr, (unsigned)n_tc);
-  if (lower) grid = dim3((unsigned)(n_tc * (n_tc + 1) / 2 + (n_tr - n_tc) * n_tc));   // (M >= Nc for every lower update)
+  if (lower) grid = dim3((unsigned)tile_ids(n_tr, n_tc, 0));   // (M >= Nc for every lower update)
   // (KBF = 32 and launch bounds asking for 3 - 4 workgroups per CU measured no better: 1244 / 1068 / 1070 ms vs
-  // 1069 ms at N = 65536 -- gpurun_out/f32_gemm_ab.txt)
+  // 1069 ms at N = 65536 -- gpurun_out/f32_gemm_ab.txt; round 4, with the deep serial schedule: <16, 4> (128 VGPRs, 4
+  // spills) 1036 ms vs <16, 2> (130 VGPRs) 987 ms)
   hipLaunchKernelGGL((gemm_nt_f32_kernel<16, 2>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, lower, n_tr, n_tc);
   SGP_HIP(hipGetLastError());
   return 0;
@@ -331,9 +328,29 @@ int panel_factor_f32(sgp_ctx* ctx, float* P, long ld, long m, long w, long g0, h
 // two-level right-looking Cholesky of the bordered fp32 matrix (m_tot x n_pad, ld) with the fp64 driver's
 // one-panel look-ahead (capi.hip: chol_bordered): the next panel is updated and factored on the panel stream
 // while the rest of the trailing matrix is updated with the current panel on the update stream
+// an outer panel of w columns by recursive halving down to wmid (the fp64 driver's panel_factor_mid): the left half, ONE
+// update of the right half with it (K = the half's width), the right half
+int panel_factor_mid_f32(sgp_ctx* ctx, float* P, long ld, long m, long w, long g0, hipStream_t s, long wmid) {
+  if (wmid <= 0 || w <= wmid) return panel_factor_f32(ctx, P, ld, m, w, g0, s);
+  const long wl = std::max(wmid, (w / 2 + wmid - 1) / wmid * wmid);
+  if (wl >= w) return panel_factor_f32(ctx, P, ld, m, w, g0, s);
+  if (int rc = panel_factor_mid_f32(ctx, P, ld, m, wl, g0, s, wmid)) return rc;
+  if (int rc = launch_gemm_f32(P + wl, ld, P + wl, ld, P + wl + wl * ld, ld, m - wl, w - wl, wl, 1, s)) return rc;
+  return panel_factor_mid_f32(ctx, P + wl + wl * ld, ld, m - wl, w - wl, g0 + wl, s, wmid);
+}
+
 int chol_f32(sgp_ctx* ctx, float* A, long ld, long n_pad, long m_tot, hipStream_t s) {
-  const long W = n_pad <= 2048 ? n_pad : (n_pad <= 8192 ? 1024 : 512);
-  const bool la = ctx->lookahead && s == ctx->stream;
+  // Round 4: from SGP_F32_SERIAL_N columns on (default 32768) the fp64 driver's serial deep schedule -- outer panels of
+  // 4096 columns factored by recursive halving down to 512, one K = 4096 trailing update per panel, no look-ahead: an fp32
+  // tile runs twice as fast as an fp64 one, so the per-tile prologue and the C-tile traffic of shallow (K = 512) updates
+  // weigh twice as much.
+  static const long serial_n = getenv("SGP_F32_SERIAL_N") ? atol(getenv("SGP_F32_SERIAL_N")) : 32768;
+  static const long wout_env = getenv("SGP_F32_WOUT") ? atol(getenv("SGP_F32_WOUT")) / TILE * TILE : 0;
+  static const long wmid_env = getenv("SGP_F32_WMID") ? atol(getenv("SGP_F32_WMID")) / TILE * TILE : 0;
+  const bool deep = n_pad >= serial_n;
+  const long W = wout_env > 0 ? wout_env : deep ? 4096 : (n_pad <= 2048 ? n_pad : (n_pad <= 8192 ? 1024 : 512));
+  const long WMID = deep ? (wmid_env > 0 ? wmid_env : 512) : 0;
+  const bool la = ctx->lookahead && s == ctx->stream && !deep;
   hipStream_t sB = la ? ctx->stream2 : s;
   bool rest_pending = false;
   if (la) {
@@ -342,7 +359,7 @@ int chol_f32(sgp_ctx* ctx, float* A, long ld, long n_pad, long m_tot, hipStream_
   }
   for (long J0 = 0; J0 < n_pad; J0 += W) {
     const long wj = std::min(W, n_pad - J0);
-    if (int rc = panel_factor_f32(ctx, A + J0 + J0 * ld, ld, m_tot - J0, wj, J0, s)) return rc;
+    if (int rc = panel_factor_mid_f32(ctx, A + J0 + J0 * ld, ld, m_tot - J0, wj, J0, s, WMID)) return rc;
     const long c0 = J0 + wj;
     if (c0 >= n_pad) break;
     const long w1 = std::min(W, n_pad - c0), c1 = c0 + w1;
