@@ -106,6 +106,17 @@ def update_bytes_avg(N):
     return tot / max(1, len(ls))
 
 
+def lookup_traffic(config, schedule):
+    """the committed counter record of `config` (profiles/r04_traffic.json), if it was collected under `schedule`"""
+    f = os.path.join(ROOT, "profiles", "r04_traffic.json")
+    if not os.path.exists(f):
+        return None
+    rec = json.load(open(f)).get(config)
+    if not rec or (rec.get("schedule") and schedule and rec["schedule"] != schedule):
+        return None
+    return dict(rec, file="profiles/r04_traffic.json")
+
+
 def resolve_devices(gpus, devices_arg, device_count, world):
     """Which GPUs an in-process (WORLD_SIZE unset) run uses: `--devices a,b,..` verbatim (a device may repeat: several
     ranks on one GPU, the 1-GPU test hook), else 0 .. gpus-1.  Raises SystemExit -- never falls back to fewer GPUs."""
@@ -343,7 +354,10 @@ def main():
         roofline = {
             "kernel": "sgp::gemm_nt_dma_kernel<0> (fp64 MFMA: deep-K row solve against Lz + split-K Gram product A A')",
             "bound": "mfma", "achieved": mfma_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": mfma_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+            "frac": mfma_tf / PEAK_FP64_MFMA_TFLOPS,
+            # (per STEP of the bound, all launches of the kernel: it runs in many shapes)
+            "traffic": (lookup_traffic("c4", None) or {}).get("hbm_bytes") if args.config == "c4" else None,
+            "traffic_source": lookup_traffic("c4", None) if args.config == "c4" else None,
             "algorithmic_flops": 2.0 * M * M * N, "stage_ms": mfma_ms,
             "whole_step_frac_on_8.86TF": flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
             # BASELINE.json calls c4 "HBM-bound"; SURVEY 8d asks for both figures and which one binds
@@ -445,28 +459,15 @@ def main():
             "busy_ms": timings[6],
             "achieved_while_busy": (upd_flops / (timings[6] * 1e-3) / 1e12) if timings[6] > 0 else None,
         }
-        # HBM traffic cannot be read from inside the process (it needs rocprofv3 --pmc passes): `traffic` is the
-        # committed per-launch average of exactly this command under the FETCH_SIZE / WRITE_SIZE passes
-        # (tools/collect_traffic.sh -> profiles/r03_update_traffic.json), null for configurations not profiled;
-        # the PMC passes of one representative launch shape are attached as well.
-        for tr_name in ("r03_update_traffic.json", "r02_update_traffic.json"):
-            tr_file = os.path.join(ROOT, "profiles", tr_name)
-            rec = json.load(open(tr_file)).get(args.config) if os.path.exists(tr_file) else None
-            if not rec:
-                continue
-            # a record only counts for the schedule it was collected under (serial-deep = today's default from 65536
-            # columns on: outer panels of 4096 columns, recursive halving inside)
-            rec_serial = rec.get("schedule", "").startswith("serial-deep")
-            if rec_serial == serial and not dataflow:
-                roofline["traffic"] = rec["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = dict(rec, file="profiles/" + tr_name)
-                break
-        if dataflow:
-            df_file = os.path.join(ROOT, "profiles", "r03_dataflow_pmc.json")
-            rec = json.load(open(df_file)).get(args.config) if os.path.exists(df_file) else None
-            if rec and rec.get("schedule") == schedule:
-                roofline["traffic"] = rec["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = dict(rec, file="profiles/r03_dataflow_pmc.json")
+        # HBM traffic cannot be read from inside the process (it needs rocprofv3 --pmc passes): `traffic` is the committed
+        # per-launch average of exactly this command under the FETCH_SIZE / WRITE_SIZE passes of the round's collection
+        # (tools/collect_r04.sh -> tools/make_r04_summary.py -> profiles/r04_traffic.json; every record carries the sha1 of
+        # the library it was collected with and the schedule it ran under), null for configurations not profiled or
+        # profiled under another schedule.
+        rec = lookup_traffic(args.config, schedule)
+        if rec:
+            roofline["traffic"] = rec["hbm_bytes"]
+            roofline["traffic_source"] = rec
         roofline["algorithmic_bytes_per_launch_avg"] = (8.0 * N * (N + 1) if dataflow else update_bytes_avg(N))   # dataflow: the
         # lower triangle read once and written once
         for pmc_name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
