@@ -77,8 +77,8 @@ for c in ("c5", "c3"):
         for k, v in d["kernels"].items():
             if DOMINANT[c] in k and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
                 out[k] = {"launches": v["GRBM_GUI_ACTIVE"]["launches"],
-                          "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (v["GRBM_GUI_ACTIVE"]["sum"] * 4.0 * 256.0)}
-        json.dump({"lib_sha1": sha, "note": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 4 SIMDs * 256 CUs)", "kernels": out},
+                          "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (v["GRBM_GUI_ACTIVE"]["sum"] * 128.0)}
+        json.dump({"lib_sha1": sha, "note": "SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 * 1024) -- the round-3 normalisation", "kernels": out},
                   open(os.path.join(DST, f"{TAG}_mfma_{c}.json"), "w"), indent=1)
 for c, d in lines.items():
     json.dump(d, open(os.path.join(DST, f"{TAG}_bench_{c}.json"), "w"), indent=1)
