@@ -56,8 +56,10 @@
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <thread>
+#include <unordered_map>
 
 using namespace sgp;
 
@@ -160,6 +162,13 @@ struct sgp_multi {
   double tail_frac = 2.0 / 3.0;   // the first tail_frac of the columns get W
   int group = 1;            // panels per group (see the head of this file); 1 = every update at K = one panel
   long sub = 512;           // sub-panel width of the factorisation / transport / look-ahead pipeline (0: whole panels)
+  // One enqueue thread per rank for the sweep of the sharded factorisation (SGP_MULTI_THREADS: 1 / 0; -1 = automatic: on
+  // with more than one rank).  Every thread walks the SAME schedule and issues only the HIP calls of its own rank's
+  // streams; an event recorded by one thread and waited for by another is ordered through a per-event sequence number
+  // (Exec::rec / Exec::wait below): the waiter knows, from the schedule alone, which record it needs.
+  int threads = -1;
+  std::unordered_map<hipEvent_t, std::atomic<long>> seq;
+  std::atomic<int> abort_flag{0};
   int ring = 10;            // receive buffers per rank: 2 * group + 2
   Rccl rccl;
   double last_ms = 0.0;
@@ -449,6 +458,23 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   }
   const char* pf = getenv("SGP_MULTI_PROFILE");
   if (pf) m->profile = atoi(pf);
+  const char* mt = getenv("SGP_MULTI_THREADS");
+  if (mt) m->threads = atoi(mt);
+  // the sequence numbers of every event the per-rank enqueue threads may order themselves by (Exec)
+  for (auto& k : m->r) {
+    auto reg = [&](hipEvent_t e) {
+      if (e) m->seq.emplace(std::piecewise_construct, std::forward_as_tuple(e), std::forward_as_tuple(0));
+    };
+    for (hipEvent_t e : {k.ev_upd, k.ev_fact, k.ev_done, k.ev_A, k.ev_B}) reg(e);
+    for (auto e : k.ev_far) reg(e);
+    for (auto e : k.ev_sub) reg(e);
+    for (auto e : k.ev_recv) reg(e);
+    for (auto e : k.ev_free) reg(e);
+    for (auto& v : k.ev_recv_sub)
+      for (auto e : v) reg(e);
+    for (auto& v : k.ev_in)
+      for (auto e : v) reg(e);
+  }
   hipSetDevice(devices[0]);
   *out = primary;
   return 0;
@@ -526,22 +552,71 @@ extern "C" int sgp_ctx_multi_profile_get(sgp_ctx* ctx, double* out, int64_t cap,
 namespace {
 
 // ---- panel transport ----------------------------------------------------------------------------------
-// `st` of rank k waits until ring slot J % ring may be overwritten with panel J: every launch that read the slot's previous
+// Who executes the schedule.  me < 0: the caller's thread issues everything (profile mode, one rank, SGP_MULTI_THREADS=0).
+// me = i: one of P threads that all walk the same schedule; this one issues the calls that go to rank i's streams.
+// rec / wait count the records of every event in schedule order (identically in every thread), so a wait knows which
+// record it refers to: the owner of the recording stream publishes the count after hipEventRecord, the waiting thread
+// spins (host side, microseconds) until that record has been issued and only then enqueues hipStreamWaitEvent.  A wait
+// only ever refers to a record EARLIER in the schedule and records never block, so the threads cannot deadlock.
+struct Exec {
+  sgp_multi* m = nullptr;
+  int me = -1;
+  std::unordered_map<hipEvent_t, long> cnt;
+  std::vector<char> factored_once;   // per rank, as the schedule sees it (every thread keeps its own copy)
+  bool mine(int i) const { return me < 0 || me == i; }
+  bool threaded() const { return me >= 0; }
+  int dev(int i) const {
+    if (hipSetDevice(m->r[i].dev) != hipSuccess) return hipfail(hipGetLastError(), "hipSetDevice");
+    return 0;
+  }
+  int rec(int i, hipEvent_t e, hipStream_t s) {
+    const long c = ++cnt[e];
+    if (!mine(i)) return 0;
+    M_RC(dev(i));
+    M_HIP(hipEventRecord(e, s));
+    if (threaded()) m->seq.at(e).store(c, std::memory_order_release);
+    return 0;
+  }
+  int wait(int i, hipStream_t s, hipEvent_t e) {
+    if (!mine(i)) return 0;
+    if (threaded()) {
+      auto it = cnt.find(e);
+      const long c = it == cnt.end() ? 0 : it->second;
+      if (c == 0) return 0;   // never recorded in this call: whatever it guarded was drained with the previous call
+      std::atomic<long>& q = m->seq.at(e);
+      while (q.load(std::memory_order_acquire) < c) {
+        if (m->abort_flag.load(std::memory_order_relaxed)) {
+          set_error("multi: another rank's enqueue thread failed");
+          return -5;
+        }
+        std::this_thread::yield();
+      }
+    }
+    M_RC(dev(i));
+    M_HIP(hipStreamWaitEvent(s, e, 0));
+    return 0;
+  }
+};
+
+// `st` of rank i waits until ring slot J % ring may be overwritten with panel J: every launch that read the slot's previous
 // panel (J - ring) is done -- its near updates (s_near: the latest ev_A is at least that late), the far update with its
 // group (s_upd: ev_far of that group, which also orders everything s_upd did before it, the near-B update included), the
 // look-ahead that used it (s_panel: ev_fact)
-int wait_slot_free(sgp_multi* m, Rank& k, long J, hipStream_t st) {
-  M_HIP(hipStreamWaitEvent(st, k.ev_A, 0));
-  M_HIP(hipStreamWaitEvent(st, k.ev_upd, 0));   // (the assembly, before the first panel)
-  if (J >= m->ring) M_HIP(hipStreamWaitEvent(st, k.ev_far[((J - m->ring) / m->group) % Rank::NGEV], 0));
-  if (k.factored_once) M_HIP(hipStreamWaitEvent(st, k.ev_fact, 0));
+int wait_slot_free(Exec& x, int i, long J, hipStream_t st) {
+  sgp_multi* m = x.m;
+  Rank& k = m->r[i];
+  M_RC(x.wait(i, st, k.ev_A));
+  M_RC(x.wait(i, st, k.ev_upd));   // (the assembly, before the first panel)
+  if (J >= m->ring) M_RC(x.wait(i, st, k.ev_far[((J - m->ring) / m->group) % Rank::NGEV]));
+  if (x.factored_once[i]) M_RC(x.wait(i, st, k.ev_fact));
   return 0;
 }
 
 // Move sub-panel q -- columns [c, c + wq) -- of factored panel J from its owner to every other rank's receive buffer (ring
 // slot J % ring), as soon as the owner's panel stream has recorded ev_sub[q].  A panel travels sub-panel by sub-panel while
 // the owner is still factoring its later columns; `last`: the whole panel has then landed (ev_recv).
-int broadcast_panel(sgp_multi* m, const Fact& F, long J, int q, long c, long wq, bool last) {
+int broadcast_panel(Exec& x, const Fact& F, long J, int q, long c, long wq, bool last) {
+  sgp_multi* m = x.m;
   const Geometry& g = F.g;
   const int o = g.owner(J);
   const size_t off = (size_t)c * g.ldp(J);
@@ -553,44 +628,44 @@ int broadcast_panel(sgp_multi* m, const Fact& F, long J, int q, long c, long wq,
   double* src = F.panel(o, J) + off;
   hipEvent_t ev_final = root.ev_sub[q];
   for (int i = 0; i < P; ++i)
-    if (i != o) m->r[i].recv_bytes += 8.0 * (double)count;
-  auto landed = [&](Rank& k) -> int {   // on k.s_comm, after its copies of this sub-panel
-    M_HIP(hipEventRecord(k.ev_recv_sub[b][q], k.s_comm));
-    if (last) M_HIP(hipEventRecord(k.ev_recv[b], k.s_comm));
+    if (i != o && x.mine(i)) m->r[i].recv_bytes += 8.0 * (double)count;
+  auto landed = [&](int i) -> int {   // on rank i's s_comm, after its copies of this sub-panel
+    Rank& k = m->r[i];
+    M_RC(x.rec(i, k.ev_recv_sub[b][q], k.s_comm));
+    if (last) M_RC(x.rec(i, k.ev_recv[b], k.s_comm));
     return 0;
   };
   if (m->transport == TR_RCCL) {
     for (int i = 0; i < P; ++i) {   // order the communicator streams behind the data / the buffer's readers
       Rank& k = m->r[i];
-      M_HIP(hipSetDevice(k.dev));
       if (i == o) {
-        M_HIP(hipStreamWaitEvent(k.s_comm, ev_final, 0));
+        M_RC(x.wait(i, k.s_comm, ev_final));
       } else if (q == 0) {
-        M_RC(wait_slot_free(m, k, J, k.s_comm));
+        M_RC(wait_slot_free(x, i, J, k.s_comm));
       }
     }
-    int rc = m->rccl.GroupStart();
+    // one grouped call from the one enqueue thread, or every rank's own call from its own thread
+    int rc = x.threaded() ? 0 : m->rccl.GroupStart();
     for (int i = 0; i < P && rc == 0; ++i) {
+      if (!x.mine(i)) continue;
       Rank& k = m->r[i];
       hipSetDevice(k.dev);
       void* buf = (i == o) ? (void*)src : (void*)(k.buf[b] + off);
       rc = m->rccl.Broadcast(buf, buf, count, NCCL_DOUBLE, o, k.comm, k.s_comm);
     }
-    int rc2 = m->rccl.GroupEnd();
+    int rc2 = x.threaded() ? 0 : m->rccl.GroupEnd();
     if (rc || rc2) {
       set_error(std::string("ncclBroadcast failed: ") +
                 (m->rccl.GetErrorString ? m->rccl.GetErrorString(rc ? rc : rc2) : "?"));
       return -4;
     }
-    for (int i = 0; i < P; ++i) {
-      Rank& k = m->r[i];
-      M_HIP(hipSetDevice(k.dev));
-      M_RC(landed(k));
-    }
+    for (int i = 0; i < P; ++i) M_RC(landed(i));
     return 0;
   }
-  auto copy = [&](Rank& dst, double* d, Rank& from, const double* sp, size_t n, hipStream_t st) -> int {
-    if (n == 0) return 0;
+  auto copy = [&](int di, double* d, int fi, const double* sp, size_t n, hipStream_t st) -> int {
+    if (n == 0 || !x.mine(di)) return 0;
+    Rank &dst = m->r[di], &from = m->r[fi];
+    M_RC(x.dev(di));
     if (dst.dev == from.dev)
       M_HIP(hipMemcpyAsync(d, sp, sizeof(double) * n, hipMemcpyDeviceToDevice, st));
     else
@@ -602,11 +677,10 @@ int broadcast_panel(sgp_multi* m, const Fact& F, long J, int q, long c, long wq,
     for (int i = 0; i < P; ++i) {
       if (i == o) continue;
       Rank& k = m->r[i];
-      M_HIP(hipSetDevice(k.dev));
-      if (q == 0) M_RC(wait_slot_free(m, k, J, k.s_comm));      // readers of the panel this slot held a ring ago
-      M_HIP(hipStreamWaitEvent(k.s_comm, ev_final, 0));         // the sub-panel is final
-      M_RC(copy(k, k.buf[b] + off, root, src, count, k.s_comm));
-      M_RC(landed(k));
+      if (q == 0) M_RC(wait_slot_free(x, i, J, k.s_comm));      // readers of the panel this slot held a ring ago
+      M_RC(x.wait(i, k.s_comm, ev_final));                       // the sub-panel is final
+      M_RC(copy(i, k.buf[b] + off, o, src, count, k.s_comm));
+      M_RC(landed(i));
     }
     return 0;
   }
@@ -627,47 +701,48 @@ int broadcast_panel(sgp_multi* m, const Fact& F, long J, int q, long c, long wq,
   //     panel: the later sub-panels follow the first on the same in-order streams.
   if (q == 0)
     for (int cc = 0; cc < np; ++cc) {
-      Rank& k = m->r[peers[cc]];
-      M_HIP(hipSetDevice(k.dev));
-      M_RC(wait_slot_free(m, k, J, k.s_comm));
+      const int pi = peers[cc];
+      Rank& k = m->r[pi];
+      M_RC(wait_slot_free(x, pi, J, k.s_comm));
       if (J >= m->ring)
         for (int d = 0; d < P; ++d) {
-          if (d == peers[cc]) continue;
-          M_HIP(hipStreamWaitEvent(k.s_comm, m->r[d].ev_in[b][peers[cc]], 0));   // (never recorded == complete)
+          if (d == pi) continue;
+          M_RC(x.wait(pi, k.s_comm, m->r[d].ev_in[b][pi]));   // (never recorded == complete)
         }
-      M_HIP(hipEventRecord(k.ev_free[b], k.s_comm));
+      M_RC(x.rec(pi, k.ev_free[b], k.s_comm));
     }
   // (2) scatter: owner -> q_c, slab c
   for (int cc = 0; cc < np; ++cc) {
-    Rank& k = m->r[peers[cc]];
+    const int pi = peers[cc];
+    Rank& k = m->r[pi];
     size_t beg, n;
     slab(cc, beg, n);
-    M_HIP(hipSetDevice(k.dev));
     hipStream_t st = k.s_in[o];
-    M_HIP(hipStreamWaitEvent(st, k.ev_free[b], 0));
-    M_HIP(hipStreamWaitEvent(st, ev_final, 0));
-    M_RC(copy(k, k.buf[b] + off + beg, root, src + beg, n, st));
-    M_HIP(hipEventRecord(k.ev_in[b][o], st));
+    M_RC(x.wait(pi, st, k.ev_free[b]));
+    M_RC(x.wait(pi, st, ev_final));
+    M_RC(copy(pi, k.buf[b] + off + beg, o, src + beg, n, st));
+    M_RC(x.rec(pi, k.ev_in[b][o], st));
   }
   // (3) all-gather: q_d <- q_c, slab c
   for (int d = 0; d < np; ++d) {
-    Rank& k = m->r[peers[d]];
-    M_HIP(hipSetDevice(k.dev));
+    const int pd = peers[d];
+    Rank& k = m->r[pd];
     for (int cc = 0; cc < np; ++cc) {
       if (cc == d) continue;
-      Rank& from = m->r[peers[cc]];
+      const int pc = peers[cc];
+      Rank& from = m->r[pc];
       size_t beg, n;
       slab(cc, beg, n);
-      hipStream_t st = k.s_in[peers[cc]];
-      M_HIP(hipStreamWaitEvent(st, k.ev_free[b], 0));
-      M_HIP(hipStreamWaitEvent(st, from.ev_in[b][o], 0));
-      M_RC(copy(k, k.buf[b] + off + beg, from, from.buf[b] + off + beg, n, st));
-      M_HIP(hipEventRecord(k.ev_in[b][peers[cc]], st));
+      hipStream_t st = k.s_in[pc];
+      M_RC(x.wait(pd, st, k.ev_free[b]));
+      M_RC(x.wait(pd, st, from.ev_in[b][o]));
+      M_RC(copy(pd, k.buf[b] + off + beg, pc, from.buf[b] + off + beg, n, st));
+      M_RC(x.rec(pd, k.ev_in[b][pc], st));
     }
     // (4) join: the whole sub-panel has landed
     for (int qq = 0; qq < P; ++qq)
-      if (qq != peers[d]) M_HIP(hipStreamWaitEvent(k.s_comm, k.ev_in[b][qq], 0));
-    M_RC(landed(k));
+      if (qq != pd) M_RC(x.wait(pd, k.s_comm, k.ev_in[b][qq]));
+    M_RC(landed(pd));
   }
   return 0;
 }
@@ -677,10 +752,10 @@ const double* panel_on(sgp_multi* m, const Fact& F, long J, int i) {
   return (F.g.owner(J) == i) ? F.panel(i, J) : m->r[i].buf[J % m->ring];
 }
 
-int wait_panel(sgp_multi* m, const Fact& F, long J, int i, hipStream_t s) {
-  Rank& k = m->r[i];
-  if (F.g.owner(J) == i) return hipStreamWaitEvent(s, k.ev_fact, 0) == hipSuccess ? 0 : -2;
-  return hipStreamWaitEvent(s, k.ev_recv[J % m->ring], 0) == hipSuccess ? 0 : -2;
+int wait_panel(Exec& x, const Fact& F, long J, int i, hipStream_t s) {
+  Rank& k = x.m->r[i];
+  if (F.g.owner(J) == i) return x.wait(i, s, k.ev_fact);
+  return x.wait(i, s, k.ev_recv[J % x.m->ring]);
 }
 
 // One launch: every panel of `dsts` (owned by rank i) -= its rows of the factored panels J_first .. J_last times their
@@ -746,6 +821,9 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   const bool prof = m->profile != 0;
   if (prof) m->prof.assign((size_t)g.npan * (3 + 3 * P), 0.0);
   const double t_begin = now_ms();
+  Exec x0;                       // the caller's thread: buffers, uploads, assembly -- and the sweep when it is not threaded
+  x0.m = m;
+  x0.factored_once.assign(P, 0);
   for (int i = 0; i < P; ++i) {
     Rank& k = m->r[i];
     M_HIP(hipSetDevice(k.dev));
@@ -807,7 +885,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         M_RC(launch_add_dense_cols(base, g.ldp(J), k.d_work, rows, c0, wv, N, k.s_upd));
       }
     }
-    M_HIP(hipEventRecord(k.ev_upd, k.s_upd));
+    M_RC(x0.rec(i, k.ev_upd, k.s_upd));
   }
   // Factor panel J on its owner's panel stream in sub-panels of `sub` columns, each sent on its way as soon as it is final
   // (broadcast_panel) while the later columns are still being factored: sub-panel q = its own factorisation (128-column
@@ -820,197 +898,248 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     c = (long)q * SUB;
     wq = (q == ns - 1) ? g.width(J) - c : SUB;   // (more than NSUB sub-panels: the last takes the rest)
   };
-  std::vector<long> self(1);
-  auto factor = [&](long J) -> int {
-    const int o = g.owner(J);
-    Rank& k = m->r[o];
-    M_HIP(hipSetDevice(k.dev));
-    double* Pj = F.panel(o, J);
-    const long ldp = g.ldp(J), w = g.width(J), J0 = g.col0(J);
-    const int ns = n_sub(J);
-    for (int q = 0; q < ns; ++q) {
-      long c, wq;
-      sub_range(J, q, c, wq);
-      M_HIP(hipSetDevice(k.dev));   // (broadcast_panel leaves another rank's device current)
-      M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, k.d_small + L.scal, k.d_info,
-                            F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr, k.s_panel));
-      M_HIP(hipEventRecord(k.ev_sub[q], k.s_panel));
-      if (q == ns - 1) M_HIP(hipEventRecord(k.ev_fact, k.s_panel));
-      if (!prof) M_RC(broadcast_panel(m, F, J, q, c, wq, q == ns - 1));
-      M_HIP(hipSetDevice(k.dev));
-      if (c + wq < w) {   // the rest of the panel -= (its rows of sub-panel q) (sub-panel q's rows of the rest)'
-        SegBatch b;
-        b.m_tot = g.m_tot;
-        for (int t = 0; t < SEG_MAX_SRC; ++t) b.src[t] = SegSrc{nullptr, 0, 0, 0};
-        b.src[0] = SegSrc{Pj + (size_t)c * ldp, ldp, J0, (int)wq};
-        const long r = c + wq;
-        b.n_dst = 1;
-        b.dst[0] = SegDst{Pj + r + (size_t)r * ldp, ldp, J0 + r, (int)(w - r), 0, 1, 0u};
-        M_RC(launch_gemm_nt_seg(b, k.s_panel));
-      }
-    }
-    k.factored_once = true;
-    k.n_factored += 1;
-    return 0;
-  };
-  // (profile mode times the factorisation alone: the sub-panels are sent afterwards)
-  auto broadcast_all = [&](long J) -> int {
-    const int ns = n_sub(J);
-    for (int q = 0; q < ns; ++q) {
-      long c, wq;
-      sub_range(J, q, c, wq);
-      M_RC(broadcast_panel(m, F, J, q, c, wq, q == ns - 1));
-    }
-    return 0;
-  };
-  // ---- panel 0
   const long G = m->group;
   auto group_of = [&](long J) { return J / G; };
-  {
-    Rank& k = m->r[g.owner(0)];
-    M_HIP(hipSetDevice(k.dev));
-    M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_upd, 0));
-    double t0 = 0;
-    if (prof) {
-      M_RC(sync_all(m));
-      t0 = now_ms();
-    }
-    M_RC(factor(0));
-    if (prof) {
-      M_RC(sync_all(m));
-      m->prof[0] = now_ms() - t0;
-      m->prof[2] = 8.0 * (double)g.ldp(0) * (double)g.width(0);
-      M_RC(broadcast_all(0));
-    }
-  }
-  for (int i = 0; i < P; ++i) {   // the near stream starts behind the assembly
-    Rank& k = m->r[i];
-    M_HIP(hipSetDevice(k.dev));
-    M_HIP(hipStreamWaitEvent(k.s_near, k.ev_upd, 0));
-    M_HIP(hipEventRecord(k.ev_A, k.s_near));
-    M_HIP(hipEventRecord(k.ev_B, k.s_upd));
-  }
-  // ---- right-looking sweep (the schedule at the head of this file)
-  std::vector<long> near_a, near_b, far, la(1);
-  for (long J = 0; J < g.npan; ++J) {
-    const long nxt = J + 1, gj = group_of(J);
-    const bool group_ends = (J % G == G - 1) || J == g.npan - 1;
-    if (nxt < g.npan) {             // (a) look-ahead on the owner of the next panel
-      const int o1 = g.owner(nxt);
-      Rank& k = m->r[o1];
-      M_HIP(hipSetDevice(k.dev));
-      // what updated panel nxt in the previous steps: near-A launches (s_near) while it was in the current group beyond
-      // the look-ahead, near-B launches (s_upd) before that -- the last of them at the previous step if nxt is the first
-      // or second panel of its group (ev_B is recorded BEFORE a far update: this never waits for one)
-      M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_A, 0));
-      if (nxt % G == 0 || J % G == 0) M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_B, 0));
-      // ... and, before those, the far update with the group two before its own (long done unless G = 1, where that is
-      // the previous step's launch)
-      if (group_of(nxt) >= 2) M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_far[(group_of(nxt) - 2) % Rank::NGEV], 0));
-      double t0 = 0, t1 = 0;
-      if (prof) {
-        M_RC(sync_all(m));
-        t0 = now_ms();
-      }
-      // the look-ahead update follows panel J sub-panel by sub-panel as they land (K = sub each): only the last one sits
-      // between the end of J's factorisation and the start of nxt's
-      la[0] = nxt;
-      {
-        const int ns = n_sub(J);
-        const int bj = (int)(J % m->ring);
-        for (int q = 0; q < ns; ++q) {
-          long c, wq;
-          sub_range(J, q, c, wq);
-          if (g.owner(J) == o1)
-            M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_sub[q], 0));   // (one rank: its own panel)
-          else
-            M_HIP(hipStreamWaitEvent(k.s_panel, k.ev_recv_sub[bj][q], 0));
-          M_RC(update_panels(m, F, J, J, la, o1, k.s_panel, &k.upd_flops, c, wq));
+  // ---- the schedule from the first panel's factorisation to the last row sums, as ONE function of who executes it
+  auto run = [&](Exec& x) -> int {
+    auto factor = [&](long J) -> int {
+      const int o = g.owner(J);
+      Rank& k = m->r[o];
+      double* Pj = F.panel(o, J);
+      const long ldp = g.ldp(J), w = g.width(J), J0 = g.col0(J);
+      const int ns = n_sub(J);
+      for (int q = 0; q < ns; ++q) {
+        long c, wq;
+        sub_range(J, q, c, wq);
+        if (x.mine(o)) {
+          M_RC(x.dev(o));   // (broadcast_panel leaves another rank's device current in the one-thread mode)
+          M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, k.d_small + L.scal, k.d_info,
+                                F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr, k.s_panel));
+        }
+        M_RC(x.rec(o, k.ev_sub[q], k.s_panel));
+        if (q == ns - 1) M_RC(x.rec(o, k.ev_fact, k.s_panel));
+        if (!prof) M_RC(broadcast_panel(x, F, J, q, c, wq, q == ns - 1));
+        if (c + wq < w && x.mine(o)) {   // the rest of the panel -= (its rows of sub-panel q) (sub-panel q's rows of the rest)'
+          M_RC(x.dev(o));
+          SegBatch b;
+          b.m_tot = g.m_tot;
+          for (int t = 0; t < SEG_MAX_SRC; ++t) b.src[t] = SegSrc{nullptr, 0, 0, 0};
+          b.src[0] = SegSrc{Pj + (size_t)c * ldp, ldp, J0, (int)wq};
+          const long r = c + wq;
+          b.n_dst = 1;
+          b.dst[0] = SegDst{Pj + r + (size_t)r * ldp, ldp, J0 + r, (int)(w - r), 0, 1, 0u};
+          M_RC(launch_gemm_nt_seg(b, k.s_panel));
         }
       }
-      if (prof) {
-        M_RC(sync_all(m));
-        t1 = now_ms();
-        m->prof[(size_t)nxt * (3 + 3 * P) + 1] = t1 - t0;
+      x.factored_once[o] = 1;
+      if (x.mine(o)) k.n_factored += 1;
+      return 0;
+    };
+    // (profile mode times the factorisation alone: the sub-panels are sent afterwards)
+    auto broadcast_all = [&](long J) -> int {
+      const int ns = n_sub(J);
+      for (int q = 0; q < ns; ++q) {
+        long c, wq;
+        sub_range(J, q, c, wq);
+        M_RC(broadcast_panel(x, F, J, q, c, wq, q == ns - 1));
       }
-      M_RC(factor(nxt));
-      if (prof) {
-        M_RC(sync_all(m));
-        m->prof[(size_t)nxt * (3 + 3 * P) + 0] = now_ms() - t1;
-        m->prof[(size_t)nxt * (3 + 3 * P) + 2] = 8.0 * (double)g.ldp(nxt) * (double)g.width(nxt);
-        M_RC(broadcast_all(nxt));
-        M_RC(sync_all(m));
-      }
-    }
-    for (int i = 0; i < P; ++i) {   // (b) every rank's trailing panels: near A, near B, and -- at the end of a group -- far
-      Rank& k = m->r[i];
-      M_HIP(hipSetDevice(k.dev));
-      near_a.clear();
-      near_b.clear();
-      far.clear();
-      for (long Jp = i; Jp < g.npan; Jp += P) {
-        if (Jp <= nxt) continue;
-        const long gp = group_of(Jp);
-        if (gp == gj) near_a.push_back(Jp);
-        else if (gp == gj + 1) near_b.push_back(Jp);
-        else if (group_ends) far.push_back(Jp);
-      }
+      return 0;
+    };
+    // ---- panel 0
+    {
+      const int o0 = g.owner(0);
+      Rank& k = m->r[o0];
+      M_RC(x.wait(o0, k.s_panel, k.ev_upd));
       double t0 = 0;
-      auto lap = [&](int slot) -> int {   // profile mode: the class just enqueued, alone on the hardware
-        if (!prof) return 0;
-        M_RC(sync_all(m));
-        const double t = now_ms();
-        m->prof[(size_t)J * (3 + 3 * P) + 3 + 3 * i + slot] = t - t0;
-        t0 = t;
-        return 0;
-      };
       if (prof) {
         M_RC(sync_all(m));
         t0 = now_ms();
       }
-      if ((!near_a.empty() || !near_b.empty() || !far.empty()) && !k.t0_set) {
-        M_HIP(hipEventRecord(k.ev_t0, k.s_upd));
-        k.t0_set = true;
+      M_RC(factor(0));
+      if (prof) {
+        M_RC(sync_all(m));
+        m->prof[0] = now_ms() - t0;
+        m->prof[2] = 8.0 * (double)g.ldp(0) * (double)g.width(0);
+        M_RC(broadcast_all(0));
       }
-      // near A: on the near stream.  A panel enters the current group out of the next one: its last near-B update (s_upd,
-      // previous step) must be done -- ev_B is recorded BEFORE a far update, so this never waits for one.
-      if (!near_a.empty()) {
-        M_RC(wait_panel(m, F, J, i, k.s_near));
-        if (J % G == 0) {
-          M_HIP(hipStreamWaitEvent(k.s_near, k.ev_B, 0));
-          if (gj >= 2) M_HIP(hipStreamWaitEvent(k.s_near, k.ev_far[(gj - 2) % Rank::NGEV], 0));
+    }
+    for (int i = 0; i < P; ++i) {   // the near stream starts behind the assembly
+      Rank& k = m->r[i];
+      M_RC(x.wait(i, k.s_near, k.ev_upd));
+      M_RC(x.rec(i, k.ev_A, k.s_near));
+      M_RC(x.rec(i, k.ev_B, k.s_upd));
+    }
+    // ---- right-looking sweep (the schedule at the head of this file)
+    std::vector<long> near_a, near_b, far, la(1);
+    for (long J = 0; J < g.npan; ++J) {
+      const long nxt = J + 1, gj = group_of(J);
+      const bool group_ends = (J % G == G - 1) || J == g.npan - 1;
+      if (nxt < g.npan) {             // (a) look-ahead on the owner of the next panel
+        const int o1 = g.owner(nxt);
+        Rank& k = m->r[o1];
+        // what updated panel nxt in the previous steps: near-A launches (s_near) while it was in the current group beyond
+        // the look-ahead, near-B launches (s_upd) before that -- the last of them at the previous step if nxt is the first
+        // or second panel of its group (ev_B is recorded BEFORE a far update: this never waits for one)
+        M_RC(x.wait(o1, k.s_panel, k.ev_A));
+        if (nxt % G == 0 || J % G == 0) M_RC(x.wait(o1, k.s_panel, k.ev_B));
+        // ... and, before those, the far update with the group two before its own (long done unless G = 1, where that is
+        // the previous step's launch)
+        if (group_of(nxt) >= 2) M_RC(x.wait(o1, k.s_panel, k.ev_far[(group_of(nxt) - 2) % Rank::NGEV]));
+        double t0 = 0, t1 = 0;
+        if (prof) {
+          M_RC(sync_all(m));
+          t0 = now_ms();
         }
-        M_RC(update_panels(m, F, J, J, near_a, i, k.s_near, &k.upd_flops));
+        // the look-ahead update follows panel J sub-panel by sub-panel as they land (K = sub each): only the last one sits
+        // between the end of J's factorisation and the start of nxt's
+        la[0] = nxt;
+        {
+          const int ns = n_sub(J);
+          const int bj = (int)(J % m->ring);
+          for (int q = 0; q < ns; ++q) {
+            long c, wq;
+            sub_range(J, q, c, wq);
+            if (g.owner(J) == o1)
+              M_RC(x.wait(o1, k.s_panel, k.ev_sub[q]));   // (one rank: its own panel)
+            else
+              M_RC(x.wait(o1, k.s_panel, k.ev_recv_sub[bj][q]));
+            if (x.mine(o1)) {
+              M_RC(x.dev(o1));
+              M_RC(update_panels(m, F, J, J, la, o1, k.s_panel, &k.upd_flops, c, wq));
+            }
+          }
+        }
+        if (prof) {
+          M_RC(sync_all(m));
+          t1 = now_ms();
+          m->prof[(size_t)nxt * (3 + 3 * P) + 1] = t1 - t0;
+        }
+        M_RC(factor(nxt));
+        if (prof) {
+          M_RC(sync_all(m));
+          m->prof[(size_t)nxt * (3 + 3 * P) + 0] = now_ms() - t1;
+          m->prof[(size_t)nxt * (3 + 3 * P) + 2] = 8.0 * (double)g.ldp(nxt) * (double)g.width(nxt);
+          M_RC(broadcast_all(nxt));
+          M_RC(sync_all(m));
+        }
       }
-      M_HIP(hipEventRecord(k.ev_A, k.s_near));
-      M_RC(lap(0));
-      // near B, then far: on the update stream, in order
-      M_RC(wait_panel(m, F, J, i, k.s_upd));
-      if (!near_b.empty()) M_RC(update_panels(m, F, J, J, near_b, i, k.s_upd, &k.upd_flops));
-      M_HIP(hipEventRecord(k.ev_B, k.s_upd));
-      M_RC(lap(1));
-      if (group_ends) {
-        if (!far.empty()) M_RC(update_panels(m, F, gj * G, J, far, i, k.s_upd, &k.upd_flops));
-        M_HIP(hipEventRecord(k.ev_far[gj % Rank::NGEV], k.s_upd));
+      for (int i = 0; i < P; ++i) {   // (b) every rank's trailing panels: near A, near B, and -- at the end of a group -- far
+        Rank& k = m->r[i];
+        near_a.clear();
+        near_b.clear();
+        far.clear();
+        for (long Jp = i; Jp < g.npan; Jp += P) {
+          if (Jp <= nxt) continue;
+          const long gp = group_of(Jp);
+          if (gp == gj) near_a.push_back(Jp);
+          else if (gp == gj + 1) near_b.push_back(Jp);
+          else if (group_ends) far.push_back(Jp);
+        }
+        double t0 = 0;
+        auto lap = [&](int slot) -> int {   // profile mode: the class just enqueued, alone on the hardware
+          if (!prof) return 0;
+          M_RC(sync_all(m));
+          const double t = now_ms();
+          m->prof[(size_t)J * (3 + 3 * P) + 3 + 3 * i + slot] = t - t0;
+          t0 = t;
+          return 0;
+        };
+        if (prof) {
+          M_RC(sync_all(m));
+          t0 = now_ms();
+        }
+        const bool any_upd = !near_a.empty() || !near_b.empty() || !far.empty();
+        if (any_upd && x.mine(i) && !k.t0_set) {
+          M_RC(x.dev(i));
+          M_HIP(hipEventRecord(k.ev_t0, k.s_upd));
+          k.t0_set = true;
+        }
+        // near A: on the near stream.  A panel enters the current group out of the next one: its last near-B update (s_upd,
+        // previous step) must be done -- ev_B is recorded BEFORE a far update, so this never waits for one.
+        if (!near_a.empty()) {
+          M_RC(wait_panel(x, F, J, i, k.s_near));
+          if (J % G == 0) {
+            M_RC(x.wait(i, k.s_near, k.ev_B));
+            if (gj >= 2) M_RC(x.wait(i, k.s_near, k.ev_far[(gj - 2) % Rank::NGEV]));
+          }
+          if (x.mine(i)) {
+            M_RC(x.dev(i));
+            M_RC(update_panels(m, F, J, J, near_a, i, k.s_near, &k.upd_flops));
+          }
+        }
+        M_RC(x.rec(i, k.ev_A, k.s_near));
+        M_RC(lap(0));
+        // near B, then far: on the update stream, in order
+        M_RC(wait_panel(x, F, J, i, k.s_upd));
+        if (!near_b.empty() && x.mine(i)) {
+          M_RC(x.dev(i));
+          M_RC(update_panels(m, F, J, J, near_b, i, k.s_upd, &k.upd_flops));
+        }
+        M_RC(x.rec(i, k.ev_B, k.s_upd));
+        M_RC(lap(1));
+        if (group_ends) {
+          if (!far.empty() && x.mine(i)) {
+            M_RC(x.dev(i));
+            M_RC(update_panels(m, F, gj * G, J, far, i, k.s_upd, &k.upd_flops));
+          }
+          M_RC(x.rec(i, k.ev_far[gj % Rank::NGEV], k.s_upd));
+        }
+        if (any_upd && x.mine(i)) {
+          M_RC(x.dev(i));
+          M_HIP(hipEventRecord(k.ev_t1, k.s_upd));
+        }
+        M_RC(lap(2));
       }
-      if (!near_a.empty() || !near_b.empty() || !far.empty()) M_HIP(hipEventRecord(k.ev_t1, k.s_upd));
-      M_RC(lap(2));
+    }
+    // ---- |L^-1 (Y - m)|^2 from the bordered rows of the owned panels
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      if (x.factored_once[i]) M_RC(x.wait(i, k.s_upd, k.ev_fact));
+      M_RC(x.wait(i, k.s_upd, k.ev_A));
+      if (S > 0 && x.mine(i)) {
+        M_RC(x.dev(i));
+        for (long J = i; J < g.npan; J += P) {
+          long nc = std::min(g.width(J), std::max<long>(0, N - g.col0(J)));
+          if (nc > 0)
+            M_RC(sgp_dev_rowsumsq(k.ctx, F.panel(i, J) + (g.n_pad - g.col0(J)), g.ldp(J), nc, S,
+                                  k.d_small + L.scal + 1, (void*)k.s_upd));
+        }
+      }
+    }
+    return 0;
+  };
+  const bool threaded = !prof && P > 1 && (m->threads == 1 || (m->threads < 0));
+  if (!threaded) {
+    M_RC(run(x0));
+  } else {
+    // one enqueue thread per rank (see Exec): the sequence numbers start from what the prologue recorded
+    for (auto& kv : m->seq) kv.second.store(0, std::memory_order_relaxed);
+    for (auto& kv : x0.cnt) m->seq.at(kv.first).store(kv.second, std::memory_order_relaxed);
+    m->abort_flag.store(0);
+    std::vector<int> rcs(P, 0);
+    std::vector<std::string> errs(P);
+    std::vector<std::thread> th;
+    for (int i = 0; i < P; ++i)
+      th.emplace_back([&, i]() {
+        Exec x = x0;
+        x.me = i;
+        const int rc = run(x);
+        if (rc) {
+          errs[i] = sgp_last_error();
+          m->abort_flag.store(1);
+        }
+        rcs[i] = rc;
+      });
+    for (auto& t : th) t.join();
+    for (int i = 0; i < P; ++i) {
+      m->r[i].factored_once = true;
+      if (rcs[i]) {
+        set_error(errs[i]);
+        return rcs[i];
+      }
     }
   }
-  // ---- |L^-1 (Y - m)|^2 from the bordered rows of the owned panels
-  for (int i = 0; i < P; ++i) {
-    Rank& k = m->r[i];
-    M_HIP(hipSetDevice(k.dev));
-    if (k.factored_once) M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_fact, 0));
-    M_HIP(hipStreamWaitEvent(k.s_upd, k.ev_A, 0));
-    if (S > 0)
-      for (long J = i; J < g.npan; J += P) {
-        long nc = std::min(g.width(J), std::max<long>(0, N - g.col0(J)));
-        if (nc > 0)
-          M_RC(sgp_dev_rowsumsq(k.ctx, F.panel(i, J) + (g.n_pad - g.col0(J)), g.ldp(J), nc, S,
-                                k.d_small + L.scal + 1, (void*)k.s_upd));
-      }
-  }
+  for (int i = 0; i < P; ++i) m->r[i].factored_once = true;
   m->last_enqueue_ms = now_ms() - t_begin;
   // completion of the factorisation proper (statistics; the reductions follow in the caller)
   for (int i = 0; i < P; ++i) {

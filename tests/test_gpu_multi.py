@@ -455,3 +455,28 @@ def test_logpdf_gradient_sharded_over_the_ranks(panel128, nranks):
     g = _with_ctx(ctx, lambda: P.logpdf_and_gradient(F(x, 0.1), y))
     assert abs(g["noise"] - fd) <= 1e-5 * max(1.0, abs(fd))
     ctx.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 5, 8])
+def test_per_rank_enqueue_threads_give_the_same_bits_as_one_thread(monkeypatch, nranks):
+    """Round 4: the sweep of the sharded factorisation is issued by one enqueue thread per rank (SGP_MULTI_THREADS, default on
+    with more than one rank): every thread walks the same schedule and issues its own rank's calls, cross-rank events are
+    ordered through per-event sequence numbers.  Same bits as the one-thread enqueue, for both panel transports' copy forms,
+    sub-panel pipelining on and off, repeated calls."""
+    F, x, xs, y = _problem(2500, D=3)
+    ref = orm.gppp_sum_logpdf(xs, y, 0.1)
+    for env in ({"SGP_MULTI_PANEL": "128"}, {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "128"},
+                {"SGP_MULTI_PANEL": "256", "SGP_MULTI_SUBPANEL": "128", "SGP_MULTI_BCAST": "direct", "SGP_MULTI_GROUP": "2"}):
+        vals = []
+        for threads in ("0", "1"):
+            for k in ("SGP_MULTI_PANEL", "SGP_MULTI_SUBPANEL", "SGP_MULTI_BCAST", "SGP_MULTI_GROUP"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            monkeypatch.setenv("SGP_MULTI_THREADS", threads)
+            ctx = P.lib.Context(devices=[0] * nranks)
+            for rep in range(3):
+                vals.append(_with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y)))
+            ctx.close()
+        assert all(v == vals[0] for v in vals), (env, vals)
+        assert abs(vals[0] - ref) <= 1e-10 * abs(ref)
