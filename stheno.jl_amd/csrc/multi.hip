@@ -135,7 +135,6 @@ struct Rank {
   bool t0_set = false;
   double upd_flops = 0.0, upd_span_ms = 0.0, recv_bytes = 0.0;
   long n_factored = 0;
-  bool factored_once = false;
   double* store = nullptr;       // owned panels of a transient factorisation, packed (grow-only)
   size_t store_cap = 0;
   std::vector<double*> buf;      // ring of receive buffers (sgp_multi::ring of them), m_tot x widest panel each
@@ -846,7 +845,6 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
       }
     }
     M_RC(grow(&k.d_small, &k.small_cap, L.total));
-    k.factored_once = false;
     k.t0_set = false;
     k.upd_flops = k.upd_span_ms = k.recv_bytes = 0.0;
     k.n_factored = 0;
@@ -1132,14 +1130,12 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
       });
     for (auto& t : th) t.join();
     for (int i = 0; i < P; ++i) {
-      m->r[i].factored_once = true;
       if (rcs[i]) {
         set_error(errs[i]);
         return rcs[i];
       }
     }
   }
-  for (int i = 0; i < P; ++i) m->r[i].factored_once = true;
   m->last_enqueue_ms = now_ms() - t_begin;
   // completion of the factorisation proper (statistics; the reductions follow in the caller)
   for (int i = 0; i < P; ++i) {
