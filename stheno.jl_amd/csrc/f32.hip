@@ -231,6 +231,88 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_kernel(const float* A, l
       }
 }
 
+// Round 4: the same tile program with the fp64 kernel's operand path -- global -> LDS directly (global_load_lds_dwordx4:
+// no staging VGPRs, no ds_write), one chunk ahead of the MFMAs, raw s_barrier + one counted wait per chunk.  One wave
+// instruction moves 1 KiB = TWO 128-row fp32 columns, so the LDS chunk is unpadded (leading dimension 128 floats: the second
+// column must follow the first); the ds_read_b32 operand fetches (lanes 0 .. 31 consecutive rows, lanes 32 .. 63 the next
+// k) are conflict free on it.  256 threads = 4 waves x (2 x 2) MFMA 32x32x2 tiles as above; 2 stages x 2 operands x KD x 512
+// B = 32 KB of LDS at KD = 16.
+template <int KD>
+__global__ __launch_bounds__(256, 4) void gemm_nt_f32_dma_kernel(const float* A, long lda, const float* B, long ldb, float* C,
+                                                                 long ldc, long K, int lower, long n_tr, long n_tc) {
+  long tr, tc;
+  if (lower) {
+    if (!tile_of_id((long)blockIdx.x, n_tr, n_tc, 0L, tr, tc)) return;
+  } else {
+    tr = blockIdx.x;
+    tc = blockIdx.y;
+  }
+  if (tr >= n_tr || tc >= n_tc) return;
+  constexpr int STAGE = 2 * KD * TILE;   // floats per stage: A chunk, then B chunk
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wr = w >> 1, wc = w & 1;
+  const int l31 = lane & 31, lh = lane >> 5;
+  const float* Ag = A + tr * TILE + 4 * l31;   // this lane's 4 rows of the column pair it moves
+  const float* Bg = B + tc * TILE + 4 * l31;
+  auto dma = [&](long k0, int stage) {
+    float* sa = smem + stage * STAGE;
+    float* sb = sa + KD * TILE;
+#pragma unroll
+    for (int i = 0; i < KD / 8; ++i) {   // wave w moves column pairs w, w + 4, ...: columns 2 p and 2 p + 1
+      const int p = w + 4 * i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ag + (k0 + 2 * p + lh) * lda), (lptr_t)(sa + 2 * p * TILE), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Bg + (k0 + 2 * p + lh) * ldb), (lptr_t)(sb + 2 * p * TILE), 16, 0, 0);
+    }
+  };
+  f16v acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+  const long nch = K / KD;
+  dma(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (long c = 0; c < nch; ++c) {
+    const int stage = (int)(c & 1);
+    if (c + 1 < nch) dma((c + 1) * KD, stage ^ 1);
+    const float* sa = smem + stage * STAGE + lh * TILE + wr * 64 + l31;
+    const float* sb = smem + stage * STAGE + KD * TILE + lh * TILE + wc * 64 + l31;
+#pragma unroll
+    for (int ks = 0; ks < KD / 2; ++ks) {
+      float av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = sa[2 * ks * TILE + a * 32];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bv[b] = sb[2 * ks * TILE + b * 32];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[b], av[a], acc[a][b], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  // C -= acc: the 16 loads of one MFMA tile in flight together, then its 16 stores (a load-wait-store chain per element
+  // would serialise 64 global round trips per thread)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float* p = C + tr * TILE + wr * 64 + a * 32 + l31 + (tc * TILE + wc * 64 + b * 32 + 4 * lh) * ldc;
+      float cv[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cv[r] = __builtin_nontemporal_load(p + ((r & 3) + 8 * (r >> 2)) * ldc);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[((r & 3) + 8 * (r >> 2)) * ldc] = cv[r] - acc[a][b][r];
+    }
+}
+
 int launch_gemm_f32(const float* A, long lda, const float* B, long ldb, float* C, long ldc, long M, long Nc, long K,
                     int lower, hipStream_t s) {
   if (M <= 0 || Nc <= 0 || K <= 0) return 0;
@@ -240,6 +322,16 @@ int launch_gemm_f32(const float* A, long lda, const float* B, long ldb, float* C
   // (KBF = 32 and launch bounds asking for 3 - 4 workgroups per CU measured no better: 1244 / 1068 / 1070 ms vs
   // 1069 ms at N = 65536 -- gpurun_out/f32_gemm_ab.txt; round 4, with the deep serial schedule: <16, 4> (128 VGPRs, 4
   // spills) 1036 ms vs <16, 2> (130 VGPRs) 987 ms)
+  // SGP_F32_DMA (read per launch, so that one process can compare the two): unset / 1 the LDS-DMA kernel, 0 the
+  // register-staged one of round 3.  The 16-byte lane loads want 16-byte aligned operands and leading dimensions that are
+  // multiples of 4 floats (every caller's are multiples of 128).  Measured at N = 65536 (logpdf_f32, whole call): 767.6 ms
+  // against 992.3 ms; a 32-deep chunk (2 workgroups per CU instead of 4) 796.8 ms.
+  const char* e = getenv("SGP_F32_DMA");
+  if ((!e || atoi(e) != 0) && K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0) {
+    hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<16>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, lower, n_tr, n_tc);
+    SGP_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL((gemm_nt_f32_kernel<16, 2>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, lower, n_tr, n_tc);
   SGP_HIP(hipGetLastError());
   return 0;

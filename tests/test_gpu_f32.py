@@ -177,3 +177,27 @@ def test_one_output_type_rule_across_the_operator_surface():
     # and the numbers are the fp64 ones, rounded
     ref = P.posterior(f(x64, float(f32(0.1))), y32.astype(np.float64))
     assert np.max(np.abs(post.cov(z32) - ref.cov(P.ColVecs(np.asfortranarray(z32.X.astype(np.float64)))))) <= 1e-5
+
+
+def test_lds_dma_update_kernel_gives_the_bits_of_the_register_staged_one(monkeypatch):
+    """Round 4: the fp32 trailing update moved to the fp64 kernel's operand path (global -> LDS directly, csrc/f32.hip:
+    gemm_nt_f32_dma_kernel).  Same MFMA, same k order, same C -= epilogue: the factor -- hence logpdf and the posterior
+    moments -- must not change by a bit against the round-3 kernel (SGP_F32_DMA=0), on a size with several panels, a
+    ragged last tile and the bordered rows."""
+    rng = np.random.default_rng(5)
+    N, D = 3300, 3
+    X = np.asfortranarray(rng.standard_normal((D, N)).astype(np.float32))
+    y = rng.standard_normal(N).astype(np.float32)
+    Xs = np.asfortranarray(rng.standard_normal((D, 200)).astype(np.float32))
+    f = P.atomic(P.GP(P.Matern52Kernel()), P.GPC())
+
+    def run():
+        fx = f(P.ColVecs(X), np.float32(0.3))
+        return P.logpdf(fx, y), P.posterior_mean_and_var_f32(fx, y, P.ColVecs(Xs))
+
+    monkeypatch.setenv("SGP_F32_DMA", "0")
+    lp0, (m0, v0) = run()
+    monkeypatch.setenv("SGP_F32_DMA", "1")
+    lp1, (m1, v1) = run()
+    assert lp0 == lp1
+    assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
