@@ -811,6 +811,19 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
               "contraction %.1f (of which waiting %.1f) | wait diag %.1f | potrf %.1f | solve %.1f | publish+dequeue %.1f\n",
               n_pad, m_tot, ms, nw, sum[0], sum[1] * us, sum[2] * us, sum[7] * us, sum[3] * us, sum[4] * us, sum[5] * us,
               sum[6] * us);
+      {   // spread over the workgroups: time in the kernel and tasks taken (min / quartiles / max)
+        std::vector<double> tk, nt;
+        for (int w = 0; w < ctx->df_wgs; ++w)
+          if (h[(size_t)8 * w + 1]) {
+            tk.push_back((double)h[(size_t)8 * w + 1] * 0.01);
+            nt.push_back((double)h[(size_t)8 * w]);
+          }
+        std::sort(tk.begin(), tk.end());
+        std::sort(nt.begin(), nt.end());
+        auto q = [](const std::vector<double>& v, double f) { return v.empty() ? 0.0 : v[(size_t)(f * (double)(v.size() - 1))]; };
+        fprintf(stderr, "  per workgroup: in kernel (us) min %.0f q1 %.0f median %.0f q3 %.0f max %.0f | tasks min %.0f median %.0f max %.0f\n",
+                q(tk, 0), q(tk, 0.25), q(tk, 0.5), q(tk, 0.75), q(tk, 1), q(nt, 0), q(nt, 0.5), q(nt, 1));
+      }
       if (d_cols && n_pad / TILE >= 3) {
         const long T = n_pad / TILE;
         std::vector<long long> c((size_t)8 * T);
