@@ -372,11 +372,12 @@ def main():
         whole_tflops = (N ** 3 / 3.0) / (ms_per_step * 1e-3) / 1e12
     if args.dtype == "f32" and not is_elbo:
         PEAK_F32 = 157.3   # v_mfma_f32_32x32x2_f32 / fp32 vector peak (guide section 3)
-        roofline = {"kernel": "gemm_nt_f32_kernel (v_mfma_f32_32x32x2_f32 trailing updates; second instantiation, register-staged)",
+        roofline = {"kernel": "gemm_nt_f32_dma_kernel (v_mfma_f32_32x32x2_f32 trailing updates; second instantiation, LDS-DMA operand "
+                              "path, 4 workgroups per CU)",
                     "bound": "mfma", "achieved": whole_tflops, "peak": PEAK_F32, "unit": "TFLOP/s",
                     "frac": whole_tflops / PEAK_F32, "traffic": None,
                     "note": "whole-step N^3/3 rate of the fp32 path (host-buffer entry point; panel chain in fp64 arithmetic "
-                            "on fp32 storage, two-stream look-ahead)"}
+                            "on fp32 storage; the kernel alone: profiles/r04_bench_c5_f32_kernel_stats.csv)"}
     multi = None
     if inproc:
         st = np.zeros(9 + 4 * len(devs))

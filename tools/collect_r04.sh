@@ -39,6 +39,8 @@ for c in c5 c3 c2 n4k c1; do
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$c -o $c -- \
       python $R/bench.py --config $c --steps $st --warmup 1 --cpu-sample 0 --no-host-api --no-extras > $OUT/prof_${c}_bench.json 2> $OUT/prof_$c.err
 done
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5_f32 -o c5_f32 -- \
+    python $R/bench.py --config c5 --dtype f32 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/prof_c5_f32_bench.json 2> $OUT/prof_c5_f32.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c4 -o c4 -- \
     python $R/bench.py --config c4 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/prof_c4_bench.json 2> $OUT/prof_c4.err
 rm -f $OUT/*/*/*kernel_trace.csv $OUT/*/*kernel_trace.csv
