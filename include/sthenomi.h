@@ -217,7 +217,7 @@ int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, 
  * after whatever Stretch / Select / Periodic transformation the host applied; chaining back to the
  * user's x is the host's job).  Stationary kernels only depend on x - x', so this is
  * sum_j 2 G_ij coef rs_i cs_j kappa'(d2_ij) 2 (x_i - x'_j) over every term that reads input k.
- * Any input dimension the term gradients take (<= 64).  Matern-1/2 is not differentiable at coincident points: those pairs
+ * Any input dimension (term and input gradients walk it in chunks of 16 beyond 64 / 16).  Matern-1/2 is not differentiable at coincident points: those pairs
  * contribute 0.  Row / column scale vectors (function-scaled processes) are held fixed here: see
  * sgp_logpdf_grad_xs. */
 int sgp_logpdf_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,

@@ -194,6 +194,101 @@ __global__ __launch_bounds__(256) void grad_reduce_kernel(const double* partials
   }
 }
 
+// Any input dimension (> 64): ONE term per launch, the dimension walked in chunks of 16 -- the thread's 64 squared
+// distances accumulate in registers (d ascending, fma: the order of the small-dimension kernel), the column chunk sits in LDS,
+// the row chunk comes from global memory; then the same kernel / derivative evaluation and the same reductions.
+constexpr int GTB_CHUNK = 16;
+__global__ __launch_bounds__(256) void grad_block_bigd_kernel(const double* Kinv, long ldk, const double* alpha, long r0,
+                                                              long nr, long c0, long nc, const DevTerm* terms,
+                                                              long tile_r_first, long tile_c_first, double* partials,
+                                                              long clo, long chi) {
+  __shared__ __attribute__((aligned(16))) double sx[TILE * GTB_CHUNK];
+  __shared__ double scs[TILE];
+  __shared__ double red[4 * GRAD_MAXT * 2];
+  const DevTerm T = terms[0];
+  const long gtr = tile_r_first + blockIdx.x;
+  const long gtc = tile_c_first + blockIdx.y;
+  const int t = threadIdx.x;
+  const int trow = t & 127, th = t >> 7;
+  long cbeg = gtc * TILE, cend = cbeg + TILE;
+  if (cbeg < c0) cbeg = c0;
+  if (cend > c0 + nc) cend = c0 + nc;
+  if (cbeg < clo) cbeg = clo;
+  if (cend > chi) cend = chi;
+  long rbeg = gtr * TILE, rend = rbeg + TILE;
+  if (rbeg < r0) rbeg = r0;
+  if (rend > r0 + nr) rend = r0 + nr;
+  const bool live_tile = cbeg < cend && rbeg < rend;
+  const long grow = gtr * TILE + trow;
+  const bool live = live_tile && grow >= rbeg && grow < rend;
+  const long lrow = grow - r0;
+  const int D = (int)T.dim;
+  if (t < TILE) {
+    const long gc = gtc * TILE + t;
+    scs[t] = (live_tile && T.cs && gc >= cbeg && gc < cend) ? T.cs[gc - c0] : 1.0;
+  }
+  double d2[64];
+#pragma unroll
+  for (int q = 0; q < 64; ++q) d2[q] = 0.0;
+  for (int d0 = 0; d0 < D; d0 += GTB_CHUNK) {
+    __syncthreads();
+    for (int idx = t; idx < TILE * GTB_CHUNK; idx += 256) {
+      const int p = idx / GTB_CHUNK, d = idx % GTB_CHUNK;
+      const long gc = gtc * TILE + p;
+      double v = 0.0;
+      if (live_tile && d0 + d < D && gc >= cbeg && gc < cend) v = T.xc[(gc - c0) * T.ldc + d0 + d];
+      sx[p * GTB_CHUNK + d] = v;
+    }
+    __syncthreads();
+    double xr[GTB_CHUNK];
+#pragma unroll
+    for (int d = 0; d < GTB_CHUNK; ++d) xr[d] = (live && d0 + d < D) ? T.xr[lrow * T.ldr + d0 + d] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+      const double* sp = &sx[(th * 64 + q) * GTB_CHUNK];
+#pragma unroll
+      for (int d = 0; d < GTB_CHUNK; ++d) {
+        const double df = xr[d] - sp[d];
+        d2[q] = fma(df, df, d2[q]);
+      }
+    }
+  }
+  double a = 0.0, b = 0.0;
+  if (live) {
+    const double ai = alpha ? alpha[grow] : 0.0;
+    const double rsv = T.rs ? T.rs[lrow] : 1.0;
+#pragma unroll
+    for (int q = 0; q < 64; ++q) {
+      const int p = th * 64 + q;
+      const long gc = gtc * TILE + p;
+      if (gc < cbeg || gc >= cend) continue;
+      const double g = alpha ? 0.5 * (ai * alpha[gc] - Kinv[grow + gc * ldk]) : Kinv[grow + gc * ldk];
+      double k, dk;
+      kern_and_dscale(T.kind, d2[q], T.param, k, dk);
+      const double w = g * rsv * scs[p];
+      a = fma(w, k, a);
+      b = fma(w * T.coef, dk, b);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
+  }
+  if ((t & 63) == 0) {
+    red[(t >> 6) * 2 + 0] = a;
+    red[(t >> 6) * 2 + 1] = b;
+  }
+  __syncthreads();
+  if (t < GRAD_MAXT * 2) {
+    double s = 0.0;
+    if (t < 2)
+      for (int wv = 0; wv < 4; ++wv) s += red[wv * 2 + t];
+    const long blk = (long)blockIdx.y * gridDim.x + blockIdx.x;
+    partials[blk * GRAD_MAXT * 2 + t] = s;   // terms 1 .. GRAD_MAXT - 1: zeros (the reduction reads nterms = 1 only)
+  }
+}
+
 template <int DMAX>
 static int launch_grad_t(const double* Kinv, long ldk, const double* alpha, long r0, long nr, long c0,
                          long nc, const DevTerm* d_terms, int nterms, long trf, long tcf, long trc, long tcc,
@@ -231,8 +326,14 @@ int launch_grad_block(const double* Kinv, long ldk, const double* alpha, long r0
   else if (dmax <= 32) SGP_GR(32);
   else if (dmax <= 64) SGP_GR(64);
   else {
-    set_error("grad: input dimension > 64 is not supported on device");
-    return -1;
+    if (nterms != 1) {
+      set_error("grad: one term per launch beyond input dimension 64");
+      return -1;
+    }
+    hipLaunchKernelGGL(grad_block_bigd_kernel, dim3((unsigned)trc, (unsigned)tcc), dim3(256), 0, s, Kinv, ldk, alpha, r0, nr,
+                       c0, nc, d_terms, trf, tcf, partials, clo, chi);
+    SGP_HIP(hipGetLastError());
+    rc = 0;
   }
 #undef SGP_GR
   if (rc) return rc;

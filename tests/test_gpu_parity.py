@@ -446,21 +446,42 @@ def test_many_right_hand_sides(S):
 
 
 def test_input_dimension_limit_is_reported():
-    """Assembly (cov, logpdf, posterior, rand, elbo) takes ColVecs of any dimension; the term-gradient kernels stop at
-    64 and must say so instead of computing something else.  Input gradients take any dimension up to that (round 3:
-    grad_inputs_bigd_kernel walks the dimension in chunks of 16; they used to stop at 16): checked against central
-    differences of the logpdf at D = 17 and 40, incl. a function-valued scale (the row-scale sums of the same kernel)."""
+    """(The name is history: there is no limit left to report.)  Assembly (cov, logpdf, posterior, rand, elbo) takes ColVecs
+    of any dimension; so do the term gradients (round 4: grad_block_bigd_kernel walks the dimension in chunks of 16 beyond
+    64, one term per launch; they used to stop at 64 with an error) and the input gradients (round 3:
+    grad_inputs_bigd_kernel; they used to stop at 16).  Term gradients at D = 65 and 130 against the oracle's cotangent
+    contraction and against central differences of the logpdf in the variance and the lengthscale; input gradients against
+    central differences at D = 17 and 40, incl. a function-valued scale (the row-scale sums of the same kernel)."""
     f = P.atomic(P.GP(P.SEKernel()), P.GPC())
     rng = np.random.default_rng(0)
     for D in (64, 65):
         X = P.ColVecs(rng.standard_normal((D, 40)) / np.sqrt(D))
         K = P.prior_cov(f, X)
         assert np.abs(K - okf.kernelmatrix(okf.SEKernel(), okf.ColVecs(X.X), faithful=False)).max() < 1e-13
-    y = rng.standard_normal(40)
-    X65 = P.ColVecs(rng.standard_normal((65, 40)) / np.sqrt(65))
-    with pytest.raises(P.SthenoMIError) as ei:
-        P.logpdf_and_gradient(f(X65, 0.1), y)
-    assert "dimension" in str(ei.value)
+    for D in (65, 130):
+        n = 300                                   # three row tiles x three column tiles, ragged last tile
+        Xd = np.asfortranarray(rng.standard_normal((D, n)) / np.sqrt(D))
+        yd = rng.standard_normal(n)
+
+        def model(v, l):
+            return np.sqrt(v) * P.stretch(P.atomic(P.GP(P.Matern52Kernel()), P.GPC()), 1.0 / l)
+
+        v, l, h = 1.3, 0.7, 1e-5
+        g = P.logpdf_and_gradient(model(v, l)(P.ColVecs(Xd), 0.2), yd)
+        (term,) = g["terms"]
+        lp = lambda vv, ll: P.logpdf(model(vv, ll)(P.ColVecs(Xd), 0.2), yd)
+        fd_v = (lp(v + h, l) - lp(v - h, l)) / (2 * h)
+        fd_l = (lp(v, l + h) - lp(v, l - h)) / (2 * h)
+        assert abs(term["d_coef"] - fd_v) <= 1e-6 * max(1.0, abs(fd_v)), (D, term["d_coef"], fd_v)
+        d_l = -(1.0 / l) * term["d_inscale"]
+        assert abs(d_l - fd_l) <= 1e-6 * max(1.0, abs(fd_l)), (D, d_l, fd_l)
+        gc, gs = g["_raw"]
+        Ko = v * okf.kernelmatrix(okf.Matern52Kernel(), okf.ColVecs(Xd / l), faithful=False) + 0.2 * np.eye(n)
+        Ci = np.linalg.inv(Ko)
+        al = Ci @ yd
+        Gm = 0.5 * (np.outer(al, al) - Ci)
+        (ec, es), = _oracle_term_grads(g["_spec"], Gm)
+        assert abs(gc[0] - ec) <= 1e-8 * max(1.0, abs(ec)) and abs(gs[0] - es) <= 2e-6 * max(1.0, abs(es))
     y60 = rng.standard_normal(60)
     for D in (17, 40):
         X = np.asfortranarray(rng.standard_normal((D, 60)) / np.sqrt(D))
