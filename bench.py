@@ -369,7 +369,16 @@ def main():
         }
         whole_tflops = flops / (ms_per_step * 1e-3) / 1e12
     else:
-        whole_tflops = (N ** 3 / 3.0) / (ms_per_step * 1e-3) / 1e12
+        # Models with independent components have exact zero blocks in their covariance and in its Cholesky factor; the
+        # factorisation skips the tile products with a structurally zero operand (sthenomi.h: sgp_ctx_factor_work).  Rates
+        # and roofline fractions are quoted on the flops that RAN (work_frac x N^3 / 3); the dense-equivalent rate -- what a
+        # dense factorisation would need to deliver for the same step time -- is reported beside them.
+        work_frac = 1.0
+        if not use_dist and not inproc and args.dtype == "f64":
+            ex, de = ctx.factor_work()
+            if de > 0:
+                work_frac = ex / de
+        whole_tflops = work_frac * (N ** 3 / 3.0) / (ms_per_step * 1e-3) / 1e12
     if args.dtype == "f32" and not is_elbo:
         PEAK_F32 = 157.3   # v_mfma_f32_32x32x2_f32 / fp32 vector peak (guide section 3)
         roofline = {"kernel": "gemm_nt_f32_dma_kernel (v_mfma_f32_32x32x2_f32 trailing updates; second instantiation, LDS-DMA operand "
@@ -414,7 +423,7 @@ def main():
         if dataflow:
             # one launch of persistent workgroups does the whole factorisation (chol_df.hip): the dominant kernel IS the
             # Cholesky stage; its algorithmic flops are the factorisation's N^3 / 3 (+ the bordered row)
-            upd_ms, n_launch, upd_flops = timings[1], 1, N ** 3 / 3.0 + 1.0 * N * N
+            upd_ms, n_launch, upd_flops = timings[1], 1, work_frac * N ** 3 / 3.0 + 1.0 * N * N
             achieved = upd_flops / (upd_ms * 1e-3) / 1e12 if upd_ms > 0 else 0.0
         elif n_launch == 0:
             # N <= 4096 is factored as ONE outer panel (no outer trailing update): the step is the latency
@@ -521,9 +530,12 @@ def main():
                 one()
             ms = (time.perf_counter() - t0x) / steps * 1e3
             gg = bc.golden(name)
-            tf = (Nn ** 3 / 3.0) / (ms * 1e-3) / 1e12
+            exx, dee = ctx.factor_work()
+            wf = exx / dee if dee > 0 else 1.0
+            tf = wf * (Nn ** 3 / 3.0) / (ms * 1e-3) / 1e12
             return {"config": name, "workload": bc.describe(name), "entry": "sgp_logpdf (host buffers)", "steps": steps,
                     "ms_per_step": ms, "cholesky_tflops_whole_step": tf, "frac": tf / PEAK_FP64_MFMA_TFLOPS,
+                    "executed_work_fraction": wf, "dense_equivalent_tflops": (Nn ** 3 / 3.0) / (ms * 1e-3) / 1e12,
                     "schedule": ctx.factor_schedule(Nn), "logpdf": float(oo[0]),
                     "parity_rel": None if gg is None else abs(float(oo[0]) - gg["logpdf"]) / abs(gg["logpdf"])}
         north_star = time_config("target", 3, 1)
@@ -551,7 +563,9 @@ def main():
                                        f"sharded inside libsthenomi, transport {ctx.transport})" if inproc
                                        else f"column-panel x{world}" if use_dist else "1 GPU"),
                        "panel_width": (multi or {}).get("panel_width") if inproc else (args.panel if use_dist else None)},
-            "cholesky_tflops_whole_step": whole_tflops,  # (c4: ELBO flops of SURVEY 8d)
+            "cholesky_tflops_whole_step": whole_tflops,  # (c4: ELBO flops of SURVEY 8d; structured models: the flops that ran)
+            "executed_work_fraction": None if is_elbo else (work_frac if args.dtype == "f64" else 1.0),
+            "dense_equivalent_tflops": None if is_elbo else (N ** 3 / 3.0) / (ms_per_step * 1e-3) / 1e12,
             "cholesky_frac_of_fp64_matrix_peak": (whole_tflops / (PEAK_FP64_MFMA_TFLOPS * (len(set(devs)) if inproc else world))
                                                   if args.dtype == "f64" else None),
             "multi_gpu": multi,

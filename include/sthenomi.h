@@ -127,6 +127,14 @@ const char* sgp_ctx_transport(sgp_ctx* ctx);
  * "dataflow" (one launch of persistent workgroups, chol_df.hip) | "launches-one-panel" | "launches-lookahead" |
  * "launches-serial" | "launches-serial-deep" (capi.hip: chol_bordered).  Every schedule gives the same bits. */
 const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N);
+/* Work of the last factorisation sgp_logpdf / sgp_rand / sgp_posterior_create ran on this context, in tile products
+ * (128 x 128 x 128) of the trailing contractions: *executed, and *dense = what the dense schedule executes.  They differ
+ * when the model has independent components: the covariance of a Stheno programme then has EXACT zero blocks (no term
+ * connects the two processes, src/gp/... cross.jl yields zeros), so has its Cholesky factor, and the factorisation skips
+ * every tile product with a structurally zero operand (tile-level symbolic factorisation with fill-in; the skipped
+ * products are exact zeros: the factor keeps its bits; the reference's LAPACK path multiplies them out).
+ * SGP_STRUCT_ZEROS=0 switches the skipping off.  Dense noise, a single block or a pattern without zeros: executed == dense. */
+int sgp_ctx_factor_work(sgp_ctx* ctx, double* executed, double* dense);
 /* Figures of the last sharded factorisation of a multi-GPU context: out[0] ranks, [1] wall ms (enqueue to
  * completion), [2] transport (0 loopback, 1 peer copies, 2 RCCL), [3] ranks the RCCL communicator reports (-1: none),
  * [4] panel width (of the first part; the tail may be narrower), [5] panels, [6] 1 = scatter + all-gather peer copies,

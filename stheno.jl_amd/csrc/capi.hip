@@ -224,6 +224,8 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (dfpr) c->df_pr = atoi(dfpr);
     const char* dfpc = getenv("SGP_DF_PC");
     if (dfpc) c->df_pc = atoi(dfpc);
+    const char* szs = getenv("SGP_STRUCT_ZEROS");
+    if (szs) c->struct_zeros = atoi(szs);
     const char* dfb2 = getenv("SGP_DF_FALLBACK");
     if (dfb2) c->df_fallback = atoi(dfb2);
     const char* dfg = getenv("SGP_DF_GANG_US");
@@ -279,6 +281,7 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->d_scal) hipFree(c->d_scal);
   if (c->d_info) hipFree(c->d_info);
   if (c->d_df_state) hipFree(c->d_df_state);
+  if (c->d_sz) hipFree(c->d_sz);
   if (c->d_df_inv) hipFree(c->d_df_inv);
   if (c->d_df_stats) hipFree(c->d_df_stats);
   if (c->d_df_tasks) hipFree(c->d_df_tasks);
@@ -649,7 +652,7 @@ static int launch_update(sgp_ctx* ctx, const double* P, long ld, double* C, long
       return -2;
     }
     ctx->ev.push_back(e1);
-    ctx->ev_flops.push_back(update_flops(M, Nc, K));
+    ctx->ev_flops.push_back(update_flops(M, Nc, K) * ctx->sz_live_fraction(P, ld, C, M, Nc, K));
     SGP_HIP(hipEventRecord(e0, s));
     CHECK_RC(launch_update_kernel(P, ld, C, M, Nc, K, s, fz));
     SGP_HIP(hipEventRecord(e1, s));
@@ -707,6 +710,12 @@ static bool use_dataflow(const sgp_ctx* ctx, long n_pad) {
   if (ctx->refine != 1 || ctx->dataflow == 0) return false;
   return ctx->dataflow == 1 || (n_pad >= ctx->df_min_n && n_pad < ctx->df_max_n);
 }
+extern "C" int sgp_ctx_factor_work(sgp_ctx* ctx, double* executed, double* dense) {
+  CHECK_ARG(ctx && executed && dense, "sgp_ctx_factor_work: NULL argument");
+  *executed = ctx->sz_executed;
+  *dense = ctx->sz_dense;
+  return 0;
+}
 extern "C" const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N) {
   if (!ctx || N < 1) return "";
   const long n_pad = rup(N, TILE);
@@ -722,9 +731,35 @@ extern "C" const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N) {
 // grow > 0: bordered rows >= n_pad hold a matrix that is upper triangular by tile from row `grow` on
 // (the identity rows of the gradient path: row grow + i stays zero left of column i), so panel
 // J0..J0+wj only touches rows < grow + J0 + wj.
+// The tile-level pattern of the factor of the matrix a caller is about to factor (structural zeros, common.h).
+struct SzMask {
+  const sz_word* d_nz = nullptr;   // device rows (ctx->d_sz), nullptr: dense
+  int words = 0;
+};
+struct SzScope {   // the launch-based updates read the pattern through gemm_nt.hip's per-thread record
+  sgp_ctx* c;
+  bool on;
+  SzScope(sgp_ctx* ctx, const double* A, long ld, const SzMask* sz) : c(ctx), on(sz && sz->d_nz) {
+    if (on) {
+      gemm_set_structure(A, ld, sz->d_nz, sz->words);
+      c->sz_base = A;
+      c->sz_ld = ld;
+      c->sz_words = sz->words;
+    }
+  }
+  ~SzScope() {
+    if (on) {
+      gemm_set_structure(nullptr, 0, nullptr, 0);
+      c->sz_base = nullptr;
+    }
+  }
+};
+
 static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
-                         hipStream_t s, long grow = 0) {
+                         hipStream_t s, long grow = 0, const SzMask* sz = nullptr) {
   CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
+  if (grow != 0) sz = nullptr;
+  SzScope sz_scope(ctx, A, ld, sz);
   // Dataflow factorisation (chol_df.hip): one launch of persistent workgroups, tile-level dependencies instead of
   // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
   // upper-triangular border, `grow`: its tasks would have to skip the structurally zero tiles.)
@@ -783,7 +818,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
     }
     CHECK_RC(launch_chol_dataflow(A, ld, n_pad, m_tot, ctx->d_df_state, d_wall ? d_wall : ctx->d_df_inv, ctx->d_slots,
                                   ctx->d_info, ctx->df_wgs, ctx->df_timeout_s, s, ctx->d_df_stats, d_cols, fat, d_tasks,
-                                  ctx->df_qstart, ctx->df_gang_us));
+                                  ctx->df_qstart, ctx->df_gang_us, sz ? sz->d_nz : nullptr, sz ? sz->words : 0));
     if (ctx->d_df_stats) {   // diagnosis only: drains the stream
       hipEventRecord(e1, s);
       hipStreamSynchronize(s);
@@ -936,11 +971,106 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
 }
 
 // K + Sigma_y (lower tiles), identity padding, bordered rows
+// Structural zeros: the tile pattern of the factor of K + Sigma_y for a symmetric spec.
+//   block level : block pair (I, J) has terms, or not (flatten.py emits none for independent processes: exact zeros)
+//   tile level  : tile (ti, tj) of the matrix is non-zero when some block pair it overlaps has terms; diagonal tiles always
+//                 (noise, identity padding); the bordered rows (y - m, extra right-hand sides) are dense
+//   factor      : symbolic factorisation, column by column -- tile (i, j) fills in when rows i and j share a non-zero
+//                 tile in an earlier column
+// Nothing is returned (dense) for one block, dense noise, or a pattern without zeros.  Also counts the k-block products of
+// the contractions with and without the skipping (ctx->sz_executed / sz_dense: what the bench lines report).
+static int sz_build(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, hipStream_t s, SzMask* out) {
+  *out = SzMask();
+  const long T_c = n_pad / TILE, T_r = m_tot / TILE;
+  double dense = 0;
+  for (long j = 0; j < T_c; ++j) dense += (double)j * (double)(T_r - j);
+  ctx->sz_dense = ctx->sz_executed = dense;
+  if (!ctx->struct_zeros || !ds->symmetric || noise_kind == SGP_NOISE_DENSE || ds->nrb < 2 || ds->nrb != ds->ncb) return 0;
+  const int nb = ds->nrb;
+  std::vector<char> bnz((size_t)nb * nb, 0);
+  bool any_zero = false;
+  for (int I = 0; I < nb; ++I)
+    for (int J = 0; J < nb; ++J) {
+      const int p = I * nb + J, q = J * nb + I;
+      const bool has = ds->term_ptr[p + 1] > ds->term_ptr[p] || ds->term_ptr[q + 1] > ds->term_ptr[q];
+      bnz[(size_t)I * nb + J] = has ? 1 : 0;
+      if (!has && ds->row_len[I] > 0 && ds->row_len[J] > 0) any_zero = true;
+    }
+  if (!any_zero) return 0;
+  // blocks a tile overlaps: [blo, bhi]
+  std::vector<int> blo(T_c, 0), bhi(T_c, -1);
+  for (long t = 0; t < T_c; ++t) {
+    const long p0 = t * TILE, p1 = std::min<long>(p0 + TILE, ds->N);
+    int lo = nb, hi = -1;
+    for (int I = 0; I < nb; ++I) {
+      if (ds->row_len[I] <= 0) continue;
+      if (ds->row_off[I] < p1 && ds->row_off[I] + ds->row_len[I] > p0) {
+        lo = std::min(lo, I);
+        hi = std::max(hi, I);
+      }
+    }
+    blo[t] = lo;
+    bhi[t] = hi;
+  }
+  const int W = (int)((T_c + 63) / 64);
+  std::vector<sz_word>& nz = ctx->h_sz;
+  nz.assign((size_t)T_r * W, 0);
+  auto setbit = [&](long i, long k) { nz[(size_t)i * W + (k >> 6)] |= (sz_word)1 << (k & 63); };
+  auto getbit = [&](long i, long k) { return (nz[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1; };
+  for (long i = 0; i < T_c; ++i) {
+    setbit(i, i);
+    for (long k = 0; k < i; ++k) {
+      bool on = false;
+      for (int I = blo[i]; I <= bhi[i] && !on; ++I)
+        for (int J = blo[k]; J <= bhi[k] && !on; ++J) on = bnz[(size_t)I * nb + J] != 0;
+      if (on) setbit(i, k);
+    }
+  }
+  for (long i = T_c; i < T_r; ++i)
+    for (long k = 0; k < T_c; ++k) setbit(i, k);
+  // fill-in, and the work of the contractions
+  double executed = 0;
+  bool zeros_left = false;
+  for (long j = 0; j < T_c; ++j) {
+    const sz_word* rj = &nz[(size_t)j * W];
+    for (long i = j; i < T_r; ++i) {
+      sz_word* ri = &nz[(size_t)i * W];
+      long shared = 0;
+      for (int q = 0; q <= (int)((j ? j - 1 : 0) >> 6) && j > 0; ++q) {
+        sz_word m = ri[q] & rj[q];
+        if (q == (int)((j - 1) >> 6) && (j & 63)) m &= ~(~(sz_word)0 << (j & 63));
+        shared += __builtin_popcountll(m);
+      }
+      if (shared > 0 && !getbit(i, j)) setbit(i, j);
+      if (getbit(i, j)) executed += (double)shared;
+      else zeros_left = true;
+    }
+  }
+  ctx->sz_executed = executed;
+  if (!zeros_left) {
+    ctx->sz_executed = dense;
+    return 0;
+  }
+  if (nz.size() > ctx->n_sz) {
+    SGP_HIP(hipStreamSynchronize(s));
+    if (ctx->d_sz) hipFree(ctx->d_sz);
+    ctx->d_sz = nullptr;
+    ctx->n_sz = 0;
+    SGP_HIP(hipMalloc(&ctx->d_sz, sizeof(sz_word) * nz.size()));
+    ctx->n_sz = nz.size();
+  }
+  SGP_HIP(hipMemcpyAsync(ctx->d_sz, nz.data(), sizeof(sz_word) * nz.size(), hipMemcpyHostToDevice, s));
+  out->d_nz = ctx->d_sz;
+  out->words = W;
+  return 0;
+}
+
 static int build_bordered(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, long n_pad, long m_tot,
                           const double* d_mean, int noise_kind, double sigma2,
                           const double* d_noise, const double* d_dense, long ld_dense,
-                          const double* d_Y, long ldy, long ncols, hipStream_t s) {
+                          const double* d_Y, long ldy, long ncols, hipStream_t s, SzMask* sz = nullptr) {
   long N = ds->N;
+  if (sz) CHECK_RC(sz_build(ctx, ds, noise_kind, n_pad, m_tot, s, sz));
   int nk = noise_kind == SGP_NOISE_DENSE ? -1 : noise_kind;
   CHECK_RC(assemble(ds, dA, m_tot, 0, n_pad / TILE, 0, n_pad / TILE, 1, nk, sigma2, d_noise, s));
   if (noise_kind == SGP_NOISE_DENSE) CHECK_RC(launch_add_dense(dA, m_tot, d_dense, ld_dense, N, 1, s));
@@ -982,14 +1112,15 @@ static int dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, const 
     for (int q = 0; q < 4; ++q) SGP_HIP(hipEventCreate(&ev[q]));
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
   if (timings) SGP_HIP(hipEventRecord(ev[0], s));
+  SzMask sz;
   CHECK_RC(build_bordered(ctx, ds, dA, n_pad, m_tot, d_mean, noise_kind, sigma2, d_noise, d_dense,
-                          ld_dense, d_Y, ldy, ncols, s));
+                          ld_dense, d_Y, ldy, ncols, s, &sz));
   if (timings) SGP_HIP(hipEventRecord(ev[1], s));
   ctx->time_updates = timings != nullptr;
   for (auto e : ctx->ev) hipEventDestroy(e);
   ctx->ev.clear();
   ctx->ev_flops.clear();
-  int rc = chol_bordered(ctx, dA, m_tot, n_pad, m_tot, nullptr, s);
+  int rc = chol_bordered(ctx, dA, m_tot, n_pad, m_tot, nullptr, s, 0, &sz);
   ctx->time_updates = false;
   if (rc) return rc;
   if (timings) SGP_HIP(hipEventRecord(ev[2], s));
@@ -1251,9 +1382,10 @@ static int sgp_rand_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* m
   CHECK_RC(dZt.alloc((size_t)s_pad * n_pad));
   CHECK_RC(dOut.alloc((size_t)n_pad * s_pad));
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  SzMask sz;
   CHECK_RC(build_bordered(ctx, g.ds, dA.p, n_pad, m_tot, nullptr, nd.kind, nd.sigma2, nd.diag.p,
-                          nd.dense.p, nd.ld_dense, nullptr, 0, 0, s));
-  CHECK_RC(chol_bordered(ctx, dA.p, m_tot, n_pad, m_tot, nullptr, s));
+                          nd.dense.p, nd.ld_dense, nullptr, 0, 0, s, &sz));
+  CHECK_RC(chol_bordered(ctx, dA.p, m_tot, n_pad, m_tot, nullptr, s, 0, &sz));
   SGP_HIP(hipMemsetAsync(dZt.p, 0, sizeof(double) * s_pad * n_pad, s));
   // Zt[s, k] = Z[k, s]
   CHECK_RC(launch_transpose_add(dZ.p, N, N, S, dZt.p, s_pad, nullptr, s));
@@ -1644,10 +1776,11 @@ static int sgp_posterior_create_impl(sgp_ctx* ctx, const sgp_cov_spec* spec, con
     return fail(-2);
   }
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
+  SzMask sz;
   int rc = build_bordered(ctx, g.ds, post->dA, n_pad, m_tot, mean ? dmean.p : nullptr, nd.kind,
-                          nd.sigma2, nd.diag.p, nd.dense.p, nd.ld_dense, dY.p, N, 1, s);
+                          nd.sigma2, nd.diag.p, nd.dense.p, nd.ld_dense, dY.p, N, 1, s, &sz);
   if (rc) return fail(rc);
-  rc = chol_bordered(ctx, post->dA, m_tot, n_pad, m_tot, post->d_wall, s);
+  rc = chol_bordered(ctx, post->dA, m_tot, n_pad, m_tot, post->d_wall, s, 0, &sz);
   if (rc) return fail(rc);
   if (alpha_out) {
     DevBuf dz, dal;

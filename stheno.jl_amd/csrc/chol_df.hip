@@ -54,6 +54,8 @@ struct DfArgs {
   long ntasks;
   long long gang_ticks;   // experiment (SGP_DF_GANG_US): soft gang start -- a workgroup that took a tile of a patch waits (at
                           // most this long) until every tile of the patch has been taken; pend[] follows the tasks
+  const sz_word* nz;  // structural zeros (common.h): bit k of row i = tile (i, k) of the factor may be non-zero; nullptr = dense
+  int nzw;            // words per row
   long long* stats;   // optional (SGP_DF_STATS): 8 tick counters per workgroup, see launch_chol_dataflow
   long long* cols;    // optional: 8 wall-clock stamps per tile column (the chain: diagonal task + the task below it)
 };
@@ -116,6 +118,54 @@ __device__ __forceinline__ int df_wait(const DfArgs& a, int i, int j, int have, 
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return avail;
+}
+
+// thread 0: wait until *word >= target; 0, or -1 on abort / timeout
+__device__ __forceinline__ int df_wait_word(const DfArgs& a, int* word, int target) {
+  const long long t0 = wall_clock64();
+  for (unsigned spins = 0;; ++spins) {
+    if (DF_RLX_LOAD(word) >= target) break;
+    if (DF_RLX_LOAD(a.state + 1) != 0) return -1;
+    __builtin_amdgcn_s_sleep(2);
+    if ((spins & 63) == 63 && wall_clock64() - t0 > a.spin_ticks) {
+      __hip_atomic_store(a.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicCAS(a.info, 0, SGP_DF_TIMEOUT);
+      return -1;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return 0;
+}
+
+// structural zeros: is tile (i, j) of the factor structurally non-zero?
+__device__ __forceinline__ bool df_nz(const DfArgs& a, int i, int j) {
+  return !a.nz || ((a.nz[(long)i * a.nzw + (j >> 6)] >> (j & 63)) & 1) != 0;
+}
+// thread 0: the next run of k blocks >= k0 (and < j) that task (i, j) has to contract -- both L_ik and L_jk structurally
+// non-zero: [ka, kb); ka == j: none left
+__device__ __forceinline__ void df_next_run(const DfArgs& a, int i, int j, int k0, int& ka, int& kb) {
+  const sz_word* ri = a.nz + (long)i * a.nzw;
+  const sz_word* rj = a.nz + (long)j * a.nzw;
+  ka = j;
+  kb = j;
+  const int qlast = (j - 1) >> 6;
+  int q = k0 >> 6;
+  sz_word m = (ri[q] & rj[q]) & (~(sz_word)0 << (k0 & 63));
+  while (m == 0 && q < qlast) {
+    ++q;
+    m = ri[q] & rj[q];
+  }
+  if (m == 0) return;
+  const int first = q * 64 + __builtin_ctzll(m);
+  if (first >= j) return;
+  ka = first;
+  // the end of the run: the first k > ka that is not needed
+  sz_word z = ~(ri[q] & rj[q]) & (~(sz_word)0 << (ka & 63));
+  while (z == 0 && q < qlast) {
+    ++q;
+    z = ~(ri[q] & rj[q]);
+  }
+  if (z != 0) kb = min(j, q * 64 + (int)__builtin_ctzll(z));
 }
 
 // lane 0, after every wave has drained its stores and met at a barrier: release fence, drain, progress counter
@@ -194,7 +244,10 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
   while (kdone < j) {
     if (t == 0) {
       const long long w0 = a.stats ? wall_clock64() : 0;
-      s_word[1] = df_wait(a, i, j, kdone, j);
+      int ka = kdone, kb = j;
+      if (a.nz) df_next_run(a, i, j, kdone, ka, kb);   // skip the k blocks with a structurally zero operand tile
+      s_word[6] = ka;
+      s_word[1] = ka < j ? df_wait(a, i, j, ka, kb) : j;
       if (a.stats) {
         const long long tot = ((long long)(unsigned)s_word[2] | ((long long)s_word[3] << 32)) + (wall_clock64() - w0);
         s_word[2] = (int)(unsigned)tot;
@@ -202,10 +255,15 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
       }
     }
     __syncthreads();
+    const int ka = __builtin_amdgcn_readfirstlane(s_word[6]);
     const int avail = __builtin_amdgcn_readfirstlane(s_word[1]);   // wave-uniform for the compiler too
     if (avail < 0) return false;
+    if (ka >= j) {
+      __syncthreads();   // (s_word is rewritten by the caller's lane 0)
+      break;
+    }
     if (a.cols && t == 0 && i == j && avail == j) a.cols[(long)j * 8 + 1] = wall_clock64();
-    df_contract(Ag, Bg, ld, (long)kdone * (TILE / DF_KB), (long)avail * (TILE / DF_KB), acc, smem, wu, lane, a_off, b_off);
+    df_contract(Ag, Bg, ld, (long)ka * (TILE / DF_KB), (long)avail * (TILE / DF_KB), acc, smem, wu, lane, a_off, b_off);
     kdone = avail;
   }
   if (a.cols && t == 0 && i == j) a.cols[(long)j * 8 + 2] = wall_clock64();
@@ -284,7 +342,8 @@ template <bool FAT>
 __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
   __shared__ int s_word[8];   // [0] task, [1] available k blocks / abort, [2..3] wait ticks (statistics), [4..5] lane 0's
-                              // queue cursor: the queue it serves, queues left to try (XCD-affine order)
+                              // queue cursor: the queue it serves, queues left to try (XCD-affine order), [6] first k
+                              // block of the run being contracted (structural zeros)
   const int t = threadIdx.x;
   int* prog = a.state + DF_PROG;
   // optional per-workgroup time accounting (lane 0, 100 MHz wall clock): [0] tasks [1] kernel [2] contraction incl. its
@@ -311,6 +370,20 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
     df_unpack((uint32_t)q, i, j);
     // the chain tasks run at raised wave priority: beside a contraction's back-to-back MFMAs the pivot chain of the
     // diagonal block and the substitution otherwise wait for issue slots (potrf 35 -> 100 us at N = 16384)
+    if (a.nz && !df_nz(a, i, j)) {
+      // a structurally zero tile: nothing to compute (its entries are the zeros the assembly wrote); the progress counter
+      // of its row still moves in column order
+      __syncthreads();   // every wave has read s_word[0]
+      if (t == 0) {
+        int r = df_wait_word(a, prog + i, j);
+        if (r == 0) {
+          df_release_store(prog + i, j + 1);
+          r = df_dequeue(a, s_word + 4);
+        }
+        s_word[0] = r;
+      }
+      continue;
+    }
     const bool chain = (i == j || i == j + 1);
     if (chain) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
@@ -355,8 +428,14 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (t == 0) {
-      df_release_store(prog + i, j + 1);
-      s_word[0] = df_dequeue(a, s_word + 4);
+      // (with skipped k blocks this task may not have waited for every earlier tile of its row: prog[i] counts the final
+      // tiles of row i in column order, so the count only moves past j once they all are)
+      int r = a.nz ? df_wait_word(a, prog + i, j) : 0;
+      if (r == 0) {
+        df_release_store(prog + i, j + 1);
+        r = df_dequeue(a, s_word + 4);
+      }
+      s_word[0] = r;
     }
     if (st) {
       const long long n = wall_clock64();
@@ -384,7 +463,8 @@ __global__ __launch_bounds__(512, 2) void chol_dataflow_fat_kernel(DfArgs a) { c
 
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
                          int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats, long long* d_cols,
-                         int fat, const uint32_t* d_tasks, const int* qstart, double gang_us) {
+                         int fat, const uint32_t* d_tasks, const int* qstart, double gang_us, const sz_word* d_nz,
+                         int nz_words) {
   if (n_pad % TILE || m_tot % TILE || n_pad <= 0 || m_tot < n_pad) {
     set_error("chol_dataflow: sizes must be multiples of 128");
     return -1;
@@ -420,6 +500,8 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
   a.gang_ticks = a.tasks ? (long long)(gang_us * 100.0) : 0;
   a.stats = d_stats;
   a.cols = d_stats ? d_cols : nullptr;
+  a.nz = d_nz;
+  a.nzw = nz_words;
   SGP_HIP(hipMemsetAsync(d_state, 0, sizeof(int) * (DF_PROG + (size_t)a.T_r), s));
   const long grid = std::min<long>(a.ntasks, n_wg);
   if (fat)

@@ -141,13 +141,26 @@ int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M
 int launch_gemm_nt_potrf(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, int outer,
                          int handoff, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
                          hipStream_t s);
+// Structural zeros (round 4).  A Stheno programme with independent components has EXACT zero blocks in its covariance (no
+// term connects the two processes: cross.jl gives zeros), and so has its Cholesky factor; the reference's dense LAPACK path
+// multiplies them out.  capi.hip: sz_build derives the tile-level pattern of the factor (symbolic factorisation with
+// fill-in) and the factorisation skips every tile product one of whose operands is structurally zero -- the skipped
+// products are exact zeros, so the factor keeps its bits.  nz: one row of `words` 64-bit words per tile row of the
+// bordered matrix, bit k = tile (row, k) of the factor may be non-zero.
+typedef unsigned long long sz_word;
+struct TileSkip {      // per launch of a lower update C -= P P': C's first tile row / column, the k tiles the panel covers
+  const sz_word* nz = nullptr;
+  int words = 0, tr0 = 0, tc0 = 0, kt0 = 0, kt1 = 0;
+};
+// while set (chol_bordered's scope; per host thread), the lower updates launched on tiles of `base` skip dead tiles
+void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words);
 // chol_df.hip: the whole bordered factorisation (lower tiles of the n_pad columns + rows n_pad .. m_tot) in one launch of
 // persistent workgroups; d_state: SGP_DF_STATE_WORDS + m_tot / 128 ints, d_invall: n_pad / 128 x 2048 doubles
 constexpr int SGP_DF_TIMEOUT = -77;   // *info when a dependency wait inside the kernel ran into its bound
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
                          int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats = nullptr,
                          long long* d_cols = nullptr, int fat = 0, const uint32_t* d_tasks = nullptr,
-                         const int* qstart = nullptr, double gang_us = 0.0);
+                         const int* qstart = nullptr, double gang_us = 0.0, const sz_word* d_nz = nullptr, int nz_words = 0);
 // d_tasks = qstart[9], the queues, pend[] (df_order.h: df_build_queues); qstart: host copy
 constexpr long SGP_DF_STATE_WORDS = 16;   // state words ahead of the per-tile-row progress counters
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,

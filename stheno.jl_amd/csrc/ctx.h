@@ -92,6 +92,36 @@ struct sgp_ctx {
   int df_qstart[9] = {0};
   bool df_timed_out = false;   // the last dataflow launch ran into its wait bound (fetch_info)
   int df_fallback = 1;         // SGP_DF_FALLBACK=0: report the timeout instead (the kernel's own error path, tests)
+  // structural zeros (common.h; capi.hip: sz_build): SGP_STRUCT_ZEROS = 0 switches the skipping off (A/B)
+  int struct_zeros = 1;
+  sgp::sz_word* d_sz = nullptr;   // device copy of the factor's tile pattern (grow-only)
+  size_t n_sz = 0;
+  std::vector<sgp::sz_word> h_sz;
+  double sz_executed = 0, sz_dense = 0;   // k-block products of the last factorisation: run / of the dense schedule
+  const double* sz_base = nullptr;        // the matrix the pattern in h_sz belongs to while chol_bordered runs (else nullptr)
+  long sz_ld = 0;
+  int sz_words = 0;
+  // fraction of the lower tiles of the update C -= P P' that are live under the pattern (1 without one): the timed
+  // (instrumented) step prices a launch by the tile products it runs
+  double sz_live_fraction(const double* P, long ld, const double* C, long M, long Nc, long K) const {
+    if (!sz_base || ld != sz_ld) return 1.0;
+    const long oc = C - sz_base, op = P - sz_base;
+    if (oc < 0 || op < 0) return 1.0;
+    const long cr = oc % ld, cc = oc / ld, pc = op / ld;
+    if (cr != cc || cr % 128 || pc % 128 || K % 128) return 1.0;
+    const long t0 = cr / 128, kt0 = pc / 128, kt1 = kt0 + K / 128, n_tr = M / 128, n_tc = Nc / 128;
+    double live = 0, all = 0;
+    for (long tc = 0; tc < n_tc; ++tc)
+      for (long tr = tc; tr < n_tr; ++tr) {
+        const sgp::sz_word* ra = &h_sz[(size_t)(t0 + tr) * sz_words];
+        const sgp::sz_word* rb = &h_sz[(size_t)(t0 + tc) * sz_words];
+        bool on = false;
+        for (long k = kt0; k < kt1 && !on; ++k) on = ((ra[k >> 6] & rb[k >> 6]) >> (k & 63)) & 1;
+        all += 1;
+        live += on ? 1 : 0;
+      }
+    return all > 0 ? live / all : 1.0;
+  }
   long df_fallbacks = 0;       // operators rerun on the launch-based schedule because of that (capi.hip: with_df_fallback)
   std::mutex mu;
   // optional per-launch timing of the trailing updates (roofline evidence for bench.py)

@@ -67,7 +67,8 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
                                                  long ldc, long K, double alpha, double beta, long mask_off,
                                                  long n_tr, long n_tc, long c_slice_stride, const double* Cin,
                                                  long ldcin, int klo, double* smem, long& tr, long& tc,
-                                                 long long* dbg = nullptr, long scr_mul = 0, long scr_mod = 0) {
+                                                 long long* dbg = nullptr, long scr_mul = 0, long scr_mod = 0,
+                                                 const TileSkip* sk = nullptr, bool keep_first = false) {
   // STAMP (bench only, sgp_bench_gemm_stamps): s_memtime of thread 0 at the phase boundaries of the tile program
   long long st0 = 0, st1 = 0, st2 = 0, stA = 0;
   if (STAMP) st0 = (long long)__builtin_amdgcn_s_memtime();
@@ -112,6 +113,20 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
     A += (long)blockIdx.y * K * lda;
     B += (long)blockIdx.y * K * ldb;
     C += (long)blockIdx.y * c_slice_stride;
+  }
+  // structural zeros: the tile's update P[tr] P[tc]' is dead when, for every k tile of the panel, one of the two operand
+  // tiles is structurally zero (keep_first: tile (0, 0) of a fused launch goes on to the diagonal-block routine anyway)
+  if (sk && sk->nz && !(keep_first && tr == 0 && tc == 0)) {
+    const sz_word* ra = sk->nz + (long)(sk->tr0 + tr) * sk->words;
+    const sz_word* rb = sk->nz + (long)(sk->tc0 + tc) * sk->words;
+    bool live = false;
+    for (int q = sk->kt0 >> 6; q <= (sk->kt1 - 1) >> 6; ++q) {
+      sz_word m = ra[q] & rb[q];
+      if (q == (sk->kt0 >> 6)) m &= ~(sz_word)0 << (sk->kt0 & 63);
+      if (q == ((sk->kt1 - 1) >> 6) && (sk->kt1 & 63)) m &= ~(~(sz_word)0 << (sk->kt1 & 63));
+      live = live || m != 0;
+    }
+    if (!live) return false;
   }
   if (STAMP) stA = (long long)__builtin_amdgcn_s_memtime();   // the tile is known
   // stage s: A chunk at smem + s*2*KB*LDS_LD, B chunk right after it
@@ -337,11 +352,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
                                                              long ldc, long K, double alpha,
                                                              double beta, long mask_off, long n_tr,
                                                              long n_tc, long c_slice_stride,
-                                                             const double* Cin, long ldcin, int klo) {
+                                                             const double* Cin, long ldcin, int klo, TileSkip sk) {
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   long tr, tc;
   gemm_nt_dma_tile<false>(A, lda, B, ldb, C, ldc, K, alpha, beta, mask_off, n_tr, n_tc, c_slice_stride, Cin, ldcin,
-                          klo, smem, tr, tc);
+                          klo, smem, tr, tc, nullptr, 0, 0, &sk);
 }
 
 // Fused lower update + Cholesky of the NEXT diagonal block (SGP_FUSE_POTRF, capi.hip: panel_factor /
@@ -360,11 +375,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_potrf_kernel(const double*
                                                                    long ldb, double* C, long ldc, long K,
                                                                    long n_tr, long n_tc, double* invd,
                                                                    double* logdet_slot, int* info, long gcol0,
-                                                                   int prio) {
+                                                                   int prio, TileSkip sk) {
   extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
   long tr, tc;
   const bool live = gemm_nt_dma_tile<HANDOFF>(A, lda, B, ldb, C, ldc, K, -1.0, 1.0, 0L, n_tr, n_tc, 0L, C, ldc, 0,
-                                              dyn_smem, tr, tc);
+                                              dyn_smem, tr, tc, nullptr, 0, 0, &sk, true);
   if (live && tr == 0 && tc == 0) {   // workgroup-uniform
     if (!HANDOFF) {
       // the tile was written by all eight waves: stores complete + visible to the workgroup before it is re-read
@@ -612,6 +627,38 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_reg_kernel(const double* A, lo
     for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = alpha * acc[j][i];
 }
 
+// Structure of the matrix being factored (structural zeros, common.h): set by chol_bordered for its scope.
+namespace {
+struct GemmStructure {
+  const double* base = nullptr;
+  long ld = 0;
+  const sz_word* nz = nullptr;
+  int words = 0;
+};
+thread_local GemmStructure g_st;
+// the skip record of the diagonal-aligned lower update C[lower] -= P P' (P's rows = C's rows = C's columns), or an empty one
+TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) {
+  TileSkip sk;
+  if (!g_st.nz || ldp != g_st.ld || ldc != g_st.ld) return sk;
+  const long oc = C - g_st.base, op = P - g_st.base;
+  if (oc < 0 || op < 0) return sk;
+  const long cr = oc % g_st.ld, cc = oc / g_st.ld, pr = op % g_st.ld, pc = op / g_st.ld;
+  if (cr != cc || pr != cr || cr % TILE || pc % TILE || K % TILE || pc + K > cc) return sk;
+  sk.nz = g_st.nz;
+  sk.words = g_st.words;
+  sk.tr0 = sk.tc0 = (int)(cr / TILE);
+  sk.kt0 = (int)(pc / TILE);
+  sk.kt1 = sk.kt0 + (int)(K / TILE);
+  return sk;
+}
+}  // namespace
+void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words) {
+  g_st.base = base;
+  g_st.ld = ld;
+  g_st.nz = d_nz;
+  g_st.words = words;
+}
+
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
                    long M, long Nc, long K, double alpha, double beta, long mask_off,
                    int kcap_mode, long kcap_off, hipStream_t s) {
@@ -633,7 +680,8 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
                        beta, mask_off, 0L, n_tr, n_tc);
   else
     hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
-                       mask_off, n_tr, n_tc, 0L, (const double*)C, ldc, 0);
+                       mask_off, n_tr, n_tc, 0L, (const double*)C, ldc, 0,
+                       (A == B && mask_off == 0 && alpha == -1.0 && beta == 1.0) ? skip_for(A, lda, C, ldc, K) : TileSkip());
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -648,7 +696,7 @@ int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M
   long n_tr = M / TILE, n_tc = Nc / TILE;
   long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1));
   hipLaunchKernelGGL(gemm_nt_dma_kernel<1>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, P, ldp, C, ldc, K,
-                     -1.0, 1.0, 0L, n_tr, n_tc, 0L, (const double*)C, ldc, 0);
+                     -1.0, 1.0, 0L, n_tr, n_tc, 0L, (const double*)C, ldc, 0, skip_for(P, ldp, C, ldc, K));
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -662,7 +710,7 @@ static int launch_potrf_variant(unsigned grid, const double* P, long ldp, double
                                 hipStream_t s) {
   SGP_LDS_ATTR_ONCE((gemm_nt_dma_potrf_kernel<TAG, HANDOFF>), PD_LDS);
   hipLaunchKernelGGL((gemm_nt_dma_potrf_kernel<TAG, HANDOFF>), dim3(grid), dim3(512), PD_LDS, s, P, ldp, P, ldp, C, ldc,
-                     K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, panel_prio());
+                     K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, panel_prio(), skip_for(P, ldp, C, ldc, K));
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -700,7 +748,7 @@ int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, con
   long groups = ((n_tr + 7) / 8 + 7) / 8;
   dim3 grid((unsigned)(groups * 8 * n_tc * 8));
   hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, grid, dim3(512), 0, s, A, lda, B, ldb, C, ldc, K, alpha, beta,
-                     -(1L << 40), n_tr, n_tc, 0L, Cin, ldcin, 0);
+                     -(1L << 40), n_tr, n_tc, 0L, Cin, ldcin, 0, TileSkip());
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -716,7 +764,7 @@ int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, h
   long n_t = n / TILE;
   long per_xcd = tri_ids_per_xcd(tri_shape(n_t, n_t, -1));
   hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
-                     1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 1);
+                     1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 1, TileSkip());
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -736,7 +784,7 @@ int launch_gemm_nt_lz_k(const double* L, long ldl, const double* Zt, long ldz, d
   long n_tr = n / TILE, n_tc = ns / TILE;
   long groups = ((n_tr + 7) / 8 + 7) / 8;
   hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(groups * 8 * n_tc * 8)), dim3(512), 0, s, L, ldl, Zt, ldz, C,
-                     ldc, K, 1.0, beta, -(1L << 40), n_tr, n_tc, 0L, (const double*)C, ldc, 2);
+                     ldc, K, 1.0, beta, -(1L << 40), n_tr, n_tc, 0L, (const double*)C, ldc, 2, TileSkip());
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -775,7 +823,7 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
     const long full = sub > 1 ? tiles / 64 * 64 : tiles;
     const long ids = full + (tiles - full) * sub;
     hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(ids * 8)), dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc,
-                       K / nsplit, 1.0, 0.0, sub, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 3);
+                       K / nsplit, 1.0, 0.0, sub, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 3, TileSkip());
     SGP_HIP(hipGetLastError());
     return 0;
   }
@@ -784,7 +832,7 @@ int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, 
   long per_xcd = lower_only ? tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1)) : groups * 8 * n_tc;
   dim3 grid((unsigned)(per_xcd * 8), (unsigned)nsplit);
   hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, grid, dim3(512), 0, s, A, lda, B, ldb, Cpart, ldc, K / nsplit, 1.0,
-                     0.0, mask_off, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 0);
+                     0.0, mask_off, n_tr, n_tc, part_stride, (const double*)Cpart, ldc, 0, TileSkip());
   SGP_HIP(hipGetLastError());
   return 0;
 }

@@ -75,6 +75,7 @@ _SIGS = {
     "sgp_ctx_ndev": (C.c_int, [_P]),
     "sgp_ctx_transport": (C.c_char_p, [_P]),
     "sgp_ctx_factor_schedule": (C.c_char_p, [_P, C.c_int64]),
+    "sgp_ctx_factor_work": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sgp_ctx_multi_stats": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_ctx_multi_profile": (C.c_int, [_P, C.c_int]),
     "sgp_ctx_multi_profile_get": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
@@ -232,6 +233,13 @@ class Context:
     def factor_schedule(self, N):
         """Which schedule the blocked Cholesky of an N-point covariance runs on this context."""
         return self.lib.sgp_ctx_factor_schedule(self.handle, int(N)).decode()
+
+    def factor_work(self):
+        """(executed, dense) tile products of the last factorisation's contractions: they differ when the model has
+        independent components whose exact zero blocks the factorisation skipped (sthenomi.h: sgp_ctx_factor_work)."""
+        e, d = C.c_double(), C.c_double()
+        check(self.lib.sgp_ctx_factor_work(self.handle, C.byref(e), C.byref(d)), "sgp_ctx_factor_work")
+        return e.value, d.value
 
     def close(self):
         if getattr(self, "handle", None):

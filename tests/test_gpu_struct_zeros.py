@@ -1,0 +1,123 @@
+"""Structural zeros (round 4; include/sthenomi.h: sgp_ctx_factor_work, csrc/capi.hip: sz_build).
+
+A Stheno programme with independent components has EXACT zero blocks in its covariance -- cross.jl / the flattener emit no
+term between two processes that share no atom -- and so has its Cholesky factor.  The reference's LAPACK path multiplies
+them out; the factorisation here derives the tile-level pattern of the factor (symbolic factorisation, fill-in included) and
+skips every tile product with a structurally zero operand.  The skipped products are exact zeros, so NOTHING may change:
+every operator built on the factorisation must come out bit-identical with the skipping on and off, on every schedule, and
+equal to the oracle's dense computation; and the work counter must show that something was skipped."""
+import numpy as np
+import pytest
+
+import oracle.abstractgps as oagp
+import oracle.stheno as ost
+import stheno_jl_amd as P
+from test_gpu_fused_potrf import _ctx, _operators, _with_ctx
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("schedule", ["launches", "dataflow", "dataflow-fat"])
+@pytest.mark.parametrize("N", [700, 3300, 5200])
+def test_every_operator_is_bit_identical_with_and_without_the_skipping(monkeypatch, N, schedule):
+    env = {"launches": dict(SGP_DATAFLOW=0), "dataflow": dict(SGP_DATAFLOW=1, SGP_DF_FAT_MAX_N=0),
+           "dataflow-fat": dict(SGP_DATAFLOW=1, SGP_DF_FAT_MAX_N=1 << 30)}[schedule]
+    off = _ctx(monkeypatch, 11, SGP_STRUCT_ZEROS=0, **env)
+    ref, _ = _with_ctx(off, lambda: _operators(N))
+    e0, d0 = off.factor_work()
+    on = _ctx(monkeypatch, 11, SGP_STRUCT_ZEROS=1, **env)
+    for rep in range(2):
+        got, _ = _with_ctx(on, lambda: _operators(N))
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (N, schedule, rep, k, np.max(np.abs(ref[k] - got[k])))
+    off.close()
+    on.close()
+
+
+def _work(ctx, fn):
+    _with_ctx(ctx, fn)
+    return ctx.factor_work()
+
+
+def test_the_work_counter_shows_what_was_skipped(monkeypatch):
+    """f3 = f1 + f2 observed at all three (the north-star model, blocks in the order f1, f2, f3): the (f2, f1) block of the
+    factor is zero, 5 / 9 of the dense work remains in the limit of many tiles per block; ordered f3, f1, f2 the (f2, f1)
+    block FILLS IN (both rows meet f3's column) and nothing can be skipped; dense noise switches the pattern off."""
+    rng = np.random.default_rng(3)
+    n = 1536                                  # 12 tiles per block: block boundaries on tile boundaries
+    xs = {k: P.ColVecs(np.asfortranarray(rng.standard_normal((2, n)))) for k in ("f1", "f2", "f3")}
+    F = P.gppp_sum_model()
+    y = rng.standard_normal(3 * n)
+
+    def logpdf(order, noise):
+        x = P.BlockData([P.GPPPInput(k, xs[k]) for k in order])
+        return lambda: P.logpdf(F(x, noise), y)
+
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=1)
+    e, d = _work(ctx, logpdf(("f1", "f2", "f3"), 0.1))
+    T = 36
+    assert d == sum(j * (T + 1 - j) for j in range(T))       # the bordered row counts as a tile row
+    assert 0.50 * d < e < 0.62 * d, (e, d)
+    e2, d2 = _work(ctx, logpdf(("f3", "f1", "f2"), 0.1))
+    assert e2 == d2 == d
+    B = rng.standard_normal((3 * n, 4))
+    e3, d3 = _work(ctx, logpdf(("f1", "f2", "f3"), 0.2 * np.eye(3 * n) + 0.01 * B @ B.T))
+    assert e3 == d3
+    ctx.close()
+    ctx0 = _ctx(monkeypatch, 11, SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=0)
+    e4, d4 = _work(ctx0, logpdf(("f1", "f2", "f3"), 0.1))
+    assert e4 == d4 == d
+    ctx0.close()
+
+
+@pytest.mark.parametrize("order", [("a", "b", "ab", "c", "ca"), ("ab", "c", "a", "ca", "b"), ("c", "b", "a", "ca", "ab")])
+def test_fill_in_and_ragged_blocks_against_the_oracle(monkeypatch, order):
+    """Five processes over three independent atoms -- a, b, c, ab = a + b, ca = c + 2 a -- in orders that produce different
+    fill-in, block sizes that put the block boundaries inside tiles; logpdf, posterior moments and a draw against the oracle's
+    dense computation, and bit-identical with the skipping off, on the launch-based and on the dataflow schedule."""
+    rng = np.random.default_rng(11)
+    sizes = dict(a=301, b=517, ab=260, c=433, ca=389)
+
+    def build(api):
+        gpc = api.GPC()
+        a = api.atomic(api.GP(api.SEKernel()), gpc)
+        b = api.atomic(api.GP(api.Matern52Kernel()), gpc)
+        c = api.atomic(api.GP(api.Matern32Kernel()), gpc)
+        return api.GPPP({"a": a, "b": b, "c": c, "ab": a + b, "ca": c + 2.0 * a}, gpc)
+
+    import models
+    Fo, Fp = build(models.oracle_api()), build(models.product_api())
+    pts = {k: rng.standard_normal(sizes[k]) for k in order}
+    xo = ost.BlockData([ost.GPPPInput(k, pts[k]) for k in order])
+    xp = P.BlockData([P.GPPPInput(k, pts[k]) for k in order])
+    N = sum(sizes.values())
+    y = rng.standard_normal(N)
+    noise = 0.2 + 0.1 * rng.random(N)
+    t = rng.standard_normal(50)
+    Z = np.asfortranarray(rng.standard_normal((N, 2)))
+    lo = oagp.logpdf(Fo(xo, noise), y)
+    mo, vo = oagp.posterior(Fo(xo, noise), y).mean_and_var(ost.GPPPInput("ca", t))
+
+    def run():
+        fx = Fp(xp, noise)
+        post = P.posterior(fx, y)
+        m, v = post.mean_and_var(P.GPPPInput("ca", t))
+        return dict(lp=np.array([P.logpdf(fx, y)]), m=np.asarray(m), v=np.asarray(v), r=np.asarray(P.rand(None, fx, 2, Z=Z)))
+
+    outs = {}
+    for name, env in (("launch-off", dict(SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=0)), ("launch-on", dict(SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=1)),
+                      ("df-on", dict(SGP_DATAFLOW=1, SGP_DF_FAT_MAX_N=0, SGP_STRUCT_ZEROS=1)),
+                      ("dffat-on", dict(SGP_DATAFLOW=1, SGP_DF_FAT_MAX_N=1 << 30, SGP_STRUCT_ZEROS=1))):
+        ctx = _ctx(monkeypatch, 11, **env)
+        outs[name] = _with_ctx(ctx, run)
+        if name == "launch-on":
+            e, d = ctx.factor_work()
+            assert e < d, (order, e, d)
+        ctx.close()
+    ref = outs["launch-off"]
+    assert abs(ref["lp"][0] - lo) <= 1e-10 * abs(lo)
+    np.testing.assert_allclose(ref["m"], mo, rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(ref["v"], vo, rtol=1e-8, atol=1e-9)
+    for name, o in outs.items():
+        for k in ref:
+            assert np.array_equal(ref[k], o[k]), (order, name, k)
