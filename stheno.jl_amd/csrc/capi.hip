@@ -712,6 +712,7 @@ static bool use_dataflow(const sgp_ctx* ctx, long n_pad) {
 }
 extern "C" int sgp_ctx_factor_work(sgp_ctx* ctx, double* executed, double* dense) {
   CHECK_ARG(ctx && executed && dense, "sgp_ctx_factor_work: NULL argument");
+  if (ctx->multi) return sgp_multi_factor_work(ctx->multi, executed, dense);
   *executed = ctx->sz_executed;
   *dense = ctx->sz_dense;
   return 0;
@@ -979,8 +980,9 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
 //                 tile in an earlier column
 // Nothing is returned (dense) for one block, dense noise, or a pattern without zeros.  Also counts the k-block products of
 // the contractions with and without the skipping (ctx->sz_executed / sz_dense: what the bench lines report).
-static int sz_build(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, hipStream_t s, SzMask* out) {
-  *out = SzMask();
+// sz_pattern: the host part (ctx->h_sz, ctx->sz_executed / sz_dense); returns the words per row through *words, 0 = dense.
+static int sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, int* words) {
+  *words = 0;
   const long T_c = n_pad / TILE, T_r = m_tot / TILE;
   double dense = 0;
   for (long j = 0; j < T_c; ++j) dense += (double)j * (double)(T_r - j);
@@ -1051,20 +1053,33 @@ static int sz_build(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pa
     ctx->sz_executed = dense;
     return 0;
   }
-  if (nz.size() > ctx->n_sz) {
+  *words = W;
+  return 0;
+}
+
+// the device copy of a pattern (`h`: rows x words, possibly another context's -- the ranks of a multi-GPU context share one)
+static int sz_upload(sgp_ctx* ctx, const std::vector<sz_word>& h, int words, hipStream_t s, SzMask* out) {
+  *out = SzMask();
+  if (words <= 0 || h.empty()) return 0;
+  if (h.size() > ctx->n_sz) {
     SGP_HIP(hipStreamSynchronize(s));
     if (ctx->d_sz) hipFree(ctx->d_sz);
     ctx->d_sz = nullptr;
     ctx->n_sz = 0;
-    SGP_HIP(hipMalloc(&ctx->d_sz, sizeof(sz_word) * nz.size()));
-    ctx->n_sz = nz.size();
+    SGP_HIP(hipMalloc(&ctx->d_sz, sizeof(sz_word) * h.size()));
+    ctx->n_sz = h.size();
   }
-  SGP_HIP(hipMemcpyAsync(ctx->d_sz, nz.data(), sizeof(sz_word) * nz.size(), hipMemcpyHostToDevice, s));
+  SGP_HIP(hipMemcpyAsync(ctx->d_sz, h.data(), sizeof(sz_word) * h.size(), hipMemcpyHostToDevice, s));
   out->d_nz = ctx->d_sz;
-  out->words = W;
+  out->words = words;
   return 0;
 }
-
+static int sz_build(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, hipStream_t s, SzMask* out) {
+  *out = SzMask();
+  int words = 0;
+  CHECK_RC(sz_pattern(ctx, ds, noise_kind, n_pad, m_tot, &words));
+  return sz_upload(ctx, ctx->h_sz, words, s, out);
+}
 static int build_bordered(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, long n_pad, long m_tot,
                           const double* d_mean, int noise_kind, double sigma2,
                           const double* d_noise, const double* d_dense, long ld_dense,
@@ -3428,4 +3443,31 @@ int drv_vfe_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz
 int drv_vfe_finish(sgp_ctx* ctx, long M, double* d_part, double* d_wg, double* h6) {
   return elbo_finish_core(ctx, M, d_part, d_wg, h6);
 }
+// the multi-GPU driver's view (multi.hip): rank 0's context computes the pattern, every rank uploads it
+int drv_sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, int* words) {
+  return ::sz_pattern(ctx, ds, noise_kind, n_pad, m_tot, words);
+}
+int drv_sz_upload(sgp_ctx* ctx, const sgp_ctx* from, int words, hipStream_t s, const sz_word** d_nz) {
+  SzMask m;
+  CHECK_RC(::sz_upload(ctx, from->h_sz, words, s, &m));
+  *d_nz = m.d_nz;
+  return 0;
+}
+// fraction of the lower tiles of destination columns [c0, c0 + w) (rows c0 .. m_tot) that the k tiles [kt0, kt1) touch
+double drv_sz_live_fraction(const sgp_ctx* ctx, int words, long c0, long w, long m_tot, long kt0, long kt1) {
+  if (words <= 0) return 1.0;
+  const long t0 = c0 / TILE, n_tc = w / TILE, n_tr = (m_tot - c0) / TILE;
+  double live = 0, all = 0;
+  for (long tc = 0; tc < n_tc; ++tc)
+    for (long tr = tc; tr < n_tr; ++tr) {
+      const sz_word* ra = &ctx->h_sz[(size_t)(t0 + tr) * words];
+      const sz_word* rb = &ctx->h_sz[(size_t)(t0 + tc) * words];
+      bool on = false;
+      for (long k = kt0; k < kt1 && !on; ++k) on = ((ra[k >> 6] & rb[k >> 6]) >> (k & 63)) & 1;
+      all += 1;
+      live += on ? 1 : 0;
+    }
+  return all > 0 ? live / all : 1.0;
+}
+
 }  // namespace sgp

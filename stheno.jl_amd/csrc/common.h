@@ -171,6 +171,8 @@ struct SegSrc {      // a factored column panel, packed: element (global row r, 
   const double* base;
   long ld, row0;
   int w;
+  long k0 = -1;      // global column of the first column (a sub-panel: row0 + its offset); -1: row0.  Only the structural-
+                     // zero test reads it.
 };
 struct SegDst {      // an owned column panel, packed: element (global row r, global column c) at C[(r - c0) + (c - c0) * ldc]
   double* C;
@@ -183,6 +185,8 @@ struct SegBatch {
   SegDst dst[SEG_MAX_DST];
   int n_dst;
   long m_tot;
+  const sz_word* nz = nullptr;   // structural zeros (above): a tile skips the sources all of whose k tiles are dead for it
+  int nz_words = 0;
 };
 int launch_gemm_nt_seg(SegBatch& b, hipStream_t s, long* n_ids = nullptr);
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,

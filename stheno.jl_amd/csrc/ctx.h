@@ -33,6 +33,8 @@ int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const 
                                 const double* mean_s, double* mean_out, double* var_out, double* cov_out,
                                 int64_t ldcov);
 void sgp_multi_posterior_destroy(sgp_mpost* mp);
+// executed / dense tile products of the last sharded factorisation (sgp_ctx_factor_work on a multi-GPU context)
+int sgp_multi_factor_work(struct sgp_multi* m, double* executed, double* dense);
 int sgp_multi_logpdf_grad(struct sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                           const double* noise, const double* y, double* logpdf_out, double* grad_y, double* grad_mean,
                           double* grad_noise, double* grad_coef, double* grad_inscale);

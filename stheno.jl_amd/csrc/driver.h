@@ -26,6 +26,11 @@ int drv_diag_of_spec(sgp_ctx* ctx, const sgp_dspec* ds, double* d_out, hipStream
 int drv_dspec_create(sgp_ctx* ctx, const sgp_cov_spec* sp, sgp_dspec** out);   // caller holds the context
 void drv_dspec_free(sgp_dspec* ds);
 long drv_invd_stride();
+// structural zeros (common.h; capi.hip: sz_pattern / sz_upload): rank 0's context computes the tile pattern of the factor
+// (host), every rank uploads it; *words = 0 / *d_nz = nullptr: dense
+int drv_sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, int* words);
+int drv_sz_upload(sgp_ctx* ctx, const sgp_ctx* from, int words, hipStream_t s, const sgp::sz_word** d_nz);
+double drv_sz_live_fraction(const sgp_ctx* ctx, int words, long c0, long w, long m_tot, long kt0, long kt1);
 // dst[i] = src[i * stride], i < n
 int drv_copy_strided(const double* src, long stride, long n, double* dst, hipStream_t s);
 // C[r + c * ldc] += a * S[r + c * lds], nr x nc

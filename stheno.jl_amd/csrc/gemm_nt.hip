@@ -432,8 +432,26 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_seg_kernel(SegBatch b) {
   // source cursor: the NEXT chunk to request
   int s = b.dst[d].s_first;
   const int s_end = s + b.dst[d].s_count;
+  // structural zeros: a source all of whose k tiles have a structurally zero operand tile for this tile is skipped (bit q
+  // of `livemask`); a tile without a live source is left alone
+  unsigned livemask = ~0u;
+  if (b.nz) {
+    livemask = 0;
+    const sz_word* ra = b.nz + (c0 / TILE + tr) * b.nz_words;
+    const sz_word* rb = b.nz + (c0 / TILE + tc) * b.nz_words;
+    for (int q = s; q < s_end; ++q) {
+      const long kc = b.src[q].k0 >= 0 ? b.src[q].k0 : b.src[q].row0;
+      const int kt0 = (int)(kc / TILE), kt1 = (int)((kc + b.src[q].w + TILE - 1) / TILE);
+      bool live = false;
+      for (int k = kt0; k < kt1; ++k) live = live || (((ra[k >> 6] & rb[k >> 6]) >> (k & 63)) & 1) != 0;
+      if (live) livemask |= 1u << q;
+    }
+    if (livemask == 0) return;
+    while (!((livemask >> s) & 1)) ++s;
+  }
   long total = 0;
-  for (int q = s; q < s_end; ++q) total += b.src[q].w / KB;
+  for (int q = s; q < s_end; ++q)
+    if ((livemask >> q) & 1) total += b.src[q].w / KB;
   const double *pa = nullptr, *pb = nullptr;
   long ld = 0;
   int left = 0;
@@ -455,7 +473,11 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_seg_kernel(SegBatch b) {
     }
     pa += KB * ld;
     pb += KB * ld;
-    if (--left == 0 && ++s < s_end) open(s);
+    if (--left == 0) {
+      ++s;
+      while (s < s_end && !((livemask >> s) & 1)) ++s;
+      if (s < s_end) open(s);
+    }
   };
   double acc[8][4];
   if (total > 0) {

@@ -135,6 +135,7 @@ struct Rank {
   bool t0_set = false;
   double upd_flops = 0.0, upd_span_ms = 0.0, recv_bytes = 0.0;
   long n_factored = 0;
+  const sz_word* d_sz = nullptr;   // this rank's device copy of the factor's tile pattern (structural zeros), or nullptr
   double* store = nullptr;       // owned panels of a transient factorisation, packed (grow-only)
   size_t store_cap = 0;
   std::vector<double*> buf;      // ring of receive buffers (sgp_multi::ring of them), m_tot x widest panel each
@@ -171,6 +172,8 @@ struct sgp_multi {
   int ring = 10;            // receive buffers per rank: 2 * group + 2
   Rccl rccl;
   double last_ms = 0.0;
+  int sz_words = 0;               // structural zeros: words per pattern row of the current call (0: dense)
+  double sz_frac = 1.0;           // executed / dense tile products of its contractions
   double last_enqueue_ms = 0.0;   // host time the one enqueue thread spent issuing the last sharded factorisation
   long last_npan = 0;
   // profile mode (sgp_ctx_multi_profile): the factorisation runs serialised, every group of launches timed alone
@@ -512,7 +515,7 @@ extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64
   out[6] = m->allgather ? 1 : 0;
   out[7] = (double)m->group;
   for (int i = 0; i < P; ++i) {
-    out[8 + 4 * i] = m->r[i].upd_flops;
+    out[8 + 4 * i] = m->r[i].upd_flops * m->sz_frac;   // (the launches are priced dense; the skipped share comes off here)
     out[9 + 4 * i] = m->r[i].upd_span_ms;
     out[10 + 4 * i] = (double)m->r[i].n_factored;
     out[11 + 4 * i] = m->r[i].recv_bytes;
@@ -770,6 +773,8 @@ int update_panels(sgp_multi* m, const Fact& F, long J_first, long J_last, const 
   }
   SegBatch b;
   b.m_tot = g.m_tot;
+  b.nz = m->sz_words > 0 ? m->r[i].d_sz : nullptr;
+  b.nz_words = m->sz_words;
   long ksum = 0;
   for (int q = 0; q < SEG_MAX_SRC; ++q) b.src[q] = SegSrc{nullptr, 0, 0, 0};
   for (long J = J_first; J <= J_last; ++J) {
@@ -777,6 +782,7 @@ int update_panels(sgp_multi* m, const Fact& F, long J_first, long J_last, const 
     if (sub_c >= 0) {   // columns [sub_c, sub_c + sub_w) of the packed panel: same first stored row, same leading dimension
       b.src[0].base += (size_t)sub_c * g.ldp(J);
       b.src[0].w = (int)sub_w;
+      b.src[0].k0 = g.col0(J) + sub_c;
     }
     ksum += b.src[J - J_first].w;
   }
@@ -849,6 +855,17 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     k.upd_flops = k.upd_span_ms = k.recv_bytes = 0.0;
     k.n_factored = 0;
     M_RC(drv_dspec_create(k.ctx, spec, &ds[i]));
+    // structural zeros (common.h): rank 0's context derives the tile pattern of the factor, every rank keeps a device copy
+    // (uploaded ahead of the assembly on the stream every update waits for)
+    if (i == 0) {
+      m->sz_words = 0;
+      M_RC(drv_sz_pattern(k.ctx, ds[0], noise_kind, g.n_pad, g.m_tot, &m->sz_words));
+      double ex = 0, de = 0;
+      sgp_ctx_factor_work(k.ctx, &ex, &de);
+      m->sz_frac = (m->sz_words > 0 && de > 0) ? ex / de : 1.0;
+    }
+    k.d_sz = nullptr;
+    if (m->sz_words > 0) M_RC(drv_sz_upload(k.ctx, m->r[0].ctx, m->sz_words, k.s_upd, &k.d_sz));
     double* dY = k.d_small + L.y;
     double* dM = k.d_small + L.mean;
     double* dNz = k.d_small + L.noise;
@@ -923,6 +940,9 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
           b.m_tot = g.m_tot;
           for (int t = 0; t < SEG_MAX_SRC; ++t) b.src[t] = SegSrc{nullptr, 0, 0, 0};
           b.src[0] = SegSrc{Pj + (size_t)c * ldp, ldp, J0, (int)wq};
+          b.src[0].k0 = J0 + c;
+          b.nz = m->sz_words > 0 ? k.d_sz : nullptr;
+          b.nz_words = m->sz_words;
           const long r = c + wq;
           b.n_dst = 1;
           b.dst[0] = SegDst{Pj + r + (size_t)r * ldp, ldp, J0 + r, (int)(w - r), 0, 1, 0u};
@@ -1858,6 +1878,14 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+int sgp_multi_factor_work(sgp_multi* m, double* executed, double* dense) {
+  if (!m || m->r.empty()) {
+    *executed = *dense = 0.0;
+    return 0;
+  }
+  return sgp_ctx_factor_work(m->r[0].ctx, executed, dense);   // rank 0's context derived the pattern (factorize)
+}
+
 // elbo(VFE(fz), fx, y): data points sharded, one reduction (reference entry: src/gp/sparse_finite_gp.jl:52-58)
 // ---------------------------------------------------------------------------------------------------------
 namespace {

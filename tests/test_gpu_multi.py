@@ -480,3 +480,42 @@ def test_per_rank_enqueue_threads_give_the_same_bits_as_one_thread(monkeypatch, 
             ctx.close()
         assert all(v == vals[0] for v in vals), (env, vals)
         assert abs(vals[0] - ref) <= 1e-10 * abs(ref)
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_structural_zeros_on_the_sharded_factorisation(monkeypatch, nranks):
+    """Round 4: the sum model's covariance has an exact zero block (f1 and f2 are independent) and so has its factor; the
+    sharded factorisation skips, tile by tile, the source panels whose k tiles are structurally zero for it
+    (gemm_nt.hip: gemm_nt_seg_kernel; the pattern comes from rank 0's context, tests/test_gpu_struct_zeros.py has the
+    single-GPU side).  Same bits with the skipping on and off -- logpdf, kept-factor posterior, draws -- for whole panels,
+    sub-panel pipelining and panel groups; the work counter shows the skipped share."""
+    F, x, xs, y = _problem(3000, D=3)
+    ref = orm.gppp_sum_logpdf(xs, y, 0.1)
+    rng = np.random.default_rng(1)
+    xs_new = P.BlockData([P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((3, 30)))))])
+    Z = np.asfortranarray(rng.standard_normal((3000, 2)))
+
+    def run():
+        fx = F(x, 0.1)
+        post = P.posterior(fx, y)
+        m, v = post.mean_and_var(xs_new)
+        return dict(lp=np.array([P.logpdf(fx, y)]), m=np.asarray(m), v=np.asarray(v), r=np.asarray(P.rand(None, fx, 2, Z=Z)))
+
+    for env in ({"SGP_MULTI_PANEL": "128"}, {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "128"},
+                {"SGP_MULTI_PANEL": "256", "SGP_MULTI_SUBPANEL": "0", "SGP_MULTI_GROUP": "2"}):
+        outs = []
+        for sz in ("0", "1"):
+            for k in ("SGP_MULTI_PANEL", "SGP_MULTI_SUBPANEL", "SGP_MULTI_GROUP"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            monkeypatch.setenv("SGP_STRUCT_ZEROS", sz)
+            ctx = P.lib.Context(devices=[0] * nranks)
+            outs.append(_with_ctx(ctx, run))
+            _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
+            e, d = ctx.factor_work()
+            assert (e < 0.75 * d) if sz == "1" else (e == d), (env, sz, e, d)
+            ctx.close()
+        for k in outs[0]:
+            assert np.array_equal(outs[0][k], outs[1][k]), (env, k)
+        assert abs(outs[0]["lp"][0] - ref) <= 1e-10 * abs(ref)

@@ -1,10 +1,18 @@
-cd $GRAFT_REPO_ROOT
-for c in c3 target; do for z in 0 1; do echo "== $c SGP_STRUCT_ZEROS=$z"; SGP_STRUCT_ZEROS=$z timeout 600 python bench.py --config $c --steps 3 --warmup 1 --cpu-sample 0 --no-extras 2>&1 | python -c "
-import sys, json
-for ln in sys.stdin:
-    ln=ln.strip()
-    if ln.startswith('{'):
-        d=json.loads(ln); print(d['ms_per_step'], d.get('parity_rel'), d.get('logpdf'))
-    elif 'rror' in ln: print(ln[:300])
-"; done; done
-timeout 900 python -m pytest tests/test_gpu_dataflow.py tests/test_gpu_parity.py tests/test_gpu_baseline_golden.py -x -q -m gpu 2>&1 | tail -4
+cd /tmp; export TMPDIR=/tmp
+for z in 1 0; do
+SGP_STRUCT_ZEROS=$z rocprofv3 --kernel-trace --output-format csv -d /tmp/szprof$z -o t -- python $GRAFT_REPO_ROOT/bench.py --config target --steps 1 --warmup 0 --cpu-sample 0 --no-host-api --no-extras > /dev/null 2>&1
+f=$(find /tmp/szprof$z -name "*kernel_trace.csv" | head -1)
+python - "$f" $z <<'PY'
+import csv, sys
+rows=list(csv.DictReader(open(sys.argv[1])))
+big=[r for r in rows if 'gemm_nt_dma_potrf_kernel<1, true>' in r['Kernel_Name']]
+# the last step's 63 launches
+big=big[-63:]
+out=[]
+for r in big:
+    d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6
+    g=int(r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size',0))//512
+    out.append((g,round(d,2)))
+print("SZ",sys.argv[2], "sum", round(sum(d for _,d in out),1)); print(out)
+PY
+done
