@@ -374,7 +374,7 @@ def main():
         # and roofline fractions are quoted on the flops that RAN (work_frac x N^3 / 3); the dense-equivalent rate -- what a
         # dense factorisation would need to deliver for the same step time -- is reported beside them.
         work_frac = 1.0
-        if not use_dist and not inproc and args.dtype == "f64":
+        if not use_dist and args.dtype == "f64":
             ex, de = ctx.factor_work()
             if de > 0:
                 work_frac = ex / de

@@ -2,6 +2,7 @@
 // every numerical result is produced by the HIP kernels in this directory.
 #include "ctx.h"
 #include "driver.h"
+#include "tilemap.h"
 #include "df_order.h"
 
 #include <algorithm>
@@ -282,6 +283,7 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->d_info) hipFree(c->d_info);
   if (c->d_df_state) hipFree(c->d_df_state);
   if (c->d_sz) hipFree(c->d_sz);
+  if (c->d_szmap) hipFree(c->d_szmap);
   if (c->d_df_inv) hipFree(c->d_df_inv);
   if (c->d_df_stats) hipFree(c->d_df_stats);
   if (c->d_df_tasks) hipFree(c->d_df_tasks);
@@ -910,6 +912,8 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // K = 128 work stays that of 1024-wide panels: per-tile prologue / epilogue share and C-tile traffic per flop drop,
   // same flops, bit-identical result.  N = 65536 on one box: W = 1024 1499 ms, 2048 / 1024 1469, 4096 / 1024 1458,
   // 8192 / 1024 1463, 16384 / 1024 1469, 4096 / 512 1465; under the look-ahead (N = 16384, 32768) it loses.
+  // (one stream: the compacted id maps of consecutive structured launches may share one scratch buffer)
+  if (sz_scope.on && !la && s == ctx->stream) gemm_set_structure(A, ld, sz->d_nz, sz->words, ctx->d_szmap, ctx->n_szmap);
   const bool deep = !la && n_pad >= 65536;
   const long WOUT = ctx->wout > 0 ? ctx->wout
                     : n_pad <= 4096 ? n_pad
@@ -1070,6 +1074,18 @@ static int sz_upload(sgp_ctx* ctx, const std::vector<sz_word>& h, int words, hip
     ctx->n_sz = h.size();
   }
   SGP_HIP(hipMemcpyAsync(ctx->d_sz, h.data(), sizeof(sz_word) * h.size(), hipMemcpyHostToDevice, s));
+  {   // room for the id map of the largest lower update this matrix can see
+    const long rows = (long)(h.size() / (size_t)words);
+    const long need = 16 + 8 * tri_ids_per_xcd(tri_shape(rows, std::min<long>(rows, (long)words * 64), -1));
+    if (need > ctx->n_szmap) {
+      SGP_HIP(hipStreamSynchronize(s));
+      if (ctx->d_szmap) hipFree(ctx->d_szmap);
+      ctx->d_szmap = nullptr;
+      ctx->n_szmap = 0;
+      SGP_HIP(hipMalloc(&ctx->d_szmap, sizeof(int) * need));
+      ctx->n_szmap = need;
+    }
+  }
   out->d_nz = ctx->d_sz;
   out->words = words;
   return 0;

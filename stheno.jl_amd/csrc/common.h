@@ -151,9 +151,16 @@ typedef unsigned long long sz_word;
 struct TileSkip {      // per launch of a lower update C -= P P': C's first tile row / column, the k tiles the panel covers
   const sz_word* nz = nullptr;
   int words = 0, tr0 = 0, tc0 = 0, kt0 = 0, kt1 = 0;
+  // big launches: the live tiles of every XCD compacted to the front of its id sequence (tile_compact_kernel): cmap[x] =
+  // live ids of XCD x, cmap[16 + x * cstride + pos] = the pos-th live id / 8 -- the live tiles keep the order, and with it
+  // the lock-step operand sharing, of the dense enumeration
+  const int* cmap = nullptr;
+  int cstride = 0;
 };
-// while set (chol_bordered's scope; per host thread), the lower updates launched on tiles of `base` skip dead tiles
-void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words);
+// while set (chol_bordered's scope; per host thread), the lower updates launched on tiles of `base` skip dead tiles;
+// scratch (optional, only for launches that are ordered on one stream): room for the compacted id maps
+void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch = nullptr,
+                        long scratch_ints = 0);
 // chol_df.hip: the whole bordered factorisation (lower tiles of the n_pad columns + rows n_pad .. m_tot) in one launch of
 // persistent workgroups; d_state: SGP_DF_STATE_WORDS + m_tot / 128 ints, d_invall: n_pad / 128 x 2048 doubles
 constexpr int SGP_DF_TIMEOUT = -77;   // *info when a dependency wait inside the kernel ran into its bound

@@ -99,6 +99,8 @@ struct sgp_ctx {
   sgp::sz_word* d_sz = nullptr;   // device copy of the factor's tile pattern (grow-only)
   size_t n_sz = 0;
   std::vector<sgp::sz_word> h_sz;
+  int* d_szmap = nullptr;         // scratch of the compacted live-tile id maps (gemm_nt.hip: tile_compact_kernel), grow-only
+  long n_szmap = 0;
   double sz_executed = 0, sz_dense = 0;   // k-block products of the last factorisation: run / of the dense schedule
   const double* sz_base = nullptr;        // the matrix the pattern in h_sz belongs to while chol_bordered runs (else nullptr)
   long sz_ld = 0;
@@ -117,10 +119,14 @@ struct sgp_ctx {
       for (long tr = tc; tr < n_tr; ++tr) {
         const sgp::sz_word* ra = &h_sz[(size_t)(t0 + tr) * sz_words];
         const sgp::sz_word* rb = &h_sz[(size_t)(t0 + tc) * sz_words];
-        bool on = false;
-        for (long k = kt0; k < kt1 && !on; ++k) on = ((ra[k >> 6] & rb[k >> 6]) >> (k & 63)) & 1;
-        all += 1;
-        live += on ? 1 : 0;
+        long kmin = -1, kmax = -1;
+        for (long k = kt0; k < kt1; ++k)
+          if (((ra[k >> 6] & rb[k >> 6]) >> (k & 63)) & 1) {
+            if (kmin < 0) kmin = k;
+            kmax = k;
+          }
+        all += (double)(kt1 - kt0);
+        if (kmin >= 0) live += (double)(kmax - kmin + 1);   // the tile contracts first .. last needed k tile
       }
     return all > 0 ? live / all : 1.0;
   }

@@ -107,6 +107,10 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
     // no longer share operand panels, which prices the L2 locality of the production order)
     if (STAMP && scr_mod > 0) {
       if (!tile_of_id(((long)blockIdx.x * (scr_mul < 0 ? -scr_mul : scr_mul)) % scr_mod, n_tr, n_tc, mask_off, tr, tc)) return false;
+    } else if (sk && sk->cmap) {
+      const int x = (int)(blockIdx.x & 7), pos = (int)(blockIdx.x >> 3);
+      if (pos >= sk->cmap[x]) return false;
+      if (!tile_of_id((long)sk->cmap[16 + (long)x * sk->cstride + pos] * 8 + x, n_tr, n_tc, mask_off, tr, tc)) return false;
     } else if (!tile_of_block(n_tr, n_tc, mask_off, tr, tc)) return false;
     // split-K (blockIdx.y > 0 only in launch_gemm_nt_splitk): slice s contracts columns
     // [s K, (s + 1) K) of A and B into its own slab of C
@@ -116,17 +120,27 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
   }
   // structural zeros: the tile's update P[tr] P[tc]' is dead when, for every k tile of the panel, one of the two operand
   // tiles is structurally zero (keep_first: tile (0, 0) of a fused launch goes on to the diagonal-block routine anyway)
-  if (sk && sk->nz && !(keep_first && tr == 0 && tc == 0)) {
+  // It contracts the k tiles from the first to the last needed one only (a panel that straddles a block boundary).
+  if (sk && sk->nz) {
     const sz_word* ra = sk->nz + (long)(sk->tr0 + tr) * sk->words;
     const sz_word* rb = sk->nz + (long)(sk->tc0 + tc) * sk->words;
-    bool live = false;
+    int kmin = -1, kmax = -1;
     for (int q = sk->kt0 >> 6; q <= (sk->kt1 - 1) >> 6; ++q) {
       sz_word m = ra[q] & rb[q];
       if (q == (sk->kt0 >> 6)) m &= ~(sz_word)0 << (sk->kt0 & 63);
       if (q == ((sk->kt1 - 1) >> 6) && (sk->kt1 & 63)) m &= ~(~(sz_word)0 << (sk->kt1 & 63));
-      live = live || m != 0;
+      if (m != 0) {
+        if (kmin < 0) kmin = q * 64 + (int)__builtin_ctzll(m);
+        kmax = q * 64 + 63 - (int)__builtin_clzll(m);
+      }
     }
-    if (!live) return false;
+    if (kmin < 0) {
+      if (!(keep_first && tr == 0 && tc == 0)) return false;
+    } else {
+      A += (long)(kmin - sk->kt0) * TILE * lda;
+      B += (long)(kmin - sk->kt0) * TILE * ldb;
+      K = (long)(kmax - kmin + 1) * TILE;
+    }
   }
   if (STAMP) stA = (long long)__builtin_amdgcn_s_memtime();   // the tile is known
   // stage s: A chunk at smem + s*2*KB*LDS_LD, B chunk right after it
@@ -656,6 +670,8 @@ struct GemmStructure {
   long ld = 0;
   const sz_word* nz = nullptr;
   int words = 0;
+  int* scratch = nullptr;
+  long scratch_ints = 0;
 };
 thread_local GemmStructure g_st;
 // the skip record of the diagonal-aligned lower update C[lower] -= P P' (P's rows = C's rows = C's columns), or an empty one
@@ -674,11 +690,64 @@ TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) 
   return sk;
 }
 }  // namespace
-void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words) {
+void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch, long scratch_ints) {
   g_st.base = base;
   g_st.ld = ld;
   g_st.nz = d_nz;
   g_st.words = words;
+  g_st.scratch = scratch;
+  g_st.scratch_ints = scratch_ints;
+}
+
+// One workgroup per XCD walks that XCD's ids of a lower update in order and writes the live ones (some k tile of the panel
+// has both operand tiles structurally non-zero; `keep_first`: tile (0, 0), which a fused launch factors) to the front.
+__global__ __launch_bounds__(1024) void tile_compact_kernel(TileSkip sk, long n_tr, long n_tc, int per_xcd, int* out,
+                                                            int keep_first) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int x = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) s_base = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < per_xcd; k0 += 1024) {
+    const int k = k0 + t;
+    bool live = false;
+    long tr, tc;
+    if (k < per_xcd && tile_of_id((long)k * 8 + x, n_tr, n_tc, 0L, tr, tc)) {
+      const sz_word* ra = sk.nz + (long)(sk.tr0 + tr) * sk.words;
+      const sz_word* rb = sk.nz + (long)(sk.tc0 + tc) * sk.words;
+      for (int q = sk.kt0 >> 6; q <= (sk.kt1 - 1) >> 6; ++q) {
+        sz_word m = ra[q] & rb[q];
+        if (q == (sk.kt0 >> 6)) m &= ~(sz_word)0 << (sk.kt0 & 63);
+        if (q == ((sk.kt1 - 1) >> 6) && (sk.kt1 & 63)) m &= ~(~(sz_word)0 << (sk.kt1 & 63));
+        live = live || m != 0;
+      }
+      live = live || (keep_first && tr == 0 && tc == 0);
+    }
+    const unsigned long long bal = __ballot(live);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int q = 0; q < 16; ++q) {
+      if (q < w) woff += s_wave[q];
+      tot += s_wave[q];
+    }
+    const int base = s_base;
+    if (live) out[16 + (long)x * per_xcd + base + woff + pre] = k;
+    __syncthreads();
+    if (t == 0) s_base = base + tot;
+    __syncthreads();
+  }
+  if (t == 0) out[x] = s_base;
+}
+// big structured launches on an ordered stream: build the compacted id map first (the update kernel reads it)
+static int maybe_compact(TileSkip& sk, long n_tr, long n_tc, long per_xcd, int keep_first, hipStream_t s) {
+  if (!sk.nz || !g_st.scratch || per_xcd * 8 < 4096 || 16 + per_xcd * 8 > g_st.scratch_ints) return 0;
+  hipLaunchKernelGGL(tile_compact_kernel, dim3(8), dim3(1024), 0, s, sk, n_tr, n_tc, (int)per_xcd, g_st.scratch, keep_first);
+  SGP_HIP(hipGetLastError());
+  sk.cmap = g_st.scratch;
+  sk.cstride = (int)per_xcd;
+  return 0;
 }
 
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc,
@@ -717,8 +786,10 @@ int launch_gemm_nt_update(const double* P, long ldp, double* C, long ldc, long M
   }
   long n_tr = M / TILE, n_tc = Nc / TILE;
   long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1));
+  TileSkip sk = skip_for(P, ldp, C, ldc, K);
+  if (int rc = maybe_compact(sk, n_tr, n_tc, per_xcd, 0, s)) return rc;
   hipLaunchKernelGGL(gemm_nt_dma_kernel<1>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, P, ldp, C, ldc, K,
-                     -1.0, 1.0, 0L, n_tr, n_tc, 0L, (const double*)C, ldc, 0, skip_for(P, ldp, C, ldc, K));
+                     -1.0, 1.0, 0L, n_tr, n_tc, 0L, (const double*)C, ldc, 0, sk);
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -731,8 +802,10 @@ static int launch_potrf_variant(unsigned grid, const double* P, long ldp, double
                                 long n_tc, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
                                 hipStream_t s) {
   SGP_LDS_ATTR_ONCE((gemm_nt_dma_potrf_kernel<TAG, HANDOFF>), PD_LDS);
+  TileSkip sk = skip_for(P, ldp, C, ldc, K);
+  if (int rc = maybe_compact(sk, n_tr, n_tc, (long)grid / 8, 1, s)) return rc;
   hipLaunchKernelGGL((gemm_nt_dma_potrf_kernel<TAG, HANDOFF>), dim3(grid), dim3(512), PD_LDS, s, P, ldp, P, ldp, C, ldc,
-                     K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, panel_prio(), skip_for(P, ldp, C, ldc, K));
+                     K, n_tr, n_tc, d_invd, d_logdet_slot, d_info, gcol0, panel_prio(), sk);
   SGP_HIP(hipGetLastError());
   return 0;
 }

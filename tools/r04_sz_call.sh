@@ -1,18 +1,10 @@
-cd /tmp; export TMPDIR=/tmp
-for z in 1 0; do
-SGP_STRUCT_ZEROS=$z rocprofv3 --kernel-trace --output-format csv -d /tmp/szprof$z -o t -- python $GRAFT_REPO_ROOT/bench.py --config target --steps 1 --warmup 0 --cpu-sample 0 --no-host-api --no-extras > /dev/null 2>&1
-f=$(find /tmp/szprof$z -name "*kernel_trace.csv" | head -1)
-python - "$f" $z <<'PY'
-import csv, sys
-rows=list(csv.DictReader(open(sys.argv[1])))
-big=[r for r in rows if 'gemm_nt_dma_potrf_kernel<1, true>' in r['Kernel_Name']]
-# the last step's 63 launches
-big=big[-63:]
-out=[]
-for r in big:
-    d=(int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e6
-    g=int(r['Grid_Size_X'] if 'Grid_Size_X' in r else r.get('Grid_Size',0))//512
-    out.append((g,round(d,2)))
-print("SZ",sys.argv[2], "sum", round(sum(d for _,d in out),1)); print(out)
-PY
-done
+cd $GRAFT_REPO_ROOT
+timeout 900 python -m pytest tests/test_gpu_struct_zeros.py tests/test_gpu_fused_potrf.py -x -q -m gpu 2>&1 | tail -3
+for c in target; do for z in 1; do SGP_STRUCT_ZEROS=$z timeout 600 python bench.py --config $c --steps 3 --warmup 1 --cpu-sample 0 --no-extras 2>/dev/null | python -c "
+import sys, json
+for ln in sys.stdin:
+    ln=ln.strip()
+    if ln.startswith('{'):
+        d=json.loads(ln); r=d['roofline']; print('$c', d['ms_per_step'], d.get('parity_rel'), 'roofline', r['frac'], r['avg_launch_ms'])
+"; done; done
+SGP_DATAFLOW=0 python tools/gpu_df_variants.py 32768 dense:SGP_STRUCT_ZEROS=0 2>&1 | grep best | cut -c1-60
