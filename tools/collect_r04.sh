@@ -16,7 +16,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 python $R/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 for c in c1 n4k c2; do timeout 300 python $R/bench.py --config $c --steps 30 --warmup 3 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; done
 for c in c3 n32k c4 target; do timeout 500 python $R/bench.py --config $c --steps 3 --warmup 1 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; done
+# the structured models under the dense schedule (A/B of the structural-zero skipping: same bits)
+for c in c3 target; do SGP_STRUCT_ZEROS=0 timeout 500 python $R/bench.py --config $c --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_${c}_dense.json 2> $OUT/bench_${c}_dense.err; done
 timeout 400 python $R/bench.py --config c5 --dtype f32 --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_f32.json 2> $OUT/bench_c5_f32.err
+timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config target --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_target_multi8_loopback.json 2> $OUT/bench_target_multi8_loopback.err
 timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config c5 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_multi8_loopback.json 2> $OUT/bench_c5_multi8_loopback.err
 SGP_MULTI_SUBPANEL=0 timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config c5 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_multi8_loopback_sub0.json 2> $OUT/bench_c5_multi8_loopback_sub0.err
 timeout 300 python $R/bench.py --gpus 2 --devices 0,0 --config c4 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c4_multi2_loopback.json 2> $OUT/bench_c4_multi2_loopback.err
@@ -29,6 +32,8 @@ for v in "default X=1" "sub0 SGP_MULTI_SUBPANEL=0"; do
 done
 timeout 600 python $R/tools/gpu_multi_profile.py target 8 $OUT/multi_profile_target_P8_default.json > $OUT/multi_profile_target_P8_default.log 2>&1
 python $R/tools/multi_projection.py $OUT/multi_profile_target_P8_default.json > $OUT/projection_target_P8_default.txt 2>&1
+SGP_STRUCT_ZEROS=0 timeout 600 python $R/tools/gpu_multi_profile.py target 8 $OUT/multi_profile_target_P8_dense.json > $OUT/multi_profile_target_P8_dense.log 2>&1
+python $R/tools/multi_projection.py $OUT/multi_profile_target_P8_dense.json > $OUT/projection_target_P8_dense.txt 2>&1
 for P in 2 4; do
   timeout 600 python $R/tools/gpu_multi_profile.py c5 $P $OUT/multi_profile_c5_P${P}_default.json > $OUT/multi_profile_c5_P${P}_default.log 2>&1
   python $R/tools/multi_projection.py $OUT/multi_profile_c5_P${P}_default.json > $OUT/projection_c5_P${P}_default.txt 2>&1

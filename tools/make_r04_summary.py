@@ -34,7 +34,7 @@ DOMINANT = {   # config -> substring of the dominant kernel's name
     "n32k": "chol_dataflow", "c4": "gemm_nt_dma_kernel<0>",
 }
 lines, traffic = {}, {}
-for c in ("default", "c1", "n4k", "c2", "c3", "n32k", "c4", "target", "c5_f32", "c5_multi8_loopback", "c5_multi8_loopback_sub0",
+for c in ("default", "c1", "n4k", "c2", "c3", "n32k", "c4", "target", "c3_dense", "target_dense", "target_multi8_loopback", "c5_f32", "c5_multi8_loopback", "c5_multi8_loopback_sub0",
           "c4_multi2_loopback", "c5_dist1"):
     d = jload(f"bench_{c}.json")
     if d:
@@ -103,6 +103,9 @@ def row(name, d, key):
     tr = traffic.get(key)
     trs = "--" if not tr else f"{tr['hbm_bytes'] / 1e9:.1f} GB per {tr['per']} = {tr['ratio_to_algorithmic']:.1f} x"
     fr = d.get("cholesky_frac_of_fp64_matrix_peak")
+    wf = d.get("executed_work_fraction")
+    if wf is not None and wf < 0.999:   # structural zeros: the fractions are on the flops that ran
+        name = f"{name} [structural zeros: {wf:.3f} of the dense tile products ran; dense-equivalent {d.get('dense_equivalent_tflops', 0):.1f} TFLOP/s]"
     return (f"| {name} | {d['ms_per_step']:.2f} | {fr:.3f} | {rf.get('frac', float('nan')):.3f} ({str(rf.get('kernel', ''))[:60]}...) | {trs} | "
             f"{d['parity_rel']:.1e} |" if fr is not None else
             f"| {name} | {d['ms_per_step']:.2f} | -- | {rf.get('frac', float('nan')):.3f} | {trs} | {d['parity_rel']:.1e} |")
@@ -113,15 +116,19 @@ if "default" in lines:
     L.append(row("c5 (the default line)", d, "c5"))
     ns = d.get("north_star_target")
     if ns:
+        if ns.get("executed_work_fraction", 1.0) < 0.999:
+            L.append(f"| ... (next row: structural zeros, {ns['executed_work_fraction']:.3f} of the dense tile products ran; the fraction is on those; "
+                     f"dense-equivalent {ns.get('dense_equivalent_tflops', 0):.1f} TFLOP/s) | | | | | |")
         L.append(f"| ... its `north_star_target` extra (3-process @gppp, N = 65536, host-buffer entry point) | {ns['ms_per_step']:.2f} | "
                  f"{ns['frac']:.3f} | | | {ns['parity_rel']:.1e} |")
     for k, v in (d.get("sizes") or {}).items():
         L.append(f"| ... its `sizes.{k}` extra | {v['ms_per_step']:.3f} | {v['frac']:.3f} | ({v['schedule']}) | | {v['parity_rel']:.1e} |")
-for c in ("target", "c3", "n32k", "c2", "n4k", "c1", "c4", "c5_f32"):
+for c in ("target", "target_dense", "c3", "c3_dense", "n32k", "c2", "n4k", "c1", "c4", "c5_f32"):
     if c in lines:
-        L.append(row(c, lines[c], c))
+        L.append(row(c + (" (SGP_STRUCT_ZEROS=0: the dense schedule, same bits)" if c.endswith("_dense") else ""), lines[c],
+                     c.replace("_dense", "") if not c.endswith("_dense") else "none"))
 L.append("")
-for c in ("c5_multi8_loopback", "c5_multi8_loopback_sub0", "c4_multi2_loopback", "c5_dist1"):
+for c in ("c5_multi8_loopback", "c5_multi8_loopback_sub0", "target_multi8_loopback", "c4_multi2_loopback", "c5_dist1"):
     if c in lines:
         d = lines[c]
         mg = d.get("multi_gpu") or {}
