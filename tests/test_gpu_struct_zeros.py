@@ -121,3 +121,55 @@ def test_fill_in_and_ragged_blocks_against_the_oracle(monkeypatch, order):
     for name, o in outs.items():
         for k in ref:
             assert np.array_equal(ref[k], o[k]), (order, name, k)
+
+
+def _symbolic_work(K, n_border_tiles=1, tile=128):
+    """Independent statement of the pattern: tile-level non-zeros of the DENSE covariance the oracle computed (exact zeros
+    included), symbolic factorisation with fill-in, and the tile products of the contractions -- executed and dense."""
+    N = K.shape[0]
+    T = -(-N // tile)
+    Tr = T + n_border_tiles
+    nz = np.zeros((Tr, T), bool)
+    for i in range(T):
+        for k in range(i + 1):
+            nz[i, k] = i == k or bool(np.any(K[i * tile:(i + 1) * tile, k * tile:(k + 1) * tile] != 0.0))
+    nz[T:, :] = True
+    executed = dense = 0
+    for j in range(T):
+        for i in range(j, Tr):
+            shared = int(np.count_nonzero(nz[i, :j] & nz[j, :j]))
+            if shared:
+                nz[i, j] = True
+            if nz[i, j]:
+                executed += shared
+            dense += j
+    return executed, dense
+
+
+@pytest.mark.parametrize("order", [("a", "b", "ab", "c", "ca"), ("c", "b", "a", "ca", "ab"), ("b", "c", "a", "ab", "ca")])
+def test_the_pattern_is_the_one_the_dense_covariance_implies(monkeypatch, order):
+    """The library derives the pattern from the spec's block-pair table; here it is derived from the exact zeros of the
+    covariance matrix the ORACLE computed, tile by tile, with its own symbolic factorisation: the work counters must agree
+    exactly (ragged block boundaries, fill-in, the bordered row)."""
+    import models
+    rng = np.random.default_rng(5)
+    sizes = dict(a=301, b=517, ab=260, c=433, ca=389)
+
+    def build(api):
+        gpc = api.GPC()
+        a = api.atomic(api.GP(api.SEKernel()), gpc)
+        b = api.atomic(api.GP(api.Matern52Kernel()), gpc)
+        c = api.atomic(api.GP(api.Matern32Kernel()), gpc)
+        return api.GPPP({"a": a, "b": b, "c": c, "ab": a + b, "ca": c + 2.0 * a}, gpc)
+
+    Fo, Fp = build(models.oracle_api()), build(models.product_api())
+    pts = {k: rng.standard_normal(sizes[k]) for k in order}
+    Ko = Fo.cov(ost.BlockData([ost.GPPPInput(k, pts[k]) for k in order]))
+    want = _symbolic_work(Ko)
+    xp = P.BlockData([P.GPPPInput(k, pts[k]) for k in order])
+    y = rng.standard_normal(sum(sizes.values()))
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=1)
+    got = _work(ctx, lambda: P.logpdf(Fp(xp, 0.3), y))
+    ctx.close()
+    assert got == want, (order, got, want)
+    assert want[0] < want[1]
