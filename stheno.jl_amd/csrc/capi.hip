@@ -3,6 +3,7 @@
 #include "ctx.h"
 #include "driver.h"
 #include "tilemap.h"
+#include "sz_pattern.h"
 #include "df_order.h"
 
 #include <algorithm>
@@ -1003,61 +1004,12 @@ static int sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_
       if (!has && ds->row_len[I] > 0 && ds->row_len[J] > 0) any_zero = true;
     }
   if (!any_zero) return 0;
-  // blocks a tile overlaps: [blo, bhi]
-  std::vector<int> blo(T_c, 0), bhi(T_c, -1);
-  for (long t = 0; t < T_c; ++t) {
-    const long p0 = t * TILE, p1 = std::min<long>(p0 + TILE, ds->N);
-    int lo = nb, hi = -1;
-    for (int I = 0; I < nb; ++I) {
-      if (ds->row_len[I] <= 0) continue;
-      if (ds->row_off[I] < p1 && ds->row_off[I] + ds->row_len[I] > p0) {
-        lo = std::min(lo, I);
-        hi = std::max(hi, I);
-      }
-    }
-    blo[t] = lo;
-    bhi[t] = hi;
-  }
-  const int W = (int)((T_c + 63) / 64);
-  std::vector<sz_word>& nz = ctx->h_sz;
-  nz.assign((size_t)T_r * W, 0);
-  auto setbit = [&](long i, long k) { nz[(size_t)i * W + (k >> 6)] |= (sz_word)1 << (k & 63); };
-  auto getbit = [&](long i, long k) { return (nz[(size_t)i * W + (k >> 6)] >> (k & 63)) & 1; };
-  for (long i = 0; i < T_c; ++i) {
-    setbit(i, i);
-    for (long k = 0; k < i; ++k) {
-      bool on = false;
-      for (int I = blo[i]; I <= bhi[i] && !on; ++I)
-        for (int J = blo[k]; J <= bhi[k] && !on; ++J) on = bnz[(size_t)I * nb + J] != 0;
-      if (on) setbit(i, k);
-    }
-  }
-  for (long i = T_c; i < T_r; ++i)
-    for (long k = 0; k < T_c; ++k) setbit(i, k);
-  // fill-in, and the work of the contractions
-  double executed = 0;
-  bool zeros_left = false;
-  for (long j = 0; j < T_c; ++j) {
-    const sz_word* rj = &nz[(size_t)j * W];
-    for (long i = j; i < T_r; ++i) {
-      sz_word* ri = &nz[(size_t)i * W];
-      long shared = 0;
-      for (int q = 0; q <= (int)((j ? j - 1 : 0) >> 6) && j > 0; ++q) {
-        sz_word m = ri[q] & rj[q];
-        if (q == (int)((j - 1) >> 6) && (j & 63)) m &= ~(~(sz_word)0 << (j & 63));
-        shared += __builtin_popcountll(m);
-      }
-      if (shared > 0 && !getbit(i, j)) setbit(i, j);
-      if (getbit(i, j)) executed += (double)shared;
-      else zeros_left = true;
-    }
-  }
-  ctx->sz_executed = executed;
-  if (!zeros_left) {
-    ctx->sz_executed = dense;
-    return 0;
-  }
-  *words = W;
+  SzPattern pat;   // sz_pattern.h: host-only, checked on the CPU by tests/sz_pattern_host.cpp
+  sz_symbolic(bnz, nb, ds->row_off, ds->row_len, ds->N, TILE, T_c, T_r, pat);
+  ctx->sz_executed = pat.zeros_left ? pat.executed : dense;
+  if (!pat.zeros_left) return 0;
+  ctx->h_sz.swap(pat.nz);
+  *words = pat.words;
   return 0;
 }
 
