@@ -1,0 +1,73 @@
+"""Block orders that keep the Cholesky factor of a programme's covariance sparse.
+
+The factorisation skips the tile products that independent components make exactly zero (DESIGN.md section 3.3c,
+include/sthenomi.h: sgp_ctx_factor_work) -- but WHICH tiles of the factor are zero depends on the order of the blocks in the
+caller's BlockData, exactly as for a sparse direct solver: f3 = f1 + f2 observed in the order (f1, f2, f3) keeps the (f2, f1)
+block of the factor zero, the order (f3, f1, f2) fills it in.  The library never permutes (the factor's layout is part of
+what `posterior` keeps and what `rand` multiplies a draw with); this module tells the caller a good order and applies it:
+logpdf, posterior moments and the ELBO do not depend on the order of the observations beyond rounding.
+
+    perm = fill_reducing_order(f, x)                      # a permutation of the blocks of x
+    x2, (y2, noise2) = permute_blocks(x, perm, y, noise)  # the same observations, reordered
+    logpdf(f(x2, noise2), y2)
+
+No reference analogue: Stheno builds the dense matrix and LAPACK factors it whatever the order."""
+import numpy as np
+
+from . import flatten as _fl
+from .inputs import BlockData, blocks
+
+
+def block_atoms(f, x):
+    """Per block of x: the set of independent atoms (identity keys of the flattener's paths) its process depends on.  Two
+    blocks have a non-zero covariance block exactly when their sets intersect."""
+    mat = _fl._MatCache()
+    return [frozenset(p.key for p in _fl._merge_paths(_fl._paths(n, v, 1.0, None, (), mat))) for n, v in _fl.block_list(f, x)]
+
+
+def fill_reducing_order(f, x):
+    """A permutation of the blocks of x under which symbolic elimination of the block graph creates the least fill, weighted
+    by block sizes (greedy minimum fill; ties: the smaller block first, then the caller's order).  Blocks are the units
+    block_list(f, x) yields -- for a GPPP indexed by a BlockData of GPPPInputs, the GPPPInputs."""
+    atoms = block_atoms(f, x)
+    sizes = [len(v) for _, v in _fl.block_list(f, x)]
+    n = len(atoms)
+    adj = [set(j for j in range(n) if j != i and atoms[i] & atoms[j]) for i in range(n)]
+    left, order = set(range(n)), []
+    while left:
+        best, best_key = None, None
+        for v in sorted(left):
+            nb = sorted(adj[v] & left)
+            fill = sum(sizes[a] * sizes[b] for ia, a in enumerate(nb) for b in nb[ia + 1:] if b not in adj[a])
+            key = (fill, sizes[v], v)
+            if best_key is None or key < best_key:
+                best, best_key = v, key
+        nb = sorted(adj[best] & left)
+        for ia, a in enumerate(nb):          # eliminating `best` couples its remaining neighbours
+            for b in nb[ia + 1:]:
+                adj[a].add(b)
+                adj[b].add(a)
+        left.remove(best)
+        order.append(best)
+    return order
+
+
+def permute_blocks(x, perm, *vectors):
+    """x with its blocks in the order `perm`, and every vector of per-observation values (observations y, a diagonal of
+    noise variances; scalars and None pass through; an N x S matrix is permuted by rows) reordered with it."""
+    bl = blocks(x) if isinstance(x, BlockData) else None
+    if bl is None or sorted(perm) != list(range(len(bl))):
+        raise ValueError("permute_blocks: x must be a BlockData and perm a permutation of its blocks")
+    lens = [len(b) for b in bl]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    idx = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in perm]) if perm else np.zeros(0, dtype=int)
+    out = []
+    for v in vectors:
+        if v is None or np.ndim(v) == 0:
+            out.append(v)
+            continue
+        a = np.asarray(v)
+        if a.shape[0] != offs[-1]:
+            raise ValueError("permute_blocks: a vector's length is not the number of observations")
+        out.append(a[idx] if a.ndim == 1 else np.asfortranarray(a[idx, :]))
+    return BlockData([bl[i] for i in perm]), tuple(out)

@@ -173,3 +173,32 @@ def test_the_pattern_is_the_one_the_dense_covariance_implies(monkeypatch, order)
     ctx.close()
     assert got == want, (order, got, want)
     assert want[0] < want[1]
+
+
+def test_reordering_the_blocks_restores_the_skipping(monkeypatch):
+    """stheno.jl_amd/ordering.py: observed in the order (f3, f1, f2) the sum model's factor fills in completely; the order
+    fill_reducing_order suggests skips 0.4 of the tile products again, and logpdf / posterior moments agree with the
+    caller's order to rounding (they do not depend on the order of the observations)."""
+    rng = np.random.default_rng(8)
+    n = 1280
+    xs = {k: P.ColVecs(np.asfortranarray(rng.standard_normal((2, n)))) for k in ("f1", "f2", "f3")}
+    F = P.gppp_sum_model()
+    x = P.BlockData([P.GPPPInput(k, xs[k]) for k in ("f3", "f1", "f2")])
+    y = rng.standard_normal(3 * n)
+    noise = 0.2 + 0.1 * rng.random(3 * n)
+    perm = P.fill_reducing_order(F, x)
+    x2, (y2, noise2) = P.permute_blocks(x, perm, y, noise)
+    t = P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((2, 20)))))
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=1)
+    lp = _with_ctx(ctx, lambda: P.logpdf(F(x, noise), y))
+    e, d = ctx.factor_work()
+    assert e == d
+    lp2 = _with_ctx(ctx, lambda: P.logpdf(F(x2, noise2), y2))
+    e2, d2 = ctx.factor_work()
+    assert d2 == d and e2 < 0.62 * d2, (e2, d2)
+    assert abs(lp - lp2) <= 1e-11 * abs(lp)
+    m, v = _with_ctx(ctx, lambda: P.posterior(F(x, noise), y).mean_and_var(t))
+    m2, v2 = _with_ctx(ctx, lambda: P.posterior(F(x2, noise2), y2).mean_and_var(t))
+    np.testing.assert_allclose(m, m2, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(v, v2, rtol=1e-9, atol=1e-11)
+    ctx.close()
