@@ -562,6 +562,10 @@ class FakeContext:
     def __init__(self):
         self.lib, self.handle, self.device = FakeLib(), None, 0
 
+    def factor_work(self):
+        """(executed, dense) tile products of the last factorisation: the double factors densely (nothing is skipped)."""
+        return 0.0, 0.0
+
 
 def install(monkeypatch):
     """Route the host mirror's calls through the NumPy double for the duration of one test."""
