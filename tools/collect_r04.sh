@@ -5,9 +5,15 @@
 # algorithmic bytes).  --kernel-trace / --stats and --pmc are separate runs.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r04final
-rm -rf $OUT; mkdir -p $OUT
 cd $R
-SHA=$(sha1sum stheno.jl_amd/csrc/libsthenomi.so | cut -d' ' -f1); echo $SHA > $OUT/lib_sha1.txt
+SHA=$(sha1sum stheno.jl_amd/csrc/libsthenomi.so | cut -d' ' -f1)
+if [ -n "$COLLECT_ONLY_PMC" ]; then
+  # add counter passes (PMC_CONFIGS) to an EXISTING collection of the same build; everything else is skipped
+  mkdir -p $OUT
+  cd /tmp && export TMPDIR=/tmp
+else
+rm -rf $OUT; mkdir -p $OUT
+echo $SHA > $OUT/lib_sha1.txt
 timeout 2400 python -m pytest tests -m gpu -q -p no:cacheprovider > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
 grep -E "passed|failed|rc=" $OUT/pytest_gpu.log | tail -2
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
@@ -49,8 +55,9 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c5
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c4 -o c4 -- \
     python $R/bench.py --config c4 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/prof_c4_bench.json 2> $OUT/prof_c4.err
 rm -f $OUT/*/*/*kernel_trace.csv $OUT/*/*kernel_trace.csv
+fi
 # ---- HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the dominant kernel of every line
-for c in c5 n4k c2 c3 n32k c4; do
+for c in ${PMC_CONFIGS:-c5 target n4k c2 c3 n32k c4}; do
   for cnt in FETCH_SIZE WRITE_SIZE; do
     timeout 500 rocprofv3 --pmc $cnt --output-format csv -d $OUT/pmc_${c}_$cnt -o p -- \
         python $R/bench.py --config $c --steps 1 --warmup 0 --cpu-sample 0 --no-host-api --no-extras > $OUT/pmc_${c}_$cnt.bench.json 2> $OUT/pmc_${c}_$cnt.err
@@ -70,6 +77,7 @@ PY
     rm -rf $OUT/pmc_${c}_$cnt
   done
 done
+if [ -z "$COLLECT_ONLY_PMC" ]; then
 # ---- MFMA pipe / clock of the c5 update kernel and the dataflow kernel (c3)
 for c in c5 c3; do
   timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${c}_MFMA -o p -- \
@@ -95,3 +103,4 @@ except Exception as e:
 PY
 done
 ls $OUT | wc -l; head -c 400 $OUT/bench_default.json; echo
+fi
