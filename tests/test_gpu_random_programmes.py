@@ -89,3 +89,40 @@ def test_random_programme_logpdf_posterior_and_gradient_on_the_device(seed):
     assert abs(lhs - rhs) <= 1e-7 * max(1.0, abs(rhs)), (lhs, rhs)
     np.testing.assert_allclose(g["y"], -alpha, rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(g["noise"], np.diag(Gm), rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("seed", list(range(540, 552)) + list(range(640, 644)))
+def test_random_programme_structural_zeros_change_no_bit(seed, monkeypatch):
+    """Random programmes have random independence structure (atoms that never meet, sums that couple some of them): the
+    factorisation's structural-zero skipping must not change a bit of logpdf, of the posterior moments or of a
+    draw against the dense schedule, on the launch-based and on the dataflow schedule -- whatever the fill-in pattern the
+    random block order produces."""
+    from test_gpu_fused_potrf import _ctx, _with_ctx
+    D = 1 if seed < 600 else 2 + seed % 2
+    names, Fo, Fp = _programme(seed, D)
+    rng = np.random.default_rng(70_000 + seed)
+    xo, xp, xs = _inputs(rng, names, D, 100, 400)         # 5 .. 15 processes of 100 .. 400 points: block boundaries inside tiles
+    N = sum(x.shape[-1] for x in xs)
+    y = rng.standard_normal(N)
+    noise = 0.3 + rng.random(N)
+    Z = np.asfortranarray(rng.standard_normal((N, 2)))
+    t = rng.standard_normal(30) if D == 1 else np.asfortranarray(rng.standard_normal((D, 30)))
+    tp = P.GPPPInput(names[-1], t if D == 1 else P.ColVecs(t))
+
+    def run():
+        fx = Fp(xp, noise)
+        m, v = P.posterior(fx, y).mean_and_var(tp)
+        return dict(lp=np.array([P.logpdf(fx, y)]), m=np.asarray(m), v=np.asarray(v), r=np.asarray(P.rand(None, fx, 2, Z=Z)))
+
+    ref = None
+    for env in (dict(SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=0), dict(SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=1),
+                dict(SGP_DATAFLOW=1, SGP_DF_FAT_MAX_N=0, SGP_STRUCT_ZEROS=1), dict(SGP_DATAFLOW=1, SGP_DF_FAT_MAX_N=1 << 30, SGP_STRUCT_ZEROS=1)):
+        ctx = _ctx(monkeypatch, 11, **env)
+        out = _with_ctx(ctx, run)
+        ctx.close()
+        if ref is None:
+            ref = out
+        for k in ref:
+            assert np.array_equal(ref[k], out[k]), (seed, env, k)
+    lo = oagp.logpdf(Fo(xo, noise), y)
+    assert abs(ref["lp"][0] - lo) <= 1e-9 * max(1.0, abs(lo))

@@ -16,6 +16,7 @@ def _numpy_double_and_direct_distances(monkeypatch):
     monkeypatch.setattr(okf, "pairwise_sqeuclidean", lambda X, Y=None, faithful=True: orig(X, Y, False))
 
 
-for _n in [n for n in dir(T) if n.startswith("test_")]:
+# (test_random_programme_structural_zeros_change_no_bit compares schedules of the real library: device only)
+for _n in [n for n in dir(T) if n.startswith("test_") and "structural_zeros" not in n]:
     globals()[_n] = getattr(T, _n)
 del _n
