@@ -513,7 +513,7 @@ def main():
     # host-buffer entry point the Julia `ccall` binds, on the same context, AFTER the timed region of the headline.
     north_star = sizes = None
     if (args.config == "c5" and not args.no_extras and not use_dist and not inproc and args.dtype == "f64" and rank == 0):
-        def time_config(name, steps, warmup):
+        def time_config(name, steps, warmup, ctx=ctx):
             kd, Nn, Dd = bc.CONFIGS[name]
             ww = bc.build(pkg, name)
             sp = pkg.build_spec(ww["f"], ww["x"])[0]
@@ -539,6 +539,26 @@ def main():
                     "schedule": ctx.factor_schedule(Nn), "logpdf": float(oo[0]),
                     "parity_rel": None if gg is None else abs(float(oo[0]) - gg["logpdf"]) / abs(gg["logpdf"])}
         north_star = time_config("target", 3, 1)
+        # ... and under the DENSE schedule (SGP_STRUCT_ZEROS=0 is read when a context is created): the same model with every
+        # structurally zero tile product multiplied out, as the reference's LAPACK path does -- same bits, the time the
+        # skipping saves.  (A second context on the same device; released before the size sweep.)
+        if north_star.get("executed_work_fraction", 1.0) < 0.999:
+            prev_env = os.environ.get("SGP_STRUCT_ZEROS")
+            os.environ["SGP_STRUCT_ZEROS"] = "0"
+            try:
+                dense_ctx = L.Context(ctx.device if hasattr(ctx, "device") else 0)
+                try:
+                    dn = time_config("target", 2, 1, dense_ctx)
+                finally:
+                    dense_ctx.close()
+            finally:
+                if prev_env is None:
+                    os.environ.pop("SGP_STRUCT_ZEROS", None)
+                else:
+                    os.environ["SGP_STRUCT_ZEROS"] = prev_env
+            north_star["dense_schedule"] = {"ms_per_step": dn["ms_per_step"], "frac": dn["frac"], "logpdf": dn["logpdf"],
+                                            "same_bits": dn["logpdf"] == north_star["logpdf"], "steps": dn["steps"],
+                                            "how": "SGP_STRUCT_ZEROS=0 on a second context"}
         sizes = {"n4k": time_config("n4k", 30, 3), "c2": time_config("c2", 10, 2)}
 
     if rank == 0:
