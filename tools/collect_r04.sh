@@ -45,7 +45,7 @@ for P in 2 4; do
   python $R/tools/multi_projection.py $OUT/multi_profile_c5_P${P}_default.json > $OUT/projection_c5_P${P}_default.txt 2>&1
 done
 # ---- kernel traces (rocprofv3 --kernel-trace --stats of the same commands)
-for c in c5 c3 c2 n4k c1; do
+for c in c5 target c3 c2 n4k c1; do
   st=3; [ $c = c1 ] && st=10
   timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$c -o $c -- \
       python $R/bench.py --config $c --steps $st --warmup 1 --cpu-sample 0 --no-host-api --no-extras > $OUT/prof_${c}_bench.json 2> $OUT/prof_$c.err

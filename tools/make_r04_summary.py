@@ -84,7 +84,7 @@ for c in ("c5", "c3"):
                   open(os.path.join(DST, f"{TAG}_mfma_{c}.json"), "w"), indent=1)
 for c, d in lines.items():
     json.dump(d, open(os.path.join(DST, f"{TAG}_bench_{c}.json"), "w"), indent=1)
-for c in ("c5", "c3", "c2", "n4k", "c1", "c4", "c5_f32"):
+for c in ("c5", "target", "c3", "c2", "n4k", "c1", "c4", "c5_f32"):
     st = glob.glob(os.path.join(SRC, f"prof_{c}", "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], os.path.join(DST, f"{TAG}_bench_{c}_kernel_stats.csv"))
