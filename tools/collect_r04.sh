@@ -79,7 +79,7 @@ PY
 done
 if [ -z "$COLLECT_ONLY_PMC" ]; then
 # ---- MFMA pipe / clock of the c5 update kernel and the dataflow kernel (c3)
-for c in c5 c3; do
+for c in ${MFMA_CONFIGS:-c5 target c3}; do
   timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_${c}_MFMA -o p -- \
       python $R/bench.py --config $c --steps 1 --warmup 0 --cpu-sample 0 --no-host-api --no-extras > /dev/null 2> $OUT/pmc_${c}_MFMA.err
   f=$(find $OUT/pmc_${c}_MFMA -name "*counter_collection.csv" | head -1)

@@ -70,7 +70,7 @@ for c, pat in DOMINANT.items():
                   "schedule": (line or {}).get("roofline", {}).get("schedule"),
                   "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --config {c} --steps 1 --warmup 0 (tools/collect_r04.sh)"}
 json.dump(traffic, open(os.path.join(DST, f"{TAG}_traffic.json"), "w"), indent=1)
-for c in ("c5", "c3"):
+for c in ("c5", "target", "c3"):
     p = os.path.join(SRC, f"pmc_{c}_MFMA.json")
     if os.path.exists(p) and os.path.getsize(p):
         d = json.load(open(p))
