@@ -54,8 +54,8 @@ PEAK_HBM_GBS = 8000.0
 def cpu_baseline(name, n_sample):
     from oracle import cpu_baseline as cb  # test infrastructure: the checker / baseline only
     kind, N, D = bc.CONFIGS[name]
-    X, y = bc.make_inputs(N, D)
-    return cb.measure(kind, D, N, bc.GPPP_BLOCKS.get(name), X, y, bc.SIGMA2, n_sample,
+    # (runs in a subprocess of its own: threading environment set before BLAS loads, inputs regenerated from the same seed)
+    return cb.measure(kind, D, N, bc.GPPP_BLOCKS.get(name), None, None, bc.SIGMA2, n_sample,
                       elbo_m=bc.ELBO_M, elbo_znoise=bc.ELBO_ZNOISE)
 
 
@@ -107,14 +107,18 @@ def update_bytes_avg(N):
 
 
 def lookup_traffic(config, schedule):
-    """the committed counter record of `config` (profiles/r04_traffic.json), if it was collected under `schedule`"""
-    f = os.path.join(ROOT, "profiles", "r04_traffic.json")
-    if not os.path.exists(f):
-        return None
-    rec = json.load(open(f)).get(config)
-    if not rec or (rec.get("schedule") and schedule and rec["schedule"] != schedule):
-        return None
-    return dict(rec, file="profiles/r04_traffic.json")
+    """the committed counter record of `config` (profiles/r05_traffic.json, else the round-4 file), if it was collected
+    under `schedule`.  A LOOKUP of a committed rocprofv3 --pmc collection, not something this run measures: the record
+    carries the sha1 of the library it was collected with and `measured_in_this_run: false`."""
+    for name in ("r05_traffic.json", "r04_traffic.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(f):
+            continue
+        rec = json.load(open(f)).get(config)
+        if not rec or (rec.get("schedule") and schedule and rec["schedule"] != schedule):
+            continue
+        return dict(rec, file="profiles/" + name, measured_in_this_run=False)
+    return None
 
 
 def resolve_devices(gpus, devices_arg, device_count, world):
@@ -358,6 +362,7 @@ def main():
             # (per STEP of the bound, all launches of the kernel: it runs in many shapes)
             "traffic": (lookup_traffic("c4", None) or {}).get("hbm_bytes") if args.config == "c4" else None,
             "traffic_source": lookup_traffic("c4", None) if args.config == "c4" else None,
+            "traffic_measured_in_this_run": False,
             "algorithmic_flops": 2.0 * M * M * N, "stage_ms": mfma_ms,
             "whole_step_frac_on_8.86TF": flops / (ms_per_step * 1e-3) / 1e12 / PEAK_FP64_MFMA_TFLOPS,
             # BASELINE.json calls c4 "HBM-bound"; SURVEY 8d asks for both figures and which one binds
@@ -389,7 +394,7 @@ def main():
                             "on fp32 storage; the kernel alone: profiles/r04_bench_c5_f32_kernel_stats.csv)"}
     multi = None
     if inproc:
-        st = np.zeros(9 + 4 * len(devs))
+        st = np.zeros(11 + 4 * len(devs))
         nst = C.c_int64()
         L.check(lib.sgp_ctx_multi_stats(ctx.handle, L.dptr(st), len(st), C.byref(nst)), "sgp_ctx_multi_stats")
         P_ = len(devs)
@@ -402,6 +407,9 @@ def main():
                  "peer_copy_form": ("scatter + all-gather" if st[6] else "direct") if ctx.transport in ("p2p", "loopback") else None,
                  "panel_width": int(st[4]), "panels": int(st[5]), "panels_per_update_group": int(st[7]),
                  "last_call_ms": st[1], "host_enqueue_ms": st[8 + 4 * P_], "per_rank": per_rank,
+                 "panel_ownership": {0: "cyclic", 1: "balanced table (own_table.h: from the symbolic tile pattern)",
+                                     2: "explicit list (SGP_MULTI_OWNERS)"}.get(int(st[9 + 4 * P_]), "?"),
+                 "late_bound_event_waits": int(st[10 + 4 * P_]),
                  "transport_probe_ms": transport_probe}
         if not is_elbo:
             tf = [r["update_tflops"] for r in per_rank if r["update_tflops"]]
@@ -480,11 +488,7 @@ def main():
             roofline["traffic_source"] = rec
         roofline["algorithmic_bytes_per_launch_avg"] = (8.0 * N * (N + 1) if dataflow else update_bytes_avg(N))   # dataflow: the
         # lower triangle read once and written once
-        for pmc_name in ("r03_gemm_pmc.json", "r02_gemm_pmc.json", "r01_gemm_pmc.json"):
-            pmc = os.path.join(ROOT, "profiles", pmc_name)
-            if os.path.exists(pmc) and not dataflow:
-                roofline["traffic_profiled"] = json.load(open(pmc))
-                break
+        roofline["traffic_measured_in_this_run"] = False   # (counters need separate rocprofv3 --pmc passes: see traffic_source)
         asm_bytes = 8.0 * N * (N + 1) / 2 + 8.0 * D * N
         stages = {"assemble_ms": timings[0], "cholesky_ms": timings[1], "finalize_ms": timings[2],
                   "kernelmatrix_GBps": asm_bytes / (timings[0] * 1e-3) / 1e9,
@@ -561,6 +565,48 @@ def main():
                                             "how": "SGP_STRUCT_ZEROS=0 on a second context"}
         sizes = {"n4k": time_config("n4k", 30, 3), "c2": time_config("c2", 10, 2)}
 
+    # ---- the gradient (the reference's main use, examples/getting_started/script.jl:154-213) under the same evidence
+    # regime as logpdf (round-4 verdict): sgp_logpdf_grad through the host API at n4k / c2 / n32k -- ms, the fraction of the fp64
+    # MFMA peak on its N^3 flops (factorisation N^3/3 + inverse 2N^3/3: LAPACK dpotri economics), and parity of d/d sigma^2
+    # and d/d inscale against the standalone CPU goldens (tests/golden/grad_configs.json; n32k: logpdf only).
+    grad = None
+    if (args.config == "c5" and not args.no_extras and not use_dist and not inproc and args.dtype == "f64" and rank == 0):
+        gg_all = {}
+        gpath = os.path.join(ROOT, "tests", "golden", "grad_configs.json")
+        if os.path.exists(gpath):
+            gg_all = json.load(open(gpath)).get("cases", {})
+        L.set_default_context(ctx)
+        grad = {}
+        for name, steps in (("n4k", 10), ("c2", 5), ("n32k", 2)):
+            ww = bc.build(pkg, name)
+            Nn = bc.CONFIGS[name][1]
+            r = pkg.logpdf_and_gradient(ww["fx"], ww["y"])          # warm-up (sizes the cache)
+            torch.cuda.synchronize()
+            t0x = time.perf_counter()
+            for _ in range(steps):
+                r = pkg.logpdf_and_gradient(ww["fx"], ww["y"])
+            ms = (time.perf_counter() - t0x) / steps * 1e3
+            # logpdf alone on the same context, same entry level
+            pkg.logpdf(ww["fx"], ww["y"])
+            t0x = time.perf_counter()
+            for _ in range(steps):
+                pkg.logpdf(ww["fx"], ww["y"])
+            ms_lp = (time.perf_counter() - t0x) / steps * 1e3
+            tf = (Nn ** 3) / (ms * 1e-3) / 1e12
+            gref = gg_all.get(name)
+            term = r["terms"][0]
+            rec = {"entry": "sgp_logpdf_grad (host buffers)", "N": Nn, "steps": steps, "ms_per_call": ms, "logpdf_ms": ms_lp,
+                   "ratio_to_logpdf": ms / ms_lp, "tflops_on_N3": tf, "frac": tf / PEAK_FP64_MFMA_TFLOPS,
+                   "d_sigma2": float(np.ravel(r["noise"])[0]), "d_inscale": float(term["d_inscale"]), "logpdf": float(r["logpdf"])}
+            if gref:
+                rec["parity_rel_d_sigma2"] = abs(rec["d_sigma2"] - gref["d_sigma2"]) / abs(gref["d_sigma2"])
+                rec["parity_rel_d_inscale"] = abs(rec["d_inscale"] - gref["d_inscale"]) / abs(gref["d_inscale"])
+                rec["parity_rel_logpdf"] = abs(rec["logpdf"] - gref["logpdf"]) / abs(gref["logpdf"])
+            else:
+                gl = bc.golden(name)
+                rec["parity_rel_logpdf"] = None if gl is None else abs(rec["logpdf"] - gl["logpdf"]) / abs(gl["logpdf"])
+            grad[name] = rec
+
     if rank == 0:
         g = bc.golden(args.config)
         gval = None if g is None else g.get("elbo" if is_elbo else "logpdf")
@@ -578,6 +624,14 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": bc.describe(args.config) + (", host-buffer C-ABI" if is_elbo else ""),
+                       # what `value` times (the round prompt: inputs resident in HBM when the timed region starts); the same step
+                       # through the host-buffer entry point the `ccall` binds -- SURVEY 8d's definition, <= 4 MB of copies
+                       # included -- is `host_api` beside it (1.002 x in round 4)
+                       "timed_entry": ("sgp_elbo (host buffers: the ELBO has no device-resident entry point)" if is_elbo else
+                                       "sgp_logpdf_f32 (host buffers)" if args.dtype == "f32" else
+                                       "sgp_logpdf on the multi-GPU context (host buffers)" if inproc else
+                                       "dist_logpdf (process per GPU, device-resident panels)" if use_dist else
+                                       "sgp_dev_logpdf (X, y device-resident; the host-buffer sgp_logpdf is timed in host_api)"),
                        "N": N, "D": D, "kernel": kind,
                        "parallelism": (f"in-process multi-GPU context x{len(devs)} ({'data points' if is_elbo else 'column panels'} "
                                        f"sharded inside libsthenomi, transport {ctx.transport})" if inproc
@@ -591,7 +645,7 @@ def main():
             "multi_gpu": multi,
             "logpdf": val, "golden": gval, "parity_rel": parity,
             "stages": stages, "roofline": roofline, "host_api": host_api, "cpu_baseline": cpu,
-            "north_star_target": north_star, "sizes": sizes,
+            "north_star_target": north_star, "sizes": sizes, "grad": grad,
         }
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if use_dist:

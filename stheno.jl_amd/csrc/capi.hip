@@ -1013,6 +1013,39 @@ static int sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_
   return 0;
 }
 
+// Per tile column of the factor of K + Sigma_y: the executed tile products of its contractions (SzPattern::col_work), from
+// the HOST spec -- what multi.hip prices the column panels with before it deals them out to the ranks (own_table.h).  Empty:
+// the model is structurally dense (one block, dense noise, no zero block pair, skipping switched off).
+int sgp::drv_sz_col_work(const sgp_ctx* ctx, const sgp_cov_spec* sp, int noise_kind, long n_pad, long m_tot,
+                         std::vector<double>& col_work) {
+  col_work.clear();
+  if (!ctx->struct_zeros || !sp || !sp->symmetric || noise_kind == SGP_NOISE_DENSE || sp->n_row_blocks < 2 ||
+      sp->n_row_blocks != sp->n_col_blocks)
+    return 0;
+  const int nb = sp->n_row_blocks;
+  std::vector<long> len((size_t)nb), off((size_t)nb);
+  long N = 0;
+  for (int I = 0; I < nb; ++I) {
+    len[(size_t)I] = (long)sp->row_len[I];
+    off[(size_t)I] = N;
+    N += len[(size_t)I];
+  }
+  std::vector<char> bnz((size_t)nb * nb, 0);
+  bool any_zero = false;
+  for (int I = 0; I < nb; ++I)
+    for (int J = 0; J < nb; ++J) {
+      const int p = I * nb + J, q = J * nb + I;
+      const bool has = sp->term_ptr[p + 1] > sp->term_ptr[p] || sp->term_ptr[q + 1] > sp->term_ptr[q];
+      bnz[(size_t)I * nb + J] = has ? 1 : 0;
+      if (!has && len[(size_t)I] > 0 && len[(size_t)J] > 0) any_zero = true;
+    }
+  if (!any_zero) return 0;
+  SzPattern pat;
+  sz_symbolic(bnz, nb, off, len, N, TILE, n_pad / TILE, m_tot / TILE, pat);
+  if (pat.zeros_left) col_work.swap(pat.col_work);
+  return 0;
+}
+
 // the device copy of a pattern (`h`: rows x words, possibly another context's -- the ranks of a multi-GPU context share one)
 static int sz_upload(sgp_ctx* ctx, const std::vector<sz_word>& h, int words, hipStream_t s, SzMask* out) {
   *out = SzMask();
@@ -1025,7 +1058,10 @@ static int sz_upload(sgp_ctx* ctx, const std::vector<sz_word>& h, int words, hip
     SGP_HIP(hipMalloc(&ctx->d_sz, sizeof(sz_word) * h.size()));
     ctx->n_sz = h.size();
   }
+  // `h` is pageable and the next call swaps / frees it (in a multi-GPU context every rank copies out of rank 0's): the copy is
+  // complete before this returns (a few KB on a stream that holds only the call's small uploads; advisor, round 4)
   SGP_HIP(hipMemcpyAsync(ctx->d_sz, h.data(), sizeof(sz_word) * h.size(), hipMemcpyHostToDevice, s));
+  SGP_HIP(hipStreamSynchronize(s));
   {   // room for the id map of the largest lower update this matrix can see
     const long rows = (long)(h.size() / (size_t)words);
     const long need = 16 + 8 * tri_ids_per_xcd(tri_shape(rows, std::min<long>(rows, (long)words * 64), -1));
@@ -1185,6 +1221,10 @@ extern "C" int sgp_bench_df_fallbacks(sgp_ctx* ctx, int64_t* out) {
 }
 template <class F>
 static int with_df_fallback(sgp_ctx* ctx, F&& run) {
+  // the flag reset, the operator and its rerun are ONE critical section of the context (advisor, round 4: two host threads
+  // on one context could erase each other's timeout flag, and the temporary dataflow = 0 leaked into the other's schedule)
+  std::unique_lock<std::recursive_mutex> hold;
+  if (ctx) hold = std::unique_lock<std::recursive_mutex>(ctx->mu);
   if (ctx) ctx->df_timed_out = false;
   int rc = run();
   if (ctx && rc == -3 && ctx->df_timed_out && ctx->df_fallback) {
@@ -2049,7 +2089,12 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
   DevBuf dAt2;
   CHECK_RC(dAt.alloc((size_t)m_pad * CH));
   if (overlap) CHECK_RC(dAt2.alloc((size_t)m_pad * CH));
-  CHECK_RC(dPart.alloc((size_t)splitk_slabs(m_pad, CH, nsplit) * stride));   // (the largest chunk has the most slabs)
+  {   // slabs of the chunk lengths actually used: the `sub` split depends on K % (8 sub 16), so a shorter LAST chunk can
+      // need more slabs than a full one (advisor, round 4: SGP_VFE_CHUNK = 768, M = 4096, 1280 rows -> 8 vs 32)
+    const long last = n_rows % CH == 0 ? std::min(CH, n_rows) : n_rows % CH;
+    const long slabs = std::max(splitk_slabs(m_pad, std::min(CH, n_rows), nsplit), splitk_slabs(m_pad, last, nsplit));
+    CHECK_RC(dPart.alloc((size_t)slabs * stride));
+  }
   hipStream_t sg = overlap ? ctx->stream2 : s;
   struct ChunkEvents {   // destroyed on every exit path
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
@@ -2954,7 +2999,7 @@ extern "C" int sgp_dev_assemble_cols(sgp_ctx* ctx, const sgp_dspec* ds, int64_t 
   CHECK_ARG(ds->symmetric && ds->N == N, "sgp_dev_assemble_cols: spec must be symmetric of size N");
   CHECK_ARG(c0 % TILE == 0 && nc % TILE == 0, "sgp_dev_assemble_cols: c0, nc must be multiples of 128");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG, "bad noise kind");
-  std::lock_guard<std::mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   int64_t n_pad, mt;
@@ -2982,7 +3027,7 @@ extern "C" int sgp_dev_assemble_cross_rows(sgp_ctx* ctx, const sgp_dspec* cross,
   CHECK_ARG(!cross->symmetric, "sgp_dev_assemble_cross_rows: needs a cross-covariance spec (rows x*, columns x)");
   CHECK_ARG(c0 % TILE == 0 && nc % TILE == 0 && row0 % TILE == 0 && row0 >= c0 + nc,
             "sgp_dev_assemble_cross_rows: c0, nc, row0 must be multiples of 128, rows below the square part");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   const long ns = cross->N, Nx = cross->M;
@@ -3001,7 +3046,7 @@ extern "C" int sgp_dev_assemble_cross_rows(sgp_ctx* ctx, const sgp_dspec* cross,
 extern "C" int sgp_dev_rows_dot(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nrows, int64_t nc,
                                 const double* d_zrow, double* d_sumsq, double* d_dot, void* stream) {
   CHECK_ARG(ctx && d_rows && d_zrow && d_sumsq && d_dot, "sgp_dev_rows_dot: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   return launch_rows_dot(d_rows, ld, nrows, nc, d_zrow, d_sumsq, d_dot, s);
@@ -3012,7 +3057,7 @@ extern "C" int sgp_dev_rows_gram(sgp_ctx* ctx, const double* d_rows, int64_t ld,
                                  double* d_G, int64_t ldg, void* stream) {
   CHECK_ARG(ctx && d_rows && d_G, "sgp_dev_rows_gram: NULL argument");
   CHECK_ARG(nrows_pad % TILE == 0 && nc % 16 == 0 && ldg >= nrows_pad, "sgp_dev_rows_gram: bad sizes");
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   return launch_gemm_nt(d_rows, ld, d_rows, ld, d_G, ldg, nrows_pad, nrows_pad, nc, 1.0, 1.0, NOMASK, 0, 0, s);
@@ -3022,7 +3067,7 @@ extern "C" int sgp_dev_panel_factor(sgp_ctx* ctx, double* d_P, int64_t ld, int64
                                     int64_t g0, double* d_logdet, int* d_info, void* stream) {
   CHECK_ARG(ctx && d_P && d_logdet && d_info, "sgp_dev_panel_factor: NULL argument");
   CHECK_ARG(w % TILE == 0 && m % TILE == 0 && m >= w, "sgp_dev_panel_factor: bad sizes");
-  std::lock_guard<std::mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   // per-block logdet slots live in ctx scratch; accumulate their sum into d_logdet[0]
@@ -3039,7 +3084,7 @@ extern "C" int sgp_dev_panel_update_batch(sgp_ctx* ctx, const sgp_panel_src* src
   CHECK_ARG(ctx && (srcs || nsrc == 0) && (dsts || ndst == 0), "sgp_dev_panel_update_batch: NULL argument");
   CHECK_ARG(nsrc >= 0 && nsrc <= SEG_MAX_SRC && ndst >= 0, "sgp_dev_panel_update_batch: at most 8 source panels");
   if (ndst == 0 || nsrc == 0) return 0;
-  std::lock_guard<std::mutex> lk(ctx->mu);
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   SegBatch b;
@@ -3069,7 +3114,7 @@ extern "C" int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp
                                     int64_t m_tot, void* stream) {
   CHECK_ARG(ctx && d_P && d_C, "sgp_dev_panel_update: NULL argument");
   CHECK_ARG(c0 % TILE == 0 && nc % TILE == 0 && w % 16 == 0 && c0 >= p_row0, "sgp_dev_panel_update: bad sizes");
-  std::lock_guard<std::mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   const double* A = d_P + (c0 - p_row0);  // panel rows c0.. (global)
@@ -3081,7 +3126,7 @@ extern "C" int sgp_dev_panel_update(sgp_ctx* ctx, const double* d_P, int64_t ldp
 extern "C" int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, int64_t nc,
                                 int64_t nrows, double* d_out, void* stream) {
   CHECK_ARG(ctx && d_rows && d_out, "sgp_dev_rowsumsq: NULL argument");
-  std::lock_guard<std::mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
+  std::lock_guard<std::recursive_mutex> lk(ctx->mu);  // ctx scratch (logdet slots, inverse blocks) is shared
   SGP_HIP(hipSetDevice(ctx->device));
   hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
   return launch_rowsumsq(d_rows, ld, nc, nrows, d_out, 1, s);

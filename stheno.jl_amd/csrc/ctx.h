@@ -131,7 +131,7 @@ struct sgp_ctx {
     return all > 0 ? live / all : 1.0;
   }
   long df_fallbacks = 0;       // operators rerun on the launch-based schedule because of that (capi.hip: with_df_fallback)
-  std::mutex mu;
+  std::recursive_mutex mu;   // recursive: with_df_fallback (capi.hip) holds it across an operator and its rerun
   // optional per-launch timing of the trailing updates (roofline evidence for bench.py)
   bool time_updates = false;
   std::vector<hipEvent_t> ev;
@@ -164,7 +164,7 @@ void pool_trim(sgp_ctx* ctx);                   // release every unused block to
 struct CtxScope {
   sgp_ctx* ctx;
   sgp_ctx* prev;
-  std::unique_lock<std::mutex> lk;
+  std::unique_lock<std::recursive_mutex> lk;
   explicit CtxScope(sgp_ctx* c) : ctx(c), prev(tl_ctx), lk(c->mu) {
     hipSetDevice(c->device);
     tl_ctx = c;

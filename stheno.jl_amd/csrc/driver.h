@@ -30,6 +30,9 @@ long drv_invd_stride();
 // (host), every rank uploads it; *words = 0 / *d_nz = nullptr: dense
 int drv_sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, int* words);
 int drv_sz_upload(sgp_ctx* ctx, const sgp_ctx* from, int words, hipStream_t s, const sgp::sz_word** d_nz);
+// executed tile products per tile column of the factor, from the host spec (empty: structurally dense) -- own_table.h
+int drv_sz_col_work(const sgp_ctx* ctx, const sgp_cov_spec* sp, int noise_kind, long n_pad, long m_tot,
+                    std::vector<double>& col_work);
 double drv_sz_live_fraction(const sgp_ctx* ctx, int words, long c0, long w, long m_tot, long kt0, long kt1);
 // dst[i] = src[i * stride], i < n
 int drv_copy_strided(const double* src, long stride, long n, double* dst, hipStream_t s);

@@ -448,33 +448,58 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_seg_kernel(SegBatch b) {
   const int s_end = s + b.dst[d].s_count;
   // structural zeros: a source all of whose k tiles have a structurally zero operand tile for this tile is skipped (bit q
   // of `livemask`); a tile without a live source is left alone
+  // Round 5: and inside a live source the tile contracts the k tiles from its first to its last needed one only (a source
+  // panel that straddles a block boundary of the programme) -- the single-GPU kernel's trim (gemm_nt_dma_tile); the tiles left
+  // out are exact zeros, the bits stay.  range_of(q): first needed k tile and number of k tiles of source q relative to the
+  // source's first column (sources whose columns start and end on tile boundaries; else the whole source), -1 = dead.
+  const sz_word* ra = b.nz ? b.nz + (c0 / TILE + tr) * b.nz_words : nullptr;
+  const sz_word* rb = b.nz ? b.nz + (c0 / TILE + tc) * b.nz_words : nullptr;
+  auto range_of = [&](int q, int& first, int& count) {
+    first = 0;
+    count = b.src[q].w / KB;   // in chunks of KB columns
+    if (!ra) return;
+    const long kc = b.src[q].k0 >= 0 ? b.src[q].k0 : b.src[q].row0;
+    const int kt0 = (int)(kc / TILE), kt1 = (int)((kc + b.src[q].w + TILE - 1) / TILE);
+    int kmin = -1, kmax = -1;
+    for (int k = kt0; k < kt1; ++k)
+      if ((((ra[k >> 6] & rb[k >> 6]) >> (k & 63)) & 1) != 0) {
+        if (kmin < 0) kmin = k;
+        kmax = k;
+      }
+    if (kmin < 0) {
+      count = -1;
+    } else if (kc % TILE == 0 && b.src[q].w % TILE == 0) {
+      first = (kmin - kt0) * (TILE / KB);
+      count = (kmax - kmin + 1) * (TILE / KB);
+    }
+  };
   unsigned livemask = ~0u;
-  if (b.nz) {
+  long total = 0;
+  {
     livemask = 0;
-    const sz_word* ra = b.nz + (c0 / TILE + tr) * b.nz_words;
-    const sz_word* rb = b.nz + (c0 / TILE + tc) * b.nz_words;
     for (int q = s; q < s_end; ++q) {
-      const long kc = b.src[q].k0 >= 0 ? b.src[q].k0 : b.src[q].row0;
-      const int kt0 = (int)(kc / TILE), kt1 = (int)((kc + b.src[q].w + TILE - 1) / TILE);
-      bool live = false;
-      for (int k = kt0; k < kt1; ++k) live = live || (((ra[k >> 6] & rb[k >> 6]) >> (k & 63)) & 1) != 0;
-      if (live) livemask |= 1u << q;
+      int f, cnt;
+      range_of(q, f, cnt);
+      if (cnt > 0) {
+        livemask |= 1u << q;
+        total += cnt;
+      }
     }
     if (livemask == 0) return;
     while (!((livemask >> s) & 1)) ++s;
   }
-  long total = 0;
-  for (int q = s; q < s_end; ++q)
-    if ((livemask >> q) & 1) total += b.src[q].w / KB;
   const double *pa = nullptr, *pb = nullptr;
   long ld = 0;
   int left = 0;
   auto open = [&](int q) {
     const long r0 = c0 - b.src[q].row0;   // first stored row of the source is its own column offset
     ld = b.src[q].ld;
-    pa = b.src[q].base + r0 + tr * TILE;
-    pb = b.src[q].base + r0 + tc * TILE;
-    left = b.src[q].w / KB;
+    int f, cnt;
+    range_of(q, f, cnt);
+    const long skip = (long)f * KB * ld;   // the columns before the first needed k tile
+    pa = b.src[q].base + r0 + tr * TILE + skip;
+    pb = b.src[q].base + r0 + tc * TILE + skip;
+    left = cnt;
   };
   auto request = [&](int stage) {
     double* sa = smem + stage * (2 * KB * LDS_LD);

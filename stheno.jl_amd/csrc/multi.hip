@@ -49,6 +49,7 @@
 // elbo: the data points are sharded (contiguous slices), every rank turns its slice into a "part" (see
 // sgp_dev_elbo_partial) on a host thread of its own, ONE reduction of M^2 + M + 2 doubles, rank 0 finishes.
 #include "driver.h"
+#include "own_table.h"
 
 #include <dlfcn.h>
 
@@ -170,6 +171,12 @@ struct sgp_multi {
   std::unordered_map<hipEvent_t, std::atomic<long>> seq;
   std::atomic<int> abort_flag{0};
   int ring = 10;            // receive buffers per rank: 2 * group + 2
+  // panel ownership (own_table.h; make_geometry): balanced from the model's tile pattern unless SGP_MULTI_OWNERS says
+  // "cyclic" or gives an explicit list; own_mode = what the last geometry used (0 cyclic, 1 balanced table, 2 list)
+  bool own_balanced = true;
+  std::vector<int> own_list;
+  int own_mode = 0;
+  std::atomic<long> late_binds{0};   // Exec::wait: records that had been re-recorded by the time the wait was enqueued
   Rccl rccl;
   double last_ms = 0.0;
   int sz_words = 0;               // structural zeros: words per pattern row of the current call (0: dense)
@@ -212,19 +219,34 @@ inline long rup(long x, long m) { return (x + m - 1) / m * m; }
 struct Geometry {
   long N = 0, n_pad = 0, m_tot = 0, W = 0, npan = 0, P = 1, S = 0;   // W: the widest panel
   std::vector<long> c0s;   // first column of every panel, and n_pad
+  // who owns which panel (own_table.h): cyclic, or balanced from the symbolic tile pattern of a structured model.  Every
+  // loop over "rank i's panels" walks mine[i] (ascending); local(J) = position of J among its owner's panels.
+  std::vector<int> own;
+  std::vector<long> loc;
+  std::vector<std::vector<long>> mine;
   long col0(long J) const { return c0s[J]; }
   long width(long J) const { return c0s[J + 1] - c0s[J]; }
   long ldp(long J) const { return m_tot - c0s[J]; }          // packed leading dimension of panel J
-  int owner(long J) const { return (int)(J % P); }
-  long local(long J) const { return J / P; }
+  int owner(long J) const { return own[(size_t)J]; }
+  long local(long J) const { return loc[(size_t)J]; }
   long ncols_owned(int i) const {
     long t = 0;
-    for (long J = i; J < npan; J += P) t += width(J);
+    for (long J : mine[(size_t)i]) t += width(J);
     return t;
+  }
+  void set_owners(const std::vector<int>& o) {
+    own = o;
+    loc.assign((size_t)npan, 0);
+    mine.assign((size_t)P, {});
+    for (long J = 0; J < npan; ++J) {
+      loc[(size_t)J] = (long)mine[(size_t)own[(size_t)J]].size();
+      mine[(size_t)own[(size_t)J]].push_back(J);
+    }
   }
 };
 
-Geometry make_geometry(const sgp_multi* m, long N, long S) {
+// spec / noise_kind: the model whose factor is about to be sharded (nullptr: unknown -- the cyclic deal)
+Geometry make_geometry(sgp_multi* m, long N, long S, const sgp_cov_spec* spec = nullptr, int noise_kind = SGP_NOISE_SCALAR) {
   Geometry g;
   int64_t n_pad, m_tot;
   sgp_geometry(N, S, &n_pad, &m_tot);
@@ -243,6 +265,26 @@ Geometry make_geometry(const sgp_multi* m, long N, long S) {
   g.npan = (long)g.c0s.size();
   g.c0s.push_back(n_pad);
   g.P = (long)m->r.size();
+  // ---- ownership (own_table.h).  SGP_MULTI_OWNERS = balanced (default) | cyclic | r0,r1,... (a list dealt out cyclically:
+  // tests).  Balanced: panel costs from the symbolic tile pattern of the model (rank 0's context holds the switch for the
+  // structural zeros), one panel per rank and round, heaviest panel to the least loaded rank; a dense model with one panel
+  // width gets the cyclic deal itself (the balanced table is within 1 % of it there and the cyclic one is what every
+  // earlier measurement ran on).
+  std::vector<int> own((size_t)g.npan);
+  for (long J = 0; J < g.npan; ++J) own[(size_t)J] = (int)(J % g.P);
+  m->own_mode = 0;
+  if (g.P > 1 && !m->own_list.empty()) {
+    for (long J = 0; J < g.npan; ++J) own[(size_t)J] = m->own_list[(size_t)J % m->own_list.size()] % (int)g.P;
+    m->own_mode = 2;
+  } else if (g.P > 1 && m->own_balanced && spec) {
+    std::vector<double> col_work;
+    if (drv_sz_col_work(m->r[0].ctx, spec, noise_kind, n_pad, m_tot, col_work) == 0 && !col_work.empty()) {
+      const std::vector<double> cost = panel_costs(g.c0s, TILE, m_tot / TILE, col_work);
+      own = balanced_owners(cost, (int)g.P);
+      m->own_mode = 1;
+    }
+  }
+  g.set_owners(own);
   return g;
 }
 
@@ -261,7 +303,7 @@ struct Fact {
 size_t plan_offsets(const Geometry& g, int i, std::vector<size_t>& off) {
   off.clear();
   size_t tot = 0;
-  for (long J = i; J < g.npan; J += g.P) {
+  for (long J : g.mine[(size_t)i]) {
     off.push_back(tot);
     tot += (size_t)g.ldp(J) * g.width(J);
   }
@@ -377,6 +419,19 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   const char* gr = getenv("SGP_MULTI_GROUP");
   if (gr && atoi(gr) >= 1 && atoi(gr) <= SEG_MAX_SRC) m->group = atoi(gr);
   m->ring = 2 * m->group + 2;
+  if (const char* ow = getenv("SGP_MULTI_OWNERS")) {
+    if (!strcmp(ow, "cyclic"))
+      m->own_balanced = false;
+    else if (strcmp(ow, "balanced") != 0) {
+      for (const char* c = ow; *c;) {
+        char* e = nullptr;
+        const long v = strtol(c, &e, 10);
+        if (e == c) break;
+        m->own_list.push_back((int)std::max<long>(0, v));
+        c = (*e == ',') ? e + 1 : e;
+      }
+    }
+  }
   const char* sp = getenv("SGP_MULTI_SUBPANEL");
   if (sp) m->sub = atol(sp) / TILE * TILE;
   m->r.resize(ndev);
@@ -525,6 +580,12 @@ extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64
     out[8 + 4 * P] = m->last_enqueue_ms;
     *n_out = 9 + 4 * P;
   }
+  if (cap >= 11 + 4 * P) {   // ... and two more: the ownership of the last geometry (0 cyclic, 1 balanced table, 2 list) and
+                             // the event waits that bound to a later record than the schedule named (Exec::wait), cumulative
+    out[9 + 4 * P] = (double)m->own_mode;
+    out[10 + 4 * P] = (double)m->late_binds.load();
+    *n_out = 11 + 4 * P;
+  }
   return 0;
 }
 
@@ -593,6 +654,10 @@ struct Exec {
         }
         std::this_thread::yield();
       }
+      // hipStreamWaitEvent binds to the LATEST record: if the producer has already re-recorded the event this waits for a
+      // later point of the same stream (still correct -- a stream is in order -- and, by the schedule's construction, never a
+      // cycle); counted so that a run can tell whether it ever happened (sgp_ctx_multi_stats)
+      if (q.load(std::memory_order_acquire) > c) m->late_binds.fetch_add(1, std::memory_order_relaxed);
     }
     M_RC(dev(i));
     M_HIP(hipStreamWaitEvent(s, e, 0));
@@ -800,20 +865,26 @@ int update_panels(sgp_multi* m, const Fact& F, long J_first, long J_last, const 
 
 // ---- host-side inputs of one call, uploaded to every rank ----------------------------------------------
 struct SmallLayout {
-  long N, S;
-  size_t y, mean, noise, scal, total;
-  SmallLayout(long N_, long S_) : N(N_), S(S_) {
+  long N, S, npan;
+  size_t y, mean, noise, scal, pan, total;
+  // pan: per panel J 1 + max(S, 1) doubles -- the panel's logdet contribution and the |L^-1 (Y - m)|^2 contributions of its
+  // columns, written by the panel's owner only.  The host adds them in PANEL order (reduce_scalars), so logpdf does not
+  // depend on who owns which panel (round 4 added per-rank sums in rank order: the value moved in the last bits with the
+  // ownership table).
+  long per() const { return 1 + std::max<long>(S, 1); }
+  SmallLayout(long N_, long S_, long npan_) : N(N_), S(S_), npan(npan_) {
     y = 0;
     mean = y + (size_t)N * std::max<long>(S, 1);
     noise = mean + N;
     scal = noise + N;
-    total = scal + 16 + 2 * (size_t)std::max<long>(S, 1);
+    pan = scal + 16 + 2 * (size_t)std::max<long>(S, 1);
+    total = pan + (size_t)npan * (size_t)per();
   }
 };
 
 // Assemble every rank's owned panels of K + Sigma_y (+ the bordered rows (Y - m)') and run the sharded
-// factorisation.  d_small of rank i afterwards holds at `scal`: [0] logdet contribution, [1 .. 1 + S) the
-// |L^-1 (Y - m)|^2 contributions of its columns.
+// factorisation.  d_small of rank i afterwards holds at `pan`, per OWNED panel: [0] logdet contribution, [1 .. 1 + S) the
+// |L^-1 (Y - m)|^2 contributions of its columns (reduce_scalars).
 int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mean, int noise_kind, const double* noise,
               const double* Y, long ldy, std::vector<sgp_dspec*>& ds) {
   const Geometry& g = F.g;
@@ -822,7 +893,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   const double s2 = noise_kind == SGP_NOISE_SCALAR ? noise[0] : 0.0;
   const bool dense_noise = noise_kind == SGP_NOISE_DENSE;   // noise: host N x N, column-major, ld = N
   const int asm_kind = dense_noise ? SGP_NOISE_SCALAR : noise_kind;   // (dense: assembled with s2 = 0, the slabs added below)
-  const SmallLayout L(N, S);
+  const SmallLayout L(N, S, g.npan);
   const bool prof = m->profile != 0;
   if (prof) m->prof.assign((size_t)g.npan * (3 + 3 * P), 0.0);
   const double t_begin = now_ms();
@@ -880,13 +951,13 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     if (mean) M_HIP(hipMemcpyAsync(dM, mean, sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
     if (noise_kind == SGP_NOISE_DIAG)
       M_HIP(hipMemcpyAsync(dNz, noise, sizeof(double) * N, hipMemcpyHostToDevice, k.s_upd));
-    M_HIP(hipMemsetAsync(dSc, 0, sizeof(double) * (16 + 2 * std::max<long>(S, 1)), k.s_upd));
+    M_HIP(hipMemsetAsync(dSc, 0, sizeof(double) * (L.total - L.scal), k.s_upd));   // scalars + the per-panel slots
     M_HIP(hipMemsetAsync(k.d_info, 0, sizeof(int), k.s_upd));
     // ---- assembly of the owned panels: no communication.  A dense Sigma_y (round 4) is added slab by slab: the owner of
     // panel J stages rows J0 .. N of ITS columns of the host matrix (one strided copy) and adds them on the tiles the
     // factorisation reads -- every rank touches 1 / P of the matrix, nothing travels between ranks.
     if (dense_noise) M_RC(grow(&k.d_work, &k.work_cap, (size_t)N * std::min<long>(g.W, N)));
-    for (long J = i; J < g.npan; J += P) {
+    for (long J : g.mine[(size_t)i]) {
       double* base = F.panel(i, J);
       M_RC(sgp_dev_assemble_cols(k.ctx, ds[i], N, g.col0(J), g.width(J), base - g.col0(J), g.ldp(J), g.m_tot,
                                  mean ? dM : nullptr, asm_kind, &s2, noise_kind == SGP_NOISE_DIAG ? dNz : nullptr,
@@ -928,7 +999,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         sub_range(J, q, c, wq);
         if (x.mine(o)) {
           M_RC(x.dev(o));   // (broadcast_panel leaves another rank's device current in the one-thread mode)
-          M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, k.d_small + L.scal, k.d_info,
+          M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, k.d_small + L.pan + (size_t)J * L.per(), k.d_info,
                                 F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr, k.s_panel));
         }
         M_RC(x.rec(o, k.ev_sub[q], k.s_panel));
@@ -1046,7 +1117,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         near_a.clear();
         near_b.clear();
         far.clear();
-        for (long Jp = i; Jp < g.npan; Jp += P) {
+        for (long Jp : g.mine[(size_t)i]) {
           if (Jp <= nxt) continue;
           const long gp = group_of(Jp);
           if (gp == gj) near_a.push_back(Jp);
@@ -1116,11 +1187,11 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
       M_RC(x.wait(i, k.s_upd, k.ev_A));
       if (S > 0 && x.mine(i)) {
         M_RC(x.dev(i));
-        for (long J = i; J < g.npan; J += P) {
+        for (long J : g.mine[(size_t)i]) {
           long nc = std::min(g.width(J), std::max<long>(0, N - g.col0(J)));
           if (nc > 0)
             M_RC(sgp_dev_rowsumsq(k.ctx, F.panel(i, J) + (g.n_pad - g.col0(J)), g.ldp(J), nc, S,
-                                  k.d_small + L.scal + 1, (void*)k.s_upd));
+                                  k.d_small + L.pan + (size_t)J * L.per() + 1, (void*)k.s_upd));
         }
       }
     }
@@ -1217,6 +1288,48 @@ long spec_rows(const sgp_cov_spec* spec) {
   return N;
 }
 
+// logdet and |L^-1 (Y - m)|^2 per column from the per-panel slots of every rank (SmallLayout::pan), added in panel order:
+// red[0] = logdet, red[1 + s] = column s.  RCCL: one ncclAllReduce of the slot array (every slot is non-zero on its owner
+// only, so the sum is exact), then rank 0's copy; else every rank's slots are fetched and the owner's taken.
+int reduce_scalars(sgp_multi* m, const Geometry& g, const SmallLayout& L, std::vector<double>& red) {
+  const int P = (int)m->r.size();
+  const long per = L.per(), nslot = g.npan * per;
+  std::vector<double> all((size_t)nslot, 0.0), tmp((size_t)nslot);
+  if (m->transport == TR_RCCL) {
+    int rc = m->rccl.GroupStart();
+    for (int i = 0; i < P && rc == 0; ++i) {
+      Rank& k = m->r[i];
+      hipSetDevice(k.dev);
+      double* sc = k.d_small + L.pan;
+      rc = m->rccl.AllReduce(sc, sc, (size_t)nslot, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
+    }
+    int rc2 = m->rccl.GroupEnd();
+    if (rc || rc2) {
+      set_error("ncclAllReduce failed");
+      return -4;
+    }
+    Rank& k0 = m->r[0];
+    M_HIP(hipSetDevice(k0.dev));
+    M_HIP(hipMemcpyAsync(all.data(), k0.d_small + L.pan, sizeof(double) * nslot, hipMemcpyDeviceToHost, k0.s_upd));
+    for (auto& k : m->r) {
+      M_HIP(hipSetDevice(k.dev));
+      M_HIP(hipStreamSynchronize(k.s_upd));
+    }
+  } else {
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      M_HIP(hipMemcpy(tmp.data(), k.d_small + L.pan, sizeof(double) * nslot, hipMemcpyDeviceToHost));
+      for (long J : g.mine[(size_t)i])
+        for (long q = 0; q < per; ++q) all[(size_t)(J * per + q)] = tmp[(size_t)(J * per + q)];
+    }
+  }
+  red.assign((size_t)per, 0.0);
+  for (long J = 0; J < g.npan; ++J)
+    for (long q = 0; q < per; ++q) red[(size_t)q] += all[(size_t)(J * per + q)];
+  return 0;
+}
+
 // transient factor in the ranks' grow-only stores
 int transient_fact(sgp_multi* m, Fact& F) {
   const int P = (int)F.g.P;
@@ -1247,42 +1360,14 @@ int sgp_multi_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean,
   M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG || noise_kind == SGP_NOISE_DENSE,
               "sgp_logpdf (multi): bad noise kind");
   Fact F;
-  F.g = make_geometry(m, N, ncols);
-  const SmallLayout L(N, ncols);
+  F.g = make_geometry(m, N, ncols, spec, noise_kind);
+  const SmallLayout L(N, ncols, F.g.npan);
   std::vector<sgp_dspec*> ds(P, nullptr);
   auto body = [&]() -> int {
     M_RC(transient_fact(m, F));
     M_RC(factorize(m, F, spec, mean, noise_kind, noise, Y, ldy, ds));
-    const long nred = 1 + ncols;
-    std::vector<double> red(nred, 0.0), tmp(nred);
-    if (m->transport == TR_RCCL) {
-      int rc = m->rccl.GroupStart();
-      for (int i = 0; i < P && rc == 0; ++i) {
-        Rank& k = m->r[i];
-        hipSetDevice(k.dev);
-        double* sc = k.d_small + L.scal;
-        rc = m->rccl.AllReduce(sc, sc, nred, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
-      }
-      int rc2 = m->rccl.GroupEnd();
-      if (rc || rc2) {
-        set_error("ncclAllReduce failed");
-        return -4;
-      }
-      Rank& k0 = m->r[0];
-      M_HIP(hipSetDevice(k0.dev));
-      M_HIP(hipMemcpyAsync(red.data(), k0.d_small + L.scal, sizeof(double) * nred, hipMemcpyDeviceToHost, k0.s_upd));
-      for (auto& k : m->r) {
-        M_HIP(hipSetDevice(k.dev));
-        M_HIP(hipStreamSynchronize(k.s_upd));
-      }
-    } else {
-      for (int i = 0; i < P; ++i) {   // fixed rank order: deterministic
-        Rank& k = m->r[i];
-        M_HIP(hipSetDevice(k.dev));
-        M_HIP(hipMemcpy(tmp.data(), k.d_small + L.scal, sizeof(double) * nred, hipMemcpyDeviceToHost));
-        for (long q = 0; q < nred; ++q) red[q] += tmp[q];
-      }
-    }
+    std::vector<double> red;
+    M_RC(reduce_scalars(m, F.g, L, red));
     int info = collect_info(m);
     if (info) return info;
     for (long s = 0; s < ncols; ++s) out[s] = -0.5 * ((double)N * 1.8378770664093453 + red[0] + red[1 + s]);
@@ -1305,7 +1390,7 @@ int sgp_multi_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, i
   M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG || noise_kind == SGP_NOISE_DENSE,
               "sgp_rand (multi): bad noise kind");
   Fact F;
-  F.g = make_geometry(m, N, 0);
+  F.g = make_geometry(m, N, 0, spec, noise_kind);
   const Geometry& g = F.g;
   const long s_pad = rup(S, TILE), n_pad = g.n_pad;
   std::vector<sgp_dspec*> ds(P, nullptr);
@@ -1330,7 +1415,7 @@ int sgp_multi_rand(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, i
       M_HIP(hipMemsetAsync(dZt, 0, sizeof(double) * s_pad * n_pad, s));
       M_HIP(hipMemsetAsync(dOut, 0, sizeof(double) * n_pad * s_pad, s));
       M_RC(launch_transpose_add(dZ, N, N, S, dZt, s_pad, nullptr, s));
-      for (long J = i; J < g.npan; J += P) {
+      for (long J : g.mine[(size_t)i]) {
         const long J0 = g.col0(J);
         M_RC(launch_gemm_nt_lz_k(F.panel(i, J), g.ldp(J), dZt + J0 * s_pad, s_pad, dOut + J0, n_pad, n_pad - J0, s_pad,
                                  g.width(J), 1.0, s));
@@ -1395,7 +1480,7 @@ int sgp_multi_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
   mp->ctx = ctx;
   for (auto& k : m->r) mp->devs.push_back(k.dev);
   Fact& F = mp->F;
-  F.g = make_geometry(m, N, 1);
+  F.g = make_geometry(m, N, 1, spec, noise_kind);
   const Geometry& g = F.g;
   F.base.assign(P, nullptr);
   F.inv.assign(P, nullptr);
@@ -1425,7 +1510,7 @@ int sgp_multi_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
       Rank& k = m->r[i];
       M_HIP(hipSetDevice(k.dev));
       long at = 0;
-      for (long J = i; J < g.npan; J += P) {
+      for (long J : g.mine[(size_t)i]) {
         M_RC(drv_copy_strided(F.panel(i, J) + (g.n_pad - g.col0(J)), g.ldp(J), g.width(J), mp->zloc[i] + at, k.s_upd));
         at += g.width(J);
       }
@@ -1440,7 +1525,7 @@ int sgp_multi_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const dou
         M_RC(grow(&k.d_work, &k.work_cap, (size_t)2 * g.n_pad));
         M_HIP(hipMemsetAsync(k.d_work, 0, sizeof(double) * 2 * g.n_pad, k.s_upd));
         long at = 0;
-        for (long J = i; J < g.npan; J += P) {
+        for (long J : g.mine[(size_t)i]) {
           M_HIP(hipMemcpyAsync(k.d_work + g.col0(J), mp->zloc[i] + at, sizeof(double) * g.width(J),
                                hipMemcpyDeviceToDevice, k.s_upd));
           at += g.width(J);
@@ -1511,7 +1596,8 @@ static int sweep_rows(sgp_multi* m, sgp_mpost* mp, long ns_pad, const std::vecto
       const long nco = g.ncols_owned(i);
       double* Si = k.d_work + (size_t)ns_pad * std::max<long>(nco, 1);
       bool first = true, any = false;
-      for (long kk = i; kk < J; kk += P) {
+      for (long kk : g.mine[(size_t)i]) {
+        if (kk >= J) break;
         // V_kk (ns_pad x w_kk) times rows J0 .. J0 + w of panel kk
         const double* Vk = k.d_work + (size_t)at[i][g.local(kk)] * ns_pad;
         const double* Ljk = F.panel(i, kk) + (J0 - g.col0(kk));
@@ -1585,7 +1671,7 @@ int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const 
       M_RC(drv_dspec_create(k.ctx, cross, &ds[i]));
       M_HIP(hipMemsetAsync(k.d_work, 0, sizeof(double) * ns_pad * std::max<long>(nco, 1), k.s_upd));
       long a = 0;
-      for (long J = i; J < g.npan; J += P) {
+      for (long J : g.mine[(size_t)i]) {
         at[i].push_back(a);
         const long c0 = g.col0(J), w = g.width(J);
         // element (r, c) of K(x*, x) at Kv[r + c * ns_pad] with Kv = block - c0 * ns_pad
@@ -1713,20 +1799,14 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
   const Fact& F = mp->F;
   const Geometry& g = F.g;
   const long n_pad = g.n_pad;
-  const SmallLayout L(N, 1);
+  const SmallLayout L(N, 1, g.npan);
   std::vector<sgp_dspec*> ds(P, nullptr);
   size_t nterms = 0;
   std::vector<double> gc_sum, gs_sum, kdiag(N, 0.0);
   auto body = [&]() -> int {
     // ---- logpdf from the scalars the factorisation left on every rank (rank order: deterministic)
-    double red[2] = {0.0, 0.0}, tmp[2];
-    for (int i = 0; i < P; ++i) {
-      Rank& k = m->r[i];
-      M_HIP(hipSetDevice(k.dev));
-      M_HIP(hipMemcpy(tmp, k.d_small + L.scal, sizeof(double) * 2, hipMemcpyDeviceToHost));
-      red[0] += tmp[0];
-      red[1] += tmp[1];
-    }
+    std::vector<double> red;
+    M_RC(reduce_scalars(m, g, L, red));
     *logpdf_out = -0.5 * ((double)N * 1.8378770664093453 + red[0] + red[1]);
     // ---- X = L^-T: identity rows through the row sweep
     std::vector<std::vector<long>> at(P);
@@ -1744,7 +1824,7 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
       M_RC(drv_dspec_create(k.ctx, spec, &ds[i]));
       M_HIP(hipMemsetAsync(k.d_work, 0, sizeof(double) * n_pad * std::max<long>(nco, 1), k.s_upd));
       long a = 0;
-      for (long J = i; J < g.npan; J += P) {
+      for (long J : g.mine[(size_t)i]) {
         at[i].push_back(a);
         const long w = g.width(J);
         hipLaunchKernelGGL(set_identity_cols_kernel, dim3((unsigned)((w + 255) / 256)), dim3(256), 0, k.s_upd,
@@ -1771,7 +1851,7 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
       M_HIP(hipSetDevice(kj.dev));
       for (int i = 0; i < P; ++i)
         if (i != j) M_HIP(hipStreamWaitEvent(kj.s_upd, m->r[i].ev_done, 0));
-      for (long J = j; J < g.npan; J += P) {
+      for (long J : g.mine[(size_t)j]) {
         const long c0 = g.col0(J), w = g.width(J);
         double* dst = kj.d_work2 + (size_t)c0 * n_pad;
         for (int i = 0; i < P; ++i) {
@@ -1807,7 +1887,7 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
       // partial-sum scratch of the contraction kernel: 16 doubles per tile of the largest window
       double* d_part = k.d_work;   // (X is no longer needed)
       M_CHECK_ARG((size_t)(n_pad / TILE) * (g.W / TILE) * 16 <= k.work_cap, "sgp_logpdf_grad (multi): scratch too small");
-      for (long J = i; J < g.npan; J += P) {
+      for (long J : g.mine[(size_t)i]) {
         const long pc0 = g.col0(J), pw = std::min(g.width(J), N - pc0);
         if (pw <= 0) continue;
         if (grad_coef || grad_inscale)

@@ -22,6 +22,7 @@ struct SzPattern {
   int words = 0;
   double executed = 0, dense = 0;
   bool zeros_left = false;   // false: the factor is structurally dense (nothing to skip)
+  std::vector<double> col_work;   // executed tile products of tile column j (sum over the rows i >= j): sums to `executed`
 };
 
 inline void sz_symbolic(const std::vector<char>& bnz, int nb, const std::vector<long>& off, const std::vector<long>& len,
@@ -66,6 +67,7 @@ inline void sz_symbolic(const std::vector<char>& bnz, int nb, const std::vector<
   // fill-in, and the work of the contractions
   out.executed = 0;
   out.zeros_left = false;
+  out.col_work.assign((size_t)T_c, 0.0);
   for (long j = 0; j < T_c; ++j) {
     const word* rj = &nz[(size_t)j * W];
     for (long i = j; i < T_r; ++i) {
@@ -80,8 +82,11 @@ inline void sz_symbolic(const std::vector<char>& bnz, int nb, const std::vector<
         }
       }
       if (shared > 0 && !getbit(i, j)) setbit(i, j);
-      if (getbit(i, j)) out.executed += (double)shared;
-      else out.zeros_left = true;
+      if (getbit(i, j)) {
+        out.executed += (double)shared;
+        out.col_work[(size_t)j] += (double)shared;
+      } else
+        out.zeros_left = true;
     }
   }
 }

@@ -8,7 +8,7 @@ what `posterior` keeps and what `rand` multiplies a draw with); this module tell
 logpdf, posterior moments and the ELBO do not depend on the order of the observations beyond rounding.
 
     perm = fill_reducing_order(f, x)                      # a permutation of the blocks of x
-    x2, (y2, noise2) = permute_blocks(x, perm, y, noise)  # the same observations, reordered
+    x2, (y2,), noise2 = permute_blocks(x, perm, y, noise=noise)  # the same observations, reordered
     logpdf(f(x2, noise2), y2)
 
 No reference analogue: Stheno builds the dense matrix and LAPACK factors it whatever the order."""
@@ -52,22 +52,43 @@ def fill_reducing_order(f, x):
     return order
 
 
-def permute_blocks(x, perm, *vectors):
+_NO_NOISE = object()
+
+
+def permute_blocks(x, perm, *vectors, noise=_NO_NOISE):
     """x with its blocks in the order `perm`, and every vector of per-observation values (observations y, a diagonal of
-    noise variances; scalars and None pass through; an N x S matrix is permuted by rows) reordered with it."""
+    noise variances; scalars and None pass through; an N x S matrix is permuted by rows) reordered with it.
+
+    `noise=` takes Sigma_y in any of the forms f(x, Sigma_y) does -- scalar, length-N diagonal or dense N x N -- and permutes
+    a dense matrix by rows AND columns; with it the result is (x2, vectors2, noise2).  A positional square N x N argument is
+    refused: whether it is N right-hand sides (rows only) or a covariance (both sides) cannot be told from its shape."""
     bl = blocks(x) if isinstance(x, BlockData) else None
     if bl is None or sorted(perm) != list(range(len(bl))):
         raise ValueError("permute_blocks: x must be a BlockData and perm a permutation of its blocks")
     lens = [len(b) for b in bl]
     offs = np.concatenate([[0], np.cumsum(lens)])
     idx = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in perm]) if perm else np.zeros(0, dtype=int)
+    n = int(offs[-1])
     out = []
     for v in vectors:
         if v is None or np.ndim(v) == 0:
             out.append(v)
             continue
         a = np.asarray(v)
-        if a.shape[0] != offs[-1]:
+        if a.shape[0] != n:
             raise ValueError("permute_blocks: a vector's length is not the number of observations")
+        if a.ndim == 2 and a.shape[1] == n and n > 1:
+            raise ValueError("permute_blocks: a square N x N argument is ambiguous -- pass a dense Sigma_y as noise=, "
+                             "N right-hand sides column by column")
         out.append(a[idx] if a.ndim == 1 else np.asfortranarray(a[idx, :]))
-    return BlockData([bl[i] for i in perm]), tuple(out)
+    x2 = BlockData([bl[i] for i in perm])
+    if noise is _NO_NOISE:
+        return x2, tuple(out)
+    if noise is None or np.ndim(noise) == 0:
+        noise2 = noise
+    else:
+        a = np.asarray(noise)
+        if a.shape[0] != n or (a.ndim == 2 and a.shape[1] != n) or a.ndim > 2:
+            raise ValueError("permute_blocks: noise must be a scalar, a length-N diagonal or an N x N matrix")
+        noise2 = a[idx] if a.ndim == 1 else np.asfortranarray(a[np.ix_(idx, idx)])
+    return x2, tuple(out), noise2

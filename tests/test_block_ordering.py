@@ -83,3 +83,15 @@ def test_values_do_not_depend_on_the_order(monkeypatch):
         P.permute_blocks(x, [0, 0, 1], y)
     with pytest.raises(ValueError):
         P.permute_blocks(x, perm, y[:-1])
+    # a dense Sigma_y goes through noise= and is permuted on BOTH sides (advisor, round 4: rows only was a silently wrong
+    # model); a positional square argument is refused
+    Bm = rng.standard_normal((N, N))
+    S = np.asfortranarray(0.05 * Bm @ Bm.T / N + np.diag(noise))
+    x3, (y3,), S3 = P.permute_blocks(x, perm, y, noise=S)
+    lp3 = P.logpdf(F(x3, S3), y3)
+    assert abs(P.logpdf(F(x, S), y) - lp3) <= 1e-10 * abs(lp3)
+    x4, (y4,), d4 = P.permute_blocks(x, perm, y, noise=noise)
+    np.testing.assert_array_equal(d4, noise2)
+    assert P.permute_blocks(x, perm, noise=0.3)[2] == 0.3
+    with pytest.raises(ValueError):
+        P.permute_blocks(x, perm, S)

@@ -246,7 +246,8 @@ def test_multi_stats_and_profile(panel128):
     out = np.zeros(64)
     n = C.c_int64()
     P.lib.check(ctx.lib.sgp_ctx_multi_stats(ctx.handle, P.lib.dptr(out), 64, C.byref(n)))
-    assert n.value == 9 + 4 * 3 and out[0] == 3 and out[1] > 0 and out[5] == 8
+    assert n.value == 11 + 4 * 3 and out[0] == 3 and out[1] > 0 and out[5] == 8
+    assert out[9 + 4 * 3] in (0.0, 1.0) and out[10 + 4 * 3] >= 0   # ownership of the last geometry; late-bound event waits
     assert 0 < out[8 + 4 * 3] <= out[1]                            # host enqueue time of that call <= its wall time
     assert all(out[8 + 4 * i] > 0 for i in range(3))              # every rank did trailing updates
     assert sum(out[10 + 4 * i] for i in range(3)) == 8             # the 8 panels were factored exactly once
@@ -510,6 +511,9 @@ def test_structural_zeros_on_the_sharded_factorisation(monkeypatch, nranks):
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
             monkeypatch.setenv("SGP_STRUCT_ZEROS", sz)
+            # (one ownership for both runs: the balanced table of round 5 is built from the pattern, so it differs between
+            # skipping on and off, and posterior / rand add per-rank partial sums in rank order)
+            monkeypatch.setenv("SGP_MULTI_OWNERS", "cyclic")
             ctx = P.lib.Context(devices=[0] * nranks)
             outs.append(_with_ctx(ctx, run))
             _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
@@ -519,3 +523,93 @@ def test_structural_zeros_on_the_sharded_factorisation(monkeypatch, nranks):
         for k in outs[0]:
             assert np.array_equal(outs[0][k], outs[1][k]), (env, k)
         assert abs(outs[0]["lp"][0] - ref) <= 1e-10 * abs(ref)
+
+
+# ---- round 5: who owns which panel --------------------------------------------------------------------------------------
+def _stats(ctx, nranks):
+    import ctypes as C
+    out = np.zeros(11 + 4 * nranks)
+    n = C.c_int64()
+    P.lib.check(ctx.lib.sgp_ctx_multi_stats(ctx.handle, P.lib.dptr(out), len(out), C.byref(n)))
+    return out
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5, 8])
+def test_any_ownership_table_gives_the_cyclic_deals_bits(monkeypatch, nranks):
+    """Round 5: the panels of the sharded factorisation are dealt out by a table (own_table.h; balanced from the symbolic tile
+    pattern of a structured model, SGP_MULTI_OWNERS = cyclic | balanced | an explicit list).  The factor does not depend on
+    who owns a panel -- every tile sees the same products in the same order -- and logdet / the quadratic forms are added
+    per panel in panel order, so logpdf comes out bit for bit the same for every table: cyclic, balanced, two scrambled
+    lists (one of them with a rank owning consecutive panels and a rank owning none), vector and matrix right-hand sides,
+    whole panels and the sub-panel pipeline, skipping on.  Posterior moments and draws add per-rank partial sums: same values
+    to rounding, checked against the cyclic deal and the oracle."""
+    F, x, xs, y = _problem(3100, D=3)
+    ref = orm.gppp_sum_logpdf(xs, y, 0.1)
+    rng = np.random.default_rng(5)
+    Y = np.asfortranarray(rng.standard_normal((3100, 3)))
+    xs_new = P.BlockData([P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((3, 21)))))])
+    Z = np.asfortranarray(rng.standard_normal((3100, 2)))
+    scr1 = ",".join(str((7 * j + 3) % nranks) for j in range(11))
+    scr2 = ",".join(str(v) for v in ([0, 0, 0] + [nranks - 1] * 2 + list(range(max(1, nranks - 1)))))   # consecutive panels on one rank
+    for env in ({"SGP_MULTI_PANEL": "128"}, {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "128"}):
+        vals, modes, posts = [], [], []
+        for owners in ("cyclic", "balanced", scr1, scr2):
+            for k in ("SGP_MULTI_PANEL", "SGP_MULTI_SUBPANEL"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            monkeypatch.setenv("SGP_MULTI_OWNERS", owners)
+            ctx = P.lib.Context(devices=[0] * nranks)
+
+            def run():
+                fx = F(x, 0.1)
+                lp = P.logpdf(fx, y)
+                mode = _stats(ctx, nranks)[9 + 4 * nranks]
+                lpY = np.asarray(P.logpdf(fx, Y))
+                m, v = P.posterior(fx, y).mean_and_var(xs_new)
+                return lp, mode, lpY, np.asarray(m), np.asarray(v), np.asarray(P.rand(None, fx, 2, Z=Z))
+
+            lp, mode, lpY, m, v, r = _with_ctx(ctx, run)
+            ctx.close()
+            vals.append((lp, lpY))
+            modes.append(mode)
+            posts.append((m, v, r))
+        assert modes[0] == 0 and modes[2] == 2 and modes[3] == 2, modes
+        assert modes[1] in (0.0, 1.0)
+        if env["SGP_MULTI_PANEL"] == "128" and nranks >= 3:
+            assert modes[1] == 1.0   # 25 panels of a model with a zero block: the table is built (and differs from the deal)
+        for lp, lpY in vals[1:]:
+            assert lp == vals[0][0] and np.array_equal(lpY, vals[0][1]), (env, vals)
+        assert abs(vals[0][0] - ref) <= 1e-10 * abs(ref)
+        for m, v, r in posts[1:]:
+            np.testing.assert_allclose(m, posts[0][0], rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(v, posts[0][1], rtol=1e-9, atol=1e-11)
+            np.testing.assert_allclose(r, posts[0][2], rtol=1e-9, atol=1e-10)
+
+
+def test_balanced_table_is_what_a_structured_model_gets_by_default(monkeypatch):
+    """The default ownership of a structured model is the balanced table (stats slot 9 + 4 P = 1), of a dense model and under
+    SGP_MULTI_OWNERS=cyclic the cyclic deal (0); every panel is factored exactly once either way.  (What the table does to the
+    per-rank work is checked on the host, tests/own_table_host.cpp, and measured: profiles/r05_projection_target_*.)"""
+    monkeypatch.setenv("SGP_MULTI_PANEL", "128")
+    F, x, xs, y = _problem(6000, D=3)
+    rng = np.random.default_rng(0)
+    xd = P.ColVecs(np.asfortranarray(rng.standard_normal((3, 6000))))
+    fd = P.atomic(P.GP(P.SEKernel()), P.GPC())
+    mode = {}
+    for owners in ("cyclic", "balanced", None):
+        if owners is None:
+            monkeypatch.delenv("SGP_MULTI_OWNERS", raising=False)
+        else:
+            monkeypatch.setenv("SGP_MULTI_OWNERS", owners)
+        ctx = P.lib.Context(devices=[0] * 4)
+        v = _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
+        st = _stats(ctx, 4)
+        assert sum(st[10 + 4 * i] for i in range(4)) == 47          # every panel factored exactly once
+        mode[owners] = st[9 + 4 * 4]
+        if owners is None:
+            assert abs(v - P.logpdf(F(x, 0.1), y)) <= 1e-11 * abs(v)
+            _with_ctx(ctx, lambda: P.logpdf(fd(xd, 0.1), y))
+            assert _stats(ctx, 4)[9 + 4 * 4] == 0                   # one block: nothing to balance against
+        ctx.close()
+    assert mode["cyclic"] == 0 and mode["balanced"] == 1 and mode[None] == 1

@@ -187,7 +187,7 @@ def test_reordering_the_blocks_restores_the_skipping(monkeypatch):
     y = rng.standard_normal(3 * n)
     noise = 0.2 + 0.1 * rng.random(3 * n)
     perm = P.fill_reducing_order(F, x)
-    x2, (y2, noise2) = P.permute_blocks(x, perm, y, noise)
+    x2, (y2,), noise2 = P.permute_blocks(x, perm, y, noise=noise)
     t = P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((2, 20)))))
     ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0, SGP_STRUCT_ZEROS=1)
     lp = _with_ctx(ctx, lambda: P.logpdf(F(x, noise), y))
