@@ -135,6 +135,23 @@ const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N);
  * products are exact zeros: the factor keeps its bits; the reference's LAPACK path multiplies them out).
  * SGP_STRUCT_ZEROS=0 switches the skipping off.  Dense noise, a single block or a pattern without zeros: executed == dense. */
 int sgp_ctx_factor_work(sgp_ctx* ctx, double* executed, double* dense);
+/* WHICH tiles of the factor are structurally zero depends on the order of the blocks in the caller's BlockData, as for
+ * any sparse direct solver: f3 = f1 + f2 observed as (f1, f2, f3) keeps the (f2, f1) block of the factor zero, (f3, f1, f2)
+ * fills it in and the factorisation silently takes the dense time.  The library never permutes (the factor's layout is
+ * part of what `posterior` keeps and `rand` multiplies a draw with); this entry point tells ANY host a good order: greedy
+ * minimum fill on the block graph of a symmetric spec (two blocks are adjacent when their pair has terms), fill weighted
+ * by block lengths, ties: the shorter block first, then the caller's order.  perm_out[k] = index of the block to put at
+ * position k (n_row_blocks entries); *changes (may be NULL) = 1 when the suggested order would skip more than the given
+ * one.  logpdf, posterior moments and the ELBO do not depend on the order of the observations beyond rounding; the caller
+ * applies the permutation to its blocks, y, mean and noise (the Python mirror: stheno.jl_amd/ordering.py permute_blocks;
+ * julia/SthenoMI355X.jl: logpdf).  Host-only: no context, no GPU work.  No reference analogue (Stheno builds the dense
+ * matrix and LAPACK factors it whatever the order). */
+int sgp_cov_spec_suggest_order(const sgp_cov_spec* spec, int32_t* perm_out, int32_t* changes);
+/* Ownership and event-binding figures of sgp_ctx_multi_stats (below) when cap >= 11 + 4 * ranks: two more doubles after the
+ * enqueue time -- how the panels of the last sharded factorisation were dealt out (0 cyclic, 1 the balanced table built from
+ * the symbolic tile pattern of a structured model: one panel per rank and round, heaviest panel to the least loaded rank,
+ * csrc/own_table.h; 2 an explicit list, SGP_MULTI_OWNERS=r0,r1,...; SGP_MULTI_OWNERS=cyclic|balanced chooses) and how many
+ * cross-thread event waits bound to a later record than the schedule named (cumulative; diagnostic). */
 /* Figures of the last sharded factorisation of a multi-GPU context: out[0] ranks, [1] wall ms (enqueue to
  * completion), [2] transport (0 loopback, 1 peer copies, 2 RCCL), [3] ranks the RCCL communicator reports (-1: none),
  * [4] panel width (of the first part; the tail may be narrower), [5] panels, [6] 1 = scatter + all-gather peer copies,

@@ -139,6 +139,27 @@ function build_spec(f, x, f2 = f, x2 = nothing)
     return Spec(c, Any[rp, cp, inputs, cin, terms, tptr, rl, cl], sum(rl), sum(cl))
 end
 
+# ---- block order (round 5) ----------------------------------------------------------------------
+# WHICH tiles of the factor are structurally zero depends on the order of the blocks of the BlockData (f3 = f1 + f2 observed
+# as (f3, f1, f2) fills the factor in and the factorisation silently takes the dense time).  The library suggests a
+# fill-reducing order (sgp_cov_spec_suggest_order: greedy minimum fill on the block graph; host-only, no GPU work);
+# logpdf -- whose value does not depend on the order of the observations beyond rounding -- applies it to the blocks, y,
+# the mean and the noise.  `rand` and `posterior` keep the caller's order: the factor's layout is part of their results.
+function suggest_order(sp::Spec)
+    nb = Int(sp.c.n_row_blocks); perm = zeros(Int32, nb); ch = Ref{Int32}(0)
+    GC.@preserve sp perm check(ccall((:sgp_cov_spec_suggest_order, LIB), Cint, (Ref{CSpec}, Ptr{Int32}, Ref{Int32}),
+        sp.c, perm, ch))
+    return Int.(perm) .+ 1, ch[] != 0
+end
+# the observation indices of the blocks of x in the order `perm` (one range per block, block lengths from the spec)
+function block_permutation(sp::Spec, perm)
+    rl = sp.keep[7]; offs = cumsum(vcat(0, rl))
+    return reduce(vcat, [collect((offs[b] + 1):offs[b + 1]) for b in perm])
+end
+permute_noise(Σ::AbstractGPs.ScalMat, idx) = Σ
+permute_noise(Σ::Diagonal, idx) = Diagonal(diag(Σ)[idx])
+permute_noise(Σ::AbstractMatrix, idx) = Σ[idx, idx]
+
 noise_args(Σ::AbstractGPs.ScalMat) = (0, [Σ.value])          # f(x, s2)   (and the 1e-18 default)
 noise_args(Σ::Diagonal) = (1, collect(Float64, diag(Σ)))     # f(x, v)
 noise_args(Σ::AbstractMatrix) = (2, Matrix{Float64}(Σ))      # f(x, S)
@@ -146,7 +167,15 @@ noise_args(Σ::AbstractMatrix) = (2, Matrix{Float64}(Σ))      # f(x, S)
 # ---- operator surface ------------------------------------------------------------------------
 function logpdf(fx::SthenoFGP, Y::AbstractMatrix{<:Real})
     sp = build_spec(fx.f, fx.x); m = collect(Float64, mean(fx.f, fx.x))
-    kind, nz = noise_args(fx.Σy); Yd = Matrix{Float64}(Y); out = zeros(size(Yd, 2))
+    Σ = fx.Σy; Yd = Matrix{Float64}(Y)
+    if fx.x isa BlockData && !(Σ isa AbstractMatrix && !(Σ isa Diagonal) && !(Σ isa AbstractGPs.ScalMat))
+        perm, changes = suggest_order(sp)            # a dense Σy has no structural zeros to keep: left alone
+        if changes                                   # a fill-reducing block order: same value, the skipped tile products back
+            idx = block_permutation(sp, perm)
+            sp = build_spec(fx.f, BlockData(fx.x.X[perm])); m = m[idx]; Yd = Yd[idx, :]; Σ = permute_noise(Σ, idx)
+        end
+    end
+    kind, nz = noise_args(Σ); out = zeros(size(Yd, 2))
     GC.@preserve sp m nz Yd out check(ccall((:sgp_logpdf, LIB), Cint,
         (Ptr{Cvoid}, Ref{CSpec}, Ptr{Float64}, Cint, Ptr{Float64}, Ptr{Float64}, Int64, Int64, Ptr{Float64}),
         ctx(), sp.c, m, kind, nz, Yd, size(Yd, 1), size(Yd, 2), out))

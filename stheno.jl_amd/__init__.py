@@ -20,4 +20,4 @@ from .finite_gp import (VFE, ApproxPosteriorGP, FiniteGP, PosteriorGP, SparseFin
                         cov, elbo, elbo_and_gradient, logpdf, logpdf_and_gradient, logpdf_f32, marginals, mean, mean_and_cov, mean_and_var,
                         posterior, posterior_mean_and_var_f32, prior_cov, prior_mean, prior_var, rand, sparse_cov, var)
 from .flatten import build_spec  # noqa: F401
-from .ordering import block_atoms, fill_reducing_order, permute_blocks  # noqa: F401
+from .ordering import block_atoms, fill_reducing_order, permute_blocks, suggest_order_capi  # noqa: F401

@@ -720,6 +720,70 @@ extern "C" int sgp_ctx_factor_work(sgp_ctx* ctx, double* executed, double* dense
   *dense = ctx->sz_dense;
   return 0;
 }
+// A block order that keeps the factor sparse (sthenomi.h): greedy minimum fill on the block graph, host only.
+extern "C" int sgp_cov_spec_suggest_order(const sgp_cov_spec* sp, int32_t* perm_out, int32_t* changes) {
+  CHECK_ARG(sp && perm_out, "sgp_cov_spec_suggest_order: NULL argument");
+  CHECK_ARG(sp->symmetric && sp->n_row_blocks == sp->n_col_blocks && sp->n_row_blocks >= 1,
+            "sgp_cov_spec_suggest_order: the spec must be symmetric (cov(f, x))");
+  const int nb = sp->n_row_blocks;
+  std::vector<std::vector<char>> adj((size_t)nb, std::vector<char>((size_t)nb, 0));
+  for (int I = 0; I < nb; ++I)
+    for (int J = 0; J < nb; ++J) {
+      const int p = I * nb + J, q = J * nb + I;
+      if (I != J && (sp->term_ptr[p + 1] > sp->term_ptr[p] || sp->term_ptr[q + 1] > sp->term_ptr[q])) adj[(size_t)I][(size_t)J] = 1;
+    }
+  // weighted fill of eliminating the blocks in a given order (what the order costs: lengths of the block pairs that fill in)
+  auto total_fill = [&](const std::vector<int>& order) {
+    std::vector<std::vector<char>> a = adj;
+    std::vector<char> gone((size_t)nb, 0);
+    double fill = 0;
+    for (int v : order) {
+      for (int x = 0; x < nb; ++x)
+        for (int y = x + 1; y < nb; ++y)
+          if (!gone[(size_t)x] && !gone[(size_t)y] && x != v && y != v && a[(size_t)v][(size_t)x] && a[(size_t)v][(size_t)y] &&
+              !a[(size_t)x][(size_t)y]) {
+            a[(size_t)x][(size_t)y] = a[(size_t)y][(size_t)x] = 1;
+            fill += (double)sp->row_len[x] * (double)sp->row_len[y];
+          }
+      gone[(size_t)v] = 1;
+    }
+    return fill;
+  };
+  std::vector<std::vector<char>> a = adj;
+  std::vector<char> left((size_t)nb, 1);
+  std::vector<int> order;
+  for (int step = 0; step < nb; ++step) {
+    int best = -1;
+    double best_fill = 0;
+    for (int v = 0; v < nb; ++v) {
+      if (!left[(size_t)v]) continue;
+      double fill = 0;
+      for (int x = 0; x < nb; ++x)
+        for (int y = x + 1; y < nb; ++y)
+          if (left[(size_t)x] && left[(size_t)y] && x != v && y != v && a[(size_t)v][(size_t)x] && a[(size_t)v][(size_t)y] &&
+              !a[(size_t)x][(size_t)y])
+            fill += (double)sp->row_len[x] * (double)sp->row_len[y];
+      const bool better = best < 0 || fill < best_fill || (fill == best_fill && sp->row_len[v] < sp->row_len[best]);
+      if (better) {
+        best = v;
+        best_fill = fill;
+      }
+    }
+    for (int x = 0; x < nb; ++x)
+      for (int y = x + 1; y < nb; ++y)
+        if (left[(size_t)x] && left[(size_t)y] && x != best && y != best && a[(size_t)best][(size_t)x] && a[(size_t)best][(size_t)y])
+          a[(size_t)x][(size_t)y] = a[(size_t)y][(size_t)x] = 1;
+    left[(size_t)best] = 0;
+    order.push_back(best);
+  }
+  for (int k = 0; k < nb; ++k) perm_out[k] = order[(size_t)k];
+  if (changes) {
+    std::vector<int> ident((size_t)nb);
+    for (int k = 0; k < nb; ++k) ident[(size_t)k] = k;
+    *changes = total_fill(order) < total_fill(ident) ? 1 : 0;
+  }
+  return 0;
+}
 extern "C" const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N) {
   if (!ctx || N < 1) return "";
   const long n_pad = rup(N, TILE);

@@ -76,6 +76,7 @@ _SIGS = {
     "sgp_ctx_transport": (C.c_char_p, [_P]),
     "sgp_ctx_factor_schedule": (C.c_char_p, [_P, C.c_int64]),
     "sgp_ctx_factor_work": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "sgp_cov_spec_suggest_order": (C.c_int, [C.POINTER(sgp_cov_spec), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sgp_ctx_multi_stats": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_ctx_multi_profile": (C.c_int, [_P, C.c_int]),
     "sgp_ctx_multi_profile_get": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),

@@ -55,6 +55,22 @@ def fill_reducing_order(f, x):
 _NO_NOISE = object()
 
 
+def suggest_order_capi(f, x):
+    """The same suggestion through the C-ABI (sgp_cov_spec_suggest_order: what a host without this Python mirror calls --
+    julia/SthenoMI355X.jl does): (perm, changes) with changes = True when the suggested order skips more than the given one.
+    Host-only arithmetic inside the library: no GPU, no context."""
+    import ctypes as C
+
+    from . import lib as _lib
+    from .finite_gp import _prior_spec
+    spec = _prior_spec(f, x)
+    nb = len(spec.row_len)
+    perm = (C.c_int32 * nb)()
+    ch = C.c_int32()
+    _lib.check(_lib.load().sgp_cov_spec_suggest_order(spec.ref(), perm, C.byref(ch)), "sgp_cov_spec_suggest_order")
+    return [int(v) for v in perm], bool(ch.value)
+
+
 def permute_blocks(x, perm, *vectors, noise=_NO_NOISE):
     """x with its blocks in the order `perm`, and every vector of per-observation values (observations y, a diagonal of
     noise variances; scalars and None pass through; an N x S matrix is permuted by rows) reordered with it.

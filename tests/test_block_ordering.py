@@ -95,3 +95,35 @@ def test_values_do_not_depend_on_the_order(monkeypatch):
     assert P.permute_blocks(x, perm, noise=0.3)[2] == 0.3
     with pytest.raises(ValueError):
         P.permute_blocks(x, perm, S)
+
+
+def test_the_c_abi_suggests_the_same_order_as_the_python_mirror():
+    """sgp_cov_spec_suggest_order (round 5: the helper lives in the library, where every host gets it) against
+    fill_reducing_order on the sum model from every starting order, the star of sums, and random programmes of sums of
+    random subsets of atoms with ragged block sizes.  Host-only arithmetic: runs without a GPU."""
+    F = P.gppp_sum_model()
+    rng = np.random.default_rng(3)
+    xs = {k: P.ColVecs(np.asfortranarray(rng.standard_normal((2, n)))) for k, n in (("f1", 30), ("f2", 40), ("f3", 25))}
+    for order in (("f1", "f2", "f3"), ("f3", "f1", "f2"), ("f2", "f3", "f1"), ("f3", "f2", "f1")):
+        x = P.BlockData([P.GPPPInput(k, xs[k]) for k in order])
+        perm, changes = P.suggest_order_capi(F, x)
+        assert perm == P.fill_reducing_order(F, x)
+        assert changes == (_fill(P.block_atoms(F, x), list(range(3))) > 0)
+    for trial in range(25):
+        gpc = P.GPC()
+        na = int(rng.integers(2, 5))
+        atoms = [P.atomic(P.GP(P.SEKernel()), gpc) for _ in range(na)]
+        procs = {}
+        for j in range(int(rng.integers(2, 7))):
+            pick = [a for a in atoms if rng.random() < 0.5] or [atoms[int(rng.integers(na))]]
+            g = pick[0]
+            for a in pick[1:]:
+                g = g + a
+            procs[f"p{j}"] = g
+        Fm = P.GPPP(procs, gpc)
+        x = P.BlockData([P.GPPPInput(k, rng.standard_normal(int(rng.integers(3, 30)))) for k in procs])
+        perm, changes = P.suggest_order_capi(Fm, x)
+        ref = P.fill_reducing_order(Fm, x)
+        assert perm == ref, (trial, perm, ref)
+        at = P.block_atoms(Fm, x)
+        assert _fill(at, perm) <= _fill(at, list(range(len(at))))
