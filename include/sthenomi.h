@@ -161,6 +161,9 @@ int sgp_cov_spec_suggest_order(const sgp_cov_spec* spec, int32_t* perm_out, int3
  * thread spent issuing that factorisation (everything is asynchronous: it must stay below the wall time).  *n_out =
  * doubles written. */
 int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out);
+/* Which rank owns which column panel of the last sharded factorisation: out[J] = rank of panel J (*n_out = panels; out may
+ * be NULL to ask for the count).  Diagnosis / tools/multi_projection.py. */
+int sgp_ctx_multi_owners(sgp_ctx* ctx, int32_t* out, int64_t cap, int64_t* n_out);
 /* Profile mode (enable != 0): the following sharded factorisations run SERIALISED, every group of launches alone on
  * the hardware and timed on the host -- per panel J {factor_ms, lookahead_update_ms, panel bytes, then for rank
  * 0 .. P - 1 the three update classes of step J: near_a_ms, near_b_ms, far_ms} (3 + 3 P doubles; csrc/multi.hip explains

@@ -176,6 +176,7 @@ struct sgp_multi {
   bool own_balanced = true;
   std::vector<int> own_list;
   int own_mode = 0;
+  std::vector<int> last_own;   // owner of every panel of the last geometry (sgp_ctx_multi_owners)
   std::atomic<long> late_binds{0};   // Exec::wait: records that had been re-recorded by the time the wait was enqueued
   Rccl rccl;
   double last_ms = 0.0;
@@ -285,6 +286,7 @@ Geometry make_geometry(sgp_multi* m, long N, long S, const sgp_cov_spec* spec = 
     }
   }
   g.set_owners(own);
+  m->last_own = own;
   return g;
 }
 
@@ -585,6 +587,17 @@ extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64
     out[9 + 4 * P] = (double)m->own_mode;
     out[10 + 4 * P] = (double)m->late_binds.load();
     *n_out = 11 + 4 * P;
+  }
+  return 0;
+}
+
+extern "C" int sgp_ctx_multi_owners(sgp_ctx* ctx, int32_t* out, int64_t cap, int64_t* n_out) {
+  M_CHECK_ARG(ctx && ctx->multi && n_out, "sgp_ctx_multi_owners: not a multi-GPU context");
+  const auto& v = ctx->multi->last_own;
+  *n_out = (int64_t)v.size();
+  if (out) {
+    M_CHECK_ARG(cap >= (int64_t)v.size(), "sgp_ctx_multi_owners: buffer too small");
+    for (size_t J = 0; J < v.size(); ++J) out[J] = v[J];
   }
   return 0;
 }

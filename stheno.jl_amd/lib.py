@@ -78,6 +78,7 @@ _SIGS = {
     "sgp_ctx_factor_work": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sgp_cov_spec_suggest_order": (C.c_int, [C.POINTER(sgp_cov_spec), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "sgp_ctx_multi_stats": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
+    "sgp_ctx_multi_owners": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_ctx_multi_profile": (C.c_int, [_P, C.c_int]),
     "sgp_ctx_multi_profile_get": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_ctx_destroy": (C.c_int, [_P]),

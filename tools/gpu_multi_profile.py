@@ -37,9 +37,13 @@ def call():
 
 call()                       # warm-up (allocations)
 overlapped_ms = call()       # the normal (overlapped) schedule with P ranks sharing the one GPU
-st = np.zeros(9 + 4 * P)
+st = np.zeros(11 + 4 * P)
 n = C.c_int64()
 L.check(ctx.lib.sgp_ctx_multi_stats(ctx.handle, L.dptr(st), len(st), C.byref(n)))
+L.check(ctx.lib.sgp_ctx_multi_owners(ctx.handle, None, 0, C.byref(n)))
+own = (C.c_int32 * n.value)()
+L.check(ctx.lib.sgp_ctx_multi_owners(ctx.handle, own, n.value, C.byref(n)))
+owners = [int(v) for v in own]
 L.check(ctx.lib.sgp_ctx_multi_profile(ctx.handle, 1))
 serial_ms = call()
 L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, None, 0, C.byref(n)))
@@ -57,7 +61,8 @@ for b in prof[:, 2]:                       # panel bytes = 8 * (m_tot - col0) * 
     c0 += w
 nsub = [min(8, -(-w // sub)) if sub >= 128 else 1 for w in widths]
 json.dump({"config": cfg, "N": N, "ranks": P, "panel_width": int(st[4]), "panels": int(st[5]), "group": int(st[7]),
-           "subpanel": sub, "widths": widths, "nsub": nsub,
+           "subpanel": sub, "widths": widths, "nsub": nsub, "owners": owners,
+           "ownership": {0: "cyclic", 1: "balanced", 2: "list"}.get(int(st[9 + 4 * P]), "?"),
            "layout": "per panel: factor_ms, lookahead_update_ms, panel_bytes, then per rank near_a_ms, near_b_ms, far_ms",
            "logpdf": float(res[0]), "parity_rel": None if g is None else abs(res[0] - g["logpdf"]) / abs(g["logpdf"]),
            "one_gpu_overlapped_ms": overlapped_ms, "one_gpu_serialised_ms": serial_ms, "host_enqueue_ms": float(st[8 + 4 * P]),

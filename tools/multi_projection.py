@@ -42,7 +42,8 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
             return 2.0 * b / ((P - 1) * link_gbps * 1e9) * 1e3
         return b / (link_gbps * 1e9) * 1e3
 
-    owner = lambda J: J % P
+    owners = prof.get("owners")       # round 5: the ownership table of the run (own_table.h); older profiles: the cyclic deal
+    owner = (lambda J: owners[J]) if owners else (lambda J: J % P)
     t_upd = [0.0] * P      # the update stream of rank i is free
     t_near = [0.0] * P     # the near stream
     t_pan = [0.0] * P      # the panel stream
@@ -144,6 +145,14 @@ def main():
     print(f"panel factorisations {sum(r[0] for r in rows):.1f} ms, look-ahead updates {sum(r[1] for r in rows):.1f} ms, "
           f"bytes per receiver {sum(r[2] for r in rows) / 1e9:.2f} GB")
     print("updates per rank, ms (near a / near b / far): " + "  ".join("%.1f/%.1f/%.1f" % tuple(v) for v in per_rank))
+    owners = prof.get("owners") or [J % P for J in range(len(rows))]
+    tot = [sum(per_rank[i]) + sum(r[0] + r[1] for J, r in enumerate(rows) if owners[J] == i) for i in range(P)]
+    upd = [sum(v) for v in per_rank]
+    mean_u, mean_t = sum(upd) / P, sum(tot) / P
+    print(f"panel ownership: {prof.get('ownership', 'cyclic')}; update sums per rank {min(upd):.1f} .. {max(upd):.1f} ms "
+          f"({100 * (min(upd) / mean_u - 1):+.1f} % / {100 * (max(upd) / mean_u - 1):+.1f} % of their mean {mean_u:.1f}); all work per "
+          f"rank (updates + its panels' factorisations and look-ahead updates) {min(tot):.1f} .. {max(tot):.1f} ms "
+          f"({100 * (min(tot) / mean_t - 1):+.1f} % / {100 * (max(tot) / mean_t - 1):+.1f} %)")
     for form in ("allgather", "direct"):
         for c in sorted({contend, 1.0, 1.3}):
             t, w, b = project(prof, P, link, form, c)
