@@ -53,7 +53,8 @@ prof = prof.reshape(-1, 3 + 3 * P)
 g = bc.golden(cfg)
 n_pad = (N + 127) // 128 * 128
 m_tot = n_pad + 128
-sub = int(os.environ.get("SGP_MULTI_SUBPANEL", "256")) // 128 * 128
+sub = int(os.environ.get("SGP_MULTI_SUBPANEL", "512")) // 128 * 128   # (the library's default, multi.hip: sgp_multi::sub; round 4
+# recorded 256 here while the library ran 512: its projections modelled a 4-deep pipeline where 2 pieces travelled)
 widths, c0 = [], 0
 for b in prof[:, 2]:                       # panel bytes = 8 * (m_tot - col0) * width
     w = int(round(b / 8.0 / (m_tot - c0)))
