@@ -466,7 +466,7 @@ def main():
                      "chain sgp::panel_solve_kernel (14 us) -> sgp::gemm_nt_dma_potrf_kernel<0, true> (K = 128 tile update + "
                      "potrf_diag of the next diagonal block, 50 us) per 128 columns") if n_launch == 0 else
                     ("achieved = (N^3 / 3 + N^2) flops / the Cholesky stage (HIP events around the one launch); SGP_DF_STATS=1 "
-                     "prints the per-workgroup time split and the per-column chain (profiles/r03_dataflow.md)") if dataflow else None,
+                     "prints the per-workgroup time split and the per-column chain (profiles/archive/r03_dataflow.md)") if dataflow else None,
             "schedule": schedule,
             "launches": n_launch, "avg_launch_ms": upd_ms / max(1, n_launch),
             "algorithmic_flops_per_launch_avg": upd_flops / max(1, n_launch),

@@ -683,7 +683,7 @@ static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, lo
                           d_invstore ? d_invstore + (c / TILE) * INVD_STRIDE : nullptr, s, fuse_mid, wmid);
 }
 
-// Which schedule factors n_pad columns (measured on MI355X, profiles/r03_dataflow.md; Matern-5/2, D = 8, whole logpdf):
+// Which schedule factors n_pad columns (measured on MI355X, profiles/archive/r03_dataflow.md; Matern-5/2, D = 8, whole logpdf):
 //   n_pad <  3072            launches (one outer panel; the dataflow chain of 68 us per 128 columns loses to the fused
 //                            launches' 62: N = 2048 1.18 vs 1.25 ms)
 //   3072 <= n_pad < 24576    dataflow, one workgroup per CU (256 VGPRs: no spills in the chain tasks, and a chain task never
@@ -691,7 +691,7 @@ static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, lo
 //   24576 <= n_pad < 65536   dataflow, two workgroups per CU (the contractions are the work): 32768 218.7 -> 204.8 ms
 //   n_pad >= 65536           launches, serial schedule with deep outer blocking: the lock-step trailing updates share
 //                            every operand k slice through L2, the desynchronised contractions of the dataflow kernel
-//                            stream theirs from HBM and the clock pays for it (-11 %, profiles/r03_experiments/)
+//                            stream theirs from HBM and the clock pays for it (-11 %, profiles/archive/r03_experiments/)
 // SGP_DATAFLOW = 0 / 1 forces never / always; SGP_DF_MIN_N, SGP_DF_MAX_N, SGP_DF_FAT_MAX_N move the limits.
 // Task order of the dataflow kernel: XCD-affine queues (1) or column-major ids (0); the patch a queue deals out.
 // Default: column-major.  Round 4 measured the queues (profiles/r04_experiments/dataflow_xcd_queues.md): handing a queue's
@@ -961,7 +961,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
     }
     return 0;
   }
-  // outer panel width, measured (profiles/r02_summary.md): one panel for n_pad <= 4096 (the outer level only
+  // outer panel width, measured (profiles/archive/r02_summary.md): one panel for n_pad <= 4096 (the outer level only
   // adds launches there: 1.52 -> 1.30 ms at N = 2048; with the fused diagonal blocks 2.73 -> 2.47 ms at N = 4096),
   // 1024 up to 8192, 512 in the
   // mid range where the panel stream is the critical path (N = 16384: 34.8 vs 35.4 ms), 1024 from 32768 on
@@ -992,7 +992,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // column update, or the whole update when the look-ahead is off) factors that block in the same launch
   // Both apply while n_pad < SGP_FUSE_MAX_N (32768), where the panel chain is the critical path: N = 2048 1.17 ->
   // 1.09 ms, 4096 2.93 -> 2.73 ms, 16384 33.8 -> 33.2 ms; from 32768 on the panel stream has slack and the fused
-  // launches measure the same or 1 % slower (profiles/r02_microbench.md).  Bit 2: at every size (A/B).
+  // launches measure the same or 1 % slower (profiles/archive/r02_microbench.md).  Bit 2: at every size (A/B).
   FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad, !la));
   const bool fuse_outer = (ctx->fuse_now & 2) && ctx->refine == 1;
   bool first_done = false;

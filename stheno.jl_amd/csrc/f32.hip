@@ -11,7 +11,7 @@
 //   diagonal block + row solve: the fp64 path's potrf_diag / panel_solve kernels instantiated on fp32 storage
 //                           (potrf.hip: values converted while they are read and written, arithmetic in fp64) --
 //                           fp32 kernels of their own took 75 + 60 us per 128 columns against 33 + 17 us, and
-//                           made N <= 16384 slower than fp64 (profiles/r02_microbench.md)
+//                           made N <= 16384 slower than fp64 (profiles/archive/r02_microbench.md)
 // Driver: two-level right-looking Cholesky (outer panels, 128-column steps inside) with the fp64 driver's
 // one-panel look-ahead on two streams.
 // Entry points: sgp_logpdf_f32, sgp_kernelmatrix_f32, sgp_rand_f32, sgp_posterior_mean_var_f32 (include/sthenomi.h).  Accuracy is fp32's: the

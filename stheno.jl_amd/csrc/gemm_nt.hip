@@ -1,6 +1,6 @@
 // fp64 MFMA GEMM kernels for gfx950.
 //
-// Instruction choice (measured on MI355X, profiles/r01_microbench.md): v_mfma_f64_16x16x4_f64
+// Instruction choice (measured on MI355X, profiles/archive/r01_microbench.md): v_mfma_f64_16x16x4_f64
 // issues only every ~96 cycles per SIMD (49 TF/s chip-wide, 62 % of the 78.6 TF/s datasheet
 // rate) while the 4-block v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (72-75 TF/s).
 // The GEMMs therefore run on the 4x4x4 form.  Its lane maps (probed on hardware,
