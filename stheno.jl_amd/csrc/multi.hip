@@ -173,7 +173,6 @@ struct sgp_multi {
   int ring = 10;            // receive buffers per rank: 2 * group + 2
   // panel ownership (own_table.h; make_geometry): balanced from the model's tile pattern unless SGP_MULTI_OWNERS says
   // "cyclic" or gives an explicit list; own_mode = what the last geometry used (0 cyclic, 1 balanced table, 2 list)
-  bool near_window = true;   // G = 1: the panel after next is updated by a launch of its own, ahead of the far launch (SGP_MULTI_NEAR=0: off)
   bool own_balanced = true;
   std::vector<int> own_list;
   int own_mode = 0;
@@ -435,7 +434,6 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
       }
     }
   }
-  if (const char* nw = getenv("SGP_MULTI_NEAR")) m->near_window = atoi(nw) != 0;
   const char* sp = getenv("SGP_MULTI_SUBPANEL");
   if (sp) m->sub = atol(sp) / TILE * TILE;
   m->r.resize(ndev);
@@ -1000,7 +998,6 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     wq = (q == ns - 1) ? g.width(J) - c : SUB;   // (more than NSUB sub-panels: the last takes the rest)
   };
   const long G = m->group;
-  const bool NW = G == 1 && m->near_window;   // the panel after next in a near launch of its own (see the sweep)
   auto group_of = [&](long J) { return J / G; };
   // ---- the schedule from the first panel's factorisation to the last row sums, as ONE function of who executes it
   auto run = [&](Exec& x) -> int {
@@ -1089,9 +1086,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         if (nxt % G == 0 || J % G == 0) M_RC(x.wait(o1, k.s_panel, k.ev_B));
         // ... and, before those, the far update with the group two before its own (long done unless G = 1, where that is
         // the previous step's launch)
-        // (G = 1: the previous step's near-A launch brought panel nxt up to panel J - 1, the far launches up to step J - 2 did the
-        // rest -- ev_B of the previous step is recorded behind far(J - 2) on the in-order update stream: nothing else to wait for)
-        if (!NW && group_of(nxt) >= 2) M_RC(x.wait(o1, k.s_panel, k.ev_far[(group_of(nxt) - 2) % Rank::NGEV]));
+        if (group_of(nxt) >= 2) M_RC(x.wait(o1, k.s_panel, k.ev_far[(group_of(nxt) - 2) % Rank::NGEV]));
         double t0 = 0, t1 = 0;
         if (prof) {
           M_RC(sync_all(m));
@@ -1138,14 +1133,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         for (long Jp : g.mine[(size_t)i]) {
           if (Jp <= nxt) continue;
           const long gp = group_of(Jp);
-          if (NW) {
-            // Round 5, one panel per group: the panel AFTER next gets panel J in a launch of its own on the near stream, ahead of
-            // the rest -- the look-ahead of the following step then waits for that small launch instead of for this rank's
-            // whole far launch (which made the structured north-star model chain-bound once the ranks were balanced:
-            // factor -> transport -> far launch of the next owner -> look-ahead -> factor ...)
-            if (Jp == nxt + 1) near_a.push_back(Jp);
-            else far.push_back(Jp);
-          } else if (gp == gj) near_a.push_back(Jp);
+          if (gp == gj) near_a.push_back(Jp);
           else if (gp == gj + 1) near_b.push_back(Jp);
           else if (group_ends) far.push_back(Jp);
         }
@@ -1172,10 +1160,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         // previous step) must be done -- ev_B is recorded BEFORE a far update, so this never waits for one.
         if (!near_a.empty()) {
           M_RC(wait_panel(x, F, J, i, k.s_near));
-          if (NW) {
-            // the panel after next was in the far launch of the previous step: that launch is done
-            if (J >= 1) M_RC(x.wait(i, k.s_near, k.ev_far[(J - 1) % Rank::NGEV]));
-          } else if (J % G == 0) {
+          if (J % G == 0) {
             M_RC(x.wait(i, k.s_near, k.ev_B));
             if (gj >= 2) M_RC(x.wait(i, k.s_near, k.ev_far[(gj - 2) % Rank::NGEV]));
           }

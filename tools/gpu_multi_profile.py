@@ -63,7 +63,6 @@ for b in prof[:, 2]:                       # panel bytes = 8 * (m_tot - col0) * 
 nsub = [min(8, -(-w // sub)) if sub >= 128 else 1 for w in widths]
 json.dump({"config": cfg, "N": N, "ranks": P, "panel_width": int(st[4]), "panels": int(st[5]), "group": int(st[7]),
            "subpanel": sub, "widths": widths, "nsub": nsub, "owners": owners,
-           "near_window": os.environ.get("SGP_MULTI_NEAR", "1") != "0",   # round 5 (G = 1): the panel after next in a launch of its own
            "ownership": {0: "cyclic", 1: "balanced", 2: "list"}.get(int(st[9 + 4 * P]), "?"),
            "layout": "per panel: factor_ms, lookahead_update_ms, panel_bytes, then per rank near_a_ms, near_b_ms, far_ms",
            "logpdf": float(res[0]), "parity_rel": None if g is None else abs(res[0] - g["logpdf"]) / abs(g["logpdf"]),

@@ -91,10 +91,6 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
             arr.append(link_free)
         return t, arr
 
-    # round 5, G = 1: the panel after next is updated by a launch of its own on the near stream (near A); the look-ahead
-    # waits for that launch and for the far launch two steps back, near A for the previous step's far launch
-    far_end = [[0.0] * (npan + 2) for _ in range(P)]     # far_end[i][J + 1] = completion of rank i's far launch of step J
-    new_g1 = G == 1 and bool(prof.get("near_window", True))
     fact_done, arr = factor_and_send(0, 0.0, 1.0)
     recv = [fact_done if i == owner(0) else arr[-1] for i in range(P)]
     waited = 0.0
@@ -103,10 +99,7 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
         new_recv = None
         if nxt < npan:
             o = owner(nxt)
-            if new_g1:
-                ready = max(ev_a[o], far_end[o][J - 1] if J >= 1 else 0.0)   # near A of step J - 1, far of step J - 2
-            else:
-                ready = max(ev_a[o], ev_b[o] if (nxt % G == 0 or J % G == 0) else 0.0)
+            ready = max(ev_a[o], ev_b[o] if (nxt % G == 0 or J % G == 0) else 0.0)
             loaded = t_upd[o] > recv[o] or t_near[o] > recv[o]
             c = contend if loaded else 1.0
             t = ready
@@ -118,10 +111,7 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
         for i in range(P):
             a, b, f = cls[J][i]
             if a > 0:
-                if new_g1:
-                    ev_a[i] = run(i, "near", max(recv[i], far_end[i][J]), a)
-                else:
-                    ev_a[i] = run(i, "near", max(recv[i], ev_b[i] if J % G == 0 else 0.0), a)
+                ev_a[i] = run(i, "near", max(recv[i], ev_b[i] if J % G == 0 else 0.0), a)
             idle_until = max(t_upd[i], t_near[i], t_pan[i])
             if b > 0 or f > 0:
                 waited += max(0.0, recv[i] - idle_until)
@@ -130,9 +120,7 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
             else:
                 ev_b[i] = max(ev_b[i], min(t_upd[i], recv[i]))
             if f > 0:
-                far_end[i][J + 1] = run(i, "upd", recv[i], f)
-            else:
-                far_end[i][J + 1] = max(far_end[i][J], min(t_upd[i], recv[i]))
+                run(i, "upd", recv[i], f)
         if new_recv is not None:
             recv = new_recv
             fact_done = fd
