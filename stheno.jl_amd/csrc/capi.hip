@@ -826,7 +826,7 @@ struct SzScope {   // the launch-based updates read the pattern through gemm_nt.
 static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
                          hipStream_t s, long grow = 0, const SzMask* sz = nullptr) {
   CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
-  if (grow != 0) sz = nullptr;
+  // (grow != 0, the gradient path: the caller's pattern covers the identity rows -- sz_pattern's grad_border form)
   SzScope sz_scope(ctx, A, ld, sz);
   // Dataflow factorisation (chol_df.hip): one launch of persistent workgroups, tile-level dependencies instead of
   // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
@@ -1050,12 +1050,18 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
 // Nothing is returned (dense) for one block, dense noise, or a pattern without zeros.  Also counts the k-block products of
 // the contractions with and without the skipping (ctx->sz_executed / sz_dense: what the bench lines report).
 // sz_pattern: the host part (ctx->h_sz, ctx->sz_executed / sz_dense); returns the words per row through *words, 0 = dense.
-static int sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, int* words) {
+// grad_border (round 5): the matrix is the gradient path's [K ; (y - m)' ; I] (m_tot = 2 n_pad + 128: logpdf_grad_core) -- the
+// identity rows get their own pattern (sz_symbolic: border_identity), and T_c more rows follow the T_r factor rows: row
+// T_r + t = the tiles (t, .) of K itself that overlap a block pair with terms (+ the diagonal), i.e. the tiles of
+// G = (alpha alpha' - C^-1) / 2 the contractions with the kernel derivatives read (TileSkip::need0).
+static int sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_pad, long m_tot, int* words,
+                      bool grad_border = false) {
   *words = 0;
   const long T_c = n_pad / TILE, T_r = m_tot / TILE;
   double dense = 0;
   for (long j = 0; j < T_c; ++j) dense += (double)j * (double)(T_r - j);
   ctx->sz_dense = ctx->sz_executed = dense;
+  if (grad_border && T_r != 2 * T_c + 1) return 0;
   if (!ctx->struct_zeros || !ds->symmetric || noise_kind == SGP_NOISE_DENSE || ds->nrb < 2 || ds->nrb != ds->ncb) return 0;
   const int nb = ds->nrb;
   std::vector<char> bnz((size_t)nb * nb, 0);
@@ -1069,9 +1075,28 @@ static int sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_
     }
   if (!any_zero) return 0;
   SzPattern pat;   // sz_pattern.h: host-only, checked on the CPU by tests/sz_pattern_host.cpp
-  sz_symbolic(bnz, nb, ds->row_off, ds->row_len, ds->N, TILE, T_c, T_r, pat);
+  sz_symbolic(bnz, nb, ds->row_off, ds->row_len, ds->N, TILE, T_c, T_r, pat, grad_border);
+  if (grad_border) ctx->sz_dense = dense = pat.dense;
   ctx->sz_executed = pat.zeros_left ? pat.executed : dense;
   if (!pat.zeros_left) return 0;
+  if (grad_border) {   // the needed result tiles: K's own (unfilled) tile pattern
+    const int W = pat.words;
+    std::vector<sz_pattern_word> need((size_t)T_c * W, 0);
+    for (long i = 0; i < T_c; ++i) {
+      const long p0 = i * TILE, p1 = std::min<long>(p0 + TILE, ds->N);
+      for (long k = 0; k <= i; ++k) {
+        const long q0 = k * TILE, q1 = std::min<long>(q0 + TILE, ds->N);
+        bool on = i == k;
+        for (int I = 0; I < nb && !on; ++I) {
+          if (ds->row_len[I] <= 0 || !(ds->row_off[I] < p1 && ds->row_off[I] + ds->row_len[I] > p0)) continue;
+          for (int J = 0; J < nb && !on; ++J)
+            on = ds->row_len[J] > 0 && ds->row_off[J] < q1 && ds->row_off[J] + ds->row_len[J] > q0 && bnz[(size_t)I * nb + J] != 0;
+        }
+        if (on) need[(size_t)i * W + (k >> 6)] |= (sz_pattern_word)1 << (k & 63);
+      }
+    }
+    pat.nz.insert(pat.nz.end(), need.begin(), need.end());
+  }
   ctx->h_sz.swap(pat.nz);
   *words = pat.words;
   return 0;
@@ -1526,6 +1551,9 @@ static int contract_spec(const sgp_dspec* ds, const double* Gm, long ldg, const 
 // ---------------------------------------------------------------------------------------
 // logpdf + reverse-mode gradient
 // ---------------------------------------------------------------------------------------
+// (every consumer of C^-1 -- the term contractions, the input-point and row-scale sums, the noise gradient -- walks the block
+// pairs WITH terms or the diagonal: none needs a tile outside K's own tile pattern)
+static bool grad_inputs_need_all(double* const*, double* const*) { return false; }
 static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                             const double* noise, const double* y, double* logpdf_out, double* grad_y,
                             double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
@@ -1573,7 +1601,18 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   if (dense_noise) CHECK_RC(launch_add_dense(dA.p, m_tot, nd.dense.p, nd.ld_dense, N, 1, s));
   CHECK_RC(launch_fill_pad(dA.p, m_tot, N, n_pad, 0, n_pad, m_tot, 0, s));
   CHECK_RC(launch_grad_border(dA.p, m_tot, n_pad, N, dy.p, mean ? dmean.p : nullptr, nrows, s));
-  CHECK_RC(chol_bordered(ctx, dA.p, m_tot, n_pad, m_tot, nullptr, s, n_pad + TILE));
+  // Structural zeros (round 5): the factorisation of [K ; (y - m)' ; I] skips the tile products a programme with independent
+  // components makes exact zeros -- in the factor AND in inv(L)', whose tile pattern is the closure of the factor's (the
+  // identity rows run through the same symbolic elimination) -- C^-1 = inv(L)' inv(L) contracts only the k tiles both
+  // operand tiles have, and only the tiles of C^-1 that a block pair WITH terms (or the diagonal: the noise gradient) reads
+  // are computed at all.  Same bits as the dense schedule: every product left out is an exact zero or is never read.
+  SzMask sz;
+  {
+    int words = 0;
+    CHECK_RC(sz_pattern(ctx, ds, noise_kind, n_pad, m_tot, &words, true));
+    CHECK_RC(sz_upload(ctx, ctx->h_sz, words, s, &sz));
+  }
+  CHECK_RC(chol_bordered(ctx, dA.p, m_tot, n_pad, m_tot, nullptr, s, n_pad + TILE, sz.d_nz ? &sz : nullptr));
   // row n_pad holds z' = (inv(L) (y - m))' ; rows n_pad + 128 .. now hold inv(L)' (upper triangular)
   const double* zrow = dA.p + n_pad;
   const double* Rinv = dA.p + n_pad + TILE;
@@ -1586,7 +1625,16 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   // alpha = inv(L)' z
   CHECK_RC(launch_gemv_rows(Rinv, m_tot, N, n_pad, zrow, m_tot, nullptr, dalpha.p, s, 1));
   // C^-1 = inv(L)' inv(L): lower tiles on the MFMA GEMM, then mirrored
-  CHECK_RC(launch_gemm_nt_uut(Rinv, m_tot, dKinv.p, n_pad, n_pad, s));
+  {
+    TileSkip usk;
+    if (sz.d_nz && !grad_inputs_need_all(grad_inputs, grad_rowscale)) {
+      usk.nz = sz.d_nz;
+      usk.words = sz.words;
+      usk.tr0 = usk.tc0 = (int)(n_pad / TILE + 1);   // the identity rows' pattern rows
+      usk.need0 = (int)(m_tot / TILE);               // K's own tile pattern, behind the factor rows
+    }
+    CHECK_RC(launch_gemm_nt_uut(Rinv, m_tot, dKinv.p, n_pad, n_pad, s, usk.nz ? &usk : nullptr));
+  }
   CHECK_RC(launch_mirror_lower(dKinv.p, n_pad, n_pad, s));
   if (grad_noise && dense_noise) CHECK_RC(launch_grad_noise_dense(dKinv.p, n_pad, dalpha.p, N, dgn.p, s));
   else if (grad_noise) CHECK_RC(launch_grad_noise(dKinv.p, n_pad, dalpha.p, N, nd.kind == SGP_NOISE_DIAG, dgn.p, s));

@@ -156,6 +156,9 @@ struct TileSkip {      // per launch of a lower update C -= P P': C's first tile
   // the lock-step operand sharing, of the dense enumeration
   const int* cmap = nullptr;
   int cstride = 0;
+  // round 5 (the gradient's C^-1 = inv(L)' inv(L), launch_gemm_nt_uut): >= 0: pattern row need0 + tr says which tiles (tr, tc)
+  // of the RESULT anyone reads -- the tiles of block pairs with terms (+ the diagonal); the others are not computed
+  int need0 = -1;
 };
 // while set (chol_bordered's scope; per host thread), the lower updates launched on tiles of `base` skip dead tiles;
 // scratch (optional, only for launches that are ordered on one stream): room for the compacted id maps
@@ -203,7 +206,7 @@ int launch_gemm_nt_lz(const double* L, long ldl, const double* Zt, long ldz, dou
                       long ns, double beta, hipStream_t s);
 int launch_gemm_nt_lz_k(const double* L, long ldl, const double* Zt, long ldz, double* C, long ldc, long n,
                         long ns, long K, double beta, hipStream_t s);
-int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, hipStream_t s);
+int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, hipStream_t s, const TileSkip* sk = nullptr);
 int launch_gemm_nt_splitk(const double* A, long lda, const double* B, long ldb, double* Cpart, long ldc,
                           long M, long Nc, long K, int nsplit, long part_stride, int lower_only,
                           hipStream_t s);

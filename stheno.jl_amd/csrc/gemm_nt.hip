@@ -122,6 +122,10 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
   // tiles is structurally zero (keep_first: tile (0, 0) of a fused launch goes on to the diagonal-block routine anyway)
   // It contracts the k tiles from the first to the last needed one only (a panel that straddles a block boundary).
   if (sk && sk->nz) {
+    if (sk->need0 >= 0) {   // a result tile nobody reads (launch_gemm_nt_uut: block pairs without terms)
+      const sz_word* rn = sk->nz + (long)(sk->need0 + tr) * sk->words;
+      if (!((rn[tc >> 6] >> (tc & 63)) & 1)) return false;
+    }
     const sz_word* ra = sk->nz + (long)(sk->tr0 + tr) * sk->words;
     const sz_word* rb = sk->nz + (long)(sk->tc0 + tc) * sk->words;
     int kmin = -1, kmax = -1;
@@ -135,7 +139,10 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
       }
     }
     if (kmin < 0) {
-      if (!(keep_first && tr == 0 && tc == 0)) return false;
+      if (sk->need0 >= 0)
+        K = 0;   // a needed result tile without a live product (cannot happen for an inverse; kept exact): zeros are stored
+      else if (!(keep_first && tr == 0 && tc == 0))
+        return false;
     } else {
       A += (long)(kmin - sk->kt0) * TILE * lda;
       B += (long)(kmin - sk->kt0) * TILE * ldb;
@@ -875,7 +882,10 @@ int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, con
 
 // C[lower tiles] = X X' for X upper-triangular by 128-tile (n x n, X[i][k] = 0 for k < 128 floor(i/128)):
 // tile (tr, tc), tr >= tc, contracts k >= tr * 128 only.
-int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, hipStream_t s) {
+// sk (round 5, structured models): X's tile pattern (rows tr0 + t of sk->nz = tile row t of X) and the result tiles that are
+// needed at all (need0); a tile then contracts its first .. last k tile with both operand tiles non-zero -- which already
+// starts at k >= tr, X being upper triangular by tile IN the pattern -- and the tiles nobody reads are not computed.
+int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, hipStream_t s, const TileSkip* sk) {
   if (n <= 0) return 0;
   if (n % TILE) {
     set_error("gemm_nt_uut: n must be a multiple of 128");
@@ -883,8 +893,16 @@ int launch_gemm_nt_uut(const double* X, long ldx, double* C, long ldc, long n, h
   }
   long n_t = n / TILE;
   long per_xcd = tri_ids_per_xcd(tri_shape(n_t, n_t, -1));
-  hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
-                     1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 1, TileSkip());
+  if (sk && sk->nz) {
+    TileSkip k2 = *sk;
+    k2.kt0 = 0;
+    k2.kt1 = (int)n_t;
+    k2.cmap = nullptr;
+    hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
+                       1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 0, k2);
+  } else
+    hipLaunchKernelGGL(gemm_nt_dma_kernel<0>, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, X, ldx, X, ldx, C, ldc, n,
+                       1.0, 0.0, 0L, n_t, n_t, 0L, (const double*)C, ldc, 1, TileSkip());
   SGP_HIP(hipGetLastError());
   return 0;
 }

@@ -25,8 +25,13 @@ struct SzPattern {
   std::vector<double> col_work;   // executed tile products of tile column j (sum over the rows i >= j): sums to `executed`
 };
 
+// border_identity (round 5, the gradient path: capi.hip logpdf_grad_core): the bordered rows are [one dense tile row (the
+// observation row) ; T_c tile rows that start as the IDENTITY] -- row T_c + 1 + q holds a single non-zero tile, at column
+// q, and what the factorisation turns it into is inv(L)': tile (q, k) of it fills in by the same rule as any other row
+// (the pattern of the inverse factor is the closure of the factor's under elimination).  T_r must be 2 T_c + 1.  `dense`
+// then counts the same bordered matrix with every block pair coupled (what SGP_STRUCT_ZEROS=0 executes).
 inline void sz_symbolic(const std::vector<char>& bnz, int nb, const std::vector<long>& off, const std::vector<long>& len,
-                        long N, long tile, long T_c, long T_r, SzPattern& out) {
+                        long N, long tile, long T_c, long T_r, SzPattern& out, bool border_identity = false) {
   typedef sz_pattern_word word;
   const int W = (int)((T_c + 63) / 64);
   out.words = W;
@@ -62,8 +67,13 @@ inline void sz_symbolic(const std::vector<char>& bnz, int nb, const std::vector<
       if (on) setbit(i, k);
     }
   }
-  for (long i = T_c; i < T_r; ++i)
+  for (long i = T_c; i < T_r; ++i) {
+    if (border_identity && i > T_c) {
+      if (i - T_c - 1 < T_c) setbit(i, i - T_c - 1);
+      continue;
+    }
     for (long k = 0; k < T_c; ++k) setbit(i, k);
+  }
   // fill-in, and the work of the contractions
   out.executed = 0;
   out.zeros_left = false;
@@ -85,8 +95,19 @@ inline void sz_symbolic(const std::vector<char>& bnz, int nb, const std::vector<
       if (getbit(i, j)) {
         out.executed += (double)shared;
         out.col_work[(size_t)j] += (double)shared;
-      } else
+      } else if (!(border_identity && i > T_c && i - T_c - 1 > j))   // (left of an identity row's own tile: zero in ANY model)
         out.zeros_left = true;
+    }
+  }
+  if (border_identity) {   // the dense count of this bordered shape: the same elimination with every block pair coupled
+    bool all = true;
+    for (char c : bnz) all = all && c != 0;
+    if (all) {
+      out.dense = out.executed;
+    } else {
+      SzPattern full;
+      sz_symbolic(std::vector<char>(bnz.size(), 1), nb, off, len, N, tile, T_c, T_r, full, true);
+      out.dense = full.executed;
     }
   }
 }

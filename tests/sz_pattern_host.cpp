@@ -152,6 +152,53 @@ int main() {
         if (L0[(size_t)i * n_pad + j] != 0.0)
           CHECK(B[(size_t)(i / tile) * T_c + j / tile], "trial %d: L(%ld, %ld) = %g lies outside the pattern", trial, i, j,
                 L0[(size_t)i * n_pad + j]);
+    // ---- round 5, the gradient path's border [one dense tile row ; identity rows] (sz_symbolic: border_identity): the
+    // pattern of row T_c + 1 + q is that of tile row q of inv(L)' -- against brute-force elimination and against the
+    // numerical inverse of the factor computed above
+    {
+      const long T_g = 2 * T_c + 1;
+      sgp::SzPattern pg;
+      sgp::sz_symbolic(bnz, nb, off, len, N, tile, T_c, T_g, pg, true);
+      std::vector<char> G((size_t)T_g * T_c, 0);
+      for (long i = 0; i < T_c; ++i)
+        for (long k = 0; k <= i; ++k) {
+          bool on = i == k;
+          for (long p = i * tile; p < std::min(N, (i + 1) * tile) && !on; ++p)
+            for (long q = k * tile; q < std::min(N, (k + 1) * tile) && !on; ++q) on = bnz[(size_t)blk[p] * nb + blk[q]] != 0;
+          G[(size_t)i * T_c + k] = on;
+        }
+      for (long k = 0; k < T_c; ++k) G[(size_t)T_c * T_c + k] = 1;
+      for (long q = 0; q < T_c; ++q) G[(size_t)(T_c + 1 + q) * T_c + q] = 1;
+      double exg = 0;
+      for (long j = 0; j < T_c; ++j)
+        for (long i = j; i < T_g; ++i) {
+          long shared = 0;
+          for (long k = 0; k < j; ++k) shared += (G[(size_t)i * T_c + k] && G[(size_t)j * T_c + k]) ? 1 : 0;
+          if (shared) G[(size_t)i * T_c + j] = 1;
+          if (G[(size_t)i * T_c + j]) exg += (double)shared;
+        }
+      CHECK(exg == pg.executed, "trial %d: gradient-border executed count %g vs %g", trial, exg, pg.executed);
+      CHECK(pg.dense >= pg.executed, "trial %d: gradient-border dense count below the executed one", trial);
+      for (long i = 0; i < T_g; ++i)
+        for (long k = 0; k < T_c; ++k) {
+          const bool bit = (pg.nz[(size_t)i * pg.words + (k >> 6)] >> (k & 63)) & 1;
+          const bool want = (i < T_c && k > i) ? false : G[(size_t)i * T_c + k] != 0;
+          CHECK(bit == want, "trial %d: gradient-border pattern bit (%ld, %ld) %d vs %d", trial, i, k, (int)bit, (int)want);
+        }
+      // numerical: W = inv(L0) by forward substitution; W(k-rows, q-cols) != 0 must lie inside row T_c + 1 + q, column k
+      std::vector<double> Wn((size_t)n_pad * n_pad, 0.0);
+      for (long c = 0; c < n_pad; ++c)
+        for (long i = c; i < n_pad; ++i) {
+          double sacc = (i == c) ? 1.0 : 0.0;
+          for (long k = c; k < i; ++k) sacc -= L0[(size_t)i * n_pad + k] * Wn[(size_t)k * n_pad + c];
+          Wn[(size_t)i * n_pad + c] = sacc / L0[(size_t)i * n_pad + i];
+        }
+      for (long i = 0; i < n_pad; ++i)
+        for (long c = 0; c <= i; ++c)
+          if (Wn[(size_t)i * n_pad + c] != 0.0)
+            CHECK(G[(size_t)(T_c + 1 + c / tile) * T_c + i / tile], "trial %d: inv(L)(%ld, %ld) = %g lies outside the identity rows' pattern",
+                  trial, i, c, Wn[(size_t)i * n_pad + c]);
+    }
   }
   std::printf("cases %ld with_zeros %ld failures %ld\n", cases, with_zeros, failures);
   return failures ? 1 : 0;

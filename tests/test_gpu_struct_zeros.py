@@ -202,3 +202,51 @@ def test_reordering_the_blocks_restores_the_skipping(monkeypatch):
     np.testing.assert_allclose(m, m2, rtol=1e-9, atol=1e-11)
     np.testing.assert_allclose(v, v2, rtol=1e-9, atol=1e-11)
     ctx.close()
+
+
+def test_the_gradient_skips_the_structural_zeros_and_keeps_its_bits(monkeypatch):
+    """Round 5: the gradient's factorisation of [K ; (y - m)' ; I] runs under the pattern as well -- the identity rows carry the
+    pattern of inv(L)' (the closure of the factor's; tests/sz_pattern_host.cpp checks it against numerical inverses) -- the
+    product C^-1 = inv(L)' inv(L) contracts only the k tiles both operand tiles have and computes only the tiles a block pair
+    with terms (or the diagonal) reads.  Value, d/dy, d/d noise (scalar and diagonal), the term gradients and the input-point
+    gradients are bit-identical with the skipping off; the work counter shows the skipped share; the oracle's cotangents
+    agree."""
+    from test_gpu_fused_potrf import _problem
+    N = 2900
+    F, x, xs, y = _problem(N)
+    noise_d = 0.05 + np.random.default_rng(1).random(N)
+    res = {}
+    for sz in (0, 1):
+        ctx = _ctx(monkeypatch, 11, SGP_STRUCT_ZEROS=sz)
+
+        def run():
+            g = P.logpdf_and_gradient(F(x, 0.1), y, inputs=True)
+            work = ctx.factor_work()
+            gd = P.logpdf_and_gradient(F(x, noise_d), y)
+            return g, gd, work
+        res[sz] = _with_ctx(ctx, run)
+        ctx.close()
+    (g0, gd0, w0), (g1, gd1, w1) = res[0], res[1]
+    assert w0[0] == w0[1] and w1[0] < 0.75 * w1[1], (w0, w1)
+    assert w1[1] == w0[1]                                     # the dense count of the bordered shape is the same number
+    assert g0["logpdf"] == g1["logpdf"] and gd0["logpdf"] == gd1["logpdf"]
+    for k in ("y", "mean"):
+        assert np.array_equal(g0[k], g1[k]), k
+    assert g0["noise"] == g1["noise"] and np.array_equal(gd0["noise"], gd1["noise"])
+    for t0, t1 in zip(g0["terms"], g1["terms"]):
+        assert t0["d_coef"] == t1["d_coef"] and t0["d_inscale"] == t1["d_inscale"], (t0, t1)
+    for a0, a1 in zip(g0["inputs"], g1["inputs"]):
+        assert np.array_equal(a0, a1)
+    # the oracle: d logpdf / d sigma^2 = tr(G), G = (alpha alpha' - C^-1) / 2, by a plain dense solve
+    Fo = ost_sum_model()
+    xo = ost.BlockData([ost.GPPPInput(k, oagp.kf.ColVecs(v)) for k, v in zip(("f1", "f2", "f3"), xs)])
+    _, C = oagp.mean_and_cov(Fo(xo, 0.1))
+    C = np.asarray(C)
+    alpha = np.linalg.solve(C, y)
+    tr = 0.5 * (alpha @ alpha - np.trace(np.linalg.inv(C)))
+    assert abs(g1["noise"] - tr) <= 1e-8 * abs(tr)
+
+
+def ost_sum_model():
+    from oracle import reference_model as orm
+    return orm.gppp_sum()
