@@ -1060,8 +1060,14 @@ static int sz_pattern(sgp_ctx* ctx, const sgp_dspec* ds, int noise_kind, long n_
   const long T_c = n_pad / TILE, T_r = m_tot / TILE;
   double dense = 0;
   for (long j = 0; j < T_c; ++j) dense += (double)j * (double)(T_r - j);
+  if (grad_border) {
+    // the dense count of the gradient's border: an identity row q only ever holds tiles at columns >= q, so column j sees
+    // j - q of its k tiles (q < j) -- j (T_c - j) for the rows of K, j for the observation row, j (j + 1) / 2 for the identity rows
+    if (T_r != 2 * T_c + 1) return 0;
+    dense = 0;
+    for (long j = 0; j < T_c; ++j) dense += (double)j * (double)(T_c - j) + (double)j + 0.5 * (double)j * (double)(j + 1);
+  }
   ctx->sz_dense = ctx->sz_executed = dense;
-  if (grad_border && T_r != 2 * T_c + 1) return 0;
   if (!ctx->struct_zeros || !ds->symmetric || noise_kind == SGP_NOISE_DENSE || ds->nrb < 2 || ds->nrb != ds->ncb) return 0;
   const int nb = ds->nrb;
   std::vector<char> bnz((size_t)nb * nb, 0);

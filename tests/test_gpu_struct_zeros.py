@@ -227,7 +227,7 @@ def test_the_gradient_skips_the_structural_zeros_and_keeps_its_bits(monkeypatch)
         res[sz] = _with_ctx(ctx, run)
         ctx.close()
     (g0, gd0, w0), (g1, gd1, w1) = res[0], res[1]
-    assert w0[0] == w0[1] and w1[0] < 0.75 * w1[1], (w0, w1)
+    assert w0[0] == w0[1] and w1[0] < 0.80 * w1[1], (w0, w1)   # (the identity rows have less to skip than K's)
     assert w1[1] == w0[1]                                     # the dense count of the bordered shape is the same number
     assert g0["logpdf"] == g1["logpdf"] and gd0["logpdf"] == gd1["logpdf"]
     for k in ("y", "mean"):
