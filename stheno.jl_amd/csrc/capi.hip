@@ -2185,7 +2185,13 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
   CHECK_RC(assemble(dz, dLz, m_pad, 0, m_pad / TILE, 0, m_pad / TILE, 1, nkz, ndz.sigma2, ndz.diag.p, s));
   if (ndz.kind == SGP_NOISE_DENSE) CHECK_RC(launch_add_dense(dLz, m_pad, ndz.dense.p, M, M, 1, s));
   CHECK_RC(launch_fill_pad(dLz, m_pad, M, m_pad, 0, m_pad, m_pad, 0, s));
-  CHECK_RC(chol_bordered(ctx, dLz, m_pad, m_pad, m_pad, d_wz, s));
+  {
+    // structural zeros (round 5): inducing points spread over independent processes give K(z,z) exact zero blocks, as they
+    // give K(x,x) -- the same pattern machinery (no bordered rows here: T_r = T_c)
+    SzMask szz;
+    CHECK_RC(sz_build(ctx, dz, ndz.kind, m_pad, m_pad, s, &szz));
+    CHECK_RC(chol_bordered(ctx, dLz, m_pad, m_pad, m_pad, d_wz, s, 0, szz.d_nz ? &szz : nullptr));
+  }
   int info = fetch_info(ctx, s);
   if (info < 0) return -3;
   if (info > 0) {
@@ -2461,7 +2467,11 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   // Factoring Kzz alone and solving the rows with the deep-K row_trsm was tried: with a leading
   // dimension of 270 000 doubles every operand column lies in its own 2 MiB page and a K = 3584 GEMM
   // thrashes the TLB (N = 262 144, M = 4096: 225 -> 700 ms).
-  CHECK_RC(chol_bordered(ctx, dA.p, ld, m_pad, ld, d_wz, s));
+  {
+    SzMask szz;   // structural zeros of K(z,z) (round 5); the N rows K(x,z) Lambda are dense bordered rows of the pattern
+    CHECK_RC(sz_build(ctx, gz.ds, ndz.kind, m_pad, ld, s, &szz));
+    CHECK_RC(chol_bordered(ctx, dA.p, ld, m_pad, ld, d_wz, s, 0, szz.d_nz ? &szz : nullptr));
+  }
   int info = fetch_info(ctx, s);
   if (info < 0) return -3;
   if (info > 0) {

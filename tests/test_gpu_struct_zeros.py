@@ -250,3 +250,30 @@ def test_the_gradient_skips_the_structural_zeros_and_keeps_its_bits(monkeypatch)
 def ost_sum_model():
     from oracle import reference_model as orm
     return orm.gppp_sum()
+
+
+@pytest.mark.parametrize("N", [900, 70000])
+def test_the_elbo_skips_the_structural_zeros_of_kzz(monkeypatch, N):
+    """Round 5: inducing points spread over the independent processes of a programme give K(z,z) the same exact zero blocks
+    K(x,x) has; its factorisation (inside both VFE pipelines: the bordered one and, beyond 65 536 data points, the row-chunked
+    one) runs under the pattern.  ELBO and the approximate posterior's moments bit-identical with the skipping off."""
+    from test_gpu_fused_potrf import _problem
+    F, x, xs, y = _problem(N)
+    rng = np.random.default_rng(4)
+    z = P.BlockData([P.GPPPInput(k, P.ColVecs(np.asfortranarray(rng.standard_normal((3, m))))) for k, m in (("f1", 300), ("f2", 420), ("f3", 333))])
+    xs_new = P.BlockData([P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((3, 25)))))])
+    res = {}
+    for sz in (0, 1):
+        ctx = _ctx(monkeypatch, 11, SGP_STRUCT_ZEROS=sz)
+
+        def run():
+            fx, vfe = F(x, 0.1), P.VFE(F(z, 1e-6))
+            e = P.elbo(vfe, fx, y)
+            work = ctx.factor_work()
+            m, v = P.posterior(vfe, fx, y).mean_and_var(xs_new)
+            return e, work, np.asarray(m), np.asarray(v)
+        res[sz] = _with_ctx(ctx, run)
+        ctx.close()
+    assert res[0][0] == res[1][0]
+    assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][3], res[1][3])
+    assert np.isfinite(res[1][0]) and res[1][0] < P.logpdf(F(x, 0.1), y) + 1e-6 * abs(res[1][0])   # ELBO <= logpdf
