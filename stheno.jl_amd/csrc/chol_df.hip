@@ -56,6 +56,7 @@ struct DfArgs {
                           // most this long) until every tile of the patch has been taken; pend[] follows the tasks
   const sz_word* nz;  // structural zeros (common.h): bit k of row i = tile (i, k) of the factor may be non-zero; nullptr = dense
   int nzw;            // words per row
+  int diag_lower;     // 1: the diagonal tiles' contractions run the lower-only form (df_contract_diag); SGP_DF_DIAG_LOWER=0: A/B
   long long* stats;   // optional (SGP_DF_STATS): 8 tick counters per workgroup, see launch_chol_dataflow
   long long* cols;    // optional: 8 wall-clock stamps per tile column (the chain: diagonal task + the task below it)
 };
@@ -97,6 +98,67 @@ __device__ __forceinline__ void df_contract(const double* Ag, const double* Bg, 
   }
 }
 
+
+// The contraction of a DIAGONAL tile (round 5): only its lower 16 x 16 blocks are ever read (the diagonal-block routine takes
+// them from LDS), 144 of the 256 MFMA fragments of the tile program.  The last k block of the diagonal tile is on the
+// factorisation's critical chain -- it waits for the tile below the previous diagonal tile, and one CU needs 16 - 18 us for a
+// full 128 x 128 x 128 product -- so the diagonal task runs a lower-only form: the eight 64 x 32 shares are dealt to the
+// waves so that the two waves of every SIMD (wave w runs on SIMD w % 4) carry 32 / 32 / 40 / 40 fragments instead of
+// 60 / 44 / 28 / 12, and a wave executes only the fragments with row block >= column block (kstep.h: tile_kstep_lower).
+//   wave 0 -> share (1, 0) all 32     wave 4 -> share (0, 2) none
+//   wave 1 -> share (1, 1) all 32     wave 5 -> share (0, 3) none
+//   wave 2 -> share (0, 0) 28         wave 6 -> share (0, 1) 12
+//   wave 3 -> share (1, 2) 28         wave 7 -> share (1, 3) 12
+// shape: 1 = every fragment, 0 = D = 0, -2 = D = -2, -9 = none (the wave still moves its operand columns and meets the barriers)
+__device__ __forceinline__ void df_diag_share(int w, int& wr, int& wc, int& shape) {
+  wr = (0x8B >> w) & 1;            // {1, 1, 0, 1, 0, 0, 0, 1}
+  wc = (0xDE84 >> (2 * w)) & 3;    // {0, 1, 0, 2, 2, 3, 1, 3}
+  const int d = 4 * wr - 2 * wc;
+  shape = d >= 1 ? 1 : (d == 0 ? 0 : (d == -2 ? -2 : -9));
+}
+__device__ __forceinline__ void df_contract_diag(const double* Ag, long ld, long c0, long c1, double (&acc)[8][4],
+                                                 double* smem, int wu, int lane, unsigned a_off, unsigned b_off, int shape) {
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const unsigned lds_base = (unsigned)(unsigned long long)(__attribute__((address_space(3))) double*)smem;
+  auto dma = [&](long k0, int stage) {
+    double* sa = smem + stage * DF_STAGE;
+    double* sb = sa + DF_KB * LDS_LD;
+#pragma unroll
+    for (int i = 0; i < DF_KB / 8; ++i) {  // (both operands are the tile row's own panel: the two stages hold the same rows)
+      const int col = wu + 8 * i;
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ag + 2 * lane + (k0 + col) * ld), (lptr_t)(sa + col * LDS_LD), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)(Ag + 2 * lane + (k0 + col) * ld), (lptr_t)(sb + col * LDS_LD), 16, 0, 0);
+    }
+  };
+  dma(c0 * DF_KB, (int)(c0 & 1));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (long c = c0; c < c1; ++c) {
+    const int stage = (int)(c & 1);
+    if (c + 1 < c1) dma((c + 1) * DF_KB, stage ^ 1);
+    const unsigned a_addr = lds_base + (unsigned)(stage * DF_STAGE * 8) + a_off;
+    const unsigned b_addr = lds_base + (unsigned)(stage * DF_STAGE * 8) + b_off;
+    if (shape == 1) {
+      tile_kstep<0>(acc, a_addr, b_addr);
+      tile_kstep<1>(acc, a_addr, b_addr);
+      tile_kstep<2>(acc, a_addr, b_addr);
+      tile_kstep<3>(acc, a_addr, b_addr);
+    } else if (shape == 0) {
+      tile_kstep_lower<0, 0>(acc, a_addr, b_addr);
+      tile_kstep_lower<1, 0>(acc, a_addr, b_addr);
+      tile_kstep_lower<2, 0>(acc, a_addr, b_addr);
+      tile_kstep_lower<3, 0>(acc, a_addr, b_addr);
+    } else if (shape == -2) {
+      tile_kstep_lower<0, -2>(acc, a_addr, b_addr);
+      tile_kstep_lower<1, -2>(acc, a_addr, b_addr);
+      tile_kstep_lower<2, -2>(acc, a_addr, b_addr);
+      tile_kstep_lower<3, -2>(acc, a_addr, b_addr);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+}
 
 // thread 0: wait until min(prog[i], prog[j]) > have (returns min(.., cap)), or -1 on abort / timeout
 __device__ __forceinline__ int df_wait(const DfArgs& a, int i, int j, int have, int cap) {
@@ -217,12 +279,16 @@ __device__ __forceinline__ int df_dequeue(const DfArgs& a, int* curleft) {
 
 // Phase 1: acc = -A_ij + sum_k L_ik L_jk' as the operand rows become final.  Diagonal tile: the result goes into
 // potrf_diag_body's packed LDS layout; off-diagonal: T = -acc is stored in place.  Returns false on abort.
+template <bool LOWER>   // LOWER: the diagonal tiles' lower-only contraction (the one-workgroup-per-CU instantiation: the sizes
+                        // where the chain is the step; the lean kernel's register budget stays what it was)
 __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j, double* smem, int* s_word) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w = t >> 6;
   const int wu = __builtin_amdgcn_readfirstlane(w);
-  const int wr = w >> 2, wc = w & 3;
+  int wr = w >> 2, wc = w & 3, shape = 1;
+  const bool lower_only = LOWER && (i == j) && a.diag_lower;   // the diagonal tile: lower blocks only, shares dealt for balance
+  if (lower_only) df_diag_share(wu, wr, wc, shape);
   const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
   const unsigned a_off = (unsigned)((lq * LDS_LD + wr * 64 + l15) * 8);
   const unsigned b_off = (unsigned)((DF_KB * LDS_LD + lq * LDS_LD + wc * 32 + l3) * 8);
@@ -263,7 +329,10 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
       break;
     }
     if (a.cols && t == 0 && i == j && avail == j) a.cols[(long)j * 8 + 1] = wall_clock64();
-    df_contract(Ag, Bg, ld, (long)ka * (TILE / DF_KB), (long)avail * (TILE / DF_KB), acc, smem, wu, lane, a_off, b_off);
+    if (lower_only)
+      df_contract_diag(Ag, ld, (long)ka * (TILE / DF_KB), (long)avail * (TILE / DF_KB), acc, smem, wu, lane, a_off, b_off, shape);
+    else
+      df_contract(Ag, Bg, ld, (long)ka * (TILE / DF_KB), (long)avail * (TILE / DF_KB), acc, smem, wu, lane, a_off, b_off);
     kdone = avail;
   }
   if (a.cols && t == 0 && i == j) a.cols[(long)j * 8 + 2] = wall_clock64();
@@ -310,7 +379,7 @@ __device__ __forceinline__ void df_solve_body(const DfArgs& a, int i, int j, dou
 // separate functions.  FAT (one workgroup per CU, 256 VGPRs -- the sizes where the diagonal chain is the critical path and
 // occupancy buys nothing): everything inline, no spills in the substitution (228 VGPRs) or the diagonal-block routine.
 __device__ __attribute__((noinline)) bool df_accumulate_lean(const DfArgs& a, int i, int j, double* smem, int* s_word) {
-  return df_accumulate_body(a, i, j, smem, s_word);
+  return df_accumulate_body<false>(a, i, j, smem, s_word);
 }
 __device__ __attribute__((noinline)) void df_diag_lean(const DfArgs& a, int j) { df_diag_body(a, j); }
 __device__ __attribute__((noinline)) void df_solve_lean(const DfArgs& a, int i, int j, double* smem) {
@@ -318,7 +387,7 @@ __device__ __attribute__((noinline)) void df_solve_lean(const DfArgs& a, int i, 
 }
 #define DF_FAT_FN __device__ __attribute__((noinline))
 DF_FAT_FN bool df_accumulate_fat(const DfArgs& a, int i, int j, double* smem, int* s_word) {
-  return df_accumulate_body(a, i, j, smem, s_word);
+  return df_accumulate_body<true>(a, i, j, smem, s_word);
 }
 DF_FAT_FN void df_diag_fat(const DfArgs& a, int j) { df_diag_body(a, j); }
 DF_FAT_FN void df_solve_fat(const DfArgs& a, int i, int j, double* smem) { df_solve_body(a, i, j, smem); }
@@ -489,6 +558,10 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
   a.slots = d_slots;
   a.info = d_info;
   a.spin_ticks = (long long)(timeout_s * 1e8);
+  {
+    static const int dl = getenv("SGP_DF_DIAG_LOWER") ? atoi(getenv("SGP_DF_DIAG_LOWER")) : 1;
+    a.diag_lower = dl;
+  }
   a.ntasks = df_ntasks(a.T_r, a.T_c);
   // the queues need a workgroup each (a queue nobody serves would only be drained by workgroups whose own queue is
   // exhausted -- and those may hold tasks that wait for it): fewer than DF_NQ workgroups run the column-major order

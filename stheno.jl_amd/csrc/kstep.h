@@ -31,5 +31,38 @@ __device__ __forceinline__ void tile_kstep(double (&acc)[8][4], unsigned a_addr,
     for (int i = 0; i < 4; ++i) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
 }
 
+// The same k-step for a wave whose 64 x 32 share of a DIAGONAL tile is only partly needed (chol_df.hip: the lower 16 x 16
+// blocks feed the diagonal-block routine, the strictly upper ones are never read).  With rb = 4 wr + i the 16-row block and
+// cb = 2 wc + (j >> 2) the 16-column block of fragment (j, i), the fragment is needed iff rb >= cb, i.e. i - (j >> 2) + D >= 0
+// with D = 4 wr - 2 wc.  D >= 1: every fragment (use tile_kstep); D = 0: all but (i = 0, j >= 4) -- 28 of 32; D = -2:
+// (i = 2, j < 4) and (i = 3, all j) -- 12 of 32; D <= -3: none.  Same per-element operation sequence as tile_kstep: the bits of
+// the needed entries do not depend on which form computed them.
+template <int KS, int D>
+__device__ __forceinline__ void tile_kstep_lower(double (&acc)[8][4], unsigned a_addr, unsigned b_addr) {
+  static_assert(D == 0 || D == -2, "tile_kstep_lower: D = 0 or -2");
+  double a_r[4], b_c[8];
+  constexpr int O = KS * 4 * LDS_LD * 8;
+  if (D == 0) {
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[0]) : "v"(a_addr), "i"(O + 0));
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[1]) : "v"(a_addr), "i"(O + 128));
+  }
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[2]) : "v"(a_addr), "i"(O + 256));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(a_r[3]) : "v"(a_addr), "i"(O + 384));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[0]) : "v"(b_addr), "i"(O + 0));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[1]) : "v"(b_addr), "i"(O + 32));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[2]) : "v"(b_addr), "i"(O + 64));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[3]) : "v"(b_addr), "i"(O + 96));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[4]) : "v"(b_addr), "i"(O + 128));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[5]) : "v"(b_addr), "i"(O + 160));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[6]) : "v"(b_addr), "i"(O + 192));
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(b_c[7]) : "v"(b_addr), "i"(O + 224));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (i - (j >> 2) + D >= 0) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
+}
 
 }  // namespace sgp
