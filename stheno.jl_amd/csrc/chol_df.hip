@@ -105,17 +105,7 @@ __device__ __forceinline__ void df_contract(const double* Ag, const double* Bg, 
 // full 128 x 128 x 128 product -- so the diagonal task runs a lower-only form: the eight 64 x 32 shares are dealt to the
 // waves so that the two waves of every SIMD (wave w runs on SIMD w % 4) carry 32 / 32 / 40 / 40 fragments instead of
 // 60 / 44 / 28 / 12, and a wave executes only the fragments with row block >= column block (kstep.h: tile_kstep_lower).
-//   wave 0 -> share (1, 0) all 32     wave 4 -> share (0, 2) none
-//   wave 1 -> share (1, 1) all 32     wave 5 -> share (0, 3) none
-//   wave 2 -> share (0, 0) 28         wave 6 -> share (0, 1) 12
-//   wave 3 -> share (1, 2) 28         wave 7 -> share (1, 3) 12
-// shape: 1 = every fragment, 0 = D = 0, -2 = D = -2, -9 = none (the wave still moves its operand columns and meets the barriers)
-__device__ __forceinline__ void df_diag_share(int w, int& wr, int& wc, int& shape) {
-  wr = (0x8B >> w) & 1;            // {1, 1, 0, 1, 0, 0, 0, 1}
-  wc = (0xDE84 >> (2 * w)) & 3;    // {0, 1, 0, 2, 2, 3, 1, 3}
-  const int d = 4 * wr - 2 * wc;
-  shape = d >= 1 ? 1 : (d == 0 ? 0 : (d == -2 ? -2 : -9));
-}
+// (the deal and the three fragment shapes: kstep.h, diag_share / tile_kstep_lower)
 __device__ __forceinline__ void df_contract_diag(const double* Ag, long ld, long c0, long c1, double (&acc)[8][4],
                                                  double* smem, int wu, int lane, unsigned a_off, unsigned b_off, int shape) {
   typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -288,7 +278,7 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
   const int wu = __builtin_amdgcn_readfirstlane(w);
   int wr = w >> 2, wc = w & 3, shape = 1;
   const bool lower_only = LOWER && (i == j) && a.diag_lower;   // the diagonal tile: lower blocks only, shares dealt for balance
-  if (lower_only) df_diag_share(wu, wr, wc, shape);
+  if (lower_only) diag_share(wu, wr, wc, shape);
   const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
   const unsigned a_off = (unsigned)((lq * LDS_LD + wr * 64 + l15) * 8);
   const unsigned b_off = (unsigned)((DF_KB * LDS_LD + lq * LDS_LD + wc * 32 + l3) * 8);

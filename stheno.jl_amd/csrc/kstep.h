@@ -65,4 +65,18 @@ __device__ __forceinline__ void tile_kstep_lower(double (&acc)[8][4], unsigned a
       if (i - (j >> 2) + D >= 0) acc[j][i] = mfma44_f64(b_c[j], a_r[i], acc[j][i]);
 }
 
+// Which 64 x 32 share of a DIAGONAL tile wave w takes when only the lower 16 x 16 blocks are needed, and what it executes of
+// it (chol_df.hip: df_contract_diag explains the deal: 32 / 32 / 40 / 40 fragments per SIMD instead of 60 / 44 / 28 / 12):
+//   wave 0 -> share (1, 0) all 32     wave 4 -> share (0, 2) none
+//   wave 1 -> share (1, 1) all 32     wave 5 -> share (0, 3) none
+//   wave 2 -> share (0, 0) 28         wave 6 -> share (0, 1) 12
+//   wave 3 -> share (1, 2) 28         wave 7 -> share (1, 3) 12
+// shape: 1 = every fragment (tile_kstep), 0 / -2 = tile_kstep_lower<., 0 / -2>, -9 = none
+__device__ __forceinline__ void diag_share(int w, int& wr, int& wc, int& shape) {
+  wr = (0x8B >> w) & 1;            // {1, 1, 0, 1, 0, 0, 0, 1}
+  wc = (0xDE84 >> (2 * w)) & 3;    // {0, 1, 0, 2, 2, 3, 1, 3}
+  const int d = 4 * wr - 2 * wc;
+  shape = d >= 1 ? 1 : (d == 0 ? 0 : (d == -2 ? -2 : -9));
+}
+
 }  // namespace sgp
