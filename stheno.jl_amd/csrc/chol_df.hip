@@ -352,17 +352,18 @@ __device__ __forceinline__ void df_diag_body(const DfArgs& a, int j) {
 }
 
 // Phase 2b: L_ij = T inv(L_jj)' for the tile's 128 rows, eight waves x 16 rows
-__device__ __forceinline__ void df_solve_body(const DfArgs& a, int i, int j, double* smem) {
+// (A, ld, invall by VALUE: through the `const DfArgs&` of a noinline phase function they are loaded from memory with vector
+// loads at the top of the phase -- one more global round trip on the chain before the first useful load; round 5)
+__device__ __forceinline__ void df_solve_body(double* A, long ld, const double* invall, int i, int j, double* smem) {
   const int t = threadIdx.x;
   const int lane = t & 63, w = t >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
-  const long ld = a.ld;
-  const double* Ljj = a.A + (long)j * TILE + (long)j * TILE * ld;
-  panel_solve_fill<double, 8>(smem, Ljj, ld, __builtin_amdgcn_readfirstlane(w), lane);
+  const double* Ljj = A + (long)j * TILE + (long)j * TILE * ld;
+  panel_solve_fill<double, 8>(smem, (const __attribute__((address_space(1))) double*)Ljj, ld, __builtin_amdgcn_readfirstlane(w), lane);
   __syncthreads();
-  double* X = a.A + (long)i * TILE + (long)j * TILE * ld;
+  double* X = A + (long)i * TILE + (long)j * TILE * ld;
   const int loff = (int)(w * 16 + l15 + lq * ld);
-  panel_solve_strip<double>(X, ld, loff, smem, a.invall + (long)j * 2048, 256, 16, lane);
+  panel_solve_strip<double>(X, ld, loff, smem, invall + (long)j * 2048, 256, 16, lane);
 }
 
 // LEAN (two workgroups per CU, 128 VGPRs -- the sizes where the trailing contractions are the work): the phases are
@@ -372,15 +373,17 @@ __device__ __attribute__((noinline)) bool df_accumulate_lean(const DfArgs& a, in
   return df_accumulate_body<false>(a, i, j, smem, s_word);
 }
 __device__ __attribute__((noinline)) void df_diag_lean(const DfArgs& a, int j) { df_diag_body(a, j); }
-__device__ __attribute__((noinline)) void df_solve_lean(const DfArgs& a, int i, int j, double* smem) {
-  df_solve_body(a, i, j, smem);
+__device__ __attribute__((noinline)) void df_solve_lean(double* A, long ld, const double* invall, int i, int j, double* smem) {
+  df_solve_body(A, ld, invall, i, j, smem);
 }
 #define DF_FAT_FN __device__ __attribute__((noinline))
 DF_FAT_FN bool df_accumulate_fat(const DfArgs& a, int i, int j, double* smem, int* s_word) {
   return df_accumulate_body<true>(a, i, j, smem, s_word);
 }
 DF_FAT_FN void df_diag_fat(const DfArgs& a, int j) { df_diag_body(a, j); }
-DF_FAT_FN void df_solve_fat(const DfArgs& a, int i, int j, double* smem) { df_solve_body(a, i, j, smem); }
+DF_FAT_FN void df_solve_fat(double* A, long ld, const double* invall, int i, int j, double* smem) {
+  df_solve_body(A, ld, invall, i, j, smem);
+}
 template <bool FAT>
 __device__ __forceinline__ bool df_accumulate(const DfArgs& a, int i, int j, double* smem, int* s_word) {
   if (FAT) return df_accumulate_fat(a, i, j, smem, s_word);
@@ -393,8 +396,8 @@ __device__ __forceinline__ void df_diag(const DfArgs& a, int j) {
 }
 template <bool FAT>
 __device__ __forceinline__ void df_solve(const DfArgs& a, int i, int j, double* smem) {
-  if (FAT) df_solve_fat(a, i, j, smem);
-  else df_solve_lean(a, i, j, smem);
+  if (FAT) df_solve_fat(a.A, a.ld, a.invall, i, j, smem);
+  else df_solve_lean(a.A, a.ld, a.invall, i, j, smem);
 }
 
 template <bool FAT>
