@@ -137,7 +137,8 @@ if d0 and d0.get("grad"):
           "|---|---|---|---|---|---|---|---|"]
     for k, v in d0["grad"].items():
         f = lambda x: "--" if x is None else f"{x:.1e}"
-        L.append(f"| {k} (N = {v['N']}) | {v['ms_per_call']:.2f} | {v['ratio_to_logpdf']:.2f} | {v['frac']:.3f} | "
+        frs = f"{v['frac']:.3f}" if v.get('frac') is not None else f"(dense-equivalent {v.get('dense_equivalent_frac', 0):.3f})"
+        L.append(f"| {k} (N = {v['N']}) | {v['ms_per_call']:.2f} | {v['ratio_to_logpdf']:.2f} | {frs} | "
                  f"{v.get('executed_work_fraction_of_the_bordered_factorisation', 1.0):.3f} | {f(v.get('parity_rel_d_sigma2'))} | "
                  f"{f(v.get('parity_rel_d_inscale'))} | {f(v.get('parity_rel_logpdf'))} |")
     L.append("")
