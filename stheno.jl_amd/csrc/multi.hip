@@ -91,6 +91,7 @@ struct Rccl {
   int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   int (*CommCount)(ncclComm_p, int*) = nullptr;
+  int (*CommAbort)(ncclComm_p) = nullptr;
   bool load() {
     if (h) return true;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
@@ -106,6 +107,7 @@ struct Rccl {
     GroupEnd = (decltype(GroupEnd))dlsym(h, "ncclGroupEnd");
     GetErrorString = (decltype(GetErrorString))dlsym(h, "ncclGetErrorString");
     CommCount = (decltype(CommCount))dlsym(h, "ncclCommCount");
+    CommAbort = (decltype(CommAbort))dlsym(h, "ncclCommAbort");
     return CommInitAll && CommDestroy && Broadcast && AllReduce && GroupStart && GroupEnd;
   }
 };
@@ -170,6 +172,7 @@ struct sgp_multi {
   int threads = -1;
   std::unordered_map<hipEvent_t, std::atomic<long>> seq;
   std::atomic<int> abort_flag{0};
+  bool broken = false;      // an enqueue thread failed under the RCCL transport: the communicators are gone
   int ring = 10;            // receive buffers per rank: 2 * group + 2
   // panel ownership (own_table.h; make_geometry): balanced from the model's tile pattern unless SGP_MULTI_OWNERS says
   // "cyclic" or gives an explicit list; own_mode = what the last geometry used (0 cyclic, 1 balanced table, 2 list)
@@ -903,6 +906,10 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   const Geometry& g = F.g;
   const int P = (int)g.P;
   const long N = g.N, S = g.S;
+  if (m->broken) {
+    set_error("multi: this context's RCCL communicators were aborted after a failed call: create a new context");
+    return -4;
+  }
   const double s2 = noise_kind == SGP_NOISE_SCALAR ? noise[0] : 0.0;
   const bool dense_noise = noise_kind == SGP_NOISE_DENSE;   // noise: host N x N, column-major, ld = N
   const int asm_kind = dense_noise ? SGP_NOISE_SCALAR : noise_kind;   // (dense: assembled with s2 = 0, the slabs added below)
@@ -1235,7 +1242,24 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     for (auto& t : th) t.join();
     for (int i = 0; i < P; ++i) {
       if (rcs[i]) {
-        set_error(errs[i]);
+        // One rank's enqueue thread failed and the others stopped where they were: part of the schedule is enqueued, part is
+        // not.  Peer-copy / loopback work only waits for events that were recorded (a wait is enqueued after its record has
+        // been issued), so it drains; RCCL broadcasts whose partners never enqueued their side cannot complete -- the
+        // communicators are aborted (ncclCommAbort) and the context refuses further sharded calls (advisor, round 4).
+        if (m->transport == TR_RCCL) {
+          for (auto& k : m->r) {
+            if (k.comm && m->rccl.CommAbort) m->rccl.CommAbort(k.comm);
+            k.comm = nullptr;
+          }
+          m->broken = true;
+        } else {
+          for (auto& k : m->r) {
+            hipSetDevice(k.dev);
+            hipDeviceSynchronize();
+          }
+          (void)hipGetLastError();
+        }
+        set_error(errs[i] + (m->broken ? " (the context's RCCL communicators were aborted: create a new context)" : ""));
         return rcs[i];
       }
     }
