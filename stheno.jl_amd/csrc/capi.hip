@@ -538,7 +538,12 @@ static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double
                       long ldl, const double* inv, long inv_cstride, long inv_kstride, hipStream_t s) {
   if (rows <= 0) return 0;
   // default: the fused blocked-substitution kernel (potrf.hip), refined at the 16x16 level
-  if (ctx->refine == 1) return launch_panel_solve(X, ldx, rows, Lkk, ldl, inv, inv_cstride, inv_kstride, s);
+  if (ctx->refine == 1) {
+    // (structured models: the 128-row tiles of this block column that are structurally zero are left alone -- the record
+    // chol_bordered / the sharded driver set for the matrix or packed panel being factored, gemm_nt.hip: strip_skip_for)
+    const StripSkip sk = strip_skip_for(X, ldx);
+    return launch_panel_solve(X, ldx, rows, Lkk, ldl, inv, inv_cstride, inv_kstride, s, sk.nz ? &sk : nullptr);
+  }
   if (!ctx->refine)
     return launch_gemm_nt(X, ldx, W, TILE, X, ldx, rows, TILE, TILE, 1.0, 0.0, NOMASK, 0, 0, s);
   if (rows > ctx->n_solve_rows) {
@@ -3529,6 +3534,9 @@ int drv_assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long 
                  hipStream_t s) {
   return assemble(ds, Kv, ld, tile_r_lo, tile_r_hi, tile_c_lo, tile_c_hi, lower_only, noise_kind, sigma2,
                   d_noise_diag, s);
+}
+void drv_set_structure(const double* base, long ld, const sgp::sz_word* d_nz, int words, long tile0) {
+  gemm_set_structure(base, ld, d_nz, words, nullptr, 0, tile0);
 }
 int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_logdet, int* d_info,
                      double* d_invstore, hipStream_t s) {

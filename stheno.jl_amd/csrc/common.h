@@ -162,8 +162,18 @@ struct TileSkip {      // per launch of a lower update C -= P P': C's first tile
 };
 // while set (chol_bordered's scope; per host thread), the lower updates launched on tiles of `base` skip dead tiles;
 // scratch (optional, only for launches that are ordered on one stream): room for the compacted id maps
+// tile0 (round 5): the global tile coordinate of base[0] -- 0 for the bordered matrix itself, c0 / 128 for a PACKED column
+// panel of the sharded factorisation (its element [0] is (row c0, column c0) of the matrix), so that the launches of a
+// panel's own factorisation find their tiles in the pattern too
 void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch = nullptr,
-                        long scratch_ints = 0);
+                        long scratch_ints = 0, long tile0 = 0);
+// the panel solve X <- X inv(L_kk)' over rows of the structured matrix: 128-row tiles of X whose tile (row, k) is structurally
+// zero are left alone (they hold the exact zeros the assembly wrote).  nz == nullptr: every row is solved.
+struct StripSkip {
+  const sz_word* nz = nullptr;
+  int words = 0, tr0 = 0, kt = 0;   // tile row of X's first row, k tile of the block column
+};
+StripSkip strip_skip_for(const double* X, long ldx);   // from the per-thread structure record (gemm_nt.hip), or an empty one
 // chol_df.hip: the whole bordered factorisation (lower tiles of the n_pad columns + rows n_pad .. m_tot) in one launch of
 // persistent workgroups; d_state: SGP_DF_STATE_WORDS + m_tot / 128 ints, d_invall: n_pad / 128 x 2048 doubles
 constexpr int SGP_DF_TIMEOUT = -77;   // *info when a dependency wait inside the kernel ran into its bound
@@ -245,7 +255,7 @@ int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot,
 int launch_potrf_diag_dbg(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long long* dbg,
                           hipStream_t s);
 int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
-                       long inv_cstride, long inv_kstride, hipStream_t s);
+                       long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk = nullptr);
 int launch_trtri(const double* L, long ld, const double* d_invd, double* d_w, hipStream_t s);
 // fp32 storage, fp64 arithmetic: the panel kernels of the fp32 instantiation (f32.hip)
 int launch_potrf_diag_f32(float* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,

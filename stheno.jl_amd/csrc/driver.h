@@ -14,6 +14,10 @@ int drv_assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long 
 // 128-block) in d_invstore (may be NULL) -- what later solves against the factor need
 int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_logdet, int* d_info,
                      double* d_invstore, hipStream_t s);
+// structural zeros inside a PACKED panel's own factorisation (round 5): while set (per host thread), the inner K = 128 updates
+// and the panel solves of drv_panel_factor on a panel whose element [0] is (row, column) = (128 tile0, 128 tile0) of the matrix
+// skip the tiles the pattern says are zero; base = nullptr clears the record
+void drv_set_structure(const double* base, long ld, const sgp::sz_word* d_nz, int words, long tile0);
 // R <- R L^-T for nrows (multiple of 128) rows against an n x n lower factor with its kept inverse blocks
 int drv_row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl, const double* d_invall,
                  long n, hipStream_t s);

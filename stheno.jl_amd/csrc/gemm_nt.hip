@@ -704,6 +704,7 @@ struct GemmStructure {
   int words = 0;
   int* scratch = nullptr;
   long scratch_ints = 0;
+  long tile0 = 0;   // global tile coordinate of base[0] (a packed panel: its first column / 128)
 };
 thread_local GemmStructure g_st;
 // the skip record of the diagonal-aligned lower update C[lower] -= P P' (P's rows = C's rows = C's columns), or an empty one
@@ -716,19 +717,34 @@ TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) 
   if (cr != cc || pr != cr || cr % TILE || pc % TILE || K % TILE || pc + K > cc) return sk;
   sk.nz = g_st.nz;
   sk.words = g_st.words;
-  sk.tr0 = sk.tc0 = (int)(cr / TILE);
-  sk.kt0 = (int)(pc / TILE);
+  sk.tr0 = sk.tc0 = (int)(cr / TILE + g_st.tile0);
+  sk.kt0 = (int)(pc / TILE + g_st.tile0);
   sk.kt1 = sk.kt0 + (int)(K / TILE);
   return sk;
 }
 }  // namespace
-void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch, long scratch_ints) {
+void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch, long scratch_ints,
+                        long tile0) {
   g_st.base = base;
   g_st.ld = ld;
   g_st.nz = d_nz;
   g_st.words = words;
   g_st.scratch = scratch;
   g_st.scratch_ints = scratch_ints;
+  g_st.tile0 = tile0;
+}
+StripSkip strip_skip_for(const double* X, long ldx) {
+  StripSkip sk;
+  if (!g_st.nz || ldx != g_st.ld) return sk;
+  const long ox = X - g_st.base;
+  if (ox < 0) return sk;
+  const long xr = ox % g_st.ld, xc = ox / g_st.ld;
+  if (xr % TILE || xc % TILE || xr <= xc) return sk;   // rows below the diagonal block of a block column
+  sk.nz = g_st.nz;
+  sk.words = g_st.words;
+  sk.tr0 = (int)(xr / TILE + g_st.tile0);
+  sk.kt = (int)(xc / TILE + g_st.tile0);
+  return sk;
 }
 
 // One workgroup per XCD walks that XCD's ids of a lower update in order and writes the live ones (some k tile of the panel

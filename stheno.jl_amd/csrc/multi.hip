@@ -1019,8 +1019,13 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         sub_range(J, q, c, wq);
         if (x.mine(o)) {
           M_RC(x.dev(o));   // (broadcast_panel leaves another rank's device current in the one-thread mode)
-          M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, k.d_small + L.pan + (size_t)J * L.per(), k.d_info,
-                                F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr, k.s_panel));
+          // structural zeros inside the panel's own factorisation (round 5): for the columns of an independent block a third of
+          // the rows below are exact zeros -- the inner K = 128 updates and the panel solves skip those tiles
+          if (m->sz_words > 0) drv_set_structure(Pj, ldp, k.d_sz, m->sz_words, J0 / TILE);
+          const int rcf = drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, k.d_small + L.pan + (size_t)J * L.per(),
+                                           k.d_info, F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr, k.s_panel);
+          if (m->sz_words > 0) drv_set_structure(nullptr, 0, nullptr, 0, 0);
+          M_RC(rcf);
         }
         M_RC(x.rec(o, k.ev_sub[q], k.s_panel));
         if (q == ns - 1) M_RC(x.rec(o, k.ev_fact, k.s_panel));

@@ -82,12 +82,13 @@ constexpr size_t PS_LDS = (size_t)36 * 256 * sizeof(double);  // == one GEMM wor
 
 template <typename TS>
 __device__ __forceinline__ void panel_solve_body(TS* X, long ldx, const TS* L, long ldl, const double* inv,
-                                                 long inv_cstride, long inv_kstride, int strips, long rows, int prio);
+                                                 long inv_cstride, long inv_kstride, int strips, long rows, int prio,
+                                                 StripSkip sk = StripSkip());
 
 __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx, const double* L, long ldl,
                                                           const double* inv, long inv_cstride,
-                                                          long inv_kstride, int strips, long rows, int prio) {
-  panel_solve_body<double>(X, ldx, L, ldl, inv, inv_cstride, inv_kstride, strips, rows, prio);
+                                                          long inv_kstride, int strips, long rows, int prio, StripSkip sk) {
+  panel_solve_body<double>(X, ldx, L, ldl, inv, inv_cstride, inv_kstride, strips, rows, prio, sk);
 }
 // fp32 storage, fp64 arithmetic (f32.hip): the rows and L11 are converted as they are read, the solved rows as
 // they are written
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(256, 2) void panel_solve_f32_kernel(float* X, long 
 
 template <typename TS>
 __device__ __forceinline__ void panel_solve_body(TS* X, long ldx, const TS* L, long ldl, const double* inv,
-                                                 long inv_cstride, long inv_kstride, int strips, long rows, int prio) {
+                                                 long inv_cstride, long inv_kstride, int strips, long rows, int prio,
+                                                 StripSkip sk) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   set_wave_prio(prio);
   double* sL = smem;  // block (c, p), c >= p at (c (c + 1) / 2 + p) * 256, [k][m]
@@ -116,6 +118,11 @@ __device__ __forceinline__ void panel_solve_body(TS* X, long ldx, const TS* L, l
     __builtin_amdgcn_sched_barrier(0);
     const long row0 = ((long)blockIdx.x * strips + st) * PS_ROWS;
     if (row0 >= rows) break;
+    // structural zeros: the 128-row tile these 64 rows belong to holds exact zeros in this block column -- nothing to solve
+    if (sk.nz) {
+      const long tr = sk.tr0 + (row0 >> 7);
+      if (!((sk.nz[tr * sk.words + (sk.kt >> 6)] >> (sk.kt & 63)) & 1)) continue;
+    }
     // uniform column base (scalar registers) + one 32-bit lane offset: keeps the 32 column
     // addresses out of the vector registers
     const int loff = (int)(row0 + w * 16 + l15 + lq * ldx);
@@ -141,7 +148,7 @@ int launch_panel_solve_f32(float* X, long ldx, long rows, const float* L, long l
 }
 
 int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
-                       long inv_cstride, long inv_kstride, hipStream_t s) {
+                       long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk) {
   if (rows <= 0) return 0;
   if (rows % PS_ROWS) {
     set_error("panel_solve: rows must be a multiple of 64");
@@ -154,7 +161,7 @@ int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl
   int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + div - 1) / div));
   long nwg = (nstrips + strips - 1) / strips;
   hipLaunchKernelGGL(panel_solve_kernel, dim3((unsigned)nwg), dim3(256), PS_LDS, s, X, ldx, L, ldl, inv,
-                     inv_cstride, inv_kstride, strips, rows, panel_prio());
+                     inv_cstride, inv_kstride, strips, rows, panel_prio(), sk ? *sk : StripSkip());
   SGP_HIP(hipGetLastError());
   return 0;
 }
