@@ -285,6 +285,15 @@ int sgp_posterior_create(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* m
 int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross, const sgp_cov_spec* prior_ss,
                           const double* mean_s, double* mean_out, double* var_out,
                           double* cov_out, int64_t ldcov);
+/* The same against a cross-covariance GIVEN as a matrix (round 5): conditioning on top of a process whose covariance is not a
+ * sum of kernel terms -- the approximate (VFE) posterior, which the reference returns as an ordinary AbstractGP
+ * (src/gp/sparse_finite_gp.jl:60-62) that can be observed and conditioned again.  `post` was created by sgp_posterior_create on
+ * a zero-term spec with dense noise = cov(f, x) + Sigma_y; cross = cov(f, x*, x), ns x N column-major (ld ldc); prior_var =
+ * var(f, x*) (ns; for var_out), prior_cov = cov(f, x*) (ns x ns, ld ldp; for cov_out), mean_s = mean(f, x*) or NULL.  Host
+ * buffers; single-GPU contexts. */
+int sgp_posterior_predict_explicit(sgp_post* post, const double* cross, int64_t ldc, int64_t ns, const double* prior_var,
+                                   const double* prior_cov, int64_t ldp, const double* mean_s, double* mean_out,
+                                   double* var_out, double* cov_out, int64_t ldcov);
 int sgp_posterior_destroy(sgp_post* post);
 
 /* ---- elbo and its reverse-mode gradient -----------------------------------

@@ -2025,6 +2025,61 @@ extern "C" int sgp_posterior_predict(sgp_post* post, const sgp_cov_spec* cross,
                         0.0, nullptr, s);
 }
 
+// Predictions against a kept factor with the cross-covariance GIVEN as a matrix (round 5): what conditioning on top of a process
+// that is not a prior Stheno process needs -- the approximate (VFE) posterior is an ordinary AbstractGP in the reference
+// (src/gp/sparse_finite_gp.jl:60-62: posterior(VFE(f(z)), fx, y) can be observed and conditioned again), but its covariance
+// is not a sum of kernel terms, so the flattened spec cannot say it.  The host evaluates cov(f, x*, x), var / cov(f, x*) and
+// mean(f, x*) with the operators it has (on the device) and hands them over; the factor was built by sgp_posterior_create on
+// the zero-term spec with dense noise = cov(f, x) + Sigma_y.
+extern "C" int sgp_posterior_predict_explicit(sgp_post* post, const double* cross, int64_t ldc, int64_t ns,
+                                              const double* prior_var, const double* prior_cov, int64_t ldp,
+                                              const double* mean_s, double* mean_out, double* var_out, double* cov_out,
+                                              int64_t ldcov) {
+  CHECK_ARG(post && cross, "sgp_posterior_predict_explicit: NULL argument");
+  sgp_ctx* ctx = post->ctx;
+  CHECK_ARG(ctx_is_live(ctx, post->ctx_serial),
+            "sgp_posterior_predict_explicit: the context this posterior was created on has been destroyed");
+  CHECK_ARG(!post->mp, "sgp_posterior_predict_explicit: not available on a multi-GPU context's sharded factor");
+  const long Ns = ns, N = post->N;
+  CHECK_ARG(Ns >= 0 && ldc >= std::max<long>(Ns, 1), "sgp_posterior_predict_explicit: bad sizes");
+  CHECK_ARG(!var_out || prior_var, "sgp_posterior_predict_explicit: prior_var required for var");
+  CHECK_ARG(!cov_out || (prior_cov && ldp >= Ns && ldcov >= Ns), "sgp_posterior_predict_explicit: prior_cov required for cov");
+  if (Ns == 0) return 0;
+  CtxScope scope(ctx);
+  const long ns_pad = rup(Ns, TILE), n_pad = post->n_pad;
+  hipStream_t s = ctx->stream;
+  DevBuf dV, dms, dmu, dprior, dvar, dcov;
+  CHECK_RC(dV.alloc((size_t)ns_pad * n_pad));
+  if (mean_s) CHECK_RC(dms.upload(mean_s, Ns));
+  SGP_HIP(hipMemsetAsync(dV.p, 0, sizeof(double) * ns_pad * n_pad, s));
+  SGP_HIP(hipMemcpy2DAsync(dV.p, sizeof(double) * ns_pad, cross, sizeof(double) * ldc, sizeof(double) * Ns, (size_t)N,
+                           hipMemcpyHostToDevice, s));
+  CHECK_RC(row_trsm(ctx, dV.p, ns_pad, ns_pad, post->dA, post->m_tot, post->d_wall, n_pad, s));
+  if (mean_out) {
+    CHECK_RC(dmu.alloc(Ns));
+    CHECK_RC(launch_gemv_rows(dV.p, ns_pad, Ns, N, post->dA + n_pad, post->m_tot, mean_s ? dms.p : nullptr, dmu.p, s));
+  }
+  if (var_out) {
+    CHECK_RC(dprior.upload(prior_var, Ns));
+    CHECK_RC(dvar.alloc(Ns));
+    CHECK_RC(launch_colsumsq_sub(dV.p, ns_pad, Ns, N, dprior.p, dvar.p, -1.0, s));
+  }
+  if (cov_out) {
+    CHECK_RC(dcov.alloc((size_t)ns_pad * ns_pad));
+    SGP_HIP(hipMemsetAsync(dcov.p, 0, sizeof(double) * ns_pad * ns_pad, s));
+    SGP_HIP(hipMemcpy2DAsync(dcov.p, sizeof(double) * ns_pad, prior_cov, sizeof(double) * ldp, sizeof(double) * Ns, (size_t)Ns,
+                             hipMemcpyHostToDevice, s));
+    CHECK_RC(launch_gemm_nt(dV.p, ns_pad, dV.p, ns_pad, dcov.p, ns_pad, ns_pad, ns_pad, n_pad, -1.0, 1.0, NOMASK, 0, 0, s));
+  }
+  SGP_HIP(hipStreamSynchronize(s));
+  if (mean_out) SGP_HIP(hipMemcpy(mean_out, dmu.p, sizeof(double) * Ns, hipMemcpyDeviceToHost));
+  if (var_out) SGP_HIP(hipMemcpy(var_out, dvar.p, sizeof(double) * Ns, hipMemcpyDeviceToHost));
+  if (cov_out)
+    SGP_HIP(hipMemcpy2D(cov_out, sizeof(double) * ldcov, dcov.p, sizeof(double) * ns_pad, sizeof(double) * Ns, (size_t)Ns,
+                        hipMemcpyDeviceToHost));
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------
 // VFE: elbo and sparse posterior (App. A.6)
 // ---------------------------------------------------------------------------------------

@@ -507,7 +507,9 @@ def posterior(fx, y, y_vfe=None):
         yy = np.concatenate([p1.y, np.asarray(y, dtype=np.float64).ravel()])
         return posterior(FiniteGP(p1.prior, xx, noise), yy)
     if not _is_prior(fx.f):
-        raise NotImplementedError("posterior on top of an approximate (VFE) posterior")
+        # a process that is not a prior Stheno process but answers mean / var / cov -- the approximate (VFE) posterior, which the
+        # reference returns as an ordinary AbstractGP (sparse_finite_gp.jl:60-62): conditioned through explicit covariances
+        return ExplicitPosteriorGP(fx.f, fx.x, fx.noise, y)
     y = _f64(np.asarray(y, dtype=np.float64).ravel())
     n = len(fx)
     if y.shape[0] != n:
@@ -783,6 +785,81 @@ class ApproxPosteriorGP:
     def mean_and_cov(self, xs):
         m, _, c = self._predict(xs, True, False, True)
         return _model_type((m, c), xs, *self._train_inputs())
+
+
+class ExplicitPosteriorGP:
+    """posterior(g(x2, S2), y2) for a process g whose covariance is not a sum of kernel terms (round 5): g answers
+    mean / var / cov itself (the approximate posterior does, on the device); the factor of cov(g, x2) + S2 is built by
+    sgp_posterior_create on the zero-term spec with dense noise, predictions go through sgp_posterior_predict_explicit with
+    cov(g, x*, x2), var / cov(g, x*) and mean(g, x*) evaluated by g.  AbstractGPs [EXT]: posterior(fx::FiniteGP, y) for any
+    AbstractGP; reference: test/gp/sparse_finite_gp.jl (the VFE posterior used as a GP)."""
+
+    def __init__(self, base, x, noise, y):
+        n = len(x)
+        y = _f64(np.asarray(y, dtype=np.float64).ravel())
+        if y.shape[0] != n:
+            raise ValueError("length(y) != length(fx)")
+        self.base, self.x, self.noise, self.y = base, x, noise, y
+        m, Cm = base.mean_and_cov(x)
+        self._mean_x = _f64(np.asarray(m, dtype=np.float64))
+        Cm = np.asfortranarray(np.asarray(Cm, dtype=np.float64) + _noise_dense(noise, n))
+        self._spec = zero_spec(n)
+        alpha = np.zeros(n)
+        h = C.c_void_p()
+        rc = _ctx().lib.sgp_posterior_create(_ctx().handle, self._spec.ref(), _lib.dptr(self._mean_x), _lib.NOISE_DENSE,
+                                             _lib.dptr(Cm), _lib.dptr(y), _lib.dptr(alpha), C.byref(h))
+        _lib.check(rc, "sgp_posterior_create")
+        self._h, self.alpha, self.delta = h, alpha, y - self._mean_x
+
+    def __del__(self):  # pragma: no cover
+        try:
+            if self._h:
+                _lib.load().sgp_posterior_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    def __call__(self, xs, noise=1e-18):
+        return FiniteGP(self, xs, noise)
+
+    def _train_inputs(self):
+        return (self.x,)
+
+    def _predict(self, xs, want_mean, want_var, want_cov):
+        ns = len(xs)
+        cross = np.asfortranarray(np.asarray(self.base.cov(xs, self.x), dtype=np.float64))       # ns x N
+        ms = _f64(np.asarray(self.base.mean(xs), dtype=np.float64))
+        pv = _f64(np.asarray(self.base.var(xs), dtype=np.float64)) if want_var else None
+        pc = np.asfortranarray(np.asarray(self.base.cov(xs), dtype=np.float64)) if want_cov else None
+        mo = np.zeros(ns) if want_mean else None
+        vo = np.zeros(ns) if want_var else None
+        co = np.zeros((ns, ns), order="F") if want_cov else None
+        rc = _ctx().lib.sgp_posterior_predict_explicit(self._h, _lib.dptr(cross), max(ns, 1), ns, _lib.dptr(pv), _lib.dptr(pc),
+                                                       max(ns, 1), _lib.dptr(ms), _lib.dptr(mo), _lib.dptr(vo), _lib.dptr(co),
+                                                       max(ns, 1))
+        _lib.check(rc, "sgp_posterior_predict_explicit")
+        return mo, vo, co
+
+    def mean(self, xs):
+        return self._predict(xs, True, False, False)[0]
+
+    def var(self, xs):
+        return self._predict(xs, False, True, False)[1]
+
+    def cov(self, xs, zs=None):
+        if zs is None:
+            return self._predict(xs, False, False, True)[2]
+        joint = self._predict(BlockData([xs, zs]) if not isinstance(xs, BlockData) else _concat(xs, zs), False, False, True)[2]
+        nx = len(xs)
+        return joint[:nx, nx:]
+
+    def mean_and_var(self, xs):
+        m, v, _ = self._predict(xs, True, True, False)
+        return m, v
+
+    def mean_and_cov(self, xs):
+        m, _, c = self._predict(xs, True, False, True)
+        return m, c
 
 
 def posterior_vfe(vfe, fx, y):

@@ -107,6 +107,7 @@ _SIGS = {
                                        C.POINTER(_P)]),
     "sgp_posterior_predict": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D,
                                         _D, _D, _D, C.c_int64]),
+    "sgp_posterior_predict_explicit": (C.c_int, [_P, _D, C.c_int64, C.c_int64, _D, _D, C.c_int64, _D, _D, _D, _D, C.c_int64]),
     "sgp_posterior_destroy": (C.c_int, [_P]),
     "sgp_elbo_grad": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D, C.c_int,
                                 _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D, _D]),

@@ -17,7 +17,7 @@ static const struct { const char* name; size_t fnptr_size; } table[] = {
 #define E(f) {#f, sizeof(&f)}
   E(sgp_abi_version), E(sgp_ctx_create), E(sgp_ctx_create_multi), E(sgp_ctx_ndev), E(sgp_ctx_transport), E(sgp_ctx_factor_schedule), E(sgp_ctx_factor_work), E(sgp_cov_spec_suggest_order), E(sgp_ctx_multi_stats), E(sgp_ctx_multi_owners), E(sgp_ctx_multi_profile), E(sgp_ctx_multi_profile_get), E(sgp_ctx_destroy), E(sgp_ctx_trim), E(sgp_ctx_stage_timing), E(sgp_ctx_stage_ms), E(sgp_last_error),
   E(sgp_kernelmatrix), E(sgp_kernelmatrix_diag), E(sgp_logpdf), E(sgp_logpdf_f32), E(sgp_kernelmatrix_f32), E(sgp_rand_f32), E(sgp_posterior_mean_var_f32), E(sgp_logpdf_grad), E(sgp_logpdf_grad_x), E(sgp_logpdf_grad_xs),
-  E(sgp_rand), E(sgp_posterior_create), E(sgp_posterior_predict), E(sgp_posterior_destroy),
+  E(sgp_rand), E(sgp_posterior_create), E(sgp_posterior_predict), E(sgp_posterior_predict_explicit), E(sgp_posterior_destroy),
   E(sgp_elbo), E(sgp_elbo_grad), E(sgp_elbo_grad_x), E(sgp_elbo_grad_xs), E(sgp_kernelmatrix_diag_grad_xs), E(sgp_kernelmatrix_diag_grad),
   E(sgp_kernelmatrix_diag_grad_x), E(sgp_sparse_posterior_create), E(sgp_sparse_posterior_predict),
   E(sgp_sparse_posterior_destroy), E(sgp_dspec_create), E(sgp_dspec_destroy), E(sgp_geometry),

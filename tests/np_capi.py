@@ -300,6 +300,21 @@ class FakeLib:
                 _mat(cov_out, ns, ns, ldcov)[:, :] = Kss - V.T @ V
         return 0
 
+    def sgp_posterior_predict_explicit(self, post, cross, ldc, ns, prior_var, prior_cov, ldp, mean_s, mean_out, var_out, cov_out, ldcov):
+        Lm, alpha = self.posts[id(post)]
+        n = Lm.shape[0]
+        Kx = _mat(cross, ns, n, ldc)                   # ns x N, given
+        ms = np.zeros(ns) if not mean_s else _vec(mean_s, ns)
+        if mean_out:
+            _vec(mean_out, ns)[:] = ms + Kx @ alpha
+        if var_out or cov_out:
+            V = sla.solve_triangular(Lm, Kx.T, lower=True, check_finite=False)
+            if var_out:
+                _vec(var_out, ns)[:] = _vec(prior_var, ns) - (V * V).sum(0)
+            if cov_out:
+                _mat(cov_out, ns, ns, ldcov)[:, :] = _mat(prior_cov, ns, ns, ldp) - V.T @ V
+        return 0
+
     def sgp_posterior_destroy(self, post):
         return 0
 
