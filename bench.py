@@ -59,16 +59,21 @@ def cpu_baseline(name, n_sample):
                       elbo_m=bc.ELBO_M, elbo_znoise=bc.ELBO_ZNOISE)
 
 
-def update_launches(N):
+def update_launches(N, schedule=None):
     """(rows m, columns nc, depth K) of every trailing-update launch of one logpdf, mirroring the driver's panel rule
-    (capi.hip: chol_bordered / panel_factor_mid): below 65536 columns outer panels of W with the look-ahead split (next
-    panel's columns, then the rest); from 65536 on the serial schedule with outer panels of 4096 columns factored by
-    recursive halving down to 1024 (one update of the right half per level)."""
+    (capi.hip: chol_bordered / panel_factor_mid): outer panels of W with the look-ahead split (next panel's columns, then
+    the rest) -- W = 2048 under the hybrid schedule (the default from 24576 columns on: the panels themselves are
+    factored by the dataflow kernel); the launch-only schedules: W = 512 / 1024 below 65536 columns, from 65536 on the
+    serial schedule with outer panels of 4096 columns factored by recursive halving down to 1024 (one update of the right
+    half per level)."""
     n_pad = (N + 127) // 128 * 128
     m_tot = n_pad + 128
     out = []
-    deep = n_pad >= 65536
+    hybrid = schedule == "hybrid"
+    deep = n_pad >= 65536 and not hybrid
     W = n_pad if n_pad <= 4096 else (1024 if n_pad <= 8192 else (4096 if deep else (1024 if n_pad >= 32768 else 512)))
+    if hybrid:
+        W = min(int(os.environ.get("SGP_HYBRID_W", 2048)) // 128 * 128, n_pad)
 
     def mid(c0, w):          # recursive halving inside the panel starting at global column c0
         if not deep or w <= 1024:
@@ -95,10 +100,10 @@ def update_launches(N):
     return out
 
 
-def update_bytes_avg(N):
+def update_bytes_avg(N, schedule=None):
     """Algorithmic bytes of an average trailing-update launch of one logpdf: every launch reads and writes the
     lower 128-tiles of its C block once and reads its panel rows once."""
-    ls = update_launches(N)
+    ls = update_launches(N, schedule)
     tot = 0.0
     for (m, nc, k) in ls:
         entries = nc * (nc + 128) / 2 + (m - nc) * nc          # lower tiles of the square part + rows below
@@ -440,7 +445,8 @@ def main():
             achieved = whole_tflops
         n_pad = (N + 127) // 128 * 128
         fused = n_pad < 32768     # capi.hip: fuse_mode -- the look-ahead column updates carry the next diagonal block
-        serial = n_pad >= 65536   # capi.hip: chol_bordered -- no look-ahead from 65536 columns on, every update launch fused
+        hybrid = schedule == "hybrid"
+        serial = n_pad >= 65536 and not hybrid   # capi.hip: chol_bordered -- launch-only schedule: no look-ahead from 65536 columns on
         if dataflow:
             kname = ("sgp::chol_dataflow_fat_kernel" if schedule == "dataflow-fat" else "sgp::chol_dataflow_kernel") + (
                 " (the whole blocked Cholesky in one launch of persistent workgroups: 128 x 128 tile tasks in topological "
@@ -448,6 +454,11 @@ def main():
                 "potrf_diag_body, off-diagonal tiles through the refined 16-row substitution; tile-row progress counters with "
                 "agent-scope release / acquire instead of kernel boundaries" +
                 ("; one workgroup per CU, 256 VGPRs)" if schedule == "dataflow-fat" else "; two workgroups per CU)"))
+        elif hybrid:
+            kname = ("sgp::gemm_nt_dma_kernel<1> (fp64 MFMA trailing update of the blocked Cholesky, v_mfma_f64_4x4x4_4b_f64; hybrid "
+                     "schedule: outer panels of 2048 columns, each factored by ONE launch of sgp::chol_dataflow_fat_kernel on the "
+                     "panel -- diagonal chain and row solves as tile tasks -- beside the previous panel's K = 2048 trailing update; "
+                     "two update launches per panel: the next panel's columns, then the rest)")
         elif serial:
             kname = ("sgp::gemm_nt_dma_potrf_kernel<1, true> (fp64 MFMA trailing update of the blocked Cholesky, "
                      "v_mfma_f64_4x4x4_4b_f64: the tile program of sgp::gemm_nt_dma_kernel, whose tile (0, 0) workgroup goes on "
@@ -486,7 +497,7 @@ def main():
         if rec:
             roofline["traffic"] = rec["hbm_bytes"]
             roofline["traffic_source"] = rec
-        roofline["algorithmic_bytes_per_launch_avg"] = (8.0 * N * (N + 1) if dataflow else update_bytes_avg(N))   # dataflow: the
+        roofline["algorithmic_bytes_per_launch_avg"] = (8.0 * N * (N + 1) if dataflow else update_bytes_avg(N, schedule))   # dataflow: the
         # lower triangle read once and written once
         roofline["traffic_measured_in_this_run"] = False   # (counters need separate rocprofv3 --pmc passes: see traffic_source)
         asm_bytes = 8.0 * N * (N + 1) / 2 + 8.0 * D * N

@@ -198,6 +198,11 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (la) c->lookahead = atoi(la);
     const char* lx = getenv("SGP_LA_MAX_N");
     if (lx) c->la_max_n = atol(lx);
+    if (const char* hy = getenv("SGP_HYBRID")) c->hybrid = atoi(hy);
+    if (const char* hy = getenv("SGP_HYBRID_WGS")) c->hybrid_wgs = std::max(8, atoi(hy));
+    if (const char* hy = getenv("SGP_HYBRID_FAT")) c->hybrid_fat = atoi(hy);
+    if (const char* hy = getenv("SGP_HYBRID_W")) c->hybrid_w = std::max<long>(TILE, atol(hy) / TILE * TILE);
+    if (const char* hy = getenv("SGP_HYBRID_MIN_N")) c->hybrid_min_n = atol(hy);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* wm = getenv("SGP_WMID");
@@ -714,6 +719,20 @@ static void df_patch_of(const sgp_ctx* ctx, int fat, int& pr, int& pc) {
   const int slots = std::max(1, ctx->df_wgs / DF_NQ);                 // workgroups that serve one queue
   pr = ctx->df_pr > 0 ? ctx->df_pr : std::max(1, slots / pc);
 }
+// Hybrid schedule (round 5; the round-4 verdict's item 4): the look-ahead schedule of the launches with every outer PANEL (2048
+// columns) factored by ONE launch of the dataflow kernel on the panel -- its diagonal chain and the row solves below it as
+// tile tasks with tile-level dependencies (the rows below the panel's diagonal block are that kernel's "bordered rows") --
+// while the trailing updates stay lock-step launches of K = 2048 (operand sharing through L2, 0.85 in situ).  The panel
+// kernel runs beside the previous panel's trailing update: the chain that the serial-deep schedule pays in full (57 ms at
+// N = 65536) and that the launch-based look-ahead ran 2.5 - 3 x slower beside an update (many small dependent launches) is
+// hidden.  Same arithmetic order per tile (k ascending): bit-identical.  Measured (profiles/r05_experiments/hybrid.md):
+// N = 65536 1454 -> 1395 ms, 32768 197 -> 182 ms, 16384 26.7 -> 28.6 (stays on the dataflow kernel).
+static bool use_hybrid(const sgp_ctx* ctx, long n_pad) {
+  if (ctx->refine != 1 || ctx->hybrid == 0 || n_pad < 4096) return false;
+  if (ctx->hybrid == 1) return true;
+  // by size -- unless the caller pinned another schedule (SGP_DATAFLOW = 0 / 1, SGP_LOOKAHEAD = 0)
+  return ctx->dataflow < 0 && ctx->lookahead != 0 && n_pad >= ctx->hybrid_min_n;
+}
 static bool use_dataflow(const sgp_ctx* ctx, long n_pad) {
   if (ctx->refine != 1 || ctx->dataflow == 0) return false;
   return ctx->dataflow == 1 || (n_pad >= ctx->df_min_n && n_pad < ctx->df_max_n);
@@ -792,6 +811,7 @@ extern "C" int sgp_cov_spec_suggest_order(const sgp_cov_spec* sp, int32_t* perm_
 extern "C" const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N) {
   if (!ctx || N < 1) return "";
   const long n_pad = rup(N, TILE);
+  if (use_hybrid(ctx, n_pad)) return "hybrid";
   if (use_dataflow(ctx, n_pad)) return n_pad < ctx->df_fat_max_n ? "dataflow-fat" : "dataflow";
   const bool la = ctx->lookahead && (n_pad < ctx->la_max_n || ctx->lookahead == 2);
   if (la) return n_pad <= 4096 && ctx->wout <= 0 ? "launches-one-panel" : "launches-lookahead";
@@ -836,7 +856,9 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // Dataflow factorisation (chol_df.hip): one launch of persistent workgroups, tile-level dependencies instead of
   // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
   // upper-triangular border, `grow`: its tasks would have to skip the structurally zero tiles.)
-  if (grow == 0 && use_dataflow(ctx, n_pad)) {
+  // hybrid (round 5 experiment): the look-ahead schedule of the launches, its panels factored by the dataflow kernel
+  const bool hybrid = grow == 0 && s == ctx->stream && use_hybrid(ctx, n_pad);
+  if (hybrid || (grow == 0 && use_dataflow(ctx, n_pad))) {
     const long need_state = SGP_DF_STATE_WORDS + m_tot / TILE, need_inv = (n_pad / TILE) * INVD_STRIDE;
     if (need_state > ctx->n_df_state) {
       SGP_HIP(hipStreamSynchronize(s));
@@ -854,6 +876,8 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       SGP_HIP(hipMalloc(&ctx->d_df_inv, sizeof(double) * need_inv));
       ctx->n_df_inv = need_inv;
     }
+  }
+  if (!hybrid && grow == 0 && use_dataflow(ctx, n_pad)) {
     const int fat = n_pad < ctx->df_fat_max_n ? 1 : 0;
     // XCD-affine task queues (df_order.h): built on the host once per shape, kept on the device
     const uint32_t* d_tasks = nullptr;
@@ -976,16 +1000,20 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // alone); the serial schedule with fused diagonal blocks measures the same or better (1525 vs 1539 ms dense
   // Matern-5/2, 1515 vs 1501 ms on the three-block model, same box) and leaves every kernel uncontended; at 32768 the
   // look-ahead still wins (202 vs 207 ms).  SGP_LOOKAHEAD=2: look-ahead at every size.
-  const bool la = ctx->lookahead && s == ctx->stream && (n_pad < ctx->la_max_n || ctx->lookahead == 2);
+  const bool la = (ctx->lookahead && s == ctx->stream && (n_pad < ctx->la_max_n || ctx->lookahead == 2)) || hybrid;
   // Serial schedule at n_pad >= 65536 (round 3): outer panels of 4096 columns factored by recursive halving down to 1024
   // (panel_factor_mid) -- the big trailing updates run with K = 4096, the mid updates with K = 2048 / 1024, the shallow
   // K = 128 work stays that of 1024-wide panels: per-tile prologue / epilogue share and C-tile traffic per flop drop,
   // same flops, bit-identical result.  N = 65536 on one box: W = 1024 1499 ms, 2048 / 1024 1469, 4096 / 1024 1458,
   // 8192 / 1024 1463, 16384 / 1024 1469, 4096 / 512 1465; under the look-ahead (N = 16384, 32768) it loses.
   // (one stream: the compacted id maps of consecutive structured launches may share one scratch buffer)
-  if (sz_scope.on && !la && s == ctx->stream) gemm_set_structure(A, ld, sz->d_nz, sz->words, ctx->d_szmap, ctx->n_szmap);
+  // (two streams under the look-ahead: a map each)
+  if (sz_scope.on && s == ctx->stream)
+    gemm_set_structure(A, ld, sz->d_nz, sz->words, ctx->d_szmap, ctx->n_szmap / 2, 0, la ? ctx->stream2 : nullptr,
+                       la ? ctx->d_szmap + ctx->n_szmap / 2 : nullptr);
   const bool deep = !la && n_pad >= 65536;
-  const long WOUT = ctx->wout > 0 ? ctx->wout
+  const long WOUT = hybrid ? std::min(ctx->hybrid_w, n_pad)
+                    : ctx->wout > 0 ? ctx->wout
                     : n_pad <= 4096 ? n_pad
                     : n_pad <= 8192 ? WOUT_LARGE
                     : deep ? 4 * WOUT_LARGE
@@ -999,7 +1027,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // 1.09 ms, 4096 2.93 -> 2.73 ms, 16384 33.8 -> 33.2 ms; from 32768 on the panel stream has slack and the fused
   // launches measure the same or 1 % slower (profiles/archive/r02_microbench.md).  Bit 2: at every size (A/B).
   FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad, !la));
-  const bool fuse_outer = (ctx->fuse_now & 2) && ctx->refine == 1;
+  const bool fuse_outer = (ctx->fuse_now & 2) && ctx->refine == 1 && !hybrid;   // (the dataflow panel factors its own first block)
   bool first_done = false;
   bool rest_pending = false;
   if (la) {
@@ -1010,8 +1038,16 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
     long wj = std::min(WOUT, n_pad - J0);
     const long m_eff = grow > 0 ? std::min(m_tot, grow + J0 + wj) : m_tot;  // rows this panel touches
-    CHECK_RC(panel_factor_mid(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
-                              ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done, WMID));
+    if (hybrid) {
+      // the panel as ONE launch of persistent workgroups: its diagonal chain and the row solves below it with tile-level
+      // dependencies (the rows below the panel's diagonal block are the kernel's "bordered rows")
+      CHECK_RC(launch_chol_dataflow(A + J0 + J0 * ld, ld, wj, m_eff - J0, ctx->d_df_state,
+                                    (d_wall ? d_wall : ctx->d_df_inv) + (J0 / TILE) * INVD_STRIDE, ctx->d_slots + J0 / TILE,
+                                    ctx->d_info, ctx->hybrid_wgs, ctx->df_timeout_s, s, nullptr, nullptr, ctx->hybrid_fat,
+                                    nullptr, nullptr, 0.0, sz ? sz->d_nz : nullptr, sz ? sz->words : 0, J0));
+    } else
+      CHECK_RC(panel_factor_mid(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
+                                ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done, WMID));
     long c0 = J0 + wj;
     if (c0 >= n_pad) break;
     const FusedDiag fz_next = {d_wall ? d_wall + (c0 / TILE) * INVD_STRIDE : ctx->d_invd, ctx->d_slots + c0 / TILE,
@@ -1164,7 +1200,8 @@ static int sz_upload(sgp_ctx* ctx, const std::vector<sz_word>& h, int words, hip
   SGP_HIP(hipStreamSynchronize(s));
   {   // room for the id map of the largest lower update this matrix can see
     const long rows = (long)(h.size() / (size_t)words);
-    const long need = 16 + 8 * tri_ids_per_xcd(tri_shape(rows, std::min<long>(rows, (long)words * 64), -1));
+    const long half = 16 + 8 * tri_ids_per_xcd(tri_shape(rows, std::min<long>(rows, (long)words * 64), -1));
+    const long need = 2 * half;   // two maps: the look-ahead schedules launch structured updates on two streams
     if (need > ctx->n_szmap) {
       SGP_HIP(hipStreamSynchronize(s));
       if (ctx->d_szmap) hipFree(ctx->d_szmap);
@@ -1328,12 +1365,14 @@ static int with_df_fallback(sgp_ctx* ctx, F&& run) {
   if (ctx) ctx->df_timed_out = false;
   int rc = run();
   if (ctx && rc == -3 && ctx->df_timed_out && ctx->df_fallback) {
-    const int keep = ctx->dataflow;
+    const int keep = ctx->dataflow, keep_h = ctx->hybrid;
     ctx->dataflow = 0;
+    ctx->hybrid = 0;
     ctx->df_timed_out = false;
     ctx->df_fallbacks += 1;
     rc = run();
     ctx->dataflow = keep;
+    ctx->hybrid = keep_h;
   }
   return rc;
 }

@@ -57,6 +57,8 @@ struct DfArgs {
   const sz_word* nz;  // structural zeros (common.h): bit k of row i = tile (i, k) of the factor may be non-zero; nullptr = dense
   int nzw;            // words per row
   int diag_lower;     // 1: the diagonal tiles' contractions run the lower-only form (df_contract_diag); SGP_DF_DIAG_LOWER=0: A/B
+  long gcol_base;     // global column of tile column 0 (the hybrid schedule factors PANELS with this kernel: PosDef info)
+  int nz_t0;          // ... and its tile index: where the panel sits in the pattern
   long long* stats;   // optional (SGP_DF_STATS): 8 tick counters per workgroup, see launch_chol_dataflow
   long long* cols;    // optional: 8 wall-clock stamps per tile column (the chain: diagonal task + the task below it)
 };
@@ -190,17 +192,22 @@ __device__ __forceinline__ int df_wait_word(const DfArgs& a, int* word, int targ
 }
 
 // structural zeros: is tile (i, j) of the factor structurally non-zero?
+// (nz_t0: the pattern is the whole matrix's; a panel factored by this kernel -- the hybrid schedule -- sits nz_t0 tiles down
+// and to the right in it, and its k blocks are the panel's own columns)
 __device__ __forceinline__ bool df_nz(const DfArgs& a, int i, int j) {
-  return !a.nz || ((a.nz[(long)i * a.nzw + (j >> 6)] >> (j & 63)) & 1) != 0;
+  const int jj = j + a.nz_t0;
+  return !a.nz || ((a.nz[(long)(i + a.nz_t0) * a.nzw + (jj >> 6)] >> (jj & 63)) & 1) != 0;
 }
 // thread 0: the next run of k blocks >= k0 (and < j) that task (i, j) has to contract -- both L_ik and L_jk structurally
 // non-zero: [ka, kb); ka == j: none left
-__device__ __forceinline__ void df_next_run(const DfArgs& a, int i, int j, int k0, int& ka, int& kb) {
-  const sz_word* ri = a.nz + (long)i * a.nzw;
-  const sz_word* rj = a.nz + (long)j * a.nzw;
+__device__ __forceinline__ void df_next_run(const DfArgs& a, int i, int j, int k0_, int& ka, int& kb) {
+  const int t0 = a.nz_t0;
+  const sz_word* ri = a.nz + (long)(i + t0) * a.nzw;
+  const sz_word* rj = a.nz + (long)(j + t0) * a.nzw;
+  const int jg = j + t0, k0 = k0_ + t0;   // global tile columns
   ka = j;
   kb = j;
-  const int qlast = (j - 1) >> 6;
+  const int qlast = (jg - 1) >> 6;
   int q = k0 >> 6;
   sz_word m = (ri[q] & rj[q]) & (~(sz_word)0 << (k0 & 63));
   while (m == 0 && q < qlast) {
@@ -209,15 +216,15 @@ __device__ __forceinline__ void df_next_run(const DfArgs& a, int i, int j, int k
   }
   if (m == 0) return;
   const int first = q * 64 + __builtin_ctzll(m);
-  if (first >= j) return;
-  ka = first;
+  if (first >= jg) return;
+  ka = first - t0;
   // the end of the run: the first k > ka that is not needed
-  sz_word z = ~(ri[q] & rj[q]) & (~(sz_word)0 << (ka & 63));
+  sz_word z = ~(ri[q] & rj[q]) & (~(sz_word)0 << (first & 63));
   while (z == 0 && q < qlast) {
     ++q;
     z = ~(ri[q] & rj[q]);
   }
-  if (z != 0) kb = min(j, q * 64 + (int)__builtin_ctzll(z));
+  if (z != 0) kb = min(j, q * 64 + (int)__builtin_ctzll(z) - t0);
 }
 
 // lane 0, after every wave has drained its stores and met at a barrier: release fence, drain, progress counter
@@ -348,7 +355,7 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
 // Phase 2a: Cholesky of the diagonal tile sitting in LDS
 __device__ __forceinline__ void df_diag_body(const DfArgs& a, int j) {
   potrf_diag_body<false, double, true>(a.A + (long)j * TILE + (long)j * TILE * a.ld, a.ld, a.invall + (long)j * 2048,
-                                       a.slots + j, a.info, (long)j * TILE, 0, nullptr);
+                                       a.slots + j, a.info, a.gcol_base + (long)j * TILE, 0, nullptr);
 }
 
 // Phase 2b: L_ij = T inv(L_jj)' for the tile's 128 rows, eight waves x 16 rows
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void chol_dataflow_fat_kernel(DfArgs a) { c
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
                          int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats, long long* d_cols,
                          int fat, const uint32_t* d_tasks, const int* qstart, double gang_us, const sz_word* d_nz,
-                         int nz_words) {
+                         int nz_words, long gcol_base) {
   if (n_pad % TILE || m_tot % TILE || n_pad <= 0 || m_tot < n_pad) {
     set_error("chol_dataflow: sizes must be multiples of 128");
     return -1;
@@ -568,6 +575,8 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
   a.cols = d_stats ? d_cols : nullptr;
   a.nz = d_nz;
   a.nzw = nz_words;
+  a.gcol_base = gcol_base;
+  a.nz_t0 = (int)(gcol_base / TILE);
   SGP_HIP(hipMemsetAsync(d_state, 0, sizeof(int) * (DF_PROG + (size_t)a.T_r), s));
   const long grid = std::min<long>(a.ntasks, n_wg);
   if (fat)

@@ -165,8 +165,10 @@ struct TileSkip {      // per launch of a lower update C -= P P': C's first tile
 // tile0 (round 5): the global tile coordinate of base[0] -- 0 for the bordered matrix itself, c0 / 128 for a PACKED column
 // panel of the sharded factorisation (its element [0] is (row c0, column c0) of the matrix), so that the launches of a
 // panel's own factorisation find their tiles in the pattern too
+// (scratch / scratch_ints: room for the compacted live-tile id map of a launch; stream2 / scratch2: a second map of the same
+// size for the launches of that other stream -- launches of one stream are ordered, so a map per stream is enough)
 void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch = nullptr,
-                        long scratch_ints = 0, long tile0 = 0);
+                        long scratch_ints = 0, long tile0 = 0, hipStream_t stream2 = nullptr, int* scratch2 = nullptr);
 // the panel solve X <- X inv(L_kk)' over rows of the structured matrix: 128-row tiles of X whose tile (row, k) is structurally
 // zero are left alone (they hold the exact zeros the assembly wrote).  nz == nullptr: every row is solved.
 struct StripSkip {
@@ -180,7 +182,8 @@ constexpr int SGP_DF_TIMEOUT = -77;   // *info when a dependency wait inside the
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
                          int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats = nullptr,
                          long long* d_cols = nullptr, int fat = 0, const uint32_t* d_tasks = nullptr,
-                         const int* qstart = nullptr, double gang_us = 0.0, const sz_word* d_nz = nullptr, int nz_words = 0);
+                         const int* qstart = nullptr, double gang_us = 0.0, const sz_word* d_nz = nullptr, int nz_words = 0,
+                         long gcol_base = 0);
 // d_tasks = qstart[9], the queues, pend[] (df_order.h: df_build_queues); qstart: host copy
 constexpr long SGP_DF_STATE_WORDS = 16;   // state words ahead of the per-tile-row progress counters
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,

@@ -705,6 +705,10 @@ struct GemmStructure {
   int* scratch = nullptr;
   long scratch_ints = 0;
   long tile0 = 0;   // global tile coordinate of base[0] (a packed panel: its first column / 128)
+  // a second map for the launches of ONE other stream (the look-ahead schedules issue the far updates there: launches of a
+  // stream are ordered, so one map per stream is enough)
+  hipStream_t stream2 = nullptr;
+  int* scratch2 = nullptr;
 };
 thread_local GemmStructure g_st;
 // the skip record of the diagonal-aligned lower update C[lower] -= P P' (P's rows = C's rows = C's columns), or an empty one
@@ -724,7 +728,7 @@ TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) 
 }
 }  // namespace
 void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch, long scratch_ints,
-                        long tile0) {
+                        long tile0, hipStream_t stream2, int* scratch2) {
   g_st.base = base;
   g_st.ld = ld;
   g_st.nz = d_nz;
@@ -732,6 +736,8 @@ void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int wo
   g_st.scratch = scratch;
   g_st.scratch_ints = scratch_ints;
   g_st.tile0 = tile0;
+  g_st.stream2 = stream2;
+  g_st.scratch2 = scratch2;
 }
 StripSkip strip_skip_for(const double* X, long ldx) {
   StripSkip sk;
@@ -790,10 +796,11 @@ __global__ __launch_bounds__(1024) void tile_compact_kernel(TileSkip sk, long n_
 }
 // big structured launches on an ordered stream: build the compacted id map first (the update kernel reads it)
 static int maybe_compact(TileSkip& sk, long n_tr, long n_tc, long per_xcd, int keep_first, hipStream_t s) {
-  if (!sk.nz || !g_st.scratch || per_xcd * 8 < 4096 || 16 + per_xcd * 8 > g_st.scratch_ints) return 0;
-  hipLaunchKernelGGL(tile_compact_kernel, dim3(8), dim3(1024), 0, s, sk, n_tr, n_tc, (int)per_xcd, g_st.scratch, keep_first);
+  int* map = (g_st.scratch2 && s == g_st.stream2) ? g_st.scratch2 : g_st.scratch;
+  if (!sk.nz || !map || per_xcd * 8 < 4096 || 16 + per_xcd * 8 > g_st.scratch_ints) return 0;
+  hipLaunchKernelGGL(tile_compact_kernel, dim3(8), dim3(1024), 0, s, sk, n_tr, n_tc, (int)per_xcd, map, keep_first);
   SGP_HIP(hipGetLastError());
-  sk.cmap = g_st.scratch;
+  sk.cmap = map;
   sk.cstride = (int)per_xcd;
   return 0;
 }

@@ -11,7 +11,7 @@ import pytest
 
 import stheno_jl_amd as P
 from oracle import reference_model as orm
-from test_gpu_fused_potrf import _ctx, _operators, _with_ctx
+from test_gpu_fused_potrf import _ctx, _operators, _problem, _with_ctx
 
 pytestmark = pytest.mark.gpu
 
@@ -74,8 +74,9 @@ def test_schedule_by_size_and_the_baseline_goldens_under_it():
     assert ctx.factor_schedule(2048) == "launches-one-panel"
     assert ctx.factor_schedule(4096) == "dataflow-fat"
     assert ctx.factor_schedule(16384) == "dataflow-fat"
-    assert ctx.factor_schedule(32768) == "dataflow"
-    assert ctx.factor_schedule(65536) == "launches-serial-deep"
+    assert ctx.factor_schedule(20000) == "dataflow-fat" or ctx.factor_schedule(20000) == "dataflow"
+    assert ctx.factor_schedule(32768) == "hybrid"
+    assert ctx.factor_schedule(65536) == "hybrid"
     for name in ("n4k", "c2"):
         w = bc.build(P, name)
         got = P.logpdf(w["fx"], w["y"])
@@ -127,7 +128,16 @@ def test_schedule_limits_move_with_their_environment_variables(monkeypatch):
     assert ctx.factor_schedule(1000) == "dataflow-fat"              # the limits apply to the padded column count (1024)
     assert ctx.factor_schedule(4096) == "dataflow"
     assert ctx.factor_schedule(8192) == "launches-lookahead"
+    assert ctx.factor_schedule(24576) == "hybrid"
     ctx.close()
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=-1, SGP_HYBRID_MIN_N=6100)
+    assert ctx.factor_schedule(6000) == "dataflow" and ctx.factor_schedule(6100) == "hybrid"   # (6016 / 6144 padded columns)
+    ctx.close()
+    monkeypatch.delenv("SGP_HYBRID_MIN_N")
+    off = _ctx(monkeypatch, 11, SGP_DATAFLOW=-1, SGP_HYBRID=0)
+    assert off.factor_schedule(32768) == "launches-lookahead" and off.factor_schedule(65536) == "launches-serial-deep"
+    off.close()
+    monkeypatch.delenv("SGP_HYBRID")
     never = _ctx(monkeypatch, 11, SGP_DATAFLOW=0)
     always = _ctx(monkeypatch, 11, SGP_DATAFLOW=1)
     for N in (130, 5000, 70000):
@@ -135,6 +145,66 @@ def test_schedule_limits_move_with_their_environment_variables(monkeypatch):
         assert always.factor_schedule(N).startswith("dataflow")
     never.close()
     always.close()
+
+
+@pytest.mark.parametrize("fat,wgs,W", [(1, 256, 1024), (0, 512, 1024), (1, 7, 2048), (0, 96, 512)])
+@pytest.mark.parametrize("N", [4500, 6200])
+def test_hybrid_schedule_is_bit_identical_to_the_launch_based_factorisation(monkeypatch, N, fat, wgs, W):
+    """The hybrid schedule (capi.hip: use_hybrid; the default from 24576 columns on, forced here at test sizes): every outer
+    panel factored by one launch of the dataflow kernel ON THE PANEL (its pattern and PosDef column offset by the panel's
+    position), the trailing updates lock-step launches with look-ahead.  The three-block sum model has structural zeros:
+    the panel launches read the whole matrix's tile pattern at their offset."""
+    ref_ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0, SGP_HYBRID=0)
+    ref, (xs, y) = _with_ctx(ref_ctx, lambda: _operators(N))
+    want = orm.gppp_sum_logpdf(xs, y, 0.1)
+    assert abs(ref["logpdf"][0] - want) <= 1e-10 * abs(want)
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=-1, SGP_HYBRID=1, SGP_HYBRID_W=W, SGP_HYBRID_WGS=wgs, SGP_HYBRID_FAT=fat)
+    assert ctx.factor_schedule(N) == "hybrid"
+    for rep in range(2):
+        got, _ = _with_ctx(ctx, lambda: _operators(N))
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (N, rep, k, np.max(np.abs(ref[k] - got[k])))
+    F, x, _, yy = _problem(N)
+    _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), yy))
+    e, d = ctx.factor_work()
+    assert e < 0.9 * d          # the structure is on under the hybrid schedule
+    for sz in (0,):             # ... and the same bits without it
+        dense = _ctx(monkeypatch, 11, SGP_DATAFLOW=-1, SGP_HYBRID=1, SGP_HYBRID_W=W, SGP_STRUCT_ZEROS=sz)
+        got, _ = _with_ctx(dense, lambda: _operators(N))
+        for k in ref:
+            assert np.array_equal(ref[k], got[k]), (N, "dense", k)
+        dense.close()
+    ctx.close()
+    ref_ctx.close()
+
+
+def test_hybrid_reports_the_same_failing_minor_and_survives_a_timeout(monkeypatch):
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    N = 5000
+    x = P.ColVecs(np.asfortranarray(rng.standard_normal((2, N))))
+    f = P.atomic(P.GP(P.SEKernel()), P.GPC())
+    y = rng.standard_normal(N)
+    msgs = []
+    for hy in (0, 1):   # SE kernel with negative noise: the failing minor lies in a later panel or the first, the text says which
+        ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0, SGP_HYBRID=hy, SGP_HYBRID_W=1024)
+        with pytest.raises(P.lib.SthenoMIError) as e:
+            _with_ctx(ctx, lambda: P.logpdf(f(x, -1e-3), y))
+        msgs.append(str(e.value))
+        ctx.close()
+    assert "not positive definite" in msgs[0] and msgs[0] == msgs[1], msgs
+    # a wait bound of a nanosecond: the operator is rerun on the launch-based schedule, same bits
+    ref_ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=0, SGP_HYBRID=0)
+    ref, _ = _with_ctx(ref_ctx, lambda: _operators(4500))
+    ctx = _ctx(monkeypatch, 11, SGP_DATAFLOW=-1, SGP_HYBRID=1, SGP_HYBRID_W=1024, SGP_DF_TIMEOUT_S="1e-9")
+    got, _ = _with_ctx(ctx, lambda: _operators(4500))
+    for k in ref:
+        assert np.array_equal(ref[k], got[k]), k
+    n = C.c_int64()
+    P.lib.check(ctx.lib.sgp_bench_df_fallbacks(ctx.handle, C.byref(n)))
+    assert n.value >= 1
+    ctx.close()
+    ref_ctx.close()
 
 
 def test_a_dataflow_timeout_falls_back_to_the_launches_with_the_same_bits(monkeypatch):

@@ -43,6 +43,9 @@ for c, pat in DOMINANT.items():
     f_, w_ = jload(f"pmc_{c}_FETCH_SIZE.json"), jload(f"pmc_{c}_WRITE_SIZE.json")
     if not f_ or not w_:
         continue
+    sched = ((lines.get("default" if c == "c5" else c) or {}).get("roofline") or {}).get("schedule")
+    if sched == "hybrid":      # the trailing updates of the hybrid schedule are plain launches (the panels: chol_dataflow_fat_kernel)
+        pat = DOMINANT[c] = "gemm_nt_dma_kernel<1>"
     ks = [k for k in f_["kernels"] if pat in k]
     if not ks:
         continue
@@ -54,10 +57,9 @@ for c, pat in DOMINANT.items():
     per_step = c == "c4"                      # many launch shapes: the figure is per STEP of the bound, not per launch
     div = 1 if per_step else max(1, n)
     hbm = (2.0 * fk + wk) * 1024.0 / div
-    if c == "c5":
-        alg = bench.update_bytes_avg(N)
-    elif c == "target":   # the launches skip the structurally dead tiles: their share of the dense launches' bytes
-        alg = bench.update_bytes_avg(N) * float(line.get("executed_work_fraction") or 1.0)
+    if c == "c5" or sched == "hybrid" or c == "target":
+        # (structured models: the launches skip the structurally dead tiles -- their share of the dense launches' bytes)
+        alg = bench.update_bytes_avg(N, sched) * float(line.get("executed_work_fraction") or 1.0)
     elif c == "c4":
         alg = line["roofline"]["hbm_stage"]["algorithmic_bytes"] * 4.0    # K(x,z) written, read, A written, read
     else:
