@@ -299,9 +299,10 @@ int sgp_posterior_destroy(sgp_post* post);
 /* ---- elbo and its reverse-mode gradient -----------------------------------
  * What Zygote derives through `elbo(VFE(f(z)), f(x, s2), y)` on the reference path
  * (AbstractGPs.elbo [EXT], App. A.6; src/gp/sparse_finite_gp.jl:37-62).  Arguments as sgp_elbo
- * (Sigma_y and Sigma_z scalar or diagonal).  Outputs (any but elbo_out may be NULL):
+ * (Sigma_y scalar or diagonal, as in AbstractGPs.elbo; Sigma_z scalar, diagonal or dense).  Outputs (any but elbo_out
+ * may be NULL):
  *   grad_y[N], grad_mean[N] = -grad_y, grad_noise[1 | N], grad_var_x[N] = -1/(2 sy),
- *   grad_z_noise[1 | M] (tr / diag of d elbo / d (Kzz + Sigma_z)),
+ *   grad_z_noise[1 | M | M x M, ld M] (tr / diag of d elbo / d (Kzz + Sigma_z); dense Sigma_z: that cotangent itself),
  *   grad_coef_zz / grad_inscale_zz: one entry per term of zz (every block pair reports its own term),
  *   grad_coef_xz / grad_inscale_xz: one entry per term of xz;  meaning as in sgp_logpdf_grad.
  * The dependence on the prior variances var_x is returned as grad_var_x; chain it through

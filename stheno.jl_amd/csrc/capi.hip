@@ -2699,8 +2699,7 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   CHECK_ARG(zz->symmetric, "sgp_elbo_grad: zz spec must be symmetric");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
             "sgp_elbo_grad: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
-  CHECK_ARG(z_noise_kind == SGP_NOISE_SCALAR || z_noise_kind == SGP_NOISE_DIAG,
-            "sgp_elbo_grad: Sigma_z must be isotropic or diagonal");
+  CHECK_ARG(z_noise_kind >= SGP_NOISE_SCALAR && z_noise_kind <= SGP_NOISE_DENSE, "sgp_elbo_grad: bad Sigma_z kind");
   CtxScope scope(ctx);
   SpecGuard gz, gx;
   CHECK_RC(dspec_create(ctx, zz, &gz.ds));
@@ -2756,7 +2755,9 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   // ---- factor 1: [Kzz + Sigma_z ; K(x,z) Lambda ; I]  ->  Lz, R = A', J = Lz^-T
   double* Rw = dA.p + m_pad;
   double* Jm = dA.p + m_pad + n_rows;
-  CHECK_RC(assemble(gz.ds, dA.p, ld, 0, m_pad / TILE, 0, m_pad / TILE, 1, ndz.kind, ndz.sigma2, ndz.diag.p, s));
+  CHECK_RC(assemble(gz.ds, dA.p, ld, 0, m_pad / TILE, 0, m_pad / TILE, 1, ndz.kind == SGP_NOISE_DENSE ? -1 : ndz.kind,
+                    ndz.sigma2, ndz.diag.p, s));
+  if (ndz.kind == SGP_NOISE_DENSE) CHECK_RC(launch_add_dense(dA.p, ld, ndz.dense.p, M, M, 1, s));   // dense Sigma_z (M x M, ld M)
   CHECK_RC(launch_fill_pad(dA.p, ld, M, m_pad, 0, m_pad, ld, 0, s));
   if (n_rows > N)
     SGP_HIP(hipMemset2DAsync(Rw + N, sizeof(double) * ld, 0, sizeof(double) * (n_rows - N), (size_t)m_pad, s));
@@ -2940,7 +2941,11 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
       grad_var_x[i] = -0.5 / s2;
     }
   }
-  if (grad_z_noise) {
+  if (grad_z_noise && z_noise_kind == SGP_NOISE_DENSE) {
+    // dense Sigma_z: the cotangent of Kzz + Sigma_z itself, M x M (ld M) -- as sgp_logpdf_grad returns G for a dense Sigma_y
+    SGP_HIP(hipMemcpy2D(grad_z_noise, sizeof(double) * M, dGzz.p, sizeof(double) * m_pad, sizeof(double) * M, (size_t)M,
+                        hipMemcpyDeviceToHost));
+  } else if (grad_z_noise) {
     std::vector<double> dg(M);
     SGP_HIP(hipMemcpy2D(dg.data(), sizeof(double), dGzz.p, sizeof(double) * (m_pad + 1), sizeof(double), (size_t)M,
                         hipMemcpyDeviceToHost));

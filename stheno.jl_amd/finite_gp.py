@@ -245,7 +245,8 @@ def logpdf_f32(fx, y):
     m = _f64(mean_vector(fx.f, fx.x))
     kind, nbuf = _lib._noise_args(fx.noise, n)
     if kind == _lib.NOISE_DENSE:
-        raise NotImplementedError("fp32 path with dense observation noise")
+        # (`logpdf` itself takes a Float32 model with dense Sigma_y through the fp64 factorisation and returns Float32)
+        raise ValueError("logpdf_f32 is the explicit fp32 kernel path (scalar / diagonal Sigma_y); call logpdf for a dense Sigma_y")
     out = np.zeros(1)
     rc = _ctx().lib.sgp_logpdf_f32(_ctx().handle, spec.ref(), _lib.dptr(m), kind, _lib.dptr(nbuf), _lib.dptr(yv), _lib.dptr(out))
     _lib.check(rc, "sgp_logpdf_f32")
@@ -653,7 +654,8 @@ def elbo_and_gradient(vfe, fx, y=None, inputs=False, scales=False):
     """elbo(VFE(fz), fx, y) and its reverse-mode gradient (what Zygote derives through
     AbstractGPs.elbo on the reference path; sgp_elbo_grad).
 
-    Returns a dict: elbo; y, mean (N each); noise (scalar or N); z_noise (scalar or M: d/d Sigma_z);
+    Returns a dict: elbo; y, mean (N each); noise (scalar or N); z_noise (scalar, M, or M x M for a dense Sigma_z:
+    d/d Sigma_z);
     zz_terms / xz_terms / xx_terms: per flattened covariance term of K(z,z), K(x,z) and diag K(x,x)
     {I, J, kind, coef, row_input, col_input, d_coef, d_inscale} (see logpdf_and_gradient).
     inputs=True adds zz_inputs / xz_inputs: d elbo / d (input points) per entry of
@@ -664,8 +666,6 @@ def elbo_and_gradient(vfe, fx, y=None, inputs=False, scales=False):
     if isinstance(vfe, SparseFiniteGP):
         return elbo_and_gradient(VFE(vfe.finducing), vfe.fobs, fx, inputs=inputs, scales=scales)
     zz, xz, mean_x, nk, nbuf, zk, zbuf = _vfe_args(vfe, fx)
-    if zk == _lib.NOISE_DENSE:
-        raise NotImplementedError("elbo gradient with dense Sigma_z")
     n, m = len(fx), len(vfe.fz)
     yv = _f64(np.asarray(y, dtype=np.float64).ravel())
     xx = _prior_spec(fx.f, fx.x)
@@ -673,7 +673,7 @@ def elbo_and_gradient(vfe, fx, y=None, inputs=False, scales=False):
     out = np.zeros(1)
     gy, gm, gv = np.zeros(n), np.zeros(n), np.zeros(n)
     gn = np.zeros(n if nk == _lib.NOISE_DIAG else 1)
-    gzn = np.zeros(m if zk == _lib.NOISE_DIAG else 1)
+    gzn = np.zeros((m, m), order="F") if zk == _lib.NOISE_DENSE else np.zeros(m if zk == _lib.NOISE_DIAG else 1)
     gcz, gsz = np.zeros(max(1, zz.n_terms)), np.zeros(max(1, zz.n_terms))
     gcx, gsx = np.zeros(max(1, xz.n_terms)), np.zeros(max(1, xz.n_terms))
     lib = _ctx().lib
@@ -722,7 +722,7 @@ def elbo_and_gradient(vfe, fx, y=None, inputs=False, scales=False):
         xd, _ = chain_input_gradients(xx, gdx)
         xb, zb = [a + b for a, b in zip(xr, xd)], [a + b for a, b in zip(zr, zc)]
     return dict(elbo=float(out[0]), y=gy, mean=gm, noise=(gn if nk == _lib.NOISE_DIAG else float(gn[0])), x=xb, z=zb,
-                z_noise=(gzn if zk == _lib.NOISE_DIAG else float(gzn[0])), var=gv,
+                z_noise=(gzn if zk != _lib.NOISE_SCALAR else float(gzn[0])), var=gv,
                 zz_terms=_term_records(zz, gcz, gsz, True), xz_terms=_term_records(xz, gcx, gsx, False),
                 xx_terms=xx_terms, zz_inputs=gxz, xz_inputs=gxx,
                 scales=(_scale_records(zz, srz, more=((xz, srx, "row"), (xz, scx, "col"), (xx, sdr, "row"), (xx, sdc, "col")))

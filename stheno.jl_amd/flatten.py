@@ -27,7 +27,7 @@ from . import gp as _gp
 from . import kernels as _kernels
 from . import lib as _lib
 from .gppp import GPPP, extract_components
-from .inputs import BlockData, ColVecs, GPPPInput, as_matrix, blocks
+from .inputs import BlockData, ColVecs, GPPPInput, as_matrix, blocks, is_pair_vector, regroup_pairs
 
 
 class _Path:
@@ -102,6 +102,10 @@ def block_list(f, x):
         for g, b in zip(f.args[1], blocks(x)):
             out.extend(block_list(g, b))
         return out
+    if is_pair_vector(x):
+        # (key, value) pairs on their way to a NESTED programme below f (gppp.jl:32-43 regroups them by key when they reach
+        # it, changing the element order): regrouped here, so that every block reads ONE inner process
+        x = regroup_pairs(x)
     if isinstance(x, BlockData):
         # BlockData is an ordinary AbstractVector for any GP (input_collection_types.jl:61-95): the
         # same process evaluated on each block
@@ -116,7 +120,8 @@ def _paths(f, x, c, r, key, mat, chain=()):
     if isinstance(f, GPPP):  # a GPPP wrapped in atomic(...) (nested programmes, test gppp.jl:107-120)
         node, v = extract_components(f, x)
         if isinstance(node, _gp.DerivedGP) and node.args[0] == "cross":
-            raise NotImplementedError("a nested GPPP must be indexed one process at a time")
+            # (block_list splits BlockData and regroups pair vectors before any path is walked)
+            raise ValueError("internal: a nested GPPP reached with inputs of several of its processes")
         return _paths(node, v, c, r, key, mat, chain)
     if isinstance(f, _gp.AtomicGP):
         k2 = key + (id(f),)

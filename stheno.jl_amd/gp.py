@@ -17,7 +17,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .inputs import BlockData, ColVecs, GPPPInput, as_matrix, blocks
+from .inputs import BlockData, ColVecs, GPPPInput, as_matrix, blocks, is_pair_vector, regroup_pairs
 from .kernels import Kernel
 
 
@@ -219,6 +219,8 @@ def mean_vector(f, x):
     if isinstance(f, GPPP):
         node, v = extract_components(f, x)
         return mean_vector(node, v)
+    if is_pair_vector(x):     # pairs on their way to a nested programme: regrouped by key (gppp.jl:32-43), as flatten.block_list does
+        x = regroup_pairs(x)
     if isinstance(x, BlockData) and not (isinstance(f, DerivedGP) and f.args[0] == "cross"):
         # BlockData is an ordinary AbstractVector for any GP: the same process on each block
         return np.concatenate([mean_vector(f, b) for b in blocks(x)]) if len(blocks(x)) else np.zeros(0)

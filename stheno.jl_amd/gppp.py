@@ -11,7 +11,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import gp as _gp
-from .inputs import BlockData, ColVecs, GPPPInput
+from .inputs import BlockData, ColVecs, GPPPInput, regroup_pairs  # noqa: F401
 
 
 class GPPP:
@@ -63,16 +63,4 @@ def extract_components(f, x):
         return _gp.cross([p[0] for p in pairs]), BlockData([p[1] for p in pairs])
     # generic vector of (key, value): regroup by unique key in order of first appearance.
     # NOTE: like the reference (gppp.jl:32-43) this changes the element order.
-    items = list(x)
-    uniq = []
-    for k, _ in items:
-        if k not in uniq:
-            uniq.append(k)
-    blks = []
-    for k in uniq:
-        sel = [v for kk, v in items if kk == k]
-        if np.ndim(sel[0]) == 0:
-            blks.append(GPPPInput(k, np.array(sel, dtype=np.float64)))
-        else:
-            blks.append(GPPPInput(k, ColVecs(np.stack(sel, axis=1))))
-    return extract_components(f, BlockData(blks))
+    return extract_components(f, regroup_pairs(list(x)))

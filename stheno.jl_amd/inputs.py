@@ -33,13 +33,39 @@ class ColVecs:
         return isinstance(other, ColVecs) and np.array_equal(self.X, other.X)
 
 
+def is_pair_vector(x):
+    """a generic vector of (process key, input) pairs -- the form gppp.jl:32-43 regroups by key"""
+    return isinstance(x, (list, tuple)) and len(x) > 0 and all(
+        isinstance(e, tuple) and len(e) == 2 and isinstance(e[0], (str, bytes)) for e in x)
+
+
+def regroup_pairs(x):
+    """BlockData of one GPPPInput per distinct key, in order of first appearance (gppp.jl:32-43: like the reference this
+    CHANGES the element order)."""
+    uniq = []
+    for k, _ in x:
+        if k not in uniq:
+            uniq.append(k)
+    blks = []
+    for k in uniq:
+        sel = [v for kk, v in x if kk == k]
+        if np.ndim(sel[0]) == 0:
+            blks.append(GPPPInput(k, np.array(sel, dtype=np.float64)))
+        else:
+            blks.append(GPPPInput(k, ColVecs(np.stack(sel, axis=1))))
+    return BlockData(blks)
+
+
 class GPPPInput:
     """GPPPInput(p, x): the inputs `x`, to be read from process `p` of a GPPP."""
 
     def __init__(self, p, x):
         self.p = p
         self.eltype = np.float32 if getattr(x, "dtype", None) == np.float32 else None   # raw 1-D vectors only
-        self.x = x if isinstance(x, (ColVecs, GPPPInput, BlockData)) else np.asarray(x, dtype=np.float64)
+        if is_pair_vector(x):    # inputs of a NESTED programme given as (key, value) pairs (gppp.jl:32-43): kept as they are
+            self.x = list(x)
+        else:
+            self.x = x if isinstance(x, (ColVecs, GPPPInput, BlockData)) else np.asarray(x, dtype=np.float64)
 
     def __len__(self):
         return len(self.x)

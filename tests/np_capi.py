@@ -519,8 +519,6 @@ class FakeLib:
 
     def sgp_elbo_grad_xs(self, ctx, zz, xz, var_x, mean_x, nk, noise_x, zk, z_noise, y, elbo_out, gy, gm, gn, gv, gzn,
                          gc_zz, gs_zz, gc_xz, gs_xz, gin_zz, gin_xz, grs_zz, grs_xz, gcs_xz):
-        if zk == L.NOISE_DENSE:
-            return self._fail("elbo gradient: Sigma_z must be scalar or diagonal")
         parts, rc = self._vfe_parts(zz, xz, mean_x, nk, noise_x, zk, z_noise, y)
         if rc:
             return rc
@@ -558,6 +556,8 @@ class FakeLib:
         if gzn:
             if zk == L.NOISE_SCALAR:
                 gzn[0] = np.trace(dKzz)
+            elif zk == L.NOISE_DENSE:       # M x M, ld M: the cotangent itself
+                _vec(gzn, M * M)[:] = np.asfortranarray(dKzz).ravel(order="F")
             else:
                 _vec(gzn, M)[:] = np.diag(dKzz)
         sz, sx = _Spec(zz), _Spec(xz)

@@ -135,6 +135,28 @@ def test_nested_gppp():
     _mean_close(P.mean_vector(Op, xp), Oo.mean(xo))
 
 
+def test_nested_gppp_with_inner_inputs_spanning_several_inner_processes():
+    """The outer process 5 * atomic(inner programme) indexed (a) with a BlockData of inner GPPPInputs and (b) with a generic
+    vector of (key, value) pairs, which the inner programme regroups by key (gppp.jl:32-43: the element order changes --
+    the same way in the oracle's recursion and in the flattening, which regroups before it walks any path)."""
+    fo, go, fp, gp = _pair(models.toy_gppp)
+    Fo, Fp = ost.GPPP(fo, go), P.GPPP(fp, gp)
+    g2o, g2p = ost.GPC(), P.GPC()
+    f1o, f1p = ost.atomic(Fo, g2o), P.atomic(Fp, g2p)
+    Oo = ost.GPPP({"f1": f1o, "f2": 5 * f1o}, g2o)
+    Op = P.GPPP({"f1": f1p, "f2": 5 * f1p}, g2p)
+    x0, x1 = np.array([0.1, 0.5, -0.3]), np.array([1.0, -1.0])
+    pairs = [("f1", 0.1), ("f3", 1.0), ("f1", 0.5), ("f2", -0.7)]
+    for inner in (lambda api: api.BlockData([api.GPPPInput("f1", x0), api.GPPPInput("f3", x1)]), lambda api: pairs):
+        xo = ost.BlockData([ost.GPPPInput("f1", ost.GPPPInput("f1", x0)), ost.GPPPInput("f2", inner(ost))])
+        xp = P.BlockData([P.GPPPInput("f1", P.GPPPInput("f1", x0)), P.GPPPInput("f2", inner(P))])
+        Ko = Oo.cov(xo)
+        s, _, _ = P.build_spec(Op, xp)
+        assert Ko.shape[0] == len(xp)
+        np.testing.assert_allclose(np_terms.dense_from_spec(s), Ko, rtol=RTOL, atol=1e-14)
+        _mean_close(P.mean_vector(Op, xp), Oo.mean(xo))
+
+
 def test_gpc_mismatch_is_rejected():
     a, _ = models.gppp_docstring(models.product_api())
     b, _ = models.gppp_docstring(models.product_api())

@@ -888,6 +888,33 @@ def test_elbo_gradient_against_oracle_cotangents(recipe):
             assert abs(gcd[t] - (w * k).sum()) <= 1e-10 * max(1.0, abs((w * k).sum()))
 
 
+def test_elbo_gradient_with_dense_inducing_noise():
+    """Sigma_z a full positive definite matrix (the reference treats dense / diagonal / isotropic noise alike:
+    test/affine_transformations/test_util.jl:114-134): the bound, its data cotangents, and d elbo / d Sigma_z = the whole
+    M x M cotangent of Kzz + Sigma_z, against the oracle's."""
+    rng = np.random.default_rng(23)
+    Fo, Fp, fo, fp = both(models.gppp_docstring)
+    names = list(fo)[:2]
+    D = 2
+    xs = [np.asfortranarray(rng.standard_normal((D, n))) for n in (230, 141)][:len(names)]
+    zs = [np.asfortranarray(rng.standard_normal((D, n))) for n in (37, 30)][:len(names)]
+    xo, xp = blockdata(names, xs, True)
+    zo, zp = blockdata(names, zs, True)
+    N, M = sum(x.shape[1] for x in xs), sum(z.shape[1] for z in zs)
+    y = rng.standard_normal(N)
+    Q = rng.standard_normal((M, M))
+    Sz = 1e-3 * np.eye(M) + 1e-3 * (Q @ Q.T) / M
+    noise = 0.1 + rng.random(N)
+    go = oagp.elbo_gradient_wrt_cov(oagp.VFE(Fo(zo, Sz)), Fo(xo, noise), y)
+    g = P.elbo_and_gradient(P.VFE(Fp(zp, Sz)), Fp(xp, noise), y)
+    assert abs(g["elbo"] - go["elbo"]) <= 1e-9 * abs(go["elbo"])
+    assert abs(g["elbo"] - P.elbo(P.VFE(Fp(zp, Sz)), Fp(xp, noise), y)) <= 1e-12 * abs(g["elbo"])
+    assert rel(g["y"], go["y"]) < 1e-7 and rel(g["noise"], go["noise"]) < 1e-7
+    assert g["z_noise"].shape == (M, M)
+    assert np.abs(g["z_noise"] - go["Kzz"]).max() <= 1e-6 * np.abs(go["Kzz"]).max()
+    assert np.abs(g["z_noise"] - g["z_noise"].T).max() <= 1e-9 * np.abs(go["Kzz"]).max()
+
+
 def test_elbo_gradient_matches_finite_differences_of_hyperparameters():
     """End to end: variance, lengthscale and noise of s * stretch(GP(Matern52), 1/l) through the
     VFE bound, against central differences of the GPU elbo itself."""

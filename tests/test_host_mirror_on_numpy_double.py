@@ -34,6 +34,7 @@ _REUSED = [
     "test_logpdf_gradient_wrt_input_points", "test_logpdf_input_gradient_matches_finite_differences",
     "test_input_gradients_chain_through_model_transformations", "test_elbo_gradient_against_oracle_cotangents",
     "test_elbo_gradient_matches_finite_differences_of_hyperparameters", "test_elbo_input_gradients_match_finite_differences",
+    "test_elbo_gradient_with_dense_inducing_noise",
     "test_gradients_at_tiny_and_tile_boundary_sizes",
 ]
 # left to the GPU suite: test_library_is_native_and_loaded (about the .so), test_rand_statistics (100 000 samples),
