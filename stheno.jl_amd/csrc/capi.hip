@@ -203,6 +203,7 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (const char* hy = getenv("SGP_HYBRID_FAT")) c->hybrid_fat = atoi(hy);
     if (const char* hy = getenv("SGP_HYBRID_W")) c->hybrid_w = std::max<long>(TILE, atol(hy) / TILE * TILE);
     if (const char* hy = getenv("SGP_HYBRID_MIN_N")) c->hybrid_min_n = atol(hy);
+    if (const char* hy = getenv("SGP_HYBRID_GROW")) c->hybrid_grow = atoi(hy);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* wm = getenv("SGP_WMID");
@@ -727,11 +728,14 @@ static void df_patch_of(const sgp_ctx* ctx, int fat, int& pr, int& pc) {
 // N = 65536) and that the launch-based look-ahead ran 2.5 - 3 x slower beside an update (many small dependent launches) is
 // hidden.  Same arithmetic order per tile (k ascending): bit-identical.  Measured (profiles/r05_experiments/hybrid.md):
 // N = 65536 1454 -> 1395 ms, 32768 197 -> 182 ms, 16384 26.7 -> 28.6 (stays on the dataflow kernel).
-static bool use_hybrid(const sgp_ctx* ctx, long n_pad) {
-  if (ctx->refine != 1 || ctx->hybrid == 0 || n_pad < 4096) return false;
+// The gradient path's factorisations (`grow`: an identity border rides along, 3 x the flops per column, no whole-matrix
+// dataflow form) take it from 16384 columns on: N = 16384 82.2 -> 81.1 ms, 24576 260.8 -> 253.5, 32768 605.8 -> 582.0
+// (profiles/r05_experiments/hybrid_grad.txt).
+static bool use_hybrid(const sgp_ctx* ctx, long n_pad, bool grow = false) {
+  if (ctx->refine != 1 || ctx->hybrid == 0 || n_pad < 4096 || (grow && !ctx->hybrid_grow)) return false;
   if (ctx->hybrid == 1) return true;
   // by size -- unless the caller pinned another schedule (SGP_DATAFLOW = 0 / 1, SGP_LOOKAHEAD = 0)
-  return ctx->dataflow < 0 && ctx->lookahead != 0 && n_pad >= ctx->hybrid_min_n;
+  return ctx->dataflow < 0 && ctx->lookahead != 0 && n_pad >= (grow ? std::min<long>(ctx->hybrid_min_n, 16384) : ctx->hybrid_min_n);
 }
 static bool use_dataflow(const sgp_ctx* ctx, long n_pad) {
   if (ctx->refine != 1 || ctx->dataflow == 0) return false;
@@ -857,7 +861,10 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
   // upper-triangular border, `grow`: its tasks would have to skip the structurally zero tiles.)
   // hybrid (round 5 experiment): the look-ahead schedule of the launches, its panels factored by the dataflow kernel
-  const bool hybrid = grow == 0 && s == ctx->stream && use_hybrid(ctx, n_pad);
+  // (also for the gradient path's border, `grow`: a panel launch takes the rows its panel touches, the identity rows among
+  // them as bordered rows -- only the few tiles above the identity's diagonal inside ONE panel are multiplied out, or
+  // skipped when the caller's pattern covers them)
+  const bool hybrid = s == ctx->stream && use_hybrid(ctx, n_pad, grow != 0);
   if (hybrid || (grow == 0 && use_dataflow(ctx, n_pad))) {
     const long need_state = SGP_DF_STATE_WORDS + m_tot / TILE, need_inv = (n_pad / TILE) * INVD_STRIDE;
     if (need_state > ctx->n_df_state) {
@@ -1767,16 +1774,20 @@ extern "C" int sgp_logpdf_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* spec, const 
                                   const double* noise, const double* y, double* logpdf_out, double* grad_y,
                                   double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
                                   double* const* grad_inputs, double* const* grad_rowscale) {
-  return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
-                          grad_coef, grad_inscale, grad_inputs, grad_rowscale);
+  return with_df_fallback(ctx, [&]() {
+    return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
+                            grad_coef, grad_inscale, grad_inputs, grad_rowscale);
+  });
 }
 
 extern "C" int sgp_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                                const double* noise, const double* y, double* logpdf_out, double* grad_y,
                                double* grad_mean, double* grad_noise, double* grad_coef,
                                double* grad_inscale) {
-  return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
-                          grad_coef, grad_inscale, nullptr);
+  return with_df_fallback(ctx, [&]() {
+    return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
+                            grad_coef, grad_inscale, nullptr);
+  });
 }
 
 extern "C" int sgp_logpdf_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
@@ -1784,8 +1795,10 @@ extern "C" int sgp_logpdf_grad_x(sgp_ctx* ctx, const sgp_cov_spec* spec, const d
                                  double* grad_mean, double* grad_noise, double* grad_coef,
                                  double* grad_inscale, double* const* grad_inputs) {
   CHECK_ARG(grad_inputs != nullptr, "sgp_logpdf_grad_x: grad_inputs is NULL");
-  return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
-                          grad_coef, grad_inscale, grad_inputs);
+  return with_df_fallback(ctx, [&]() {
+    return logpdf_grad_core(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise,
+                            grad_coef, grad_inscale, grad_inputs);
+  });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -2993,9 +3006,11 @@ extern "C" int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov
                              double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
                              double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
                              double* grad_inscale_xz) {
-  return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
-                        grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
-                        grad_inscale_xz, nullptr, nullptr);
+  return with_df_fallback(ctx, [&]() {
+    return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
+                          grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
+                          grad_inscale_xz, nullptr, nullptr);
+  });
 }
 
 extern "C" int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
@@ -3006,9 +3021,11 @@ extern "C" int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_c
                                double* grad_inscale_xz, double* const* grad_inputs_zz,
                                double* const* grad_inputs_xz) {
   CHECK_ARG(grad_inputs_zz && grad_inputs_xz, "sgp_elbo_grad_x: grad_inputs_* is NULL");
-  return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
-                        grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
-                        grad_inscale_xz, grad_inputs_zz, grad_inputs_xz);
+  return with_df_fallback(ctx, [&]() {
+    return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
+                          grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
+                          grad_inscale_xz, grad_inputs_zz, grad_inputs_xz);
+  });
 }
 
 extern "C" int sgp_elbo_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
@@ -3019,10 +3036,12 @@ extern "C" int sgp_elbo_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_
                                 double* grad_inscale_xz, double* const* grad_inputs_zz,
                                 double* const* grad_inputs_xz, double* const* grad_rowscale_zz,
                                 double* const* grad_rowscale_xz, double* const* grad_colscale_xz) {
-  return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
-                        grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
-                        grad_inscale_xz, grad_inputs_zz, grad_inputs_xz, grad_rowscale_zz, grad_rowscale_xz,
-                        grad_colscale_xz);
+  return with_df_fallback(ctx, [&]() {
+    return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
+                          grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
+                          grad_inscale_xz, grad_inputs_zz, grad_inputs_xz, grad_rowscale_zz, grad_rowscale_xz,
+                          grad_colscale_xz);
+  });
 }
 
 // sum_i w[i] d var_i / d theta over the diagonal of `spec` (the blocks (I, I) kernelmatrix_diag reads)
