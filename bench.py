@@ -497,6 +497,44 @@ def main():
         if rec:
             roofline["traffic"] = rec["hbm_bytes"]
             roofline["traffic_source"] = rec
+        if hybrid:
+            # Under the hybrid schedule the HIP events around an update launch include the time its grid waits while the
+            # panel kernel (one 256-VGPR workgroup per CU: it does not share a CU) holds the chip, and the two update
+            # streams overlap: `frac` above is the launches' IN SITU rate.  The same launches with the chip to themselves:
+            # one more instrumented step on a second context whose schedule issues everything on ONE stream
+            # (SGP_HYBRID_SERIAL=1 is read when a context is created; same launches, same bits, no overlap).
+            prev_env = os.environ.get("SGP_HYBRID_SERIAL")
+            os.environ["SGP_HYBRID_SERIAL"] = "1"
+            try:
+                sctx = L.Context(ctx.device if hasattr(ctx, "device") else 0)
+                try:
+                    sds = C.c_void_p()
+                    L.check(lib.sgp_dspec_create(sctx.handle, spec.ref(), C.byref(sds)), "sgp_dspec_create")
+                    st, so = np.zeros(8), np.zeros(1)
+                    for tm_ in (None, st):     # one warm-up, one instrumented
+                        t0s = time.perf_counter()
+                        L.check(lib.sgp_dev_logpdf(sctx.handle, sds, A.data_ptr(), None, L.NOISE_SCALAR, L.dptr(nz), None,
+                                                   dY.data_ptr(), N, 1, L.dptr(so), L.dptr(tm_) if tm_ is not None else None),
+                                "sgp_dev_logpdf (serial)")
+                        ser_ms = (time.perf_counter() - t0s) * 1e3
+                    lib.sgp_dspec_destroy(sds)
+                finally:
+                    sctx.close()
+            finally:
+                if prev_env is None:
+                    os.environ.pop("SGP_HYBRID_SERIAL", None)
+                else:
+                    os.environ["SGP_HYBRID_SERIAL"] = prev_env
+            s_ach = st[5] / (st[3] * 1e-3) / 1e12 if st[3] > 0 else 0.0
+            roofline["uncontended"] = {
+                "how": "the same schedule issued on ONE stream (SGP_HYBRID_SERIAL=1, second context, one instrumented step): "
+                       "no kernel shares the chip, HIP events around every update launch",
+                "launches": int(st[4]), "avg_launch_ms": st[3] / max(1, int(st[4])), "achieved": s_ach,
+                "frac": s_ach / PEAK_FP64_MFMA_TFLOPS, "ms_per_step": ser_ms, "same_bits": float(so[0]) == float(out[0])}
+            roofline["note"] = ("hybrid schedule: `frac` is the update launches' rate IN SITU (their HIP-event durations include the "
+                                "time the panel kernel holds the chip and the overlap of the two update streams); "
+                                "`achieved_while_busy` = their flops / the union of their intervals; `uncontended` = the same "
+                                "launches alone on the chip")
         roofline["algorithmic_bytes_per_launch_avg"] = (8.0 * N * (N + 1) if dataflow else update_bytes_avg(N, schedule))   # dataflow: the
         # lower triangle read once and written once
         roofline["traffic_measured_in_this_run"] = False   # (counters need separate rocprofv3 --pmc passes: see traffic_source)

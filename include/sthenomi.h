@@ -124,7 +124,8 @@ int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out);
 int sgp_ctx_ndev(sgp_ctx* ctx);
 const char* sgp_ctx_transport(sgp_ctx* ctx);
 /* Which schedule the blocked Cholesky of an N-point covariance runs on this context (bench / diagnosis): "dataflow-fat" |
- * "dataflow" (one launch of persistent workgroups, chol_df.hip) | "launches-one-panel" | "launches-lookahead" |
+ * "dataflow" (one launch of persistent workgroups, chol_df.hip) | "hybrid" (from 24576 columns on: every 2048-column panel by
+ * one launch of that kernel, trailing updates as lock-step launches) | "launches-one-panel" | "launches-lookahead" |
  * "launches-serial" | "launches-serial-deep" (capi.hip: chol_bordered).  Every schedule gives the same bits. */
 const char* sgp_ctx_factor_schedule(sgp_ctx* ctx, int64_t N);
 /* Work of the last factorisation sgp_logpdf / sgp_rand / sgp_posterior_create ran on this context, in tile products

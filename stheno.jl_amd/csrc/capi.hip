@@ -204,6 +204,7 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (const char* hy = getenv("SGP_HYBRID_W")) c->hybrid_w = std::max<long>(TILE, atol(hy) / TILE * TILE);
     if (const char* hy = getenv("SGP_HYBRID_MIN_N")) c->hybrid_min_n = atol(hy);
     if (const char* hy = getenv("SGP_HYBRID_GROW")) c->hybrid_grow = atoi(hy);
+    if (const char* hy = getenv("SGP_HYBRID_SERIAL")) c->hybrid_serial = atoi(hy);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* wm = getenv("SGP_WMID");
@@ -1027,7 +1028,8 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
                     : n_pad >= 32768 ? WOUT_LARGE
                                      : WOUT_SMALL;
   const long WMID = ctx->wmid > 0 ? ctx->wmid : (deep && ctx->wout <= 0 ? WOUT_LARGE : 0);
-  hipStream_t sB = la ? ctx->stream2 : s;
+  // (SGP_HYBRID_SERIAL=1, measurement only: the far updates on the panel stream too -- every kernel has the chip alone)
+  hipStream_t sB = (la && !(hybrid && ctx->hybrid_serial)) ? ctx->stream2 : s;
   // SGP_FUSE_POTRF bit 1: the trailing update that finishes the next panel's first diagonal block (the look-ahead
   // column update, or the whole update when the look-ahead is off) factors that block in the same launch
   // Both apply while n_pad < SGP_FUSE_MAX_N (32768), where the panel chain is the critical path: N = 2048 1.17 ->

@@ -99,6 +99,7 @@ struct sgp_ctx {
   // one-workgroup-per-CU instantiation
   int hybrid = -1, hybrid_wgs = 256, hybrid_fat = 1;
   long hybrid_w = 2048, hybrid_min_n = 24576;
+  int hybrid_serial = 0;       // SGP_HYBRID_SERIAL = 1: one stream (bench.py: the update launches' rate with the chip to themselves)
   int hybrid_grow = 1;         // SGP_HYBRID_GROW = 0: not for the gradient path's factorisations (A/B)
   bool df_timed_out = false;   // the last dataflow launch ran into its wait bound (fetch_info)
   int df_fallback = 1;         // SGP_DF_FALLBACK=0: report the timeout instead (the kernel's own error path, tests)
