@@ -497,7 +497,7 @@ def main():
         if rec:
             roofline["traffic"] = rec["hbm_bytes"]
             roofline["traffic_source"] = rec
-        if hybrid:
+        if hybrid and not args.no_extras:
             # Under the hybrid schedule the HIP events around an update launch include the time its grid waits while the
             # panel kernel (one 256-VGPR workgroup per CU: it does not share a CU) holds the chip, and the two update
             # streams overlap: `frac` above is the launches' IN SITU rate.  The same launches with the chip to themselves:
@@ -531,6 +531,7 @@ def main():
                        "no kernel shares the chip, HIP events around every update launch",
                 "launches": int(st[4]), "avg_launch_ms": st[3] / max(1, int(st[4])), "achieved": s_ach,
                 "frac": s_ach / PEAK_FP64_MFMA_TFLOPS, "ms_per_step": ser_ms, "same_bits": float(so[0]) == float(out[0])}
+        if hybrid:
             roofline["note"] = ("hybrid schedule: `frac` is the update launches' rate IN SITU (their HIP-event durations include the "
                                 "time the panel kernel holds the chip and the overlap of the two update streams); "
                                 "`achieved_while_busy` = their flops / the union of their intervals; `uncontended` = the same "

@@ -110,7 +110,12 @@ def row(name, d, key):
     wf = d.get("executed_work_fraction")
     if wf is not None and wf < 0.999:   # structural zeros: the fractions are on the flops that ran
         name = f"{name} [structural zeros: {wf:.3f} of the dense tile products ran; dense-equivalent {d.get('dense_equivalent_tflops', 0):.1f} TFLOP/s]"
-    return (f"| {name} | {d['ms_per_step']:.2f} | {fr:.3f} | {rf.get('frac', float('nan')):.3f} ({str(rf.get('kernel', ''))[:60]}...) | {trs} | "
+    extra = ""
+    if rf.get("schedule") == "hybrid":      # in situ / flops over the union of the launch intervals / the same launches alone
+        wb = rf.get("achieved_while_busy")
+        un = (rf.get("uncontended") or {}).get("frac")
+        extra = (" [hybrid: in situ" + (f"; while busy {wb / rf['peak']:.3f}" if wb else "") + (f"; uncontended {un:.3f}" if un else "") + "]")
+    return (f"| {name} | {d['ms_per_step']:.2f} | {fr:.3f} | {rf.get('frac', float('nan')):.3f}{extra} ({str(rf.get('kernel', ''))[:60]}...) | {trs} | "
             f"{d['parity_rel']:.1e} |" if fr is not None else
             f"| {name} | {d['ms_per_step']:.2f} | -- | {rf.get('frac', float('nan')):.3f} | {trs} | {d['parity_rel']:.1e} |")
 
