@@ -2138,12 +2138,16 @@ extern "C" int sgp_posterior_predict_explicit(sgp_post* post, const double* cros
 // VFE: elbo and sparse posterior (App. A.6)
 // ---------------------------------------------------------------------------------------
 // o[0] = sum log s2_n, o[1] = sum delta_n^2, o[2] = sum var_n / s2_n, delta_n = (y_n - m_n)/sqrt(s2_n)
+// Two stages (round 5: one 256-thread block over N = 262144 elements took 1.2 ms of the c4 step, latency-bound on its four
+// waves): up to 128 blocks stride over the elements and leave one partial sum each, one block adds the partials in a fixed
+// order -- the result depends on N only, not on the launch.
+constexpr int ELBO_SC_BLOCKS = 128;
 __global__ void elbo_scalars_kernel(const double* y, const double* mean, const double* var_x,
                                     int noise_kind, double sigma2, const double* noise, long N,
-                                    double* delta, double* rsig, double* o) {
+                                    double* delta, double* rsig, double* part) {
   __shared__ double sh[3][4];
   double a0 = 0, a1 = 0, a2 = 0;
-  for (long i = threadIdx.x; i < N; i += blockDim.x) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (long)gridDim.x * blockDim.x) {
     double s2 = noise_kind == 0 ? sigma2 : noise[i];
     double rs = 1.0 / sqrt(s2);
     double d = (y[i] - (mean ? mean[i] : 0.0)) * rs;
@@ -2166,8 +2170,35 @@ __global__ void elbo_scalars_kernel(const double* y, const double* mean, const d
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int q = 0; q < 3; ++q) o[q] = (sh[q][0] + sh[q][1]) + (sh[q][2] + sh[q][3]);
+    for (int q = 0; q < 3; ++q) part[q * ELBO_SC_BLOCKS + blockIdx.x] = (sh[q][0] + sh[q][1]) + (sh[q][2] + sh[q][3]);
   }
+}
+__global__ void elbo_scalars_sum_kernel(const double* part, int blocks, double* o) {   // <<<1, ELBO_SC_BLOCKS>>>
+  __shared__ double sh[3][2];
+  const int t = threadIdx.x;
+  double a[3];
+  for (int q = 0; q < 3; ++q) a[q] = t < blocks ? part[q * ELBO_SC_BLOCKS + t] : 0.0;
+  for (int off = 32; off >= 1; off >>= 1)
+    for (int q = 0; q < 3; ++q) a[q] += __shfl_xor(a[q], off, 64);
+  if ((t & 63) == 0)
+    for (int q = 0; q < 3; ++q) sh[q][t >> 6] = a[q];
+  __syncthreads();
+  if (t == 0)
+    for (int q = 0; q < 3; ++q) o[q] = sh[q][0] + sh[q][1];
+}
+static int launch_elbo_scalars(sgp_ctx* ctx, const double* y, const double* mean, const double* var_x, int noise_kind,
+                               double sigma2, const double* noise, long N, double* delta, double* rsig, double* o,
+                               hipStream_t s) {
+  // the partial sums live at the tail of the context's scalar buffer (the per-column sums of a many-column logpdf use its
+  // head; a context runs one operator at a time)
+  double* part = ctx->d_scal + ctx->n_scal - 3 * ELBO_SC_BLOCKS;
+  const int blocks = (int)std::max<long>(1, std::min<long>(ELBO_SC_BLOCKS, (N + 255) / 256));
+  hipLaunchKernelGGL(elbo_scalars_kernel, dim3((unsigned)blocks), dim3(256), 0, s, y, mean, var_x, noise_kind, sigma2, noise, N,
+                     delta, rsig, part);
+  SGP_HIP(hipGetLastError());
+  hipLaunchKernelGGL(elbo_scalars_sum_kernel, dim3(1), dim3(ELBO_SC_BLOCKS), 0, s, (const double*)part, blocks, o);
+  SGP_HIP(hipGetLastError());
+  return 0;
 }
 // per column j of the bordered rows R (nrows x ncols): dots[j] = sum_n R[n, j] delta[n],
 // sq[j] = sum_n R[n, j]^2
@@ -2291,9 +2322,8 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
   SGP_HIP(hipMemsetAsync(sq.p, 0, sizeof(double) * m_pad, s));
   SGP_HIP(hipMemsetAsync(ddelta.p, 0, sizeof(double) * n_rows, s));
   SGP_HIP(hipMemsetAsync(drsig.p, 0, sizeof(double) * n_rows, s));
-  hipLaunchKernelGGL(elbo_scalars_kernel, dim3(1), dim3(256), 0, s, dy.p, mean_x ? dmean.p : nullptr,
-                     var_x ? dvar.p : nullptr, ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_sc);
-  SGP_HIP(hipGetLastError());
+  CHECK_RC(launch_elbo_scalars(ctx, dy.p, mean_x ? dmean.p : nullptr,
+                     var_x ? dvar.p : nullptr, ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_sc, s));
   // ---- Lz (replicated on every rank of a sharded run: M^3 / 3 flops, no communication)
   int nkz = ndz.kind == SGP_NOISE_DENSE ? -1 : ndz.kind;
   CHECK_RC(assemble(dz, dLz, m_pad, 0, m_pad / TILE, 0, m_pad / TILE, 1, nkz, ndz.sigma2, ndz.diag.p, s));
@@ -2555,10 +2585,9 @@ static int vfe_pipeline(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
   SGP_HIP(hipMemsetAsync(ddelta.p, 0, sizeof(double) * n_rows, s));
   SGP_HIP(hipMemsetAsync(drsig.p, 0, sizeof(double) * n_rows, s));
-  hipLaunchKernelGGL(elbo_scalars_kernel, dim3(1), dim3(256), 0, s, dy.p, mean_x ? dmean.p : nullptr,
+  CHECK_RC(launch_elbo_scalars(ctx, dy.p, mean_x ? dmean.p : nullptr,
                      var_x ? dvar.p : nullptr, ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p,
-                     d_o);
-  SGP_HIP(hipGetLastError());
+                     d_o, s));
   // top: Kzz + Sigma_z (lower), identity padding; bottom rows: K(x, z) Lambda_y^-1
   int nkz = ndz.kind == SGP_NOISE_DENSE ? -1 : ndz.kind;
   CHECK_RC(assemble(gz.ds, dA.p, ld, 0, m_pad / TILE, 0, m_pad / TILE, 1, nkz, ndz.sigma2, ndz.diag.p, s));
@@ -2764,9 +2793,8 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   SGP_HIP(hipMemsetAsync(ctx->d_info, 0, sizeof(int), s));
   SGP_HIP(hipMemsetAsync(ddelta.p, 0, sizeof(double) * n_rows, s));
   SGP_HIP(hipMemsetAsync(drsig.p, 0, sizeof(double) * n_rows, s));
-  hipLaunchKernelGGL(elbo_scalars_kernel, dim3(1), dim3(256), 0, s, dy.p, mean_x ? dmean.p : nullptr, dvar.p,
-                     ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_o);
-  SGP_HIP(hipGetLastError());
+  CHECK_RC(launch_elbo_scalars(ctx, dy.p, mean_x ? dmean.p : nullptr, dvar.p,
+                     ndx.kind, ndx.sigma2, ndx.diag.p, N, ddelta.p, drsig.p, d_o, s));
   // ---- factor 1: [Kzz + Sigma_z ; K(x,z) Lambda ; I]  ->  Lz, R = A', J = Lz^-T
   double* Rw = dA.p + m_pad;
   double* Jm = dA.p + m_pad + n_rows;
