@@ -24,6 +24,8 @@ for c in c1 n4k c2; do timeout 300 python $R/bench.py --config $c --steps 30 --w
 for c in c3 n32k c4 target; do timeout 500 python $R/bench.py --config $c --steps 3 --warmup 1 > $OUT/bench_$c.json 2> $OUT/bench_$c.err; done
 # the structured models under the dense schedule (A/B of the structural-zero skipping: same bits)
 for c in c3 target; do SGP_STRUCT_ZEROS=0 timeout 500 python $R/bench.py --config $c --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_${c}_dense.json 2> $OUT/bench_${c}_dense.err; done
+# the schedules of round 4 on the same box (SGP_HYBRID=0: serial-deep launches at 65536 columns, the dataflow kernel at 32768)
+for c in c5 target n32k c3; do SGP_HYBRID=0 timeout 500 python $R/bench.py --config $c --steps 3 --warmup 1 --cpu-sample 0 --no-host-api --no-extras > $OUT/bench_${c}_nohybrid.json 2> $OUT/bench_${c}_nohybrid.err; done
 timeout 400 python $R/bench.py --config c5 --dtype f32 --steps 3 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_f32.json 2> $OUT/bench_c5_f32.err
 timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config target --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_target_multi8_loopback.json 2> $OUT/bench_target_multi8_loopback.err
 timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config c5 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_multi8_loopback.json 2> $OUT/bench_c5_multi8_loopback.err

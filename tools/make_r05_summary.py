@@ -35,7 +35,7 @@ DOMINANT = {   # config -> substring of the dominant kernel's name
 }
 lines, traffic = {}, {}
 for c in ("default", "c1", "n4k", "c2", "c3", "n32k", "c4", "target", "c3_dense", "target_dense", "target_multi8_loopback", "c5_f32", "c5_multi8_loopback", "c5_multi8_loopback_sub0",
-          "c4_multi2_loopback", "c5_dist1"):
+          "c4_multi2_loopback", "c5_dist1", "c5_nohybrid", "target_nohybrid", "n32k_nohybrid", "c3_nohybrid"):
     d = jload(f"bench_{c}.json")
     if d:
         lines[c] = d
@@ -132,10 +132,12 @@ if "default" in lines:
                  f"{ns['frac']:.3f} | | | {ns['parity_rel']:.1e} |")
     for k, v in (d.get("sizes") or {}).items():
         L.append(f"| ... its `sizes.{k}` extra | {v['ms_per_step']:.3f} | {v['frac']:.3f} | ({v['schedule']}) | | {v['parity_rel']:.1e} |")
-for c in ("target", "target_dense", "c3", "c3_dense", "n32k", "c2", "n4k", "c1", "c4", "c5_f32"):
+for c in ("c5_nohybrid", "target", "target_nohybrid", "target_dense", "c3", "c3_nohybrid", "c3_dense", "n32k", "n32k_nohybrid", "c2", "n4k", "c1",
+          "c4", "c5_f32"):
     if c in lines:
-        L.append(row(c + (" (SGP_STRUCT_ZEROS=0: the dense schedule, same bits)" if c.endswith("_dense") else ""), lines[c],
-                     c.replace("_dense", "") if not c.endswith("_dense") else "none"))
+        L.append(row(c + (" (SGP_STRUCT_ZEROS=0: the dense schedule, same bits)" if c.endswith("_dense") else
+                          " (SGP_HYBRID=0: the round-4 schedule on the same box, same bits)" if c.endswith("_nohybrid") else ""), lines[c],
+                     c if not (c.endswith("_dense") or c.endswith("_nohybrid")) else "none"))
 L.append("")
 d0 = lines.get("default")
 if d0 and d0.get("grad"):
