@@ -34,6 +34,36 @@ def test_resolve_devices_never_falls_back():
         assert e.value.code not in (0, None), bad
 
 
+@pytest.mark.parametrize("schedule", [None, "hybrid"])
+@pytest.mark.parametrize("N", [8192, 16384, 32768, 65536, 40000])
+def test_update_launch_model_covers_the_trailing_matrix(N, schedule):
+    """bench.update_launches mirrors the driver's panel rule (it prices `roofline.algorithmic_bytes_per_launch_avg`): whatever
+    the schedule, every column of the factor must receive exactly the columns to its left that lie in EARLIER panels of its
+    own level as contraction depth -- for the look-ahead schedules (one level: outer panels of W): column c gets K = the
+    first column of its panel; for the serial-deep schedule the halving inside a panel adds the panel's own earlier halves."""
+    import bench
+    n_pad = (N + 127) // 128 * 128
+    ls = bench.update_launches(N, schedule)
+    got = [0] * (n_pad // 128)
+    for m, nc, k in ls:
+        assert m % 128 == 0 and nc % 128 == 0 and k % 128 == 0 and nc > 0 and k > 0 and m >= nc
+        c0 = n_pad + 128 - m                      # the launch's first column: its rows run to the bordered row
+        for t in range(c0 // 128, (c0 + nc) // 128):
+            got[t] += k
+    deep = schedule is None and n_pad >= 65536
+    W = 2048 if schedule == "hybrid" else (n_pad if n_pad <= 4096 else 1024 if n_pad <= 8192 else 4096 if deep
+                                          else 1024 if n_pad >= 32768 else 512)
+    for t, g in enumerate(got):
+        c = t * 128
+        want = c // W * W                                                    # everything left of its outer panel
+        if deep:                                                             # + the earlier 1024-blocks of its own panel
+            want += (c % W) // 1024 * 1024
+        assert g == want, (N, schedule, t, g, want)
+    if schedule == "hybrid":
+        assert all(k == 2048 for _, _, k in ls[:-2])
+        assert len(ls) == 2 * ((n_pad + 2047) // 2048 - 1) - (1 if (n_pad + 2047) // 2048 >= 2 else 0)
+
+
 def test_gpus_2_exits_nonzero_without_two_gpus():
     import torch
     if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
