@@ -137,6 +137,29 @@ def test_two_contexts_on_one_device_run_concurrently(monkeypatch):
     ctx_b.close()
 
 
+def test_two_contexts_under_the_hybrid_schedule():
+    """From 24576 columns on a factorisation launches one persistent panel kernel per 2048 columns beside its update launches
+    (capi.hip: use_hybrid).  Two contexts + a second thread on one of them, all factoring at once: bit-equal to the serial run;
+    the number of operators that had to be rerun on the launches after a wait bound is printed (0 on an otherwise idle box)."""
+    import ctypes as C
+    a, b = L.Context(0), L.Context(0)
+    call = _Call(24700)
+    assert a.factor_schedule(24700) == "hybrid"
+    ref = call.run(a)
+    assert ref[0] == 0 and call.run(b) == ref
+
+    def worker(ctx):
+        return lambda: [call.run(ctx) for _ in range(4)]
+
+    for got in _run_threads([worker(a), worker(b), worker(a)]):
+        assert all(r == ref for r in got), (got, ref)
+    for ctx in (a, b):
+        fb = C.c_int64()
+        L.check(ctx.lib.sgp_bench_df_fallbacks(ctx.handle, C.byref(fb)))
+        print("operators rerun on the launches:", fb.value)
+        ctx.close()
+
+
 def test_two_threads_predict_on_one_posterior():
     F, x, y = _problem(2600)
     rng = np.random.default_rng(3)
