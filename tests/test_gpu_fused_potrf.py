@@ -28,8 +28,8 @@ def _problem(N, D=3, seed=4242):
 
 
 def _ctx(monkeypatch, fuse, **env):
-    # (these tests are about the launch-based schedules: the dataflow kernel, the default between 3072 and 65536
-    # columns, has its own -- tests/test_gpu_dataflow.py)
+    # (these tests are about the launch-based schedules: the dataflow kernel and the hybrid schedule, the defaults from 3072
+    # and 24576 columns on, have their own -- tests/test_gpu_dataflow.py)
     monkeypatch.setenv("SGP_DATAFLOW", "0")
     monkeypatch.setenv("SGP_FUSE_POTRF", str(fuse))
     for k, v in env.items():
