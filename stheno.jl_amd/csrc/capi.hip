@@ -861,7 +861,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // Dataflow factorisation (chol_df.hip): one launch of persistent workgroups, tile-level dependencies instead of
   // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
   // upper-triangular border, `grow`: its tasks would have to skip the structurally zero tiles.)
-  // hybrid (round 5 experiment): the look-ahead schedule of the launches, its panels factored by the dataflow kernel
+  // hybrid (round 5; use_hybrid above): the look-ahead schedule of the launches, its panels factored by the dataflow kernel
   // (also for the gradient path's border, `grow`: a panel launch takes the rows its panel touches, the identity rows among
   // them as bordered rows -- only the few tiles above the identity's diagonal inside ONE panel are multiplied out, or
   // skipped when the caller's pattern covers them)

@@ -92,7 +92,7 @@ struct sgp_ctx {
   long n_df_tasks = 0;
   long df_tasks_key[4] = {0, 0, 0, 0};   // T_r, T_c, pr, pc of what d_df_tasks holds
   int df_qstart[9] = {0};
-  // hybrid schedule (round 5 experiment, SGP_HYBRID=1): launches with look-ahead whose PANEL factorisation is one dataflow
+  // hybrid schedule (round 5; capi.hip: use_hybrid): launches with look-ahead whose PANEL factorisation is one dataflow
   // launch on the panel (tile-level dependencies for the chain and its row solves), lock-step launches for the trailing updates
   // SGP_HYBRID = 0 never, 1 whenever it applies (n_pad >= 4096), unset (-1): from SGP_HYBRID_MIN_N columns on (measured:
   // profiles/r05_experiments/hybrid.md); SGP_HYBRID_W / _WGS / _FAT: panel width, persistent workgroups of a panel launch, the
