@@ -2,7 +2,7 @@
 logpdf and the oracle (LAPACK) with a 50-digit mpmath reference."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 P = entry.load_package()

@@ -3,7 +3,7 @@ tests/golden/illcond_truth.json -- the numbers behind test_logpdf_ill_conditione
 (A/B of variants of the diagonal-block factorisation)."""
 import json, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 P = entry.load_package()
