@@ -4,7 +4,7 @@
 #include "driver.h"
 #include "tilemap.h"
 #include "sz_pattern.h"
-#include "df_order.h"
+#include "df_tasks.h"
 
 #include <algorithm>
 #include <cmath>
@@ -227,18 +227,10 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (dff) c->df_fat_max_n = atol(dff);
     const char* dft = getenv("SGP_DF_TIMEOUT_S");
     if (dft) c->df_timeout_s = atof(dft);
-    const char* dfo = getenv("SGP_DF_ORDER");
-    if (dfo) c->df_order = atoi(dfo);
-    const char* dfpr = getenv("SGP_DF_PR");
-    if (dfpr) c->df_pr = atoi(dfpr);
-    const char* dfpc = getenv("SGP_DF_PC");
-    if (dfpc) c->df_pc = atoi(dfpc);
     const char* szs = getenv("SGP_STRUCT_ZEROS");
     if (szs) c->struct_zeros = atoi(szs);
     const char* dfb2 = getenv("SGP_DF_FALLBACK");
     if (dfb2) c->df_fallback = atoi(dfb2);
-    const char* dfg = getenv("SGP_DF_GANG_US");
-    if (dfg) c->df_gang_us = atof(dfg);
     {
       hipDeviceProp_t prop;
       SGP_HIP(hipGetDeviceProperties(&prop, device));
@@ -294,7 +286,6 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->d_szmap) hipFree(c->d_szmap);
   if (c->d_df_inv) hipFree(c->d_df_inv);
   if (c->d_df_stats) hipFree(c->d_df_stats);
-  if (c->d_df_tasks) hipFree(c->d_df_tasks);
   if (c->ev_panel) hipEventDestroy(c->ev_panel);
   if (c->ev_rest) hipEventDestroy(c->ev_rest);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -705,22 +696,9 @@ static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, lo
 //                            every operand k slice through L2, the desynchronised contractions of the dataflow kernel
 //                            stream theirs from HBM and the clock pays for it (-11 %, profiles/archive/r03_experiments/)
 // SGP_DATAFLOW = 0 / 1 forces never / always; SGP_DF_MIN_N, SGP_DF_MAX_N, SGP_DF_FAT_MAX_N move the limits.
-// Task order of the dataflow kernel: XCD-affine queues (1) or column-major ids (0); the patch a queue deals out.
-// Default: column-major.  Round 4 measured the queues (profiles/r04_experiments/dataflow_xcd_queues.md): handing a queue's
-// patches to the free workgroups of its XCD does NOT make them share operand panels -- they start their tiles whenever they
-// become free, not together (L2 hit 0.11 -> 0.15, step +3.6 % at 32768 columns, +2 .. 5 % at 65536); a soft gang start
-// (SGP_DF_GANG_US) does create the sharing (L2 hit 0.43, contraction time per workgroup -10 %) but the waiting it costs is
-// larger (+15 .. 25 %).  Kept as SGP_DF_ORDER=1 for the record and for whoever finds a cheaper way to keep a patch in step.
-static bool df_order_of(const sgp_ctx* ctx, int fat) {
-  (void)fat;
-  return ctx->df_order > 0;
-}
-static void df_patch_of(const sgp_ctx* ctx, int fat, int& pr, int& pc) {
-  pc = ctx->df_pc;
-  if (pc != 1 && pc != 2 && pc != 4 && pc != 8) pc = fat ? 2 : 4;   // (the order's progress argument wants pc | 8)
-  const int slots = std::max(1, ctx->df_wgs / DF_NQ);                 // workgroups that serve one queue
-  pr = ctx->df_pr > 0 ? ctx->df_pr : std::max(1, slots / pc);
-}
+// (Round 4 also measured XCD-affine task queues for the dataflow kernel -- profiles/r04_experiments/dataflow_xcd_queues.md: handing
+// a queue's patches to the free workgroups of its XCD does not make them share operand panels, they start their tiles whenever
+// they become free; +3.6 % at 32768 columns.  The code was removed in round 6.)
 // Hybrid schedule (round 5; the round-4 verdict's item 4): the look-ahead schedule of the launches with every outer PANEL (2048
 // columns) factored by ONE launch of the dataflow kernel on the panel -- its diagonal chain and the row solves below it as
 // tile tasks with tile-level dependencies (the rows below the panel's diagonal block are that kernel's "bordered rows") --
@@ -853,6 +831,29 @@ struct SzScope {   // the launch-based updates read the pattern through gemm_nt.
   }
 };
 
+// scratch of a dataflow launch on this context (grow-only): progress words for nb matrices of m_tot rows and -- when the caller
+// keeps no inverse diagonal blocks itself -- room for those of inv_cols columns (0: not needed)
+static int df_scratch(sgp_ctx* ctx, long m_tot, int nb, long inv_cols, hipStream_t s) {
+  const long need_state = df_state_words(m_tot, nb), need_inv = (inv_cols / TILE) * INVD_STRIDE;
+  if (need_state > ctx->n_df_state) {
+    SGP_HIP(hipStreamSynchronize(s));
+    if (ctx->d_df_state) hipFree(ctx->d_df_state);
+    ctx->d_df_state = nullptr;
+    ctx->n_df_state = 0;
+    SGP_HIP(hipMalloc(&ctx->d_df_state, sizeof(int) * need_state));
+    ctx->n_df_state = need_state;
+  }
+  if (need_inv > ctx->n_df_inv) {
+    SGP_HIP(hipStreamSynchronize(s));
+    if (ctx->d_df_inv) hipFree(ctx->d_df_inv);
+    ctx->d_df_inv = nullptr;
+    ctx->n_df_inv = 0;
+    SGP_HIP(hipMalloc(&ctx->d_df_inv, sizeof(double) * need_inv));
+    ctx->n_df_inv = need_inv;
+  }
+  return 0;
+}
+
 static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
                          hipStream_t s, long grow = 0, const SzMask* sz = nullptr) {
   CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
@@ -866,52 +867,9 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // them as bordered rows -- only the few tiles above the identity's diagonal inside ONE panel are multiplied out, or
   // skipped when the caller's pattern covers them)
   const bool hybrid = s == ctx->stream && use_hybrid(ctx, n_pad, grow != 0);
-  if (hybrid || (grow == 0 && use_dataflow(ctx, n_pad))) {
-    const long need_state = SGP_DF_STATE_WORDS + m_tot / TILE, need_inv = (n_pad / TILE) * INVD_STRIDE;
-    if (need_state > ctx->n_df_state) {
-      SGP_HIP(hipStreamSynchronize(s));
-      if (ctx->d_df_state) hipFree(ctx->d_df_state);
-      ctx->d_df_state = nullptr;
-      ctx->n_df_state = 0;
-      SGP_HIP(hipMalloc(&ctx->d_df_state, sizeof(int) * need_state));
-      ctx->n_df_state = need_state;
-    }
-    if (!d_wall && need_inv > ctx->n_df_inv) {
-      SGP_HIP(hipStreamSynchronize(s));
-      if (ctx->d_df_inv) hipFree(ctx->d_df_inv);
-      ctx->d_df_inv = nullptr;
-      ctx->n_df_inv = 0;
-      SGP_HIP(hipMalloc(&ctx->d_df_inv, sizeof(double) * need_inv));
-      ctx->n_df_inv = need_inv;
-    }
-  }
+  if (hybrid || (grow == 0 && use_dataflow(ctx, n_pad))) CHECK_RC(df_scratch(ctx, m_tot, 1, d_wall ? 0 : n_pad, s));
   if (!hybrid && grow == 0 && use_dataflow(ctx, n_pad)) {
     const int fat = n_pad < ctx->df_fat_max_n ? 1 : 0;
-    // XCD-affine task queues (df_order.h): built on the host once per shape, kept on the device
-    const uint32_t* d_tasks = nullptr;
-    if (df_order_of(ctx, fat)) {
-      int pr, pc;
-      df_patch_of(ctx, fat, pr, pc);
-      const long key[4] = {m_tot / TILE, n_pad / TILE, pr, pc};
-      if (std::memcmp(key, ctx->df_tasks_key, sizeof(key)) != 0) {
-        std::vector<uint32_t> tasks, pend;
-        df_build_queues((int)key[0], (int)key[1], pr, pc, tasks, ctx->df_qstart, &pend);
-        tasks.insert(tasks.end(), pend.begin(), pend.end());
-        SGP_HIP(hipStreamSynchronize(s));   // (an earlier launch may still read the old queues)
-        tasks.insert(tasks.begin(), ctx->df_qstart, ctx->df_qstart + DF_NQ + 1);   // device layout: qstart[9], then the queues
-        if ((long)tasks.size() > ctx->n_df_tasks) {
-          if (ctx->d_df_tasks) hipFree(ctx->d_df_tasks);
-          ctx->d_df_tasks = nullptr;
-          ctx->n_df_tasks = 0;
-          SGP_HIP(hipMalloc(&ctx->d_df_tasks, sizeof(uint32_t) * tasks.size()));
-          ctx->n_df_tasks = (long)tasks.size();
-        }
-        ctx->df_tasks_key[0] = 0;
-        SGP_HIP(hipMemcpy(ctx->d_df_tasks, tasks.data(), sizeof(uint32_t) * tasks.size(), hipMemcpyHostToDevice));
-        std::memcpy(ctx->df_tasks_key, key, sizeof(key));
-      }
-      d_tasks = ctx->d_df_tasks;
-    }
     if (getenv("SGP_DF_STATS") && !ctx->d_df_stats)   // + 8 stamps for each of up to 4096 tile columns
       SGP_HIP(hipMalloc(&ctx->d_df_stats, sizeof(long long) * 8 * ((size_t)ctx->df_wgs + 4096)));
     long long* d_cols = ctx->d_df_stats && n_pad / TILE <= 4096 ? ctx->d_df_stats + 8 * (size_t)ctx->df_wgs : nullptr;
@@ -922,8 +880,8 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       SGP_HIP(hipEventRecord(e0, s));
     }
     CHECK_RC(launch_chol_dataflow(A, ld, n_pad, m_tot, ctx->d_df_state, d_wall ? d_wall : ctx->d_df_inv, ctx->d_slots,
-                                  ctx->d_info, ctx->df_wgs, ctx->df_timeout_s, s, ctx->d_df_stats, d_cols, fat, d_tasks,
-                                  ctx->df_qstart, ctx->df_gang_us, sz ? sz->d_nz : nullptr, sz ? sz->words : 0));
+                                  ctx->d_info, ctx->df_wgs, ctx->df_timeout_s, s, ctx->d_df_stats, d_cols, fat,
+                                  sz ? sz->d_nz : nullptr, sz ? sz->words : 0));
     if (ctx->d_df_stats) {   // diagnosis only: drains the stream
       hipEventRecord(e1, s);
       hipStreamSynchronize(s);
@@ -943,8 +901,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
         h[(size_t)8 * w] &= (1LL << 40) - 1;
         for (int q = 0; q < 8; ++q) sum[q] += (double)h[(size_t)8 * w + q];
       }
-      fprintf(stderr, "dataflow order %s, %ld of %ld workgroups NOT on XCD (id %% 8)\n",
-              d_tasks ? "queues" : "column-major", off_xcd, nw);
+      fprintf(stderr, "dataflow: %ld of %ld workgroups NOT on XCD (id %% 8)\n", off_xcd, nw);
       const double us = 0.01 / (double)std::max<long>(nw, 1);   // ticks (100 MHz) -> us, averaged over the workgroups
       fprintf(stderr,
               "dataflow n_pad=%ld m_tot=%ld: %.3f ms, %ld workgroups, %.0f tasks; per workgroup (us): in kernel %.1f | "
@@ -1053,7 +1010,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       CHECK_RC(launch_chol_dataflow(A + J0 + J0 * ld, ld, wj, m_eff - J0, ctx->d_df_state,
                                     (d_wall ? d_wall : ctx->d_df_inv) + (J0 / TILE) * INVD_STRIDE, ctx->d_slots + J0 / TILE,
                                     ctx->d_info, ctx->hybrid_wgs, ctx->df_timeout_s, s, nullptr, nullptr, ctx->hybrid_fat,
-                                    nullptr, nullptr, 0.0, sz ? sz->d_nz : nullptr, sz ? sz->words : 0, J0));
+                                    sz ? sz->d_nz : nullptr, sz ? sz->words : 0, J0));
     } else
       CHECK_RC(panel_factor_mid(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
                                 ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done, WMID));
@@ -3683,15 +3640,31 @@ int drv_assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long 
   return assemble(ds, Kv, ld, tile_r_lo, tile_r_hi, tile_c_lo, tile_c_hi, lower_only, noise_kind, sigma2,
                   d_noise_diag, s);
 }
-void drv_set_structure(const double* base, long ld, const sgp::sz_word* d_nz, int words, long tile0) {
-  gemm_set_structure(base, ld, d_nz, words, nullptr, 0, tile0);
-}
+// Factor a PACKED panel of the sharded factorisation (w columns over m rows, element [0] = (row g0, column g0) of the matrix).
+// df != 0 (round 6: the hybrid schedule carried into the sharded sweep): ONE launch of the dataflow kernel -- the diagonal
+// chain and the row solves below it as tile tasks, the pattern d_nz read at the panel's offset; px (optional): factor only
+// the first px->n_fact columns and update the others with them, external source panels applied first (chol_df.hip).
+// df == 0: the launch-based chain of rounds 2 - 5 (px must be empty; the caller issues the updates as launches of its own).
 int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_logdet, int* d_info,
-                     double* d_invstore, hipStream_t s) {
+                     double* d_invstore, hipStream_t s, int df, const sz_word* d_nz, int nz_words, const DfPanel* px) {
   CHECK_ARG(w % TILE == 0 && m % TILE == 0 && m >= w, "drv_panel_factor: bad sizes");
-  FuseScope fuse_scope(ctx, fuse_mode(ctx, m));
-  CHECK_RC(panel_factor(ctx, P, ld, m, w, g0, ctx->d_slots, d_info, d_invstore, s));
-  CHECK_RC(launch_sum_array(ctx->d_slots, w / TILE, ctx->d_scal + 8, s));
+  long n_fact = w;
+  if (df && ctx->refine == 1) {
+    if (px) n_fact = px->n_fact;
+    CHECK_ARG(n_fact / TILE <= ctx->n_slots, "drv_panel_factor: panel too wide for the logdet slot buffer");
+    CHECK_RC(df_scratch(ctx, m, 1, d_invstore ? 0 : n_fact, s));
+    CHECK_RC(launch_chol_dataflow(P, ld, w, m, ctx->d_df_state, d_invstore ? d_invstore : ctx->d_df_inv, ctx->d_slots, d_info,
+                                  ctx->hybrid_wgs, ctx->df_timeout_s, s, nullptr, nullptr, ctx->hybrid_fat, d_nz, nz_words, g0,
+                                  px));
+  } else {
+    CHECK_ARG(!px || (px->n_ext == 0 && px->n_fact == w), "drv_panel_factor: the launch-based chain takes whole panels only");
+    FuseScope fuse_scope(ctx, fuse_mode(ctx, m));
+    if (d_nz) gemm_set_structure(P, ld, d_nz, nz_words, nullptr, 0, g0 / TILE);
+    const int rc = panel_factor(ctx, P, ld, m, w, g0, ctx->d_slots, d_info, d_invstore, s);
+    if (d_nz) gemm_set_structure(nullptr, 0, nullptr, 0);
+    CHECK_RC(rc);
+  }
+  CHECK_RC(launch_sum_array(ctx->d_slots, n_fact / TILE, ctx->d_scal + 8, s));
   hipLaunchKernelGGL(accum_kernel, dim3(1), dim3(1), 0, s, d_logdet, ctx->d_scal + 8);
   SGP_HIP(hipGetLastError());
   return 0;

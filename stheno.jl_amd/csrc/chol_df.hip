@@ -25,10 +25,22 @@
 // plain loads.  No tile is read by another workgroup before it is final, so no cache can hold a stale copy of it.
 // Every wait is bounded: a poll that exceeds the limit raises the abort word (all workgroups leave) and reports through
 // *info = SGP_DF_TIMEOUT, which the host turns into an error.
+//
+// Round 6 -- two generalisations of the same task loop:
+//  * a PANEL launch of the sharded factorisation (csrc/multi.hip) may carry EXTERNAL SOURCES -- factored column panels left
+//    of this matrix, received from another GPU: every task contracts their k blocks first (k ascending, exactly the order in
+//    which the separate look-ahead update launch applied them) -- and may FACTOR only its first T_f tile columns: the tasks
+//    of the columns from T_f on are update-only (contraction over the sources and the T_f factored columns, stored, not
+//    solved, no progress published).  So "look-ahead update with the last received sub-panel + factorisation of the next
+//    sub-panel + update of the panel's remaining columns" is ONE launch with tile-level dependencies: the diagonal chain
+//    starts as soon as the first tile column has seen the sources and runs under the rest of the update.
+//  * a BATCH of nb equally shaped, independent matrices as one task pool (sgp_logpdf_batch): ids are dealt round robin, every
+//    matrix has its own progress counters; at sizes where one factorisation is bound by its diagonal chain (N <= 8192: 0.13
+//    of the MFMA peak at N = 4096) the nb chains sit on different workgroups and hide each other.
 #include "common.h"
 #include "potrf_diag.h"
 #include "panel_solve.h"
-#include "df_order.h"
+#include "df_tasks.h"
 #include "kstep.h"
 #include <vector>
 
@@ -37,28 +49,24 @@ namespace sgp {
 constexpr int DF_KB = 16;                       // K chunk per LDS stage (as gemm_nt.hip)
 constexpr int DF_STAGE = 2 * DF_KB * LDS_LD;    // doubles per stage: A chunk + B chunk
 constexpr int DF_PROG = (int)SGP_DF_STATE_WORDS; // offset of the tile-row progress counters in the state words
-constexpr int DF_HEAD = 2;                      // state[DF_HEAD + x]: head of queue x (XCD-affine order, df_order.h)
-static_assert(DF_HEAD + DF_NQ <= DF_PROG, "state words");
 
 struct DfArgs {
-  double* A;        // m_tot x n_pad, column-major, lower tiles + bordered rows
+  DfProb p[DF_MAX_BATCH];   // the matrices of the launch: A (m_tot x n_pad, column-major, lower tiles + bordered rows), invall (T_c x
+                            // INVD = 2048 doubles: inverse 16x16 diagonal blocks of every 128-block), slots (T_c logdet
+                            // contributions), info
+  int nb;           // how many (1: the plain factorisation)
   long ld;
   int T_r, T_c;     // tile rows (m_tot / 128), tile columns (n_pad / 128)
-  int* state;       // [0] next task id, [1] abort, [DF_HEAD + x] head of queue x, [DF_PROG + i] prog[i]; zeroed before every launch
-  const uint32_t* tasks;   // XCD-affine order: qstart[0 .. DF_NQ], then the eight queues back to back (df_build_queues,
-                           // offsets relative to tasks + DF_NQ + 1); nullptr = column-major ids
-  double* invall;   // T_c x INVD (2048 doubles): inverse 16x16 diagonal blocks of every 128-block
-  double* slots;    // T_c logdet contributions
-  int* info;
+  int T_f;          // tile columns this launch FACTORS (<= T_c); the tasks of columns >= T_f are update-only
+  int* state;       // [0] next task id, [1] abort, [DF_PROG + b * T_r + i] prog[i] of matrix b; zeroed before every launch
   long long spin_ticks;   // wall_clock64 ticks (100 MHz) a single wait may last
-  long ntasks;
-  long long gang_ticks;   // experiment (SGP_DF_GANG_US): soft gang start -- a workgroup that took a tile of a patch waits (at
-                          // most this long) until every tile of the patch has been taken; pend[] follows the tasks
+  long ntasks;      // nb * df_ntasks(T_r, T_c)
   const sz_word* nz;  // structural zeros (common.h): bit k of row i = tile (i, k) of the factor may be non-zero; nullptr = dense
   int nzw;            // words per row
-  int diag_lower;     // 1: the diagonal tiles' contractions run the lower-only form (df_contract_diag); SGP_DF_DIAG_LOWER=0: A/B
   long gcol_base;     // global column of tile column 0 (the hybrid schedule factors PANELS with this kernel: PosDef info)
   int nz_t0;          // ... and its tile index: where the panel sits in the pattern
+  DfExt ext[DF_MAX_EXT];   // external sources (factored panels left of this matrix), contracted first, in this order
+  int n_ext;
   long long* stats;   // optional (SGP_DF_STATS): 8 tick counters per workgroup, see launch_chol_dataflow
   long long* cols;    // optional: 8 wall-clock stamps per tile column (the chain: diagonal task + the task below it)
 };
@@ -153,8 +161,7 @@ __device__ __forceinline__ void df_contract_diag(const double* Ag, long ld, long
 }
 
 // thread 0: wait until min(prog[i], prog[j]) > have (returns min(.., cap)), or -1 on abort / timeout
-__device__ __forceinline__ int df_wait(const DfArgs& a, int i, int j, int have, int cap) {
-  int* prog = a.state + DF_PROG;
+__device__ __forceinline__ int df_wait(const DfArgs& a, int* prog, int* info, int i, int j, int have, int cap) {
   const long long t0 = wall_clock64();
   int avail;
   for (unsigned spins = 0;; ++spins) {
@@ -166,7 +173,7 @@ __device__ __forceinline__ int df_wait(const DfArgs& a, int i, int j, int have, 
     __builtin_amdgcn_s_sleep(4);
     if ((spins & 63) == 63 && wall_clock64() - t0 > a.spin_ticks) {
       __hip_atomic_store(a.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicCAS(a.info, 0, SGP_DF_TIMEOUT);
+      atomicCAS(info, 0, SGP_DF_TIMEOUT);
       return -1;
     }
   }
@@ -175,7 +182,7 @@ __device__ __forceinline__ int df_wait(const DfArgs& a, int i, int j, int have, 
 }
 
 // thread 0: wait until *word >= target; 0, or -1 on abort / timeout
-__device__ __forceinline__ int df_wait_word(const DfArgs& a, int* word, int target) {
+__device__ __forceinline__ int df_wait_word(const DfArgs& a, int* info, int* word, int target) {
   const long long t0 = wall_clock64();
   for (unsigned spins = 0;; ++spins) {
     if (DF_RLX_LOAD(word) >= target) break;
@@ -183,7 +190,7 @@ __device__ __forceinline__ int df_wait_word(const DfArgs& a, int* word, int targ
     __builtin_amdgcn_s_sleep(2);
     if ((spins & 63) == 63 && wall_clock64() - t0 > a.spin_ticks) {
       __hip_atomic_store(a.state + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicCAS(a.info, 0, SGP_DF_TIMEOUT);
+      atomicCAS(info, 0, SGP_DF_TIMEOUT);
       return -1;
     }
   }
@@ -192,22 +199,18 @@ __device__ __forceinline__ int df_wait_word(const DfArgs& a, int* word, int targ
 }
 
 // structural zeros: is tile (i, j) of the factor structurally non-zero?
-// (nz_t0: the pattern is the whole matrix's; a panel factored by this kernel -- the hybrid schedule -- sits nz_t0 tiles down
-// and to the right in it, and its k blocks are the panel's own columns)
+// (nz_t0: the pattern is the whole matrix's; a panel factored by this kernel -- the hybrid schedule, the sharded sweep --
+// sits nz_t0 tiles down and to the right in it, and its k blocks are the panel's own columns)
 __device__ __forceinline__ bool df_nz(const DfArgs& a, int i, int j) {
   const int jj = j + a.nz_t0;
   return !a.nz || ((a.nz[(long)(i + a.nz_t0) * a.nzw + (jj >> 6)] >> (jj & 63)) & 1) != 0;
 }
-// thread 0: the next run of k blocks >= k0 (and < j) that task (i, j) has to contract -- both L_ik and L_jk structurally
-// non-zero: [ka, kb); ka == j: none left
-__device__ __forceinline__ void df_next_run(const DfArgs& a, int i, int j, int k0_, int& ka, int& kb) {
-  const int t0 = a.nz_t0;
-  const sz_word* ri = a.nz + (long)(i + t0) * a.nzw;
-  const sz_word* rj = a.nz + (long)(j + t0) * a.nzw;
-  const int jg = j + t0, k0 = k0_ + t0;   // global tile columns
-  ka = j;
-  kb = j;
-  const int qlast = (jg - 1) >> 6;
+// the next run of k tiles in [k0, kend) (GLOBAL tile columns, k0 < kend) for which both pattern rows are non-zero:
+// [ka, kb); ka == kend: none left
+__device__ __forceinline__ void df_run(const sz_word* ri, const sz_word* rj, int k0, int kend, int& ka, int& kb) {
+  ka = kend;
+  kb = kend;
+  const int qlast = (kend - 1) >> 6;
   int q = k0 >> 6;
   sz_word m = (ri[q] & rj[q]) & (~(sz_word)0 << (k0 & 63));
   while (m == 0 && q < qlast) {
@@ -216,15 +219,23 @@ __device__ __forceinline__ void df_next_run(const DfArgs& a, int i, int j, int k
   }
   if (m == 0) return;
   const int first = q * 64 + __builtin_ctzll(m);
-  if (first >= jg) return;
-  ka = first - t0;
+  if (first >= kend) return;
+  ka = first;
   // the end of the run: the first k > ka that is not needed
   sz_word z = ~(ri[q] & rj[q]) & (~(sz_word)0 << (first & 63));
   while (z == 0 && q < qlast) {
     ++q;
     z = ~(ri[q] & rj[q]);
   }
-  if (z != 0) kb = min(j, q * 64 + (int)__builtin_ctzll(z) - t0);
+  if (z != 0) kb = min(kend, q * 64 + (int)__builtin_ctzll(z));
+}
+// thread 0: the next run of the matrix's OWN k blocks >= k0 (and < jend) that task (i, j) has to contract -- both L_ik and
+// L_jk structurally non-zero: [ka, kb); ka == jend: none left
+__device__ __forceinline__ void df_next_run(const DfArgs& a, int i, int j, int k0, int jend, int& ka, int& kb) {
+  const int t0 = a.nz_t0;
+  df_run(a.nz + (long)(i + t0) * a.nzw, a.nz + (long)(j + t0) * a.nzw, k0 + t0, jend + t0, ka, kb);
+  ka -= t0;
+  kb -= t0;
 }
 
 // lane 0, after every wave has drained its stores and met at a barrier: release fence, drain, progress counter
@@ -233,40 +244,18 @@ __device__ __forceinline__ void df_release_store(int* word, int value) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (ROCm 7.2 may drop the wait after buffer_wbl2: restate it)
   __hip_atomic_store(word, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// lane 0: the next task -- tile (i << 16 | j) -- or -1: none left / abort raised.  Column-major order: one counter.
-// XCD-affine order: the workgroup serves queue `cur` (starts at workgroup id % 8 = the XCD the hardware dispatched it
-// to) and moves on to the next queue once that one is exhausted; every queue is handed out in order.
-__device__ __forceinline__ int df_dequeue(const DfArgs& a, int* curleft) {
+// lane 0: the next task -- tile (i << 16 | j), its matrix through *b -- or -1: none left / abort raised.  One counter:
+// column-major order per matrix, the matrices of a batch round robin (df_tasks.h).
+__device__ __forceinline__ int df_dequeue(const DfArgs& a, int* b) {
   if (DF_RLX_LOAD(a.state + 1) != 0) return -1;
-  if (!a.tasks) {
-    const int q = atomicAdd(a.state, 1);
-    if ((long)q >= a.ntasks) return -1;
-    int i, j;
-    df_task_tile((long)q, a.T_r, a.T_c, i, j);
-    return (int)df_pack(i, j);
-  }
-  int cur = curleft[0], left = curleft[1];
-  int r = -1;
-  while (left > 0) {
-    const int q0 = (int)a.tasks[cur], len = (int)a.tasks[cur + 1] - q0;
-    if (len > 0 && DF_RLX_LOAD(a.state + DF_HEAD + cur) < len) {
-      const int q = atomicAdd(a.state + DF_HEAD + cur, 1);
-      if (q < len) {
-        r = (int)a.tasks[DF_NQ + 1 + q0 + q];
-        if (a.gang_ticks > 0) {
-          const int pe = (int)a.tasks[DF_NQ + 1 + a.ntasks + q0 + q];
-          const long long t0 = wall_clock64();
-          while (DF_RLX_LOAD(a.state + DF_HEAD + cur) < pe && wall_clock64() - t0 < a.gang_ticks) __builtin_amdgcn_s_sleep(2);
-        }
-        break;
-      }
-    }
-    cur = (cur + 1) & (DF_NQ - 1);
-    --left;
-  }
-  curleft[0] = cur;
-  curleft[1] = left;
-  return r;
+  const int q = atomicAdd(a.state, 1);
+  if ((long)q >= a.ntasks) return -1;
+  long ql = q;
+  *b = 0;
+  if (a.nb > 1) df_batch_task((long)q, a.nb, *b, ql);
+  int i, j;
+  df_task_tile(ql, a.T_r, a.T_c, i, j);
+  return (int)df_pack(i, j);
 }
 
 // The three phases of a task are separate (non-inlined) functions: each gets its own register allocation -- inlined
@@ -274,25 +263,28 @@ __device__ __forceinline__ int df_dequeue(const DfArgs& a, int* curleft) {
 // accumulators + LDS pipeline spilled into each other (265 VGPR / 220 SGPR spills); nothing but (i, j) crosses a phase
 // boundary: the accumulators leave through LDS (diagonal tile) or through the tile's own memory (off-diagonal).
 
-// Phase 1: acc = -A_ij + sum_k L_ik L_jk' as the operand rows become final.  Diagonal tile: the result goes into
-// potrf_diag_body's packed LDS layout; off-diagonal: T = -acc is stored in place.  Returns false on abort.
+// Phase 1: acc = -A_ij + sum_k L_ik L_jk' -- the external sources first, then the matrix's own columns as the operand rows
+// become final.  Diagonal tile of a factored column: the result goes into potrf_diag_body's packed LDS layout; every other
+// tile: T = -acc is stored in place.  Returns false on abort.
 template <bool LOWER>   // LOWER: the diagonal tiles' lower-only contraction (the one-workgroup-per-CU instantiation: the sizes
                         // where the chain is the step; the lean kernel's register budget stays what it was)
-__device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j, double* smem, int* s_word) {
+__device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, double* A, int* prog, int* info, int i, int j, double* smem,
+                                                   int* s_word) {
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int w = t >> 6;
   const int wu = __builtin_amdgcn_readfirstlane(w);
   int wr = w >> 2, wc = w & 3, shape = 1;
-  const bool lower_only = LOWER && (i == j) && a.diag_lower;   // the diagonal tile: lower blocks only, shares dealt for balance
+  const bool fin = j < a.T_f;   // this launch factors column j (else: an update-only tile)
+  const bool lower_only = LOWER && (i == j) && fin;   // the diagonal tile: lower blocks only, shares dealt for balance
   if (lower_only) diag_share(wu, wr, wc, shape);
   const int l15 = lane & 15, lq = lane >> 4, l3 = lane & 3;
   const unsigned a_off = (unsigned)((lq * LDS_LD + wr * 64 + l15) * 8);
   const unsigned b_off = (unsigned)((DF_KB * LDS_LD + lq * LDS_LD + wc * 32 + l3) * 8);
   const long ld = a.ld;
-  const double* Ag = a.A + (long)i * TILE;
-  const double* Bg = a.A + (long)j * TILE;
-  double* Cg = a.A + ((long)i * TILE + wr * 64 + l15) + ((long)j * TILE + wc * 32 + lq) * ld;
+  const double* Ag = A + (long)i * TILE;
+  const double* Bg = A + (long)j * TILE;
+  double* Cg = A + ((long)i * TILE + wr * 64 + l15) + ((long)j * TILE + wc * 32 + lq) * ld;
   // acc[jj][ii] = -A[row 64 wr + 16 ii + l15][col 32 wc + 4 jj + lq]: the seed of C_new = -(acc + P P')
   double acc[8][4];
 #pragma unroll
@@ -303,14 +295,42 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
   for (int jj = 0; jj < 8; ++jj)
 #pragma unroll
     for (int ii = 0; ii < 4; ++ii) acc[jj][ii] *= -1.0;
+  // ---- external sources: final before the launch (the host ordered it behind their arrival), no waits.  Every lane
+  // derives the same runs from the pattern (wave-uniform values).
+  for (int e = 0; e < a.n_ext; ++e) {
+    const DfExt& x = a.ext[e];
+    const double* Ae = x.base + (long)i * TILE;
+    const double* Be = x.base + (long)j * TILE;
+    int ka = x.kt0;
+    const int kend = x.kt0 + x.kt;
+    while (ka < kend) {
+      int kb = kend;
+      if (a.nz) {
+        const int t0 = a.nz_t0;
+        int ra, rb;
+        df_run(a.nz + (long)(i + t0) * a.nzw, a.nz + (long)(j + t0) * a.nzw, ka, kend, ra, rb);
+        ka = __builtin_amdgcn_readfirstlane(ra);
+        kb = __builtin_amdgcn_readfirstlane(rb);
+        if (ka >= kend) break;
+      }
+      const long c0 = (long)(ka - x.kt0) * (TILE / DF_KB), c1 = (long)(kb - x.kt0) * (TILE / DF_KB);
+      if (lower_only)
+        df_contract_diag(Ae, x.ld, c0, c1, acc, smem, wu, lane, a_off, b_off, shape);
+      else
+        df_contract(Ae, Be, x.ld, c0, c1, acc, smem, wu, lane, a_off, b_off);
+      ka = kb;
+    }
+  }
+  // ---- the matrix's own columns k < min(j, T_f)
+  const int jend = min(j, a.T_f);
   int kdone = 0;
-  while (kdone < j) {
+  while (kdone < jend) {
     if (t == 0) {
       const long long w0 = a.stats ? wall_clock64() : 0;
-      int ka = kdone, kb = j;
-      if (a.nz) df_next_run(a, i, j, kdone, ka, kb);   // skip the k blocks with a structurally zero operand tile
+      int ka = kdone, kb = jend;
+      if (a.nz) df_next_run(a, i, j, kdone, jend, ka, kb);   // skip the k blocks with a structurally zero operand tile
       s_word[6] = ka;
-      s_word[1] = ka < j ? df_wait(a, i, j, ka, kb) : j;
+      s_word[1] = ka < jend ? df_wait(a, prog, info, i, j, ka, kb) : jend;
       if (a.stats) {
         const long long tot = ((long long)(unsigned)s_word[2] | ((long long)s_word[3] << 32)) + (wall_clock64() - w0);
         s_word[2] = (int)(unsigned)tot;
@@ -321,7 +341,7 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
     const int ka = __builtin_amdgcn_readfirstlane(s_word[6]);
     const int avail = __builtin_amdgcn_readfirstlane(s_word[1]);   // wave-uniform for the compiler too
     if (avail < 0) return false;
-    if (ka >= j) {
+    if (ka >= jend) {
       __syncthreads();   // (s_word is rewritten by the caller's lane 0)
       break;
     }
@@ -333,7 +353,7 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
     kdone = avail;
   }
   if (a.cols && t == 0 && i == j) a.cols[(long)j * 8 + 2] = wall_clock64();
-  if (i == j) {
+  if (i == j && fin) {
     // accumulators -> potrf_diag_body's packed LDS layout (as gemm_nt_dma_tile<HANDOFF>)
 #pragma unroll
     for (int jj = 0; jj < 8; ++jj)
@@ -353,9 +373,9 @@ __device__ __forceinline__ bool df_accumulate_body(const DfArgs& a, int i, int j
 }
 
 // Phase 2a: Cholesky of the diagonal tile sitting in LDS
-__device__ __forceinline__ void df_diag_body(const DfArgs& a, int j) {
-  potrf_diag_body<false, double, true>(a.A + (long)j * TILE + (long)j * TILE * a.ld, a.ld, a.invall + (long)j * 2048,
-                                       a.slots + j, a.info, a.gcol_base + (long)j * TILE, 0, nullptr);
+__device__ __forceinline__ void df_diag_body(const DfArgs& a, const DfProb& p, int j) {
+  potrf_diag_body<false, double, true>(p.A + (long)j * TILE + (long)j * TILE * a.ld, a.ld, p.invall + (long)j * 2048,
+                                       p.slots + j, p.info, a.gcol_base + (long)j * TILE, 0, nullptr);
 }
 
 // Phase 2b: L_ij = T inv(L_jj)' for the tile's 128 rows, eight waves x 16 rows
@@ -376,53 +396,51 @@ __device__ __forceinline__ void df_solve_body(double* A, long ld, const double* 
 // LEAN (two workgroups per CU, 128 VGPRs -- the sizes where the trailing contractions are the work): the phases are
 // separate functions.  FAT (one workgroup per CU, 256 VGPRs -- the sizes where the diagonal chain is the critical path and
 // occupancy buys nothing): everything inline, no spills in the substitution (228 VGPRs) or the diagonal-block routine.
-__device__ __attribute__((noinline)) bool df_accumulate_lean(const DfArgs& a, int i, int j, double* smem, int* s_word) {
-  return df_accumulate_body<false>(a, i, j, smem, s_word);
+__device__ __attribute__((noinline)) bool df_accumulate_lean(const DfArgs& a, double* A, int* prog, int* info, int i, int j,
+                                                             double* smem, int* s_word) {
+  return df_accumulate_body<false>(a, A, prog, info, i, j, smem, s_word);
 }
-__device__ __attribute__((noinline)) void df_diag_lean(const DfArgs& a, int j) { df_diag_body(a, j); }
+__device__ __attribute__((noinline)) void df_diag_lean(const DfArgs& a, const DfProb& p, int j) { df_diag_body(a, p, j); }
 __device__ __attribute__((noinline)) void df_solve_lean(double* A, long ld, const double* invall, int i, int j, double* smem) {
   df_solve_body(A, ld, invall, i, j, smem);
 }
 #define DF_FAT_FN __device__ __attribute__((noinline))
-DF_FAT_FN bool df_accumulate_fat(const DfArgs& a, int i, int j, double* smem, int* s_word) {
-  return df_accumulate_body<true>(a, i, j, smem, s_word);
+DF_FAT_FN bool df_accumulate_fat(const DfArgs& a, double* A, int* prog, int* info, int i, int j, double* smem, int* s_word) {
+  return df_accumulate_body<true>(a, A, prog, info, i, j, smem, s_word);
 }
-DF_FAT_FN void df_diag_fat(const DfArgs& a, int j) { df_diag_body(a, j); }
+DF_FAT_FN void df_diag_fat(const DfArgs& a, const DfProb& p, int j) { df_diag_body(a, p, j); }
 DF_FAT_FN void df_solve_fat(double* A, long ld, const double* invall, int i, int j, double* smem) {
   df_solve_body(A, ld, invall, i, j, smem);
 }
 template <bool FAT>
-__device__ __forceinline__ bool df_accumulate(const DfArgs& a, int i, int j, double* smem, int* s_word) {
-  if (FAT) return df_accumulate_fat(a, i, j, smem, s_word);
-  return df_accumulate_lean(a, i, j, smem, s_word);
+__device__ __forceinline__ bool df_accumulate(const DfArgs& a, double* A, int* prog, int* info, int i, int j, double* smem,
+                                              int* s_word) {
+  if (FAT) return df_accumulate_fat(a, A, prog, info, i, j, smem, s_word);
+  return df_accumulate_lean(a, A, prog, info, i, j, smem, s_word);
 }
 template <bool FAT>
-__device__ __forceinline__ void df_diag(const DfArgs& a, int j) {
-  if (FAT) df_diag_fat(a, j);
-  else df_diag_lean(a, j);
+__device__ __forceinline__ void df_diag(const DfArgs& a, const DfProb& p, int j) {
+  if (FAT) df_diag_fat(a, p, j);
+  else df_diag_lean(a, p, j);
 }
 template <bool FAT>
-__device__ __forceinline__ void df_solve(const DfArgs& a, int i, int j, double* smem) {
-  if (FAT) df_solve_fat(a.A, a.ld, a.invall, i, j, smem);
-  else df_solve_lean(a.A, a.ld, a.invall, i, j, smem);
+__device__ __forceinline__ void df_solve(const DfArgs& a, const DfProb& p, int i, int j, double* smem) {
+  if (FAT) df_solve_fat(p.A, a.ld, p.invall, i, j, smem);
+  else df_solve_lean(p.A, a.ld, p.invall, i, j, smem);
 }
 
 template <bool FAT>
 __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
   extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
-  __shared__ int s_word[8];   // [0] task, [1] available k blocks / abort, [2..3] wait ticks (statistics), [4..5] lane 0's
-                              // queue cursor: the queue it serves, queues left to try (XCD-affine order), [6] first k
-                              // block of the run being contracted (structural zeros)
+  __shared__ int s_word[8];   // [0] task, [1] available k blocks / abort, [2..3] wait ticks (statistics), [4] the task's
+                              // matrix (batch), [6] first k block of the run being contracted (structural zeros)
   const int t = threadIdx.x;
-  int* prog = a.state + DF_PROG;
   // optional per-workgroup time accounting (lane 0, 100 MHz wall clock): [0] tasks [1] kernel [2] contraction incl. its
   // waits [3] wait for the diagonal tile [4] potrf [5] solve [6] publish + dequeue [7] of [2]: waiting
   long long tk0 = 0, tk = 0, acc_c = 0, acc_w = 0, acc_p = 0, acc_s = 0, acc_q = 0, ntask = 0;
   const bool st = a.stats != nullptr && t == 0;
   if (st) tk0 = wall_clock64();
   if (t == 0) {
-    s_word[4] = (int)(blockIdx.x & (DF_NQ - 1));
-    s_word[5] = DF_NQ;
     s_word[0] = df_dequeue(a, s_word + 4);
     s_word[2] = s_word[3] = 0;
   }
@@ -435,39 +453,50 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
     __syncthreads();   // s_word[0] is set; the previous task's LDS phases are over for every wave
     const int q = __builtin_amdgcn_readfirstlane(s_word[0]);
     if (q < 0) break;
+    const int b = __builtin_amdgcn_readfirstlane(s_word[4]);
     int j, i;
     df_unpack((uint32_t)q, i, j);
+    const DfProb& p = a.p[b];
+    int* prog = a.state + DF_PROG + (long)b * a.T_r;
+    const bool fin = j < a.T_f;
     // the chain tasks run at raised wave priority: beside a contraction's back-to-back MFMAs the pivot chain of the
     // diagonal block and the substitution otherwise wait for issue slots (potrf 35 -> 100 us at N = 16384)
     if (a.nz && !df_nz(a, i, j)) {
       // a structurally zero tile: nothing to compute (its entries are the zeros the assembly wrote); the progress counter
-      // of its row still moves in column order
+      // of its row still moves in column order (an update-only column publishes nothing)
       __syncthreads();   // every wave has read s_word[0]
       if (t == 0) {
-        int r = df_wait_word(a, prog + i, j);
+        int r = fin ? df_wait_word(a, p.info, prog + i, j) : 0;
         if (r == 0) {
-          df_release_store(prog + i, j + 1);
+          if (fin) df_release_store(prog + i, j + 1);
           r = df_dequeue(a, s_word + 4);
         }
         s_word[0] = r;
       }
       continue;
     }
-    const bool chain = (i == j || i == j + 1);
+    const bool chain = fin && (i == j || i == j + 1);
     if (chain) __builtin_amdgcn_s_setprio(3);
     else __builtin_amdgcn_s_setprio(0);
     if (st) tk = wall_clock64();
     if (st && a.cols && i == j) a.cols[(long)j * 8 + 0] = tk;
-    if (!__builtin_amdgcn_readfirstlane((int)df_accumulate<FAT>(a, i, j, dyn_smem, s_word))) break;
+    if (!__builtin_amdgcn_readfirstlane((int)df_accumulate<FAT>(a, p.A, prog, p.info, i, j, dyn_smem, s_word))) break;
     if (st) {
       const long long n = wall_clock64();
       acc_c += n - tk;
       tk = n;
       ++ntask;
     }
+    if (!fin) {
+      // update-only: the tile is stored; the NEXT launch on the stream reads it (kernel boundary), nothing to publish
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) s_word[0] = df_dequeue(a, s_word + 4);
+      continue;
+    }
     if (i == j) {
       __syncthreads();
-      df_diag<FAT>(a, j);
+      df_diag<FAT>(a, p, j);
       if (st) {
         const long long n = wall_clock64();
         acc_p += n - tk;
@@ -475,7 +504,7 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
         if (a.cols) a.cols[(long)j * 8 + 3] = n;
       }
     } else {
-      if (t == 0) s_word[1] = df_wait(a, j, j, j, j + 1);   // prog[j] == j + 1: the diagonal tile of column j is final
+      if (t == 0) s_word[1] = df_wait(a, prog, p.info, j, j, j, j + 1);   // prog[j] == j + 1: the diagonal tile of column j is final
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (__builtin_amdgcn_readfirstlane(s_word[1]) < 0) break;
@@ -485,7 +514,7 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
         tk = n;
         if (a.cols && i == j + 1) a.cols[(long)j * 8 + 5] = n;
       }
-      df_solve<FAT>(a, i, j, dyn_smem);
+      df_solve<FAT>(a, p, i, j, dyn_smem);
       if (st) {
         const long long n = wall_clock64();
         acc_s += n - tk;
@@ -499,7 +528,7 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
     if (t == 0) {
       // (with skipped k blocks this task may not have waited for every earlier tile of its row: prog[i] counts the final
       // tiles of row i in column order, so the count only moves past j once they all are)
-      int r = a.nz ? df_wait_word(a, prog + i, j) : 0;
+      int r = a.nz ? df_wait_word(a, p.info, prog + i, j) : 0;
       if (r == 0) {
         df_release_store(prog + i, j + 1);
         r = df_dequeue(a, s_word + 4);
@@ -515,7 +544,7 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
   }
   if (st) {
     long long* d = a.stats + (long)blockIdx.x * 8;
-    // (bits 40..43: the XCD this workgroup ran on, XCC_ID -- the queues assume workgroup id % 8)
+    // (bits 40..43: the XCD this workgroup ran on, XCC_ID)
     d[0] = ntask | ((long long)(__builtin_amdgcn_s_getreg(6164) & 15) << 40);
     d[1] = wall_clock64() - tk0;
     d[2] = acc_c;
@@ -530,10 +559,10 @@ __device__ __forceinline__ void chol_dataflow_body(const DfArgs& a) {
 __global__ __launch_bounds__(512, 4) void chol_dataflow_kernel(DfArgs a) { chol_dataflow_body<false>(a); }
 __global__ __launch_bounds__(512, 2) void chol_dataflow_fat_kernel(DfArgs a) { chol_dataflow_body<true>(a); }
 
-int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
-                         int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats, long long* d_cols,
-                         int fat, const uint32_t* d_tasks, const int* qstart, double gang_us, const sz_word* d_nz,
-                         int nz_words, long gcol_base) {
+// state words a launch of nb matrices with m_tot rows needs (the callers size d_state with it)
+long df_state_words(long m_tot, int nb) { return SGP_DF_STATE_WORDS + (long)nb * (m_tot / TILE); }
+
+static int df_launch(DfArgs& a, long n_pad, long m_tot, long ld, int n_wg, double timeout_s, int fat, hipStream_t s) {
   if (n_pad % TILE || m_tot % TILE || n_pad <= 0 || m_tot < n_pad) {
     set_error("chol_dataflow: sizes must be multiples of 128");
     return -1;
@@ -548,36 +577,16 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
   }
   SGP_LDS_ATTR_ONCE(chol_dataflow_kernel, PD_LDS);
   SGP_LDS_ATTR_ONCE(chol_dataflow_fat_kernel, PD_LDS);
-  DfArgs a;
-  a.A = A;
   a.ld = ld;
   a.T_r = (int)(m_tot / TILE);
   a.T_c = (int)(n_pad / TILE);
-  a.state = d_state;
-  a.invall = d_invall;
-  a.slots = d_slots;
-  a.info = d_info;
   a.spin_ticks = (long long)(timeout_s * 1e8);
-  {
-    static const int dl = getenv("SGP_DF_DIAG_LOWER") ? atoi(getenv("SGP_DF_DIAG_LOWER")) : 1;
-    a.diag_lower = dl;
-  }
-  a.ntasks = df_ntasks(a.T_r, a.T_c);
-  // the queues need a workgroup each (a queue nobody serves would only be drained by workgroups whose own queue is
-  // exhausted -- and those may hold tasks that wait for it): fewer than DF_NQ workgroups run the column-major order
-  a.tasks = (d_tasks && qstart && std::min<long>(a.ntasks, n_wg) >= DF_NQ) ? d_tasks : nullptr;
-  if (a.tasks && (long)qstart[DF_NQ] != a.ntasks) {
-    set_error("chol_dataflow: task queues do not match the tile grid");
+  a.ntasks = (long)a.nb * df_ntasks(a.T_r, a.T_c);
+  if (a.ntasks >= (1L << 31)) {   // (the task counter is an int)
+    set_error("chol_dataflow: too many tasks for one launch");
     return -1;
   }
-  a.gang_ticks = a.tasks ? (long long)(gang_us * 100.0) : 0;
-  a.stats = d_stats;
-  a.cols = d_stats ? d_cols : nullptr;
-  a.nz = d_nz;
-  a.nzw = nz_words;
-  a.gcol_base = gcol_base;
-  a.nz_t0 = (int)(gcol_base / TILE);
-  SGP_HIP(hipMemsetAsync(d_state, 0, sizeof(int) * (DF_PROG + (size_t)a.T_r), s));
+  SGP_HIP(hipMemsetAsync(a.state, 0, sizeof(int) * (size_t)df_state_words(m_tot, a.nb), s));
   const long grid = std::min<long>(a.ntasks, n_wg);
   if (fat)
     hipLaunchKernelGGL(chol_dataflow_fat_kernel, dim3((unsigned)grid), dim3(512), PD_LDS, s, a);
@@ -585,6 +594,61 @@ int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_stat
     hipLaunchKernelGGL(chol_dataflow_kernel, dim3((unsigned)grid), dim3(512), PD_LDS, s, a);
   SGP_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
+                         int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats, long long* d_cols,
+                         int fat, const sz_word* d_nz, int nz_words, long gcol_base, const DfPanel* px) {
+  DfArgs a;
+  a.p[0] = DfProb{A, d_invall, d_slots, d_info};
+  a.nb = 1;
+  a.state = d_state;
+  a.stats = d_stats;
+  a.cols = d_stats ? d_cols : nullptr;
+  a.nz = d_nz;
+  a.nzw = nz_words;
+  a.gcol_base = gcol_base;
+  a.nz_t0 = (int)(gcol_base / TILE);
+  a.T_f = (int)(n_pad / TILE);
+  a.n_ext = 0;
+  if (px) {
+    if (px->n_fact % TILE || px->n_fact <= 0 || px->n_fact > n_pad || px->n_ext < 0 || px->n_ext > DF_MAX_EXT) {
+      set_error("chol_dataflow: bad panel extension");
+      return -1;
+    }
+    a.T_f = (int)(px->n_fact / TILE);
+    a.n_ext = px->n_ext;
+    for (int e = 0; e < px->n_ext; ++e) {
+      a.ext[e] = px->ext[e];
+      if (!a.ext[e].base || a.ext[e].kt <= 0 || a.ext[e].kt0 < 0 || a.ext[e].kt0 + a.ext[e].kt > a.nz_t0) {
+        set_error("chol_dataflow: an external source must lie left of the panel");
+        return -1;
+      }
+    }
+  }
+  return df_launch(a, n_pad, m_tot, ld, n_wg, timeout_s, fat, s);
+}
+
+// nb equally shaped independent matrices as one task pool (dense patterns: a batch shares no structure)
+int launch_chol_dataflow_batch(const DfProb* probs, int nb, long ld, long n_pad, long m_tot, int* d_state, int n_wg,
+                               double timeout_s, int fat, hipStream_t s) {
+  if (nb < 1 || nb > DF_MAX_BATCH) {
+    set_error("chol_dataflow: batch size out of range");
+    return -1;
+  }
+  DfArgs a;
+  for (int b = 0; b < nb; ++b) a.p[b] = probs[b];
+  a.nb = nb;
+  a.state = d_state;
+  a.stats = nullptr;
+  a.cols = nullptr;
+  a.nz = nullptr;
+  a.nzw = 0;
+  a.gcol_base = 0;
+  a.nz_t0 = 0;
+  a.T_f = (int)(n_pad / TILE);
+  a.n_ext = 0;
+  return df_launch(a, n_pad, m_tot, ld, n_wg, timeout_s, fat, s);
 }
 
 }  // namespace sgp

@@ -177,14 +177,36 @@ struct StripSkip {
 };
 StripSkip strip_skip_for(const double* X, long ldx);   // from the per-thread structure record (gemm_nt.hip), or an empty one
 // chol_df.hip: the whole bordered factorisation (lower tiles of the n_pad columns + rows n_pad .. m_tot) in one launch of
-// persistent workgroups; d_state: SGP_DF_STATE_WORDS + m_tot / 128 ints, d_invall: n_pad / 128 x 2048 doubles
+// persistent workgroups; d_state: df_state_words(m_tot, 1) ints, d_invall: n_pad / 128 x 2048 doubles
 constexpr int SGP_DF_TIMEOUT = -77;   // *info when a dependency wait inside the kernel ran into its bound
+// One matrix of a launch (a batch holds up to DF_MAX_BATCH equally shaped ones: launch_chol_dataflow_batch)
+constexpr int DF_MAX_BATCH = 16, DF_MAX_EXT = 2;
+struct DfProb {
+  double* A;        // m_tot x n_pad, column-major, lower tiles + bordered rows
+  double* invall;   // n_pad / 128 x 2048 doubles: inverse 16x16 diagonal blocks of every 128-block
+  double* slots;    // n_pad / 128 logdet contributions
+  int* info;
+};
+// A factored column panel LEFT of the matrix a panel launch works on (round 6, the sharded factorisation): base points at the
+// source's element (row of A's first row, first column of the source), kt0 = global tile column of that first column, kt =
+// its tile columns.  Every task contracts the sources first, in the order given (k ascending).
+struct DfExt {
+  const double* base;
+  long ld;
+  int kt0, kt;
+};
+struct DfPanel {    // launch_chol_dataflow's optional extension: factor only the first n_fact columns (the others: update-only)
+  long n_fact = 0;
+  int n_ext = 0;
+  DfExt ext[DF_MAX_EXT];
+};
 int launch_chol_dataflow(double* A, long ld, long n_pad, long m_tot, int* d_state, double* d_invall, double* d_slots,
                          int* d_info, int n_wg, double timeout_s, hipStream_t s, long long* d_stats = nullptr,
-                         long long* d_cols = nullptr, int fat = 0, const uint32_t* d_tasks = nullptr,
-                         const int* qstart = nullptr, double gang_us = 0.0, const sz_word* d_nz = nullptr, int nz_words = 0,
-                         long gcol_base = 0);
-// d_tasks = qstart[9], the queues, pend[] (df_order.h: df_build_queues); qstart: host copy
+                         long long* d_cols = nullptr, int fat = 0, const sz_word* d_nz = nullptr, int nz_words = 0,
+                         long gcol_base = 0, const DfPanel* px = nullptr);
+int launch_chol_dataflow_batch(const DfProb* probs, int nb, long ld, long n_pad, long m_tot, int* d_state, int n_wg,
+                               double timeout_s, int fat, hipStream_t s);
+long df_state_words(long m_tot, int nb);   // ints of d_state a launch needs
 constexpr long SGP_DF_STATE_WORDS = 16;   // state words ahead of the per-tile-row progress counters
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
                           long* n_ids, hipStream_t s, double beta = 1.0, long scr_mul = 0);   // bench: per-workgroup phase stamps of one lower update
@@ -210,6 +232,12 @@ struct SegBatch {
   long m_tot;
   const sz_word* nz = nullptr;   // structural zeros (above): a tile skips the sources all of whose k tiles are dead for it
   int nz_words = 0;
+  // round 6: room for the compacted live-tile id map of a big structured launch (launches of ONE stream only: they are
+  // ordered); nullptr: the dead ids leave where they stand.  cmap / cstride: filled in by the launcher.
+  int* map_scratch = nullptr;
+  long map_ints = 0, map_min_ids = 4096;   // (smaller launches are not worth the extra kernel; tests lower the bound)
+  const int* cmap = nullptr;
+  int cstride = 0;
 };
 int launch_gemm_nt_seg(SegBatch& b, hipStream_t s, long* n_ids = nullptr);
 int launch_gemm_nt_cin(const double* A, long lda, const double* B, long ldb, const double* Cin, long ldcin,

@@ -83,15 +83,6 @@ struct sgp_ctx {
   long long* d_df_stats = nullptr;  // SGP_DF_STATS=1: per-workgroup tick counters, summarised on stderr after every launch
   double* d_df_inv = nullptr;       // inverse diagonal blocks of every 128-block when the caller keeps none
   long n_df_inv = 0;
-  // XCD-affine task queues of the dataflow factorisation (df_order.h; an experiment that lost, see capi.hip: df_order_of):
-  // SGP_DF_ORDER 1 = queues (default 0 = column-major ids); SGP_DF_PR / SGP_DF_PC = patch rows / columns (0 = automatic);
-  // SGP_DF_GANG_US = soft gang start of a patch (0 = off).  The queues of the last shape are kept on the device.
-  int df_order = 0, df_pr = 0, df_pc = 0;
-  double df_gang_us = 0.0;
-  uint32_t* d_df_tasks = nullptr;
-  long n_df_tasks = 0;
-  long df_tasks_key[4] = {0, 0, 0, 0};   // T_r, T_c, pr, pc of what d_df_tasks holds
-  int df_qstart[9] = {0};
   // hybrid schedule (round 5; capi.hip: use_hybrid): launches with look-ahead whose PANEL factorisation is one dataflow
   // launch on the panel (tile-level dependencies for the chain and its row solves), lock-step launches for the trailing updates
   // SGP_HYBRID = 0 never, 1 whenever it applies (n_pad >= 4096), unset (-1): from SGP_HYBRID_MIN_N columns on (measured:

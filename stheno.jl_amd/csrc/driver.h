@@ -10,14 +10,15 @@ namespace sgp {
 int drv_assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long tile_r_hi, long tile_c_lo,
                  long tile_c_hi, int lower_only, int noise_kind, double sigma2, const double* d_noise_diag,
                  hipStream_t s);
-// sgp_dev_panel_factor that also keeps the panel's inverse 16x16 diagonal blocks (INVD_STRIDE doubles per
-// 128-block) in d_invstore (may be NULL) -- what later solves against the factor need
+// Factor a PACKED column panel (w columns over m rows, element [0] = (row g0, column g0) of the matrix); keeps the panel's
+// inverse 16x16 diagonal blocks (INVD_STRIDE doubles per 128-block) in d_invstore (may be NULL) -- what later solves against
+// the factor need -- and adds the logdet contribution of the factored columns to *d_logdet.
+// df != 0: one launch of the dataflow kernel on the panel (the hybrid schedule, round 6), with the optional extension px: only
+// the first px->n_fact columns are factored (the others updated with them), external source panels applied first.
+// d_nz / nz_words: the factor's tile pattern (structural zeros), read at the panel's offset g0 / 128; NULL: dense.
 int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_logdet, int* d_info,
-                     double* d_invstore, hipStream_t s);
-// structural zeros inside a PACKED panel's own factorisation (round 5): while set (per host thread), the inner K = 128 updates
-// and the panel solves of drv_panel_factor on a panel whose element [0] is (row, column) = (128 tile0, 128 tile0) of the matrix
-// skip the tiles the pattern says are zero; base = nullptr clears the record
-void drv_set_structure(const double* base, long ld, const sgp::sz_word* d_nz, int words, long tile0);
+                     double* d_invstore, hipStream_t s, int df = 0, const sgp::sz_word* d_nz = nullptr, int nz_words = 0,
+                     const sgp::DfPanel* px = nullptr);
 // R <- R L^-T for nrows (multiple of 128) rows against an n x n lower factor with its kept inverse blocks
 int drv_row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl, const double* d_invall,
                  long n, hipStream_t s);

@@ -430,7 +430,15 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_seg_kernel(SegBatch b) {
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   // destination of this workgroup: ids are dealt destination after destination (id0 ascending, multiples of 8 so that
   // id % 8 -- the XCD -- keeps its meaning inside every destination)
-  const unsigned id = blockIdx.x;
+  unsigned id = blockIdx.x;
+  if (b.cmap) {
+    // structured launches (round 6): the live tiles of every XCD compacted to the front of its id sequence
+    // (seg_compact_kernel) -- the dead ids leave at the END of the grid, and the live tiles keep the order, and with it the
+    // lock-step operand sharing, of the dense enumeration
+    const int x = (int)(id & 7), pos = (int)(id >> 3);
+    if (pos >= b.cmap[x]) return;
+    id = (unsigned)b.cmap[16 + (long)x * b.cstride + pos] * 8u + (unsigned)x;
+  }
   int d = 0;
   for (int q = 1; q < b.n_dst; ++q)
     if (id >= b.dst[q].id0) d = q;
@@ -560,6 +568,53 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_seg_kernel(SegBatch b) {
     for (int i = 0; i < 4; ++i) Cg[i * 16 + (long)(j * 4) * ldc] = -acc[j][i];
 }
 
+// One workgroup per XCD walks that XCD's ids of a segmented update in order and writes the live ones (some source has a k tile
+// with both operand tiles structurally non-zero) to the front: out[x] = live ids of XCD x, out[16 + x * per_xcd + pos] = the
+// pos-th live id / 8 (the single-GPU launches' tile_compact_kernel, for a list of destinations).
+__global__ __launch_bounds__(1024) void seg_compact_kernel(SegBatch b, int per_xcd, int* out) {
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int x = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) s_base = 0;
+  __syncthreads();
+  for (int k0 = 0; k0 < per_xcd; k0 += 1024) {
+    const int k = k0 + t;
+    bool live = false;
+    if (k < per_xcd) {
+      const unsigned id = (unsigned)k * 8u + (unsigned)x;
+      int d = 0;
+      for (int q = 1; q < b.n_dst; ++q)
+        if (id >= b.dst[q].id0) d = q;
+      const long c0 = b.dst[d].c0;
+      long tr, tc;
+      if (tile_of_id((long)(id - b.dst[d].id0), (b.m_tot - c0) / TILE, b.dst[d].w / TILE, 0L, tr, tc)) {
+        const sz_word* ra = b.nz + (c0 / TILE + tr) * b.nz_words;
+        const sz_word* rb = b.nz + (c0 / TILE + tc) * b.nz_words;
+        for (int q = b.dst[d].s_first; q < b.dst[d].s_first + b.dst[d].s_count && !live; ++q) {
+          const long kc = b.src[q].k0 >= 0 ? b.src[q].k0 : b.src[q].row0;
+          const int kt0 = (int)(kc / TILE), kt1 = (int)((kc + b.src[q].w + TILE - 1) / TILE);
+          for (int kk = kt0; kk < kt1 && !live; ++kk) live = (((ra[kk >> 6] & rb[kk >> 6]) >> (kk & 63)) & 1) != 0;
+        }
+      }
+    }
+    const unsigned long long bal = __ballot(live);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int q = 0; q < 16; ++q) {
+      if (q < w) woff += s_wave[q];
+      tot += s_wave[q];
+    }
+    const int base = s_base;
+    if (live) out[16 + (long)x * per_xcd + base + woff + pre] = k;
+    __syncthreads();
+    if (t == 0) s_base = base + tot;
+    __syncthreads();
+  }
+  if (t == 0) out[x] = s_base;
+}
+
 // dsts[i].id0 is filled in here.  Every width a multiple of 128, every c0 a multiple of 128 and >= the row0 of its
 // sources.  Returns the number of workgroups launched through *n_ids (may be NULL).
 int launch_gemm_nt_seg(SegBatch& b, hipStream_t s, long* n_ids) {
@@ -589,6 +644,16 @@ int launch_gemm_nt_seg(SegBatch& b, hipStream_t s, long* n_ids) {
     return -1;
   }
   if (n_ids) *n_ids = ids;
+  // big structured launches (the caller lends a scratch map that only launches of THIS stream use): compact the live ids first
+  const int* map = nullptr;
+  if (b.nz && b.map_scratch && ids >= b.map_min_ids && 16 + ids <= b.map_ints) {
+    b.cmap = nullptr;
+    hipLaunchKernelGGL(seg_compact_kernel, dim3(8), dim3(1024), 0, s, b, (int)(ids / 8), b.map_scratch);
+    SGP_HIP(hipGetLastError());
+    map = b.map_scratch;
+  }
+  b.cmap = map;
+  b.cstride = (int)(ids / 8);
   hipLaunchKernelGGL(gemm_nt_seg_kernel, dim3((unsigned)ids), dim3(512), 0, s, b);
   SGP_HIP(hipGetLastError());
   return 0;

@@ -165,6 +165,14 @@ struct sgp_multi {
   double tail_frac = 2.0 / 3.0;   // the first tail_frac of the columns get W
   int group = 1;            // panels per group (see the head of this file); 1 = every update at K = one panel
   long sub = 512;           // sub-panel width of the factorisation / transport / look-ahead pipeline (0: whole panels)
+  // Round 6 -- the hybrid schedule in the sharded sweep (SGP_MULTI_PANEL_DF, default 1; 0 = the launch-based chain of rounds 2 - 5):
+  // a sub-panel is factored by ONE launch of the dataflow kernel (chol_df.hip) that also updates the panel's remaining columns
+  // with it, and (SGP_MULTI_FUSE_LA, default 1) the look-ahead update with the LAST sub-panel of the previous panel rides in the
+  // first of those launches as an external source: the diagonal chain starts as soon as the first tile column has seen it.
+  // Off together with the primary context's hybrid switch (SGP_HYBRID=0; the dataflow time-out fallback reruns that way).
+  int panel_df = 1, fuse_la = 1;
+  int compact = 1;          // SGP_MULTI_COMPACT: compacted live-tile ids in the far update launches of a structured model (2: at any size)
+  sgp_ctx* primary = nullptr;
   // One enqueue thread per rank for the sweep of the sharded factorisation (SGP_MULTI_THREADS: 1 / 0; -1 = automatic: on
   // with more than one rank).  Every thread walks the SAME schedule and issues only the HIP calls of its own rank's
   // streams; an event recorded by one thread and waited for by another is ordered through a per-event sequence number
@@ -390,6 +398,7 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   sgp_multi* m = new sgp_multi();
   primary->multi = m;
   primary->multi_nranks = ndev;
+  m->primary = primary;
   auto fail = [&](int rc) {
     sgp_ctx_destroy(primary);   // destroys m as well
     return rc;
@@ -439,6 +448,9 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   }
   const char* sp = getenv("SGP_MULTI_SUBPANEL");
   if (sp) m->sub = atol(sp) / TILE * TILE;
+  if (const char* v = getenv("SGP_MULTI_PANEL_DF")) m->panel_df = atoi(v);
+  if (const char* v = getenv("SGP_MULTI_FUSE_LA")) m->fuse_la = atoi(v);
+  if (const char* v = getenv("SGP_MULTI_COMPACT")) m->compact = atoi(v);
   m->r.resize(ndev);
   for (int i = 0; i < ndev; ++i) {
     Rank& k = m->r[i];
@@ -844,8 +856,10 @@ int wait_panel(Exec& x, const Fact& F, long J, int i, hipStream_t s) {
 // One launch: every panel of `dsts` (owned by rank i) -= its rows of the factored panels J_first .. J_last times their
 // rows of the panel's diagonal block, in that order (gemm_nt.hip: gemm_nt_seg_kernel).  Returns the flops through *fl.
 // sub_c >= 0: ONE source, the sub_w columns from sub_c on of panel J_first (== J_last).
+// compact: a big structured launch on the rank's UPDATE stream may compact its live tile ids first (the child context's map
+// scratch; launches of one stream are ordered, so one map is enough -- the near / look-ahead launches are small and keep theirs)
 int update_panels(sgp_multi* m, const Fact& F, long J_first, long J_last, const std::vector<long>& dsts, int i,
-                  hipStream_t s, double* fl, long sub_c = -1, long sub_w = 0) {
+                  hipStream_t s, double* fl, long sub_c = -1, long sub_w = 0, bool compact = false) {
   const Geometry& g = F.g;
   if (dsts.empty() || J_last < J_first) return 0;
   if (J_last - J_first + 1 > SEG_MAX_SRC) {
@@ -856,6 +870,11 @@ int update_panels(sgp_multi* m, const Fact& F, long J_first, long J_last, const 
   b.m_tot = g.m_tot;
   b.nz = m->sz_words > 0 ? m->r[i].d_sz : nullptr;
   b.nz_words = m->sz_words;
+  if (compact && b.nz && m->compact && m->r[i].ctx->d_szmap) {
+    b.map_scratch = m->r[i].ctx->d_szmap;
+    b.map_ints = m->r[i].ctx->n_szmap;
+    if (m->compact >= 2) b.map_min_ids = 8;   // (tests: every structured far launch)
+  }
   long ksum = 0;
   for (int q = 0; q < SEG_MAX_SRC; ++q) b.src[q] = SegSrc{nullptr, 0, 0, 0};
   for (long J = J_first; J <= J_last; ++J) {
@@ -1006,6 +1025,9 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   };
   const long G = m->group;
   auto group_of = [&](long J) { return J / G; };
+  // the panel kernel (see sgp_multi::panel_df): with the primary context's hybrid switch, which the time-out fallback clears
+  const bool df_panels = m->panel_df != 0 && m->primary && m->primary->hybrid != 0 && m->r[0].ctx->refine == 1;
+  const bool fuse_la = df_panels && m->fuse_la != 0;
   // ---- the schedule from the first panel's factorisation to the last row sums, as ONE function of who executes it
   auto run = [&](Exec& x) -> int {
     auto factor = [&](long J) -> int {
@@ -1017,15 +1039,39 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
       for (int q = 0; q < ns; ++q) {
         long c, wq;
         sub_range(J, q, c, wq);
+        double* d_logdet = k.d_small + L.pan + (size_t)J * L.per();
+        double* invq = F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr;
+        const sz_word* nzp = m->sz_words > 0 ? k.d_sz : nullptr;   // structural zeros inside the panel's own factorisation
+        if (df_panels) {
+          // ONE launch: [the look-ahead update with the previous panel's last sub-panel -- an external source, q == 0 only]
+          // + factorisation of sub-panel q + update of the panel's remaining columns with it (update-only tile columns)
+          if (x.mine(o)) {
+            M_RC(x.dev(o));   // (broadcast_panel leaves another rank's device current in the one-thread mode)
+            DfPanel px;
+            px.n_fact = wq;
+            px.n_ext = 0;
+            if (q == 0 && fuse_la && J > 0) {
+              long cl, wl;
+              sub_range(J - 1, n_sub(J - 1) - 1, cl, wl);
+              const long ldq = g.ldp(J - 1), Jm = g.col0(J - 1);
+              px.ext[0] = DfExt{panel_on(m, F, J - 1, o) + (J0 - Jm) + (size_t)cl * ldq, ldq, (int)((Jm + cl) / TILE), (int)(wl / TILE)};
+              px.n_ext = 1;
+              k.upd_flops += update_flops(g.m_tot - J0, w, wl);
+            }
+            M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, w - c, J0 + c, d_logdet, k.d_info, invq, k.s_panel, 1, nzp,
+                                  m->sz_words, &px));
+          }
+          M_RC(x.rec(o, k.ev_sub[q], k.s_panel));
+          if (q == ns - 1) M_RC(x.rec(o, k.ev_fact, k.s_panel));
+          if (!prof) M_RC(broadcast_panel(x, F, J, q, c, wq, q == ns - 1));
+          continue;
+        }
         if (x.mine(o)) {
-          M_RC(x.dev(o));   // (broadcast_panel leaves another rank's device current in the one-thread mode)
-          // structural zeros inside the panel's own factorisation (round 5): for the columns of an independent block a third of
-          // the rows below are exact zeros -- the inner K = 128 updates and the panel solves skip those tiles
-          if (m->sz_words > 0) drv_set_structure(Pj, ldp, k.d_sz, m->sz_words, J0 / TILE);
-          const int rcf = drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, k.d_small + L.pan + (size_t)J * L.per(),
-                                           k.d_info, F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr, k.s_panel);
-          if (m->sz_words > 0) drv_set_structure(nullptr, 0, nullptr, 0, 0);
-          M_RC(rcf);
+          M_RC(x.dev(o));
+          // (structural zeros, round 5: for the columns of an independent block a third of the rows below are exact zeros --
+          // the inner K = 128 updates and the panel solves skip those tiles)
+          M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, wq, J0 + c, d_logdet, k.d_info, invq, k.s_panel, 0, nzp,
+                                m->sz_words, nullptr));
         }
         M_RC(x.rec(o, k.ev_sub[q], k.s_panel));
         if (q == ns - 1) M_RC(x.rec(o, k.ev_fact, k.s_panel));
@@ -1117,6 +1163,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
               M_RC(x.wait(o1, k.s_panel, k.ev_sub[q]));   // (one rank: its own panel)
             else
               M_RC(x.wait(o1, k.s_panel, k.ev_recv_sub[bj][q]));
+            if (fuse_la && q == ns - 1) break;   // the last piece rides in nxt's first panel launch (factor: external source)
             if (x.mine(o1)) {
               M_RC(x.dev(o1));
               M_RC(update_panels(m, F, J, J, la, o1, k.s_panel, &k.upd_flops, c, wq));
@@ -1194,7 +1241,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         if (group_ends) {
           if (!far.empty() && x.mine(i)) {
             M_RC(x.dev(i));
-            M_RC(update_panels(m, F, gj * G, J, far, i, k.s_upd, &k.upd_flops));
+            M_RC(update_panels(m, F, gj * G, J, far, i, k.s_upd, &k.upd_flops, -1, 0, true));
           }
           M_RC(x.rec(i, k.ev_far[gj % Rank::NGEV], k.s_upd));
         }
@@ -1298,6 +1345,13 @@ int collect_info(sgp_multi* m) {
     int inf = 0;
     M_HIP(hipSetDevice(k.dev));
     M_HIP(hipMemcpy(&inf, k.d_info, sizeof(int), hipMemcpyDeviceToHost));
+    if (inf == SGP_DF_TIMEOUT) {
+      // a panel launch of the dataflow kernel ran into its wait bound (a preempted queue, a profiler serialising kernels): the
+      // entry point reruns the operator with the launch-based panel chain (capi.hip: with_df_fallback clears `hybrid`)
+      if (m->primary) m->primary->df_timed_out = true;
+      set_error("multi: a panel launch of the dataflow kernel ran into its wait bound (SGP_DF_TIMEOUT_S)");
+      return -3;
+    }
     if (inf > 0 && (info == 0 || inf < info)) info = inf;
   }
   if (info > 0)

@@ -613,3 +613,93 @@ def test_balanced_table_is_what_a_structured_model_gets_by_default(monkeypatch):
             assert _stats(ctx, 4)[9 + 4 * 4] == 0                   # one block: nothing to balance against
         ctx.close()
     assert mode["cyclic"] == 0 and mode["balanced"] == 1 and mode[None] == 1
+
+
+# ---- round 6: the hybrid schedule in the sharded sweep ------------------------------------------------------------------
+@pytest.mark.parametrize("nranks", [1, 2, 3, 8])
+def test_dataflow_panel_launches_give_the_launch_based_chains_bits(monkeypatch, nranks):
+    """Round 6: a sub-panel of the sharded factorisation is factored by ONE launch of the dataflow kernel that also updates the
+    panel's remaining columns (update-only tile columns), and the look-ahead update with the previous panel's last sub-panel
+    rides in the first of those launches as an external source (multi.hip: factor; chol_df.hip: DfExt / T_f).  Same bits as
+    the launch-based chain of rounds 2 - 5 (SGP_MULTI_PANEL_DF=0) and as the unfused form (SGP_MULTI_FUSE_LA=0): logpdf with
+    vector and matrix right-hand sides, kept-factor posterior, draws -- whole panels, sub-panels, panel groups, mixed widths,
+    structural zeros on and off, one enqueue thread and one per rank."""
+    F, x, xs, y = _problem(3100, D=3)
+    ref = orm.gppp_sum_logpdf(xs, y, 0.1)
+    rng = np.random.default_rng(7)
+    Y = np.asfortranarray(rng.standard_normal((3100, 3)))
+    xs_new = P.BlockData([P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((3, 40)))))])
+    Z = np.asfortranarray(rng.standard_normal((3100, 2)))
+
+    def run():
+        fx = F(x, 0.1)
+        post = P.posterior(fx, y)
+        mm, vv = post.mean_and_var(xs_new)
+        return dict(lp=np.array([P.logpdf(fx, y)]), lpm=np.asarray(P.logpdf(fx, Y)), m=np.asarray(mm), v=np.asarray(vv),
+                    r=np.asarray(P.rand(None, fx, 2, Z=Z)))
+
+    keys = ("SGP_MULTI_PANEL", "SGP_MULTI_SUBPANEL", "SGP_MULTI_GROUP", "SGP_MULTI_PANEL_TAIL", "SGP_STRUCT_ZEROS", "SGP_MULTI_THREADS")
+    for env in ({"SGP_MULTI_PANEL": "128"},
+                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "128"},
+                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "256", "SGP_STRUCT_ZEROS": "0"},
+                {"SGP_MULTI_PANEL": "1024", "SGP_MULTI_SUBPANEL": "0", "SGP_MULTI_THREADS": "0"},
+                {"SGP_MULTI_PANEL": "256", "SGP_MULTI_SUBPANEL": "128", "SGP_MULTI_GROUP": "2"},
+                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PANEL_TAIL": "256", "SGP_MULTI_SUBPANEL": "128"}):
+        outs = []
+        for df, fuse in (("0", "1"), ("1", "0"), ("1", "1")):
+            for k in keys:
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            monkeypatch.setenv("SGP_MULTI_PANEL_DF", df)
+            monkeypatch.setenv("SGP_MULTI_FUSE_LA", fuse)
+            monkeypatch.setenv("SGP_MULTI_OWNERS", "cyclic")
+            ctx = P.lib.Context(devices=[0] * nranks)
+            outs.append(_with_ctx(ctx, run))
+            outs.append(_with_ctx(ctx, run))   # (repeated call: the rings and stores are reused)
+            ctx.close()
+        for o in outs[1:]:
+            for k in outs[0]:
+                assert np.array_equal(outs[0][k], o[k]), (env, k)
+        assert abs(outs[0]["lp"][0] - ref) <= 1e-10 * abs(ref)
+
+
+def test_dataflow_panel_launch_reports_the_failing_minor(monkeypatch):
+    """PosDef information from a panel launch of the dataflow kernel carries the GLOBAL column (gcol_base of the packed
+    sub-panel), whichever rank's launch meets the bad pivot."""
+    monkeypatch.setenv("SGP_MULTI_PANEL", "256")
+    monkeypatch.setenv("SGP_MULTI_SUBPANEL", "128")
+    F, x, xs, y = _problem(1500)
+    infos = []
+    for df in ("0", "1"):
+        monkeypatch.setenv("SGP_MULTI_PANEL_DF", df)
+        ctx = P.lib.Context(devices=[0, 0, 0])
+        with pytest.raises(P.PosDefException) as e:
+            _with_ctx(ctx, lambda: P.logpdf(F(x, -5.0), y))
+        infos.append(e.value.info)
+        ctx.close()
+    assert infos[0] == infos[1] and infos[0] >= 1
+
+
+@pytest.mark.parametrize("nranks", [2, 5])
+def test_compacted_live_tile_ids_in_the_far_updates_keep_the_bits(monkeypatch, nranks):
+    """Round 6: the far update launches of a structured model compact their live tile ids per XCD first (gemm_nt.hip:
+    seg_compact_kernel -- the single-GPU launches' compaction for a list of destination panels).  Same bits with the map on
+    (forced at every size), off, and against the dense schedule; the work counter is unchanged."""
+    F, x, xs, y = _problem(4200, D=3)
+    ref = orm.gppp_sum_logpdf(xs, y, 0.1)
+    vals = []
+    for env in ({"SGP_MULTI_COMPACT": "2"}, {"SGP_MULTI_COMPACT": "0"}, {"SGP_MULTI_COMPACT": "2", "SGP_STRUCT_ZEROS": "0"},
+                {"SGP_MULTI_COMPACT": "2", "SGP_MULTI_GROUP": "2", "SGP_MULTI_PANEL": "256"}):
+        for k in ("SGP_MULTI_COMPACT", "SGP_STRUCT_ZEROS", "SGP_MULTI_GROUP", "SGP_MULTI_PANEL"):
+            monkeypatch.delenv(k, raising=False)
+        monkeypatch.setenv("SGP_MULTI_PANEL", "128")
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = P.lib.Context(devices=[0] * nranks)
+        vals.append(_with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y)))
+        vals.append(_with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y)))
+        ctx.close()
+    assert all(v == vals[0] for v in vals[:6]), vals          # one panel layout: bit for bit
+    assert abs(vals[6] - vals[0]) <= 1e-12 * abs(vals[0])      # another layout: to rounding
+    assert abs(vals[0] - ref) <= 1e-10 * abs(ref)

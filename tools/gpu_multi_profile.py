@@ -63,6 +63,11 @@ for b in prof[:, 2]:                       # panel bytes = 8 * (m_tot - col0) * 
 nsub = [min(8, -(-w // sub)) if sub >= 128 else 1 for w in widths]
 json.dump({"config": cfg, "N": N, "ranks": P, "panel_width": int(st[4]), "panels": int(st[5]), "group": int(st[7]),
            "subpanel": sub, "widths": widths, "nsub": nsub, "owners": owners,
+           # round 6: panels factored by launches of the dataflow kernel; the look-ahead update with the previous panel's LAST
+           # sub-panel rides in the first of them (then factor_ms holds it and lookahead_update_ms only the earlier pieces)
+           "panel_df": int(os.environ.get("SGP_MULTI_PANEL_DF", "1")) if os.environ.get("SGP_HYBRID", "") != "0" else 0,
+           "fuse_la": int(os.environ.get("SGP_MULTI_FUSE_LA", "1")) if (os.environ.get("SGP_HYBRID", "") != "0" and
+                                                                       int(os.environ.get("SGP_MULTI_PANEL_DF", "1"))) else 0,
            "ownership": {0: "cyclic", 1: "balanced", 2: "list"}.get(int(st[9 + 4 * P]), "?"),
            "layout": "per panel: factor_ms, lookahead_update_ms, panel_bytes, then per rank near_a_ms, near_b_ms, far_ms",
            "logpdf": float(res[0]), "parity_rel": None if g is None else abs(res[0] - g["logpdf"]) / abs(g["logpdf"]),

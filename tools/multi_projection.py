@@ -21,6 +21,10 @@ Dependencies as csrc/multi.hip enqueues them (G = panels per group, g = J // G):
 
 transport(bytes): scatter + all-gather over point-to-point xGMI links of `link` GB/s per direction: 2 * bytes / ((P - 1) *
 link); direct copy: bytes / link.
+Round 6 (profile field fuse_la): the look-ahead update with the LAST sub-panel of J rides in the first panel launch of J+1, so
+it is part of fac[J+1] (priced as equal pieces -- the first launch is in fact the heaviest, so the first sub-panel leaves a
+little later and the last a little earlier than modelled; the end of the factorisation, which is what the chain waits for, is
+exact).
 usage: python tools/multi_projection.py profile.json [link_GBps=77] [contend=1.0]"""
 import json
 import sys
@@ -77,6 +81,7 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
         return end
 
     nsub = prof.get("nsub") or [1] * npan
+    fused_la = bool(prof.get("fuse_la"))
 
     def factor_and_send(J, start_ready, scale):
         """factor panel J on its owner from `start_ready` on; returns (end of the factorisation, arrival time of every
@@ -103,9 +108,18 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
             loaded = t_upd[o] > recv[o] or t_near[o] > recv[o]
             c = contend if loaded else 1.0
             t = ready
-            for q in range(nsub[J]):       # the look-ahead update follows the sub-panels of J as they land
+            nq = nsub[J]
+            for q in range(nq):       # the look-ahead update follows the sub-panels of J as they land
                 landed = arr[q] if o != owner(J) else fact_done
-                t = run(o, "panel", max(t, landed), la[nxt] * c / nsub[J])
+                if fused_la:
+                    # round 6: the LAST piece rides in nxt's first panel launch (its cost is part of fac[nxt]); la[nxt] is the
+                    # sum of the nq - 1 earlier pieces
+                    if q == nq - 1:
+                        t = max(t, landed)
+                    else:
+                        t = run(o, "panel", max(t, landed), la[nxt] * c / (nq - 1))
+                else:
+                    t = run(o, "panel", max(t, landed), la[nxt] * c / nq)
             fd, new_arr = factor_and_send(nxt, t, c)
             new_recv = [fd if i == o else new_arr[-1] for i in range(P)]
         for i in range(P):
