@@ -38,6 +38,17 @@ int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only
  * its wait bound (SGP_DF_TIMEOUT_S; capi.hip: with_df_fallback) */
 int sgp_bench_df_fallbacks(sgp_ctx* ctx, int64_t* out);
 
+/* Multi-GPU context, failure path (tests/test_gpu_multi_faults.py; csrc/multi.hip: sgp_multi::fault_rank).  TEST-ONLY fault
+ * hook: the next sharded factorisation fails mid-schedule -- at panel `step`, on the enqueue thread of `rank` (rank < 0
+ * disarms) -- exactly as a failing HIP / RCCL call on that thread would; the hook disarms itself when it fires.  Also
+ * SGP_MULTI_FAULT=rank:step at context creation. */
+int sgp_bench_multi_fault(sgp_ctx* ctx, int rank, int64_t step);
+/* ... or makes that thread SLEEP `seconds` there without failing: the other ranks' threads then wait for its event records and
+ * must give up at their wall-clock bound (SGP_MULTI_SPIN_TIMEOUT_S) instead of spinning for ever */
+int sgp_bench_multi_stall(sgp_ctx* ctx, int rank, int64_t step, double seconds);
+/* *out = 1 once a failed call has left the context's RCCL communicators aborted (it then refuses sharded calls) */
+int sgp_bench_multi_broken(sgp_ctx* ctx, int* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -59,6 +59,7 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <memory>
 #include <thread>
 #include <unordered_map>
 
@@ -181,6 +182,18 @@ struct sgp_multi {
   std::unordered_map<hipEvent_t, std::atomic<long>> seq;
   std::atomic<int> abort_flag{0};
   bool broken = false;      // an enqueue thread failed under the RCCL transport: the communicators are gone
+  // Round 6 -- so that the first run on a real node can neither hang nor lie:
+  //  * every cross-thread host spin (Exec::wait) is bounded by wall-clock time (SGP_MULTI_SPIN_TIMEOUT_S, default 30 s): past it
+  //    the waiter raises the abort flag and the call fails with rc < 0 and a text naming the rank it waited for;
+  //  * ncclCommInitAll runs under a bound of its own (SGP_MULTI_INIT_TIMEOUT_S, default 180 s);
+  //  * a TEST-ONLY fault hook (SGP_MULTI_FAULT=rank:step, sgp_bench_multi_fault): the enqueue thread of `rank` (the one thread
+  //    when the sweep is not threaded) fails at panel `step` of the next sharded factorisation, mid-schedule, after which the
+  //    hook disarms itself.
+  double spin_timeout_s = 30.0, init_timeout_s = 180.0;
+  int fault_rank = -1;
+  long fault_step = -1;
+  double fault_stall_s = 0.0;   // > 0: the thread does not fail but SLEEPS that long at the step (sgp_bench_multi_stall): what
+                                // the other threads' spin bound is for
   int ring = 10;            // receive buffers per rank: 2 * group + 2
   // panel ownership (own_table.h; make_geometry): balanced from the model's tile pattern unless SGP_MULTI_OWNERS says
   // "cyclic" or gives an explicit list; own_mode = what the last geometry used (0 cyclic, 1 balanced table, 2 list)
@@ -451,6 +464,13 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   if (const char* v = getenv("SGP_MULTI_PANEL_DF")) m->panel_df = atoi(v);
   if (const char* v = getenv("SGP_MULTI_FUSE_LA")) m->fuse_la = atoi(v);
   if (const char* v = getenv("SGP_MULTI_COMPACT")) m->compact = atoi(v);
+  if (const char* v = getenv("SGP_MULTI_SPIN_TIMEOUT_S")) m->spin_timeout_s = std::max(0.01, atof(v));
+  if (const char* v = getenv("SGP_MULTI_INIT_TIMEOUT_S")) m->init_timeout_s = std::max(1.0, atof(v));
+  if (const char* v = getenv("SGP_MULTI_FAULT")) {   // rank:step (tests)
+    const char* c = strchr(v, ':');
+    m->fault_rank = atoi(v);
+    m->fault_step = c ? atol(c + 1) : 0;
+  }
   m->r.resize(ndev);
   for (int i = 0; i < ndev; ++i) {
     Rank& k = m->r[i];
@@ -521,8 +541,32 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     }
   }
   if (m->transport == TR_RCCL) {
-    std::vector<ncclComm_p> comms(ndev, nullptr);
-    int rc = m->rccl.CommInitAll(comms.data(), ndev, devices);
+    // ncclCommInitAll on its own thread, bounded: a node whose fabric / driver state is bad has been seen to sit in the
+    // bootstrap for ever.  On a time-out the thread is left behind (it owns its copies of everything it touches).
+    struct InitJob {
+      std::vector<ncclComm_p> comms;
+      std::vector<int> devs;
+      std::atomic<int> done{0};
+      int rc = 0;
+    };
+    auto job = std::make_shared<InitJob>();
+    job->comms.assign(ndev, nullptr);
+    job->devs.assign(devices, devices + ndev);
+    auto init_fn = m->rccl.CommInitAll;
+    std::thread([job, init_fn, ndev]() {
+      job->rc = init_fn(job->comms.data(), ndev, job->devs.data());
+      job->done.store(1, std::memory_order_release);
+    }).detach();
+    const double t0 = now_ms();
+    while (!job->done.load(std::memory_order_acquire) && now_ms() - t0 < 1e3 * m->init_timeout_s)
+      std::this_thread::sleep_for(std::chrono::milliseconds(2));
+    if (!job->done.load(std::memory_order_acquire)) {
+      set_error("sgp_ctx_create_multi: ncclCommInitAll did not return within " + std::to_string((long)m->init_timeout_s) +
+                " s (SGP_MULTI_INIT_TIMEOUT_S); SGP_MULTI_TRANSPORT=p2p runs the panel copies without RCCL");
+      return fail(-4);
+    }
+    std::vector<ncclComm_p> comms = job->comms;
+    int rc = job->rc;
     if (rc != 0) {
       set_error(std::string("ncclCommInitAll failed: ") +
                 (m->rccl.GetErrorString ? m->rccl.GetErrorString(rc) : "?"));
@@ -606,6 +650,28 @@ extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64
   return 0;
 }
 
+// test-only fault hook (sthenomi_bench.h): the next sharded factorisation fails at panel `step` on rank `rank`'s enqueue thread
+extern "C" int sgp_bench_multi_fault(sgp_ctx* ctx, int rank, int64_t step) {
+  M_CHECK_ARG(ctx && ctx->multi, "sgp_bench_multi_fault: not a multi-GPU context");
+  ctx->multi->fault_rank = rank;
+  ctx->multi->fault_step = rank >= 0 ? (long)std::max<int64_t>(0, step) : -1;
+  return 0;
+}
+// ... or stalls there for `seconds` without failing (the other threads then run into their spin bound)
+extern "C" int sgp_bench_multi_stall(sgp_ctx* ctx, int rank, int64_t step, double seconds) {
+  M_CHECK_ARG(ctx && ctx->multi && seconds > 0.0, "sgp_bench_multi_stall: bad argument");
+  ctx->multi->fault_rank = rank;
+  ctx->multi->fault_step = (long)std::max<int64_t>(0, step);
+  ctx->multi->fault_stall_s = seconds;
+  return 0;
+}
+// 1 after a failed call left the RCCL communicators aborted (the context then refuses sharded calls), else 0
+extern "C" int sgp_bench_multi_broken(sgp_ctx* ctx, int* out) {
+  M_CHECK_ARG(ctx && ctx->multi && out, "sgp_bench_multi_broken: not a multi-GPU context");
+  *out = ctx->multi->broken ? 1 : 0;
+  return 0;
+}
+
 extern "C" int sgp_ctx_multi_owners(sgp_ctx* ctx, int32_t* out, int64_t cap, int64_t* n_out) {
   M_CHECK_ARG(ctx && ctx->multi && n_out, "sgp_ctx_multi_owners: not a multi-GPU context");
   const auto& v = ctx->multi->last_own;
@@ -675,9 +741,18 @@ struct Exec {
       const long c = it == cnt.end() ? 0 : it->second;
       if (c == 0) return 0;   // never recorded in this call: whatever it guarded was drained with the previous call
       std::atomic<long>& q = m->seq.at(e);
-      while (q.load(std::memory_order_acquire) < c) {
+      const double t0 = now_ms();
+      for (unsigned spins = 0; q.load(std::memory_order_acquire) < c; ++spins) {
         if (m->abort_flag.load(std::memory_order_relaxed)) {
           set_error("multi: another rank's enqueue thread failed");
+          return -5;
+        }
+        if ((spins & 1023) == 1023 && now_ms() - t0 > 1e3 * m->spin_timeout_s) {
+          // the producer never issued the record this wait refers to (a stuck HIP call on its thread, a diverged schedule):
+          // stop everybody instead of spinning for ever
+          m->abort_flag.store(1);
+          set_error("multi: rank " + std::to_string(i) + "'s enqueue thread waited more than " +
+                    std::to_string((long)m->spin_timeout_s) + " s for an event record of another rank (SGP_MULTI_SPIN_TIMEOUT_S)");
           return -5;
         }
         std::this_thread::yield();
@@ -1028,6 +1103,12 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   // the panel kernel (see sgp_multi::panel_df): with the primary context's hybrid switch, which the time-out fallback clears
   const bool df_panels = m->panel_df != 0 && m->primary && m->primary->hybrid != 0 && m->r[0].ctx->refine == 1;
   const bool fuse_la = df_panels && m->fuse_la != 0;
+  const int fault_rank = std::min<int>(m->fault_rank, P - 1);   // the hook fires once: disarmed before the sweep starts
+  const long fault_step = m->fault_rank >= 0 ? std::min<long>(m->fault_step, g.npan - 1) : -1;
+  const double fault_stall_s = m->fault_stall_s;
+  m->fault_rank = -1;
+  m->fault_step = -1;
+  m->fault_stall_s = 0.0;
   // ---- the schedule from the first panel's factorisation to the last row sums, as ONE function of who executes it
   auto run = [&](Exec& x) -> int {
     auto factor = [&](long J) -> int {
@@ -1134,6 +1215,14 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     for (long J = 0; J < g.npan; ++J) {
       const long nxt = J + 1, gj = group_of(J);
       const bool group_ends = (J % G == G - 1) || J == g.npan - 1;
+      if (J == fault_step && (x.me == fault_rank || x.me < 0)) {   // test-only (sgp_multi::fault_rank)
+        if (fault_stall_s > 0.0) {
+          std::this_thread::sleep_for(std::chrono::milliseconds((long)(1e3 * fault_stall_s)));
+        } else {
+          set_error("multi: injected fault at panel " + std::to_string(J) + " (SGP_MULTI_FAULT / sgp_bench_multi_fault)");
+          return -6;
+        }
+      }
       if (nxt < g.npan) {             // (a) look-ahead on the owner of the next panel
         const int o1 = g.owner(nxt);
         Rank& k = m->r[o1];
@@ -1269,9 +1358,32 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
     }
     return 0;
   };
-  const bool threaded = !prof && P > 1 && (m->threads == 1 || (m->threads < 0));
+  // A failed sweep: part of the schedule is enqueued, part is not.  Peer-copy / loopback work only waits for events that were
+  // recorded (a wait is enqueued after its record has been issued), so it drains; RCCL broadcasts whose partners never
+  // enqueued their side cannot complete -- the communicators are aborted (ncclCommAbort) and the context refuses further
+  // sharded calls (`broken`; advisor, round 4).  Under the one-thread enqueue a grouped broadcast is issued for all ranks or
+  // for none, so the communicators survive.
+  auto failed = [&](int rc, const std::string& text, bool comm_partial) -> int {
+    if (m->transport == TR_RCCL && comm_partial) {
+      for (auto& k : m->r) {
+        if (k.comm && m->rccl.CommAbort) m->rccl.CommAbort(k.comm);
+        k.comm = nullptr;
+      }
+      m->broken = true;
+    } else {
+      for (auto& k : m->r) {
+        hipSetDevice(k.dev);
+        hipDeviceSynchronize();
+      }
+      (void)hipGetLastError();
+    }
+    set_error(text + (m->broken ? " (the context's RCCL communicators were aborted: create a new context)" : ""));
+    return rc;
+  };
+  const bool threaded = !prof && ((P > 1 && m->threads < 0) || m->threads == 1);   // (threads == 1 with ONE rank: tests of the failure path)
   if (!threaded) {
-    M_RC(run(x0));
+    const int rc = run(x0);
+    if (rc) return failed(rc, sgp_last_error(), false);
   } else {
     // one enqueue thread per rank (see Exec): the sequence numbers start from what the prologue recorded
     for (auto& kv : m->seq) kv.second.store(0, std::memory_order_relaxed);
@@ -1292,29 +1404,11 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         rcs[i] = rc;
       });
     for (auto& t : th) t.join();
-    for (int i = 0; i < P; ++i) {
-      if (rcs[i]) {
-        // One rank's enqueue thread failed and the others stopped where they were: part of the schedule is enqueued, part is
-        // not.  Peer-copy / loopback work only waits for events that were recorded (a wait is enqueued after its record has
-        // been issued), so it drains; RCCL broadcasts whose partners never enqueued their side cannot complete -- the
-        // communicators are aborted (ncclCommAbort) and the context refuses further sharded calls (advisor, round 4).
-        if (m->transport == TR_RCCL) {
-          for (auto& k : m->r) {
-            if (k.comm && m->rccl.CommAbort) m->rccl.CommAbort(k.comm);
-            k.comm = nullptr;
-          }
-          m->broken = true;
-        } else {
-          for (auto& k : m->r) {
-            hipSetDevice(k.dev);
-            hipDeviceSynchronize();
-          }
-          (void)hipGetLastError();
-        }
-        set_error(errs[i] + (m->broken ? " (the context's RCCL communicators were aborted: create a new context)" : ""));
-        return rcs[i];
-      }
-    }
+    // report the root cause: a thread that stopped because ANOTHER one failed (-5) only says so
+    int bad = -1;
+    for (int i = 0; i < P; ++i)
+      if (rcs[i] && (bad < 0 || (rcs[bad] == -5 && rcs[i] != -5))) bad = i;
+    if (bad >= 0) return failed(rcs[bad], errs[bad], true);
   }
   m->last_enqueue_ms = now_ms() - t_begin;
   // completion of the factorisation proper (statistics; the reductions follow in the caller)

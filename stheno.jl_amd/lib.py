@@ -146,6 +146,9 @@ _SIGS = {
                                        C.c_int, _D, _D, _P, C.c_int64]),
     "sgp_dev_elbo_finish": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _D]),
     "sgp_bench_df_fallbacks": (C.c_int, [_P, C.POINTER(C.c_int64)]),
+    "sgp_bench_multi_fault": (C.c_int, [_P, C.c_int, C.c_int64]),
+    "sgp_bench_multi_broken": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "sgp_bench_multi_stall": (C.c_int, [_P, C.c_int, C.c_int64, C.c_double]),
     "sgp_bench_mfma_f64": (C.c_int, [_P, C.c_int, _D, _D]),
     "sgp_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D]),
     "sgp_bench_potrf": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_longlong)]),

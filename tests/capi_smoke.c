@@ -22,7 +22,7 @@ static const struct { const char* name; size_t fnptr_size; } table[] = {
   E(sgp_kernelmatrix_diag_grad_x), E(sgp_sparse_posterior_create), E(sgp_sparse_posterior_predict),
   E(sgp_sparse_posterior_destroy), E(sgp_dspec_create), E(sgp_dspec_destroy), E(sgp_geometry),
   E(sgp_dev_logpdf), E(sgp_dev_assemble_cols), E(sgp_dev_panel_factor), E(sgp_dev_panel_update), E(sgp_dev_panel_update_batch),
-  E(sgp_dev_rowsumsq), E(sgp_dev_assemble_cross_rows), E(sgp_dev_rows_dot), E(sgp_dev_rows_gram), E(sgp_elbo_part_len), E(sgp_dev_elbo_partial), E(sgp_dev_elbo_finish), E(sgp_bench_df_fallbacks), E(sgp_bench_mfma_f64), E(sgp_bench_hbm), E(sgp_bench_potrf), E(sgp_bench_potrf_contended), E(sgp_bench_cumask), E(sgp_bench_gemm_stamps), E(sgp_bench_gemm),
+  E(sgp_dev_rowsumsq), E(sgp_dev_assemble_cross_rows), E(sgp_dev_rows_dot), E(sgp_dev_rows_gram), E(sgp_elbo_part_len), E(sgp_dev_elbo_partial), E(sgp_dev_elbo_finish), E(sgp_bench_df_fallbacks), E(sgp_bench_multi_fault), E(sgp_bench_multi_broken), E(sgp_bench_multi_stall), E(sgp_bench_mfma_f64), E(sgp_bench_hbm), E(sgp_bench_potrf), E(sgp_bench_potrf_contended), E(sgp_bench_cumask), E(sgp_bench_gemm_stamps), E(sgp_bench_gemm),
 #undef E
 };
 

@@ -64,11 +64,12 @@ def test_update_launch_model_covers_the_trailing_matrix(N, schedule):
         assert len(ls) == 2 * ((n_pad + 2047) // 2048 - 1) - (1 if (n_pad + 2047) // 2048 >= 2 else 0)
 
 
-def test_gpus_2_exits_nonzero_without_two_gpus():
+@pytest.mark.parametrize("gpus", ["2", "8"])
+def test_gpus_2_exits_nonzero_without_two_gpus(gpus):
     import torch
-    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
-        pytest.skip("this box has two GPUs")
-    r = _bench("--gpus", "2", "--config", "c1", "--steps", "1", "--warmup", "0", "--cpu-sample", "0")
+    if torch.cuda.is_available() and torch.cuda.device_count() >= int(gpus):
+        pytest.skip("this box has that many GPUs")
+    r = _bench("--gpus", gpus, "--config", "c1", "--steps", "1", "--warmup", "0", "--cpu-sample", "0")
     assert r.returncode != 0
     assert r.stdout.strip() == ""                     # no result line for a run that did not happen
     assert "GPU" in r.stderr or "HIP device" in r.stderr
@@ -103,9 +104,11 @@ def test_transport_probe_code_path_on_loopback_ranks():
 
 
 @pytest.mark.gpu
-def test_gpus_2_refuses_on_the_one_gpu_box():
+@pytest.mark.parametrize("gpus", ["2", "8"])
+def test_gpus_2_refuses_on_the_one_gpu_box(gpus):
+    """(round 6: and `--gpus 8`, the command the driver issues on a node, on the 1-GPU box: exit != 0, no JSON line)"""
     import torch
-    if torch.cuda.device_count() >= 2:
-        pytest.skip("this box has two GPUs")
-    r = _bench("--gpus", "2", "--config", "c1", "--steps", "1", "--warmup", "0", "--cpu-sample", "0")
+    if torch.cuda.device_count() >= int(gpus):
+        pytest.skip("this box has that many GPUs")
+    r = _bench("--gpus", gpus, "--config", "c1", "--steps", "1", "--warmup", "0", "--cpu-sample", "0")
     assert r.returncode != 0 and r.stdout.strip() == "" and "refusing" in r.stderr
