@@ -531,6 +531,42 @@ def main():
                        "no kernel shares the chip, HIP events around every update launch",
                 "launches": int(st[4]), "avg_launch_ms": st[3] / max(1, int(st[4])), "achieved": s_ach,
                 "frac": s_ach / PEAK_FP64_MFMA_TFLOPS, "ms_per_step": ser_ms, "same_bits": float(so[0]) == float(out[0])}
+        if hybrid and not args.no_extras:
+            # The round-4 schedule (SGP_HYBRID=0: serial-deep launches at 65536 columns, the whole-matrix dataflow kernel below)
+            # on the SAME box, same buffers, second context: separates schedule from box in the driver's record (round-5
+            # verdict: the driver's fresh boxes saw -1.2 % where the same-box A/B said -4.5 %).  Same bits.
+            prev_env = os.environ.get("SGP_HYBRID")
+            os.environ["SGP_HYBRID"] = "0"
+            try:
+                hctx = L.Context(ctx.device if hasattr(ctx, "device") else 0)
+                try:
+                    hds = C.c_void_p()
+                    L.check(lib.sgp_dspec_create(hctx.handle, spec.ref(), C.byref(hds)), "sgp_dspec_create")
+                    ho = np.zeros(1)
+
+                    def hstep():
+                        L.check(lib.sgp_dev_logpdf(hctx.handle, hds, A.data_ptr(), None, L.NOISE_SCALAR, L.dptr(nz), None,
+                                                   dY.data_ptr(), N, 1, L.dptr(ho), None), "sgp_dev_logpdf (SGP_HYBRID=0)")
+                    hstep()
+                    torch.cuda.synchronize()
+                    nrep_h = 3 if N >= 32768 else 10
+                    t0h = time.perf_counter()
+                    for _ in range(nrep_h):
+                        hstep()
+                    h_ms = (time.perf_counter() - t0h) / nrep_h * 1e3
+                    h_sched = hctx.factor_schedule(N)
+                    lib.sgp_dspec_destroy(hds)
+                finally:
+                    hctx.close()
+            finally:
+                if prev_env is None:
+                    os.environ.pop("SGP_HYBRID", None)
+                else:
+                    os.environ["SGP_HYBRID"] = prev_env
+            roofline["round4_schedule_same_box"] = {
+                "how": "SGP_HYBRID=0 on a second context, same device buffers, after the timed region: " + h_sched,
+                "schedule": h_sched, "steps": nrep_h, "ms_per_step": h_ms, "hybrid_over_this": ms_per_step / h_ms,
+                "same_bits": float(ho[0]) == float(out[0])}
         if hybrid:
             roofline["note"] = ("hybrid schedule: `frac` is the update launches' rate IN SITU (their HIP-event durations include the "
                                 "time the panel kernel holds the chip and the overlap of the two update streams); "

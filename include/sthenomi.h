@@ -203,6 +203,19 @@ int sgp_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, double* out);
  * out[s] = -(N log 2pi + logdet C + |L^-1 (Y[:,s]-m)|^2)/2,  C = K + Sigma_y = L L'. */
 int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                const double* noise, const double* Y, int64_t ldy, int64_t ncols, double* out);
+/* logpdf of nspec INDEPENDENT models in one call (round 6): the loop a host runs around logpdf when it restarts an
+ * optimiser from several initial hyper-parameters, cross-validates, or evaluates a population of candidates
+ * (/root/reference/examples/getting_started/script.jl:154-213 is one such chain; its restarts are B of them).  Member b:
+ * specs[b], means[b] (means or means[b] may be NULL == zeros), noises[b] (SCALAR: one value, DIAG: N values; one kind for the
+ * batch), ys[b] (one vector); out[b] = logpdf(f_b(x_b, noise_b), y_b) -- bit-equal to the member's own sgp_logpdf call.
+ * Equally sized members up to SGP_BATCH_MAX_N (12288) padded columns are assembled side by side and factored by ONE launch
+ * of the dataflow kernel as a single task pool: at sizes where one factorisation is bound by its diagonal chain (N <= 8192)
+ * the B chains hide each other and the aggregate rate is a multiple of the single call's (docs/05).  Anything else
+ * (different sizes, dense noise, larger members, a multi-GPU context) runs member by member.
+ * A member whose matrix is not positive definite gets out[b] = NaN and infos[b] = the failing leading minor (LAPACK's info;
+ * 0 for the others); with infos == NULL the call returns the first such info (> 0) instead of 0. */
+int sgp_logpdf_batch(sgp_ctx* ctx, int nspec, const sgp_cov_spec* const* specs, const double* const* means,
+                     int noise_kind, const double* const* noises, const double* const* ys, double* out, int* infos);
 
 /* ---- fp32 instantiation (the reference is type-stable in Float32:
  * /root/reference/test/gp/util.jl:76-88).  Same spec (the fp64 inputs are rounded to fp32 once on the

@@ -46,6 +46,8 @@ int sgp_bench_multi_fault(sgp_ctx* ctx, int rank, int64_t step);
 /* ... or makes that thread SLEEP `seconds` there without failing: the other ranks' threads then wait for its event records and
  * must give up at their wall-clock bound (SGP_MULTI_SPIN_TIMEOUT_S) instead of spinning for ever */
 int sgp_bench_multi_stall(sgp_ctx* ctx, int rank, int64_t step, double seconds);
+/* profile mode (sgp_ctx_multi_profile): per panel 8 doubles, the ms of each sub-panel's launch group alone on the hardware */
+int sgp_bench_multi_profile_pieces(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out);
 /* *out = 1 once a failed call has left the context's RCCL communicators aborted (it then refuses sharded calls) */
 int sgp_bench_multi_broken(sgp_ctx* ctx, int* out);
 

@@ -170,7 +170,9 @@ function logpdf(fx::SthenoFGP, Y::AbstractMatrix{<:Real})
     Σ = fx.Σy; Yd = Matrix{Float64}(Y)
     if fx.x isa BlockData && !(Σ isa AbstractMatrix && !(Σ isa Diagonal) && !(Σ isa AbstractGPs.ScalMat))
         perm, changes = suggest_order(sp)            # a dense Σy has no structural zeros to keep: left alone
-        if changes                                   # a fill-reducing block order: same value, the skipped tile products back
+        # (`perm` indexes the spec's FLATTENED row blocks: a nested programme observed through BlockData can have more of them
+        # than fx.x.X has entries -- then the caller's order is kept; advisor, round 5)
+        if changes && length(perm) == length(fx.x.X) # a fill-reducing block order: same value, the skipped tile products back
             idx = block_permutation(sp, perm)
             sp = build_spec(fx.f, BlockData(fx.x.X[perm])); m = m[idx]; Yd = Yd[idx, :]; Σ = permute_noise(Σ, idx)
         end

@@ -17,7 +17,7 @@ from .gp import (GP, GPC, AtomicGP, DerivedGP, Periodic, Select, Shift, Stretch,
                  stretch)
 from .gppp import GPPP, extract_components, gppp, gppp_sum_model  # noqa: F401
 from .finite_gp import (VFE, ApproxPosteriorGP, FiniteGP, PosteriorGP, SparseFiniteGP,  # noqa: F401
-                        cov, elbo, elbo_and_gradient, logpdf, logpdf_and_gradient, logpdf_f32, marginals, mean, mean_and_cov, mean_and_var,
+                        cov, elbo, elbo_and_gradient, logpdf, logpdf_and_gradient, logpdf_batch, logpdf_f32, marginals, mean, mean_and_cov, mean_and_var,
                         posterior, posterior_mean_and_var_f32, prior_cov, prior_mean, prior_var, rand, sparse_cov, var)
 from .flatten import build_spec  # noqa: F401
 from .ordering import block_atoms, fill_reducing_order, permute_blocks, suggest_order_capi  # noqa: F401

@@ -5,6 +5,7 @@
 #include "tilemap.h"
 #include "sz_pattern.h"
 #include "df_tasks.h"
+#include <limits>
 
 #include <algorithm>
 #include <cmath>
@@ -202,9 +203,17 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     if (const char* hy = getenv("SGP_HYBRID_WGS")) c->hybrid_wgs = std::max(8, atoi(hy));
     if (const char* hy = getenv("SGP_HYBRID_FAT")) c->hybrid_fat = atoi(hy);
     if (const char* hy = getenv("SGP_HYBRID_W")) c->hybrid_w = std::max<long>(TILE, atol(hy) / TILE * TILE);
-    if (const char* hy = getenv("SGP_HYBRID_MIN_N")) c->hybrid_min_n = atol(hy);
+    if (const char* hy = getenv("SGP_HYBRID_MIN_N")) {
+      // (the gradient path's crossover -- 16384 by default -- follows a limit the user sets: advisor, round 5: it used to stay
+      // at min(limit, 16384), so raising the limit could not move it; SGP_HYBRID_GROW_MIN_N names it separately)
+      c->hybrid_min_n = atol(hy);
+      c->hybrid_grow_min_n = c->hybrid_min_n;
+    }
+    if (const char* hy = getenv("SGP_HYBRID_GROW_MIN_N")) c->hybrid_grow_min_n = atol(hy);
     if (const char* hy = getenv("SGP_HYBRID_GROW")) c->hybrid_grow = atoi(hy);
     if (const char* hy = getenv("SGP_HYBRID_SERIAL")) c->hybrid_serial = atoi(hy);
+    if (const char* v = getenv("SGP_BATCH_MAX_N")) c->batch_max_n = atol(v);
+    if (const char* v = getenv("SGP_BATCH_FAT")) c->batch_fat = atoi(v);
     const char* wo = getenv("SGP_WOUT");
     if (wo) c->wout = atol(wo) / TILE * TILE;
     const char* wm = getenv("SGP_WMID");
@@ -284,6 +293,8 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   if (c->d_df_state) hipFree(c->d_df_state);
   if (c->d_sz) hipFree(c->d_sz);
   if (c->d_szmap) hipFree(c->d_szmap);
+  if (c->h_sz_pin) hipHostFree(c->h_sz_pin);
+  if (c->ev_sz) hipEventDestroy(c->ev_sz);
   if (c->d_df_inv) hipFree(c->d_df_inv);
   if (c->d_df_stats) hipFree(c->d_df_stats);
   if (c->ev_panel) hipEventDestroy(c->ev_panel);
@@ -714,7 +725,7 @@ static bool use_hybrid(const sgp_ctx* ctx, long n_pad, bool grow = false) {
   if (ctx->refine != 1 || ctx->hybrid == 0 || n_pad < 4096 || (grow && !ctx->hybrid_grow)) return false;
   if (ctx->hybrid == 1) return true;
   // by size -- unless the caller pinned another schedule (SGP_DATAFLOW = 0 / 1, SGP_LOOKAHEAD = 0)
-  return ctx->dataflow < 0 && ctx->lookahead != 0 && n_pad >= (grow ? std::min<long>(ctx->hybrid_min_n, 16384) : ctx->hybrid_min_n);
+  return ctx->dataflow < 0 && ctx->lookahead != 0 && n_pad >= (grow ? ctx->hybrid_grow_min_n : ctx->hybrid_min_n);
 }
 static bool use_dataflow(const sgp_ctx* ctx, long n_pad) {
   if (ctx->refine != 1 || ctx->dataflow == 0) return false;
@@ -815,9 +826,9 @@ struct SzMask {
 struct SzScope {   // the launch-based updates read the pattern through gemm_nt.hip's per-thread record
   sgp_ctx* c;
   bool on;
-  SzScope(sgp_ctx* ctx, const double* A, long ld, const SzMask* sz) : c(ctx), on(sz && sz->d_nz) {
+  SzScope(sgp_ctx* ctx, const double* A, long ld, long ncols, const SzMask* sz) : c(ctx), on(sz && sz->d_nz) {
     if (on) {
-      gemm_set_structure(A, ld, sz->d_nz, sz->words);
+      gemm_set_structure(A, ld, sz->d_nz, sz->words, ncols);
       c->sz_base = A;
       c->sz_ld = ld;
       c->sz_words = sz->words;
@@ -858,7 +869,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
                          hipStream_t s, long grow = 0, const SzMask* sz = nullptr) {
   CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
   // (grow != 0, the gradient path: the caller's pattern covers the identity rows -- sz_pattern's grad_border form)
-  SzScope sz_scope(ctx, A, ld, sz);
+  SzScope sz_scope(ctx, A, ld, n_pad, sz);
   // Dataflow factorisation (chol_df.hip): one launch of persistent workgroups, tile-level dependencies instead of
   // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
   // upper-triangular border, `grow`: its tasks would have to skip the structurally zero tiles.)
@@ -974,7 +985,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // (one stream: the compacted id maps of consecutive structured launches may share one scratch buffer)
   // (two streams under the look-ahead: a map each)
   if (sz_scope.on && s == ctx->stream)
-    gemm_set_structure(A, ld, sz->d_nz, sz->words, ctx->d_szmap, ctx->n_szmap / 2, 0, la ? ctx->stream2 : nullptr,
+    gemm_set_structure(A, ld, sz->d_nz, sz->words, n_pad, ctx->d_szmap, ctx->n_szmap / 2, 0, la ? ctx->stream2 : nullptr,
                        la ? ctx->d_szmap + ctx->n_szmap / 2 : nullptr);
   const bool deep = !la && n_pad >= 65536;
   const long WOUT = hybrid ? std::min(ctx->hybrid_w, n_pad)
@@ -1160,10 +1171,23 @@ static int sz_upload(sgp_ctx* ctx, const std::vector<sz_word>& h, int words, hip
     SGP_HIP(hipMalloc(&ctx->d_sz, sizeof(sz_word) * h.size()));
     ctx->n_sz = h.size();
   }
-  // `h` is pageable and the next call swaps / frees it (in a multi-GPU context every rank copies out of rank 0's): the copy is
-  // complete before this returns (a few KB on a stream that holds only the call's small uploads; advisor, round 4)
-  SGP_HIP(hipMemcpyAsync(ctx->d_sz, h.data(), sizeof(sz_word) * h.size(), hipMemcpyHostToDevice, s));
-  SGP_HIP(hipStreamSynchronize(s));
+  // `h` is pageable and the next call swaps / frees it (in a multi-GPU context every rank copies out of rank 0's): it is staged
+  // through a pinned buffer of the context, so the copy is asynchronous AND safe (advisor, round 4: the pageable source; round
+  // 5: the stream synchronisation that fixed it stalled the host enqueue of every structured logpdf / gradient call).  The
+  // staging buffer is reused only after the previous copy out of it has completed (ev_sz: long done by then).
+  const size_t bytes = sizeof(sz_word) * h.size();
+  if (!ctx->ev_sz) SGP_HIP(hipEventCreateWithFlags(&ctx->ev_sz, hipEventDisableTiming));
+  else SGP_HIP(hipEventSynchronize(ctx->ev_sz));
+  if (bytes > ctx->n_sz_pin) {
+    if (ctx->h_sz_pin) hipHostFree(ctx->h_sz_pin);
+    ctx->h_sz_pin = nullptr;
+    ctx->n_sz_pin = 0;
+    SGP_HIP(hipHostMalloc((void**)&ctx->h_sz_pin, bytes + bytes / 2, hipHostMallocDefault));
+    ctx->n_sz_pin = bytes + bytes / 2;
+  }
+  std::memcpy(ctx->h_sz_pin, h.data(), bytes);
+  SGP_HIP(hipMemcpyAsync(ctx->d_sz, ctx->h_sz_pin, bytes, hipMemcpyHostToDevice, s));
+  SGP_HIP(hipEventRecord(ctx->ev_sz, s));
   {   // room for the id map of the largest lower update this matrix can see
     const long rows = (long)(h.size() / (size_t)words);
     const long half = 16 + 8 * tri_ids_per_xcd(tri_shape(rows, std::min<long>(rows, (long)words * 64), -1));
@@ -1477,6 +1501,120 @@ extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
   return with_df_fallback(ctx, [&]() { return sgp_logpdf_impl(ctx, spec, mean, noise_kind, noise, Y, ldy, ncols, out); });
 }
 
+// logpdf of nspec INDEPENDENT models in one call (round 6; sthenomi.h: sgp_logpdf_batch).  At the sizes where one
+// factorisation is bound by its diagonal chain (N = 4096: 0.13 of the fp64 MFMA peak, ~220 CUs idle) the members of an equally
+// sized batch are factored by ONE launch of the dataflow kernel as a single task pool (chol_df.hip: ids dealt round robin,
+// progress counters per matrix): the B chains sit on different workgroups and hide each other.  Every member sees exactly
+// the arithmetic of its own sgp_logpdf call (assembly, k-ascending contractions, the same reductions): the values are
+// bit-equal.  Members of different sizes, dense noise, sizes outside the batched range, a multi-GPU context: one after the
+// other through sgp_logpdf's own path.
+static int logpdf_batch_impl(sgp_ctx* ctx, int nspec, const sgp_cov_spec* const* specs, const double* const* means,
+                             int noise_kind, const double* const* noises, const double* const* ys, double* out, int* infos) {
+  CHECK_ARG(ctx && specs && noises && ys && out && nspec >= 1, "sgp_logpdf_batch: NULL argument");
+  for (int b = 0; b < nspec; ++b) {
+    CHECK_ARG(specs[b] && noises[b] && ys[b], "sgp_logpdf_batch: NULL member");
+    CHECK_ARG(specs[b]->symmetric, "sgp_logpdf_batch: specs must be symmetric");
+    if (infos) infos[b] = 0;
+  }
+  auto rows_of = [](const sgp_cov_spec* sp) {
+    long n = 0;
+    for (int i = 0; i < sp->n_row_blocks; ++i) n += sp->row_len[i];
+    return n;
+  };
+  const long N = rows_of(specs[0]);
+  bool same = true;
+  for (int b = 1; b < nspec; ++b) same = same && rows_of(specs[b]) == N;
+  int64_t n_pad = 0, m_tot = 0;
+  if (N >= 1) sgp_geometry(N, 1, &n_pad, &m_tot);
+  const bool pooled = same && N >= 1 && nspec >= 2 && !ctx->multi && ctx->refine == 1 && ctx->dataflow != 0 &&
+                      ctx->batch_max_n > 0 && n_pad <= ctx->batch_max_n &&
+                      (noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG);
+  if (!pooled) {
+    int first_bad = 0;
+    for (int b = 0; b < nspec; ++b) {
+      const int rc = sgp_logpdf(ctx, specs[b], means ? means[b] : nullptr, noise_kind, noises[b], ys[b], rows_of(specs[b]), 1, out + b);
+      if (rc < 0) return rc;
+      if (rc > 0) {
+        out[b] = std::numeric_limits<double>::quiet_NaN();
+        if (infos) infos[b] = rc;
+        if (!first_bad) first_bad = rc;
+      }
+    }
+    return infos ? 0 : first_bad;
+  }
+  CtxScope scope(ctx);
+  hipStream_t s = ctx->stream;
+  const long T_c = n_pad / TILE;
+  const long per_small = T_c + 8;   // per member: logdet slots | [T_c] logdet | [T_c + 1] |L^-1 (y - m)|^2 | [T_c + 2] logpdf
+  int first_bad = 0;
+  for (int b0 = 0; b0 < nspec; b0 += DF_MAX_BATCH) {
+    const int nb = std::min(DF_MAX_BATCH, nspec - b0);
+    struct Member {
+      SpecGuard g;
+      DevBuf A, mean, y;
+      NoiseDev nd;
+    };
+    std::vector<Member> mem((size_t)nb);
+    DevBuf inv, small, infobuf;
+    CHECK_RC(inv.alloc((size_t)nb * T_c * INVD_STRIDE));
+    CHECK_RC(small.alloc((size_t)nb * per_small));
+    CHECK_RC(infobuf.alloc((size_t)nb));   // (ints inside doubles' storage)
+    int* d_infos = reinterpret_cast<int*>(infobuf.p);
+    SGP_HIP(hipMemsetAsync(d_infos, 0, sizeof(int) * nb, s));
+    CHECK_RC(df_scratch(ctx, m_tot, nb, 0, s));
+    DfProb probs[DF_MAX_BATCH];
+    for (int b = 0; b < nb; ++b) {
+      Member& M = mem[(size_t)b];
+      const int gb = b0 + b;
+      CHECK_RC(dspec_create(ctx, specs[gb], &M.g.ds));
+      CHECK_RC(M.A.alloc((size_t)m_tot * n_pad));
+      if (means && means[gb]) CHECK_RC(M.mean.upload(means[gb], N));
+      CHECK_RC(upload_noise(M.nd, noise_kind, noises[gb], N));
+      CHECK_RC(M.y.upload(ys[gb], N));
+      // (no structural zeros inside a batch: its members need not share a pattern, and these sizes are chain-bound anyway)
+      CHECK_RC(build_bordered(ctx, M.g.ds, M.A.p, n_pad, m_tot, M.mean.p, M.nd.kind, M.nd.sigma2, M.nd.diag.p, nullptr, 0, M.y.p,
+                              N, 1, s, nullptr));
+      probs[b] = DfProb{M.A.p, inv.p + (size_t)b * T_c * INVD_STRIDE, small.p + (size_t)b * per_small, d_infos + b};
+    }
+    CHECK_RC(launch_chol_dataflow_batch(probs, nb, m_tot, n_pad, m_tot, ctx->d_df_state, ctx->batch_fat ? ctx->hybrid_wgs : ctx->df_wgs,
+                                        ctx->df_timeout_s, ctx->batch_fat, s));
+    for (int b = 0; b < nb; ++b) {
+      double* sm = small.p + (size_t)b * per_small;
+      CHECK_RC(launch_rowsumsq(mem[(size_t)b].A.p + n_pad, m_tot, N, 1, sm + T_c + 1, 0, s));
+      CHECK_RC(launch_sum_array(sm, T_c, sm + T_c, s));
+      CHECK_RC(launch_logpdf_final(sm + T_c, sm + T_c + 1, N, 1, sm + T_c + 2, s));
+    }
+    std::vector<double> h_small((size_t)nb * per_small);
+    std::vector<int> h_info((size_t)nb);
+    SGP_HIP(hipMemcpyAsync(h_small.data(), small.p, sizeof(double) * h_small.size(), hipMemcpyDeviceToHost, s));
+    SGP_HIP(hipMemcpyAsync(h_info.data(), d_infos, sizeof(int) * nb, hipMemcpyDeviceToHost, s));
+    SGP_HIP(hipStreamSynchronize(s));
+    for (int b = 0; b < nb; ++b) {
+      const int info = h_info[(size_t)b];
+      if (info == SGP_DF_TIMEOUT) {
+        ctx->df_timed_out = true;   // (with_df_fallback reruns the call member by member on the launch-based schedule)
+        set_error("dataflow factorisation: a dependency wait inside the kernel ran into its bound (SGP_DF_TIMEOUT_S)");
+        return -3;
+      }
+      out[b0 + b] = h_small[(size_t)b * per_small + T_c + 2];
+      if (info > 0) {
+        out[b0 + b] = std::numeric_limits<double>::quiet_NaN();
+        if (infos) infos[b0 + b] = info;
+        if (!first_bad) {
+          first_bad = info;
+          set_error("matrix is not positive definite; Cholesky factorization failed at leading minor " + std::to_string(info) +
+                    " (batch member " + std::to_string(b0 + b) + ")");
+        }
+      }
+    }
+  }
+  return infos ? 0 : first_bad;
+}
+extern "C" int sgp_logpdf_batch(sgp_ctx* ctx, int nspec, const sgp_cov_spec* const* specs, const double* const* means,
+                                int noise_kind, const double* const* noises, const double* const* ys, double* out, int* infos) {
+  return with_df_fallback(ctx, [&]() { return logpdf_batch_impl(ctx, nspec, specs, means, noise_kind, noises, ys, out, infos); });
+}
+
 // dst[i + c * ld] = mean[i] (i < N) else 0, for an nrows x ncols block
 __global__ void fill_mean_cols_kernel(double* dst, long ld, long nrows, long ncols, long N, const double* mean) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1569,7 +1707,6 @@ static int contract_spec(const sgp_dspec* ds, const double* Gm, long ldg, const 
 // ---------------------------------------------------------------------------------------
 // (every consumer of C^-1 -- the term contractions, the input-point and row-scale sums, the noise gradient -- walks the block
 // pairs WITH terms or the diagonal: none needs a tile outside K's own tile pattern)
-static bool grad_inputs_need_all(double* const*, double* const*) { return false; }
 static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                             const double* noise, const double* y, double* logpdf_out, double* grad_y,
                             double* grad_mean, double* grad_noise, double* grad_coef, double* grad_inscale,
@@ -1643,7 +1780,10 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   // C^-1 = inv(L)' inv(L): lower tiles on the MFMA GEMM, then mirrored
   {
     TileSkip usk;
-    if (sz.d_nz && !grad_inputs_need_all(grad_inputs, grad_rowscale)) {
+    if (sz.d_nz) {
+      // the tiles outside K's own pattern are not computed: they must not be pool garbage for whoever reads all of C^-1
+      // (today nobody does -- a dense Sigma_y has no pattern -- but the mirror below copies them; advisor, round 5)
+      SGP_HIP(hipMemsetAsync(dKinv.p, 0, sizeof(double) * (size_t)n_pad * n_pad, s));
       usk.nz = sz.d_nz;
       usk.words = sz.words;
       usk.tr0 = usk.tc0 = (int)(n_pad / TILE + 1);   // the identity rows' pattern rows
@@ -3659,7 +3799,7 @@ int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, 
   } else {
     CHECK_ARG(!px || (px->n_ext == 0 && px->n_fact == w), "drv_panel_factor: the launch-based chain takes whole panels only");
     FuseScope fuse_scope(ctx, fuse_mode(ctx, m));
-    if (d_nz) gemm_set_structure(P, ld, d_nz, nz_words, nullptr, 0, g0 / TILE);
+    if (d_nz) gemm_set_structure(P, ld, d_nz, nz_words, w, nullptr, 0, g0 / TILE);
     const int rc = panel_factor(ctx, P, ld, m, w, g0, ctx->d_slots, d_info, d_invstore, s);
     if (d_nz) gemm_set_structure(nullptr, 0, nullptr, 0);
     CHECK_RC(rc);

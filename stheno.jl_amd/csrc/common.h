@@ -167,7 +167,8 @@ struct TileSkip {      // per launch of a lower update C -= P P': C's first tile
 // panel's own factorisation find their tiles in the pattern too
 // (scratch / scratch_ints: room for the compacted live-tile id map of a launch; stream2 / scratch2: a second map of the same
 // size for the launches of that other stream -- launches of one stream are ordered, so a map per stream is enough)
-void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch = nullptr,
+// ncols: the columns of the matrix at `base` (pointers beyond base + ld * ncols are not part of it and get no pattern)
+void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, long ncols = 0, int* scratch = nullptr,
                         long scratch_ints = 0, long tile0 = 0, hipStream_t stream2 = nullptr, int* scratch2 = nullptr);
 // the panel solve X <- X inv(L_kk)' over rows of the structured matrix: 128-row tiles of X whose tile (row, k) is structurally
 // zero are left alone (they hold the exact zeros the assembly wrote).  nz == nullptr: every row is solved.

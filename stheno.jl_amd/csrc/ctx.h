@@ -90,6 +90,11 @@ struct sgp_ctx {
   // one-workgroup-per-CU instantiation
   int hybrid = -1, hybrid_wgs = 256, hybrid_fat = 1;
   long hybrid_w = 2048, hybrid_min_n = 24576;
+  long hybrid_grow_min_n = 16384;   // the gradient path's factorisations (identity border): SGP_HYBRID_GROW_MIN_N
+  // sgp_logpdf_batch (round 6): equally sized members up to SGP_BATCH_MAX_N padded columns are factored as ONE task pool of the
+  // dataflow kernel (0: never); SGP_BATCH_FAT: its one-workgroup-per-CU instantiation (1) or the lean one (0)
+  long batch_max_n = 12288;
+  int batch_fat = 1;
   int hybrid_serial = 0;       // SGP_HYBRID_SERIAL = 1: one stream (bench.py: the update launches' rate with the chip to themselves)
   int hybrid_grow = 1;         // SGP_HYBRID_GROW = 0: not for the gradient path's factorisations (A/B)
   bool df_timed_out = false;   // the last dataflow launch ran into its wait bound (fetch_info)
@@ -99,6 +104,9 @@ struct sgp_ctx {
   sgp::sz_word* d_sz = nullptr;   // device copy of the factor's tile pattern (grow-only)
   size_t n_sz = 0;
   std::vector<sgp::sz_word> h_sz;
+  sgp::sz_word* h_sz_pin = nullptr;   // pinned staging copy of the pattern (capi.hip: sz_upload), reused behind ev_sz
+  size_t n_sz_pin = 0;
+  hipEvent_t ev_sz = nullptr;
   int* d_szmap = nullptr;         // scratch of the compacted live-tile id maps (gemm_nt.hip: tile_compact_kernel), grow-only
   long n_szmap = 0;
   double sz_executed = 0, sz_dense = 0;   // k-block products of the last factorisation: run / of the dense schedule

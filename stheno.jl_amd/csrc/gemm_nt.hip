@@ -770,6 +770,8 @@ struct GemmStructure {
   int* scratch = nullptr;
   long scratch_ints = 0;
   long tile0 = 0;   // global tile coordinate of base[0] (a packed panel: its first column / 128)
+  long ncols = 0;   // columns of the registered matrix: a pointer beyond base + ld * ncols is NOT part of it (advisor, round 5: a
+                    // scratch buffer with the same leading dimension allocated above the matrix must not inherit its pattern)
   // a second map for the launches of ONE other stream (the look-ahead schedules issue the far updates there: launches of a
   // stream are ordered, so one map per stream is enough)
   hipStream_t stream2 = nullptr;
@@ -781,7 +783,7 @@ TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) 
   TileSkip sk;
   if (!g_st.nz || ldp != g_st.ld || ldc != g_st.ld) return sk;
   const long oc = C - g_st.base, op = P - g_st.base;
-  if (oc < 0 || op < 0) return sk;
+  if (oc < 0 || op < 0 || oc >= g_st.ld * g_st.ncols || op >= g_st.ld * g_st.ncols) return sk;
   const long cr = oc % g_st.ld, cc = oc / g_st.ld, pr = op % g_st.ld, pc = op / g_st.ld;
   if (cr != cc || pr != cr || cr % TILE || pc % TILE || K % TILE || pc + K > cc) return sk;
   sk.nz = g_st.nz;
@@ -792,8 +794,8 @@ TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) 
   return sk;
 }
 }  // namespace
-void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, int* scratch, long scratch_ints,
-                        long tile0, hipStream_t stream2, int* scratch2) {
+void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, long ncols, int* scratch,
+                        long scratch_ints, long tile0, hipStream_t stream2, int* scratch2) {
   g_st.base = base;
   g_st.ld = ld;
   g_st.nz = d_nz;
@@ -801,6 +803,7 @@ void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int wo
   g_st.scratch = scratch;
   g_st.scratch_ints = scratch_ints;
   g_st.tile0 = tile0;
+  g_st.ncols = ncols;
   g_st.stream2 = stream2;
   g_st.scratch2 = scratch2;
 }
@@ -808,7 +811,7 @@ StripSkip strip_skip_for(const double* X, long ldx) {
   StripSkip sk;
   if (!g_st.nz || ldx != g_st.ld) return sk;
   const long ox = X - g_st.base;
-  if (ox < 0) return sk;
+  if (ox < 0 || ox >= g_st.ld * g_st.ncols) return sk;
   const long xr = ox % g_st.ld, xc = ox / g_st.ld;
   if (xr % TILE || xc % TILE || xr <= xc) return sk;   // rows below the diagonal block of a block column
   sk.nz = g_st.nz;

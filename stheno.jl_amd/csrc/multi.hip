@@ -172,6 +172,7 @@ struct sgp_multi {
   // first of those launches as an external source: the diagonal chain starts as soon as the first tile column has seen it.
   // Off together with the primary context's hybrid switch (SGP_HYBRID=0; the dataflow time-out fallback reruns that way).
   int panel_df = 1, fuse_la = 1;
+  std::vector<long> pieces;   // SGP_MULTI_PIECES: uneven sub-panel widths of a full panel (multi.hip: factorize), empty: regular
   int compact = 1;          // SGP_MULTI_COMPACT: compacted live-tile ids in the far update launches of a structured model (2: at any size)
   sgp_ctx* primary = nullptr;
   // One enqueue thread per rank for the sweep of the sharded factorisation (SGP_MULTI_THREADS: 1 / 0; -1 = automatic: on
@@ -211,6 +212,8 @@ struct sgp_multi {
   // profile mode (sgp_ctx_multi_profile): the factorisation runs serialised, every group of launches timed alone
   int profile = 0;
   std::vector<double> prof;   // per panel J: factor_ms, lookahead_update_ms, panel bytes, rest_update_ms[rank 0..P)
+  std::vector<double> prof_pieces;   // per panel J, Rank::NSUB slots: ms of each sub-panel's launches, alone on the hardware
+                                     // (sgp_bench_multi_profile_pieces; tools/multi_projection.py prices uneven pieces with it)
 };
 
 namespace {
@@ -464,6 +467,19 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   if (const char* v = getenv("SGP_MULTI_PANEL_DF")) m->panel_df = atoi(v);
   if (const char* v = getenv("SGP_MULTI_FUSE_LA")) m->fuse_la = atoi(v);
   if (const char* v = getenv("SGP_MULTI_COMPACT")) m->compact = atoi(v);
+  if (const char* v = getenv("SGP_MULTI_PIECES")) {
+    std::vector<long> pc;
+    bool ok = true;
+    for (const char* c = v; *c;) {
+      char* e = nullptr;
+      const long w = strtol(c, &e, 10);
+      if (e == c) break;
+      if (w < TILE || w % TILE) ok = false;
+      pc.push_back(w);
+      c = (*e == ',') ? e + 1 : e;
+    }
+    if (ok && !pc.empty() && (int)pc.size() <= Rank::NSUB) m->pieces = pc;
+  }
   if (const char* v = getenv("SGP_MULTI_SPIN_TIMEOUT_S")) m->spin_timeout_s = std::max(0.01, atof(v));
   if (const char* v = getenv("SGP_MULTI_INIT_TIMEOUT_S")) m->init_timeout_s = std::max(1.0, atof(v));
   if (const char* v = getenv("SGP_MULTI_FAULT")) {   // rank:step (tests)
@@ -665,6 +681,17 @@ extern "C" int sgp_bench_multi_stall(sgp_ctx* ctx, int rank, int64_t step, doubl
   ctx->multi->fault_stall_s = seconds;
   return 0;
 }
+// profile mode: per panel Rank::NSUB (8) doubles -- the ms of every sub-panel's launch group of the last profiled factorisation
+extern "C" int sgp_bench_multi_profile_pieces(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out) {
+  M_CHECK_ARG(ctx && ctx->multi && n_out, "sgp_bench_multi_profile_pieces: bad argument");
+  const auto& v = ctx->multi->prof_pieces;
+  *n_out = (int64_t)v.size();
+  if (out) {
+    M_CHECK_ARG(cap >= (int64_t)v.size(), "sgp_bench_multi_profile_pieces: buffer too small");
+    std::copy(v.begin(), v.end(), out);
+  }
+  return 0;
+}
 // 1 after a failed call left the RCCL communicators aborted (the context then refuses sharded calls), else 0
 extern "C" int sgp_bench_multi_broken(sgp_ctx* ctx, int* out) {
   M_CHECK_ARG(ctx && ctx->multi && out, "sgp_bench_multi_broken: not a multi-GPU context");
@@ -752,8 +779,8 @@ struct Exec {
           // stop everybody instead of spinning for ever
           m->abort_flag.store(1);
           set_error("multi: rank " + std::to_string(i) + "'s enqueue thread waited more than " +
-                    std::to_string((long)m->spin_timeout_s) + " s for an event record of another rank (SGP_MULTI_SPIN_TIMEOUT_S)");
-          return -5;
+                    std::to_string(m->spin_timeout_s) + " s for an event record of another rank (SGP_MULTI_SPIN_TIMEOUT_S)");
+          return -7;   // (a root cause, unlike -5: the threads that leave because of the flag)
         }
         std::this_thread::yield();
       }
@@ -976,7 +1003,7 @@ int update_panels(sgp_multi* m, const Fact& F, long J_first, long J_last, const 
 // ---- host-side inputs of one call, uploaded to every rank ----------------------------------------------
 struct SmallLayout {
   long N, S, npan;
-  size_t y, mean, noise, scal, pan, total;
+  size_t y, mean, noise, scal, pan, red, total;
   // pan: per panel J 1 + max(S, 1) doubles -- the panel's logdet contribution and the |L^-1 (Y - m)|^2 contributions of its
   // columns, written by the panel's owner only.  The host adds them in PANEL order (reduce_scalars), so logpdf does not
   // depend on who owns which panel (round 4 added per-rank sums in rank order: the value moved in the last bits with the
@@ -988,7 +1015,9 @@ struct SmallLayout {
     noise = mean + N;
     scal = noise + N;
     pan = scal + 16 + 2 * (size_t)std::max<long>(S, 1);
-    total = pan + (size_t)npan * (size_t)per();
+    red = pan + (size_t)npan * (size_t)per();     // receive buffer of the RCCL all-reduce of the slots (advisor, round 5: an
+                                                  // in-place reduction would return P times the values on a second call)
+    total = red + (size_t)npan * (size_t)per();
   }
 };
 
@@ -1010,6 +1039,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   const SmallLayout L(N, S, g.npan);
   const bool prof = m->profile != 0;
   if (prof) m->prof.assign((size_t)g.npan * (3 + 3 * P), 0.0);
+  if (prof) m->prof_pieces.assign((size_t)g.npan * Rank::NSUB, 0.0);
   const double t_begin = now_ms();
   Exec x0;                       // the caller's thread: buffers, uploads, assembly -- and the sweep when it is not threaded
   x0.m = m;
@@ -1092,8 +1122,24 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   // steps inside: drv_panel_factor) + ONE update of the panel's remaining columns with it (K = sub; the same ascending-k
   // accumulation per tile as the 128-column steps of an unsplit panel: bit-identical).
   const long SUB = (m->sub >= TILE) ? m->sub : (1L << 40);
-  auto n_sub = [&](long J) { return (int)std::min<long>(Rank::NSUB, (g.width(J) + SUB - 1) / SUB); };
+  // round 6: UNEVEN pieces (SGP_MULTI_PIECES=768,256: widths that add up to the panel width) -- what sits between the end of one
+  // panel's factorisation and the start of the next is the LAST piece's transport and look-ahead update, so a short last
+  // piece shortens the chain while the long first piece travels under the factorisation of the rest.  Panels of another
+  // width (a narrow tail, the last panel) keep the regular pieces.
+  long pieces_sum = 0;
+  for (long w : m->pieces) pieces_sum += w;
+  auto uneven = [&](long J) { return !m->pieces.empty() && pieces_sum == g.width(J); };
+  auto n_sub = [&](long J) {
+    if (uneven(J)) return (int)m->pieces.size();
+    return (int)std::min<long>(Rank::NSUB, (g.width(J) + SUB - 1) / SUB);
+  };
   auto sub_range = [&](long J, int q, long& c, long& wq) {
+    if (uneven(J)) {
+      c = 0;
+      for (int t = 0; t < q; ++t) c += m->pieces[(size_t)t];
+      wq = m->pieces[(size_t)q];
+      return;
+    }
     const int ns = n_sub(J);
     c = (long)q * SUB;
     wq = (q == ns - 1) ? g.width(J) - c : SUB;   // (more than NSUB sub-panels: the last takes the rest)
@@ -1122,6 +1168,17 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
         sub_range(J, q, c, wq);
         double* d_logdet = k.d_small + L.pan + (size_t)J * L.per();
         double* invq = F.invp(o, J) ? F.invp(o, J) + (c / TILE) * drv_invd_stride() : nullptr;
+        double tq0 = 0;
+        if (prof) {
+          M_RC(sync_all(m));
+          tq0 = now_ms();
+        }
+        auto piece_done = [&]() -> int {   // profile mode: this piece's launches, alone on the hardware
+          if (!prof) return 0;
+          M_RC(sync_all(m));
+          m->prof_pieces[(size_t)J * Rank::NSUB + q] = now_ms() - tq0;
+          return 0;
+        };
         const sz_word* nzp = m->sz_words > 0 ? k.d_sz : nullptr;   // structural zeros inside the panel's own factorisation
         if (df_panels) {
           // ONE launch: [the look-ahead update with the previous panel's last sub-panel -- an external source, q == 0 only]
@@ -1145,6 +1202,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
           M_RC(x.rec(o, k.ev_sub[q], k.s_panel));
           if (q == ns - 1) M_RC(x.rec(o, k.ev_fact, k.s_panel));
           if (!prof) M_RC(broadcast_panel(x, F, J, q, c, wq, q == ns - 1));
+          M_RC(piece_done());
           continue;
         }
         if (x.mine(o)) {
@@ -1171,6 +1229,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
           b.dst[0] = SegDst{Pj + r + (size_t)r * ldp, ldp, J0 + r, (int)(w - r), 0, 1, 0u};
           M_RC(launch_gemm_nt_seg(b, k.s_panel));
         }
+        M_RC(piece_done());
       }
       x.factored_once[o] = 1;
       if (x.mine(o)) k.n_factored += 1;
@@ -1490,8 +1549,7 @@ int reduce_scalars(sgp_multi* m, const Geometry& g, const SmallLayout& L, std::v
     for (int i = 0; i < P && rc == 0; ++i) {
       Rank& k = m->r[i];
       hipSetDevice(k.dev);
-      double* sc = k.d_small + L.pan;
-      rc = m->rccl.AllReduce(sc, sc, (size_t)nslot, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
+      rc = m->rccl.AllReduce(k.d_small + L.pan, k.d_small + L.red, (size_t)nslot, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
     }
     int rc2 = m->rccl.GroupEnd();
     if (rc || rc2) {
@@ -1500,7 +1558,7 @@ int reduce_scalars(sgp_multi* m, const Geometry& g, const SmallLayout& L, std::v
     }
     Rank& k0 = m->r[0];
     M_HIP(hipSetDevice(k0.dev));
-    M_HIP(hipMemcpyAsync(all.data(), k0.d_small + L.pan, sizeof(double) * nslot, hipMemcpyDeviceToHost, k0.s_upd));
+    M_HIP(hipMemcpyAsync(all.data(), k0.d_small + L.red, sizeof(double) * nslot, hipMemcpyDeviceToHost, k0.s_upd));
     for (auto& k : m->r) {
       M_HIP(hipSetDevice(k.dev));
       M_HIP(hipStreamSynchronize(k.s_upd));

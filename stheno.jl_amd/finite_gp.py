@@ -233,6 +233,53 @@ def logpdf(fx, y):
     return float(out[0]) if vec else out
 
 
+def logpdf_batch(fxs, ys, return_infos=False):
+    """[logpdf(fx, y) for fx, y in zip(fxs, ys)] in ONE library call (sgp_logpdf_batch): the members are independent models
+    -- restarts of an optimiser, cross-validation folds, a population of hyper-parameter candidates.  Equally sized members
+    with scalar / diagonal noise are factored as one task pool of the dataflow kernel (their diagonal chains hide each other);
+    every value is bit-equal to the member's own `logpdf`.  A member that is not positive definite gives NaN (and, with
+    return_infos=True, its LAPACK info in the second result) instead of raising, so that one bad candidate does not lose the
+    others."""
+    fxs, ys = list(fxs), list(ys)
+    if len(fxs) != len(ys):
+        raise ValueError("logpdf_batch: one y per model")
+    if not fxs:
+        return (np.zeros(0), np.zeros(0, dtype=np.int32)) if return_infos else np.zeros(0)
+    keep = []          # (spec, mean, noise buffer, y) stay alive until the call returns
+    kinds = set()
+    for fx, y in zip(fxs, ys):
+        if isinstance(fx, SparseFiniteGP):
+            raise NotImplementedError("logpdf_batch takes FiniteGPs (use elbo for a SparseFiniteGP)")
+        yv = _f64(np.asarray(y, dtype=np.float64).ravel())
+        if yv.shape[0] != len(fx):
+            raise ValueError("length(y) != length(fx)")
+        spec, m, kind, nbuf = _spec_mean_noise(fx)
+        kinds.add(kind)
+        keep.append((spec, _f64(m), nbuf, yv))
+    if len(kinds) != 1 or _lib.NOISE_DENSE in kinds:
+        # mixed or dense noise kinds: member by member (same values; sgp_logpdf_batch takes one noise kind)
+        vals, infos = [], []
+        for fx, y in zip(fxs, ys):
+            try:
+                vals.append(float(logpdf(fx, y)))
+                infos.append(0)
+            except _lib.PosDefException as e:
+                vals.append(float("nan"))
+                infos.append(e.info)
+        return (np.array(vals), np.array(infos, dtype=np.int32)) if return_infos else np.array(vals)
+    nb = len(keep)
+    specs = (C.POINTER(_lib.sgp_cov_spec) * nb)(*[C.pointer(k[0].c) for k in keep])
+    means = (C.POINTER(C.c_double) * nb)(*[_lib.dptr(k[1]) for k in keep])
+    noises = (C.POINTER(C.c_double) * nb)(*[_lib.dptr(k[2]) for k in keep])
+    yp = (C.POINTER(C.c_double) * nb)(*[_lib.dptr(k[3]) for k in keep])
+    out = np.zeros(nb)
+    infos = np.zeros(nb, dtype=np.int32)
+    rc = _ctx().lib.sgp_logpdf_batch(_ctx().handle, nb, specs, means, kinds.pop(), noises, yp, _lib.dptr(out),
+                                     infos.ctypes.data_as(C.POINTER(C.c_int)))
+    _lib.check(rc, "sgp_logpdf_batch")
+    return (out, infos) if return_infos else out
+
+
 def logpdf_f32(fx, y):
     """logpdf(fx, y) on the fp32 device path (sgp_logpdf_f32: fp32 assembly, fp32 blocked Cholesky on
     v_mfma_f32_32x32x2_f32, fp32 forward substitution) -> np.float32.  Selected automatically by `logpdf`

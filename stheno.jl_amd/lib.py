@@ -90,6 +90,8 @@ _SIGS = {
     "sgp_kernelmatrix_diag": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D]),
     "sgp_logpdf": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64,
                              C.c_int64, _D]),
+    "sgp_logpdf_batch": (C.c_int, [_P, C.c_int, C.POINTER(C.POINTER(sgp_cov_spec)), C.POINTER(_D), C.c_int, C.POINTER(_D),
+                                   C.POINTER(_D), _D, C.POINTER(C.c_int)]),
     "sgp_logpdf_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, _D]),
     "sgp_kernelmatrix_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(C.c_float), C.c_int64]),
     "sgp_rand_f32": (C.c_int, [_P, C.POINTER(sgp_cov_spec), _D, C.c_int, _D, _D, C.c_int64, C.c_int64,
@@ -148,6 +150,7 @@ _SIGS = {
     "sgp_bench_df_fallbacks": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sgp_bench_multi_fault": (C.c_int, [_P, C.c_int, C.c_int64]),
     "sgp_bench_multi_broken": (C.c_int, [_P, C.POINTER(C.c_int)]),
+    "sgp_bench_multi_profile_pieces": (C.c_int, [_P, _D, C.c_int64, C.POINTER(C.c_int64)]),
     "sgp_bench_multi_stall": (C.c_int, [_P, C.c_int, C.c_int64, C.c_double]),
     "sgp_bench_mfma_f64": (C.c_int, [_P, C.c_int, _D, _D]),
     "sgp_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D]),

@@ -16,13 +16,13 @@
 static const struct { const char* name; size_t fnptr_size; } table[] = {
 #define E(f) {#f, sizeof(&f)}
   E(sgp_abi_version), E(sgp_ctx_create), E(sgp_ctx_create_multi), E(sgp_ctx_ndev), E(sgp_ctx_transport), E(sgp_ctx_factor_schedule), E(sgp_ctx_factor_work), E(sgp_cov_spec_suggest_order), E(sgp_ctx_multi_stats), E(sgp_ctx_multi_owners), E(sgp_ctx_multi_profile), E(sgp_ctx_multi_profile_get), E(sgp_ctx_destroy), E(sgp_ctx_trim), E(sgp_ctx_stage_timing), E(sgp_ctx_stage_ms), E(sgp_last_error),
-  E(sgp_kernelmatrix), E(sgp_kernelmatrix_diag), E(sgp_logpdf), E(sgp_logpdf_f32), E(sgp_kernelmatrix_f32), E(sgp_rand_f32), E(sgp_posterior_mean_var_f32), E(sgp_logpdf_grad), E(sgp_logpdf_grad_x), E(sgp_logpdf_grad_xs),
+  E(sgp_kernelmatrix), E(sgp_kernelmatrix_diag), E(sgp_logpdf), E(sgp_logpdf_batch), E(sgp_logpdf_f32), E(sgp_kernelmatrix_f32), E(sgp_rand_f32), E(sgp_posterior_mean_var_f32), E(sgp_logpdf_grad), E(sgp_logpdf_grad_x), E(sgp_logpdf_grad_xs),
   E(sgp_rand), E(sgp_posterior_create), E(sgp_posterior_predict), E(sgp_posterior_predict_explicit), E(sgp_posterior_destroy),
   E(sgp_elbo), E(sgp_elbo_grad), E(sgp_elbo_grad_x), E(sgp_elbo_grad_xs), E(sgp_kernelmatrix_diag_grad_xs), E(sgp_kernelmatrix_diag_grad),
   E(sgp_kernelmatrix_diag_grad_x), E(sgp_sparse_posterior_create), E(sgp_sparse_posterior_predict),
   E(sgp_sparse_posterior_destroy), E(sgp_dspec_create), E(sgp_dspec_destroy), E(sgp_geometry),
   E(sgp_dev_logpdf), E(sgp_dev_assemble_cols), E(sgp_dev_panel_factor), E(sgp_dev_panel_update), E(sgp_dev_panel_update_batch),
-  E(sgp_dev_rowsumsq), E(sgp_dev_assemble_cross_rows), E(sgp_dev_rows_dot), E(sgp_dev_rows_gram), E(sgp_elbo_part_len), E(sgp_dev_elbo_partial), E(sgp_dev_elbo_finish), E(sgp_bench_df_fallbacks), E(sgp_bench_multi_fault), E(sgp_bench_multi_broken), E(sgp_bench_multi_stall), E(sgp_bench_mfma_f64), E(sgp_bench_hbm), E(sgp_bench_potrf), E(sgp_bench_potrf_contended), E(sgp_bench_cumask), E(sgp_bench_gemm_stamps), E(sgp_bench_gemm),
+  E(sgp_dev_rowsumsq), E(sgp_dev_assemble_cross_rows), E(sgp_dev_rows_dot), E(sgp_dev_rows_gram), E(sgp_elbo_part_len), E(sgp_dev_elbo_partial), E(sgp_dev_elbo_finish), E(sgp_bench_df_fallbacks), E(sgp_bench_multi_fault), E(sgp_bench_multi_broken), E(sgp_bench_multi_stall), E(sgp_bench_multi_profile_pieces), E(sgp_bench_mfma_f64), E(sgp_bench_hbm), E(sgp_bench_potrf), E(sgp_bench_potrf_contended), E(sgp_bench_cumask), E(sgp_bench_gemm_stamps), E(sgp_bench_gemm),
 #undef E
 };
 

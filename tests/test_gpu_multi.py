@@ -638,13 +638,17 @@ def test_dataflow_panel_launches_give_the_launch_based_chains_bits(monkeypatch, 
         return dict(lp=np.array([P.logpdf(fx, y)]), lpm=np.asarray(P.logpdf(fx, Y)), m=np.asarray(mm), v=np.asarray(vv),
                     r=np.asarray(P.rand(None, fx, 2, Z=Z)))
 
-    keys = ("SGP_MULTI_PANEL", "SGP_MULTI_SUBPANEL", "SGP_MULTI_GROUP", "SGP_MULTI_PANEL_TAIL", "SGP_STRUCT_ZEROS", "SGP_MULTI_THREADS")
+    keys = ("SGP_MULTI_PANEL", "SGP_MULTI_SUBPANEL", "SGP_MULTI_GROUP", "SGP_MULTI_PANEL_TAIL", "SGP_STRUCT_ZEROS", "SGP_MULTI_THREADS",
+            "SGP_MULTI_PIECES")
     for env in ({"SGP_MULTI_PANEL": "128"},
                 {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "128"},
                 {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "256", "SGP_STRUCT_ZEROS": "0"},
                 {"SGP_MULTI_PANEL": "1024", "SGP_MULTI_SUBPANEL": "0", "SGP_MULTI_THREADS": "0"},
                 {"SGP_MULTI_PANEL": "256", "SGP_MULTI_SUBPANEL": "128", "SGP_MULTI_GROUP": "2"},
-                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PANEL_TAIL": "256", "SGP_MULTI_SUBPANEL": "128"}):
+                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PANEL_TAIL": "256", "SGP_MULTI_SUBPANEL": "128"},
+                # uneven pieces: a long first piece, a short last one (what sits on the chain); the last panel keeps regular pieces
+                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PIECES": "384,128"},
+                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PIECES": "256,128,128", "SGP_MULTI_SUBPANEL": "256"}):
         outs = []
         for df, fuse in (("0", "1"), ("1", "0"), ("1", "1")):
             for k in keys:

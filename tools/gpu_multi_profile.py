@@ -50,6 +50,10 @@ L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, None, 0, C.byref(n)))
 prof = np.zeros(n.value)
 L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, L.dptr(prof), n.value, C.byref(n)))
 prof = prof.reshape(-1, 3 + 3 * P)
+L.check(ctx.lib.sgp_bench_multi_profile_pieces(ctx.handle, None, 0, C.byref(n)))
+pcs = np.zeros(n.value)
+L.check(ctx.lib.sgp_bench_multi_profile_pieces(ctx.handle, L.dptr(pcs), n.value, C.byref(n)))
+pcs = pcs.reshape(-1, 8)
 g = bc.golden(cfg)
 n_pad = (N + 127) // 128 * 128
 m_tot = n_pad + 128
@@ -61,8 +65,14 @@ for b in prof[:, 2]:                       # panel bytes = 8 * (m_tot - col0) * 
     widths.append(w)
     c0 += w
 nsub = [min(8, -(-w // sub)) if sub >= 128 else 1 for w in widths]
+pieces = [int(v) for v in os.environ.get("SGP_MULTI_PIECES", "").split(",") if v.strip()]
+piece_frac = None
+if pieces:       # uneven pieces (round 6): panels whose width the pieces add up to
+    nsub = [len(pieces) if w == sum(pieces) else n for w, n in zip(widths, nsub)]
+    piece_frac = [p / sum(pieces) for p in pieces]
 json.dump({"config": cfg, "N": N, "ranks": P, "panel_width": int(st[4]), "panels": int(st[5]), "group": int(st[7]),
-           "subpanel": sub, "widths": widths, "nsub": nsub, "owners": owners,
+           "subpanel": sub, "widths": widths, "nsub": nsub, "owners": owners, "pieces": pieces, "piece_frac": piece_frac,
+           "piece_ms": pcs.tolist(),      # per panel: the ms of each sub-panel's launches (8 slots)
            # round 6: panels factored by launches of the dataflow kernel; the look-ahead update with the previous panel's LAST
            # sub-panel rides in the first of them (then factor_ms holds it and lookahead_update_ms only the earlier pieces)
            "panel_df": int(os.environ.get("SGP_MULTI_PANEL_DF", "1")) if os.environ.get("SGP_HYBRID", "") != "0" else 0,

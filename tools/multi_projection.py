@@ -82,17 +82,22 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
 
     nsub = prof.get("nsub") or [1] * npan
     fused_la = bool(prof.get("fuse_la"))
+    piece_ms = prof.get("piece_ms")
+    piece_frac = prof.get("piece_frac")
 
     def factor_and_send(J, start_ready, scale):
         """factor panel J on its owner from `start_ready` on; returns (end of the factorisation, arrival time of every
         sub-panel at the other ranks)"""
         o = owner(J)
         ns = nsub[J]
-        piece = fac[J] * scale / ns
+        # time share of every piece: measured (round 6: profile field piece_ms) or equal; byte share: its width (uneven pieces)
+        pm = piece_ms[J][:ns] if piece_ms else None
+        tfrac = [v / sum(pm) for v in pm] if pm and sum(pm) > 0 else [1.0 / ns] * ns
+        bfrac = piece_frac if (piece_frac and len(piece_frac) == ns) else [1.0 / ns] * ns
         arr, t, link_free = [], start_ready, 0.0
         for q in range(ns):
-            t = run(o, "panel", t, piece)
-            link_free = max(t, link_free) + transport(byt[J]) / ns
+            t = run(o, "panel", t, fac[J] * scale * tfrac[q])
+            link_free = max(t, link_free) + transport(byt[J]) * bfrac[q]
             arr.append(link_free)
         return t, arr
 
@@ -117,7 +122,8 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
                     if q == nq - 1:
                         t = max(t, landed)
                     else:
-                        t = run(o, "panel", max(t, landed), la[nxt] * c / (nq - 1))
+                        bf = piece_frac if (piece_frac and len(piece_frac) == nq) else [1.0 / nq] * nq
+                        t = run(o, "panel", max(t, landed), la[nxt] * c * bf[q] / sum(bf[:nq - 1]))
                 else:
                     t = run(o, "panel", max(t, landed), la[nxt] * c / nq)
             fd, new_arr = factor_and_send(nxt, t, c)
