@@ -20,9 +20,6 @@ namespace sgp {
 static thread_local std::string g_err;
 void set_error(const std::string& s) { g_err = s; }
 
-int run_mfma_bench(hipStream_t s, int iters, double* tflops_out, double* layout_maxerr_out);
-int run_hbm_bench(hipStream_t s, long bytes, int iters, double* write_gbs, double* copy_gbs);
-
 static inline long rup(long x, long m) { return (x + m - 1) / m * m; }
 static inline long spec_rows_host(const sgp_cov_spec* sp) {
   long n = 0;
@@ -168,6 +165,50 @@ static bool ctx_is_live(const sgp_ctx* c, long serial) {
   return g_live_ctx.count(c) != 0 && c->serial == serial;
 }
 
+// ---------------------------------------------------------------------------------------
+// Run-time switches of a context: ONE table, read once when the context is created (docs/03_kernels.md section 3.5 lists
+// every entry with the test that exercises it).  Round 6 pruned the switches whose A/B was closed -- the XCD task queues of
+// the dataflow kernel, the explicit-inverse panel solves (SGP_REFINE), the stamp-kernel experiments, the fp32 driver's
+// panel widths, the VFE two-chunk overlap, SGP_POOL, SGP_FUSE_MAX_N, SGP_LA_MAX_N, SGP_SPLITK_SUB, SGP_HYBRID_GROW.
+// What is left selects between schedules that all give the same bits (the bit-identity tests flip them) or bounds a wait.
+// ---------------------------------------------------------------------------------------
+namespace {
+struct CtxKnob {
+  const char* name;
+  void (*set)(sgp_ctx*, const char*);
+};
+const CtxKnob kCtxKnobs[] = {
+    // ---- schedule of the blocked Cholesky (capi.hip: chol_bordered; every choice gives the same factor)
+    {"SGP_LOOKAHEAD", [](sgp_ctx* c, const char* v) { c->lookahead = atoi(v); }},          // 0: no second stream, 2: at every size
+    {"SGP_WOUT", [](sgp_ctx* c, const char* v) { c->wout = atol(v) / TILE * TILE; }},       // outer panel width of the launches
+    {"SGP_WMID", [](sgp_ctx* c, const char* v) { c->wmid = atol(v) / TILE * TILE; }},       // middle blocking level
+    {"SGP_FUSE_POTRF", [](sgp_ctx* c, const char* v) { c->fuse_potrf = atoi(v); }},        // fused update + diagonal block
+    {"SGP_DATAFLOW", [](sgp_ctx* c, const char* v) { c->dataflow = atoi(v); }},            // 0 never / 1 always / unset by size
+    {"SGP_DF_MIN_N", [](sgp_ctx* c, const char* v) { c->df_min_n = atol(v); }},
+    {"SGP_DF_MAX_N", [](sgp_ctx* c, const char* v) { c->df_max_n = atol(v); }},
+    {"SGP_DF_FAT_MAX_N", [](sgp_ctx* c, const char* v) { c->df_fat_max_n = atol(v); }},    // one workgroup per CU below this
+    {"SGP_DF_WGS", [](sgp_ctx* c, const char* v) { if (atoi(v) > 0) c->df_wgs = atoi(v); }},
+    {"SGP_DF_TIMEOUT_S", [](sgp_ctx* c, const char* v) { c->df_timeout_s = atof(v); }},    // bound of one wait inside the kernel
+    {"SGP_DF_FALLBACK", [](sgp_ctx* c, const char* v) { c->df_fallback = atoi(v); }},      // 0: report the time-out (tests)
+    {"SGP_HYBRID", [](sgp_ctx* c, const char* v) { c->hybrid = atoi(v); }},                // 0 never / 1 from 4096 columns on
+    {"SGP_HYBRID_W", [](sgp_ctx* c, const char* v) { c->hybrid_w = std::max<long>(TILE, atol(v) / TILE * TILE); }},
+    {"SGP_HYBRID_WGS", [](sgp_ctx* c, const char* v) { c->hybrid_wgs = std::max(8, atoi(v)); }},
+    {"SGP_HYBRID_FAT", [](sgp_ctx* c, const char* v) { c->hybrid_fat = atoi(v); }},
+    // (the gradient path's crossover -- 16384 by default -- follows a limit the user sets: advisor, round 5: it used to stay at
+    // min(limit, 16384), so raising the limit could not move it; SGP_HYBRID_GROW_MIN_N, read after it, names it separately)
+    {"SGP_HYBRID_MIN_N", [](sgp_ctx* c, const char* v) { c->hybrid_min_n = c->hybrid_grow_min_n = atol(v); }},
+    {"SGP_HYBRID_GROW_MIN_N", [](sgp_ctx* c, const char* v) { c->hybrid_grow_min_n = atol(v); }},
+    {"SGP_HYBRID_SERIAL", [](sgp_ctx* c, const char* v) { c->hybrid_serial = atoi(v); }},  // one stream (bench.py: uncontended leg)
+    {"SGP_BATCH_MAX_N", [](sgp_ctx* c, const char* v) { c->batch_max_n = atol(v); }},      // sgp_logpdf_batch: pooled up to this size
+    // ---- structural zeros
+    {"SGP_STRUCT_ZEROS", [](sgp_ctx* c, const char* v) { c->struct_zeros = atoi(v); }},    // 0: the dense schedule (A/B, same bits)
+};
+void apply_env_knobs(sgp_ctx* c) {
+  for (const CtxKnob& k : kCtxKnobs)
+    if (const char* v = getenv(k.name)) k.set(c, v);
+}
+}  // namespace
+
 extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
   CHECK_ARG(out != nullptr, "sgp_ctx_create: out is NULL");
   int ndev = 0;
@@ -195,60 +236,13 @@ extern "C" int sgp_ctx_create(int device, sgp_ctx** out) {
     SGP_HIP(hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, lo));
     SGP_HIP(hipEventCreateWithFlags(&c->ev_panel, hipEventDisableTiming));
     SGP_HIP(hipEventCreateWithFlags(&c->ev_rest, hipEventDisableTiming));
-    const char* la = getenv("SGP_LOOKAHEAD");
-    if (la) c->lookahead = atoi(la);
-    const char* lx = getenv("SGP_LA_MAX_N");
-    if (lx) c->la_max_n = atol(lx);
-    if (const char* hy = getenv("SGP_HYBRID")) c->hybrid = atoi(hy);
-    if (const char* hy = getenv("SGP_HYBRID_WGS")) c->hybrid_wgs = std::max(8, atoi(hy));
-    if (const char* hy = getenv("SGP_HYBRID_FAT")) c->hybrid_fat = atoi(hy);
-    if (const char* hy = getenv("SGP_HYBRID_W")) c->hybrid_w = std::max<long>(TILE, atol(hy) / TILE * TILE);
-    if (const char* hy = getenv("SGP_HYBRID_MIN_N")) {
-      // (the gradient path's crossover -- 16384 by default -- follows a limit the user sets: advisor, round 5: it used to stay
-      // at min(limit, 16384), so raising the limit could not move it; SGP_HYBRID_GROW_MIN_N names it separately)
-      c->hybrid_min_n = atol(hy);
-      c->hybrid_grow_min_n = c->hybrid_min_n;
-    }
-    if (const char* hy = getenv("SGP_HYBRID_GROW_MIN_N")) c->hybrid_grow_min_n = atol(hy);
-    if (const char* hy = getenv("SGP_HYBRID_GROW")) c->hybrid_grow = atoi(hy);
-    if (const char* hy = getenv("SGP_HYBRID_SERIAL")) c->hybrid_serial = atoi(hy);
-    if (const char* v = getenv("SGP_BATCH_MAX_N")) c->batch_max_n = atol(v);
-    if (const char* v = getenv("SGP_BATCH_FAT")) c->batch_fat = atoi(v);
-    const char* wo = getenv("SGP_WOUT");
-    if (wo) c->wout = atol(wo) / TILE * TILE;
-    const char* wm = getenv("SGP_WMID");
-    if (wm) c->wmid = atol(wm) / TILE * TILE;
-    const char* rf = getenv("SGP_REFINE");
-    if (rf) c->refine = atoi(rf);
-    const char* fp = getenv("SGP_FUSE_POTRF");
-    if (fp) c->fuse_potrf = atoi(fp);
-    const char* fm = getenv("SGP_FUSE_MAX_N");
-    if (fm) c->fuse_max_n = atol(fm);
-    const char* po = getenv("SGP_POOL");
-    if (po) c->pool_enabled = atoi(po);
-    const char* df = getenv("SGP_DATAFLOW");
-    if (df) c->dataflow = atoi(df);
-    const char* dfa = getenv("SGP_DF_MIN_N");
-    if (dfa) c->df_min_n = atol(dfa);
-    const char* dfb = getenv("SGP_DF_MAX_N");
-    if (dfb) c->df_max_n = atol(dfb);
-    const char* dff = getenv("SGP_DF_FAT_MAX_N");
-    if (dff) c->df_fat_max_n = atol(dff);
-    const char* dft = getenv("SGP_DF_TIMEOUT_S");
-    if (dft) c->df_timeout_s = atof(dft);
-    const char* szs = getenv("SGP_STRUCT_ZEROS");
-    if (szs) c->struct_zeros = atoi(szs);
-    const char* dfb2 = getenv("SGP_DF_FALLBACK");
-    if (dfb2) c->df_fallback = atoi(dfb2);
     {
       hipDeviceProp_t prop;
       SGP_HIP(hipGetDeviceProperties(&prop, device));
       c->df_wgs = 2 * prop.multiProcessorCount;
-      const char* dfw = getenv("SGP_DF_WGS");
-      if (dfw && atoi(dfw) > 0) c->df_wgs = atoi(dfw);
     }
+    apply_env_knobs(c);
     SGP_HIP(hipMalloc(&c->d_invd, sizeof(double) * 8 * 256));
-    SGP_HIP(hipMalloc(&c->d_w, sizeof(double) * TILE * TILE));
     c->n_slots = 1 << 15;
     SGP_HIP(hipMalloc(&c->d_slots, sizeof(double) * c->n_slots));
     c->n_scal = 16 + (1 << 16);
@@ -285,8 +279,6 @@ extern "C" int sgp_ctx_destroy(sgp_ctx* c) {
   for (auto& b : c->pool) hipFree(b.p);
   if (c->h_stage) hipHostFree(c->h_stage);
   if (c->d_invd) hipFree(c->d_invd);
-  if (c->d_w) hipFree(c->d_w);
-  if (c->d_solve) hipFree(c->d_solve);
   if (c->d_slots) hipFree(c->d_slots);
   if (c->d_scal) hipFree(c->d_scal);
   if (c->d_info) hipFree(c->d_info);
@@ -534,43 +526,21 @@ static int assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, lo
 // blocked Cholesky on the bordered matrix
 // ---------------------------------------------------------------------------------------
 // X <- X inv(Lkk)' for `rows` (multiple of 128) rows at X: the panel TRSM.
-// A product with the explicit inverse W = inv(Lkk) alone is not backward stable -- on the
-// ill-conditioned covariances smooth kernels produce it loses 2+ digits against LAPACK dtrsm and
-// can push the Schur complement indefinite (tools/gpu_illcond.py).  SGP_REFINE selects
-//   1 (default): panel_solve_kernel -- blocked substitution over 16-column blocks, each diagonal
-//                solve = inverse product + one refinement step; one launch, no inv(Lkk) needed;
-//   2: three K = 128 GEMMs  S = B W',  R = B - S Lkk',  X = S + R W'  (128-level refinement);
-//   0: X = B W' only (fast, unstable; A/B timing).
-// `inv` points at the eight 16x16 inverse diagonal blocks (block c at inv + c * inv_cstride,
-// element [m][k] at + k * inv_kstride + m): what potrf_diag just wrote (ctx scratch or a kept copy).
-static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double* W, const double* Lkk,
-                      long ldl, const double* inv, long inv_cstride, long inv_kstride, hipStream_t s) {
+// A product with the explicit inverse W = inv(Lkk) alone is not backward stable -- on the ill-conditioned covariances smooth
+// kernels produce it loses 2+ digits against LAPACK dtrsm and can push the Schur complement indefinite -- so the solve is
+// panel_solve_kernel: blocked substitution over 16-column blocks, each diagonal solve = inverse product + one refinement
+// step; one launch, no inv(Lkk) needed.  (Rounds 2 - 5 kept the explicit-inverse product and a 128-level refinement as
+// SGP_REFINE = 0 / 2 A/B modes; removed in round 6.)
+// `inv` points at the eight 16x16 inverse diagonal blocks (block c at inv + c * inv_cstride, element [m][k] at
+// + k * inv_kstride + m): what potrf_diag just wrote (ctx scratch or a kept copy).
+static int solve_rows(sgp_ctx* ctx, double* X, long ldx, long rows, const double* Lkk, long ldl, const double* inv,
+                      long inv_cstride, long inv_kstride, hipStream_t s) {
+  (void)ctx;
   if (rows <= 0) return 0;
-  // default: the fused blocked-substitution kernel (potrf.hip), refined at the 16x16 level
-  if (ctx->refine == 1) {
-    // (structured models: the 128-row tiles of this block column that are structurally zero are left alone -- the record
-    // chol_bordered / the sharded driver set for the matrix or packed panel being factored, gemm_nt.hip: strip_skip_for)
-    const StripSkip sk = strip_skip_for(X, ldx);
-    return launch_panel_solve(X, ldx, rows, Lkk, ldl, inv, inv_cstride, inv_kstride, s, sk.nz ? &sk : nullptr);
-  }
-  if (!ctx->refine)
-    return launch_gemm_nt(X, ldx, W, TILE, X, ldx, rows, TILE, TILE, 1.0, 0.0, NOMASK, 0, 0, s);
-  if (rows > ctx->n_solve_rows) {
-    SGP_HIP(hipDeviceSynchronize());
-    if (ctx->d_solve) hipFree(ctx->d_solve);
-    ctx->d_solve = nullptr;
-    ctx->n_solve_rows = 0;
-    if (hipMalloc(&ctx->d_solve, sizeof(double) * rows * TILE) != hipSuccess) {
-      set_error("panel solve: hipMalloc failed (refinement scratch)");
-      return -2;
-    }
-    ctx->n_solve_rows = rows;
-  }
-  double* S = ctx->d_solve;
-  CHECK_RC(launch_gemm_nt(X, ldx, W, TILE, S, rows, rows, TILE, TILE, 1.0, 0.0, NOMASK, 0, 0, s));
-  CHECK_RC(launch_gemm_nt(S, rows, Lkk, ldl, X, ldx, rows, TILE, TILE, -1.0, 1.0, NOMASK, 0, 0, s));
-  // in place: every workgroup owns complete rows of X (Nc == K == 128)
-  return launch_gemm_nt_cin(X, ldx, W, TILE, S, rows, X, ldx, rows, TILE, TILE, 1.0, 1.0, s);
+  // (structured models: the 128-row tiles of this block column that are structurally zero are left alone -- the record
+  // chol_bordered / the sharded driver set for the matrix or packed panel being factored, gemm_nt.hip: strip_skip_for)
+  const StripSkip sk = strip_skip_for(X, ldx);
+  return launch_panel_solve(X, ldx, rows, Lkk, ldl, inv, inv_cstride, inv_kstride, s, sk.nz ? &sk : nullptr);
 }
 
 // Factor one column panel in place (inner right-looking loop, nb = 128).
@@ -600,7 +570,7 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
   // Fused inner updates (SGP_FUSE_POTRF bit 0): the K = 128 update with block column j also factors the diagonal
   // block of block column j + 1 in the workgroup that updates it, so the 128-pivot chain runs under the rest of
   // the update instead of after it and one launch per block column disappears.
-  const bool fuse = (ctx->fuse_now & 1) && ctx->refine == 1;
+  const bool fuse = (ctx->fuse_now & 1) != 0;
   bool diag_done = first_done;
   for (long j = 0; j < w; j += TILE) {
     double* D = P + j + j * ld;
@@ -608,10 +578,9 @@ static int panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g
     if (!diag_done) CHECK_RC(launch_potrf_diag(D, ld, invd, d_slots + j / TILE, d_info, g0 + j, s));
     diag_done = false;
     long mrest = m - j - TILE;
-    if (mrest > 0 && ctx->refine != 1) CHECK_RC(launch_trtri(D, ld, invd, ctx->d_w, s));  // A/B modes only
     if (mrest > 0) {
       double* A21 = P + (j + TILE) + j * ld;
-      CHECK_RC(solve_rows(ctx, A21, ld, mrest, ctx->d_w, D, ld, invd, 256, 16, s));  // L21 = A21 * L11^-T
+      CHECK_RC(solve_rows(ctx, A21, ld, mrest, D, ld, invd, 256, 16, s));  // L21 = A21 * L11^-T
       long wrest = w - j - TILE;
       if (wrest > 0) {
         if (fuse) {
@@ -686,7 +655,7 @@ static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, lo
                             double* d_invstore, hipStream_t s, bool first_done, long wmid) {
   if (wmid < TILE || wmid >= w) return panel_factor(ctx, P, ld, m, w, g0, d_slots, d_info, d_invstore, s, first_done);
   // recursive halving down to wmid: the left half, ONE update of the right half with it (K = w / 2), the right half
-  const bool fuse_mid = (ctx->fuse_now & 2) && ctx->refine == 1;
+  const bool fuse_mid = (ctx->fuse_now & 2) != 0;
   const long wl = std::max(wmid, (w / 2 + wmid - 1) / wmid * wmid), c = wl, rest = w - wl;
   CHECK_RC(panel_factor_mid(ctx, P, ld, m, wl, g0, d_slots, d_info, d_invstore, s, first_done, wmid));
   if (rest <= 0) return 0;
@@ -722,13 +691,13 @@ static int panel_factor_mid(sgp_ctx* ctx, double* P, long ld, long m, long w, lo
 // dataflow form) take it from 16384 columns on: N = 16384 82.2 -> 81.1 ms, 24576 260.8 -> 253.5, 32768 605.8 -> 582.0
 // (profiles/r05_experiments/hybrid_grad.txt).
 static bool use_hybrid(const sgp_ctx* ctx, long n_pad, bool grow = false) {
-  if (ctx->refine != 1 || ctx->hybrid == 0 || n_pad < 4096 || (grow && !ctx->hybrid_grow)) return false;
+  if (ctx->hybrid == 0 || n_pad < 4096) return false;
   if (ctx->hybrid == 1) return true;
   // by size -- unless the caller pinned another schedule (SGP_DATAFLOW = 0 / 1, SGP_LOOKAHEAD = 0)
   return ctx->dataflow < 0 && ctx->lookahead != 0 && n_pad >= (grow ? ctx->hybrid_grow_min_n : ctx->hybrid_min_n);
 }
 static bool use_dataflow(const sgp_ctx* ctx, long n_pad) {
-  if (ctx->refine != 1 || ctx->dataflow == 0) return false;
+  if (ctx->dataflow == 0) return false;
   return ctx->dataflow == 1 || (n_pad >= ctx->df_min_n && n_pad < ctx->df_max_n);
 }
 extern "C" int sgp_ctx_factor_work(sgp_ctx* ctx, double* executed, double* dense) {
@@ -1004,7 +973,7 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
   // 1.09 ms, 4096 2.93 -> 2.73 ms, 16384 33.8 -> 33.2 ms; from 32768 on the panel stream has slack and the fused
   // launches measure the same or 1 % slower (profiles/archive/r02_microbench.md).  Bit 2: at every size (A/B).
   FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad, !la));
-  const bool fuse_outer = (ctx->fuse_now & 2) && ctx->refine == 1 && !hybrid;   // (the dataflow panel factors its own first block)
+  const bool fuse_outer = (ctx->fuse_now & 2) && !hybrid;   // (the dataflow panel factors its own first block)
   bool first_done = false;
   bool rest_pending = false;
   if (la) {
@@ -1341,11 +1310,6 @@ static int dev_logpdf_impl(sgp_ctx* ctx, const sgp_dspec* ds, double* dA, const 
 // runs, and the kernel aborts although nothing is wrong (advisor, round 3).  An operator that comes back with that
 // timeout is therefore run again, once, on the launch-based schedule -- every operator rebuilds its matrix from the spec,
 // and every schedule gives the same bits, so the caller sees the result it would have seen, only later.
-extern "C" int sgp_bench_df_fallbacks(sgp_ctx* ctx, int64_t* out) {
-  CHECK_ARG(ctx && out, "sgp_bench_df_fallbacks: NULL argument");
-  *out = ctx->df_fallbacks;
-  return 0;
-}
 template <class F>
 static int with_df_fallback(sgp_ctx* ctx, F&& run) {
   // the flag reset, the operator and its rerun are ONE critical section of the context (advisor, round 4: two host threads
@@ -1427,6 +1391,7 @@ static int upload_noise(NoiseDev& nd, int kind, const double* noise, long N) {
 extern "C" int sgp_kernelmatrix(sgp_ctx* ctx, const sgp_cov_spec* spec, double* K, int64_t ldk) {
   CHECK_ARG(ctx && spec && K, "sgp_kernelmatrix: NULL argument");
   CtxScope scope(ctx);
+  if (ctx->multi) return sgp_multi_kernelmatrix(ctx, spec, K, ldk);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N, M = g.ds->M;
@@ -1458,6 +1423,7 @@ static int diag_of_spec(sgp_ctx* ctx, const sgp_dspec* ds, double* d_out, hipStr
 extern "C" int sgp_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, double* out) {
   CHECK_ARG(ctx && spec && out, "sgp_kernelmatrix_diag: NULL argument");
   CtxScope scope(ctx);
+  if (ctx->multi) return sgp_multi_kernelmatrix_diag(ctx, spec, out);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   long N = g.ds->N;
@@ -1526,7 +1492,7 @@ static int logpdf_batch_impl(sgp_ctx* ctx, int nspec, const sgp_cov_spec* const*
   for (int b = 1; b < nspec; ++b) same = same && rows_of(specs[b]) == N;
   int64_t n_pad = 0, m_tot = 0;
   if (N >= 1) sgp_geometry(N, 1, &n_pad, &m_tot);
-  const bool pooled = same && N >= 1 && nspec >= 2 && !ctx->multi && ctx->refine == 1 && ctx->dataflow != 0 &&
+  const bool pooled = same && N >= 1 && nspec >= 2 && !ctx->multi && ctx->dataflow != 0 &&
                       ctx->batch_max_n > 0 && n_pad <= ctx->batch_max_n &&
                       (noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG);
   if (!pooled) {
@@ -1715,11 +1681,11 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   CHECK_ARG(spec->symmetric, "sgp_logpdf_grad: spec must be symmetric");
   CHECK_ARG(noise_kind >= SGP_NOISE_SCALAR && noise_kind <= SGP_NOISE_DENSE, "sgp_logpdf_grad: bad noise kind");
   CtxScope scope(ctx);
-  // a multi-GPU context shards the gradient w.r.t. the kernel terms, the noise, y and the mean (multi.hip); the
-  // input-point / function-scale gradients and a dense Sigma_y run on devices[0]
-  if (ctx->multi && !grad_inputs && !grad_rowscale && noise_kind != SGP_NOISE_DENSE)
+  // a multi-GPU context shards the gradient -- kernel terms, noise, y, the mean and (round 6) the input points and function
+  // scales (multi.hip); a dense Sigma_y runs on devices[0]
+  if (ctx->multi && noise_kind != SGP_NOISE_DENSE)
     return sgp_multi_logpdf_grad(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise, grad_coef,
-                                 grad_inscale);
+                                 grad_inscale, grad_inputs, grad_rowscale);
   SpecGuard g;
   CHECK_RC(dspec_create(ctx, spec, &g.ds));
   const sgp_dspec* ds = g.ds;
@@ -2443,45 +2409,22 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
   const int nsplit = 8;  // one K slice per XCD (gemm_nt.hip, klo == 3)
   const long stride = ldg * m_pad;
   CHECK_RC(dR.alloc((size_t)CH * m_pad));
-  // Two chunks in flight (round 4, SGP_VFE_OVERLAP=1; OFF by default): the Gram product of chunk c (split-K MFMA GEMM + its
-  // fixed-order reduction into G, on the context's second stream) runs while chunk c + 1 is assembled, solved against Lz
-  // and transposed on the first; the transposed chunk A' is double-buffered; G is still accumulated in chunk order.
-  // Measured on the N = 262144, M = 4096 bound (profiles/r04_experiments/elbo_c4.txt): 159.7 -> 161.5 ms -- two MFMA-bound
-  // streams sharing the chip lose more to each other than the solve's latency-bound substitutions leave idle, the same
-  // finding as the factorisation's look-ahead at N = 65536.
-  const bool overlap = n_rows > CH && getenv("SGP_VFE_OVERLAP") && atoi(getenv("SGP_VFE_OVERLAP")) != 0 &&
-                       !ctx->stage_timing;
-  DevBuf dAt2;
+  // (Round 4 also built "two chunks in flight" -- the Gram product of chunk c on the second stream while chunk c + 1 is assembled
+  // and solved on the first; measured on the N = 262144, M = 4096 bound, profiles/r04_experiments/elbo_c4.txt: 159.7 -> 161.5 ms,
+  // two MFMA-bound streams lose more to each other than the solve's substitutions leave idle.  Removed in round 6.)
   CHECK_RC(dAt.alloc((size_t)m_pad * CH));
-  if (overlap) CHECK_RC(dAt2.alloc((size_t)m_pad * CH));
   {   // slabs of the chunk lengths actually used: the `sub` split depends on K % (8 sub 16), so a shorter LAST chunk can
       // need more slabs than a full one (advisor, round 4: SGP_VFE_CHUNK = 768, M = 4096, 1280 rows -> 8 vs 32)
     const long last = n_rows % CH == 0 ? std::min(CH, n_rows) : n_rows % CH;
     const long slabs = std::max(splitk_slabs(m_pad, std::min(CH, n_rows), nsplit), splitk_slabs(m_pad, last, nsplit));
     CHECK_RC(dPart.alloc((size_t)slabs * stride));
   }
-  hipStream_t sg = overlap ? ctx->stream2 : s;
-  struct ChunkEvents {   // destroyed on every exit path
-    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
-    ~ChunkEvents() {
-      for (auto e : ready)
-        if (e) hipEventDestroy(e);
-      for (auto e : done)
-        if (e) hipEventDestroy(e);
-    }
-  } cev;
-  if (overlap)
-    for (int b = 0; b < 2; ++b) {
-      SGP_HIP(hipEventCreateWithFlags(&cev.ready[b], hipEventDisableTiming));
-      SGP_HIP(hipEventCreateWithFlags(&cev.done[b], hipEventDisableTiming));
-    }
   // ---- row chunks
   long chunk = 0;
   for (long r0 = 0; r0 < n_rows; r0 += CH, ++chunk) {
     const long ch = std::min(CH, n_rows - r0);            // rows of this chunk (multiple of 128)
     const long nv = std::max<long>(0, std::min(N - r0, ch));  // of which real data points
-    const int b = overlap ? (int)(chunk & 1) : 0;
-    double* At = b ? dAt2.p : dAt.p;
+    double* At = dAt.p;
     tm.mark(1);
     // (a full chunk of an unpadded M is written entry for entry by the assembly: nothing to clear)
     if (nv < ch || M < m_pad) SGP_HIP(hipMemsetAsync(dR.p, 0, sizeof(double) * ch * m_pad, s));
@@ -2496,21 +2439,11 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
     hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, dR.p, ch, ch, ddelta.p + r0, d_dots, sq.p,
                        r0 > 0 ? 1 : 0, drsig.p + r0);
     SGP_HIP(hipGetLastError());
-    if (overlap && chunk >= 2) SGP_HIP(hipStreamWaitEvent(s, cev.done[b], 0));   // the Gram product that read this buffer
     CHECK_RC(launch_transpose_add(dR.p, ch, ch, m_pad, At, m_pad, nullptr, s, drsig.p + r0));
     tm.mark(4);
-    if (overlap) {
-      SGP_HIP(hipEventRecord(cev.ready[b], s));
-      SGP_HIP(hipStreamWaitEvent(sg, cev.ready[b], 0));
-    }
     // (the split-K slices need ch to be a multiple of 16 * nsplit = 128: it is)
-    CHECK_RC(launch_gemm_nt_splitk(At, m_pad, At, m_pad, dPart.p, ldg, m_pad, m_pad, ch, nsplit, stride, 1, sg));
-    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, r0 > 0 ? 1.0 : 0.0, 1, sg, ch));
-    if (overlap) SGP_HIP(hipEventRecord(cev.done[b], sg));
-  }
-  if (overlap) {   // join: everything the Gram stream did is visible to the first stream
-    SGP_HIP(hipEventRecord(cev.done[0], sg));
-    SGP_HIP(hipStreamWaitEvent(s, cev.done[0], 0));
+    CHECK_RC(launch_gemm_nt_splitk(At, m_pad, At, m_pad, dPart.p, ldg, m_pad, m_pad, ch, nsplit, stride, 1, s));
+    CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG, ldg, m_pad, m_pad, 1.0, r0 > 0 ? 1.0 : 0.0, 1, s, ch));
   }
   tm.mark(5);
   CHECK_RC(launch_sum_array(sq.p, m_pad, d_sc + 3, s));
@@ -3511,259 +3444,6 @@ extern "C" int sgp_dev_rowsumsq(sgp_ctx* ctx, const double* d_rows, int64_t ld, 
 }
 
 // ---------------------------------------------------------------------------------------
-// micro-benchmarks
-// ---------------------------------------------------------------------------------------
-extern "C" int sgp_bench_mfma_f64(sgp_ctx* ctx, int iters, double* tflops_out, double* layout_maxerr_out) {
-  CHECK_ARG(ctx && tflops_out && layout_maxerr_out, "sgp_bench_mfma_f64: NULL argument");
-  CtxScope scope(ctx);
-  return run_mfma_bench(ctx->stream, iters, tflops_out, layout_maxerr_out);
-}
-extern "C" int sgp_bench_hbm(sgp_ctx* ctx, int64_t bytes, int iters, double* write_gbs_out, double* copy_gbs_out) {
-  CHECK_ARG(ctx && write_gbs_out && copy_gbs_out, "sgp_bench_hbm: NULL argument");
-  CtxScope scope(ctx);
-  return run_hbm_bench(ctx->stream, bytes, iters, write_gbs_out, copy_gbs_out);
-}
-
-// CU census under a CU mask: which (XCD, SE, SH, CU) the workgroups of a stream created with `mask` land on
-// (cnt[xcc << 8 | HW_ID[15:8]]); one workgroup per CU at a time (80 KB of LDS), each staying ~10 us.
-__global__ __launch_bounds__(256) void cu_census_kernel(unsigned* cnt, long long spin) {
-  extern __shared__ double census_lds[];
-  if (threadIdx.x == 0) {
-    const unsigned hw = __builtin_amdgcn_s_getreg(63492);   // HW_ID
-    const unsigned xcc = __builtin_amdgcn_s_getreg(6164);   // XCC_ID 3:0
-    atomicAdd(&cnt[((xcc & 15) << 8) | ((hw >> 8) & 255)], 1u);
-    census_lds[0] = 0.0;
-  }
-  const long long t0 = (long long)__builtin_amdgcn_s_memtime();
-  while ((long long)__builtin_amdgcn_s_memtime() - t0 < spin) __builtin_amdgcn_s_sleep(8);
-}
-extern "C" int sgp_bench_cumask(sgp_ctx* ctx, const uint32_t* mask, int words, int nwg, unsigned* out /* [4096] */) {
-  CHECK_ARG(ctx && out && nwg > 0, "sgp_bench_cumask: NULL argument");
-  CtxScope scope(ctx);
-  hipStream_t st = nullptr;
-  if (mask && words > 0) SGP_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
-  else SGP_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-  unsigned* d = nullptr;
-  if (hipMalloc(&d, 4096 * sizeof(unsigned)) != hipSuccess) { hipStreamDestroy(st); set_error("hipMalloc failed"); return -2; }
-  hipMemsetAsync(d, 0, 4096 * sizeof(unsigned), st);
-  SGP_LDS_ATTR_ONCE(cu_census_kernel, 81920);
-  hipLaunchKernelGGL(cu_census_kernel, dim3((unsigned)nwg), dim3(256), 81920, st, d, 20000LL);
-  hipError_t e = hipStreamSynchronize(st);
-  if (e == hipSuccess) e = hipMemcpy(out, d, 4096 * sizeof(unsigned), hipMemcpyDeviceToHost);
-  hipFree(d);
-  hipStreamDestroy(st);
-  SGP_HIP(e);
-  return 0;
-}
-
-__global__ void fill_rand_kernel(double* p, long n, unsigned long long seed) {
-  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  unsigned long long x = seed + (unsigned long long)i * 0x9E3779B97F4A7C15ULL;
-  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 27; x *= 0x94D049BB133111EBULL; x ^= x >> 31;
-  p[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) * 2.0 - 1.0;
-}
-
-// one potrf_diag launch on a well-conditioned 128 x 128 tile with s_memtime stamps of wave 0 at its phase
-// boundaries (stamps_out[64], ticks; 0-terminated) and the launch time by HIP events (us_out)
-extern "C" int sgp_bench_potrf(sgp_ctx* ctx, int iters, double* us_out, long long* stamps_out) {
-  CHECK_ARG(ctx && us_out && stamps_out, "sgp_bench_potrf: NULL argument");
-  CtxScope scope(ctx);
-  hipStream_t s = ctx->stream;
-  DevBuf A, A0;
-  CHECK_RC(A.alloc((size_t)TILE * TILE));
-  CHECK_RC(A0.alloc((size_t)TILE * TILE));
-  std::vector<double> h((size_t)TILE * TILE);
-  for (int c = 0; c < TILE; ++c)
-    for (int r = 0; r < TILE; ++r) h[r + (size_t)c * TILE] = (r == c ? 2.0 : 0.0) + std::exp(-0.02 * (r - c) * (r - c));
-  SGP_HIP(hipMemcpy(A0.p, h.data(), sizeof(double) * TILE * TILE, hipMemcpyHostToDevice));
-  long long* d_dbg = nullptr;
-  SGP_HIP(hipMalloc(&d_dbg, sizeof(long long) * 64));
-  SGP_HIP(hipMemset(d_dbg, 0, sizeof(long long) * 64));
-  hipEvent_t e0, e1;
-  SGP_HIP(hipEventCreate(&e0));
-  SGP_HIP(hipEventCreate(&e1));
-  double tot = 0;
-  for (int it = 0; it < iters + 1; ++it) {
-    SGP_HIP(hipMemcpyAsync(A.p, A0.p, sizeof(double) * TILE * TILE, hipMemcpyDeviceToDevice, s));
-    SGP_HIP(hipEventRecord(e0, s));
-    if (it == iters)
-      CHECK_RC(launch_potrf_diag_dbg(A.p, TILE, ctx->d_invd, ctx->d_slots, ctx->d_info, d_dbg, s));
-    else
-      CHECK_RC(launch_potrf_diag(A.p, TILE, ctx->d_invd, ctx->d_slots, ctx->d_info, 0, s));
-    SGP_HIP(hipEventRecord(e1, s));
-    SGP_HIP(hipEventSynchronize(e1));
-    float ms = 0;
-    SGP_HIP(hipEventElapsedTime(&ms, e0, e1));
-    if (it > 0 && it < iters) tot += ms;
-  }
-  *us_out = tot / std::max(1, iters - 1) * 1e3;
-  SGP_HIP(hipMemcpy(stamps_out, d_dbg, sizeof(long long) * 64, hipMemcpyDeviceToHost));
-  hipFree(d_dbg);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  return 0;
-}
-
-// potrf_diag under the look-ahead's contention: `gemm_launches` trailing updates C(m^2 lower) -= P P' (depth k) are
-// queued on the update stream, then n potrf_diag launches go one by one down the panel stream: us_out[i] is launch
-// i's time by HIP events (it includes the wait for a free workgroup slot), ticks_out[i] its own s_memtime span of
-// wave 0 (the time it runs once resident).  busy_out[i] = 1 while the updates had not finished.
-extern "C" int sgp_bench_potrf_contended(sgp_ctx* ctx, int64_t m, int64_t k, int gemm_launches, int n,
-                                         double* us_out, long long* ticks_out, int* busy_out) {
-  CHECK_ARG(ctx && us_out && ticks_out && busy_out && n > 0, "sgp_bench_potrf_contended: NULL argument");
-  CHECK_ARG(m % TILE == 0 && k % 16 == 0 && m > 0, "sgp_bench_potrf_contended: bad sizes");
-  CtxScope scope(ctx);
-  hipStream_t s = ctx->stream, s2 = ctx->stream2;
-  DevBuf P, Cm, A, A0;
-  CHECK_RC(P.alloc((size_t)m * k));
-  CHECK_RC(Cm.alloc((size_t)m * m));
-  CHECK_RC(A.alloc((size_t)TILE * TILE));
-  CHECK_RC(A0.alloc((size_t)TILE * TILE));
-  std::vector<double> h((size_t)TILE * TILE);
-  for (int c = 0; c < TILE; ++c)
-    for (int r = 0; r < TILE; ++r) h[r + (size_t)c * TILE] = (r == c ? 2.0 : 0.0) + std::exp(-0.02 * (r - c) * (r - c));
-  SGP_HIP(hipMemcpy(A0.p, h.data(), sizeof(double) * TILE * TILE, hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(fill_rand_kernel, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, s2, P.p, m * k, 99ULL);
-  SGP_HIP(hipMemsetAsync(Cm.p, 0, sizeof(double) * m * m, s2));
-  long long* d_dbg = nullptr;
-  SGP_HIP(hipMalloc(&d_dbg, sizeof(long long) * 64));
-  SGP_HIP(hipMemset(d_dbg, 0, sizeof(long long) * 64));
-  hipEvent_t e0, e1, eg;
-  SGP_HIP(hipEventCreate(&e0));
-  SGP_HIP(hipEventCreate(&e1));
-  SGP_HIP(hipEventCreate(&eg));
-  SGP_HIP(hipStreamSynchronize(s2));
-  int rc = 0;
-  for (int i = 0; i < gemm_launches && rc == 0; ++i) rc = launch_gemm_nt_update(P.p, m, Cm.p, m, m, m, k, s2);
-  if (rc == 0 && hipEventRecord(eg, s2) != hipSuccess) rc = -2;
-  long long st[64];
-  for (int i = 0; i < n && rc == 0; ++i) {
-    hipMemcpyAsync(A.p, A0.p, sizeof(double) * TILE * TILE, hipMemcpyDeviceToDevice, s);
-    hipStreamSynchronize(s);
-    hipEventRecord(e0, s);
-    rc = launch_potrf_diag_dbg(A.p, TILE, ctx->d_invd, ctx->d_slots, ctx->d_info, d_dbg, s);
-    hipEventRecord(e1, s);
-    hipEventSynchronize(e1);
-    busy_out[i] = hipEventQuery(eg) == hipErrorNotReady ? 1 : 0;
-    float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
-    us_out[i] = ms * 1e3;
-    hipMemcpyAsync(st, d_dbg, sizeof(st), hipMemcpyDeviceToHost, s);
-    hipStreamSynchronize(s);
-    long long last = 0;
-    for (int q = 0; q < 64; ++q)
-      if (st[q]) last = st[q];
-    ticks_out[i] = last - st[0];
-  }
-  hipStreamSynchronize(s2);
-  hipFree(d_dbg);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  hipEventDestroy(eg);
-  return rc;
-}
-
-// one lower update C(m x m) -= P P' (depth k) with per-workgroup phase stamps: out[8 * id + {0: entry, 1: first operand
-// chunk + old C tile landed, 2: contraction done, 3: stores drained, 4: XCC_ID << 16 | HW_ID, 5: tile row, 6: tile col}]
-// (s_memtime ticks; 0 rows = ids without a tile).  *n_ids = workgroups of the launch (call with out == NULL to size).
-extern "C" int sgp_bench_gemm_stamps(sgp_ctx* ctx, int64_t m, int64_t k, long long* out, int64_t cap, int64_t* n_ids) {
-  CHECK_ARG(ctx && n_ids && m % TILE == 0 && k % 16 == 0, "sgp_bench_gemm_stamps: bad argument");
-  CtxScope scope(ctx);
-  long ids = 0;
-  CHECK_RC(launch_gemm_nt_stamps(nullptr, m, nullptr, m, m, m, k, nullptr, &ids, ctx->stream));
-  *n_ids = ids;
-  if (!out) return 0;
-  CHECK_ARG(cap >= 8 * ids, "sgp_bench_gemm_stamps: buffer too small");
-  hipStream_t s = ctx->stream;
-  DevBuf A, C, D;
-  CHECK_RC(A.alloc((size_t)m * k));
-  CHECK_RC(C.alloc((size_t)m * m));
-  CHECK_RC(D.alloc((size_t)8 * ids));
-  hipLaunchKernelGGL(fill_rand_kernel, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, s, A.p, m * k, 1234ULL);
-  SGP_HIP(hipMemsetAsync(C.p, 0, sizeof(double) * m * m, s));
-  CHECK_RC(launch_gemm_nt_update(A.p, m, C.p, m, m, m, k, s));   // warm-up (clocks, caches)
-  SGP_HIP(hipMemsetAsync(D.p, 0, sizeof(double) * 8 * ids, s));
-  // SGP_STAMP_BETA0=1 (experiment): beta = 0, i.e. no old C tile to fetch -- isolates its share of the prologue
-  // SGP_STAMP_SCRAMBLE=<multiplier> (experiment): tiles dealt to the workgroup ids through id -> id * multiplier mod n_ids
-  // (made coprime here), i.e. no operand panel shared between neighbouring workgroups
-  long scr = getenv("SGP_STAMP_SCRAMBLE") ? atol(getenv("SGP_STAMP_SCRAMBLE")) : 0;
-  auto gcd = [](long a, long b) { while (b) { long t = a % b; a = b; b = t; } return a; };
-  // SGP_STAMP_ROTATE=1 on top: every workgroup also starts at its own k offset (desynchronised panel reads)
-  while (scr > 1 && gcd(scr, ids) != 1) ++scr;
-  if (scr > 1 && getenv("SGP_STAMP_ROTATE")) scr = -scr;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  SGP_HIP(hipEventCreate(&e0));
-  SGP_HIP(hipEventCreate(&e1));
-  SGP_HIP(hipEventRecord(e0, s));
-  int rc_st = launch_gemm_nt_stamps(A.p, m, C.p, m, m, m, k, (long long*)D.p, &ids, s, getenv("SGP_STAMP_BETA0") ? 0.0 : 1.0,
-                                    (scr > 1 || scr < -1) ? scr : 0);
-  hipEventRecord(e1, s);
-  hipStreamSynchronize(s);
-  float ms_st = 0;
-  hipEventElapsedTime(&ms_st, e0, e1);
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  if (rc_st) return rc_st;
-  if (getenv("SGP_STAMP_VERBOSE")) fprintf(stderr, "sgp_bench_gemm_stamps: launch %.3f ms (HIP events)\n", ms_st);
-  SGP_HIP(hipStreamSynchronize(s));
-  SGP_HIP(hipMemcpy(out, D.p, sizeof(long long) * 8 * ids, hipMemcpyDeviceToHost));
-  return 0;
-}
-
-extern "C" int sgp_bench_gemm(sgp_ctx* ctx, int64_t m, int64_t n, int64_t k, int lower_only,
-                              int iters, double* tflops_out, double* maxerr_out) {
-  CHECK_ARG(ctx && tflops_out && maxerr_out, "sgp_bench_gemm: NULL argument");
-  CHECK_ARG(m % TILE == 0 && n % TILE == 0 && k % 16 == 0 && m >= n, "sgp_bench_gemm: bad sizes");
-  CtxScope scope(ctx);
-  hipStream_t s = ctx->stream;
-  DevBuf A, C;
-  CHECK_RC(A.alloc((size_t)m * k));
-  CHECK_RC(C.alloc((size_t)m * n));
-  hipLaunchKernelGGL(fill_rand_kernel, dim3((unsigned)((m * k + 255) / 256)), dim3(256), 0, s, A.p, m * k, 1234ULL);
-  SGP_HIP(hipMemsetAsync(C.p, 0, sizeof(double) * m * n, s));
-  // C = -A[0:m] A[0:n]'
-  CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, (lower_only & 1) ? 0 : NOMASK, 0, 0, s));
-  SGP_HIP(hipStreamSynchronize(s));
-  // spot check 64 entries in the lower part against a host dot product
-  std::vector<double> hA((size_t)m * k);
-  SGP_HIP(hipMemcpy(hA.data(), A.p, sizeof(double) * m * k, hipMemcpyDeviceToHost));
-  double me = 0;
-  for (int q = 0; q < 64; ++q) {
-    long c = (long)((q * 7919L) % n), r = c + (long)((q * 104729L) % (m - c));
-    double ref = 0;
-    for (long kk = 0; kk < k; ++kk) ref -= hA[r + kk * m] * hA[c + kk * m];
-    double got = 0;
-    SGP_HIP(hipMemcpy(&got, C.p + r + c * m, sizeof(double), hipMemcpyDeviceToHost));
-    me = std::max(me, std::fabs(got - ref));
-  }
-  *maxerr_out = me;
-  hipEvent_t e0, e1;
-  SGP_HIP(hipEventCreate(&e0));
-  SGP_HIP(hipEventCreate(&e1));
-  SGP_HIP(hipEventRecord(e0, s));
-  const bool reg_baseline = (lower_only & 2) != 0;  // bench-only: bit 1 = register-staged baseline kernel
-  const long REG_BASELINE = -(1L << 50);            // (an argument of this one call: no process-global switch)
-  lower_only &= 1;
-  for (int i = 0; i < iters; ++i)
-    if (reg_baseline)
-      CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, lower_only ? 0 : NOMASK, 0, REG_BASELINE, s));
-    else if (lower_only)
-      CHECK_RC(launch_gemm_nt_update(A.p, m, C.p, m, m, n, k, s));  // the production trailing-update symbol
-    else
-      CHECK_RC(launch_gemm_nt(A.p, m, A.p, m, C.p, m, m, n, k, -1.0, 1.0, NOMASK, 0, 0, s));
-  SGP_HIP(hipEventRecord(e1, s));
-  SGP_HIP(hipEventSynchronize(e1));
-  float ms = 0;
-  SGP_HIP(hipEventElapsedTime(&ms, e0, e1));
-  double fl = lower_only ? update_flops(m, n, k) : 2.0 * (double)m * (double)n * (double)k;
-  *tflops_out = fl * iters / (ms * 1e-3) / 1e12;
-  hipEventDestroy(e0);
-  hipEventDestroy(e1);
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------
 // driver.h: the routines above for the multi-GPU driver (multi.hip)
 // ---------------------------------------------------------------------------------------
 __global__ void axpy_block_kernel(double* C, long ldc, const double* S, long lds, long nr, long nc, double a) {
@@ -3789,7 +3469,7 @@ int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, 
                      double* d_invstore, hipStream_t s, int df, const sz_word* d_nz, int nz_words, const DfPanel* px) {
   CHECK_ARG(w % TILE == 0 && m % TILE == 0 && m >= w, "drv_panel_factor: bad sizes");
   long n_fact = w;
-  if (df && ctx->refine == 1) {
+  if (df) {
     if (px) n_fact = px->n_fact;
     CHECK_ARG(n_fact / TILE <= ctx->n_slots, "drv_panel_factor: panel too wide for the logdet slot buffer");
     CHECK_RC(df_scratch(ctx, m, 1, d_invstore ? 0 : n_fact, s));

@@ -210,7 +210,7 @@ int launch_chol_dataflow_batch(const DfProb* probs, int nb, long ld, long n_pad,
 long df_state_words(long m_tot, int nb);   // ints of d_state a launch needs
 constexpr long SGP_DF_STATE_WORDS = 16;   // state words ahead of the per-tile-row progress counters
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
-                          long* n_ids, hipStream_t s, double beta = 1.0, long scr_mul = 0);   // bench: per-workgroup phase stamps of one lower update
+                          long* n_ids, hipStream_t s);   // bench: per-workgroup phase stamps of one lower update
 // batched, segmented trailing update (gemm_nt.hip: gemm_nt_seg_kernel): destination panels, each with a range of source panels
 constexpr int SEG_MAX_SRC = 8, SEG_MAX_DST = 16;
 struct SegSrc {      // a factored column panel, packed: element (global row r, local column k) at base[(r - row0) + k * ld]
@@ -288,7 +288,6 @@ int launch_potrf_diag_dbg(double* A, long ld, double* d_invd, double* d_logdet_s
                           hipStream_t s);
 int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
                        long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk = nullptr);
-int launch_trtri(const double* L, long ld, const double* d_invd, double* d_w, hipStream_t s);
 // fp32 storage, fp64 arithmetic: the panel kernels of the fp32 instantiation (f32.hip)
 int launch_potrf_diag_f32(float* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
                           hipStream_t s);

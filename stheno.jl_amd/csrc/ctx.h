@@ -33,11 +33,19 @@ int sgp_multi_posterior_predict(sgp_mpost* mp, const sgp_cov_spec* cross, const 
                                 const double* mean_s, double* mean_out, double* var_out, double* cov_out,
                                 int64_t ldcov);
 void sgp_multi_posterior_destroy(sgp_mpost* mp);
+// covariance entry points on a multi-GPU context (round 6): column chunks / point slices per rank, no communication
+int sgp_multi_kernelmatrix(struct sgp_ctx* ctx, const sgp_cov_spec* spec, double* K, int64_t ldk);
+int sgp_multi_kernelmatrix_diag(struct sgp_ctx* ctx, const sgp_cov_spec* spec, double* out);
+// state behind the test / diagnosis hooks of include/sthenomi_bench.h (libsthenomi_bench.so: bench_hooks.hip)
+int sgp_multi_set_fault(struct sgp_multi* m, int rank, long step, double stall_s);
+int sgp_multi_is_broken(struct sgp_multi* m);
+const std::vector<double>& sgp_multi_profile_pieces(struct sgp_multi* m);
 // executed / dense tile products of the last sharded factorisation (sgp_ctx_factor_work on a multi-GPU context)
 int sgp_multi_factor_work(struct sgp_multi* m, double* executed, double* dense);
 int sgp_multi_logpdf_grad(struct sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind,
                           const double* noise, const double* y, double* logpdf_out, double* grad_y, double* grad_mean,
-                          double* grad_noise, double* grad_coef, double* grad_inscale);
+                          double* grad_noise, double* grad_coef, double* grad_inscale, double* const* grad_inputs = nullptr,
+                          double* const* grad_rowscale = nullptr);
 // h6: the six terms of the bound (capi.hip: vfe_pipeline).  dLz / d_wz / d_part0 / d_wg non-NULL (device 0
 // buffers): the M x M factors a sparse posterior keeps (d_part0 doubles as rank 0's part and ends up holding chol(A A' + I))
 int sgp_multi_vfe(struct sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
@@ -58,15 +66,11 @@ struct sgp_ctx {
   long wout = 0;  // 0 = automatic
   long wmid = 0;  // middle blocking level of an outer panel (capi.hip: panel_factor_mid); 0 = automatic
   double* d_invd = nullptr;    // 8 x 256: micro-block inverses of the current diagonal block
-  double* d_w = nullptr;       // 128 x 128 scratch inverse
-  double* d_solve = nullptr;   // rows x 128 scratch of the refined panel solve (grown on demand)
-  long n_solve_rows = 0;
   int fuse_potrf = 11;         // SGP_FUSE_POTRF: bit 0 = inner K = 128 updates, bit 1 = outer trailing updates also factor the next
                                // diagonal block (tile (0, 0) of their C) in the workgroup that updates it, bit 3 = that tile goes
                                // from the accumulators straight into the factorisation's LDS layout; bit 2 = at every size
   long fuse_max_n = 32768;     // SGP_FUSE_MAX_N: fused launches only while n_pad is below this (bit 2 lifts the limit)
   int fuse_now = 0;            // what the factorisation under way uses (set by chol_bordered / sgp_dev_panel_factor)
-  int refine = 1;              // SGP_REFINE=0: plain explicit-inverse panel solve (A/B timing only)
   double* d_slots = nullptr;   // per-128-block logdet contributions
   long n_slots = 0;
   double* d_scal = nullptr;    // [0] logdet, [1] misc, [16 ..] per-rhs sums
@@ -96,7 +100,6 @@ struct sgp_ctx {
   long batch_max_n = 12288;
   int batch_fat = 1;
   int hybrid_serial = 0;       // SGP_HYBRID_SERIAL = 1: one stream (bench.py: the update launches' rate with the chip to themselves)
-  int hybrid_grow = 1;         // SGP_HYBRID_GROW = 0: not for the gradient path's factorisations (A/B)
   bool df_timed_out = false;   // the last dataflow launch ran into its wait bound (fetch_info)
   int df_fallback = 1;         // SGP_DF_FALLBACK=0: report the timeout instead (the kernel's own error path, tests)
   // structural zeros (common.h; capi.hip: sz_build): SGP_STRUCT_ZEROS = 0 switches the skipping off (A/B)
@@ -151,7 +154,7 @@ struct sgp_ctx {
   // device-memory cache (see sgp_pool_block); guarded by mu
   std::vector<sgp_pool_block> pool;
   size_t pool_bytes = 0;
-  int pool_enabled = 1;        // SGP_POOL=0: plain hipMalloc / hipFree per call (A/B timing)
+  int pool_enabled = 1;
   // pinned staging area for small host -> device uploads (spec inputs, y, mean): one async copy
   // per call instead of one blocking hipMemcpy per array
   char* h_stage = nullptr;

@@ -432,16 +432,13 @@ int panel_factor_mid_f32(sgp_ctx* ctx, float* P, long ld, long m, long w, long g
 }
 
 int chol_f32(sgp_ctx* ctx, float* A, long ld, long n_pad, long m_tot, hipStream_t s) {
-  // Round 4: from SGP_F32_SERIAL_N columns on (default 32768) the fp64 driver's serial deep schedule -- outer panels of
+  // Round 4: from 32768 columns on the fp64 driver's serial deep schedule -- outer panels of
   // 4096 columns factored by recursive halving down to 512, one K = 4096 trailing update per panel, no look-ahead: an fp32
   // tile runs twice as fast as an fp64 one, so the per-tile prologue and the C-tile traffic of shallow (K = 512) updates
   // weigh twice as much.
-  static const long serial_n = getenv("SGP_F32_SERIAL_N") ? atol(getenv("SGP_F32_SERIAL_N")) : 32768;
-  static const long wout_env = getenv("SGP_F32_WOUT") ? atol(getenv("SGP_F32_WOUT")) / TILE * TILE : 0;
-  static const long wmid_env = getenv("SGP_F32_WMID") ? atol(getenv("SGP_F32_WMID")) / TILE * TILE : 0;
-  const bool deep = n_pad >= serial_n;
-  const long W = wout_env > 0 ? wout_env : deep ? 4096 : (n_pad <= 2048 ? n_pad : (n_pad <= 8192 ? 1024 : 512));
-  const long WMID = deep ? (wmid_env > 0 ? wmid_env : 512) : 0;
+  const bool deep = n_pad >= 32768;
+  const long W = deep ? 4096 : (n_pad <= 2048 ? n_pad : (n_pad <= 8192 ? 1024 : 512));
+  const long WMID = deep ? 512 : 0;
   const bool la = ctx->lookahead && s == ctx->stream && !deep;
   hipStream_t sB = la ? ctx->stream2 : s;
   bool rest_pending = false;

@@ -67,8 +67,8 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
                                                  long ldc, long K, double alpha, double beta, long mask_off,
                                                  long n_tr, long n_tc, long c_slice_stride, const double* Cin,
                                                  long ldcin, int klo, double* smem, long& tr, long& tc,
-                                                 long long* dbg = nullptr, long scr_mul = 0, long scr_mod = 0,
-                                                 const TileSkip* sk = nullptr, bool keep_first = false) {
+                                                 long long* dbg = nullptr, const TileSkip* sk = nullptr,
+                                                 bool keep_first = false) {
   // STAMP (bench only, sgp_bench_gemm_stamps): s_memtime of thread 0 at the phase boundaries of the tile program
   long long st0 = 0, st1 = 0, st2 = 0, stA = 0;
   if (STAMP) st0 = (long long)__builtin_amdgcn_s_memtime();
@@ -103,11 +103,7 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
     C += (sl * sub + q) * c_slice_stride;
     K = kk;
   } else {
-    // (STAMP only, experiment: ids dealt to the tiles through a multiplicative permutation -- neighbouring workgroups
-    // no longer share operand panels, which prices the L2 locality of the production order)
-    if (STAMP && scr_mod > 0) {
-      if (!tile_of_id(((long)blockIdx.x * (scr_mul < 0 ? -scr_mul : scr_mul)) % scr_mod, n_tr, n_tc, mask_off, tr, tc)) return false;
-    } else if (sk && sk->cmap) {
+    if (sk && sk->cmap) {
       const int x = (int)(blockIdx.x & 7), pos = (int)(blockIdx.x >> 3);
       if (pos >= sk->cmap[x]) return false;
       if (!tile_of_id((long)sk->cmap[16 + (long)x * sk->cstride + pos] * 8 + x, n_tr, n_tc, mask_off, tr, tc)) return false;
@@ -187,10 +183,7 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
   if (klo == 2 && (tr + 1) * (TILE / KB) < nchunks) nchunks = (tr + 1) * (TILE / KB);
   // prologue: the first operand chunk and the old C tile are requested together, so their
   // latencies overlap (one wait for both)
-  // (STAMP + scramble: every workgroup starts its contraction at its own k offset and wraps around -- the workgroups of
-  // a launch no longer read the same k slice of the panels at the same time, the access pattern of desynchronised tiles)
-  const long rot = (STAMP && scr_mod > 0 && scr_mul < 0) ? (((long)blockIdx.x * 40503L) % nchunks) : 0;
-  auto kof = [&](long c) { return STAMP ? ((c + rot) % nchunks) * KB : c * KB; };
+  auto kof = [&](long c) { return c * KB; };
   if (cbeg < nchunks) dma(kof(cbeg), 0);
   if (beta != 0.0) {
 #pragma unroll
@@ -343,26 +336,19 @@ __device__ __forceinline__ bool gemm_nt_dma_tile(const double* A, long lda, cons
 
 // bench only: the production tile program with phase stamps (own symbol: the production kernels' code is untouched)
 __global__ __launch_bounds__(512, 4) void gemm_nt_dma_stamp_kernel(const double* A, long lda, double* C, long ldc, long K,
-                                                                   long n_tr, long n_tc, long long* dbg, double beta,
-                                                                   long scr_mul, long scr_mod) {
+                                                                   long n_tr, long n_tc, long long* dbg) {
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   long tr, tc;
-  gemm_nt_dma_tile<false, true>(A, lda, A, lda, C, ldc, K, -1.0, beta, 0L, n_tr, n_tc, 0L, C, ldc, 0, smem, tr, tc, dbg,
-                                scr_mul, scr_mod);
+  gemm_nt_dma_tile<false, true>(A, lda, A, lda, C, ldc, K, -1.0, 1.0, 0L, n_tr, n_tc, 0L, C, ldc, 0, smem, tr, tc, dbg);
 }
 
 int launch_gemm_nt_stamps(const double* P, long ldp, double* C, long ldc, long M, long Nc, long K, long long* dbg,
-                          long* n_ids, hipStream_t s, double beta, long scr_mul) {
+                          long* n_ids, hipStream_t s) {
   long n_tr = M / TILE, n_tc = Nc / TILE;
   long per_xcd = tri_ids_per_xcd(tri_shape(n_tr, n_tc, -1));
   *n_ids = per_xcd * 8;
   if (!dbg) return 0;
-  // SGP_STAMP_LDS_PAD=<bytes> (experiment): unused dynamic LDS on top of the tile program's 73.7 KB -- from 12.6 KB on only
-  // ONE workgroup fits a CU (8 waves, two per SIMD): what the tile program delivers at the occupancy a 256 x 128 tile
-  // (128 accumulator registers per wave) would have to live with
-  const size_t pad = getenv("SGP_STAMP_LDS_PAD") ? (size_t)atol(getenv("SGP_STAMP_LDS_PAD")) : 0;
-  hipLaunchKernelGGL(gemm_nt_dma_stamp_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), pad, s, P, ldp, C, ldc, K, n_tr,
-                     n_tc, dbg, beta, scr_mul, scr_mul != 0 ? per_xcd * 8 : 0L);
+  hipLaunchKernelGGL(gemm_nt_dma_stamp_kernel, dim3((unsigned)(per_xcd * 8)), dim3(512), 0, s, P, ldp, C, ldc, K, n_tr, n_tc, dbg);
   SGP_HIP(hipGetLastError());
   return 0;
 }
@@ -377,7 +363,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_kernel(const double* A, lo
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * KB * LDS_LD];
   long tr, tc;
   gemm_nt_dma_tile<false>(A, lda, B, ldb, C, ldc, K, alpha, beta, mask_off, n_tr, n_tc, c_slice_stride, Cin, ldcin,
-                          klo, smem, tr, tc, nullptr, 0, 0, &sk);
+                          klo, smem, tr, tc, nullptr, &sk);
 }
 
 // Fused lower update + Cholesky of the NEXT diagonal block (SGP_FUSE_POTRF, capi.hip: panel_factor /
@@ -400,7 +386,7 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_dma_potrf_kernel(const double*
   extern __shared__ __attribute__((aligned(16))) double dyn_smem[];
   long tr, tc;
   const bool live = gemm_nt_dma_tile<HANDOFF>(A, lda, B, ldb, C, ldc, K, -1.0, 1.0, 0L, n_tr, n_tc, 0L, C, ldc, 0,
-                                              dyn_smem, tr, tc, nullptr, 0, 0, &sk, true);
+                                              dyn_smem, tr, tc, nullptr, &sk, true);
   if (live && tr == 0 && tc == 0) {   // workgroup-uniform
     if (!HANDOFF) {
       // the tile was written by all eight waves: stores complete + visible to the workgroup before it is re-read
@@ -1029,9 +1015,8 @@ int launch_gemm_nt_lz(const double* L, long ldl, const double* Zt, long ldz, dou
 // that is a whole number > 1 and the pieces stay multiples of the 16-column chunk; 1 = none.  The slab buffer then holds
 // 8 * sub slabs (launch_gemm_nt_splitk / launch_splitk_reduce callers size it with splitk_slabs).
 long splitk_sub(long M, long K) {
-  static const bool off = getenv("SGP_SPLITK_SUB") && atoi(getenv("SGP_SPLITK_SUB")) == 0;
   const long n_t = M / TILE, tiles = n_t * (n_t + 1) / 2, left = tiles % 64;
-  if (off || left == 0 || tiles < 64 || 64 % left) return 1;
+  if (left == 0 || tiles < 64 || 64 % left) return 1;
   const long sub = 64 / left;
   if (sub < 2 || sub > 8 || K % (8 * sub * KB)) return 1;
   return sub;

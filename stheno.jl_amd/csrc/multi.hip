@@ -172,7 +172,6 @@ struct sgp_multi {
   // first of those launches as an external source: the diagonal chain starts as soon as the first tile column has seen it.
   // Off together with the primary context's hybrid switch (SGP_HYBRID=0; the dataflow time-out fallback reruns that way).
   int panel_df = 1, fuse_la = 1;
-  std::vector<long> pieces;   // SGP_MULTI_PIECES: uneven sub-panel widths of a full panel (multi.hip: factorize), empty: regular
   int compact = 1;          // SGP_MULTI_COMPACT: compacted live-tile ids in the far update launches of a structured model (2: at any size)
   sgp_ctx* primary = nullptr;
   // One enqueue thread per rank for the sweep of the sharded factorisation (SGP_MULTI_THREADS: 1 / 0; -1 = automatic: on
@@ -407,6 +406,56 @@ void sgp_multi_destroy(sgp_multi* m) {
   delete m;
 }
 
+// Run-time switches of a multi-GPU context: one table, read once at creation (docs/03_kernels.md section 3.5 lists every entry
+// with the test that exercises it).  Layout and schedule switches select between forms that give the same bits (for one panel
+// layout); the time bounds and the fault hook belong to the failure path (tests/test_gpu_multi_faults.py).
+namespace {
+struct MultiKnob {
+  const char* name;
+  void (*set)(sgp_multi*, const char*);
+};
+const MultiKnob kMultiKnobs[] = {
+    {"SGP_MULTI_TRANSPORT", [](sgp_multi*, const char*) {}},      // rccl | p2p | auto (read by sgp_ctx_create_multi itself)
+    {"SGP_MULTI_ALLOW_STAGED", [](sgp_multi*, const char*) {}},   // accept peer copies staged through the host (ditto)
+    {"SGP_MULTI_BCAST", [](sgp_multi* m, const char* v) { m->allgather = strcmp(v, "direct") != 0; }},
+    {"SGP_MULTI_PANEL", [](sgp_multi* m, const char* v) { if (atol(v) >= TILE) m->W = atol(v) / TILE * TILE; }},
+    {"SGP_MULTI_PANEL_TAIL", [](sgp_multi* m, const char* v) { m->W_tail = atol(v) / TILE * TILE; }},
+    {"SGP_MULTI_TAIL_FRAC", [](sgp_multi* m, const char* v) { if (atof(v) >= 0.0 && atof(v) <= 1.0) m->tail_frac = atof(v); }},
+    {"SGP_MULTI_GROUP", [](sgp_multi* m, const char* v) { if (atoi(v) >= 1 && atoi(v) <= SEG_MAX_SRC) m->group = atoi(v); }},
+    {"SGP_MULTI_SUBPANEL", [](sgp_multi* m, const char* v) { m->sub = atol(v) / TILE * TILE; }},
+    {"SGP_MULTI_OWNERS",                                            // balanced (default) | cyclic | r0,r1,... (dealt out cyclically)
+     [](sgp_multi* m, const char* ow) {
+       if (!strcmp(ow, "cyclic")) {
+         m->own_balanced = false;
+       } else if (strcmp(ow, "balanced") != 0) {
+         for (const char* c = ow; *c;) {
+           char* e = nullptr;
+           const long v = strtol(c, &e, 10);
+           if (e == c) break;
+           m->own_list.push_back((int)std::max<long>(0, v));
+           c = (*e == ',') ? e + 1 : e;
+         }
+       }
+     }},
+    {"SGP_MULTI_THREADS", [](sgp_multi* m, const char* v) { m->threads = atoi(v); }},       // 0: one enqueue thread, 1: one per rank
+    {"SGP_MULTI_PANEL_DF", [](sgp_multi* m, const char* v) { m->panel_df = atoi(v); }},     // 0: the launch-based panel chain
+    {"SGP_MULTI_FUSE_LA", [](sgp_multi* m, const char* v) { m->fuse_la = atoi(v); }},       // 0: the last look-ahead piece as a launch
+    {"SGP_MULTI_COMPACT", [](sgp_multi* m, const char* v) { m->compact = atoi(v); }},       // 0 off, 2 at any size (tests)
+    {"SGP_MULTI_SPIN_TIMEOUT_S", [](sgp_multi* m, const char* v) { m->spin_timeout_s = std::max(0.01, atof(v)); }},
+    {"SGP_MULTI_INIT_TIMEOUT_S", [](sgp_multi* m, const char* v) { m->init_timeout_s = std::max(1.0, atof(v)); }},
+    {"SGP_MULTI_FAULT",                                             // rank:step (tests)
+     [](sgp_multi* m, const char* v) {
+       const char* c = strchr(v, ':');
+       m->fault_rank = atoi(v);
+       m->fault_step = c ? atol(c + 1) : 0;
+     }},
+};
+void apply_multi_knobs(sgp_multi* m) {
+  for (const MultiKnob& k : kMultiKnobs)
+    if (const char* v = getenv(k.name)) k.set(m, v);
+}
+}  // namespace
+
 extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out) {
   M_CHECK_ARG(devices && out && ndev >= 1 && ndev <= 64, "sgp_ctx_create_multi: bad argument");
   sgp_ctx* primary = nullptr;
@@ -423,8 +472,13 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
   for (int i = 0; i < ndev; ++i)
     for (int j = 0; j < i; ++j)
       if (devices[i] == devices[j]) distinct = false;
-  const char* tr = getenv("SGP_MULTI_TRANSPORT");
-  std::string want = tr ? tr : "auto";
+  std::string want = "auto";
+  bool allow_staged = false;
+  for (const MultiKnob& k : kMultiKnobs)          // the two switches that steer the creation itself
+    if (const char* v = getenv(k.name)) {
+      if (!strcmp(k.name, "SGP_MULTI_TRANSPORT")) want = v;
+      if (!strcmp(k.name, "SGP_MULTI_ALLOW_STAGED")) allow_staged = atoi(v) != 0;
+    }
   if (!distinct) {
     m->transport = TR_LOOPBACK;   // several ranks on one GPU: same-device copies (test configuration)
   } else if (want == "p2p" || (ndev == 1 && want != "rccl")) {
@@ -438,55 +492,8 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     } else
       m->transport = TR_P2P;
   }
-  const char* bc = getenv("SGP_MULTI_BCAST");
-  m->allgather = !(bc && !strcmp(bc, "direct"));
-  const char* pw = getenv("SGP_MULTI_PANEL");
-  if (pw && atol(pw) >= TILE) m->W = atol(pw) / TILE * TILE;
-  const char* pt = getenv("SGP_MULTI_PANEL_TAIL");
-  if (pt) m->W_tail = atol(pt) / TILE * TILE;
-  const char* tf = getenv("SGP_MULTI_TAIL_FRAC");
-  if (tf && atof(tf) >= 0.0 && atof(tf) <= 1.0) m->tail_frac = atof(tf);
-  const char* gr = getenv("SGP_MULTI_GROUP");
-  if (gr && atoi(gr) >= 1 && atoi(gr) <= SEG_MAX_SRC) m->group = atoi(gr);
+  apply_multi_knobs(m);
   m->ring = 2 * m->group + 2;
-  if (const char* ow = getenv("SGP_MULTI_OWNERS")) {
-    if (!strcmp(ow, "cyclic"))
-      m->own_balanced = false;
-    else if (strcmp(ow, "balanced") != 0) {
-      for (const char* c = ow; *c;) {
-        char* e = nullptr;
-        const long v = strtol(c, &e, 10);
-        if (e == c) break;
-        m->own_list.push_back((int)std::max<long>(0, v));
-        c = (*e == ',') ? e + 1 : e;
-      }
-    }
-  }
-  const char* sp = getenv("SGP_MULTI_SUBPANEL");
-  if (sp) m->sub = atol(sp) / TILE * TILE;
-  if (const char* v = getenv("SGP_MULTI_PANEL_DF")) m->panel_df = atoi(v);
-  if (const char* v = getenv("SGP_MULTI_FUSE_LA")) m->fuse_la = atoi(v);
-  if (const char* v = getenv("SGP_MULTI_COMPACT")) m->compact = atoi(v);
-  if (const char* v = getenv("SGP_MULTI_PIECES")) {
-    std::vector<long> pc;
-    bool ok = true;
-    for (const char* c = v; *c;) {
-      char* e = nullptr;
-      const long w = strtol(c, &e, 10);
-      if (e == c) break;
-      if (w < TILE || w % TILE) ok = false;
-      pc.push_back(w);
-      c = (*e == ',') ? e + 1 : e;
-    }
-    if (ok && !pc.empty() && (int)pc.size() <= Rank::NSUB) m->pieces = pc;
-  }
-  if (const char* v = getenv("SGP_MULTI_SPIN_TIMEOUT_S")) m->spin_timeout_s = std::max(0.01, atof(v));
-  if (const char* v = getenv("SGP_MULTI_INIT_TIMEOUT_S")) m->init_timeout_s = std::max(1.0, atof(v));
-  if (const char* v = getenv("SGP_MULTI_FAULT")) {   // rank:step (tests)
-    const char* c = strchr(v, ':');
-    m->fault_rank = atoi(v);
-    m->fault_step = c ? atol(c + 1) : 0;
-  }
   m->r.resize(ndev);
   for (int i = 0; i < ndev; ++i) {
     Rank& k = m->r[i];
@@ -548,8 +555,7 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     // a node without peer access between its GPUs would run every panel through host memory: say so
     // instead of silently being an order of magnitude slower (SGP_MULTI_ALLOW_STAGED=1 accepts it)
     if (!m->peer_ok && m->transport == TR_P2P) {
-      const char* ok = getenv("SGP_MULTI_ALLOW_STAGED");
-      if (!(ok && atoi(ok))) {
+      if (!allow_staged) {
         set_error("sgp_ctx_create_multi: peer access between the listed GPUs is not available and RCCL could not be "
                   "loaded: panel copies would be staged through host memory (SGP_MULTI_ALLOW_STAGED=1 to accept)");
         return fail(-3);
@@ -590,10 +596,6 @@ extern "C" int sgp_ctx_create_multi(const int* devices, int ndev, sgp_ctx** out)
     }
     for (int i = 0; i < ndev; ++i) m->r[i].comm = comms[i];
   }
-  const char* pf = getenv("SGP_MULTI_PROFILE");
-  if (pf) m->profile = atoi(pf);
-  const char* mt = getenv("SGP_MULTI_THREADS");
-  if (mt) m->threads = atoi(mt);
   // the sequence numbers of every event the per-rank enqueue threads may order themselves by (Exec)
   for (auto& k : m->r) {
     auto reg = [&](hipEvent_t e) {
@@ -666,38 +668,17 @@ extern "C" int sgp_ctx_multi_stats(sgp_ctx* ctx, double* out, int64_t cap, int64
   return 0;
 }
 
-// test-only fault hook (sthenomi_bench.h): the next sharded factorisation fails at panel `step` on rank `rank`'s enqueue thread
-extern "C" int sgp_bench_multi_fault(sgp_ctx* ctx, int rank, int64_t step) {
-  M_CHECK_ARG(ctx && ctx->multi, "sgp_bench_multi_fault: not a multi-GPU context");
-  ctx->multi->fault_rank = rank;
-  ctx->multi->fault_step = rank >= 0 ? (long)std::max<int64_t>(0, step) : -1;
+// state behind the test hooks of sthenomi_bench.h (the extern "C" wrappers live in libsthenomi_bench.so: bench_hooks.hip).
+// Fault hook: the next sharded factorisation fails at panel `step` on rank `rank`'s enqueue thread -- or, with stall_s > 0,
+// sleeps there without failing (the other threads then run into their spin bound).
+int sgp_multi_set_fault(sgp_multi* m, int rank, long step, double stall_s) {
+  m->fault_rank = rank;
+  m->fault_step = step;
+  m->fault_stall_s = stall_s;
   return 0;
 }
-// ... or stalls there for `seconds` without failing (the other threads then run into their spin bound)
-extern "C" int sgp_bench_multi_stall(sgp_ctx* ctx, int rank, int64_t step, double seconds) {
-  M_CHECK_ARG(ctx && ctx->multi && seconds > 0.0, "sgp_bench_multi_stall: bad argument");
-  ctx->multi->fault_rank = rank;
-  ctx->multi->fault_step = (long)std::max<int64_t>(0, step);
-  ctx->multi->fault_stall_s = seconds;
-  return 0;
-}
-// profile mode: per panel Rank::NSUB (8) doubles -- the ms of every sub-panel's launch group of the last profiled factorisation
-extern "C" int sgp_bench_multi_profile_pieces(sgp_ctx* ctx, double* out, int64_t cap, int64_t* n_out) {
-  M_CHECK_ARG(ctx && ctx->multi && n_out, "sgp_bench_multi_profile_pieces: bad argument");
-  const auto& v = ctx->multi->prof_pieces;
-  *n_out = (int64_t)v.size();
-  if (out) {
-    M_CHECK_ARG(cap >= (int64_t)v.size(), "sgp_bench_multi_profile_pieces: buffer too small");
-    std::copy(v.begin(), v.end(), out);
-  }
-  return 0;
-}
-// 1 after a failed call left the RCCL communicators aborted (the context then refuses sharded calls), else 0
-extern "C" int sgp_bench_multi_broken(sgp_ctx* ctx, int* out) {
-  M_CHECK_ARG(ctx && ctx->multi && out, "sgp_bench_multi_broken: not a multi-GPU context");
-  *out = ctx->multi->broken ? 1 : 0;
-  return 0;
-}
+int sgp_multi_is_broken(sgp_multi* m) { return m->broken ? 1 : 0; }
+const std::vector<double>& sgp_multi_profile_pieces(sgp_multi* m) { return m->prof_pieces; }
 
 extern "C" int sgp_ctx_multi_owners(sgp_ctx* ctx, int32_t* out, int64_t cap, int64_t* n_out) {
   M_CHECK_ARG(ctx && ctx->multi && n_out, "sgp_ctx_multi_owners: not a multi-GPU context");
@@ -1122,24 +1103,11 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   // steps inside: drv_panel_factor) + ONE update of the panel's remaining columns with it (K = sub; the same ascending-k
   // accumulation per tile as the 128-column steps of an unsplit panel: bit-identical).
   const long SUB = (m->sub >= TILE) ? m->sub : (1L << 40);
-  // round 6: UNEVEN pieces (SGP_MULTI_PIECES=768,256: widths that add up to the panel width) -- what sits between the end of one
-  // panel's factorisation and the start of the next is the LAST piece's transport and look-ahead update, so a short last
-  // piece shortens the chain while the long first piece travels under the factorisation of the rest.  Panels of another
-  // width (a narrow tail, the last panel) keep the regular pieces.
-  long pieces_sum = 0;
-  for (long w : m->pieces) pieces_sum += w;
-  auto uneven = [&](long J) { return !m->pieces.empty() && pieces_sum == g.width(J); };
-  auto n_sub = [&](long J) {
-    if (uneven(J)) return (int)m->pieces.size();
-    return (int)std::min<long>(Rank::NSUB, (g.width(J) + SUB - 1) / SUB);
-  };
+  // (Round 6 also measured UNEVEN pieces -- a long first piece, a short last one, so that less transport and look-ahead work sits
+  // between two factorisations: profiles/r06_experiments/sharded_chain.md.  Every split lost to equal halves: the receiver
+  // side is bound by transport + look-ahead update of ALL pieces, which only equal pieces pipeline.  Removed.)
+  auto n_sub = [&](long J) { return (int)std::min<long>(Rank::NSUB, (g.width(J) + SUB - 1) / SUB); };
   auto sub_range = [&](long J, int q, long& c, long& wq) {
-    if (uneven(J)) {
-      c = 0;
-      for (int t = 0; t < q; ++t) c += m->pieces[(size_t)t];
-      wq = m->pieces[(size_t)q];
-      return;
-    }
     const int ns = n_sub(J);
     c = (long)q * SUB;
     wq = (q == ns - 1) ? g.width(J) - c : SUB;   // (more than NSUB sub-panels: the last takes the rest)
@@ -1147,7 +1115,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   const long G = m->group;
   auto group_of = [&](long J) { return J / G; };
   // the panel kernel (see sgp_multi::panel_df): with the primary context's hybrid switch, which the time-out fallback clears
-  const bool df_panels = m->panel_df != 0 && m->primary && m->primary->hybrid != 0 && m->r[0].ctx->refine == 1;
+  const bool df_panels = m->panel_df != 0 && m->primary && m->primary->hybrid != 0;
   const bool fuse_la = df_panels && m->fuse_la != 0;
   const int fault_rank = std::min<int>(m->fault_rank, P - 1);   // the hook fires once: disarmed before the sweep starts
   const long fault_step = m->fault_rank >= 0 ? std::min<long>(m->fault_step, g.npan - 1) : -1;
@@ -2031,9 +1999,13 @@ __global__ void set_identity_cols_kernel(double* blk, long ld, long c0, long w, 
 }
 }  // namespace
 
+// grad_inputs / grad_rowscale (round 6; sgp_logpdf_grad_x / _xs): the input-point and function-scale gradients on the sharded
+// result as well -- every rank contracts ITS column slabs of G = (alpha alpha' - C^-1) / 2 with the kernel derivatives row-side
+// (the single-GPU kernel, grad.hip: launch_grad_inputs, on a column window of the block pair), the per-rank sums are added on
+// the host in rank order.  "Row side x 2" covers the column side as on one GPU (the spec and G are symmetric).
 int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int noise_kind, const double* noise,
                           const double* y, double* logpdf_out, double* grad_y, double* grad_mean, double* grad_noise,
-                          double* grad_coef, double* grad_inscale) {
+                          double* grad_coef, double* grad_inscale, double* const* grad_inputs, double* const* grad_rowscale) {
   sgp_multi* m = ctx->multi;
   const int P = (int)m->r.size();
   const long N = spec_rows(spec);
@@ -2051,6 +2023,7 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
   std::vector<sgp_dspec*> ds(P, nullptr);
   size_t nterms = 0;
   std::vector<double> gc_sum, gs_sum, kdiag(N, 0.0);
+  std::vector<std::vector<double*>> gx_dev((size_t)P), gr_dev((size_t)P);   // [rank][input] / [rank][term], freed below
   auto body = [&]() -> int {
     // ---- logpdf from the scalars the factorisation left on every rank (rank order: deterministic)
     std::vector<double> red;
@@ -2135,6 +2108,25 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
       // partial-sum scratch of the contraction kernel: 16 doubles per tile of the largest window
       double* d_part = k.d_work;   // (X is no longer needed)
       M_CHECK_ARG((size_t)(n_pad / TILE) * (g.W / TILE) * 16 <= k.work_cap, "sgp_logpdf_grad (multi): scratch too small");
+      // per-rank accumulators of the input-point / row-scale gradients (device; summed over ranks on the host below)
+      if (grad_inputs) {
+        gx_dev[i].assign((size_t)spec->n_inputs, nullptr);
+        for (int a = 0; a < spec->n_inputs; ++a) {
+          const size_t cnt = (size_t)std::max<long>(1, (long)d->in_dim[a] * d->in_n[a]);
+          M_HIP(hipMalloc(&gx_dev[i][(size_t)a], sizeof(double) * cnt));
+          M_HIP(hipMemsetAsync(gx_dev[i][(size_t)a], 0, sizeof(double) * cnt, k.s_upd));
+        }
+      }
+      if (grad_rowscale) {
+        gr_dev[i].assign(nterms, nullptr);
+        for (int I = 0; I < d->nrb; ++I)
+          for (int Jb = 0; Jb < d->ncb; ++Jb)
+            for (int t = d->term_ptr[I * d->ncb + Jb]; t < d->term_ptr[I * d->ncb + Jb + 1]; ++t)
+              if (grad_rowscale[t] && d->h_terms[t].rs && d->row_len[I] > 0) {
+                M_HIP(hipMalloc(&gr_dev[i][(size_t)t], sizeof(double) * d->row_len[I]));
+                M_HIP(hipMemsetAsync(gr_dev[i][(size_t)t], 0, sizeof(double) * d->row_len[I], k.s_upd));
+              }
+      }
       for (long J : g.mine[(size_t)i]) {
         const long pc0 = g.col0(J), pw = std::min(g.width(J), N - pc0);
         if (pw <= 0) continue;
@@ -2162,6 +2154,26 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
               }
             }
           }
+        if (grad_inputs || grad_rowscale)
+          for (int I = 0; I < d->nrb; ++I) {
+            if (d->row_len[I] == 0) continue;
+            for (int Jb = 0; Jb < d->ncb; ++Jb) {
+              const long bc0 = d->col_off[Jb], bc1 = bc0 + d->col_len[Jb];
+              const long lo = std::max(bc0, pc0), hi = std::min(bc1, pc0 + pw);
+              if (lo >= hi) continue;
+              const int p = I * d->ncb + Jb;
+              for (int t = d->term_ptr[p]; t < d->term_ptr[p + 1]; ++t) {
+                double* gsv = (grad_rowscale && grad_rowscale[t] && d->h_terms[t].rs) ? gr_dev[i][(size_t)t] : nullptr;
+                double* gxa = grad_inputs ? gx_dev[i][(size_t)d->term_row_input[t]] : nullptr;
+                if (!gxa && !gsv) continue;
+                DevTerm Tw = d->h_terms[t];          // the term's column data from column `lo` of its block on
+                Tw.xc += (lo - bc0) * Tw.ldc;
+                if (Tw.cs) Tw.cs += (lo - bc0);
+                M_RC(launch_grad_inputs(k.d_work2, 1, n_pad, d_alpha, d->row_off[I], d->row_len[I], lo, hi - lo, Tw, d->pair_dmax[p],
+                                        2.0, gxa, k.s_upd, gsv));
+              }
+            }
+          }
         M_RC(drv_copy_strided(k.d_work2 + pc0 + (size_t)pc0 * n_pad, n_pad + 1, pw, d_diag, k.s_upd));
         M_HIP(hipMemcpyAsync(kdiag.data() + pc0, d_diag, sizeof(double) * pw, hipMemcpyDeviceToHost, k.s_upd));
         M_HIP(hipStreamSynchronize(k.s_upd));   // (d_diag is reused by the next panel; kdiag is pageable)
@@ -2179,10 +2191,49 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
       M_HIP(hipMemcpy(tmpv.data(), d_gc + 4096, sizeof(double) * nterms, hipMemcpyDeviceToHost));
       for (size_t t = 0; t < nterms; ++t) gs_sum[t] += tmpv[t];
     }
+    // ---- input-point / row-scale gradients: per-rank sums added in rank order
+    std::vector<double> hb;
+    if (grad_inputs)
+      for (int a = 0; a < spec->n_inputs; ++a) {
+        const sgp_input& in = spec->inputs[a];
+        if (!grad_inputs[a] || in.n == 0) continue;
+        const size_t cnt = (size_t)(in.dim * in.n);
+        std::fill(grad_inputs[a], grad_inputs[a] + cnt, 0.0);
+        hb.resize(cnt);
+        for (int i = 0; i < P; ++i) {
+          M_HIP(hipSetDevice(m->r[i].dev));
+          M_HIP(hipMemcpy(hb.data(), gx_dev[i][(size_t)a], sizeof(double) * cnt, hipMemcpyDeviceToHost));
+          for (size_t q = 0; q < cnt; ++q) grad_inputs[a][q] += hb[q];
+        }
+      }
+    if (grad_rowscale) {
+      const sgp_dspec* d = ds[0];
+      for (int I = 0; I < d->nrb; ++I)
+        for (int Jb = 0; Jb < d->ncb; ++Jb)
+          for (int t = d->term_ptr[I * d->ncb + Jb]; t < d->term_ptr[I * d->ncb + Jb + 1]; ++t) {
+            if (!grad_rowscale[t] || !d->h_terms[t].rs || d->row_len[I] <= 0) continue;
+            const size_t cnt = (size_t)d->row_len[I];
+            std::fill(grad_rowscale[t], grad_rowscale[t] + cnt, 0.0);
+            hb.resize(cnt);
+            for (int i = 0; i < P; ++i) {
+              M_HIP(hipSetDevice(m->r[i].dev));
+              M_HIP(hipMemcpy(hb.data(), gr_dev[i][(size_t)t], sizeof(double) * cnt, hipMemcpyDeviceToHost));
+              for (size_t q = 0; q < cnt; ++q) grad_rowscale[t][q] += hb[q];
+            }
+          }
+    }
     return 0;
   };
   int rc = body();
   drain(m, ds, ctx->device);
+  for (int i = 0; i < P; ++i) {
+    hipSetDevice(m->r[i].dev);
+    for (double* q : gx_dev[(size_t)i])
+      if (q) hipFree(q);
+    for (double* q : gr_dev[(size_t)i])
+      if (q) hipFree(q);
+  }
+  hipSetDevice(ctx->device);
   sgp_multi_posterior_destroy(mp);
   if (rc) return rc;
   if (grad_y)
@@ -2203,6 +2254,133 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
   if (grad_inscale)
     for (size_t t = 0; t < nterms; ++t) grad_inscale[t] = gs_sum[t];
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// cov(f, x) / cov(f, x, x') and var(f, x) on a multi-GPU context (round 6; they used to run on devices[0]): the assembly the
+// sharded factorisation already does per rank, for its own sake.  kernelmatrix: the M columns in P contiguous tile-aligned
+// chunks, rank i assembles chunk i for all rows and copies it straight into the caller's matrix (one host thread per rank: P
+// PCIe links at once); no communication.  A symmetric spec keeps its guarantee of an EXACTLY symmetric result: a rank builds
+// the lower trapezoid of its chunk, mirrors the diagonal square, and obtains the rows ABOVE its chunk's diagonal as the
+// transpose of the row slab [chunk rows, columns left of the chunk] -- lower tiles it assembles itself (twice the kernel
+// evaluations of the one-GPU path over the strictly upper part, still 1 / P of the matrix per rank, no exchange).
+// kernelmatrix_diag: every block's points in P slices, the terms' device pointers advanced to the slice.
+int sgp_multi_kernelmatrix(sgp_ctx* ctx, const sgp_cov_spec* spec, double* K, int64_t ldk) {
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  long N = 0, M = 0;
+  for (int i = 0; i < spec->n_row_blocks; ++i) N += spec->row_len[i];
+  for (int j = 0; j < spec->n_col_blocks; ++j) M += spec->col_len[j];
+  M_CHECK_ARG(ldk >= N, "sgp_kernelmatrix (multi): ldk < N");
+  if (N == 0 || M == 0) return 0;
+  const bool sym = spec->symmetric != 0;
+  const long T_r = rup(N, TILE) / TILE, T_c = rup(M, TILE) / TILE;
+  const long per = (T_c + P - 1) / P;   // tile columns per rank
+  std::vector<sgp_dspec*> ds(P, nullptr);
+  auto body = [&]() -> int {
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      const long tc0 = std::min<long>(T_c, (long)i * per), tc1 = std::min<long>(T_c, tc0 + per);
+      if (tc0 >= tc1) continue;
+      const long c0 = tc0 * TILE, wv = std::min(M, tc1 * TILE) - c0;
+      M_HIP(hipSetDevice(k.dev));
+      M_RC(grow(&k.d_work, &k.work_cap, (size_t)N * (size_t)(tc1 - tc0) * TILE));
+      if (sym && c0 > 0) M_RC(grow(&k.d_work2, &k.work2_cap, (size_t)(tc1 - tc0) * TILE * (size_t)c0));
+      M_RC(drv_dspec_create(k.ctx, spec, &ds[i]));
+      double* Kc = k.d_work;                      // element (r, chunk column c - c0) at Kc[r + (c - c0) * N]
+      double* Kv = Kc - (size_t)c0 * N;            // ... i.e. global (r, c) at Kv[r + c * N]
+      if (!sym) {
+        M_RC(drv_assemble(ds[i], Kv, N, 0, T_r, tc0, tc1, 0, -1, 0.0, nullptr, k.s_upd));
+      } else {
+        M_RC(drv_assemble(ds[i], Kv, N, tc0, T_r, tc0, tc1, 1, -1, 0.0, nullptr, k.s_upd));
+        M_RC(launch_mirror_lower(Kc + c0, N, wv, k.s_upd));
+        if (c0 > 0) {
+          const long ldS = (tc1 - tc0) * TILE;
+          double* S = k.d_work2;                   // global (r, c), r in the chunk's rows, c < c0, at S[(r - c0) + c * ldS]
+          M_RC(drv_assemble(ds[i], S - c0, ldS, tc0, tc1, 0, tc0, 1, -1, 0.0, nullptr, k.s_upd));
+          M_RC(launch_transpose_add(S, ldS, wv, c0, Kc, N, nullptr, k.s_upd));
+        }
+      }
+    }
+    std::vector<std::thread> th;
+    std::vector<int> rcs(P, 0);
+    for (int i = 0; i < P; ++i) {
+      const long tc0 = std::min<long>(T_c, (long)i * per), tc1 = std::min<long>(T_c, tc0 + per);
+      if (tc0 >= tc1) continue;
+      th.emplace_back([&, i, tc0, tc1]() {
+        Rank& k = m->r[i];
+        const long c0 = tc0 * TILE, wv = std::min(M, tc1 * TILE) - c0;
+        if (hipSetDevice(k.dev) != hipSuccess || hipStreamSynchronize(k.s_upd) != hipSuccess ||
+            hipMemcpy2D(K + (size_t)c0 * ldk, sizeof(double) * ldk, k.d_work, sizeof(double) * N, sizeof(double) * N, (size_t)wv,
+                        hipMemcpyDeviceToHost) != hipSuccess)
+          rcs[i] = -2;
+      });
+    }
+    for (auto& t : th) t.join();
+    for (int i = 0; i < P; ++i)
+      if (rcs[i]) {
+        set_error("sgp_kernelmatrix (multi): device -> host copy failed");
+        return rcs[i];
+      }
+    return 0;
+  };
+  const int rc = body();
+  drain(m, ds, ctx->device);
+  return rc;
+}
+
+int sgp_multi_kernelmatrix_diag(sgp_ctx* ctx, const sgp_cov_spec* spec, double* out) {
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  M_CHECK_ARG(spec->n_row_blocks == spec->n_col_blocks, "kernelmatrix_diag: row / col block counts differ");
+  long N = 0;
+  for (int i = 0; i < spec->n_row_blocks; ++i) {
+    M_CHECK_ARG(spec->row_len[i] == spec->col_len[i], "kernelmatrix_diag: block lengths differ");
+    N += spec->row_len[i];
+  }
+  if (N == 0) return 0;
+  std::vector<sgp_dspec*> ds(P, nullptr);
+  auto body = [&]() -> int {
+    for (int i = 0; i < P; ++i) {
+      Rank& k = m->r[i];
+      M_HIP(hipSetDevice(k.dev));
+      M_RC(drv_dspec_create(k.ctx, spec, &ds[i]));
+      const sgp_dspec* d = ds[i];
+      const size_t nt = d->h_terms.size();
+      const size_t term_doubles = (nt * sizeof(DevTerm) + 7) / 8 + 1;
+      M_RC(grow(&k.d_work, &k.work_cap, (size_t)N + term_doubles));
+      std::vector<DevTerm> tw(d->h_terms);
+      std::vector<std::pair<long, long>> sl((size_t)d->nrb);   // this rank's slice of every block
+      for (int I = 0; I < d->nrb; ++I) {
+        const long len = d->row_len[I], lo = len * i / P, hi = len * (i + 1) / P;
+        sl[(size_t)I] = {lo, hi};
+        const int p = I * d->ncb + I;
+        for (int t = d->term_ptr[p]; t < d->term_ptr[p + 1]; ++t) {
+          DevTerm& T = tw[(size_t)t];
+          T.xr += lo * T.ldr;
+          T.xc += lo * T.ldc;
+          if (T.rs) T.rs += lo;
+          if (T.cs) T.cs += lo;
+        }
+      }
+      DevTerm* d_tw = reinterpret_cast<DevTerm*>(k.d_work + N);
+      if (nt) M_HIP(hipMemcpyAsync(d_tw, tw.data(), nt * sizeof(DevTerm), hipMemcpyHostToDevice, k.s_upd));
+      M_HIP(hipStreamSynchronize(k.s_upd));   // (tw is a local)
+      for (int I = 0; I < d->nrb; ++I) {
+        const long lo = sl[(size_t)I].first, hi = sl[(size_t)I].second;
+        if (hi <= lo) continue;
+        const int p = I * d->ncb + I;
+        const int t0 = d->term_ptr[p], t1 = d->term_ptr[p + 1];
+        M_RC(launch_diag_terms(k.d_work + d->row_off[I] + lo, hi - lo, d_tw + t0, t1 - t0, k.s_upd));
+        M_HIP(hipMemcpyAsync(out + d->row_off[I] + lo, k.d_work + d->row_off[I] + lo, sizeof(double) * (hi - lo),
+                             hipMemcpyDeviceToHost, k.s_upd));
+      }
+    }
+    return 0;
+  };
+  const int rc = body();
+  drain(m, ds, ctx->device);
+  return rc;
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1,8 +1,8 @@
 // Diagonal-block kernels of the blocked Cholesky (the latency-bound critical path):
 //   potrf_diag_kernel : Cholesky of one 128x128 diagonal block, entirely in LDS, one workgroup.
-//   trtri_kernel      : W = inv(L11) (128x128 lower) so that the panel TRSM
-//                       L21 = A21 * L11^-T becomes a plain MFMA GEMM (gemm_nt, B = W).
-// Together they replace LAPACK dpotf2/dtrsm inside dpotrf on the reference path
+//   (round 6: the explicit-inverse trtri_kernel of the SGP_REFINE = 0 / 2 A/B modes is gone: the refined 16 x 16 substitution,
+//   panel_solve_kernel, has been the only panel solve since round 2)
+// Together with the panel solve (panel_solve.h) it replaces LAPACK dpotf2/dtrsm inside dpotrf on the reference path
 // (LinearAlgebra.cholesky under AbstractGPs.logpdf/posterior/rand/elbo [EXT]).
 //
 // potrf_diag (potrf_diag.h: potrf_diag_body, shared with the fused update + diagonal block launches of
@@ -162,61 +162,6 @@ int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl
   long nwg = (nstrips + strips - 1) / strips;
   hipLaunchKernelGGL(panel_solve_kernel, dim3((unsigned)nwg), dim3(256), PS_LDS, s, X, ldx, L, ldl, inv,
                      inv_cstride, inv_kstride, strips, rows, panel_prio(), sk ? *sk : StripSkip());
-  SGP_HIP(hipGetLastError());
-  return 0;
-}
-
-// ---------------------------------------------------------------------------------------
-// W = inv(L11).  Wave cb owns block-column cb of W, kept transposed in a 16 x 128 LDS strip:
-//   strip[b*16 + j] = W[b][cb16 + j].
-// Block recurrence: W[cb][cb] = invD[cb];  W[rb][cb] = -invD[rb] * sum_{p=cb}^{rb-1} L[rb][p] W[p][cb].
-// The f64 MFMA result lane map (m = lq + 4r, n = l15) is exactly the B-operand map of four
-// successive k-steps, so the second product consumes the first one's accumulator directly.
-// ---------------------------------------------------------------------------------------
-constexpr size_t TT_LDS = (size_t)8 * TILE * 16 * sizeof(double);
-
-__global__ __launch_bounds__(512) void trtri_kernel(const double* L, long ld, const double* invd,
-                                                    double* Wg) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int t = threadIdx.x;
-  const int lane = t & 63, cb = t >> 6;
-  const int l15 = lane & 15, lq = lane >> 4;
-  double* strip = smem + cb * (TILE * 16);
-  for (int idx = lane; idx < TILE * 16; idx += 64) strip[idx] = 0.0;
-  for (int idx = lane; idx < 256; idx += 64) {
-    int j = idx & 15, i = idx >> 4;
-    strip[(cb * 16 + i) * 16 + j] = invd[cb * 256 + j * 16 + i];  // W[cb16+i][cb16+j]
-  }
-  for (int rb = cb + 1; rb < 8; ++rb) {
-    d4 S = (d4){0.0, 0.0, 0.0, 0.0};
-    for (int p = cb; p < rb; ++p) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        int k = p * 16 + ks * 4 + lq;
-        double aop = L[(rb * 16 + l15) + (long)k * ld];  // L[rb16+m][k]
-        double bop = strip[k * 16 + l15];                // W[k][cb16+n]
-        S = mfma_f64(aop, bop, S);
-      }
-    }
-    d4 T2 = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      double aop = invd[rb * 256 + (ks * 4 + lq) * 16 + l15];  // invD_rb[m=l15][k=4ks+lq]
-      T2 = mfma_f64(aop, S[ks], T2);                           // S[ks] == S[k=4ks+lq][n=l15]
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) strip[(rb * 16 + lq + 4 * r) * 16 + l15] = -T2[r];
-  }
-  // Wg[b + (cb16+j)*128] = W[b][cb16+j]
-  for (int idx = lane; idx < TILE * 16; idx += 64) {
-    int b = idx & 127, j = idx >> 7;
-    Wg[b + (cb * 16 + j) * TILE] = strip[b * 16 + j];
-  }
-}
-
-int launch_trtri(const double* L, long ld, const double* d_invd, double* d_w, hipStream_t s) {
-  SGP_LDS_ATTR_ONCE(trtri_kernel, TT_LDS);
-  hipLaunchKernelGGL(trtri_kernel, dim3(1), dim3(512), TT_LDS, s, L, ld, d_invd, d_w);
   SGP_HIP(hipGetLastError());
   return 0;
 }

@@ -14,6 +14,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libsthenomi.so")
+BENCH_LIB_PATH = os.path.join(_HERE, "csrc", "libsthenomi_bench.so")
 
 # kernel kinds / noise kinds (sthenomi.h enums)
 SE, MATERN12, MATERN32, MATERN52, WHITE, CONST = range(6)
@@ -147,6 +148,13 @@ _SIGS = {
     "sgp_dev_elbo_partial": (C.c_int, [_P, C.POINTER(sgp_cov_spec), C.POINTER(sgp_cov_spec), _D, _D, C.c_int, _D,
                                        C.c_int, _D, _D, _P, C.c_int64]),
     "sgp_dev_elbo_finish": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _D]),
+    "sgp_dev_assemble_cross_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
+    "sgp_dev_rows_dot": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
+    "sgp_dev_rows_gram": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
+}
+# include/sthenomi_bench.h: micro-benchmark / diagnosis / test hooks, exported by libsthenomi_bench.so (round 6), NOT by the product
+# library -- bench.py, tools/ and the GPU tests reach them through bench_lib() / Context.bench
+_SIGS_BENCH = {
     "sgp_bench_df_fallbacks": (C.c_int, [_P, C.POINTER(C.c_int64)]),
     "sgp_bench_multi_fault": (C.c_int, [_P, C.c_int, C.c_int64]),
     "sgp_bench_multi_broken": (C.c_int, [_P, C.POINTER(C.c_int)]),
@@ -155,9 +163,6 @@ _SIGS = {
     "sgp_bench_mfma_f64": (C.c_int, [_P, C.c_int, _D, _D]),
     "sgp_bench_hbm": (C.c_int, [_P, C.c_int64, C.c_int, _D, _D]),
     "sgp_bench_potrf": (C.c_int, [_P, C.c_int, _D, C.POINTER(C.c_longlong)]),
-    "sgp_dev_assemble_cross_rows": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int64, _P]),
-    "sgp_dev_rows_dot": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, _P, _P, _P]),
-    "sgp_dev_rows_gram": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
     "sgp_bench_cumask": (C.c_int, [_P, C.POINTER(C.c_uint32), C.c_int, C.c_int, C.POINTER(C.c_uint)]),
     "sgp_bench_potrf_contended": (C.c_int, [_P, C.c_int64, C.c_int64, C.c_int, C.c_int, _D, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "sgp_bench_gemm_stamps": (C.c_int, [_P, C.c_int64, C.c_int64, C.POINTER(C.c_longlong), C.c_int64, C.POINTER(C.c_int64)]),
@@ -168,6 +173,33 @@ _SIGS = {
 def exported_symbols():
     """Names include/sthenomi.h declares (used by the CPU-side symbol test)."""
     return sorted(_SIGS)
+
+
+def bench_symbols():
+    """Names include/sthenomi_bench.h declares: the entry points of libsthenomi_bench.so."""
+    return sorted(_SIGS_BENCH)
+
+
+_bench = None
+
+
+def bench_lib():
+    """dlopen libsthenomi_bench.so (micro-benchmarks, diagnosis and test hooks: include/sthenomi_bench.h).  It links against
+    the product library and works on contexts created there; nothing on a product path loads it."""
+    global _bench
+    load()
+    with _lib_lock:
+        if _bench is not None:
+            return _bench
+        if not os.path.exists(BENCH_LIB_PATH):
+            raise SthenoMIError(f"{BENCH_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(BENCH_LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGS_BENCH.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bench = lib
+        return lib
 
 
 def load():
@@ -232,6 +264,11 @@ class Context:
         self.handle = h
         self.device = device
         self.lib = lib
+
+    @property
+    def bench(self):
+        """libsthenomi_bench.so (sthenomi_bench.h): `ctx.bench.sgp_bench_*(ctx.handle, ...)`"""
+        return bench_lib()
 
     @property
     def ndev(self):

@@ -30,15 +30,32 @@ def test_product_header_carries_no_bench_hooks():
     assert bench and all(s.startswith("sgp_bench_") for s in bench)
 
 
+def _c_exports(path):
+    """the C-level (unmangled) sgp_* symbols a shared library defines"""
+    import subprocess
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    return sorted({ln.split()[-1] for ln in out.splitlines() if len(ln.split()) == 3 and ln.split()[1] == "T" and ln.split()[2].startswith("sgp_")})
+
+
 def test_library_exports_every_declared_symbol():
     lib = P.lib.load()
-    syms = header_symbols()
+    syms = _symbols_of("sthenomi.h")
     assert len(syms) >= 25
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in sthenomi.h but not exported"
     # and the Python binding types exactly that set
     assert sorted(P.lib.exported_symbols()) == syms
     assert lib.sgp_abi_version() == 1
+
+
+def test_product_library_exports_exactly_the_product_header():
+    """Round-5 verdict: `microbench.hip` was linked into the product .so.  Now: libsthenomi.so's C-level exports ARE
+    include/sthenomi.h (no bench / test hook, nothing undeclared); the hooks of include/sthenomi_bench.h live in
+    libsthenomi_bench.so, which links against the product library and which only bench.py, tools/ and tests load."""
+    assert _c_exports(P.lib.LIB_PATH) == _symbols_of("sthenomi.h")
+    assert _c_exports(P.lib.BENCH_LIB_PATH) == _symbols_of("sthenomi_bench.h") == sorted(P.lib.bench_symbols())
+    src = open(os.path.join(ROOT, "stheno.jl_amd", "csrc", "Makefile")).read()
+    assert "microbench" not in src.split("BENCH_OBJS")[0]          # not among the product objects
 
 
 def test_geometry_is_pure_host_arithmetic():
@@ -78,10 +95,11 @@ def test_header_is_plain_c_and_struct_offsets_match_ctypes(tmp_path):
     exe = str(tmp_path / "capi_smoke")
     src = os.path.join(ROOT, "tests", "capi_smoke.c")
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-o", exe, src, "-ldl"])
-    out = subprocess.check_output([exe, P.lib.LIB_PATH], text=True)
+    out = subprocess.check_output([exe, P.lib.LIB_PATH, P.lib.BENCH_LIB_PATH], text=True)
     mirror = {"sgp_input": P.lib.sgp_input, "sgp_term": P.lib.sgp_term, "sgp_cov_spec": P.lib.sgp_cov_spec,
               "sgp_panel_src": P.lib.sgp_panel_src, "sgp_panel_dst": P.lib.sgp_panel_dst}
     seen = 0
+    seen_bench = False
     for ln in out.splitlines():
         w = ln.split()
         if w[0] == "sizeof":
@@ -90,10 +108,13 @@ def test_header_is_plain_c_and_struct_offsets_match_ctypes(tmp_path):
             st, field = w[1].split(".")
             assert getattr(mirror[st], field).offset == int(w[2]), ln
             seen += 1
+        elif w[:3] == ["loaded", "bench", "symbols"]:
+            assert int(w[3]) == len(_symbols_of("sthenomi_bench.h")), "tests/capi_smoke.c's bench table misses a hook"
+            seen_bench = True
         elif w[0] == "loaded":
             assert int(w[2]) == P.lib.load().sgp_abi_version()
-            assert int(w[4]) == len(header_symbols()), "tests/capi_smoke.c's table misses a declared entry point"
-    assert seen == sum(len(m._fields_) for m in mirror.values())
+            assert int(w[4]) == len(_symbols_of("sthenomi.h")), "tests/capi_smoke.c's table misses a declared entry point"
+    assert seen == sum(len(m._fields_) for m in mirror.values()) and seen_bench
     src_txt = open(src).read()
     for s in header_symbols():
         assert f"E({s})" in src_txt, f"{s} missing from tests/capi_smoke.c"

@@ -81,12 +81,12 @@ def test_one_bad_member_does_not_lose_the_others(N):
     assert np.array_equal(vals[keep], good[keep]) and not infos[keep].any()
 
 
-def test_batch_on_the_lean_instantiation_and_under_a_forced_timeout(monkeypatch):
-    """SGP_BATCH_FAT=0: two workgroups per CU.  SGP_DF_TIMEOUT_S tiny: the pooled launch runs into its wait bound, the entry
+def test_batch_switched_off_and_under_a_forced_timeout(monkeypatch):
+    """SGP_BATCH_MAX_N=0: member by member.  SGP_DF_TIMEOUT_S tiny: the pooled launch runs into its wait bound, the entry
     point reruns member by member on the launch-based schedule (with_df_fallback) -- same bits either way."""
     fxs, ys, _ = _members(6, 1024, seed=3)
     good = np.array([P.logpdf(fx, y) for fx, y in zip(fxs, ys)])
-    for env in ({"SGP_BATCH_FAT": "0"}, {"SGP_BATCH_MAX_N": "0"}, {"SGP_DF_TIMEOUT_S": "1e-7"}):
+    for env in ({"SGP_BATCH_MAX_N": "0"}, {"SGP_DF_TIMEOUT_S": "1e-7"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         ctx = P.lib.Context(0)

@@ -201,7 +201,7 @@ def test_hybrid_reports_the_same_failing_minor_and_survives_a_timeout(monkeypatc
     for k in ref:
         assert np.array_equal(ref[k], got[k]), k
     n = C.c_int64()
-    P.lib.check(ctx.lib.sgp_bench_df_fallbacks(ctx.handle, C.byref(n)))
+    P.lib.check(ctx.bench.sgp_bench_df_fallbacks(ctx.handle, C.byref(n)))
     assert n.value >= 1
     ctx.close()
     ref_ctx.close()
@@ -221,7 +221,7 @@ def test_a_dataflow_timeout_falls_back_to_the_launches_with_the_same_bits(monkey
     for k in ref:
         assert np.array_equal(ref[k], got[k]), k
     n = C.c_int64()
-    P.lib.check(ctx.lib.sgp_bench_df_fallbacks(ctx.handle, C.byref(n)))
+    P.lib.check(ctx.bench.sgp_bench_df_fallbacks(ctx.handle, C.byref(n)))
     assert n.value >= 1, "no wait ran into the 1 ns bound?"
     ctx.close()
     ref_ctx.close()

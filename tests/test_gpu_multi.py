@@ -638,17 +638,13 @@ def test_dataflow_panel_launches_give_the_launch_based_chains_bits(monkeypatch, 
         return dict(lp=np.array([P.logpdf(fx, y)]), lpm=np.asarray(P.logpdf(fx, Y)), m=np.asarray(mm), v=np.asarray(vv),
                     r=np.asarray(P.rand(None, fx, 2, Z=Z)))
 
-    keys = ("SGP_MULTI_PANEL", "SGP_MULTI_SUBPANEL", "SGP_MULTI_GROUP", "SGP_MULTI_PANEL_TAIL", "SGP_STRUCT_ZEROS", "SGP_MULTI_THREADS",
-            "SGP_MULTI_PIECES")
+    keys = ("SGP_MULTI_PANEL", "SGP_MULTI_SUBPANEL", "SGP_MULTI_GROUP", "SGP_MULTI_PANEL_TAIL", "SGP_STRUCT_ZEROS", "SGP_MULTI_THREADS")
     for env in ({"SGP_MULTI_PANEL": "128"},
                 {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "128"},
                 {"SGP_MULTI_PANEL": "512", "SGP_MULTI_SUBPANEL": "256", "SGP_STRUCT_ZEROS": "0"},
                 {"SGP_MULTI_PANEL": "1024", "SGP_MULTI_SUBPANEL": "0", "SGP_MULTI_THREADS": "0"},
                 {"SGP_MULTI_PANEL": "256", "SGP_MULTI_SUBPANEL": "128", "SGP_MULTI_GROUP": "2"},
-                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PANEL_TAIL": "256", "SGP_MULTI_SUBPANEL": "128"},
-                # uneven pieces: a long first piece, a short last one (what sits on the chain); the last panel keeps regular pieces
-                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PIECES": "384,128"},
-                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PIECES": "256,128,128", "SGP_MULTI_SUBPANEL": "256"}):
+                {"SGP_MULTI_PANEL": "512", "SGP_MULTI_PANEL_TAIL": "256", "SGP_MULTI_SUBPANEL": "128"}):
         outs = []
         for df, fuse in (("0", "1"), ("1", "0"), ("1", "1")):
             for k in keys:
@@ -707,3 +703,66 @@ def test_compacted_live_tile_ids_in_the_far_updates_keep_the_bits(monkeypatch, n
     assert all(v == vals[0] for v in vals[:6]), vals          # one panel layout: bit for bit
     assert abs(vals[6] - vals[0]) <= 1e-12 * abs(vals[0])      # another layout: to rounding
     assert abs(vals[0] - ref) <= 1e-10 * abs(ref)
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_input_point_and_function_scale_gradients_sharded_over_the_ranks(panel128, nranks):
+    """Round 6: sgp_logpdf_grad_x / _xs on a multi-GPU context (they used to run on devices[0]) -- every rank contracts its
+    column slabs of G with the kernel derivatives row-side on a column window of each block pair, the per-rank sums are added
+    in rank order.  Against the single-GPU results (1e-10 of the largest entry): the three-block sum model (panel boundaries
+    inside blocks, a block boundary inside a panel) and a programme with two function-valued scales, one nested under the
+    other and shared by two blocks (product.jl:25-48)."""
+    F, x, xs, y = _problem(1411, D=3)
+    ctx = P.lib.Context(devices=[0] * nranks)
+    for noise in (0.1, 0.05 + np.random.default_rng(3).random(len(y))):
+        g0 = P.logpdf_and_gradient(F(x, noise), y, inputs=True)
+        g1 = _with_ctx(ctx, lambda: P.logpdf_and_gradient(F(x, noise), y, inputs=True))
+        assert abs(g1["logpdf"] - g0["logpdf"]) <= 1e-11 * abs(g0["logpdf"])
+        assert len(g0["inputs"]) == len(g1["inputs"]) >= 3
+        for a0, a1 in zip(g0["inputs"], g1["inputs"]):
+            assert a0.shape == a1.shape and np.abs(a1 - a0).max() <= 1e-10 * max(1.0, np.abs(a0).max())
+    rng = np.random.default_rng(33)
+    x1, x2 = rng.standard_normal(420), rng.standard_normal(275)
+    yy = rng.standard_normal(695)
+    gpc = P.GPC()
+    f1 = P.atomic(P.GP(P.Matern32Kernel()), gpc)
+    f2 = P.atomic(P.GP(P.SEKernel()), gpc)
+    g1_ = (lambda t: 1.0 + 0.4 * float(np.sum(np.sin(t)))) * f1
+    G = P.GPPP({"f1": f1, "g1": g1_, "h": (lambda t: float(np.exp(0.15 * np.sum(t)))) * (g1_ + f2)}, gpc)
+    fx = G(P.BlockData([P.GPPPInput("h", x1), P.GPPPInput("g1", x2)]), 0.3)
+    for kw in (dict(scales=True), dict(scales=True, inputs=True)):
+        r0 = P.logpdf_and_gradient(fx, yy, **kw)
+        r1 = _with_ctx(ctx, lambda: P.logpdf_and_gradient(fx, yy, **kw))
+        assert abs(r1["logpdf"] - r0["logpdf"]) <= 1e-11 * abs(r0["logpdf"])
+        assert len(r0["scales"]) == len(r1["scales"]) == 3
+        for s0, s1 in zip(r0["scales"], r1["scales"]):
+            assert np.abs(s1["d_values"] - s0["d_values"]).max() <= 1e-10 * max(1.0, np.abs(s0["d_values"]).max())
+        if "inputs" in kw:
+            for a0, a1 in zip(r0["inputs"], r1["inputs"]):
+                assert np.abs(a1 - a0).max() <= 1e-10 * max(1.0, np.abs(a0).max())
+    ctx.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5, 8])
+def test_covariance_entry_points_sharded_over_the_ranks(nranks):
+    """Round 6: sgp_kernelmatrix / sgp_kernelmatrix_diag on a multi-GPU context (they used to run on devices[0]): column chunks
+    / point slices per rank, no communication.  cov(fx) keeps the symmetric spec's guarantee -- EXACTLY symmetric -- and its
+    bits (the lower triangle comes from the same tile program, the upper one by transposition); cov(fx, gx) and var(fx)
+    likewise; sizes that leave ranks without a chunk, block boundaries inside tiles and inside chunks."""
+    ctx = P.lib.Context(devices=[0] * nranks)
+    for N in (97, 700, 1411):
+        F, x, xs, y = _problem(N, D=3)
+        fx = F(x, 0.1)
+        K0, v0 = P.cov(fx), P.var(fx)
+        K1, v1 = _with_ctx(ctx, lambda: (P.cov(fx), P.var(fx)))
+        assert K1.shape == (N, N) and np.array_equal(K1, K1.T)
+        assert np.array_equal(K1, K0) and np.array_equal(v1, v0)
+        assert np.array_equal(np.diag(K1), v1)
+        # a rectangular cross-covariance between two different collections of the programme
+        rng = np.random.default_rng(N)
+        x2 = P.BlockData([P.GPPPInput("f3", P.ColVecs(np.asfortranarray(rng.standard_normal((3, 333))))),
+                          P.GPPPInput("f1", P.ColVecs(np.asfortranarray(rng.standard_normal((3, 130)))))])
+        C0 = P.cov(fx, F(x2, 0.1))
+        C1 = _with_ctx(ctx, lambda: P.cov(fx, F(x2, 0.1)))
+        assert C1.shape == (N, 463) and np.array_equal(C1, C0)
+    ctx.close()

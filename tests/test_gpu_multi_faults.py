@@ -38,7 +38,7 @@ def _with_ctx(ctx, fn):
 
 def _broken(ctx):
     b = C.c_int()
-    P.lib.check(ctx.lib.sgp_bench_multi_broken(ctx.handle, C.byref(b)))
+    P.lib.check(ctx.bench.sgp_bench_multi_broken(ctx.handle, C.byref(b)))
     return b.value
 
 
@@ -52,7 +52,7 @@ def test_injected_fault_returns_quickly_and_the_loopback_context_stays_usable(mo
     ctx = P.lib.Context(devices=[0] * nranks)
     good = _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
     for rank, step in ((nranks - 1, 7), (0, 0), (1 % nranks, 19)):
-        P.lib.check(ctx.lib.sgp_bench_multi_fault(ctx.handle, rank, step))
+        P.lib.check(ctx.bench.sgp_bench_multi_fault(ctx.handle, rank, step))
         t0 = time.perf_counter()
         with pytest.raises(P.SthenoMIError) as e:
             _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
@@ -63,7 +63,7 @@ def test_injected_fault_returns_quickly_and_the_loopback_context_stays_usable(mo
         # the hook disarmed itself; the context drained and gives the undisturbed bits again -- logpdf and a kept factor
         assert _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y)) == good
     post = _with_ctx(ctx, lambda: P.posterior(F(x, 0.1), y))
-    P.lib.check(ctx.lib.sgp_bench_multi_fault(ctx.handle, 0, 3))
+    P.lib.check(ctx.bench.sgp_bench_multi_fault(ctx.handle, 0, 3))
     with pytest.raises(P.SthenoMIError):
         _with_ctx(ctx, lambda: P.posterior(F(x, 0.1), y))
     xs_new = P.BlockData([P.GPPPInput("f3", P.ColVecs(np.asfortranarray(np.random.default_rng(2).standard_normal((3, 17)))))])
@@ -87,7 +87,7 @@ def test_rccl_context_whose_communicators_were_aborted_refuses_further_calls(mon
     assert ctx.transport == "rccl"
     good = _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
     assert abs(good - P.logpdf(F(x, 0.1), y)) <= 1e-11 * abs(good)
-    P.lib.check(ctx.lib.sgp_bench_multi_fault(ctx.handle, 0, 5))
+    P.lib.check(ctx.bench.sgp_bench_multi_fault(ctx.handle, 0, 5))
     t0 = time.perf_counter()
     with pytest.raises(P.SthenoMIError) as e:
         _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
@@ -105,7 +105,7 @@ def test_rccl_context_whose_communicators_were_aborted_refuses_further_calls(mon
     # the one-thread enqueue issues a grouped broadcast for all ranks or for none: the communicators survive a fault
     monkeypatch.setenv("SGP_MULTI_THREADS", "0")
     ctx = P.lib.Context(devices=[0])
-    P.lib.check(ctx.lib.sgp_bench_multi_fault(ctx.handle, 0, 2))
+    P.lib.check(ctx.bench.sgp_bench_multi_fault(ctx.handle, 0, 2))
     with pytest.raises(P.SthenoMIError):
         _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))
     assert _broken(ctx) == 0
@@ -132,7 +132,7 @@ def test_fault_from_the_environment_and_the_spin_bound(monkeypatch):
     monkeypatch.setenv("SGP_MULTI_SPIN_TIMEOUT_S", "0.5")
     ctx = P.lib.Context(devices=[0, 0, 0])
     assert _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y)) == v
-    P.lib.check(ctx.lib.sgp_bench_multi_stall(ctx.handle, 1, 3, 3.0))
+    P.lib.check(ctx.bench.sgp_bench_multi_stall(ctx.handle, 1, 3, 3.0))
     t0 = time.perf_counter()
     with pytest.raises(P.SthenoMIError) as e:
         _with_ctx(ctx, lambda: P.logpdf(F(x, 0.1), y))

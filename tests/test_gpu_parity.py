@@ -47,7 +47,7 @@ def test_library_is_native_and_loaded():
     with open("/proc/self/maps") as fh:
         assert any("stheno.jl_amd/csrc/libsthenomi.so" in ln for ln in fh)
     tf, err = ctypes.c_double(), ctypes.c_double()
-    P.lib.check(lib.sgp_bench_mfma_f64(ctx.handle, 50, ctypes.byref(tf), ctypes.byref(err)))
+    P.lib.check(ctx.bench.sgp_bench_mfma_f64(ctx.handle, 50, ctypes.byref(tf), ctypes.byref(err)))
     assert err.value == 0.0  # documented MFMA lane maps hold on this device
 
 

@@ -131,7 +131,7 @@ def test_two_contexts_on_one_device_run_concurrently(monkeypatch):
         for n, rc, v, msg in got:
             assert rc == 0 and msg == "" and v == serial[n][1], (n, rc, v, msg, serial[n])
     fb = C.c_int64()
-    L.check(ctx_a.lib.sgp_bench_df_fallbacks(ctx_a.handle, C.byref(fb)))
+    L.check(ctx_a.bench.sgp_bench_df_fallbacks(ctx_a.handle, C.byref(fb)))
     print("dataflow launches rerun on the launch-based schedule while sharing the device:", fb.value)
     ctx_a.close()
     ctx_b.close()
@@ -155,7 +155,7 @@ def test_two_contexts_under_the_hybrid_schedule():
         assert all(r == ref for r in got), (got, ref)
     for ctx in (a, b):
         fb = C.c_int64()
-        L.check(ctx.lib.sgp_bench_df_fallbacks(ctx.handle, C.byref(fb)))
+        L.check(ctx.bench.sgp_bench_df_fallbacks(ctx.handle, C.byref(fb)))
         print("operators rerun on the launches:", fb.value)
         ctx.close()
 

@@ -60,6 +60,6 @@ for k, v in res.items():
     assert all(r == ref for r in v), (k, v, ref)
 for name, ctx in (("a", a), ("b", b)):
     fb = C.c_int64()
-    L.check(ctx.lib.sgp_bench_df_fallbacks(ctx.handle, C.byref(fb)))
+    L.check(ctx.bench.sgp_bench_df_fallbacks(ctx.handle, C.byref(fb)))
     print("context", name, "operators rerun on the launches after a wait bound:", fb.value)
 print("bit-equal to the serial run: ok")

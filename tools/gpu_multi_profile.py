@@ -50,9 +50,9 @@ L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, None, 0, C.byref(n)))
 prof = np.zeros(n.value)
 L.check(ctx.lib.sgp_ctx_multi_profile_get(ctx.handle, L.dptr(prof), n.value, C.byref(n)))
 prof = prof.reshape(-1, 3 + 3 * P)
-L.check(ctx.lib.sgp_bench_multi_profile_pieces(ctx.handle, None, 0, C.byref(n)))
+L.check(ctx.bench.sgp_bench_multi_profile_pieces(ctx.handle, None, 0, C.byref(n)))
 pcs = np.zeros(n.value)
-L.check(ctx.lib.sgp_bench_multi_profile_pieces(ctx.handle, L.dptr(pcs), n.value, C.byref(n)))
+L.check(ctx.bench.sgp_bench_multi_profile_pieces(ctx.handle, L.dptr(pcs), n.value, C.byref(n)))
 pcs = pcs.reshape(-1, 8)
 g = bc.golden(cfg)
 n_pad = (N + 127) // 128 * 128
@@ -65,7 +65,7 @@ for b in prof[:, 2]:                       # panel bytes = 8 * (m_tot - col0) * 
     widths.append(w)
     c0 += w
 nsub = [min(8, -(-w // sub)) if sub >= 128 else 1 for w in widths]
-pieces = [int(v) for v in os.environ.get("SGP_MULTI_PIECES", "").split(",") if v.strip()]
+pieces = []      # (round 6 measured uneven pieces through a library switch that is gone: profiles/r06_experiments/sharded_chain.md)
 piece_frac = None
 if pieces:       # uneven pieces (round 6): panels whose width the pieces add up to
     nsub = [len(pieces) if w == sum(pieces) else n for w, n in zip(widths, nsub)]

@@ -21,6 +21,10 @@ Dependencies as csrc/multi.hip enqueues them (G = panels per group, g = J // G):
 
 transport(bytes): scatter + all-gather over point-to-point xGMI links of `link` GB/s per direction: 2 * bytes / ((P - 1) *
 link); direct copy: bytes / link.
+Round 6: the bracketed "phases pipelined" figure lets the all-gather of sub-panel q run under the scatter of sub-panel q + 1 (they
+use different links and the library issues them on different streams); the headline figure keeps the round-4 / 5 assumption
+(a piece occupies "the links" for both phases) so that rounds stay comparable.  Pieces are priced with their MEASURED times
+(profile field piece_ms) and widths (piece_frac).
 Round 6 (profile field fuse_la): the look-ahead update with the LAST sub-panel of J rides in the first panel launch of J+1, so
 it is part of fac[J+1] (priced as equal pieces -- the first launch is in fact the heaviest, so the first sub-panel leaves a
 little later and the last a little earlier than modelled; the end of the factorisation, which is what the chain waits for, is
@@ -30,7 +34,7 @@ import json
 import sys
 
 
-def project(prof, P, link_gbps, form, contend, free_overlap=False):
+def project(prof, P, link_gbps, form, contend, free_overlap=False, phases=False):
     rows = prof["per_panel"]
     G = int(prof.get("group", 1))
     npan = len(rows)
@@ -94,11 +98,22 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False):
         pm = piece_ms[J][:ns] if piece_ms else None
         tfrac = [v / sum(pm) for v in pm] if pm and sum(pm) > 0 else [1.0 / ns] * ns
         bfrac = piece_frac if (piece_frac and len(piece_frac) == ns) else [1.0 / ns] * ns
-        arr, t, link_free = [], start_ready, 0.0
+        arr, t, link_free, p1_free, p2_free = [], start_ready, 0.0, 0.0, 0.0
         for q in range(ns):
             t = run(o, "panel", t, fac[J] * scale * tfrac[q])
-            link_free = max(t, link_free) + transport(byt[J]) * bfrac[q]
-            arr.append(link_free)
+            if phases and form == "allgather" and P > 2:
+                # round 6: the two phases of scatter + all-gather use DIFFERENT links (owner -> peer, then peer -> peer: xGMI is
+                # a full mesh of point-to-point links) and the library issues them on different streams (one incoming stream
+                # per source rank), so the gather of piece q runs under the scatter of piece q + 1
+                ph = byt[J] * bfrac[q] / ((P - 1) * link_gbps * 1e9) * 1e3
+                e1 = max(t, p1_free) + ph
+                p1_free = e1
+                e2 = max(e1, p2_free) + ph
+                p2_free = e2
+                arr.append(e2)
+            else:
+                link_free = max(t, link_free) + transport(byt[J]) * bfrac[q]
+                arr.append(link_free)
         return t, arr
 
     fact_done, arr = factor_and_send(0, 0.0, 1.0)
@@ -177,9 +192,11 @@ def main():
         for c in sorted({contend, 1.0, 1.3}):
             t, w, b = project(prof, P, link, form, c)
             t3, _, _ = project(prof, P, link, form, c, free_overlap=True)
+            tp, _, _ = project(prof, P, link, form, c, phases=True)
             print(f"  {form:9s} link {link:.0f} GB/s contend {c:.2f}: projected {t:8.1f} ms  (busiest GPU {b:6.1f} ms of work; "
                   f"update streams idle waiting for panels: {w:6.1f} ms summed over ranks)   "
-                  f"[round-3 model, look-ahead overlaps the owner's updates for free: {t3:.1f} ms]")
+                  f"[round-3 model, look-ahead overlaps the owner's updates for free: {t3:.1f} ms]"
+                  + (f"   [scatter / gather phases of successive pieces pipelined: {tp:.1f} ms]" if form == "allgather" else ""))
     t_inf, _, _ = project(prof, P, 1e9, "direct", 1.0)
     print(f"  infinite link bandwidth: {t_inf:.1f} ms  -> compute / critical-path bound of this schedule")
 
