@@ -113,10 +113,10 @@ def update_bytes_avg(N, schedule=None):
 
 
 def lookup_traffic(config, schedule):
-    """the committed counter record of `config` (profiles/r05_traffic.json, else the round-4 file), if it was collected
+    """the committed counter record of `config` (profiles/r06_traffic.json, else the round-5 / round-4 files), if it was collected
     under `schedule`.  A LOOKUP of a committed rocprofv3 --pmc collection, not something this run measures: the record
     carries the sha1 of the library it was collected with and `measured_in_this_run: false`."""
-    for name in ("r05_traffic.json", "r04_traffic.json"):
+    for name in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json"):
         f = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(f):
             continue

@@ -834,21 +834,16 @@ static int df_scratch(sgp_ctx* ctx, long m_tot, int nb, long inv_cols, hipStream
   return 0;
 }
 
-static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
-                         hipStream_t s, long grow = 0, const SzMask* sz = nullptr) {
-  CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
-  // (grow != 0, the gradient path: the caller's pattern covers the identity rows -- sz_pattern's grad_border form)
-  SzScope sz_scope(ctx, A, ld, n_pad, sz);
-  // Dataflow factorisation (chol_df.hip): one launch of persistent workgroups, tile-level dependencies instead of
-  // launches, streams and events.  Same arithmetic, bit-identical factor.  (Not for the gradient path's
-  // upper-triangular border, `grow`: its tasks would have to skip the structurally zero tiles.)
-  // hybrid (round 5; use_hybrid above): the look-ahead schedule of the launches, its panels factored by the dataflow kernel
-  // (also for the gradient path's border, `grow`: a panel launch takes the rows its panel touches, the identity rows among
-  // them as bordered rows -- only the few tiles above the identity's diagonal inside ONE panel are multiplied out, or
-  // skipped when the caller's pattern covers them)
-  const bool hybrid = s == ctx->stream && use_hybrid(ctx, n_pad, grow != 0);
-  if (hybrid || (grow == 0 && use_dataflow(ctx, n_pad))) CHECK_RC(df_scratch(ctx, m_tot, 1, d_wall ? 0 : n_pad, s));
-  if (!hybrid && grow == 0 && use_dataflow(ctx, n_pad)) {
+// ---- one function per schedule of the blocked Cholesky (round 6: rounds 3 - 5 had grown ONE loop that threaded six booleans --
+// hybrid, la, deep, fuse_outer, grow, sz -- through itself); chol_bordered below only chooses.  Every schedule performs the
+// same arithmetic per tile (k ascending): the factor is bit-identical whichever runs (tests/test_gpu_dataflow.py).
+
+// (1) the whole bordered factorisation as ONE launch of the dataflow kernel (chol_df.hip): persistent workgroups, tile-level
+// dependencies instead of launches, streams and events.  3072 <= n_pad < 24576 by default.
+static int chol_dataflow_whole(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall, hipStream_t s,
+                               const SzMask* sz) {
+  CHECK_RC(df_scratch(ctx, m_tot, 1, d_wall ? 0 : n_pad, s));
+  {
     const int fat = n_pad < ctx->df_fat_max_n ? 1 : 0;
     if (getenv("SGP_DF_STATS") && !ctx->d_df_stats)   // + 8 stamps for each of up to 4096 tile columns
       SGP_HIP(hipMalloc(&ctx->d_df_stats, sizeof(long long) * 8 * ((size_t)ctx->df_wgs + 4096)));
@@ -933,85 +928,39 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
         }
       }
     }
-    return 0;
   }
-  // outer panel width, measured (profiles/archive/r02_summary.md): one panel for n_pad <= 4096 (the outer level only
-  // adds launches there: 1.52 -> 1.30 ms at N = 2048; with the fused diagonal blocks 2.73 -> 2.47 ms at N = 4096),
-  // 1024 up to 8192, 512 in the
-  // mid range where the panel stream is the critical path (N = 16384: 34.8 vs 35.4 ms), 1024 from 32768 on
-  // (halves the C-tile traffic per flop of the big trailing updates).
-  // Look-ahead below SGP_LA_MAX_N (65536) columns only.  At N = 65536 the overlap hides ~70 ms of panel chain but the
-  // sharing costs the trailing updates as much (per launch 0.72 of the fp64 MFMA peak beside the panel stream, 0.81
-  // alone); the serial schedule with fused diagonal blocks measures the same or better (1525 vs 1539 ms dense
-  // Matern-5/2, 1515 vs 1501 ms on the three-block model, same box) and leaves every kernel uncontended; at 32768 the
-  // look-ahead still wins (202 vs 207 ms).  SGP_LOOKAHEAD=2: look-ahead at every size.
-  const bool la = (ctx->lookahead && s == ctx->stream && (n_pad < ctx->la_max_n || ctx->lookahead == 2)) || hybrid;
-  // Serial schedule at n_pad >= 65536 (round 3): outer panels of 4096 columns factored by recursive halving down to 1024
-  // (panel_factor_mid) -- the big trailing updates run with K = 4096, the mid updates with K = 2048 / 1024, the shallow
-  // K = 128 work stays that of 1024-wide panels: per-tile prologue / epilogue share and C-tile traffic per flop drop,
-  // same flops, bit-identical result.  N = 65536 on one box: W = 1024 1499 ms, 2048 / 1024 1469, 4096 / 1024 1458,
-  // 8192 / 1024 1463, 16384 / 1024 1469, 4096 / 512 1465; under the look-ahead (N = 16384, 32768) it loses.
-  // (one stream: the compacted id maps of consecutive structured launches may share one scratch buffer)
-  // (two streams under the look-ahead: a map each)
-  if (sz_scope.on && s == ctx->stream)
-    gemm_set_structure(A, ld, sz->d_nz, sz->words, n_pad, ctx->d_szmap, ctx->n_szmap / 2, 0, la ? ctx->stream2 : nullptr,
-                       la ? ctx->d_szmap + ctx->n_szmap / 2 : nullptr);
-  const bool deep = !la && n_pad >= 65536;
-  const long WOUT = hybrid ? std::min(ctx->hybrid_w, n_pad)
-                    : ctx->wout > 0 ? ctx->wout
-                    : n_pad <= 4096 ? n_pad
-                    : n_pad <= 8192 ? WOUT_LARGE
-                    : deep ? 4 * WOUT_LARGE
-                    : n_pad >= 32768 ? WOUT_LARGE
-                                     : WOUT_SMALL;
-  const long WMID = ctx->wmid > 0 ? ctx->wmid : (deep && ctx->wout <= 0 ? WOUT_LARGE : 0);
-  // (SGP_HYBRID_SERIAL=1, measurement only: the far updates on the panel stream too -- every kernel has the chip alone)
-  hipStream_t sB = (la && !(hybrid && ctx->hybrid_serial)) ? ctx->stream2 : s;
-  // SGP_FUSE_POTRF bit 1: the trailing update that finishes the next panel's first diagonal block (the look-ahead
-  // column update, or the whole update when the look-ahead is off) factors that block in the same launch
-  // Both apply while n_pad < SGP_FUSE_MAX_N (32768), where the panel chain is the critical path: N = 2048 1.17 ->
-  // 1.09 ms, 4096 2.93 -> 2.73 ms, 16384 33.8 -> 33.2 ms; from 32768 on the panel stream has slack and the fused
-  // launches measure the same or 1 % slower (profiles/archive/r02_microbench.md).  Bit 2: at every size (A/B).
-  FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad, !la));
-  const bool fuse_outer = (ctx->fuse_now & 2) && !hybrid;   // (the dataflow panel factors its own first block)
-  bool first_done = false;
+  return 0;
+}
+
+// what the two launch-based schedules share: the trailing updates of outer panel [J0, J0 + wj) -- with look-ahead (`la`) the
+// next panel's columns on the panel stream s (optionally factoring that panel's first diagonal block in the same launch, fz)
+// and the rest on the update stream sB; without it one launch on s
+struct OuterSweep {
+  sgp_ctx* ctx;
+  double* A;
+  long ld, n_pad, m_tot, grow;
+  hipStream_t s, sB;
+  bool la;
   bool rest_pending = false;
-  if (la) {
+  long rows(long J0, long wj) const { return grow > 0 ? std::min(m_tot, grow + J0 + wj) : m_tot; }   // rows panel J0 touches
+  int begin() {
+    if (!la) return 0;
     // the update stream must see everything enqueued on s so far (assembly)
     SGP_HIP(hipEventRecord(ctx->ev_panel, s));
     SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
+    return 0;
   }
-  for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
-    long wj = std::min(WOUT, n_pad - J0);
-    const long m_eff = grow > 0 ? std::min(m_tot, grow + J0 + wj) : m_tot;  // rows this panel touches
-    if (hybrid) {
-      // the panel as ONE launch of persistent workgroups: its diagonal chain and the row solves below it with tile-level
-      // dependencies (the rows below the panel's diagonal block are the kernel's "bordered rows")
-      CHECK_RC(launch_chol_dataflow(A + J0 + J0 * ld, ld, wj, m_eff - J0, ctx->d_df_state,
-                                    (d_wall ? d_wall : ctx->d_df_inv) + (J0 / TILE) * INVD_STRIDE, ctx->d_slots + J0 / TILE,
-                                    ctx->d_info, ctx->hybrid_wgs, ctx->df_timeout_s, s, nullptr, nullptr, ctx->hybrid_fat,
-                                    sz ? sz->d_nz : nullptr, sz ? sz->words : 0, J0));
-    } else
-      CHECK_RC(panel_factor_mid(ctx, A + J0 + J0 * ld, ld, m_eff - J0, wj, J0, ctx->d_slots + J0 / TILE,
-                                ctx->d_info, d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done, WMID));
-    long c0 = J0 + wj;
-    if (c0 >= n_pad) break;
-    const FusedDiag fz_next = {d_wall ? d_wall + (c0 / TILE) * INVD_STRIDE : ctx->d_invd, ctx->d_slots + c0 / TILE,
-                               ctx->d_info, c0, (ctx->fuse_now & 8) ? 1 : 0};
-    const FusedDiag* fz = fuse_outer ? &fz_next : nullptr;
-    first_done = fuse_outer;
-    long w1 = std::min(WOUT, n_pad - c0);   // width of the next panel
-    long c1 = c0 + w1;
-    const bool la_k = la;
-    if (la_k) {
+  int updates(long J0, long wj, long WOUT, const FusedDiag* fz) {
+    const long c0 = J0 + wj, m_eff = rows(J0, wj);
+    const long w1 = std::min(WOUT, n_pad - c0), c1 = c0 + w1;   // the next panel
+    if (la) {
       SGP_HIP(hipEventRecord(ctx->ev_panel, s));
       // look-ahead: next panel's columns on the panel stream (after the previous rest update)
       if (rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
       CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_eff - c0, w1, wj, s, fz));
       if (c1 < n_pad) {
         SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
-        CHECK_RC(launch_update(ctx, A + c1 + J0 * ld, ld, A + c1 + c1 * ld, m_eff - c1, n_pad - c1,
-                               wj, sB));
+        CHECK_RC(launch_update(ctx, A + c1 + J0 * ld, ld, A + c1 + c1 * ld, m_eff - c1, n_pad - c1, wj, sB));
         SGP_HIP(hipEventRecord(ctx->ev_rest, sB));
         rest_pending = true;
       }
@@ -1022,9 +971,97 @@ static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_to
       }
       CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_eff - c0, n_pad - c0, wj, s, fz));
     }
+    return 0;
   }
-  if (la && rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
-  return 0;
+  int end() {
+    if (la && rest_pending) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
+    return 0;
+  }
+};
+
+// (2) hybrid (round 5; use_hybrid above): the look-ahead schedule of the launches with every outer PANEL (2048 columns) factored
+// by ONE launch of the dataflow kernel on the panel -- also for the gradient path's border (`grow`: a panel launch takes the
+// rows its panel touches, the identity rows among them as bordered rows; only the few tiles above the identity's diagonal
+// inside one panel are multiplied out, or skipped when the caller's pattern covers them).  From 24576 columns on.
+static int chol_hybrid(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall, hipStream_t s, long grow,
+                       const SzMask* sz) {
+  CHECK_RC(df_scratch(ctx, m_tot, 1, d_wall ? 0 : n_pad, s));
+  const long WOUT = std::min(ctx->hybrid_w, n_pad);
+  // (SGP_HYBRID_SERIAL=1, measurement only: the far updates on the panel stream too -- every kernel has the chip alone)
+  OuterSweep sw{ctx, A, ld, n_pad, m_tot, grow, s, ctx->hybrid_serial ? s : ctx->stream2, true};
+  CHECK_RC(sw.begin());
+  for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
+    const long wj = std::min(WOUT, n_pad - J0);
+    // the panel as ONE launch of persistent workgroups: its diagonal chain and the row solves below it with tile-level
+    // dependencies (the rows below the panel's diagonal block are the kernel's "bordered rows")
+    CHECK_RC(launch_chol_dataflow(A + J0 + J0 * ld, ld, wj, sw.rows(J0, wj) - J0, ctx->d_df_state,
+                                  (d_wall ? d_wall : ctx->d_df_inv) + (J0 / TILE) * INVD_STRIDE, ctx->d_slots + J0 / TILE,
+                                  ctx->d_info, ctx->hybrid_wgs, ctx->df_timeout_s, s, nullptr, nullptr, ctx->hybrid_fat,
+                                  sz ? sz->d_nz : nullptr, sz ? sz->words : 0, J0));
+    if (J0 + wj >= n_pad) break;
+    CHECK_RC(sw.updates(J0, wj, WOUT, nullptr));   // (the dataflow panel factors its own first block: nothing fused)
+  }
+  return sw.end();
+}
+
+// (3) launches: the two-level right-looking schedule of rounds 1 - 3 -- n_pad < 3072, and whenever the other two are switched
+// off (SGP_DATAFLOW=0 SGP_HYBRID=0: the dataflow time-out fallback, the A/B tests).
+//   outer panel width, measured (profiles/archive/r02_summary.md): one panel for n_pad <= 4096 (the outer level only adds
+//   launches there: 1.52 -> 1.30 ms at N = 2048), 1024 up to 8192, 512 in the mid range where the panel stream is the
+//   critical path (N = 16384: 34.8 vs 35.4 ms), 1024 from 32768 on (halves the C-tile traffic per flop of the big updates);
+//   look-ahead below 65536 columns only (la_max_n): at N = 65536 the overlap hides ~70 ms of panel chain but the sharing costs
+//   the trailing updates as much; SGP_LOOKAHEAD=2: look-ahead at every size;
+//   serial-deep at n_pad >= 65536 (round 3): outer panels of 4096 columns factored by recursive halving down to 1024
+//   (panel_factor_mid) -- the big trailing updates run with K = 4096, the mid updates with K = 2048 / 1024;
+//   SGP_FUSE_POTRF bit 1: the trailing update that finishes the next panel's first diagonal block factors that block in the
+//   same launch, below 32768 columns where the panel chain is the critical path (fuse_max_n; bit 2: at every size).
+static int chol_launches(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall, hipStream_t s, long grow) {
+  const bool la = ctx->lookahead && s == ctx->stream && (n_pad < ctx->la_max_n || ctx->lookahead == 2);
+  const bool deep = !la && n_pad >= 65536;
+  const long WOUT = ctx->wout > 0 ? ctx->wout
+                    : n_pad <= 4096 ? n_pad
+                    : n_pad <= 8192 ? WOUT_LARGE
+                    : deep ? 4 * WOUT_LARGE
+                    : n_pad >= 32768 ? WOUT_LARGE
+                                     : WOUT_SMALL;
+  const long WMID = ctx->wmid > 0 ? ctx->wmid : (deep && ctx->wout <= 0 ? WOUT_LARGE : 0);
+  FuseScope fuse_scope(ctx, fuse_mode(ctx, n_pad, !la));
+  const bool fuse_outer = (ctx->fuse_now & 2) != 0;
+  OuterSweep sw{ctx, A, ld, n_pad, m_tot, grow, s, la ? ctx->stream2 : s, la};
+  CHECK_RC(sw.begin());
+  bool first_done = false;
+  for (long J0 = 0; J0 < n_pad; J0 += WOUT) {
+    const long wj = std::min(WOUT, n_pad - J0);
+    CHECK_RC(panel_factor_mid(ctx, A + J0 + J0 * ld, ld, sw.rows(J0, wj) - J0, wj, J0, ctx->d_slots + J0 / TILE, ctx->d_info,
+                              d_wall ? d_wall + (J0 / TILE) * INVD_STRIDE : nullptr, s, first_done, WMID));
+    const long c0 = J0 + wj;
+    if (c0 >= n_pad) break;
+    const FusedDiag fz_next = {d_wall ? d_wall + (c0 / TILE) * INVD_STRIDE : ctx->d_invd, ctx->d_slots + c0 / TILE,
+                               ctx->d_info, c0, (ctx->fuse_now & 8) ? 1 : 0};
+    first_done = fuse_outer;
+    CHECK_RC(sw.updates(J0, wj, WOUT, fuse_outer ? &fz_next : nullptr));
+  }
+  return sw.end();
+}
+
+// The dispatcher.  grow > 0 (the gradient path): bordered rows >= n_pad hold a matrix that is upper triangular by tile from row
+// `grow` on (the identity rows: row grow + i stays zero left of column i), so panel J0 .. J0 + wj only touches rows
+// < grow + J0 + wj; its pattern (sz) covers the identity rows (sz_pattern's grad_border form).
+static int chol_bordered(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot, double* d_wall,
+                         hipStream_t s, long grow = 0, const SzMask* sz = nullptr) {
+  CHECK_ARG(n_pad / TILE <= ctx->n_slots, "matrix too large for the logdet slot buffer");
+  SzScope sz_scope(ctx, A, ld, n_pad, sz);
+  const bool hybrid = s == ctx->stream && use_hybrid(ctx, n_pad, grow != 0);
+  if (!hybrid && grow == 0 && use_dataflow(ctx, n_pad)) return chol_dataflow_whole(ctx, A, ld, n_pad, m_tot, d_wall, s, sz);
+  // the launch-based updates read the pattern through gemm_nt.hip's per-thread record; the compacted id maps of consecutive
+  // structured launches of ONE stream may share a scratch buffer, the update stream of a look-ahead gets a map of its own
+  if (sz_scope.on && s == ctx->stream) {
+    const bool two = hybrid || (ctx->lookahead && (n_pad < ctx->la_max_n || ctx->lookahead == 2));
+    gemm_set_structure(A, ld, sz->d_nz, sz->words, n_pad, ctx->d_szmap, ctx->n_szmap / 2, 0, two ? ctx->stream2 : nullptr,
+                       two ? ctx->d_szmap + ctx->n_szmap / 2 : nullptr);
+  }
+  if (hybrid) return chol_hybrid(ctx, A, ld, n_pad, m_tot, d_wall, s, grow, sz);
+  return chol_launches(ctx, A, ld, n_pad, m_tot, d_wall, s, grow);
 }
 
 // K + Sigma_y (lower tiles), identity padding, bordered rows

@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-5 evidence, ONE gpurun call -> gpurun_out/r05final (tools/make_r05_summary.py turns it into profiles/r05_*).
+# Round-6 evidence, ONE gpurun call -> gpurun_out/r06final (tools/make_r06_summary.py turns it into profiles/r06_*).
 # Everything is collected against ONE build: the sha1 of libsthenomi.so is written next to every record and the summary
 # tool refuses a collection whose pieces disagree (round-3 verdict: a stale PMC pass had been divided by a new schedule's
 # algorithmic bytes).  --kernel-trace / --stats and --pmc are separate runs.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/r05final
+OUT=$R/gpurun_out/r06final
 cd $R
 SHA=$(sha1sum stheno.jl_amd/csrc/libsthenomi.so | cut -d' ' -f1)
 if [ -n "$COLLECT_ONLY_PMC" ]; then
@@ -30,27 +30,30 @@ timeout 400 python $R/bench.py --config c5 --dtype f32 --steps 3 --warmup 1 --cp
 timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config target --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_target_multi8_loopback.json 2> $OUT/bench_target_multi8_loopback.err
 timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config c5 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_multi8_loopback.json 2> $OUT/bench_c5_multi8_loopback.err
 SGP_MULTI_SUBPANEL=0 timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config c5 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_multi8_loopback_sub0.json 2> $OUT/bench_c5_multi8_loopback_sub0.err
+# the launch-based panel chain of rounds 2 - 5 on the same box (SGP_MULTI_PANEL_DF=0: same bits)
+for c in c5 target; do SGP_MULTI_PANEL_DF=0 timeout 400 python $R/bench.py --gpus 8 --devices 0,0,0,0,0,0,0,0 --config $c --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_${c}_multi8_loopback_r5chain.json 2> $OUT/bench_${c}_multi8_loopback_r5chain.err; done
 timeout 300 python $R/bench.py --gpus 2 --devices 0,0 --config c4 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c4_multi2_loopback.json 2> $OUT/bench_c4_multi2_loopback.err
 timeout 400 python $R/bench.py --config c5 --force-dist --steps 2 --warmup 1 --cpu-sample 0 > $OUT/bench_c5_dist1.json 2> $OUT/bench_c5_dist1.err
-# ---- multi-GPU profiles (serialised per-panel timings) + projections
-for v in "default X=1" "sub0 SGP_MULTI_SUBPANEL=0"; do
-  set -- $v; tag=$1; shift
-  env "$@" timeout 600 python $R/tools/gpu_multi_profile.py c5 8 $OUT/multi_profile_c5_P8_$tag.json > $OUT/multi_profile_c5_P8_$tag.log 2>&1
-  python $R/tools/multi_projection.py $OUT/multi_profile_c5_P8_$tag.json > $OUT/projection_c5_P8_$tag.txt 2>&1
+# ---- multi-GPU profiles (serialised per-panel timings) + projections: the default (dataflow panel launches, last look-ahead piece
+# fused), the unfused form, the round-5 chain, whole panels -- all on this one box
+mprof() {   # tag config P env...
+  tag=$1; cfg=$2; PP=$3; shift 3
+  env "$@" timeout 600 python $R/tools/gpu_multi_profile.py $cfg $PP $OUT/multi_profile_${cfg}_P${PP}_$tag.json > $OUT/multi_profile_${cfg}_P${PP}_$tag.log 2>&1
+  python $R/tools/multi_projection.py $OUT/multi_profile_${cfg}_P${PP}_$tag.json > $OUT/projection_${cfg}_P${PP}_$tag.txt 2>&1
+}
+for cfg in c5 target; do
+  mprof default $cfg 8 X=1
+  mprof nofuse $cfg 8 SGP_MULTI_FUSE_LA=0
+  mprof r5chain $cfg 8 SGP_MULTI_PANEL_DF=0
+  mprof sub0 $cfg 8 SGP_MULTI_SUBPANEL=0
 done
-timeout 600 python $R/tools/gpu_multi_profile.py target 8 $OUT/multi_profile_target_P8_default.json > $OUT/multi_profile_target_P8_default.log 2>&1
-python $R/tools/multi_projection.py $OUT/multi_profile_target_P8_default.json > $OUT/projection_target_P8_default.txt 2>&1
-# the same model under the round-4 ownership (cyclic deal) and with sub-panels of 256
-SGP_MULTI_OWNERS=cyclic timeout 600 python $R/tools/gpu_multi_profile.py target 8 $OUT/multi_profile_target_P8_cyclic.json > $OUT/multi_profile_target_P8_cyclic.log 2>&1
-python $R/tools/multi_projection.py $OUT/multi_profile_target_P8_cyclic.json > $OUT/projection_target_P8_cyclic.txt 2>&1
-SGP_MULTI_SUBPANEL=256 timeout 600 python $R/tools/gpu_multi_profile.py target 8 $OUT/multi_profile_target_P8_sub256.json > $OUT/multi_profile_target_P8_sub256.log 2>&1
-python $R/tools/multi_projection.py $OUT/multi_profile_target_P8_sub256.json > $OUT/projection_target_P8_sub256.txt 2>&1
-SGP_STRUCT_ZEROS=0 timeout 600 python $R/tools/gpu_multi_profile.py target 8 $OUT/multi_profile_target_P8_dense.json > $OUT/multi_profile_target_P8_dense.log 2>&1
-python $R/tools/multi_projection.py $OUT/multi_profile_target_P8_dense.json > $OUT/projection_target_P8_dense.txt 2>&1
-for P in 2 4; do
-  timeout 600 python $R/tools/gpu_multi_profile.py c5 $P $OUT/multi_profile_c5_P${P}_default.json > $OUT/multi_profile_c5_P${P}_default.log 2>&1
-  python $R/tools/multi_projection.py $OUT/multi_profile_c5_P${P}_default.json > $OUT/projection_c5_P${P}_default.txt 2>&1
-done
+mprof nocompact target 8 SGP_MULTI_COMPACT=0
+mprof dense target 8 SGP_STRUCT_ZEROS=0
+mprof cyclic target 8 SGP_MULTI_OWNERS=cyclic
+for P in 2 4; do mprof default c5 $P X=1; done
+# ---- small N through sgp_logpdf_batch / concurrent contexts, the mid-N schedule sweep
+timeout 600 python $R/tools/gpu_batch_time.py 2048 4096 8192 > $OUT/batch_time.json 2> $OUT/batch_time.err
+timeout 900 python $R/tools/gpu_midn_sweep.py 12288 16384 20480 > $OUT/midn_sweep.txt 2> $OUT/midn_sweep.err
 # ---- kernel traces (rocprofv3 --kernel-trace --stats of the same commands)
 for c in c5 target c3 c2 n4k c1; do
   st=3; [ $c = c1 ] && st=10
@@ -63,6 +66,12 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_gr
     python $R/tools/gpu_grad_split.py 16384 > $OUT/prof_grad_c2.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_c4 -o c4 -- \
     python $R/bench.py --config c4 --steps 2 --warmup 1 --cpu-sample 0 > $OUT/prof_c4_bench.json 2> $OUT/prof_c4.err
+# the dominant kernel's rate while it is on the chip, from the trace's begin / end stamps alone (tools/trace_busy.py)
+for c in c5 target; do
+  tr=$(find $OUT/prof_$c -name "*kernel_trace.csv" | head -1)
+  [ -n "$tr" ] && python $R/tools/trace_busy.py $tr $OUT/prof_${c}_bench.json > $OUT/trace_busy_$c.json 2> $OUT/trace_busy_$c.err
+  [ -n "$tr" ] && python $R/tools/trace_busy.py $tr $OUT/prof_${c}_bench.json chol_dataflow_fat_kernel > $OUT/trace_busy_${c}_panel_kernel.json 2>> $OUT/trace_busy_$c.err
+done
 rm -f $OUT/*/*/*kernel_trace.csv $OUT/*/*kernel_trace.csv
 fi
 # ---- HBM-side traffic (FETCH_SIZE / WRITE_SIZE, separate passes) of the dominant kernel of every line

@@ -1,6 +1,6 @@
-"""gpurun_out/r05final (tools/collect_r05.sh, ONE gpurun call) -> profiles/r05_*: bench lines, rocprofv3 kernel stats, the
-HBM-side traffic of every line's dominant kernel (profiles/r05_traffic.json -- what bench.py prints as roofline.traffic), the
-multi-GPU profiles / projections, and profiles/r05_summary.md.  Refuses a collection whose pieces were not produced by ONE
+"""gpurun_out/r06final (tools/collect_r06.sh, ONE gpurun call) -> profiles/r06_*: bench lines, rocprofv3 kernel stats, the
+HBM-side traffic of every line's dominant kernel (profiles/r06_traffic.json -- what bench.py prints as roofline.traffic), the
+multi-GPU profiles / projections, and profiles/r06_summary.md.  Refuses a collection whose pieces were not produced by ONE
 build of libsthenomi.so (every record carries the library's sha1)."""
 import csv
 import glob
@@ -10,9 +10,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r05final")
+SRC = os.path.join(ROOT, "gpurun_out", "r06final")
 DST = os.path.join(ROOT, "profiles")
-TAG = "r05"
+TAG = "r06"
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (update_bytes_avg: the algorithmic bytes of the trailing updates)
 
@@ -35,7 +35,8 @@ DOMINANT = {   # config -> substring of the dominant kernel's name
 }
 lines, traffic = {}, {}
 for c in ("default", "c1", "n4k", "c2", "c3", "n32k", "c4", "target", "c3_dense", "target_dense", "target_multi8_loopback", "c5_f32", "c5_multi8_loopback", "c5_multi8_loopback_sub0",
-          "c4_multi2_loopback", "c5_dist1", "c5_nohybrid", "target_nohybrid", "n32k_nohybrid", "c3_nohybrid"):
+          "c4_multi2_loopback", "c5_dist1", "c5_nohybrid", "target_nohybrid", "n32k_nohybrid", "c3_nohybrid",
+          "c5_multi8_loopback_r5chain", "target_multi8_loopback_r5chain"):
     d = jload(f"bench_{c}.json")
     if d:
         lines[c] = d
@@ -70,7 +71,7 @@ for c, pat in DOMINANT.items():
                                     "streaming reads (MI355X_MICROARCH.md, HBM); Infinity-Cache hits are counted: an upper bound",
                   "algorithmic_bytes": alg, "ratio_to_algorithmic": hbm / alg, "lib_sha1": sha,
                   "schedule": (line or {}).get("roofline", {}).get("schedule"),
-                  "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --config {c} --steps 1 --warmup 0 (tools/collect_r05.sh)"}
+                  "command": f"rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE -- python bench.py --config {c} --steps 1 --warmup 0 (tools/collect_r06.sh)"}
 json.dump(traffic, open(os.path.join(DST, f"{TAG}_traffic.json"), "w"), indent=1)
 for c in ("c5", "target", "c3"):
     p = os.path.join(SRC, f"pmc_{c}_MFMA.json")
@@ -79,7 +80,7 @@ for c in ("c5", "target", "c3"):
         assert d["lib_sha1"] == sha
         out = {}
         for k, v in d["kernels"].items():
-            if DOMINANT[c] in k and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
+            if (DOMINANT[c] in k or "chol_dataflow" in k) and "SQ_VALU_MFMA_BUSY_CYCLES" in v and "GRBM_GUI_ACTIVE" in v:
                 out[k] = {"launches": v["GRBM_GUI_ACTIVE"]["launches"],
                           "mfma_busy_frac": v["SQ_VALU_MFMA_BUSY_CYCLES"]["sum"] / (v["GRBM_GUI_ACTIVE"]["sum"] * 128.0)}
         json.dump({"lib_sha1": sha, "note": "SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 * 1024) -- the round-3 normalisation", "kernels": out},
@@ -90,11 +91,13 @@ for c in ("c5", "target", "c3", "c2", "n4k", "c1", "c4", "c5_f32", "grad_c2"):
     st = glob.glob(os.path.join(SRC, f"prof_{c}", "**", "*kernel_stats.csv"), recursive=True)
     if st:
         shutil.copy(st[0], os.path.join(DST, f"{TAG}_bench_{c}_kernel_stats.csv"))
-for f in glob.glob(os.path.join(SRC, "multi_profile_*.json")) + glob.glob(os.path.join(SRC, "projection_*.txt")):
+for f in (glob.glob(os.path.join(SRC, "multi_profile_*.json")) + glob.glob(os.path.join(SRC, "projection_*.txt")) +
+          glob.glob(os.path.join(SRC, "trace_busy_*.json")) + glob.glob(os.path.join(SRC, "batch_time.json")) +
+          glob.glob(os.path.join(SRC, "midn_sweep.txt"))):
     shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
 
 # ---- summary
-L = [f"# Round 5 -- collected evidence (one `gpurun` call, `tools/collect_r05.sh`; libsthenomi.so sha1 `{sha[:12]}`)", ""]
+L = [f"# Round 6 -- collected evidence (one `gpurun` call, `tools/collect_r06.sh`; libsthenomi.so sha1 `{sha[:12]}`)", ""]
 py = open(os.path.join(SRC, "pytest_gpu.log")).read().strip().splitlines()
 L += ["* `pytest -m gpu`: " + next((ln for ln in reversed(py) if "passed" in ln or "failed" in ln), "?"),
       "* smoke: " + open(os.path.join(SRC, "smoke.log")).read().strip().splitlines()[-1], ""]
@@ -130,8 +133,17 @@ if "default" in lines:
                      f"dense-equivalent {ns.get('dense_equivalent_tflops', 0):.1f} TFLOP/s) | | | | | |")
         L.append(f"| ... its `north_star_target` extra (3-process @gppp, N = 65536, host-buffer entry point) | {ns['ms_per_step']:.2f} | "
                  f"{ns['frac']:.3f} | | | {ns['parity_rel']:.1e} |")
+    r4 = (d.get("roofline") or {}).get("round4_schedule_same_box")
+    if r4:
+        L.append(f"| ... its `roofline.round4_schedule_same_box` leg (SGP_HYBRID=0, second context, same buffers; same bits: {r4['same_bits']}) | "
+                 f"{r4['ms_per_step']:.2f} | | hybrid / this = {r4['hybrid_over_this']:.3f} | | |")
     for k, v in (d.get("sizes") or {}).items():
-        L.append(f"| ... its `sizes.{k}` extra | {v['ms_per_step']:.3f} | {v['frac']:.3f} | ({v['schedule']}) | | {v['parity_rel']:.1e} |")
+        if "members" in v:
+            L.append(f"| ... its `sizes.{k}` extra: sgp_logpdf_batch, {v['members']} members, one task pool | {v['ms_per_call']:.3f} per call = "
+                     f"{v['ms_per_member']:.3f} per member | {v['frac']:.3f} aggregate | every member bit-equal to its own call: "
+                     f"{v['every_member_bit_equal_to_its_own_call']} | | {v['member0_parity_rel']:.1e} (member 0) |")
+        else:
+            L.append(f"| ... its `sizes.{k}` extra | {v['ms_per_step']:.3f} | {v['frac']:.3f} | ({v['schedule']}) | | {v['parity_rel']:.1e} |")
 for c in ("c5_nohybrid", "target", "target_nohybrid", "target_dense", "c3", "c3_nohybrid", "c3_dense", "n32k", "n32k_nohybrid", "c2", "n4k", "c1",
           "c4", "c5_f32"):
     if c in lines:
@@ -156,7 +168,20 @@ if d0 and d0.get("cpu_baseline"):
     L += ["## CPU baseline of the default line (a restatement, NOT Julia; a reported number, not credit)", "",
           f"* {cb.get('sample')}", f"* value {cb['value']:.5f} {cb['unit']} on {cb['cores']} threads of {cb.get('host_cores')} logical / "
           f"{cb.get('physical_cores_visible')} physical cores; Cholesky sweep (GFLOP/s at n = {cb.get('cholesky_sweep_n')}): `{json.dumps(cb.get('cholesky_sweep_gflops'))}`", ""]
-for c in ("c5_multi8_loopback", "c5_multi8_loopback_sub0", "target_multi8_loopback", "c4_multi2_loopback", "c5_dist1"):
+for c in ("c5", "target"):
+    for suffix, what in (("", "update launches (gemm_nt_dma_kernel<1>)"), ("_panel_kernel", "panel launches (chol_dataflow_fat_kernel)")):
+        p = os.path.join(SRC, f"trace_busy_{c}{suffix}.json")
+        if os.path.exists(p) and os.path.getsize(p):
+            tb = json.load(open(p))
+            ms_ = tb.get("median_step") or {}
+            if ms_:
+                fr_ = tb.get("achieved_while_busy_frac_of_78.6")
+                L.append(f"* rocprofv3 kernel trace of `{c}`, {what}: {ms_['dispatches_of_kernel']} dispatches per step, union of their intervals "
+                         f"{ms_['busy_ms']:.1f} ms, sum of their durations {ms_['sum_of_durations_ms']:.1f} ms, step span {ms_['step_span_ms']:.1f} ms"
+                         + (f" => {fr_:.3f} of the fp64 MFMA peak while the kernel is on the chip" if fr_ and not suffix else ""))
+L.append("")
+for c in ("c5_multi8_loopback", "c5_multi8_loopback_r5chain", "c5_multi8_loopback_sub0", "target_multi8_loopback", "target_multi8_loopback_r5chain",
+          "c4_multi2_loopback", "c5_dist1"):
     if c in lines:
         d = lines[c]
         mg = d.get("multi_gpu") or {}

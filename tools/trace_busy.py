@@ -37,8 +37,9 @@ def main():
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
     starts = [i for i, r in enumerate(rows) if "assemble_block" in r[2]]
-    # one assembly launch per logpdf step (several per step would be adjacent: keep the first of a run closer than 1 ms)
-    firsts = [i for k, i in enumerate(starts) if k == 0 or rows[i][0] - rows[starts[k - 1]][0] > 1_000_000]
+    # a step starts with its assembly launches (one per block pair and term group: a CONTIGUOUS run of dispatches); keep the
+    # first launch of every run
+    firsts = [i for k, i in enumerate(starts) if k == 0 or i != starts[k - 1] + 1]
     line = json.loads(open(bench).read().strip().splitlines()[-1])
     roof = line.get("roofline") or {}
     flops = (roof.get("algorithmic_flops_per_launch_avg") or 0.0) * (roof.get("launches") or 0)
