@@ -158,8 +158,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=os.environ.get("SGP_BENCH_CONFIG", "c5"), choices=sorted(bc.CONFIGS))
-    ap.add_argument("--cpu-sample", type=int, default=16384,
-                    help="N of the bounded CPU-baseline sample (0 = skip; ELBO: 2x this many data points)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="N of the bounded CPU-baseline sample (0 = skip; -1 = automatic: min(N, 32768) -- at the headline size the "
+                         "Cholesky of the sample is 1/8 of the workload's, 8 s of LAPACK dpotrf; round 5 sampled 16384 = 1/64; "
+                         "ELBO: 2x this many data points, automatic 16384)")
     ap.add_argument("--panel", type=int, default=1024, help="column-panel width of the multi-GPU path")
     ap.add_argument("--force-dist", action="store_true", help="use the sharded (multi-GPU) driver even at 1 GPU")
     ap.add_argument("--devices", default=os.environ.get("SGP_BENCH_DEVICES", ""),
@@ -747,8 +749,9 @@ def main():
         gval = None if g is None else g.get("elbo" if is_elbo else "logpdf")
         parity = None if gval is None else abs(val - gval) / abs(gval)   # (fp32 lines: fp32 accuracy, ~1e-6)
         cpu = None
-        if args.cpu_sample > 0 and world == 1 and not inproc:
-            cpu = cpu_baseline(args.config, args.cpu_sample * (2 if is_elbo else 1))
+        cpu_n = args.cpu_sample if args.cpu_sample >= 0 else (16384 if is_elbo else min(N, 32768))
+        if cpu_n > 0 and world == 1 and not inproc:
+            cpu = cpu_baseline(args.config, cpu_n * (2 if is_elbo else 1))
         line = {
             "metric": "elbo_per_sec" if is_elbo else "logpdf_per_sec",
             "value": 1e3 / ms_per_step, "unit": "elbo/s" if is_elbo else "logpdf/s",

@@ -113,10 +113,18 @@ int sgp_ctx_create(int device, sgp_ctx** out);
  *   sgp_logpdf_grad       (round 4) the kept sharded factor, L^-T through the posterior's row sweep, C^-1 as a sum over
  *                         ranks with a reduce-scatter by column slabs, every rank contracting its slabs with the kernel
  *                         derivatives: gradients w.r.t. the kernel terms, scalar / diagonal noise, y and the mean.
+ *   sgp_logpdf_grad_x / _xs  (round 6) the input-point and function-scale gradients on the same sharded result: every rank
+ *                         contracts its column slabs of G row-side, per-rank sums added in rank order.
+ *   sgp_kernelmatrix      (round 6) the columns in ndev tile-aligned chunks, one per rank, copied straight into the caller's
+ *                         matrix; a symmetric spec stays EXACTLY symmetric (upper part by transposition) and bit-equal to the
+ *                         one-GPU matrix; sgp_kernelmatrix_diag: every block's points in ndev slices.
  * Dense Sigma_y shards as well (round 4: the owner of a panel adds its column slab at assembly).
- * One host thread, one `ccall`: the Julia side is unchanged.  The input-point / function-scale gradients
- * (sgp_logpdf_grad_x / _xs), a gradient with dense Sigma_y, the ELBO gradients, the M x M factors of a sparse posterior
- * and the covariance entry points run on devices[0].  A device listed several times gives that many ranks on one GPU
+ * One host thread, one `ccall`: the Julia side is unchanged.  Still on devices[0]: a gradient with a dense Sigma_y (its result
+ * is an N x N host matrix), the ELBO gradients, and the M x M factors of a sparse posterior (0.02 TFLOP: replicated work by
+ * design).  Failure (round 6): a HIP / RCCL error on any rank's enqueue thread fails the call with rc < 0 and the root cause
+ * in sgp_last_error(), within seconds (every cross-thread wait is bounded: SGP_MULTI_SPIN_TIMEOUT_S, ncclCommInitAll:
+ * SGP_MULTI_INIT_TIMEOUT_S); a peer-copy context stays usable, an RCCL context whose communicators had to be aborted refuses
+ * further sharded calls and says so.  A device listed several times gives that many ranks on one GPU
  * (test configuration).  SGP_MULTI_PANEL=<cols> sets the panel width (default 1024).  sgp_ctx_ndev -> number of ranks
  * (1 for an ordinary context); sgp_ctx_transport -> "single" | "rccl" | "p2p" | "p2p-staged" (peer access missing:
  * refused unless SGP_MULTI_ALLOW_STAGED=1) | "loopback". */

@@ -185,6 +185,40 @@ function logpdf(fx::SthenoFGP, Y::AbstractMatrix{<:Real})
 end
 logpdf(fx::SthenoFGP, y::AbstractVector{<:Real}) = only(logpdf(fx, reshape(y, :, 1)))
 
+# logpdf of several INDEPENDENT models in one call (sgp_logpdf_batch, round 6): restarts of an optimiser, cross-validation
+# folds, a population of hyper-parameter candidates -- [logpdf(fx, y) for (fx, y) in zip(fxs, ys)], every value bit-equal to
+# the member's own call.  Equally sized members (scalar / diagonal Σy) are factored as ONE task pool of the dataflow kernel:
+# at N <= 8192 one factorisation is bound by its diagonal chain and the B chains hide each other (N = 4096: 0.13 -> 0.49 of
+# the fp64 MFMA peak at B = 8).  A member that is not positive definite gives NaN instead of throwing (its LAPACK info in
+# the second result), so that one bad candidate does not lose the others.
+function logpdf_batch(fxs::AbstractVector{<:SthenoFGP}, ys::AbstractVector{<:AbstractVector{<:Real}})
+    length(fxs) == length(ys) || throw(DimensionMismatch("logpdf_batch: one y per model"))
+    B = length(fxs)
+    kinds = [noise_args(fx.Σy)[1] for fx in fxs]
+    if B == 0 || !allequal(kinds) || first(kinds) == 2        # mixed or dense noise kinds: member by member
+        vals = Float64[]; infos = Cint[]
+        for (fx, y) in zip(fxs, ys)
+            try
+                push!(vals, logpdf(fx, y)); push!(infos, 0)
+            catch e
+                e isa PosDefException || rethrow()
+                push!(vals, NaN); push!(infos, e.info)
+            end
+        end
+        return vals, infos
+    end
+    sps = [build_spec(fx.f, fx.x) for fx in fxs]
+    ms = [collect(Float64, mean(fx.f, fx.x)) for fx in fxs]
+    nzs = [noise_args(fx.Σy)[2] for fx in fxs]
+    yv = [collect(Float64, y) for y in ys]
+    specs = [Ptr{CSpec}(pointer_from_objref(sp)) for sp in sps]     # (`c` is the first field of the mutable Spec: its address)
+    out = zeros(B); infos = zeros(Cint, B)
+    GC.@preserve sps ms nzs yv specs out infos check(ccall((:sgp_logpdf_batch, LIB), Cint,
+        (Ptr{Cvoid}, Cint, Ptr{Ptr{CSpec}}, Ptr{Ptr{Float64}}, Cint, Ptr{Ptr{Float64}}, Ptr{Ptr{Float64}}, Ptr{Float64}, Ptr{Cint}),
+        ctx(), B, specs, pointer.(ms), first(kinds), pointer.(nzs), pointer.(yv), out, infos))
+    return out, infos
+end
+
 # Float32 models (test/gp/util.jl:76-88: `logpdf(fx, y) isa Float32`): fp32 assembly + fp32 Cholesky on the device
 # (sgp_logpdf_f32).  The spec is passed in Float64 (an exact conversion); the library rounds it to fp32 once.
 # The element type of the POINTS, looking through GPPPInput / BlockData (whose own eltype is a Tuple / a Union): what decides

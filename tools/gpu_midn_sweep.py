@@ -1,7 +1,8 @@
 """Mid-N schedules (round-5 verdict item 5: c2 = 16384 at 0.68, own bar 25.0 ms; gppp3 at 16384: 16.0 ms): sgp_logpdf of the
 dense Matern-5/2 GP and the three-block sum model at 12288 / 16384 / 20480 under every schedule the library has for the range
--- whole-matrix dataflow kernel (one / two workgroups per CU), hybrid with panels of 1024 / 2048 / 4096 columns, a hybrid
-panel in pieces (SGP_HYBRID_WMID), fewer panel workgroups -- each on a context of its own (the variables are read at
+-- whole-matrix dataflow kernel (one / two workgroups per CU), hybrid with panels of 1024 / 2048 / 4096 columns, fewer panel
+workgroups (a hybrid panel in pieces was measured through a switch that is gone: profiles/r06_experiments/midn_sweep.md) -- each
+on a context of its own (the variables are read at
 creation), best of 5 after a warm-up, bit-equality across the variants asserted.  Host-buffer entry point."""
 import json
 import os
@@ -26,9 +27,6 @@ VARIANTS = [
     ("hybrid W2048", {"SGP_HYBRID": "1"}),
     ("hybrid W1024", {"SGP_HYBRID": "1", "SGP_HYBRID_W": "1024"}),
     ("hybrid W4096", {"SGP_HYBRID": "1", "SGP_HYBRID_W": "4096"}),
-    ("hybrid W2048 pieces 1024", {"SGP_HYBRID": "1", "SGP_HYBRID_WMID": "1024"}),
-    ("hybrid W4096 pieces 2048", {"SGP_HYBRID": "1", "SGP_HYBRID_W": "4096", "SGP_HYBRID_WMID": "2048"}),
-    ("hybrid W4096 pieces 1024", {"SGP_HYBRID": "1", "SGP_HYBRID_W": "4096", "SGP_HYBRID_WMID": "1024"}),
     ("hybrid W2048 wgs128", {"SGP_HYBRID": "1", "SGP_HYBRID_WGS": "128"}),
     ("hybrid W2048 lean 512", {"SGP_HYBRID": "1", "SGP_HYBRID_FAT": "0", "SGP_HYBRID_WGS": "512"}),
     ("launches look-ahead", {"SGP_HYBRID": "0", "SGP_DATAFLOW": "0"}),
