@@ -260,6 +260,25 @@ class FakeLib:
         return 0
 
     # -- rand (sthenomi.h:194-198) -----------------------------------------------------------------------
+    def sgp_logpdf_batch(self, ctx, nspec, specs, means, kind, noises, ys, out, infos):
+        """include/sthenomi.h: member b = (specs[b], means[b], noises[b], ys[b]); out[b] its logpdf, NaN + infos[b] for a member
+        that is not positive definite (rc stays 0 when infos is given)."""
+        o = _vec(out, nspec)
+        inf = np.ctypeslib.as_array(infos, shape=(nspec,)) if infos else None
+        first_bad = 0
+        for b in range(nspec):
+            one = np.zeros(1)
+            n = _Spec(specs[b]).N
+            rc = self.sgp_logpdf(ctx, specs[b], means[b], kind, noises[b], ys[b], n, 1, one.ctypes.data_as(C.POINTER(C.c_double)))
+            if rc < 0:
+                return rc
+            o[b] = one[0] if rc == 0 else np.nan
+            if inf is not None:
+                inf[b] = rc
+            if rc > 0 and not first_bad:
+                first_bad = rc
+        return 0 if inf is not None else first_bad
+
     def sgp_rand(self, ctx, spec, mean, kind, noise, Z, ldz, S, out, ldo):
         s, m, Cm, rc = self._observed(spec, mean, kind, noise)
         if rc:

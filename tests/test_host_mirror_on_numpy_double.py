@@ -76,3 +76,34 @@ import test_gpu_dense_titsias as TD  # noqa: E402
 for _name in [n for n in dir(TD) if n.startswith("test_")]:
     globals()[_name] = getattr(TD, _name)
 del _name
+
+
+def test_logpdf_batch_host_mirror_marshalling():
+    """Round 6: `logpdf_batch(fxs, ys)` -> sgp_logpdf_batch: the arrays of spec / mean / noise / y pointers the host builds, the
+    NaN + info convention for a member that is not positive definite, and the member-by-member route for mixed noise kinds --
+    against each member's own `logpdf` and the oracle (the pooled factorisation itself is tests/test_gpu_batch.py's business)."""
+    import stheno_jl_amd as P
+    from oracle import reference_model as orm
+    rng = np.random.default_rng(4)
+    F = P.gppp_sum_model()
+    fxs, ys, refs = [], [], []
+    for b in range(4):
+        xs = [np.asfortranarray(rng.standard_normal((2, n))) for n in (30, 25, 40)]
+        x = P.BlockData([P.GPPPInput(k, P.ColVecs(v)) for k, v in zip(("f1", "f2", "f3"), xs)])
+        y = rng.standard_normal(95)
+        fxs.append(F(x, 0.1 + 0.05 * b))
+        ys.append(y)
+        refs.append(orm.gppp_sum_logpdf(xs, y, 0.1 + 0.05 * b))
+    got = P.logpdf_batch(fxs, ys)
+    np.testing.assert_allclose(got, refs, rtol=1e-10)
+    assert np.array_equal(got, np.array([P.logpdf(fx, y) for fx, y in zip(fxs, ys)]))
+    bad = list(fxs)
+    bad[1] = F(fxs[1].x, -4.0)
+    vals, infos = P.logpdf_batch(bad, ys, return_infos=True)
+    assert np.isnan(vals[1]) and infos[1] >= 1 and not infos[[0, 2, 3]].any() and np.array_equal(vals[[0, 2, 3]], got[[0, 2, 3]])
+    mixed = list(fxs)
+    mixed[2] = F(fxs[2].x, 0.05 + rng.random(95))                      # a diagonal-noise member among scalar ones
+    assert np.array_equal(P.logpdf_batch(mixed, ys), np.array([P.logpdf(fx, y) for fx, y in zip(mixed, ys)]))
+    assert P.logpdf_batch([], []).shape == (0,)
+    with pytest.raises(ValueError):
+        P.logpdf_batch(fxs, ys[:2])
