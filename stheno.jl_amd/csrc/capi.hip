@@ -199,7 +199,6 @@ const CtxKnob kCtxKnobs[] = {
     {"SGP_HYBRID_MIN_N", [](sgp_ctx* c, const char* v) { c->hybrid_min_n = c->hybrid_grow_min_n = atol(v); }},
     {"SGP_HYBRID_GROW_MIN_N", [](sgp_ctx* c, const char* v) { c->hybrid_grow_min_n = atol(v); }},
     {"SGP_HYBRID_SERIAL", [](sgp_ctx* c, const char* v) { c->hybrid_serial = atoi(v); }},  // one stream (bench.py: uncontended leg)
-    {"SGP_HYBRID_GROUP", [](sgp_ctx* c, const char* v) { c->hybrid_group = std::max(1, std::min(4, atoi(v))); }},  // far updates per G panels
     {"SGP_BATCH_MAX_N", [](sgp_ctx* c, const char* v) { c->batch_max_n = atol(v); }},      // sgp_logpdf_batch: pooled up to this size
     // ---- structural zeros
     {"SGP_STRUCT_ZEROS", [](sgp_ctx* c, const char* v) { c->struct_zeros = atoi(v); }},    // 0: the dense schedule (A/B, same bits)
@@ -988,49 +987,9 @@ static int chol_hybrid(sgp_ctx* ctx, double* A, long ld, long n_pad, long m_tot,
                        const SzMask* sz) {
   CHECK_RC(df_scratch(ctx, m_tot, 1, d_wall ? 0 : n_pad, s));
   const long WOUT = std::min(ctx->hybrid_w, n_pad);
-  if (ctx->hybrid_group > 1 && grow == 0 && !ctx->hybrid_serial && n_pad > 4 * WOUT) {
-    // Panel GROUPS (SGP_HYBRID_GROUP = G, round 6 -- the round-5 verdict's item 3: "the far update only every second panel with
-    // K = 4096 while the look-ahead columns stay K = 2048"; the sharded sweep's near / far classes, multi.hip): with g = J / G
-    // the group of the newest factored panel J,
-    //   look-ahead  panel J + 1                      on s,  K = W, with panel J (as before)
-    //   near        the rest of groups g and g + 1    on sB, K = W, with panel J, every step
-    //   far         groups >= g + 2                   on sB, K = up to G W, with all of group g, ONCE per group
-    // ev_rest is recorded after the near launch and BEFORE the far one: the look-ahead of the next step waits for the near
-    // update of its panel, never for a far launch.  A tile still sees k ascending: same bits.
-    const long G = ctx->hybrid_group, W = WOUT, npan = (n_pad + W - 1) / W;
-    auto dfpanel = [&](long J0, long wj) {
-      return launch_chol_dataflow(A + J0 + J0 * ld, ld, wj, m_tot - J0, ctx->d_df_state,
-                                  (d_wall ? d_wall : ctx->d_df_inv) + (J0 / TILE) * INVD_STRIDE, ctx->d_slots + J0 / TILE, ctx->d_info,
-                                  ctx->hybrid_wgs, ctx->df_timeout_s, s, nullptr, nullptr, ctx->hybrid_fat, sz ? sz->d_nz : nullptr,
-                                  sz ? sz->words : 0, J0);
-    };
-    hipStream_t sB = ctx->stream2;
-    SGP_HIP(hipEventRecord(ctx->ev_panel, s));
-    SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
-    bool b_recorded = false;
-    for (long J = 0; J < npan; ++J) {
-      const long J0 = J * W, wj = std::min(W, n_pad - J0), g = J / G;
-      CHECK_RC(dfpanel(J0, wj));
-      if (J + 1 >= npan) break;
-      SGP_HIP(hipEventRecord(ctx->ev_panel, s));
-      const long c0 = J0 + wj, w1 = std::min(W, n_pad - c0), c1 = c0 + w1;           // the look-ahead panel
-      const long cfar = std::min(n_pad, (g + 2) * G * W);                             // first far column
-      if (b_recorded) SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));               // the near update of panel J + 1 (step J - 1)
-      CHECK_RC(launch_update(ctx, A + c0 + J0 * ld, ld, A + c0 + c0 * ld, m_tot - c0, w1, wj, s, nullptr));
-      SGP_HIP(hipStreamWaitEvent(sB, ctx->ev_panel, 0));
-      if (c1 < cfar) CHECK_RC(launch_update(ctx, A + c1 + J0 * ld, ld, A + c1 + c1 * ld, m_tot - c1, cfar - c1, wj, sB));
-      SGP_HIP(hipEventRecord(ctx->ev_rest, sB));
-      b_recorded = true;
-      const bool group_ends = (J % G == G - 1) || J + 2 >= npan;
-      if (group_ends && cfar < n_pad) {
-        const long k0 = g * G * W;                                                    // first column of the group
-        CHECK_RC(launch_update(ctx, A + cfar + k0 * ld, ld, A + cfar + cfar * ld, m_tot - cfar, n_pad - cfar, c0 - k0, sB));
-      }
-    }
-    SGP_HIP(hipEventRecord(ctx->ev_rest, sB));
-    SGP_HIP(hipStreamWaitEvent(s, ctx->ev_rest, 0));
-    return 0;
-  }
+  // (Round 6 measured panel GROUPS here -- far updates once per G panels with K = G x 2048, near classes every step, the sharded
+  // sweep's scheme and the round-5 verdict's item 3: c5 1373 -> 1466 / 1476 / 1472 ms at G = 2 / 3 / 4, bit-identical; the near
+  // launches cost more than the deeper far launches save.  profiles/r06_experiments/hybrid_groups.md; removed.)
   // (SGP_HYBRID_SERIAL=1, measurement only: the far updates on the panel stream too -- every kernel has the chip alone)
   OuterSweep sw{ctx, A, ld, n_pad, m_tot, grow, s, ctx->hybrid_serial ? s : ctx->stream2, true};
   CHECK_RC(sw.begin());

@@ -94,7 +94,6 @@ struct sgp_ctx {
   // one-workgroup-per-CU instantiation
   int hybrid = -1, hybrid_wgs = 256, hybrid_fat = 1;
   long hybrid_w = 2048, hybrid_min_n = 24576;
-  int hybrid_group = 1;             // SGP_HYBRID_GROUP: far updates once per this many panels (K = group x panel width)
   long hybrid_grow_min_n = 16384;   // the gradient path's factorisations (identity border): SGP_HYBRID_GROW_MIN_N
   // sgp_logpdf_batch (round 6): equally sized members up to SGP_BATCH_MAX_N padded columns are factored as ONE task pool of the
   // dataflow kernel (0: never); SGP_BATCH_FAT: its one-workgroup-per-CU instantiation (1) or the lean one (0)
