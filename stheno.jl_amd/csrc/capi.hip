@@ -3506,16 +3506,17 @@ int drv_assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long 
 // the first px->n_fact columns and update the others with them, external source panels applied first (chol_df.hip).
 // df == 0: the launch-based chain of rounds 2 - 5 (px must be empty; the caller issues the updates as launches of its own).
 int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_logdet, int* d_info,
-                     double* d_invstore, hipStream_t s, int df, const sz_word* d_nz, int nz_words, const DfPanel* px) {
+                     double* d_invstore, hipStream_t s, int df, const sz_word* d_nz, int nz_words, const DfPanel* px, int lean) {
   CHECK_ARG(w % TILE == 0 && m % TILE == 0 && m >= w, "drv_panel_factor: bad sizes");
   long n_fact = w;
   if (df) {
     if (px) n_fact = px->n_fact;
     CHECK_ARG(n_fact / TILE <= ctx->n_slots, "drv_panel_factor: panel too wide for the logdet slot buffer");
     CHECK_RC(df_scratch(ctx, m, 1, d_invstore ? 0 : n_fact, s));
+    // lean: two workgroups per CU (the panel kernel of ranks that SHARE a GPU: it must fit beside other ranks' update launches)
     CHECK_RC(launch_chol_dataflow(P, ld, w, m, ctx->d_df_state, d_invstore ? d_invstore : ctx->d_df_inv, ctx->d_slots, d_info,
-                                  ctx->hybrid_wgs, ctx->df_timeout_s, s, nullptr, nullptr, ctx->hybrid_fat, d_nz, nz_words, g0,
-                                  px));
+                                  lean ? ctx->df_wgs : ctx->hybrid_wgs, ctx->df_timeout_s, s, nullptr, nullptr,
+                                  lean ? 0 : ctx->hybrid_fat, d_nz, nz_words, g0, px));
   } else {
     CHECK_ARG(!px || (px->n_ext == 0 && px->n_fact == w), "drv_panel_factor: the launch-based chain takes whole panels only");
     FuseScope fuse_scope(ctx, fuse_mode(ctx, m));

@@ -15,10 +15,11 @@ int drv_assemble(const sgp_dspec* ds, double* Kv, long ld, long tile_r_lo, long 
 // the factor need -- and adds the logdet contribution of the factored columns to *d_logdet.
 // df != 0: one launch of the dataflow kernel on the panel (the hybrid schedule, round 6), with the optional extension px: only
 // the first px->n_fact columns are factored (the others updated with them), external source panels applied first.
+// lean != 0: the two-workgroups-per-CU instantiation of that kernel (ranks sharing one GPU).
 // d_nz / nz_words: the factor's tile pattern (structural zeros), read at the panel's offset g0 / 128; NULL: dense.
 int drv_panel_factor(sgp_ctx* ctx, double* P, long ld, long m, long w, long g0, double* d_logdet, int* d_info,
                      double* d_invstore, hipStream_t s, int df = 0, const sgp::sz_word* d_nz = nullptr, int nz_words = 0,
-                     const sgp::DfPanel* px = nullptr);
+                     const sgp::DfPanel* px = nullptr, int lean = 0);
 // R <- R L^-T for nrows (multiple of 128) rows against an n x n lower factor with its kept inverse blocks
 int drv_row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl, const double* d_invall,
                  long n, hipStream_t s);

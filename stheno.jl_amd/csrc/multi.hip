@@ -1117,6 +1117,11 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
   // the panel kernel (see sgp_multi::panel_df): with the primary context's hybrid switch, which the time-out fallback clears
   const bool df_panels = m->panel_df != 0 && m->primary && m->primary->hybrid != 0;
   const bool fuse_la = df_panels && m->fuse_la != 0;
+  // Ranks that SHARE a GPU (a device listed several times: the test configuration) run the panel kernel's two-workgroups-per-CU
+  // instantiation: the one-per-CU form waits for whole CUs to drain from the other ranks' update launches (8 ranks on one GPU:
+  // c5 1869 vs 1667 ms, north-star model 1167 vs 1021; profiles/r06_experiments/sharded_chain.md).  On distinct devices -- and in
+  // profile mode, whose launches run alone as they would on a node -- the one-per-CU form is faster (projection 142 vs 154 ms).
+  const int lean_panels = (m->transport == TR_LOOPBACK && P > 1 && !prof) ? 1 : 0;
   const int fault_rank = std::min<int>(m->fault_rank, P - 1);   // the hook fires once: disarmed before the sweep starts
   const long fault_step = m->fault_rank >= 0 ? std::min<long>(m->fault_step, g.npan - 1) : -1;
   const double fault_stall_s = m->fault_stall_s;
@@ -1165,7 +1170,7 @@ int factorize(sgp_multi* m, Fact& F, const sgp_cov_spec* spec, const double* mea
               k.upd_flops += update_flops(g.m_tot - J0, w, wl);
             }
             M_RC(drv_panel_factor(k.ctx, Pj + c + c * ldp, ldp, ldp - c, w - c, J0 + c, d_logdet, k.d_info, invq, k.s_panel, 1, nzp,
-                                  m->sz_words, &px));
+                                  m->sz_words, &px, lean_panels));
           }
           M_RC(x.rec(o, k.ev_sub[q], k.s_panel));
           if (q == ns - 1) M_RC(x.rec(o, k.ev_fact, k.s_panel));
