@@ -119,9 +119,9 @@ int sgp_ctx_create(int device, sgp_ctx** out);
  *                         matrix; a symmetric spec stays EXACTLY symmetric (upper part by transposition) and bit-equal to the
  *                         one-GPU matrix; sgp_kernelmatrix_diag: every block's points in ndev slices.
  * Dense Sigma_y shards as well (round 4: the owner of a panel adds its column slab at assembly).
- * One host thread, one `ccall`: the Julia side is unchanged.  Still on devices[0]: a gradient with a dense Sigma_y (its result
- * is an N x N host matrix), the ELBO gradients, and the M x M factors of a sparse posterior (0.02 TFLOP: replicated work by
- * design).  Failure (round 6): a HIP / RCCL error on any rank's enqueue thread fails the call with rc < 0 and the root cause
+ * (a gradient with a dense Sigma_y too, round 6: G = (alpha alpha' - C^-1) / 2 comes back column slab by column slab.)
+ * One host thread, one `ccall`: the Julia side is unchanged.  Still on devices[0]: the ELBO gradients, and the M x M factors of
+ * a sparse posterior (0.02 TFLOP: replicated work by design).  Failure (round 6): a HIP / RCCL error on any rank's enqueue thread fails the call with rc < 0 and the root cause
  * in sgp_last_error(), within seconds (every cross-thread wait is bounded: SGP_MULTI_SPIN_TIMEOUT_S, ncclCommInitAll:
  * SGP_MULTI_INIT_TIMEOUT_S); a peer-copy context stays usable, an RCCL context whose communicators had to be aborted refuses
  * further sharded calls and says so.  A device listed several times gives that many ranks on one GPU

@@ -1722,8 +1722,8 @@ static int logpdf_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double
   CHECK_ARG(noise_kind >= SGP_NOISE_SCALAR && noise_kind <= SGP_NOISE_DENSE, "sgp_logpdf_grad: bad noise kind");
   CtxScope scope(ctx);
   // a multi-GPU context shards the gradient -- kernel terms, noise, y, the mean and (round 6) the input points and function
-  // scales (multi.hip); a dense Sigma_y runs on devices[0]
-  if (ctx->multi && noise_kind != SGP_NOISE_DENSE)
+  // scales, a dense Sigma_y (multi.hip)
+  if (ctx->multi)
     return sgp_multi_logpdf_grad(ctx, spec, mean, noise_kind, noise, y, logpdf_out, grad_y, grad_mean, grad_noise, grad_coef,
                                  grad_inscale, grad_inputs, grad_rowscale);
   SpecGuard g;

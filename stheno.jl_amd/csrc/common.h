@@ -280,6 +280,8 @@ int launch_grad_border(double* A, long ld, long n_pad, long N, const double* y, 
 int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N, int diag, double* out,
                       hipStream_t s);
 int launch_grad_noise_dense(const double* Kinv, long ldk, const double* alpha, long N, double* out, hipStream_t s);
+int launch_grad_noise_dense_cols(const double* Kinv, long ldk, const double* alpha, long N, long c0, long w, double* out, long ldo,
+                                 hipStream_t s);
 
 // potrf.hip
 int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info,

@@ -398,6 +398,25 @@ int launch_grad_noise_dense(const double* Kinv, long ldk, const double* alpha, l
   return 0;
 }
 
+// ... its columns [c0, c0 + w) only, into an N x w slab (ld ldo): the sharded gradient, where a rank holds the columns of C^-1 of
+// its own panels (multi.hip)
+__global__ void grad_noise_dense_cols_kernel(const double* Kinv, long ldk, const double* alpha, long N, long c0, long w,
+                                             double* out, long ldo) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= N * w) return;
+  const long r = idx % N, c = idx / N;
+  out[r + c * ldo] = 0.5 * (alpha[r] * alpha[c0 + c] - Kinv[r + (c0 + c) * ldk]);
+}
+int launch_grad_noise_dense_cols(const double* Kinv, long ldk, const double* alpha, long N, long c0, long w, double* out, long ldo,
+                                 hipStream_t s) {
+  const long tot = N * w;
+  if (tot <= 0) return 0;
+  hipLaunchKernelGGL(grad_noise_dense_cols_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, Kinv, ldk, alpha, N, c0, w,
+                     out, ldo);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_grad_noise(const double* Kinv, long ldk, const double* alpha, long N, int diag, double* out,
                       hipStream_t s) {
   hipLaunchKernelGGL(grad_noise_kernel, dim3(1), dim3(256), 0, s, Kinv, ldk, alpha, N, diag, out);

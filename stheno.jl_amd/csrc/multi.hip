@@ -2015,8 +2015,9 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
   const int P = (int)m->r.size();
   const long N = spec_rows(spec);
   M_CHECK_ARG(N >= 1, "sgp_logpdf_grad (multi): empty data");
-  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
-              "sgp_logpdf_grad (multi): noise kind must be SCALAR or DIAG");
+  M_CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG || noise_kind == SGP_NOISE_DENSE,
+              "sgp_logpdf_grad (multi): bad noise kind");
+  const bool dense_noise = noise_kind == SGP_NOISE_DENSE;   // (round 6) d / d Sigma_y = G itself, N x N: every rank returns its columns
   M_CHECK_ARG(m->W <= 4096, "sgp_logpdf_grad (multi): panels wider than 4096 columns");
   std::vector<double> alpha(N);
   sgp_mpost* mp = nullptr;
@@ -2102,6 +2103,7 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
       Rank& k = m->r[i];
       M_HIP(hipSetDevice(k.dev));
       const sgp_dspec* d = ds[i];
+      const long nco = g.ncols_owned(i);
       double* d_alpha = k.d_work2 + (size_t)n_pad * n_pad;
       double* d_gc = d_alpha + n_pad;          // nterms <= 4096 each (checked below)
       double* d_gs = d_gc + 4096;
@@ -2179,6 +2181,12 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
               }
             }
           }
+        if (dense_noise && grad_noise) {
+          // the panel's columns of G = (alpha alpha' - C^-1) / 2, straight into the caller's N x N matrix (ld N)
+          double* slab = k.d_work + (size_t)n_pad * std::max<long>(nco, 1);   // (the n_pad x W tail of the scratch)
+          M_RC(launch_grad_noise_dense_cols(k.d_work2, n_pad, d_alpha, N, pc0, pw, slab, N, k.s_upd));
+          M_HIP(hipMemcpyAsync(grad_noise + (size_t)pc0 * N, slab, sizeof(double) * N * pw, hipMemcpyDeviceToHost, k.s_upd));
+        }
         M_RC(drv_copy_strided(k.d_work2 + pc0 + (size_t)pc0 * n_pad, n_pad + 1, pw, d_diag, k.s_upd));
         M_HIP(hipMemcpyAsync(kdiag.data() + pc0, d_diag, sizeof(double) * pw, hipMemcpyDeviceToHost, k.s_upd));
         M_HIP(hipStreamSynchronize(k.s_upd));   // (d_diag is reused by the next panel; kdiag is pageable)
@@ -2245,7 +2253,7 @@ int sgp_multi_logpdf_grad(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
     for (long i = 0; i < N; ++i) grad_y[i] = -alpha[i];
   if (grad_mean)
     for (long i = 0; i < N; ++i) grad_mean[i] = alpha[i];
-  if (grad_noise) {
+  if (grad_noise && !dense_noise) {
     if (noise_kind == SGP_NOISE_DIAG) {
       for (long i = 0; i < N; ++i) grad_noise[i] = 0.5 * (alpha[i] * alpha[i] - kdiag[i]);
     } else {

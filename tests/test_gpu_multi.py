@@ -766,3 +766,27 @@ def test_covariance_entry_points_sharded_over_the_ranks(nranks):
         C1 = _with_ctx(ctx, lambda: P.cov(fx, F(x2, 0.1)))
         assert C1.shape == (N, 463) and np.array_equal(C1, C0)
     ctx.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_gradient_with_dense_observation_noise_sharded_over_the_ranks(panel128, nranks):
+    """Round 6: sgp_logpdf_grad with f(x, S::Matrix) on a multi-GPU context (it used to run on devices[0]): the sharded
+    factorisation takes the dense Sigma_y at assembly (round 4), and the gradient with respect to it -- the cotangent
+    G = (alpha alpha' - C^-1) / 2 itself, N x N -- comes back column slab by column slab from the ranks that own the panels.
+    Against the single-GPU gradient: G, the term gradients, y and the mean."""
+    N = 901
+    F, x, xs, y = _problem(N, D=3)
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((N, 6))
+    S = 0.05 * np.eye(N) + 0.01 * B @ B.T
+    g0 = P.logpdf_and_gradient(F(x, S), y)
+    ctx = P.lib.Context(devices=[0] * nranks)
+    g1 = _with_ctx(ctx, lambda: P.logpdf_and_gradient(F(x, S), y))
+    ctx.close()
+    assert abs(g1["logpdf"] - g0["logpdf"]) <= 1e-11 * abs(g0["logpdf"])
+    G0, G1 = np.asarray(g0["noise"]), np.asarray(g1["noise"])
+    assert G0.shape == G1.shape == (N, N) and np.abs(G1 - G0).max() <= 1e-9 * np.abs(G0).max()
+    assert np.abs(g1["y"] - g0["y"]).max() <= 1e-9 * np.abs(g0["y"]).max()
+    for t0, t1 in zip(g0["terms"], g1["terms"]):
+        assert abs(t1["d_coef"] - t0["d_coef"]) <= 1e-8 * max(1.0, abs(t0["d_coef"]))
+        assert abs(t1["d_inscale"] - t0["d_inscale"]) <= 1e-8 * max(1.0, abs(t0["d_inscale"]))
