@@ -177,6 +177,11 @@ struct StripSkip {
   int words = 0, tr0 = 0, kt = 0;   // tile row of X's first row, k tile of the block column
 };
 StripSkip strip_skip_for(const double* X, long ldx);   // from the per-thread structure record (gemm_nt.hip), or an empty one
+// the fp32 instantiation (f32.hip, round 6): the same record over a float matrix; its update launches keep the dense tile
+// enumeration (no compacted id maps) and skip / trim per workgroup
+void gemm_set_structure_f32(const float* base, long ld, const sz_word* d_nz, int words, long ncols);
+TileSkip gemm_skip_for_f32(const float* P, long ldp, const float* C, long ldc, long K);
+StripSkip strip_skip_for_f32(const float* X, long ldx);
 // chol_df.hip: the whole bordered factorisation (lower tiles of the n_pad columns + rows n_pad .. m_tot) in one launch of
 // persistent workgroups; d_state: df_state_words(m_tot, 1) ints, d_invall: n_pad / 128 x 2048 doubles
 constexpr int SGP_DF_TIMEOUT = -77;   // *info when a dependency wait inside the kernel ran into its bound
@@ -294,7 +299,7 @@ int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl
 int launch_potrf_diag_f32(float* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
                           hipStream_t s);
 int launch_panel_solve_f32(float* X, long ldx, long rows, const float* L, long ldl, const double* inv,
-                           long inv_cstride, long inv_kstride, hipStream_t s);
+                           long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk = nullptr);
 
 // reduce.hip
 int launch_rowsumsq(const double* rows, long ld, long nc, long nrows, double* out, int accumulate,

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, OCC) void gemm_nt_f32_kernel(const float* A, l
 // B = 32 KB of LDS at KD = 16.
 template <int KD>
 __global__ __launch_bounds__(256, 4) void gemm_nt_f32_dma_kernel(const float* A, long lda, const float* B, long ldb, float* C,
-                                                                 long ldc, long K, int lower, long n_tr, long n_tc) {
+                                                                 long ldc, long K, int lower, long n_tr, long n_tc, TileSkip sk) {
   long tr, tc;
   if (lower) {
     if (!tile_of_id((long)blockIdx.x, n_tr, n_tc, 0L, tr, tc)) return;
@@ -248,6 +248,28 @@ __global__ __launch_bounds__(256, 4) void gemm_nt_f32_dma_kernel(const float* A,
     tc = blockIdx.y;
   }
   if (tr >= n_tr || tc >= n_tc) return;
+  // structural zeros (round 6; the fp64 tile program's rule, gemm_nt.hip): the update P[tr] P[tc]' is dead when every k tile
+  // of the panel has a structurally zero operand tile -- C keeps its bits (C - 0); a live tile contracts from its first to
+  // its last live k tile only (the products outside are exact zeros).  Tile boundaries are multiples of KD, so the chunks,
+  // and with them the bits, are those of the dense run.
+  if (sk.nz) {
+    const sz_word* ra = sk.nz + (long)(sk.tr0 + tr) * sk.words;
+    const sz_word* rb = sk.nz + (long)(sk.tc0 + tc) * sk.words;
+    int kmin = -1, kmax = -1;
+    for (int q = sk.kt0 >> 6; q <= (sk.kt1 - 1) >> 6; ++q) {
+      sz_word m = ra[q] & rb[q];
+      if (q == (sk.kt0 >> 6)) m &= ~(sz_word)0 << (sk.kt0 & 63);
+      if (q == ((sk.kt1 - 1) >> 6) && (sk.kt1 & 63)) m &= ~(~(sz_word)0 << (sk.kt1 & 63));
+      if (m != 0) {
+        if (kmin < 0) kmin = q * 64 + (int)__builtin_ctzll(m);
+        kmax = q * 64 + 63 - (int)__builtin_clzll(m);
+      }
+    }
+    if (kmin < 0) return;
+    A += (long)(kmin - sk.kt0) * TILE * lda;
+    B += (long)(kmin - sk.kt0) * TILE * ldb;
+    K = (long)(kmax - kmin + 1) * TILE;
+  }
   constexpr int STAGE = 2 * KD * TILE;   // floats per stage: A chunk, then B chunk
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
   typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -328,7 +350,8 @@ int launch_gemm_f32(const float* A, long lda, const float* B, long ldb, float* C
   // against 992.3 ms; a 32-deep chunk (2 workgroups per CU instead of 4) 796.8 ms.
   const char* e = getenv("SGP_F32_DMA");
   if ((!e || atoi(e) != 0) && K % 16 == 0 && lda % 4 == 0 && ldb % 4 == 0 && (((uintptr_t)A | (uintptr_t)B) & 15) == 0) {
-    hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<16>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, lower, n_tr, n_tc);
+    const TileSkip sk = (lower && A == B) ? gemm_skip_for_f32(A, lda, C, ldc, K) : TileSkip();
+    hipLaunchKernelGGL((gemm_nt_f32_dma_kernel<16>), grid, dim3(256), 0, s, A, lda, B, ldb, C, ldc, K, lower, n_tr, n_tc, sk);
     SGP_HIP(hipGetLastError());
     return 0;
   }
@@ -408,7 +431,8 @@ int panel_factor_f32(sgp_ctx* ctx, float* P, long ld, long m, long w, long g0, h
     const long mrest = m - j - TILE;
     if (mrest > 0) {
       float* A21 = P + (j + TILE) + j * ld;
-      if (int rc = launch_panel_solve_f32(A21, ld, mrest, D, ld, ctx->d_invd, 256, 16, s)) return rc;
+      const StripSkip sk = strip_skip_for_f32(A21, ld);   // (empty unless sgp_logpdf_f32 registered a pattern)
+      if (int rc = launch_panel_solve_f32(A21, ld, mrest, D, ld, ctx->d_invd, 256, 16, s, &sk)) return rc;
       const long wrest = w - j - TILE;
       if (wrest > 0)
         if (int rc = launch_gemm_f32(A21, ld, A21, ld, P + (j + TILE) + (j + TILE) * ld, ld, mrest, wrest, TILE, 1, s)) return rc;
@@ -527,7 +551,22 @@ extern "C" int sgp_logpdf_f32(sgp_ctx* ctx, const sgp_cov_spec* spec, const doub
                        dy.p, mean ? dm.p : nullptr);
     SGP_HIP(hipGetLastError());
   }
-  if (int rc = chol_f32(ctx, A, m_tot, n_pad, m_tot, s)) return rc;
+  // structural zeros (round 6): the fp64 driver's tile pattern of the factor (capi.hip: sz_pattern, host; one upload) --
+  // dead tile products are skipped, a live tile contracts its live k range, the row solve leaves zero tiles alone.  The
+  // bits are those of the dense run (SGP_STRUCT_ZEROS=0).
+  {
+    int words = 0;
+    const sz_word* d_nz = nullptr;
+    if (int rc = drv_sz_pattern(ctx, ds, noise_kind, n_pad, m_tot, &words)) return rc;
+    if (words > 0)
+      if (int rc = drv_sz_upload(ctx, ctx, words, s, &d_nz)) return rc;
+    struct Scope {
+      bool on;
+      ~Scope() { if (on) gemm_set_structure(nullptr, 0, nullptr, 0); }
+    } scope_sz{d_nz != nullptr};
+    if (d_nz) gemm_set_structure_f32(A, m_tot, d_nz, words, n_pad);
+    if (int rc = chol_f32(ctx, A, m_tot, n_pad, m_tot, s)) return rc;
+  }
   double* d_logdet = ctx->d_scal;
   double* d_sq = ctx->d_scal + 16;
   hipLaunchKernelGGL(rowsumsq_f32_kernel, dim3(1), dim3(256), 0, s, A + n_pad, (long)m_tot, N, d_sq);

@@ -749,7 +749,8 @@ __global__ __launch_bounds__(512, 4) void gemm_nt_reg_kernel(const double* A, lo
 // Structure of the matrix being factored (structural zeros, common.h): set by chol_bordered for its scope.
 namespace {
 struct GemmStructure {
-  const double* base = nullptr;
+  const char* base = nullptr;   // (bytes: the fp32 instantiation registers a float matrix, f32.hip)
+  long elem = 8;                // bytes per element of the registered matrix
   long ld = 0;
   const sz_word* nz = nullptr;
   int words = 0;
@@ -765,11 +766,11 @@ struct GemmStructure {
 };
 thread_local GemmStructure g_st;
 // the skip record of the diagonal-aligned lower update C[lower] -= P P' (P's rows = C's rows = C's columns), or an empty one
-TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) {
+TileSkip skip_for_bytes(const void* P, long ldp, const void* C, long ldc, long K, long elem) {
   TileSkip sk;
-  if (!g_st.nz || ldp != g_st.ld || ldc != g_st.ld) return sk;
-  const long oc = C - g_st.base, op = P - g_st.base;
-  if (oc < 0 || op < 0 || oc >= g_st.ld * g_st.ncols || op >= g_st.ld * g_st.ncols) return sk;
+  if (!g_st.nz || ldp != g_st.ld || ldc != g_st.ld || elem != g_st.elem) return sk;
+  const long oc = ((const char*)C - g_st.base) / elem, op = ((const char*)P - g_st.base) / elem;
+  if ((const char*)C < g_st.base || (const char*)P < g_st.base || oc >= g_st.ld * g_st.ncols || op >= g_st.ld * g_st.ncols) return sk;
   const long cr = oc % g_st.ld, cc = oc / g_st.ld, pr = op % g_st.ld, pc = op / g_st.ld;
   if (cr != cc || pr != cr || cr % TILE || pc % TILE || K % TILE || pc + K > cc) return sk;
   sk.nz = g_st.nz;
@@ -779,10 +780,25 @@ TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) 
   sk.kt1 = sk.kt0 + (int)(K / TILE);
   return sk;
 }
+TileSkip skip_for(const double* P, long ldp, const double* C, long ldc, long K) { return skip_for_bytes(P, ldp, C, ldc, K, 8); }
+StripSkip strip_skip_bytes(const void* X, long ldx, long elem) {
+  StripSkip sk;
+  if (!g_st.nz || ldx != g_st.ld || elem != g_st.elem || (const char*)X < g_st.base) return sk;
+  const long ox = ((const char*)X - g_st.base) / elem;
+  if (ox >= g_st.ld * g_st.ncols) return sk;
+  const long xr = ox % g_st.ld, xc = ox / g_st.ld;
+  if (xr % TILE || xc % TILE || xr <= xc) return sk;   // rows below the diagonal block of a block column
+  sk.nz = g_st.nz;
+  sk.words = g_st.words;
+  sk.tr0 = (int)(xr / TILE + g_st.tile0);
+  sk.kt = (int)(xc / TILE + g_st.tile0);
+  return sk;
+}
 }  // namespace
 void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int words, long ncols, int* scratch,
                         long scratch_ints, long tile0, hipStream_t stream2, int* scratch2) {
-  g_st.base = base;
+  g_st.base = (const char*)base;
+  g_st.elem = 8;
   g_st.ld = ld;
   g_st.nz = d_nz;
   g_st.words = words;
@@ -793,19 +809,15 @@ void gemm_set_structure(const double* base, long ld, const sz_word* d_nz, int wo
   g_st.stream2 = stream2;
   g_st.scratch2 = scratch2;
 }
-StripSkip strip_skip_for(const double* X, long ldx) {
-  StripSkip sk;
-  if (!g_st.nz || ldx != g_st.ld) return sk;
-  const long ox = X - g_st.base;
-  if (ox < 0 || ox >= g_st.ld * g_st.ncols) return sk;
-  const long xr = ox % g_st.ld, xc = ox / g_st.ld;
-  if (xr % TILE || xc % TILE || xr <= xc) return sk;   // rows below the diagonal block of a block column
-  sk.nz = g_st.nz;
-  sk.words = g_st.words;
-  sk.tr0 = (int)(xr / TILE + g_st.tile0);
-  sk.kt = (int)(xc / TILE + g_st.tile0);
-  return sk;
+// the fp32 instantiation's matrix (f32.hip: no compacted id maps -- its launches keep the dense enumeration)
+void gemm_set_structure_f32(const float* base, long ld, const sz_word* d_nz, int words, long ncols) {
+  gemm_set_structure(nullptr, ld, d_nz, words, ncols);
+  g_st.base = (const char*)base;
+  g_st.elem = 4;
 }
+TileSkip gemm_skip_for_f32(const float* P, long ldp, const float* C, long ldc, long K) { return skip_for_bytes(P, ldp, C, ldc, K, 4); }
+StripSkip strip_skip_for_f32(const float* X, long ldx) { return strip_skip_bytes(X, ldx, 4); }
+StripSkip strip_skip_for(const double* X, long ldx) { return strip_skip_bytes(X, ldx, 8); }
 
 // One workgroup per XCD walks that XCD's ids of a lower update in order and writes the live ones (some k tile of the panel
 // has both operand tiles structurally non-zero; `keep_first`: tile (0, 0), which a fused launch factors) to the front.

@@ -94,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void panel_solve_kernel(double* X, long ldx
 // they are written
 __global__ __launch_bounds__(256, 2) void panel_solve_f32_kernel(float* X, long ldx, const float* L, long ldl,
                                                               const double* inv, long inv_cstride,
-                                                              long inv_kstride, int strips, long rows, int prio) {
-  panel_solve_body<float>(X, ldx, L, ldl, inv, inv_cstride, inv_kstride, strips, rows, prio);
+                                                              long inv_kstride, int strips, long rows, int prio, StripSkip sk) {
+  panel_solve_body<float>(X, ldx, L, ldl, inv, inv_cstride, inv_kstride, strips, rows, prio, sk);
 }
 
 template <typename TS>
@@ -131,7 +131,7 @@ __device__ __forceinline__ void panel_solve_body(TS* X, long ldx, const TS* L, l
 }
 
 int launch_panel_solve_f32(float* X, long ldx, long rows, const float* L, long ldl, const double* inv,
-                           long inv_cstride, long inv_kstride, hipStream_t s) {
+                           long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk) {
   if (rows <= 0) return 0;
   if (rows % PS_ROWS) {
     set_error("panel_solve_f32: rows must be a multiple of 64");
@@ -142,7 +142,7 @@ int launch_panel_solve_f32(float* X, long ldx, long rows, const float* L, long l
   int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + 255) / 256));
   long nwg = (nstrips + strips - 1) / strips;
   hipLaunchKernelGGL(panel_solve_f32_kernel, dim3((unsigned)nwg), dim3(256), PS_LDS, s, X, ldx, L, ldl, inv,
-                     inv_cstride, inv_kstride, strips, rows, panel_prio());
+                     inv_cstride, inv_kstride, strips, rows, panel_prio(), sk ? *sk : StripSkip());
   SGP_HIP(hipGetLastError());
   return 0;
 }

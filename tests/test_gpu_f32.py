@@ -201,3 +201,36 @@ def test_lds_dma_update_kernel_gives_the_bits_of_the_register_staged_one(monkeyp
     lp1, (m1, v1) = run()
     assert lp0 == lp1
     assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+
+
+@pytest.mark.parametrize("n", [384, 1536, 1400])
+def test_logpdf_f32_skips_the_structural_zeros_and_keeps_its_bits(monkeypatch, n):
+    """Round 6: the fp32 factorisation takes the fp64 driver's tile pattern of the factor (csrc/f32.hip: sgp_logpdf_f32 ->
+    drv_sz_pattern; gemm_nt_f32_dma_kernel and panel_solve_f32_kernel skip / trim by it).  f3 = f1 + f2 observed at all
+    three, ordered f1, f2, f3: the (f2, f1) block of the factor is zero.  The skipped products are exact zeros, so logpdf must
+    not change by a bit against SGP_STRUCT_ZEROS=0 -- aligned blocks, several outer panels, ragged blocks (1400: block
+    boundaries inside tiles) -- while the work counter shows the skipping; the value stays the oracle's at fp32 tolerance."""
+    from test_gpu_fused_potrf import _with_ctx
+    rng = np.random.default_rng(n)
+    xs = {k: np.asfortranarray(rng.standard_normal((2, n)).astype(np.float32)) for k in ("f1", "f2", "f3")}
+    y = rng.standard_normal(3 * n).astype(np.float32)
+    Fp = P.gppp_sum_model()
+
+    def logpdf():
+        x = P.BlockData([P.GPPPInput(k, P.ColVecs(xs[k])) for k in ("f1", "f2", "f3")])
+        return P.logpdf(Fp(x, np.float32(0.1)), y)
+
+    out = {}
+    for sz in (0, 1):
+        monkeypatch.setenv("SGP_STRUCT_ZEROS", str(sz))
+        ctx = P.lib.Context(0)
+        out[sz] = [_with_ctx(ctx, logpdf) for _ in range(2)]
+        e, d = ctx.factor_work()
+        assert (e < 0.75 * d) if sz else (e == d), (sz, e, d)
+        ctx.close()
+    assert isinstance(out[1][0], np.float32)
+    assert out[0][0] == out[0][1] == out[1][0] == out[1][1], out
+    from oracle import reference_model as orm
+    xo = ost.BlockData([ost.GPPPInput(k, okf.ColVecs(xs[k].astype(np.float64))) for k in ("f1", "f2", "f3")])
+    ref = oagp.logpdf(orm.gppp_sum()(xo, float(np.float32(0.1))), y.astype(np.float64))
+    assert abs(float(out[1][0]) - ref) <= 2e-4 * max(1.0, abs(ref)), (out[1][0], ref)
