@@ -120,8 +120,13 @@ int sgp_ctx_create(int device, sgp_ctx** out);
  *                         one-GPU matrix; sgp_kernelmatrix_diag: every block's points in ndev slices.
  * Dense Sigma_y shards as well (round 4: the owner of a panel adds its column slab at assembly).
  * (a gradient with a dense Sigma_y too, round 6: G = (alpha alpha' - C^-1) / 2 comes back column slab by column slab.)
- * One host thread, one `ccall`: the Julia side is unchanged.  Still on devices[0]: the ELBO gradients, and the M x M factors of
- * a sparse posterior (0.02 TFLOP: replicated work by design).  Failure (round 6): a HIP / RCCL error on any rank's enqueue thread fails the call with rc < 0 and the root cause
+ *   sgp_elbo_grad / _x / _xs  (round 6) shard the data points like sgp_elbo: every rank runs the pipeline on its slice, the
+ *                         sums over data points (A A', A delta, four scalars: M^2 + M + 4 doubles) meet in ONE reduction
+ *                         between the two factorisations, the M x M stage runs replicated on identical numbers; per-point
+ *                         results come back slice by slice, sums over data points are added in rank order, the K(z,z) side
+ *                         is rank 0's.  Fewer than 128 data points per rank: not sharded.
+ * One host thread, one `ccall`: the Julia side is unchanged.  Still on devices[0]: the M x M factors of a sparse posterior
+ * (0.02 TFLOP: replicated work by design) and the O(N) diagonal entry points' gradients.  Failure (round 6): a HIP / RCCL error on any rank's enqueue thread fails the call with rc < 0 and the root cause
  * in sgp_last_error(), within seconds (every cross-thread wait is bounded: SGP_MULTI_SPIN_TIMEOUT_S, ncclCommInitAll:
  * SGP_MULTI_INIT_TIMEOUT_S); a peer-copy context stays usable, an RCCL context whose communicators had to be aborted refuses
  * further sharded calls and says so.  A device listed several times gives that many ranks on one GPU

@@ -2808,7 +2808,11 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
                           double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
                           double* grad_inscale_xz, double* const* grad_inputs_zz, double* const* grad_inputs_xz,
                           double* const* grad_rowscale_zz = nullptr, double* const* grad_rowscale_xz = nullptr,
-                          double* const* grad_colscale_xz = nullptr) {
+                          double* const* grad_colscale_xz = nullptr, const sgp::ElboGradShard* shard = nullptr) {
+  // shard (round 6, multi.hip: sgp_multi_elbo_grad): this call sees ONE rank's slice of the data points (xz, var_x, mean_x, a
+  // diagonal noise_x, y and the per-point results are the slice's).  The sums over data points -- A A', A delta, the four
+  // scalar sums -- are added up over the ranks by shard->reduce (every rank gets the total), the M x M stage runs replicated
+  // on identical numbers, the data-point stage on the slice; the zz-side results are the primary rank's business only.
   CHECK_ARG(ctx && zz && xz && var_x && noise_x && z_noise && y && elbo_out, "sgp_elbo_grad: NULL argument");
   CHECK_ARG(zz->symmetric, "sgp_elbo_grad: zz spec must be symmetric");
   CHECK_ARG(noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG,
@@ -2908,6 +2912,24 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
     CHECK_RC(launch_splitk_reduce(dPart.p, stride, nsplit, dG.p, ldg, m_pad, m_pad, 1.0, 0.0, 1, s, n_rows));
     SGP_HIP(hipStreamSynchronize(s));
   }
+  if (shard) {
+    // the slice's sums, packed: A A' (m_pad x m_pad, lower), A delta (m_pad), h[0..3] -> summed over the ranks -> back
+    const long mm = m_pad * m_pad, len = mm + m_pad + 8;
+    DevBuf dP;
+    CHECK_RC(dP.alloc((size_t)len));
+    SGP_HIP(hipMemsetAsync(dP.p + mm + m_pad, 0, sizeof(double) * 8, s));
+    SGP_HIP(hipMemcpy2DAsync(dP.p, sizeof(double) * m_pad, dG.p, sizeof(double) * ldg, sizeof(double) * m_pad, (size_t)m_pad,
+                             hipMemcpyDeviceToDevice, s));
+    SGP_HIP(hipMemcpyAsync(dP.p + mm, dots.p, sizeof(double) * m_pad, hipMemcpyDeviceToDevice, s));
+    SGP_HIP(hipMemcpyAsync(dP.p + mm + m_pad, ctx->d_scal + 1, sizeof(double) * 4, hipMemcpyDeviceToDevice, s));
+    SGP_HIP(hipStreamSynchronize(s));
+    CHECK_RC(shard->reduce(dP.p, len));   // collective: returns on every rank with the total in place, visible to `s`
+    SGP_HIP(hipMemcpy2DAsync(dG.p, sizeof(double) * ldg, dP.p, sizeof(double) * m_pad, sizeof(double) * m_pad, (size_t)m_pad,
+                             hipMemcpyDeviceToDevice, s));
+    SGP_HIP(hipMemcpyAsync(dots.p, dP.p + mm, sizeof(double) * m_pad, hipMemcpyDeviceToDevice, s));
+    SGP_HIP(hipMemcpyAsync(ctx->d_scal + 1, dP.p + mm + m_pad, sizeof(double) * 4, hipMemcpyDeviceToDevice, s));
+    SGP_HIP(hipStreamSynchronize(s));   // dP goes out of scope
+  }
   hipLaunchKernelGGL(add_identity_kernel, dim3((unsigned)((m_pad + 255) / 256)), dim3(256), 0, s, dG.p, ldg, m_pad);
   SGP_HIP(hipMemcpy2DAsync(dB.p, sizeof(double) * m_pad, dG.p, sizeof(double) * ldg, sizeof(double) * m_pad,
                            (size_t)m_pad, hipMemcpyDeviceToDevice, s));
@@ -2932,7 +2954,7 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   }
   {
     double tmp = h[0] + h[4] + h[1] - h[5];
-    double dtc = -0.5 * ((double)N * 1.8378770664093453 + tmp);
+    double dtc = -0.5 * ((double)(shard ? shard->n_total : N) * 1.8378770664093453 + tmp);
     elbo_out[0] = dtc - 0.5 * (h[2] - h[3]);
   }
   // ---- M x M stage
@@ -2949,9 +2971,11 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   CHECK_RC(dE.alloc((size_t)n_rows * m_pad));
   CHECK_RC(launch_gemm_nt(dRZ.p, n_rows, Jm, ld, dE.p, n_rows, n_rows, m_pad, m_pad, 1.0, 0.0, NOMASK, 0, 0, s));
   CHECK_RC(launch_vfe_gxz(dE.p, n_rows, ddelta.p, dut.p, drsig.p, n_rows, m_pad, s));
-  // ---- G_zz = -1/2 J S J'
-  CHECK_RC(launch_gemm_nt(Jm, ld, dS.p, m_pad, dT1.p, m_pad, m_pad, m_pad, m_pad, 1.0, 0.0, NOMASK, 0, 0, s));
-  CHECK_RC(launch_gemm_nt(dT1.p, m_pad, Jm, ld, dGzz.p, m_pad, m_pad, m_pad, m_pad, -0.5, 0.0, NOMASK, 0, 0, s));
+  // ---- G_zz = -1/2 J S J' (a sharded call: on the primary rank only)
+  if (!shard || shard->primary) {
+    CHECK_RC(launch_gemm_nt(Jm, ld, dS.p, m_pad, dT1.p, m_pad, m_pad, m_pad, m_pad, 1.0, 0.0, NOMASK, 0, 0, s));
+    CHECK_RC(launch_gemm_nt(dT1.p, m_pad, Jm, ld, dGzz.p, m_pad, m_pad, m_pad, m_pad, -0.5, 0.0, NOMASK, 0, 0, s));
+  }
   // ---- contractions against the flattened terms
   if (grad_coef_xz || grad_inscale_xz)
     CHECK_RC(contract_spec(gx.ds, dE.p, n_rows, nullptr, n_rows / TILE, m_pad / TILE, dpart, dgcx.p, dgsx.p, s));
@@ -3100,17 +3124,28 @@ static int elbo_grad_core(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_sp
   return 0;
 }
 
+// the three entry points: one record of arguments; a multi-GPU context shards the data points over its ranks (round 6)
+static int elbo_grad_entry(sgp_ctx* ctx, const sgp::ElboGradArgs& a) {
+  CHECK_ARG(ctx, "sgp_elbo_grad: NULL context");
+  if (ctx->multi && ctx->multi_nranks > 1) return sgp_multi_elbo_grad(ctx, a);
+  return sgp::drv_elbo_grad(ctx, a, nullptr);
+}
+#define SGP_ELBO_GRAD_ARGS(a)                                                                                      \
+  sgp::ElboGradArgs a;                                                                                             \
+  a.zz = zz, a.xz = xz, a.var_x = var_x, a.mean_x = mean_x, a.noise_kind = noise_kind, a.noise_x = noise_x;       \
+  a.z_noise_kind = z_noise_kind, a.z_noise = z_noise, a.y = y, a.elbo_out = elbo_out, a.grad_y = grad_y;          \
+  a.grad_mean = grad_mean, a.grad_noise = grad_noise, a.grad_var_x = grad_var_x, a.grad_z_noise = grad_z_noise;   \
+  a.grad_coef_zz = grad_coef_zz, a.grad_inscale_zz = grad_inscale_zz, a.grad_coef_xz = grad_coef_xz;              \
+  a.grad_inscale_xz = grad_inscale_xz
+
 extern "C" int sgp_elbo_grad(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
                              const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind,
                              const double* z_noise, const double* y, double* elbo_out, double* grad_y,
                              double* grad_mean, double* grad_noise, double* grad_var_x, double* grad_z_noise,
                              double* grad_coef_zz, double* grad_inscale_zz, double* grad_coef_xz,
                              double* grad_inscale_xz) {
-  return with_df_fallback(ctx, [&]() {
-    return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
-                          grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
-                          grad_inscale_xz, nullptr, nullptr);
-  });
+  SGP_ELBO_GRAD_ARGS(a);
+  return elbo_grad_entry(ctx, a);
 }
 
 extern "C" int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
@@ -3121,11 +3156,9 @@ extern "C" int sgp_elbo_grad_x(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_c
                                double* grad_inscale_xz, double* const* grad_inputs_zz,
                                double* const* grad_inputs_xz) {
   CHECK_ARG(grad_inputs_zz && grad_inputs_xz, "sgp_elbo_grad_x: grad_inputs_* is NULL");
-  return with_df_fallback(ctx, [&]() {
-    return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
-                          grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
-                          grad_inscale_xz, grad_inputs_zz, grad_inputs_xz);
-  });
+  SGP_ELBO_GRAD_ARGS(a);
+  a.grad_inputs_zz = grad_inputs_zz, a.grad_inputs_xz = grad_inputs_xz;
+  return elbo_grad_entry(ctx, a);
 }
 
 extern "C" int sgp_elbo_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
@@ -3136,13 +3169,12 @@ extern "C" int sgp_elbo_grad_xs(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_
                                 double* grad_inscale_xz, double* const* grad_inputs_zz,
                                 double* const* grad_inputs_xz, double* const* grad_rowscale_zz,
                                 double* const* grad_rowscale_xz, double* const* grad_colscale_xz) {
-  return with_df_fallback(ctx, [&]() {
-    return elbo_grad_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, elbo_out, grad_y,
-                          grad_mean, grad_noise, grad_var_x, grad_z_noise, grad_coef_zz, grad_inscale_zz, grad_coef_xz,
-                          grad_inscale_xz, grad_inputs_zz, grad_inputs_xz, grad_rowscale_zz, grad_rowscale_xz,
-                          grad_colscale_xz);
-  });
+  SGP_ELBO_GRAD_ARGS(a);
+  a.grad_inputs_zz = grad_inputs_zz, a.grad_inputs_xz = grad_inputs_xz, a.grad_rowscale_zz = grad_rowscale_zz;
+  a.grad_rowscale_xz = grad_rowscale_xz, a.grad_colscale_xz = grad_colscale_xz;
+  return elbo_grad_entry(ctx, a);
 }
+#undef SGP_ELBO_GRAD_ARGS
 
 // sum_i w[i] d var_i / d theta over the diagonal of `spec` (the blocks (I, I) kernelmatrix_diag reads)
 static int diag_grad_core(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* w, double* grad_coef,
@@ -3570,6 +3602,16 @@ int drv_vfe_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz
                     const double* y, double* dLz, double* d_wz, double* d_part, long part_len) {
   return elbo_partial_core(ctx, zz, xz, var_x, mean_x, noise_kind, noise_x, z_noise_kind, z_noise, y, dLz, d_wz, d_part,
                            part_len);
+}
+int drv_elbo_grad(sgp_ctx* ctx, const ElboGradArgs& a, const ElboGradShard* shard) {
+  auto run = [&]() {
+    return elbo_grad_core(ctx, a.zz, a.xz, a.var_x, a.mean_x, a.noise_kind, a.noise_x, a.z_noise_kind, a.z_noise, a.y,
+                          a.elbo_out, a.grad_y, a.grad_mean, a.grad_noise, a.grad_var_x, a.grad_z_noise, a.grad_coef_zz,
+                          a.grad_inscale_zz, a.grad_coef_xz, a.grad_inscale_xz, a.grad_inputs_zz, a.grad_inputs_xz,
+                          a.grad_rowscale_zz, a.grad_rowscale_xz, a.grad_colscale_xz, shard);
+  };
+  // (a rank of a sharded call cannot rerun on its own -- the reduction is collective: multi.hip reruns all of them)
+  return shard ? run() : with_df_fallback(ctx, run);
 }
 int drv_vfe_finish(sgp_ctx* ctx, long M, double* d_part, double* d_wg, double* h6) {
   return elbo_finish_core(ctx, M, d_part, d_wg, h6);

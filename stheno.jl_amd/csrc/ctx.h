@@ -1,6 +1,7 @@
 // Host-side state shared by the translation units of libsthenomi.so: the context (one GPU, its
 // streams, scratch and a grow-only device-memory cache), device-resident specs, RAII buffers.
 #pragma once
+#include <functional>
 #include "common.h"
 #include "../../include/sthenomi.h"
 #include "../../include/sthenomi_bench.h"
@@ -46,6 +47,34 @@ int sgp_multi_logpdf_grad(struct sgp_ctx* ctx, const sgp_cov_spec* spec, const d
                           const double* noise, const double* y, double* logpdf_out, double* grad_y, double* grad_mean,
                           double* grad_noise, double* grad_coef, double* grad_inscale, double* const* grad_inputs = nullptr,
                           double* const* grad_rowscale = nullptr);
+// sgp_elbo_grad / _x / _xs: the arguments of the three entry points as one record (NULL = not asked for), and one rank's
+// view of a data-sharded call (round 6)
+namespace sgp {
+struct ElboGradArgs {
+  const sgp_cov_spec *zz = nullptr, *xz = nullptr;
+  const double *var_x = nullptr, *mean_x = nullptr;
+  int noise_kind = 0;
+  const double* noise_x = nullptr;
+  int z_noise_kind = 0;
+  const double *z_noise = nullptr, *y = nullptr;
+  double *elbo_out = nullptr, *grad_y = nullptr, *grad_mean = nullptr, *grad_noise = nullptr, *grad_var_x = nullptr,
+         *grad_z_noise = nullptr, *grad_coef_zz = nullptr, *grad_inscale_zz = nullptr, *grad_coef_xz = nullptr,
+         *grad_inscale_xz = nullptr;
+  double* const* grad_inputs_zz = nullptr;
+  double* const* grad_inputs_xz = nullptr;
+  double* const* grad_rowscale_zz = nullptr;
+  double* const* grad_rowscale_xz = nullptr;
+  double* const* grad_colscale_xz = nullptr;
+};
+struct ElboGradShard {
+  bool primary = false;   // the rank that also produces the zz-side results (G_zz and its contractions)
+  long n_total = 0;       // data points of the whole call (the bound's N log 2 pi)
+  // collective over the ranks of the call: d_part (device memory of this rank, len doubles, complete) <- the sum over ranks
+  std::function<int(double* d_part, long len)> reduce;
+};
+}  // namespace sgp
+// data points sharded over the ranks: one reduction of M^2 + M + 4 doubles between the two factorisations (multi.hip)
+int sgp_multi_elbo_grad(struct sgp_ctx* ctx, const sgp::ElboGradArgs& a);
 // h6: the six terms of the bound (capi.hip: vfe_pipeline).  dLz / d_wz / d_part0 / d_wg non-NULL (device 0
 // buffers): the M x M factors a sparse posterior keeps (d_part0 doubles as rank 0's part and ends up holding chol(A A' + I))
 int sgp_multi_vfe(struct sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,

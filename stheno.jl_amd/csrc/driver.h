@@ -54,6 +54,8 @@ long drv_vfe_part_len(long m_pad);
 int drv_vfe_partial(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, const double* var_x,
                     const double* mean_x, int noise_kind, const double* noise_x, int z_noise_kind, const double* z_noise,
                     const double* y, double* dLz, double* d_wz, double* d_part, long part_len);
+// ELBO + gradient on `ctx` (takes the context itself); shard == nullptr: the whole call, with the dataflow fallback
+int drv_elbo_grad(sgp_ctx* ctx, const ElboGradArgs& a, const ElboGradShard* shard);
 // h6: the six ELBO terms (see vfe_pipeline); d_wg (optional) keeps the inverse diagonal blocks of chol(A A' + I)
 int drv_vfe_finish(sgp_ctx* ctx, long M, double* d_part, double* d_wg, double* h6);
 

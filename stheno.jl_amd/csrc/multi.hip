@@ -55,6 +55,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <functional>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
@@ -2416,18 +2418,23 @@ struct SlicedSpec {
   std::vector<int64_t> row_len;
   std::vector<sgp_input> inputs;
   std::vector<sgp_term> terms;
+  std::vector<long> row_a;                        // per row block: its first row inside the slice's view of the block
+  std::vector<std::pair<int, long>> origin;       // per input of the sliced spec: (input of the whole spec, first point)
   SlicedSpec(const sgp_cov_spec* sp, long lo, long hi) {
     c = *sp;
     const int nrb = sp->n_row_blocks, ncb = sp->n_col_blocks;
     inputs.assign(sp->inputs, sp->inputs + sp->n_inputs);
     terms.assign(sp->terms, sp->terms + sp->term_ptr[nrb * ncb]);
     row_len.resize(nrb);
+    row_a.resize(nrb);
+    for (int k = 0; k < sp->n_inputs; ++k) origin.emplace_back(k, 0L);
     std::map<std::pair<int, int>, int> made;
     long off = 0;
     for (int I = 0; I < nrb; ++I) {
       const long n = sp->row_len[I];
       const long a = std::min(std::max(lo - off, 0L), n), e = std::min(std::max(hi - off, 0L), n);
       row_len[I] = e - a;
+      row_a[I] = a;
       for (int J = 0; J < ncb; ++J) {
         const int p = I * ncb + J;
         for (int t = sp->term_ptr[p]; t < sp->term_ptr[p + 1]; ++t) {
@@ -2439,6 +2446,7 @@ struct SlicedSpec {
             in.x = in.x + a * in.ld;
             in.n = e - a;
             inputs.push_back(in);
+            origin.emplace_back((int)T.row_input, a);
             it = made.emplace(key, (int)inputs.size() - 1).first;
           }
           T.row_input = it->second;
@@ -2541,4 +2549,272 @@ int sgp_multi_vfe(sgp_ctx* ctx, const sgp_cov_spec* zz, const sgp_cov_spec* xz, 
   m->last_ms = now_ms() - t0;
   hipSetDevice(ctx->device);
   return rc;
+}
+
+// elbo + its gradient (sgp_elbo_grad / _x / _xs; formulas: capi.hip elbo_grad_core): the data points are sharded as in
+// sgp_multi_vfe, every rank runs the whole pipeline on its slice on a host thread of its own, and the sums over data points
+// (A A', A delta, four scalars) meet in ONE reduction between the two factorisations -- the second factorisation and the
+// M x M stage then run replicated on identical numbers.  Per-point results (d/dy, d/dmean, a diagonal d/dSigma_y, the x
+// points, the function scales at x) land in the caller's arrays slice by slice; sums over data points (kernel parameters of
+// the xz spec, the z points, the scales at z, an isotropic d/dsigma^2) are added on the host in rank order; the zz side is
+// rank 0's.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct PartBarrier {   // the ranks' host threads meet here; the last one in performs the reduction for all
+  std::mutex mu;
+  std::condition_variable cv;
+  int P = 0, arrived = 0;
+  long gen = 0;
+  bool failed = false;
+  int rc = 0;
+  std::vector<double*> part;
+  long len = 0;
+  std::function<int()> work;
+  int arrive(int i, double* d_part, long n) {
+    std::unique_lock<std::mutex> lk(mu);
+    if (failed) return -5;
+    part[i] = d_part;
+    len = n;
+    if (++arrived == P) {
+      rc = work();
+      arrived = 0;
+      ++gen;
+      cv.notify_all();
+      return rc;
+    }
+    const long g = gen;
+    cv.wait(lk, [&] { return gen != g || failed; });
+    return gen != g ? rc : -5;
+  }
+  void fail() {   // a rank left the pipeline early: nobody may wait for it
+    std::lock_guard<std::mutex> lk(mu);
+    failed = true;
+    cv.notify_all();
+  }
+};
+
+}  // namespace
+
+int sgp_multi_elbo_grad(sgp_ctx* ctx, const ElboGradArgs& a) {
+  sgp_multi* m = ctx->multi;
+  const int P = (int)m->r.size();
+  M_CHECK_ARG(a.zz && a.xz && a.var_x && a.noise_x && a.z_noise && a.y && a.elbo_out, "sgp_elbo_grad: NULL argument");
+  M_CHECK_ARG(a.noise_kind == SGP_NOISE_SCALAR || a.noise_kind == SGP_NOISE_DIAG,
+              "sgp_elbo_grad: Sigma_y must be isotropic or diagonal (as in AbstractGPs.elbo)");
+  const long N = spec_rows(a.xz);
+  if (P == 1 || N < (long)P * TILE) return drv_elbo_grad(m->r[0].ctx, a, nullptr);   // nothing to shard
+  const sgp_cov_spec* xz = a.xz;
+  const int nrb = xz->n_row_blocks, ncb = xz->n_col_blocks;
+  const int nt = xz->term_ptr[nrb * ncb];
+  const bool diag = a.noise_kind == SGP_NOISE_DIAG;
+  // ---- per rank: the slice, its arguments, host buffers for what is summed over the ranks
+  struct PerRank {
+    std::unique_ptr<SlicedSpec> sl;
+    ElboGradArgs b;
+    double elbo = 0.0, noise_sum = 0.0;
+    std::vector<double> coef, inscale;
+    std::vector<std::vector<double>> in_buf, cs_buf;
+    std::vector<double*> in_ptr, rs_ptr, cs_ptr;
+  };
+  std::vector<PerRank> pr(P);
+  for (int i = 0; i < P; ++i) {
+    PerRank& q = pr[i];
+    const long lo = N * i / P, hi = N * (i + 1) / P;
+    q.sl.reset(new SlicedSpec(xz, lo, hi));
+    const sgp_cov_spec& c = q.sl->c;
+    ElboGradArgs& b = q.b;
+    b = a;
+    b.xz = &c;
+    b.var_x = a.var_x + lo;
+    b.mean_x = a.mean_x ? a.mean_x + lo : nullptr;
+    b.noise_x = diag ? a.noise_x + lo : a.noise_x;
+    b.y = a.y + lo;
+    b.elbo_out = i == 0 ? a.elbo_out : &q.elbo;
+    b.grad_y = a.grad_y ? a.grad_y + lo : nullptr;
+    b.grad_mean = a.grad_mean ? a.grad_mean + lo : nullptr;
+    b.grad_var_x = a.grad_var_x ? a.grad_var_x + lo : nullptr;
+    b.grad_noise = a.grad_noise ? (diag ? a.grad_noise + lo : &q.noise_sum) : nullptr;
+    if (i != 0) {   // the zz side: rank 0
+      b.grad_z_noise = b.grad_coef_zz = b.grad_inscale_zz = nullptr;
+      b.grad_inputs_zz = nullptr;
+      b.grad_rowscale_zz = nullptr;
+    }
+    if (a.grad_coef_xz) q.coef.assign((size_t)std::max(1, nt), 0.0), b.grad_coef_xz = q.coef.data();
+    if (a.grad_inscale_xz) q.inscale.assign((size_t)std::max(1, nt), 0.0), b.grad_inscale_xz = q.inscale.data();
+    if (a.grad_inputs_xz) {
+      q.in_buf.resize((size_t)c.n_inputs);
+      q.in_ptr.assign((size_t)c.n_inputs, nullptr);
+      for (int k = 0; k < c.n_inputs; ++k) {
+        if (!a.grad_inputs_xz[q.sl->origin[(size_t)k].first] || c.inputs[k].n <= 0) continue;
+        q.in_buf[(size_t)k].assign((size_t)(c.inputs[k].dim * c.inputs[k].n), 0.0);
+        q.in_ptr[(size_t)k] = q.in_buf[(size_t)k].data();
+      }
+      b.grad_inputs_xz = q.in_ptr.data();
+    }
+    if (a.grad_rowscale_xz || a.grad_colscale_xz) {
+      q.rs_ptr.assign((size_t)std::max(1, nt), nullptr);
+      q.cs_ptr.assign((size_t)std::max(1, nt), nullptr);
+      q.cs_buf.resize((size_t)std::max(1, nt));
+      for (int I = 0; I < nrb; ++I)
+        for (int J = 0; J < ncb; ++J)
+          for (int t = xz->term_ptr[I * ncb + J]; t < xz->term_ptr[I * ncb + J + 1]; ++t) {
+            if (a.grad_rowscale_xz && a.grad_rowscale_xz[t]) q.rs_ptr[(size_t)t] = a.grad_rowscale_xz[t] + q.sl->row_a[(size_t)I];
+            if (a.grad_colscale_xz && a.grad_colscale_xz[t]) {
+              q.cs_buf[(size_t)t].assign((size_t)std::max<long>(1, (long)xz->col_len[J]), 0.0);
+              q.cs_ptr[(size_t)t] = q.cs_buf[(size_t)t].data();
+            }
+          }
+      b.grad_rowscale_xz = a.grad_rowscale_xz ? q.rs_ptr.data() : nullptr;
+      b.grad_colscale_xz = a.grad_colscale_xz ? q.cs_ptr.data() : nullptr;
+    }
+  }
+  // ---- the reduction the ranks meet in
+  PartBarrier bar;
+  bar.P = P;
+  bar.part.assign((size_t)P, nullptr);
+  bar.work = [&]() -> int {   // (runs on the host thread of the last rank to arrive, every part complete)
+    const long len = bar.len;
+    if (m->transport == TR_RCCL) {
+      int rc = m->rccl.GroupStart();
+      for (int i = 0; i < P && rc == 0; ++i) {
+        Rank& k = m->r[i];
+        hipSetDevice(k.dev);
+        rc = m->rccl.AllReduce(bar.part[(size_t)i], bar.part[(size_t)i], (size_t)len, NCCL_DOUBLE, NCCL_SUM, k.comm, k.s_upd);
+      }
+      const int rc2 = m->rccl.GroupEnd();
+      if (rc || rc2) {
+        set_error("ncclAllReduce failed (elbo gradient parts)");
+        return -4;
+      }
+      for (auto& k : m->r) {
+        M_HIP(hipSetDevice(k.dev));
+        M_HIP(hipStreamSynchronize(k.s_upd));
+      }
+      return 0;
+    }
+    Rank& k0 = m->r[0];
+    M_HIP(hipSetDevice(k0.dev));
+    M_RC(grow(&k0.d_work2, &k0.work2_cap, (size_t)len));
+    for (int i = 1; i < P; ++i) {   // rank order: deterministic
+      Rank& k = m->r[i];
+      if (k.dev == k0.dev)
+        M_HIP(hipMemcpyAsync(k0.d_work2, bar.part[(size_t)i], sizeof(double) * len, hipMemcpyDeviceToDevice, k0.s_upd));
+      else
+        M_HIP(hipMemcpyPeerAsync(k0.d_work2, k0.dev, bar.part[(size_t)i], k.dev, sizeof(double) * len, k0.s_upd));
+      M_RC(drv_axpy_block(bar.part[0], len, k0.d_work2, len, len, 1, 1.0, k0.s_upd));
+    }
+    for (int i = 1; i < P; ++i) {   // and back: every rank continues on the same numbers
+      Rank& k = m->r[i];
+      if (k.dev == k0.dev)
+        M_HIP(hipMemcpyAsync(bar.part[(size_t)i], bar.part[0], sizeof(double) * len, hipMemcpyDeviceToDevice, k0.s_upd));
+      else
+        M_HIP(hipMemcpyPeerAsync(bar.part[(size_t)i], k.dev, bar.part[0], k0.dev, sizeof(double) * len, k0.s_upd));
+    }
+    M_HIP(hipStreamSynchronize(k0.s_upd));
+    return 0;
+  };
+  std::vector<int> rcs(P, 0);
+  std::vector<std::string> errs(P);
+  const double t0 = now_ms();
+  auto run_all = [&]() {
+    bar.failed = false;
+    bar.arrived = 0;
+    std::vector<std::thread> th;
+    for (int i = 0; i < P; ++i) {
+      th.emplace_back([&, i]() {
+        Rank& k = m->r[i];
+        hipSetDevice(k.dev);
+        ElboGradShard sh;
+        sh.primary = i == 0;
+        sh.n_total = N;
+        sh.reduce = [&, i](double* d_part, long len) -> int {
+          const int rc = bar.arrive(i, d_part, len);
+          hipSetDevice(m->r[i].dev);   // (the reduction visits every rank's device on this thread)
+          if (rc == -5) set_error("sgp_elbo_grad (multi): another rank failed before the reduction");
+          return rc;
+        };
+        rcs[i] = drv_elbo_grad(k.ctx, pr[i].b, &sh);
+        if (rcs[i]) {
+          errs[i] = sgp_last_error();
+          bar.fail();
+        }
+      });
+    }
+    for (auto& t : th) t.join();
+  };
+  run_all();
+  {   // a dataflow launch that timed out on some rank: once more, every rank on the launch-based schedule (capi.hip:
+      // with_df_fallback -- a rank cannot rerun on its own, the reduction is collective)
+    bool timed_out = false;
+    for (int i = 0; i < P; ++i) timed_out = timed_out || (rcs[i] == -3 && m->r[i].ctx->df_timed_out);
+    if (timed_out) {
+      std::vector<std::pair<int, int>> keep;
+      for (auto& k : m->r) {
+        keep.emplace_back(k.ctx->dataflow, k.ctx->hybrid);
+        k.ctx->dataflow = k.ctx->hybrid = 0;
+        k.ctx->df_timed_out = false;
+        k.ctx->df_fallbacks += 1;
+      }
+      run_all();
+      for (int i = 0; i < P; ++i) m->r[i].ctx->dataflow = keep[(size_t)i].first, m->r[i].ctx->hybrid = keep[(size_t)i].second;
+    }
+  }
+  hipSetDevice(ctx->device);
+  {   // the root cause first: a rank that merely saw another one fail (-5) is not it
+    int first = -1;
+    for (int i = 0; i < P; ++i)
+      if (rcs[i] && rcs[i] != -5 && first < 0) first = i;
+    for (int i = 0; i < P && first < 0; ++i)
+      if (rcs[i]) first = i;
+    if (first >= 0) {
+      set_error(errs[(size_t)first]);
+      return rcs[(size_t)first];
+    }
+  }
+  // ---- what is summed over the ranks, in rank order
+  if (a.grad_noise && !diag) {
+    double acc = 0.0;
+    for (int i = 0; i < P; ++i) acc += pr[i].noise_sum;
+    a.grad_noise[0] = acc;
+  }
+  for (int t = 0; t < nt; ++t) {
+    if (a.grad_coef_xz) {
+      double acc = 0.0;
+      for (int i = 0; i < P; ++i) acc += pr[i].coef[(size_t)t];
+      a.grad_coef_xz[t] = acc;
+    }
+    if (a.grad_inscale_xz) {
+      double acc = 0.0;
+      for (int i = 0; i < P; ++i) acc += pr[i].inscale[(size_t)t];
+      a.grad_inscale_xz[t] = acc;
+    }
+  }
+  if (a.grad_inputs_xz) {
+    for (int k = 0; k < xz->n_inputs; ++k)
+      if (a.grad_inputs_xz[k] && xz->inputs[k].n > 0)
+        std::fill(a.grad_inputs_xz[k], a.grad_inputs_xz[k] + xz->inputs[k].dim * xz->inputs[k].n, 0.0);
+    for (int i = 0; i < P; ++i) {
+      const SlicedSpec& sl = *pr[i].sl;
+      for (int k = 0; k < sl.c.n_inputs; ++k) {
+        const std::vector<double>& src = pr[i].in_buf[(size_t)k];
+        if (src.empty()) continue;
+        double* dst = a.grad_inputs_xz[sl.origin[(size_t)k].first] + sl.origin[(size_t)k].second * sl.c.inputs[k].dim;
+        for (size_t e = 0; e < src.size(); ++e) dst[e] += src[e];
+      }
+    }
+  }
+  if (a.grad_colscale_xz)
+    for (int I = 0; I < nrb; ++I)
+      for (int J = 0; J < ncb; ++J)
+        for (int t = xz->term_ptr[I * ncb + J]; t < xz->term_ptr[I * ncb + J + 1]; ++t) {
+          if (!a.grad_colscale_xz[t] || !xz->terms[t].col_scale) continue;
+          for (long e = 0; e < (long)xz->col_len[J]; ++e) {
+            double acc = 0.0;
+            for (int i = 0; i < P; ++i) acc += pr[i].cs_buf[(size_t)t][(size_t)e];
+            a.grad_colscale_xz[t][e] = acc;
+          }
+        }
+  m->last_ms = now_ms() - t0;
+  return 0;
 }

@@ -251,8 +251,9 @@ class Context:
     """One sgp_ctx (one GPU, one stream).  `default_context()` gives a process-wide one."""
 
     def __init__(self, device=0, devices=None):
-        """device: one GPU.  devices=[...]: a multi-GPU context (sgp_ctx_create_multi): logpdf is sharded
-        over the listed GPUs inside the library; everything else runs on devices[0]."""
+        """device: one GPU.  devices=[...]: a multi-GPU context (sgp_ctx_create_multi): logpdf, rand, the posterior, the
+        gradients, the covariance entry points, the ELBO and its gradients are sharded over the listed GPUs inside the
+        library (include/sthenomi.h lists what is not)."""
         lib = load()
         h = _P()
         if devices is not None:

@@ -790,3 +790,110 @@ def test_gradient_with_dense_observation_noise_sharded_over_the_ranks(panel128, 
     for t0, t1 in zip(g0["terms"], g1["terms"]):
         assert abs(t1["d_coef"] - t0["d_coef"]) <= 1e-8 * max(1.0, abs(t0["d_coef"]))
         assert abs(t1["d_inscale"] - t0["d_inscale"]) <= 1e-8 * max(1.0, abs(t0["d_inscale"]))
+
+
+def _close(a, b, tol, what):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    if a.size:
+        assert np.abs(a - b).max() <= tol * max(1.0, np.abs(a).max()), (what, np.abs(a - b).max(), np.abs(a).max())
+
+
+def _same_elbo_gradient(g0, g1, tol=1e-9):
+    assert abs(g1["elbo"] - g0["elbo"]) <= 1e-10 * abs(g0["elbo"]), (g0["elbo"], g1["elbo"])
+    for k in ("y", "mean", "noise", "z_noise", "var"):
+        _close(g0[k], g1[k], tol, k)
+    for k in ("zz", "xz", "xx"):
+        for a0, a1 in zip(g0["_raw"][k], g1["_raw"][k]):
+            _close(a0, a1, tol, "terms " + k)
+    for k in ("x", "z", "zz_inputs", "xz_inputs"):
+        if g0[k] is None:
+            assert g1[k] is None
+            continue
+        assert len(g0[k]) == len(g1[k])
+        for a0, a1 in zip(g0[k], g1[k]):
+            _close(a0, a1, tol, k)
+    if g0["scales"] is None:
+        assert g1["scales"] is None
+    else:
+        assert len(g0["scales"]) == len(g1["scales"])
+        for s0, s1 in zip(g0["scales"], g1["scales"]):
+            _close(s0["d_values"], s1["d_values"], tol, "scales")
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 5])
+def test_elbo_gradient_data_sharded_over_the_ranks(nranks):
+    """Round 6: sgp_elbo_grad / _x / _xs on a multi-GPU context (they used to run on devices[0]) -- the data points are
+    sharded as for the ELBO itself, every rank runs the pipeline on its slice, the sums over data points (A A', A delta, four
+    scalars) meet in one reduction between the two factorisations, the M x M stage runs replicated.  Against the single-GPU
+    results: a single process with isotropic and diagonal noise (every result the entry points return); a programme whose
+    data blocks are split by the slices, with inducing points on two processes, input-point gradients (x points come back
+    slice by slice, z points summed over the ranks); function-valued scales at x (sliced) and at z (summed)."""
+    ctx = P.lib.Context(devices=[0] * nranks)
+    rng = np.random.default_rng(41)
+    D, N, M = 3, 1700, 130
+    f = P.stretch(P.atomic(P.GP(0.3, P.Matern52Kernel()), P.GPC()), 0.7)
+    X = np.asfortranarray(rng.standard_normal((D, N)))
+    Z = np.asfortranarray(X[:, :M] + 0.01)
+    y = rng.standard_normal(N)
+    for nz in (0.1, 0.05 + rng.random(N)):
+        for kw in (dict(), dict(inputs=True)):
+            vfe, fx = P.VFE(f(P.ColVecs(Z), 1e-4)), f(P.ColVecs(X), nz)
+            g0 = P.elbo_and_gradient(vfe, fx, y, **kw)
+            g1 = _with_ctx(ctx, lambda: P.elbo_and_gradient(vfe, fx, y, **kw))
+            g2 = _with_ctx(ctx, lambda: P.elbo_and_gradient(vfe, fx, y, **kw))
+            _same_elbo_gradient(g0, g1)
+            _same_elbo_gradient(g1, g2, tol=0.0)                 # deterministic: fixed-order reductions
+            # ... and really sharded: A A' summed slice by slice rounds differently from the one-GPU split-K sum
+            assert not np.array_equal(g0["y"], g1["y"])
+    # a programme: three data blocks of different lengths (slice boundaries fall inside them), inducing points on f1 and f3
+    F = P.gppp_sum_model()
+    mats = [np.asfortranarray(rng.standard_normal((2, n))) for n in (300, 420, 515)]
+    zm = [np.asfortranarray(rng.standard_normal((2, 40))), np.asfortranarray(rng.standard_normal((2, 33)))]
+    xb = P.BlockData([P.GPPPInput(k, P.ColVecs(a)) for k, a in zip(("f1", "f2", "f3"), mats)])
+    zb = P.BlockData([P.GPPPInput("f1", P.ColVecs(zm[0])), P.GPPPInput("f3", P.ColVecs(zm[1]))])
+    yy = rng.standard_normal(len(xb))
+    g0 = P.elbo_and_gradient(P.VFE(F(zb, 1e-4)), F(xb, 0.2), yy, inputs=True)
+    g1 = _with_ctx(ctx, lambda: P.elbo_and_gradient(P.VFE(F(zb, 1e-4)), F(xb, 0.2), yy, inputs=True))
+    _same_elbo_gradient(g0, g1)
+    # function-valued scales, one nested under the other (product.jl:25-48), with dense Sigma_z
+    x, z1, z2 = rng.standard_normal(900), rng.standard_normal(30), rng.standard_normal(25)
+    gpc = P.GPC()
+    f1 = P.atomic(P.GP(P.Matern32Kernel()), gpc)
+    f2 = P.atomic(P.GP(P.SEKernel()), gpc)
+    g1_ = (lambda t: 1.0 + 0.4 * float(np.sum(np.sin(t)))) * f1
+    G = P.GPPP({"f1": f1, "f2": f2, "g1": g1_, "h": (lambda t: float(np.exp(0.15 * np.sum(t)))) * (g1_ + f2)}, gpc)
+    B = rng.standard_normal((55, 4))
+    Sz = 1e-3 * np.eye(55) + 1e-4 * B @ B.T
+    vfe = P.VFE(G(P.BlockData([P.GPPPInput("g1", z1), P.GPPPInput("f2", z2)]), Sz))
+    fx = G(P.GPPPInput("h", x), 0.3)
+    ys = rng.standard_normal(900)
+    for kw in (dict(scales=True), dict(scales=True, inputs=True)):
+        r0 = P.elbo_and_gradient(vfe, fx, ys, **kw)
+        r1 = _with_ctx(ctx, lambda: P.elbo_and_gradient(vfe, fx, ys, **kw))
+        _same_elbo_gradient(r0, r1)
+    # fewer data points than 128 per rank: not sharded, still exact
+    fxs = f(P.ColVecs(np.asfortranarray(X[:, :100])), 0.1)
+    g0 = P.elbo_and_gradient(P.VFE(f(P.ColVecs(Z[:, :8]), 1e-4)), fxs, y[:100])
+    g1 = _with_ctx(ctx, lambda: P.elbo_and_gradient(P.VFE(f(P.ColVecs(Z[:, :8]), 1e-4)), fxs, y[:100]))
+    _same_elbo_gradient(g0, g1)
+    ctx.close()
+
+
+def test_elbo_gradient_failure_on_the_multi_gpu_context_is_reported_and_the_context_stays_usable():
+    """K(z,z) + Sigma_z not positive definite: every rank's first factorisation fails before the reduction -- nobody waits for
+    anybody, the leading minor is reported, and the next call on the same context works."""
+    ctx = P.lib.Context(devices=[0, 0, 0])
+    rng = np.random.default_rng(42)
+    N, M = 700, 40
+    f = P.atomic(P.GP(P.SEKernel()), P.GPC())
+    X = np.asfortranarray(rng.standard_normal((2, N)))
+    Zd = np.asfortranarray(np.repeat(X[:, :M // 2], 2, axis=1))          # duplicated inducing points, no jitter
+    y = rng.standard_normal(N)
+    with pytest.raises(P.PosDefException):
+        _with_ctx(ctx, lambda: P.elbo_and_gradient(P.VFE(f(P.ColVecs(Zd), -1e-3)), f(P.ColVecs(X), 0.1), y))
+    Zg = np.asfortranarray(X[:, :M] + 0.01)
+    g0 = P.elbo_and_gradient(P.VFE(f(P.ColVecs(Zg), 1e-4)), f(P.ColVecs(X), 0.1), y)
+    g1 = _with_ctx(ctx, lambda: P.elbo_and_gradient(P.VFE(f(P.ColVecs(Zg), 1e-4)), f(P.ColVecs(X), 0.1), y))
+    _same_elbo_gradient(g0, g1)
+    ctx.close()
