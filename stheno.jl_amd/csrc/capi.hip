@@ -1923,10 +1923,27 @@ struct sgp_post {
 // block first receives everything left of it in ONE deep GEMM (K = its column offset: the efficient
 // shape of the MFMA kernel), then is solved in place in 128-column steps with K = 128 updates inside
 // the block only.  Same flops as the right-looking sweep, a fraction of its C-tile traffic.
+// the columns [c, c + w) of a block, everything left of the block already applied: by halving -- the left half, ONE update
+// of the right half with it (K = the left half's width), the right half.  The same ascending-k accumulation per entry as
+// 128-column steps with K = 128 updates of everything to their right (each launch seeds its accumulators with the stored
+// value), at 2 / 3 of their C-tile traffic in a 512-column block.
+static int row_trsm_block(double* R, long ldr, long nrows, const double* L, long ldl, const double* d_invall, long c, long w,
+                          long solve_div, hipStream_t s) {
+  if (w <= TILE)
+    return launch_panel_solve(R + c * ldr, ldr, nrows, L + c + c * ldl, ldl, d_invall + (c / TILE) * INVD_STRIDE, 256, 16, s,
+                              nullptr, solve_div);
+  const long wl = (w / TILE + 1) / 2 * TILE;
+  CHECK_RC(row_trsm_block(R, ldr, nrows, L, ldl, d_invall, c, wl, solve_div, s));
+  CHECK_RC(launch_gemm_nt(R + c * ldr, ldr, L + (c + wl) + c * ldl, ldl, R + (c + wl) * ldr, ldr, nrows, w - wl, wl, -1.0, 1.0,
+                          NOMASK, 0, 0, s));
+  return row_trsm_block(R, ldr, nrows, L, ldl, d_invall, c + wl, w - wl, solve_div, s);
+}
 static int row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double* L, long ldl,
                     const double* d_invall, long n_pad, hipStream_t s) {
   // (block width measured round 3 on the N = 262144, M = 4096 ELBO: 128 / 256 / 512 / 1024 columns -> row solve
-  // 80.3 / 78.7 / 78.6 / 80.6 ms: flat -- the in-block part is not what bounds it)
+  // 80.3 / 78.7 / 78.6 / 80.6 ms: flat -- the in-block part is not what bounds it; round 6, with the halving inside the block
+  // and two solve workgroups per CU: 256 / 512 / 1024 / 2048 columns -> step 152.2 / 150.7 / 150.7 / 150.4 ms, against 154.2
+  // for the 128-column steps with K = 128 updates -- profiles/r06_experiments/elbo_c4.md)
   const long WB = 4 * TILE;
   for (long c0 = 0; c0 < n_pad; c0 += WB) {
     long wb = std::min(WB, n_pad - c0);
@@ -1936,15 +1953,7 @@ static int row_trsm(sgp_ctx* ctx, double* R, long ldr, long nrows, const double*
     for (long k0 = 0; k0 < c0; k0 += KC)
       CHECK_RC(launch_gemm_nt(R + k0 * ldr, ldr, L + c0 + k0 * ldl, ldl, R + c0 * ldr, ldr, nrows, wb,
                               std::min(KC, c0 - k0), -1.0, 1.0, NOMASK, 0, 0, s));
-    for (long k = c0; k < c0 + wb; k += TILE) {
-      double* Rk = R + k * ldr;
-      CHECK_RC(launch_panel_solve(Rk, ldr, nrows, L + k + k * ldl, ldl, d_invall + (k / TILE) * INVD_STRIDE, 256, 16,
-                                  s));
-      long rest = c0 + wb - k - TILE;
-      if (rest > 0)
-        CHECK_RC(launch_gemm_nt(Rk, ldr, L + (k + TILE) + k * ldl, ldl, R + (k + TILE) * ldr, ldr, nrows, rest, TILE,
-                                -1.0, 1.0, NOMASK, 0, 0, s));
-    }
+    CHECK_RC(row_trsm_block(R, ldr, nrows, L, ldl, d_invall, c0, wb, 512, s));
   }
   return 0;
 }
@@ -2453,6 +2462,8 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
   // and solved on the first; measured on the N = 262144, M = 4096 bound, profiles/r04_experiments/elbo_c4.txt: 159.7 -> 161.5 ms,
   // two MFMA-bound streams lose more to each other than the solve's substitutions leave idle.  Removed in round 6.)
   CHECK_RC(dAt.alloc((size_t)m_pad * CH));
+  DevBuf dCs;
+  CHECK_RC(dCs.alloc((size_t)transpose_colsum_scratch(CH, m_pad)));
   {   // slabs of the chunk lengths actually used: the `sub` split depends on K % (8 sub 16), so a shorter LAST chunk can
       // need more slabs than a full one (advisor, round 4: SGP_VFE_CHUNK = 768, M = 4096, 1280 rows -> 8 vs 32)
     const long last = n_rows % CH == 0 ? std::min(CH, n_rows) : n_rows % CH;
@@ -2476,10 +2487,10 @@ static int vfe_rows_partial(sgp_ctx* ctx, const sgp_dspec* dz, const sgp_dspec* 
     // the solved rows are read anyway -- the column sums and the transposition (padded rows carry the factor 0)
     CHECK_RC(row_trsm(ctx, dR.p, ch, ch, dLz, m_pad, d_wz, m_pad, s));
     tm.mark(3);
-    hipLaunchKernelGGL(coldot_kernel, dim3((unsigned)m_pad), dim3(256), 0, s, dR.p, ch, ch, ddelta.p + r0, d_dots, sq.p,
-                       r0 > 0 ? 1 : 0, drsig.p + r0);
-    SGP_HIP(hipGetLastError());
-    CHECK_RC(launch_transpose_add(dR.p, ch, ch, m_pad, At, m_pad, nullptr, s, drsig.p + r0));
+    // (round 6: ONE pass over the solved rows -- the column sums ride with the transposition, 6.0 -> 3.6 ms per step at
+    // N = 262 144, M = 4096)
+    CHECK_RC(launch_transpose_colsum(dR.p, ch, ch, m_pad, At, m_pad, drsig.p + r0, ddelta.p + r0, d_dots, sq.p, r0 > 0 ? 1 : 0,
+                                     dCs.p, s));
     tm.mark(4);
     // (the split-K slices need ch to be a multiple of 16 * nsplit = 128: it is)
     CHECK_RC(launch_gemm_nt_splitk(At, m_pad, At, m_pad, dPart.p, ldg, m_pad, m_pad, ch, nsplit, stride, 1, s));

@@ -294,7 +294,7 @@ int launch_potrf_diag(double* A, long ld, double* d_invd, double* d_logdet_slot,
 int launch_potrf_diag_dbg(double* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long long* dbg,
                           hipStream_t s);
 int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
-                       long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk = nullptr);
+                       long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk = nullptr, long div = 256);
 // fp32 storage, fp64 arithmetic: the panel kernels of the fp32 instantiation (f32.hip)
 int launch_potrf_diag_f32(float* A, long ld, double* d_invd, double* d_logdet_slot, int* d_info, long gcol0,
                           hipStream_t s);
@@ -311,6 +311,11 @@ int launch_colsumsq_sub(const double* V, long ld, long nrows, long ncols, const 
                         double* out, double sign, hipStream_t s);
 int launch_gemv_rows(const double* rows, long ld, long nrows, long nc, const double* z, long ldz,
                      const double* add, double* out, hipStream_t s, int upper_tri = 0);
+// transposition + column sums in one pass (the ELBO's chunked pipeline): dst = (diag(row_scale) src)', dots[c] (+)= sum_r v delta[r],
+// sq[c] (+)= sum_r v^2; scratch: transpose_colsum_scratch(nr, nc) doubles
+long transpose_colsum_scratch(long nr, long nc);
+int launch_transpose_colsum(const double* src, long lds, long nr, long nc, double* dst, long ldd, const double* row_scale,
+                            const double* delta, double* dots, double* sq, int accumulate, double* scratch, hipStream_t s);
 int launch_transpose_add(const double* src, long lds, long nr, long nc, double* dst, long ldd,
                          const double* add_vec, hipStream_t s,
                          const double* row_scale = nullptr);   // row_scale: src row r is multiplied by row_scale[r]

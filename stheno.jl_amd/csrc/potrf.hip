@@ -148,15 +148,16 @@ int launch_panel_solve_f32(float* X, long ldx, long rows, const float* L, long l
 }
 
 int launch_panel_solve(double* X, long ldx, long rows, const double* L, long ldl, const double* inv,
-                       long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk) {
+                       long inv_cstride, long inv_kstride, hipStream_t s, const StripSkip* sk, long div) {
   if (rows <= 0) return 0;
   if (rows % PS_ROWS) {
     set_error("panel_solve: rows must be a multiple of 64");
     return -1;
   }
   SGP_LDS_ATTR_ONCE(panel_solve_kernel, PS_LDS);
-  // one strip per workgroup until the chip is full (256 CUs), then fatter workgroups
-  const long div = 256;
+  // one strip per workgroup until the chip is full (`div` workgroups: 256 = one per CU, what the factorisation's panel solve
+  // wants under the look-ahead overlap; a stand-alone row solve takes two per CU), then fatter workgroups
+  if (div <= 0) div = 256;
   long nstrips = rows / PS_ROWS;
   int strips = (int)std::min<long>(8, std::max<long>(1, (nstrips + div - 1) / div));
   long nwg = (nstrips + strips - 1) / strips;

@@ -208,6 +208,81 @@ int launch_transpose_add(const double* src, long lds, long nr, long nc, double* 
   return 0;
 }
 
+// The transposition and the column sums of the ELBO's chunked pipeline in ONE pass over the solved rows (round 6: they were two,
+// 2 x 2.1 GB per chunk at M = 4096): dst[c + r ldd] = v, part_dot[b][c] = sum_r v delta[r], part_sq[b][c] = sum_r v^2 over the
+// rows of row block b (TC_RB rows), v = src[r + c lds] rs[r].  One workgroup: 32 columns x TC_RB rows, tile by tile;
+// colsum_finish_kernel adds the blocks' partial sums in block order (deterministic).
+constexpr long TC_RB = 2048;
+__global__ __launch_bounds__(256) void transpose_colsum_kernel(const double* src, long lds, long nr, long nc, double* dst,
+                                                               long ldd, const double* row_scale, const double* delta,
+                                                               double* part_dot, double* part_sq) {
+  __shared__ double tile[32][33];
+  const long rb = blockIdx.x, c0 = (long)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0 .. 7, this thread's columns c0 + ty + 8 q
+  double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+  const long r_end = min(nr, (rb + 1) * TC_RB);
+  for (long r0 = rb * TC_RB; r0 < r_end; r0 += 32) {
+    const long r = r0 + tx;
+    const double rs = r < nr ? row_scale[r] : 0.0, dl = r < nr ? delta[r] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = ty + 8 * q;
+      const long c = c0 + k;
+      const double v = (r < nr && c < nc) ? src[r + c * lds] * rs : 0.0;
+      tile[k][tx] = v;
+      a[q] = fma(v, dl, a[q]);
+      b[q] = fma(v, v, b[q]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = ty + 8 * q;
+      const long c = c0 + tx, rr = r0 + k;
+      if (rr < nr && c < nc) dst[c + rr * ldd] = tile[tx][k];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1) {   // over tx: the 32 lanes of a half wave
+      a[q] += __shfl_xor(a[q], off, 64);
+      b[q] += __shfl_xor(b[q], off, 64);
+    }
+    const long c = c0 + ty + 8 * q;
+    if (tx == 0 && c < nc) {
+      part_dot[rb * nc + c] = a[q];
+      part_sq[rb * nc + c] = b[q];
+    }
+  }
+}
+__global__ void colsum_finish_kernel(const double* part_dot, const double* part_sq, long nb, long nc, double* dots, double* sq,
+                                     int accumulate) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nc) return;
+  double a = 0.0, b = 0.0;
+  for (long q = 0; q < nb; ++q) {
+    a += part_dot[q * nc + c];
+    b += part_sq[q * nc + c];
+  }
+  dots[c] = accumulate ? dots[c] + a : a;
+  sq[c] = accumulate ? sq[c] + b : b;
+}
+long transpose_colsum_scratch(long nr, long nc) { return 2 * ((nr + TC_RB - 1) / TC_RB) * nc; }
+int launch_transpose_colsum(const double* src, long lds, long nr, long nc, double* dst, long ldd, const double* row_scale,
+                            const double* delta, double* dots, double* sq, int accumulate, double* scratch, hipStream_t s) {
+  if (nr <= 0 || nc <= 0) return 0;
+  const long nb = (nr + TC_RB - 1) / TC_RB;
+  double* pd = scratch;
+  double* ps = scratch + nb * nc;
+  hipLaunchKernelGGL(transpose_colsum_kernel, dim3((unsigned)nb, (unsigned)((nc + 31) / 32)), dim3(256), 0, s, src, lds, nr, nc,
+                     dst, ldd, row_scale, delta, pd, ps);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, pd, ps, nb, nc, dots, sq,
+                     accumulate);
+  SGP_HIP(hipGetLastError());
+  return 0;
+}
+
 // rows[j + c*ld] *= scale[j]   (Lambda_y^-1 scaling of K(x, z) rows for the ELBO, App. A.6)
 __global__ void scale_rows_kernel(double* rows, long ld, long nrows, long nc, const double* scale) {
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;

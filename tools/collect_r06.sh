@@ -54,6 +54,8 @@ for P in 2 4; do mprof default c5 $P X=1; done
 # ---- small N through sgp_logpdf_batch / concurrent contexts, the mid-N schedule sweep
 timeout 600 python $R/tools/gpu_batch_time.py 2048 4096 8192 > $OUT/batch_time.json 2> $OUT/batch_time.err
 timeout 900 python $R/tools/gpu_midn_sweep.py 12288 16384 20480 > $OUT/midn_sweep.txt 2> $OUT/midn_sweep.err
+# ---- the fp32 instantiation on the structured north-star model, structural zeros skipped and not (same bits)
+timeout 400 python $R/tools/gpu_f32_sz_time.py --out $OUT/f32_sz_time.json 4096 10923 21845 > $OUT/f32_sz_time.txt 2>&1
 # ---- kernel traces (rocprofv3 --kernel-trace --stats of the same commands)
 for c in c5 target c3 c2 n4k c1; do
   st=3; [ $c = c1 ] && st=10

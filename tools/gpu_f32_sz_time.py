@@ -1,5 +1,5 @@
 """fp32 logpdf of the structured north-star model (f3 = f1 + f2 at n points each, ordered f1, f2, f3) with the structural
-zeros skipped and not (SGP_STRUCT_ZEROS): wall time per call and the bits.  Usage: python tools/gpu_f32_sz_time.py [n ...]"""
+zeros skipped and not (SGP_STRUCT_ZEROS): wall time per call and the bits.  Usage: python tools/gpu_f32_sz_time.py [--out FILE] [n ...]"""
 import json
 import os
 import sys
@@ -14,7 +14,13 @@ P = entry.load_package()
 
 
 def main():
-    ns = [int(a) for a in sys.argv[1:]] or [4096, 10923, 21845]
+    out_path = "gpurun_out/f32_sz_time.json"
+    args = sys.argv[1:]
+    if "--out" in args:
+        i = args.index("--out")
+        out_path = args[i + 1]
+        del args[i:i + 2]
+    ns = [int(a) for a in args] or [4096, 10923, 21845]
     out = []
     for n in ns:
         rng = np.random.default_rng(n)
@@ -43,8 +49,8 @@ def main():
         rec["speedup"] = rec["sz0"]["ms"] / rec["sz1"]["ms"]
         print(json.dumps(rec), flush=True)
         out.append(rec)
-    os.makedirs("gpurun_out", exist_ok=True)
-    json.dump(out, open("gpurun_out/f32_sz_time.json", "w"), indent=1)
+    os.makedirs(os.path.dirname(out_path) or ".", exist_ok=True)
+    json.dump(out, open(out_path, "w"), indent=1)
 
 
 if __name__ == "__main__":

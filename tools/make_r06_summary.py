@@ -93,7 +93,7 @@ for c in ("c5", "target", "c3", "c2", "n4k", "c1", "c4", "c5_f32", "grad_c2"):
         shutil.copy(st[0], os.path.join(DST, f"{TAG}_bench_{c}_kernel_stats.csv"))
 for f in (glob.glob(os.path.join(SRC, "multi_profile_*.json")) + glob.glob(os.path.join(SRC, "projection_*.txt")) +
           glob.glob(os.path.join(SRC, "trace_busy_*.json")) + glob.glob(os.path.join(SRC, "batch_time.json")) +
-          glob.glob(os.path.join(SRC, "midn_sweep.txt"))):
+          glob.glob(os.path.join(SRC, "midn_sweep.txt")) + glob.glob(os.path.join(SRC, "f32_sz_time.json"))):
     shutil.copy(f, os.path.join(DST, f"{TAG}_" + os.path.basename(f)))
 
 # ---- summary
