@@ -2314,16 +2314,13 @@ static int launch_elbo_scalars(sgp_ctx* ctx, const double* y, const double* mean
 }
 // per column j of the bordered rows R (nrows x ncols): dots[j] = sum_n R[n, j] delta[n],
 // sq[j] = sum_n R[n, j]^2
-// rs (optional): row n of R still lacks its factor rs[n] (the Lambda_y^-1/2 scaling of the ELBO's chunked pipeline is
-// applied here and in the transposition instead of in a pass of its own over the chunk)
-__global__ void coldot_kernel(const double* R, long ld, long nrows, const double* delta,
-                              double* dots, double* sq, int accumulate = 0, const double* rs = nullptr) {
+__global__ void coldot_kernel(const double* R, long ld, long nrows, const double* delta, double* dots, double* sq) {
   __shared__ double sh[2][4];
   const long j = blockIdx.x;
   const double* col = R + j * ld;
   double a = 0, b = 0;
   for (long n = threadIdx.x; n < nrows; n += blockDim.x) {
-    double v = rs ? col[n] * rs[n] : col[n];
+    double v = col[n];
     a = fma(v, delta[n], a);
     b = fma(v, v, b);
   }
@@ -2338,10 +2335,8 @@ __global__ void coldot_kernel(const double* R, long ld, long nrows, const double
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    double a0 = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-    double b0 = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
-    dots[j] = accumulate ? dots[j] + a0 : a0;
-    sq[j] = accumulate ? sq[j] + b0 : b0;
+    dots[j] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+    sq[j] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
   }
 }
 __global__ void add_identity_kernel(double* G, long ld, long n) {

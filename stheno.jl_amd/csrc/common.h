@@ -317,8 +317,7 @@ long transpose_colsum_scratch(long nr, long nc);
 int launch_transpose_colsum(const double* src, long lds, long nr, long nc, double* dst, long ldd, const double* row_scale,
                             const double* delta, double* dots, double* sq, int accumulate, double* scratch, hipStream_t s);
 int launch_transpose_add(const double* src, long lds, long nr, long nc, double* dst, long ldd,
-                         const double* add_vec, hipStream_t s,
-                         const double* row_scale = nullptr);   // row_scale: src row r is multiplied by row_scale[r]
+                         const double* add_vec, hipStream_t s);   // row_scale: src row r is multiplied by row_scale[r]
 int launch_scale_rows(double* rows, long ld, long nrows, long nc, const double* scale,
                       hipStream_t s);
 

@@ -183,13 +183,13 @@ int launch_gemv_rows(const double* rows, long ld, long nrows, long nc, const dou
 
 // dst[c + r*ldd] = src[r + c*lds] (+ add_vec[c])   -- tiled transpose, nr x nc -> nc x nr
 __global__ void transpose_add_kernel(const double* src, long lds, long nr, long nc, double* dst,
-                                     long ldd, const double* add_vec, const double* row_scale) {
+                                     long ldd, const double* add_vec) {
   __shared__ double tile[32][33];
   long r0 = (long)blockIdx.x * 32, c0 = (long)blockIdx.y * 32;
   int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: ty 0..7
   for (int k = ty; k < 32; k += 8) {
     long r = r0 + tx, c = c0 + k;
-    tile[k][tx] = (r < nr && c < nc) ? (row_scale ? src[r + c * lds] * row_scale[r] : src[r + c * lds]) : 0.0;
+    tile[k][tx] = (r < nr && c < nc) ? src[r + c * lds] : 0.0;
   }
   __syncthreads();
   for (int k = ty; k < 32; k += 8) {
@@ -199,11 +199,11 @@ __global__ void transpose_add_kernel(const double* src, long lds, long nr, long 
 }
 
 int launch_transpose_add(const double* src, long lds, long nr, long nc, double* dst, long ldd,
-                         const double* add_vec, hipStream_t s, const double* row_scale) {
+                         const double* add_vec, hipStream_t s) {
   if (nr <= 0 || nc <= 0) return 0;
   dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((nc + 31) / 32));
   hipLaunchKernelGGL(transpose_add_kernel, grid, dim3(256), 0, s, src, lds, nr, nc, dst, ldd,
-                     add_vec, row_scale);
+                     add_vec);
   SGP_HIP(hipGetLastError());
   return 0;
 }
