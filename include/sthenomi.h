@@ -221,10 +221,11 @@ int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* mean, int n
  * (/root/reference/examples/getting_started/script.jl:154-213 is one such chain; its restarts are B of them).  Member b:
  * specs[b], means[b] (means or means[b] may be NULL == zeros), noises[b] (SCALAR: one value, DIAG: N values; one kind for the
  * batch), ys[b] (one vector); out[b] = logpdf(f_b(x_b, noise_b), y_b) -- bit-equal to the member's own sgp_logpdf call.
- * Equally sized members up to SGP_BATCH_MAX_N (12288) padded columns are assembled side by side and factored by ONE launch
+  * Members of one PADDED size (the same number of 128-column tiles: equal N, or the folds of a cross-validation, which differ by
+ * a point or two) up to SGP_BATCH_MAX_N (12288) padded columns are assembled side by side and factored by ONE launch
  * of the dataflow kernel as a single task pool: at sizes where one factorisation is bound by its diagonal chain (N <= 8192)
  * the B chains hide each other and the aggregate rate is a multiple of the single call's (docs/05).  Anything else
- * (different sizes, dense noise, larger members, a multi-GPU context) runs member by member.
+ * (different padded sizes, dense noise, larger members, a multi-GPU context) runs member by member.
  * A member whose matrix is not positive definite gets out[b] = NaN and infos[b] = the failing leading minor (LAPACK's info;
  * 0 for the others); with infos == NULL the call returns the first such info (> 0) instead of 0. */
 int sgp_logpdf_batch(sgp_ctx* ctx, int nspec, const sgp_cov_spec* const* specs, const double* const* means,

@@ -187,7 +187,8 @@ logpdf(fx::SthenoFGP, y::AbstractVector{<:Real}) = only(logpdf(fx, reshape(y, :,
 
 # logpdf of several INDEPENDENT models in one call (sgp_logpdf_batch, round 6): restarts of an optimiser, cross-validation
 # folds, a population of hyper-parameter candidates -- [logpdf(fx, y) for (fx, y) in zip(fxs, ys)], every value bit-equal to
-# the member's own call.  Equally sized members (scalar / diagonal Σy) are factored as ONE task pool of the dataflow kernel:
+# the member's own call.  Members of one padded size (equal N or N within one 128-column tile; scalar / diagonal Σy) are
+# factored as ONE task pool of the dataflow kernel:
 # at N <= 8192 one factorisation is bound by its diagonal chain and the B chains hide each other (N = 4096: 0.13 -> 0.49 of
 # the fp64 MFMA peak at B = 8).  A member that is not positive definite gives NaN instead of throwing (its LAPACK info in
 # the second result), so that one bad candidate does not lose the others.

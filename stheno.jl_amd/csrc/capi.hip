@@ -1512,8 +1512,9 @@ extern "C" int sgp_logpdf(sgp_ctx* ctx, const sgp_cov_spec* spec, const double* 
 // sized batch are factored by ONE launch of the dataflow kernel as a single task pool (chol_df.hip: ids dealt round robin,
 // progress counters per matrix): the B chains sit on different workgroups and hide each other.  Every member sees exactly
 // the arithmetic of its own sgp_logpdf call (assembly, k-ascending contractions, the same reductions): the values are
-// bit-equal.  Members of different sizes, dense noise, sizes outside the batched range, a multi-GPU context: one after the
-// other through sgp_logpdf's own path.
+// bit-equal.  "Equally sized" = the same PADDED size (the same number of 128-column tiles: the folds of a cross-validation,
+// which differ by a point or two, pool).  Members of different padded sizes, dense noise, sizes outside the batched range, a
+// multi-GPU context: one after the other through sgp_logpdf's own path.
 static int logpdf_batch_impl(sgp_ctx* ctx, int nspec, const sgp_cov_spec* const* specs, const double* const* means,
                              int noise_kind, const double* const* noises, const double* const* ys, double* out, int* infos) {
   CHECK_ARG(ctx && specs && noises && ys && out && nspec >= 1, "sgp_logpdf_batch: NULL argument");
@@ -1527,11 +1528,18 @@ static int logpdf_batch_impl(sgp_ctx* ctx, int nspec, const sgp_cov_spec* const*
     for (int i = 0; i < sp->n_row_blocks; ++i) n += sp->row_len[i];
     return n;
   };
+  // members pool when their PADDED geometry agrees (the folds of a cross-validation differ by a point or two: the same 128-column
+  // tiles, each member's own N in its assembly, its row sums and its logpdf)
   const long N = rows_of(specs[0]);
-  bool same = true;
-  for (int b = 1; b < nspec; ++b) same = same && rows_of(specs[b]) == N;
   int64_t n_pad = 0, m_tot = 0;
   if (N >= 1) sgp_geometry(N, 1, &n_pad, &m_tot);
+  bool same = N >= 1;
+  for (int b = 1; b < nspec && same; ++b) {
+    const long nb_ = rows_of(specs[b]);
+    int64_t np_b = 0, mt_b = 0;
+    if (nb_ >= 1) sgp_geometry(nb_, 1, &np_b, &mt_b);
+    same = nb_ >= 1 && np_b == n_pad && mt_b == m_tot;
+  }
   const bool pooled = same && N >= 1 && nspec >= 2 && !ctx->multi && ctx->dataflow != 0 &&
                       ctx->batch_max_n > 0 && n_pad <= ctx->batch_max_n &&
                       (noise_kind == SGP_NOISE_SCALAR || noise_kind == SGP_NOISE_DIAG);
@@ -1572,23 +1580,25 @@ static int logpdf_batch_impl(sgp_ctx* ctx, int nspec, const sgp_cov_spec* const*
     for (int b = 0; b < nb; ++b) {
       Member& M = mem[(size_t)b];
       const int gb = b0 + b;
+      const long Nb = rows_of(specs[gb]);   // this member's own size (n_pad, m_tot are the batch's)
       CHECK_RC(dspec_create(ctx, specs[gb], &M.g.ds));
       CHECK_RC(M.A.alloc((size_t)m_tot * n_pad));
-      if (means && means[gb]) CHECK_RC(M.mean.upload(means[gb], N));
-      CHECK_RC(upload_noise(M.nd, noise_kind, noises[gb], N));
-      CHECK_RC(M.y.upload(ys[gb], N));
+      if (means && means[gb]) CHECK_RC(M.mean.upload(means[gb], Nb));
+      CHECK_RC(upload_noise(M.nd, noise_kind, noises[gb], Nb));
+      CHECK_RC(M.y.upload(ys[gb], Nb));
       // (no structural zeros inside a batch: its members need not share a pattern, and these sizes are chain-bound anyway)
       CHECK_RC(build_bordered(ctx, M.g.ds, M.A.p, n_pad, m_tot, M.mean.p, M.nd.kind, M.nd.sigma2, M.nd.diag.p, nullptr, 0, M.y.p,
-                              N, 1, s, nullptr));
+                              Nb, 1, s, nullptr));
       probs[b] = DfProb{M.A.p, inv.p + (size_t)b * T_c * INVD_STRIDE, small.p + (size_t)b * per_small, d_infos + b};
     }
     CHECK_RC(launch_chol_dataflow_batch(probs, nb, m_tot, n_pad, m_tot, ctx->d_df_state, ctx->batch_fat ? ctx->hybrid_wgs : ctx->df_wgs,
                                         ctx->df_timeout_s, ctx->batch_fat, s));
     for (int b = 0; b < nb; ++b) {
       double* sm = small.p + (size_t)b * per_small;
-      CHECK_RC(launch_rowsumsq(mem[(size_t)b].A.p + n_pad, m_tot, N, 1, sm + T_c + 1, 0, s));
+      const long Nb = rows_of(specs[b0 + b]);
+      CHECK_RC(launch_rowsumsq(mem[(size_t)b].A.p + n_pad, m_tot, Nb, 1, sm + T_c + 1, 0, s));
       CHECK_RC(launch_sum_array(sm, T_c, sm + T_c, s));
-      CHECK_RC(launch_logpdf_final(sm + T_c, sm + T_c + 1, N, 1, sm + T_c + 2, s));
+      CHECK_RC(launch_logpdf_final(sm + T_c, sm + T_c + 1, Nb, 1, sm + T_c + 2, s));
     }
     std::vector<double> h_small((size_t)nb * per_small);
     std::vector<int> h_info((size_t)nb);

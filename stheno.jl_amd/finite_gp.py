@@ -235,8 +235,9 @@ def logpdf(fx, y):
 
 def logpdf_batch(fxs, ys, return_infos=False):
     """[logpdf(fx, y) for fx, y in zip(fxs, ys)] in ONE library call (sgp_logpdf_batch): the members are independent models
-    -- restarts of an optimiser, cross-validation folds, a population of hyper-parameter candidates.  Equally sized members
-    with scalar / diagonal noise are factored as one task pool of the dataflow kernel (their diagonal chains hide each other);
+    -- restarts of an optimiser, cross-validation folds, a population of hyper-parameter candidates.  Members of one padded
+    size (equal N, or folds that differ by a point or two inside one 128-column tile) with scalar / diagonal noise are
+    factored as one task pool of the dataflow kernel (their diagonal chains hide each other);
     every value is bit-equal to the member's own `logpdf`.  A member that is not positive definite gives NaN (and, with
     return_infos=True, its LAPACK info in the second result) instead of raising, so that one bad candidate does not lose the
     others."""

@@ -68,6 +68,39 @@ def test_members_of_different_sizes_and_mixed_noise_run_member_by_member():
     assert np.array_equal(P.logpdf_batch(fxs, ys), np.array([P.logpdf(fx, y) for fx, y in zip(fxs, ys)]))
 
 
+def test_folds_that_differ_by_a_few_points_pool_like_equal_sizes():
+    """Round 6: members pool when their PADDED size agrees -- the folds of a cross-validation differ by a point or two, not by a
+    128-column tile.  Every member keeps the bits of its own call (its own N in the assembly, the row sums and the constant),
+    and the call takes a fraction of the member-by-member time (8 chains hiding each other: 0.13 -> ~0.5 of the peak at this
+    size; the bound here is loose)."""
+    import time
+    rng = np.random.default_rng(17)
+    sizes = [3968, 3967, 3966, 3967, 3968, 3950, 3900, 3845]          # 31 tiles of 128 columns each
+    fxs, ys = [], []
+    for b, N in enumerate(sizes):
+        f = P.atomic(P.GP(P.with_lengthscale(P.Matern52Kernel(), 0.6 + 0.1 * b)), P.GPC())
+        fxs.append(f(P.ColVecs(np.asfortranarray(rng.standard_normal((3, N)))), 0.1 + 0.01 * b))
+        ys.append(rng.standard_normal(N))
+    single = np.array([P.logpdf(fx, y) for fx, y in zip(fxs, ys)])
+    assert np.array_equal(P.logpdf_batch(fxs, ys), single)
+
+    def best(fn, reps=3):
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return min(ts)
+
+    t_batch = best(lambda: P.logpdf_batch(fxs, ys))
+    t_single = best(lambda: [P.logpdf(fx, y) for fx, y in zip(fxs, ys)])
+    assert t_batch < 0.7 * t_single, (t_batch, t_single)
+    # one more tile in one member: that batch runs member by member, same values
+    fxs[0] = fxs[0].f(P.ColVecs(np.asfortranarray(rng.standard_normal((3, 3969)))), 0.1)
+    ys[0] = rng.standard_normal(3969)
+    assert np.array_equal(P.logpdf_batch(fxs, ys), np.array([P.logpdf(fx, y) for fx, y in zip(fxs, ys)]))
+
+
 @pytest.mark.parametrize("N", [640, 4096])
 def test_one_bad_member_does_not_lose_the_others(N):
     fxs, ys, _ = _members(4, N, seed=9)
