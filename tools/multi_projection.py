@@ -164,6 +164,91 @@ def project(prof, P, link_gbps, form, contend, free_overlap=False, phases=False)
     return total, waited, max(busy)
 
 
+def project_rowchain(prof, P, link_gbps, ineff=1.25, latency_ms=0.02):
+    """WHAT-IF, not a schedule the library has (docs/08_scope_and_next.md, section 9.1): the panel chain distributed over the
+    ranks BY ROWS.  From a profile of the unfused chain (fuse_la = 0: factor_ms and lookahead_update_ms measured apart):
+      top[J]   = the factorisation of the panel's w x w top block on its owner -- priced with the LAST panel's factor_ms (that
+                 panel is its top block and the bordered rows);
+      slice[J] = (factor_ms[J] - top + lookahead_update_ms[J]) / P * ineff -- every rank updates and solves 1 / P of the rows
+                 below the top block (smaller launches: `ineff`);
+      the owner scatters the raw rows ahead of time (same bytes as today's scatter of solved slabs: off the chain), broadcasts the
+      factored top block (w x w doubles + latency), every rank sends its solved slice to the P - 1 others (bytes / P per link).
+    Panel J+1's chain starts when panel J has been gathered everywhere; a rank's chain work runs on its panel stream ahead of
+    its updates (the GPU-as-one-server model of project()).  Updates: as measured, released by the gather of their panel."""
+    rows = prof["per_panel"]
+    G = int(prof.get("group", 1))
+    npan = len(rows)
+    fac = [r[0] for r in rows]
+    la = [r[1] for r in rows]
+    byt = [r[2] for r in rows]
+    cls = [[r[3 + 3 * i: 6 + 3 * i] for i in range(P)] for r in rows]
+    owners = prof.get("owners")
+    owner = (lambda J: owners[J]) if owners else (lambda J: J % P)
+    top = min(fac[-1], min(fac))
+    W = int(prof["panel_width"])
+    bc = 8.0 * W * W / (link_gbps * 1e9) * 1e3 + latency_ms
+    t_upd, t_near, t_pan = [0.0] * P, [0.0] * P, [0.0] * P
+    ev_a, ev_b, busy = [0.0] * P, [0.0] * P, [0.0] * P
+
+    def run(i, stream, ready, dur):
+        busy[i] += dur
+        if stream == "panel":
+            start = max(ready, t_pan[i])
+            end = start + dur
+            t_pan[i] = end
+            for t in (t_near, t_upd):
+                t[i] = t[i] + dur if t[i] > start else max(t[i], end)
+            return end
+        if stream == "near":
+            start = max(ready, t_near[i], t_pan[i])
+            end = start + dur
+            t_near[i] = end
+            t_upd[i] = t_upd[i] + dur if t_upd[i] > start else max(t_upd[i], end)
+            return end
+        start = max(ready, t_upd[i], t_near[i], t_pan[i])
+        end = start + dur
+        t_upd[i] = end
+        return end
+
+    def chain(J, ready):
+        """panel J: every rank holds its raw row slice and (J > 0) the whole of panel J - 1 at `ready`; returns the time panel J
+        has been gathered everywhere"""
+        o = owner(J)
+        work = max(0.0, fac[J] - top) + (la[J] if J > 0 else 0.0)
+        sl = work / P * ineff
+        share_la = (la[J] / max(work, 1e-12)) if J > 0 else 0.0
+        t_top = run(o, "panel", ready, top) + bc                     # the owner: its top block first
+        done = 0.0
+        for i in range(P):
+            t = run(i, "panel", ready, sl * share_la)               # the slice's look-ahead update needs nothing from the owner
+            t = run(i, "panel", max(t, t_top), sl * (1.0 - share_la))   # its solve needs the factored top block
+            done = max(done, t)
+        return done + byt[J] / P / (link_gbps * 1e9) * 1e3 + latency_ms
+
+    recv_t = chain(0, 0.0)
+    for J in range(npan):
+        nxt = J + 1
+        new_recv = None
+        if nxt < npan:
+            # the raw slices of nxt leave its owner when its updates through J - 1 are in (near A of the previous step)
+            o = owner(nxt)
+            raw = max(ev_a[o], ev_b[o] if (nxt % G == 0 or J % G == 0) else 0.0) + byt[nxt] / P / (link_gbps * 1e9) * 1e3
+            new_recv = chain(nxt, max(recv_t, raw))
+        for i in range(P):
+            a, b, f = cls[J][i]
+            if a > 0:
+                ev_a[i] = run(i, "near", max(recv_t, ev_b[i] if J % G == 0 else 0.0), a)
+            if b > 0:
+                ev_b[i] = run(i, "upd", recv_t, b)
+            else:
+                ev_b[i] = max(ev_b[i], min(t_upd[i], recv_t))
+            if f > 0:
+                run(i, "upd", recv_t, f)
+        if new_recv is not None:
+            recv_t = new_recv
+    return max(max(t_upd), max(t_near), max(t_pan), recv_t), max(busy), top
+
+
 def main():
     prof = json.load(open(sys.argv[1]))
     link = float(sys.argv[2]) if len(sys.argv) > 2 else 77.0
@@ -199,6 +284,11 @@ def main():
                   + (f"   [scatter / gather phases of successive pieces pipelined: {tp:.1f} ms]" if form == "allgather" else ""))
     t_inf, _, _ = project(prof, P, 1e9, "direct", 1.0)
     print(f"  infinite link bandwidth: {t_inf:.1f} ms  -> compute / critical-path bound of this schedule")
+    if not prof.get("fuse_la") and P > 2:
+        for ineff in (1.0, 1.25, 1.5):
+            t, b, top = project_rowchain(prof, P, link, ineff)
+            print(f"  WHAT-IF (not built, docs/08 section 9.1) panel chain distributed by rows, slice launches {ineff:.2f} x the full-height "
+                  f"cost: {t:8.1f} ms  (busiest GPU {b:6.1f} ms of work; top block {top:.2f} ms per panel)")
 
 
 if __name__ == "__main__":
