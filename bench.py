@@ -205,7 +205,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         backend = os.environ.get("SGP_DIST_BACKEND", "nccl")
+        # (a collective that never completes -- a rank that died, a link that is down -- fails the run after this bound instead
+        # of the backend's default ten minutes: the first multi-GPU run must not hang)
+        import datetime
         dist.init_process_group(backend=backend, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("SGP_DIST_TIMEOUT_S", "300"))),
                                 device_id=torch.device("cuda", local_rank) if backend == "nccl" else None)
 
     import __graft_entry__ as entry
